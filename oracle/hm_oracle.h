@@ -1,0 +1,46 @@
+/* oracle/hm_oracle.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * Plain-C restatement of the reference's depth-pruned all-intra CTU decision path
+ * (TEncSlice::compressSlice -> TEncCu::compressCtu -> xCompressCU -> xCheckRDCostIntra
+ *  -> TEncSearch::estIntraPredLumaQT / estIntraPredChromaQT).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ * Pinned against the reference itself: oracle/_ref (built by oracle/build_ref.sh) through
+ * oracle/gen_fixtures.py -> tests/golden/rd_*.npz.
+ */
+#ifndef HM_ORACLE_H
+#define HM_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as hevcdl_ctu_record (include/hevcdl.h): 15120 bytes. */
+typedef struct {
+  uint8_t  depth[256], part_size[256], luma_dir[256], chroma_dir[256], tr_idx[256];
+  uint8_t  cbf[3][256], tskip[3][256];
+  uint32_t bits, dist;
+  double   cost;
+  int16_t  coeff_y[4096], coeff_cb[1024], coeff_cr[1024];
+} hm_ctu_record;
+
+typedef struct {
+  uint64_t sse[3];      /* reconstruction SSE per plane (before in-loop filters) */
+  uint64_t est_bits;    /* sum over CTUs of the CABAC-estimated bits of the final encode */
+  uint32_t ctus;
+  uint32_t pad;
+} hm_frame_stats;
+
+/* Encode n_frames independent all-intra frames (8-bit 4:2:0 planar, Y then U then V per frame).
+ * labels: [n_frames][ctus][16] depth labels (already clamped/valid).  out_recs: [n_frames][ctus].
+ * recon: same layout as yuv (may be NULL).  stats: [n_frames] (may be NULL).  Returns 0 on success. */
+int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_frames, int qp,
+                            const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
+                            hm_frame_stats *stats);
+
+/* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */
+void hm_oracle_set_trace(const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,241 @@
+"""oracle/ref_tools.py -- TEST INFRASTRUCTURE.
+
+Helpers that (a) drive the reference encoder built by oracle/build_ref.sh (only available in the
+container that has /root/reference) and (b) call the plain-C oracle (oracle/hm_oracle.c) through ctypes.
+Nothing here is imported by the product package.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_ENC = os.path.join(HERE, "_ref", "TAppEncoder_ref")
+REF_DEC = os.path.join(HERE, "_ref", "TAppDecoder_ref")
+REF_CFG = "/root/reference/encoder_intra_main.cfg"
+ORACLE_SO = os.path.join(HERE, "_build", "libhm_oracle.so")
+
+# hevcdl_ctu_record (include/hevcdl.h) as a numpy dtype: 15120 bytes
+REC_DTYPE = np.dtype([
+    ("depth", "u1", 256), ("part_size", "u1", 256), ("luma_dir", "u1", 256), ("chroma_dir", "u1", 256),
+    ("tr_idx", "u1", 256), ("cbf", "u1", (3, 256)), ("tskip", "u1", (3, 256)),
+    ("bits", "<u4"), ("dist", "<u4"), ("cost", "<f8"),
+    ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024)])
+assert REC_DTYPE.itemsize == 15120
+DUMP_DTYPE = np.dtype([("frame", "<i4"), ("addr", "<i4"), ("rec", REC_DTYPE),
+                       ("rec_y", "u1", 4096), ("rec_cb", "u1", 1024), ("rec_cr", "u1", 1024)])
+STATS_DTYPE = np.dtype([("sse", "<u8", 3), ("est_bits", "<u8"), ("ctus", "<u4"), ("pad", "<u4")])
+
+
+def synth_yuv(width, height, n_frames, seed):
+    """Synthetic 8-bit 4:2:0 frames (generator of SURVEY.md section 8d, reduced block size for small pictures)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    y, x = np.mgrid[0:height, 0:width]
+    for f in range(n_frames):
+        Y = 128 + 50 * np.sin(x / 57.0) * np.cos(y / 43.0) + 30 * np.sin((x + y + 3 * f) / 19.0) + rng.normal(0, 5, (height, width))
+        bw, bh = max(16, width // 3), max(16, height // 3)
+        bx, by = (width // 5 + 4 * f) % max(1, width - bw), height // 4
+        blk = Y[by:by + bh, bx:bx + bw]
+        Y[by:by + bh, bx:bx + bw] = np.floor(blk / 24) * 24
+        Y = np.clip(Y, 0, 255).astype(np.uint8)
+        xc, yc = x[::2, ::2], y[::2, ::2]
+        U = np.clip(128 + 25 * np.sin(xc / 61.0) + rng.normal(0, 2, xc.shape), 0, 255).astype(np.uint8)
+        V = np.clip(128 + 25 * np.cos(yc / 47.0) + rng.normal(0, 2, yc.shape), 0, 255).astype(np.uint8)
+        out.append(np.concatenate([Y.ravel(), U.ravel(), V.ravel()]))
+    return np.stack(out)
+
+
+def min_depth_table(width, height):
+    """Per CTU, per 16x16 cell: smallest depth at which the CU containing the cell lies inside the picture
+    (SURVEY.md section 5 fact 2).  Cells outside the picture get 0."""
+    cx, cy = (width + 63) // 64, (height + 63) // 64
+    t = np.zeros((cy * cx, 16), np.uint8)
+    for a in range(cx * cy):
+        x0, y0 = (a % cx) * 64, (a // cx) * 64
+        for c in range(16):
+            px, py = x0 + (c % 4) * 16, y0 + (c // 4) * 16
+            if px >= width or py >= height:
+                continue
+            for d in range(4):
+                s = 64 >> d
+                bx, by = px // s * s, py // s * s
+                if bx + s <= width and by + s <= height:
+                    t[a, c] = d
+                    break
+            else:
+                t[a, c] = 3
+    return t
+
+
+def fixup_labels(lab):
+    """Quadrant consistency rules of /root/reference/use_model.py:102-119 applied to a [16] label vector
+    (after any clamping), so that the labels describe a valid quadtree."""
+    lab = [int(v) for v in lab]
+    quads = [(0, 1, 4, 5), (2, 3, 6, 7), (8, 9, 12, 13), (10, 11, 14, 15)]
+    for qi, q in enumerate(quads):
+        p = [lab[i] for i in q]
+        if 0 in p and p != [0, 0, 0, 0]:
+            p = [1 if v == 0 else v for v in p]
+        if 1 in p and p != [1, 1, 1, 1]:
+            p = [2 if v == 1 else v for v in p]
+        if qi == 1 and p == [0, 0, 0, 0] and lab[0] != 0:
+            p = [1, 1, 1, 1]
+        if qi == 2 and p == [0, 0, 0, 0] and lab[2] != 0:
+            p = [1, 1, 1, 1]
+        if qi == 3 and p == [0, 0, 0, 0] and lab[8] != 0:
+            p = [1, 1, 1, 1]
+        for i, v in zip(q, p):
+            lab[i] = v
+    return lab
+
+
+def clamp_labels(lab, md):
+    """Boundary policy: raise labels to the minimum depth that keeps every coded CU
+    inside the picture, then restore quadtree validity (a CTU that is split has every cell >= 1; a 32x32
+    quadrant that is split has every cell >= 2)."""
+    lab = np.maximum(np.asarray(lab, np.uint8), md)
+    if lab.max() > 0:
+        lab = np.maximum(lab, 1)
+    for q in ((0, 1, 4, 5), (2, 3, 6, 7), (8, 9, 12, 13), (10, 11, 14, 15)):
+        q = list(q)
+        if lab[q].max() >= 2:
+            lab[q] = np.maximum(lab[q], 2)
+    return lab
+
+
+def make_labels(width, height, n_frames, kind, seed=0):
+    """kind: 0..3 = constant depth; 'rand' = random valid quadtrees.  Always clamped to the picture."""
+    cx, cy = (width + 63) // 64, (height + 63) // 64
+    md = min_depth_table(width, height)
+    rng = np.random.default_rng(seed)
+    labs = np.zeros((n_frames, cx * cy, 16), np.uint8)
+    for f in range(n_frames):
+        for a in range(cx * cy):
+            lab = [0] * 16
+            if kind == "rand":
+                if rng.integers(0, 4) != 0:
+                    for q in [(0, 1, 4, 5), (2, 3, 6, 7), (8, 9, 12, 13), (10, 11, 14, 15)]:
+                        v = [1, 1, 1, 1] if rng.integers(0, 3) == 0 else [int(t) for t in rng.integers(2, 4, 4)]
+                        for i, t in zip(q, v):
+                            lab[i] = t
+            else:
+                lab = [int(kind)] * 16
+            labs[f, a] = clamp_labels(lab, md[a])
+    return labs
+
+
+def run_reference(yuv, width, height, qp, labels, extra_args=(), keep_dir=None, trace=False):
+    """Run the reference encoder; returns (dump records array, stdout text, bitstream bytes, recon bytes)."""
+    n_frames = yuv.shape[0]
+    d = keep_dir or tempfile.mkdtemp(prefix="hmref_")
+    os.makedirs(os.path.join(d, "rec"), exist_ok=True)
+    if os.path.isdir(os.path.join(d, "pred")):
+        shutil.rmtree(os.path.join(d, "pred"))
+    yuv.astype(np.uint8).tofile(os.path.join(d, "in.yuv"))
+    for f in range(n_frames):
+        os.makedirs(os.path.join(d, "pred", str(f)))
+        for a in range(labels.shape[1]):
+            with open(os.path.join(d, "pred", str(f), "ctu%d.txt" % a), "w") as fh:
+                fh.write(" ".join(str(int(v)) for v in labels[f, a]) + " ")
+    cfg = open(REF_CFG).read().replace(".\\rec\\", "rec/")
+    open(os.path.join(d, "enc.cfg"), "w").write(cfg)
+    open(os.path.join(d, "bs.cfg"), "w").write(
+        "InputFile : in.yuv\nInputBitDepth : 8\nInputChromaFormat : 420\nFrameRate : 30\nFrameSkip : 0\n"
+        "SourceWidth : %d\nSourceHeight : %d\nFramesToBeEncoded : %d\nLevel : 6.2\n" % (width, height, n_frames))
+    env = dict(os.environ, HEVCDL_DUMP=os.path.join(d, "dump.bin"))
+    if trace:
+        env["HEVCDL_TRACE"] = os.path.join(d, "trace.txt")
+    if os.path.exists(env["HEVCDL_DUMP"]):
+        os.remove(env["HEVCDL_DUMP"])
+    cmd = [REF_ENC, "-c", "enc.cfg", "-c", "bs.cfg", "-q", str(qp), "--SEIDecodedPictureHash=1"] + list(extra_args)
+    p = subprocess.run(cmd, cwd=d, env=env, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("reference encoder failed: " + p.stdout[-2000:] + p.stderr[-2000:])
+    dump = np.fromfile(env["HEVCDL_DUMP"], dtype=DUMP_DTYPE)
+    bitstream = open(os.path.join(d, "rec", "str.bin"), "rb").read()
+    recon = open(os.path.join(d, "rec", "rec.yuv"), "rb").read()
+    if keep_dir is None:
+        shutil.rmtree(d)
+    return dump, p.stdout, bitstream, recon
+
+
+_lib = None
+
+
+def oracle_lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(ORACLE_SO)
+        _lib.hm_oracle_encode_frames.restype = ctypes.c_int
+        _lib.hm_oracle_encode_frames.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.hm_oracle_set_trace.argtypes = [ctypes.c_char_p]
+    return _lib
+
+
+def run_oracle(yuv, width, height, qp, labels, trace_path=None):
+    """Returns (records [frames][ctus] REC_DTYPE, recon uint8 [frames][w*h*3/2], stats [frames])."""
+    lib = oracle_lib()
+    yuv = np.ascontiguousarray(yuv, np.uint8)
+    labels = np.ascontiguousarray(labels, np.uint8)
+    n_frames, nctu = labels.shape[0], labels.shape[1]
+    recs = np.zeros((n_frames, nctu), REC_DTYPE)
+    recon = np.zeros_like(yuv)
+    stats = np.zeros(n_frames, STATS_DTYPE)
+    lib.hm_oracle_set_trace(trace_path.encode() if trace_path else None)
+    rc = lib.hm_oracle_encode_frames(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
+                                     recs.ctypes.data, recon.ctypes.data, stats.ctypes.data)
+    lib.hm_oracle_set_trace(None)
+    if rc != 0:
+        raise RuntimeError("oracle failed rc=%d" % rc)
+    return recs, recon, stats
+
+
+def ctu_recon_from_frame(recon_frame, width, height, addr):
+    """Cut the 64x64 / 32x32 / 32x32 CTU blocks (zeros outside the picture) out of one planar frame."""
+    cx = (width + 63) // 64
+    x0, y0 = (addr % cx) * 64, (addr // cx) * 64
+    Y = recon_frame[:width * height].reshape(height, width)
+    U = recon_frame[width * height:width * height * 5 // 4].reshape(height // 2, width // 2)
+    V = recon_frame[width * height * 5 // 4:].reshape(height // 2, width // 2)
+    out = []
+    for P, n, xx, yy in ((Y, 64, x0, y0), (U, 32, x0 // 2, y0 // 2), (V, 32, x0 // 2, y0 // 2)):
+        b = np.zeros((n, n), np.uint8)
+        sub = P[yy:yy + n, xx:xx + n]
+        b[:sub.shape[0], :sub.shape[1]] = sub
+        out.append(b.ravel())
+    return out
+
+
+FIELDS = ["depth", "part_size", "luma_dir", "chroma_dir", "tr_idx", "cbf", "tskip", "bits", "dist", "cost",
+          "coeff_y", "coeff_cb", "coeff_cr"]
+
+
+def compare(dump, recs, recon, width, height, verbose=True):
+    """Compare reference dump with oracle output; returns number of mismatching (ctu, field) pairs."""
+    bad = 0
+    for e in dump:
+        f, a = int(e["frame"]), int(e["addr"])
+        r = recs[f, a]
+        for k in FIELDS:
+            if not np.array_equal(e["rec"][k], r[k]):
+                bad += 1
+                if verbose and bad <= 12:
+                    ev, rv = np.asarray(e["rec"][k]), np.asarray(r[k])
+                    if ev.ndim:
+                        idx = np.argwhere(ev != rv)[:4].tolist()
+                        print("MISMATCH frame %d ctu %d field %s at %s ref=%s ours=%s" % (f, a, k, idx, ev[ev != rv][:6], rv[ev != rv][:6]))
+                    else:
+                        print("MISMATCH frame %d ctu %d field %s ref=%s ours=%s" % (f, a, k, ev, rv))
+        ry, ru, rv_ = ctu_recon_from_frame(recon[f], width, height, a)
+        for k, ours in (("rec_y", ry), ("rec_cb", ru), ("rec_cr", rv_)):
+            if not np.array_equal(e[k], ours):
+                bad += 1
+                if verbose and bad <= 12:
+                    idx = np.argwhere(e[k] != ours)[:4].ravel().tolist()
+                    print("MISMATCH frame %d ctu %d %s at %s" % (f, a, k, idx))
+    return bad
