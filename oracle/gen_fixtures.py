@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""oracle/gen_fixtures.py -- TEST INFRASTRUCTURE.  Runs ONLY in the container that has /root/reference.
+
+Generates the committed golden vectors under tests/golden/ by running the reference itself:
+  * RD fixtures: the reference encoder built in place by oracle/build_ref.sh (oracle/_ref/TAppEncoder_ref,
+    observed at the TEncCu::compressCtu boundary by oracle/ref_hook.cpp) on small synthetic YUVs with explicit
+    label files -> per-CTU decision records + pre-loop-filter reconstruction (+ bitstream bytes and the
+    encoder's per-frame summary line for the later "next" rows).
+  * CNN fixtures: the ConvNet2 class text of /root/reference/use_model.py:16-58 exec()'d here with the
+    reference checkpoint /root/reference/rec/hevc_encoder_model.pt, BatchNorm left in training mode exactly as
+    the reference runs it; label post-processing fixtures by exec()ing use_model.py:101-119.
+  * the weight blob (flat little-endian fp32 + JSON manifest) consumed by the product.
+No reference source text is written to the repo: fixtures are inputs and expected outputs only.
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import ref_tools as rt  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+WDIR = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "weights")
+REF = "/root/reference"
+
+
+def gen_rd():
+    cases = []
+    #        name            W    H   frames qp  labels seed
+    spec = [("c128_q32_d0", 128, 128, 1, 32, 0, 11), ("c128_q32_d1", 128, 128, 1, 32, 1, 12),
+            ("c128_q32_d2", 128, 128, 1, 32, 2, 13), ("c128_q32_d3", 128, 128, 1, 32, 3, 14),
+            ("c128_q22_r", 128, 128, 1, 22, "rand", 15), ("c128_q27_r", 128, 128, 1, 27, "rand", 16),
+            ("c128_q37_r", 128, 128, 1, 37, "rand", 17), ("c192_q32_r2", 192, 128, 2, 32, "rand", 18),
+            ("c384_q32_r", 384, 192, 1, 32, "rand", 19),
+            ("b416_q32_r", 416, 240, 1, 32, "rand", 20), ("b200_q27_r2", 200, 136, 2, 27, "rand", 21),
+            ("b200_q37_d3", 200, 136, 1, 37, 3, 22)]
+    for name, w, h, nf, qp, kind, seed in spec:
+        yuv = rt.synth_yuv(w, h, nf, seed)
+        if name.startswith("c128_q22"):            # one noisy case: transform skip, escapes, sign hiding
+            rng = np.random.default_rng(seed)
+            yuv = rng.integers(0, 256, yuv.shape).astype(np.uint8)
+        lab = rt.make_labels(w, h, nf, kind, seed + 100)
+        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab)
+        order = np.lexsort((dump["addr"], dump["frame"]))
+        dump = dump[order]
+        nctu = lab.shape[1]
+        assert len(dump) == nf * nctu
+        summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab,
+                            records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
+                            rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
+                            bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8),
+                            summary=np.array(summary))
+        cases.append(name)
+        print("rd fixture", name, "ctus", nf * nctu, summary[0][:60] if summary else "")
+    return cases
+
+
+def load_ref_model():
+    import torch
+    import torch.nn as nn
+    src = open(os.path.join(REF, "use_model.py"), encoding="utf-8").read()
+    cls = src[src.index("class ConvNet2"):src.index("DEVICE = ")]
+    ns = {"torch": torch, "nn": nn}
+    exec(cls, ns)
+    model = ns["ConvNet2"]()
+    sd = torch.load(os.path.join(REF, "rec", "hevc_encoder_model.pt"), map_location="cpu")
+    model.load_state_dict(sd)
+    assert model.training            # reference never calls .eval()
+    return model, sd, src
+
+
+def gen_weights(sd):
+    os.makedirs(WDIR, exist_ok=True)
+    tensors, chunks, off = [], [], 0
+    for k, v in sd.items():
+        a = v.detach().cpu().numpy()
+        if a.dtype != np.float32:      # num_batches_tracked (int64): unused in training-mode BN
+            continue
+        tensors.append({"name": k, "shape": list(a.shape), "offset": off})
+        chunks.append(a.astype("<f4").ravel())
+        off += a.size
+    np.concatenate(chunks).tofile(os.path.join(WDIR, "hevc_encoder_model.f32"))
+    json.dump({"source": "wolverinn/HEVC-deep-learning-pipeline rec/hevc_encoder_model.pt", "dtype": "f32le",
+               "floats": off, "tensors": tensors}, open(os.path.join(WDIR, "hevc_encoder_model.json"), "w"), indent=1)
+    print("weights:", off, "floats,", len(tensors), "tensors")
+
+
+def gen_cnn(model, src):
+    import torch
+    rng = np.random.default_rng(1234)
+    n = 64
+    ctus = np.zeros((n, 64, 64, 3), np.uint8)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for i in range(n):
+        k = i % 8
+        if k == 0:
+            ctus[i] = rng.integers(0, 256, (64, 64, 3))
+        elif k == 1:
+            base = 128 + 60 * np.sin(xx / (3.0 + i)) * np.cos(yy / (5.0 + i / 3))
+            ctus[i] = np.clip(base[..., None] + rng.normal(0, 4, (64, 64, 3)), 0, 255)
+        elif k == 2:
+            ctus[i] = int(rng.integers(0, 256))
+        elif k == 3:
+            b = (rng.integers(0, 2, (8, 8)) * 200 + 20).repeat(8, 0).repeat(8, 1)
+            ctus[i] = np.clip(b[..., None] + rng.integers(-10, 10, (64, 64, 3)), 0, 255)
+        elif k == 4:
+            b = (((xx * (1 + i % 5) + yy * 3) // 23) % 2) * 150 + 40
+            ctus[i] = np.clip(b[..., None] + rng.normal(0, 2, (64, 64, 3)), 0, 255)
+        elif k == 5:                               # picture-edge CTU: zero fill right/bottom (PIL crop)
+            ctus[i] = np.clip(128 + 50 * np.sin((xx + yy) / 9.0)[..., None] + rng.normal(0, 6, (64, 64, 3)), 0, 255)
+            ctus[i, :, 32 + (i % 3) * 8:] = 0
+            ctus[i, 48:, :] = 0
+        elif k == 6:
+            b = (rng.integers(0, 2, (16, 16)) * 255).repeat(4, 0).repeat(4, 1)
+            ctus[i] = b[..., None]
+        else:
+            g = np.clip(xx * 4 * (i % 3 == 0) + yy * 4 * (i % 3 != 0), 0, 255)
+            ctus[i] = np.stack([g, 255 - g, (g // 2 + 60)], -1)
+    logits = np.zeros((n, 4, 16), np.float32)
+    with torch.no_grad():
+        for i in range(n):
+            x = torch.from_numpy(ctus[i].astype(np.float32) / 255.0).permute(2, 0, 1)   # ToTensor: HWC u8 -> CHW /255
+            for q in range(4):
+                ox, oy = (q % 2) * 32, (q // 2) * 32
+                logits[i, q] = model(x[:, oy:oy + 32, ox:ox + 32].unsqueeze(0).contiguous(), x.unsqueeze(0))[0].numpy()
+    # label post-processing through the reference's own lines (use_model.py:101-119), driven with fake outputs
+    lines = src.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.strip().startswith("pred = str(int(torch.argmax"))
+    end = next(i for i, l in enumerate(lines) if "label[10],label[11],label[14],label[15]" in l)
+    body = "\n".join(l[16:] if len(l) > 16 else l.strip() for l in lines[start:end + 1])
+    code = compile(body, "use_model_101_119", "exec")
+
+    def ref_labels(lg4):                           # lg4 [4,16] logits
+        label = [str(i) for i in range(16)]
+        for layer2 in range(4):
+            ns = {"torch": torch, "output": torch.from_numpy(lg4[layer2:layer2 + 1].copy()), "layer2": layer2, "label": label}
+            exec(code, ns)
+        return [int(v) for v in label]
+
+    labels = np.array([ref_labels(logits[i]) for i in range(n)], np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "cnn_f1.npz"), ctu_rgb=ctus, logits=logits, labels=labels)
+    m = 4000
+    digits = rng.integers(0, 4, (m, 4, 4))
+    fake = np.zeros((m, 4, 16), np.float32)
+    for k in range(4):
+        fake[:, :, 4 * k:4 * k + 4] = np.eye(4, dtype=np.float32)[digits[:, :, k]]
+    lab2 = np.array([ref_labels(fake[i]) for i in range(m)], np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "cnn_f2.npz"), digits=digits.astype(np.uint8), labels=lab2)
+    print("cnn fixtures:", n, "CTUs,", m, "label tuples; label histogram", np.bincount(labels.ravel(), minlength=4))
+
+
+def gen_bd():
+    """Known-answer for a BD-rate script: values computed from the reference's
+    calc_BDBR sample with its own bundled formula."""
+    json.dump({"bd_psnr_db": -1.1922290103850435, "bd_rate_percent": 31.424376673861843,
+               "source": "calc_BDBR/Bjontegaard-python3.zip:RatePsnrSample.txt"}, open(os.path.join(GOLD, "bd_known_answer.json"), "w"))
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["rd", "cnn", "weights", "bd"]
+    if "rd" in what:
+        gen_rd()
+    if "cnn" in what or "weights" in what:
+        model, sd, src = load_ref_model()
+        if "weights" in what:
+            gen_weights(sd)
+        if "cnn" in what:
+            gen_cnn(model, src)
+    if "bd" in what:
+        gen_bd()
