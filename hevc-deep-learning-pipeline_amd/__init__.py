@@ -1,0 +1,205 @@
+"""hevc-deep-learning-pipeline_amd -- host-side mirror (Python, ctypes) of the C ABI in include/hevcdl.h.
+
+The compute path is the hand-written HIP library csrc/*.hip -> lib/libhevcdl_hip.so (gfx950).  There is NO CPU
+fallback: if the library is missing or no GPU is visible, every entry point raises.  The CPU oracle under
+oracle/ is test infrastructure and is never imported from here.
+
+Reference interfaces this replaces:
+  * TEncCu::compressCtu loop of TEncSlice::compressSlice (HM_dl/source/Lib/TLibEncoder/TEncSlice.cpp:792-983,
+    TEncCu.cpp:234-287)                                 -> Encoder.compress_frames / encode_frames_dev
+  * python gen_frames.py + python use_model.py sidecar  -> Encoder.predict_depth
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
+WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
+WEIGHT_FLOATS = 637712
+SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "hevcdl_api.hip"]
+
+STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
+
+REC_DTYPE = np.dtype([
+    ("depth", "u1", 256), ("part_size", "u1", 256), ("luma_dir", "u1", 256), ("chroma_dir", "u1", 256),
+    ("tr_idx", "u1", 256), ("cbf", "u1", (3, 256)), ("tskip", "u1", (3, 256)),
+    ("bits", "<u4"), ("dist", "<u4"), ("cost", "<f8"),
+    ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024)])
+STATS_DTYPE = np.dtype([("sse", "<u8", 3), ("est_bits", "<u8"), ("ctus", "<u4"), ("pad", "<u4")])
+assert REC_DTYPE.itemsize == 15120 and STATS_DTYPE.itemsize == 40
+
+
+class HevcdlError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__("hevcdl status %s%s" % (STATUS.get(status, status), (": " + msg) if msg else ""))
+        self.status = status
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("bit_depth", ctypes.c_int32), ("chroma_format", ctypes.c_int32), ("qp", ctypes.c_int32),
+                ("ctu_size", ctypes.c_int32), ("max_partition_depth", ctypes.c_int32),
+                ("tu_log2_min", ctypes.c_int32), ("tu_log2_max", ctypes.c_int32), ("tu_max_depth_intra", ctypes.c_int32),
+                ("tools", ctypes.c_uint32), ("bn_mode", ctypes.c_int32), ("boundary_policy", ctypes.c_int32),
+                ("cnn_input", ctypes.c_int32), ("device", ctypes.c_int32), ("max_frames", ctypes.c_int32),
+                ("lambda_", ctypes.c_double), ("sqrt_lambda", ctypes.c_double), ("chroma_weight", ctypes.c_double),
+                ("lambda_chroma", ctypes.c_double), ("err_scale", (ctypes.c_double * 4) * 2),
+                ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class Profile(ctypes.Structure):
+    _fields_ = [("cnn_ms", ctypes.c_double), ("rd_ms", ctypes.c_double), ("cnn_launches", ctypes.c_uint32), ("rd_launches", ctypes.c_uint32)]
+
+
+def build_ext(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into lib/libhevcdl_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(PKG_DIR, "csrc", s) for s in SOURCES]
+    deps = srcs + [os.path.join(PKG_DIR, "csrc", "hevcdl_dev.h"), os.path.join(ROOT, "include", "hevcdl.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-unused-value",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library; fails loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(this package has no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.hevcdl_config_default.argtypes = [ctypes.POINTER(Config), ci, ci, ci]
+    lib.hevcdl_create.argtypes = [ctypes.POINTER(Config), vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.hevcdl_destroy.argtypes = [vp]
+    lib.hevcdl_destroy.restype = None
+    lib.hevcdl_last_error.argtypes = [vp]
+    lib.hevcdl_last_error.restype = ctypes.c_char_p
+    lib.hevcdl_predict_depth.argtypes = [vp, vp, ci, vp, vp]
+    lib.hevcdl_predict_depth_rgb.argtypes = [vp, vp, ci, vp, vp]
+    lib.hevcdl_compress_frames.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.hevcdl_predict_depth_dev.argtypes = [vp, vp, ci, vp, vp, vp]
+    lib.hevcdl_compress_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.hevcdl_encode_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.hevcdl_profile_enable.argtypes = [vp, ci]
+    lib.hevcdl_profile_get.argtypes = [vp, ctypes.POINTER(Profile)]
+    lib.hevcdl_ctus_per_frame.argtypes = [ci, ci]
+    lib.hevcdl_frame_bytes.argtypes = [ci, ci]
+    lib.hevcdl_frame_bytes.restype = ctypes.c_size_t
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
+           "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
+           "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes"]
+
+
+def load_weights(path=WEIGHTS_PATH):
+    w = np.fromfile(path, dtype="<f4")
+    if w.size != WEIGHT_FLOATS:
+        raise ValueError("weight blob must hold %d floats, got %d" % (WEIGHT_FLOATS, w.size))
+    return w
+
+
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0):
+    lib = load_library()
+    cfg = Config()
+    st = lib.hevcdl_config_default(ctypes.byref(cfg), width, height, qp)
+    if st:
+        raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
+    cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
+    return cfg
+
+
+class Encoder:
+    """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
+
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None):
+        self.lib = load_library()
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input)
+        self.width, self.height, self.qp = self.cfg.width, self.cfg.height, self.cfg.qp
+        self.ctus = self.lib.hevcdl_ctus_per_frame(self.width, self.height)
+        self.frame_bytes = self.lib.hevcdl_frame_bytes(self.width, self.height)
+        w = np.ascontiguousarray(load_weights() if weights is None else weights, dtype="<f4")
+        self._h = ctypes.c_void_p()
+        st = self.lib.hevcdl_create(ctypes.byref(self.cfg), w.ctypes.data, w.size, ctypes.byref(self._h))
+        if st:
+            self._h = None
+            raise HevcdlError(st, "hevcdl_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.hevcdl_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, st):
+        if st:
+            raise HevcdlError(st, (self.lib.hevcdl_last_error(self._h) or b"").decode())
+
+    def _frames(self, yuv):
+        yuv = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.frame_bytes)
+        return yuv, yuv.shape[0]
+
+    def predict_depth(self, yuv, want_logits=False):
+        yuv, n = self._frames(yuv)
+        labels = np.zeros((n, self.ctus, 16), np.uint8)
+        logits = np.zeros((n, self.ctus, 4, 16), np.float32) if want_logits else None
+        self._check(self.lib.hevcdl_predict_depth(self._h, yuv.ctypes.data, n, labels.ctypes.data, logits.ctypes.data if want_logits else None))
+        return (labels, logits) if want_logits else labels
+
+    def predict_depth_rgb(self, ctu_rgb):
+        ctu_rgb = np.ascontiguousarray(ctu_rgb, np.uint8).reshape(-1, 64, 64, 3)
+        n = ctu_rgb.shape[0]
+        labels = np.zeros((n, 16), np.uint8)
+        logits = np.zeros((n, 4, 16), np.float32)
+        self._check(self.lib.hevcdl_predict_depth_rgb(self._h, ctu_rgb.ctypes.data, n, labels.ctypes.data, logits.ctypes.data))
+        return labels, logits
+
+    def compress_frames(self, yuv, labels=None):
+        """-> (records [n, ctus] REC_DTYPE, recon [n, frame_bytes] uint8, stats [n] STATS_DTYPE)."""
+        yuv, n = self._frames(yuv)
+        recs = np.zeros((n, self.ctus), REC_DTYPE)
+        recon = np.zeros_like(yuv)
+        stats = np.zeros(n, STATS_DTYPE)
+        lab_ptr = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, np.uint8).reshape(n, self.ctus, 16)
+            lab_ptr = labels.ctypes.data
+        self._check(self.lib.hevcdl_compress_frames(self._h, yuv.ctypes.data, n, lab_ptr, recs.ctypes.data, recon.ctypes.data, stats.ctypes.data))
+        return recs, recon, stats
+
+    # ---- device-resident entry points: arguments are raw device pointers (ints), e.g. torch.Tensor.data_ptr() ----
+    def predict_depth_dev(self, d_yuv, n, d_labels, d_logits=None, stream=None):
+        self._check(self.lib.hevcdl_predict_depth_dev(self._h, d_yuv, n, d_labels, d_logits, stream))
+
+    def compress_frames_dev(self, d_yuv, n, d_labels, d_records, d_recon, d_stats=None, stream=None):
+        self._check(self.lib.hevcdl_compress_frames_dev(self._h, d_yuv, n, d_labels, d_records, d_recon, d_stats, stream))
+
+    def encode_frames_dev(self, d_yuv, n, d_labels, d_records, d_recon, d_stats=None, stream=None):
+        self._check(self.lib.hevcdl_encode_frames_dev(self._h, d_yuv, n, d_labels, d_records, d_recon, d_stats, stream))
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.hevcdl_profile_enable(self._h, int(on)))
+
+    def profile_get(self):
+        p = Profile()
+        self._check(self.lib.hevcdl_profile_get(self._h, ctypes.byref(p)))
+        return {"cnn_ms": p.cnn_ms, "rd_ms": p.rd_ms, "cnn_launches": p.cnn_launches, "rd_launches": p.rd_launches}

@@ -1,0 +1,307 @@
+// hevcdl_api.hip -- host side of the C ABI declared in include/hevcdl.h (compiled by hipcc for gfx950).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "hevcdl.h"
+#include "hevcdl_dev.h"
+
+extern "C" __global__ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p);
+extern "C" __global__ void hevcdl_rd_frame_kernel(hevcdl_rd_params p);
+
+struct hevcdl_ctx {
+  hevcdl_config cfg;
+  int ctus_x, ctus_y, ctus;
+  size_t frame_bytes;
+  float *d_weights;
+  unsigned char *d_scratch;      // RD per-frame workspace
+  size_t scratch_per_frame;
+  // staging buffers for the host-pointer entry points
+  uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
+  hipStream_t stream;
+  bool profile;
+  std::vector<hipEvent_t> ev_cnn, ev_rd;       // start/stop pairs
+  char err[256];
+};
+
+static const int CHROMA_SCALE_420[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+  29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };   // TComRom.cpp:536
+static const int QUANT_SCALES[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   // TComRom.cpp:354-357
+static const int INV_QUANT_SCALES[6] = { 40, 45, 51, 57, 64, 72 };                  // TComRom.cpp:359-362
+
+static hevcdl_status fail(hevcdl_ctx *c, hevcdl_status s, const char *what, hipError_t e = hipSuccess)
+{
+  if (c) snprintf(c->err, sizeof c->err, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+  return s;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, #call, e_); } while (0)
+
+extern "C" int hevcdl_ctus_per_frame(int w, int h) { return ((w + 63) >> 6) * ((h + 63) >> 6); }
+extern "C" size_t hevcdl_frame_bytes(int w, int h) { return (size_t)w * h * 3 / 2; }
+
+extern "C" hevcdl_status hevcdl_config_default(hevcdl_config *cfg, int width, int height, int qp)
+{
+  if (!cfg || width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51) return HEVCDL_ERR_INVALID_ARG;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = sizeof *cfg;
+  cfg->width = width; cfg->height = height; cfg->bit_depth = 8; cfg->chroma_format = 420; cfg->qp = qp;
+  cfg->ctu_size = 64; cfg->max_partition_depth = 4; cfg->tu_log2_min = 2; cfg->tu_log2_max = 5; cfg->tu_max_depth_intra = 3;
+  cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->bn_mode = HEVCDL_BN_REFERENCE; cfg->boundary_policy = HEVCDL_BOUNDARY_CLAMP;
+  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1;
+  // TEncSlice::calculateLambda (TEncSlice.cpp:433-527) for an all-intra GOP of 1, then setUpLambda (:112-140)
+  cfg->lambda = 0.57 * 1.0 * pow(2.0, (qp - 12) / 3.0);
+  cfg->sqrt_lambda = sqrt(cfg->lambda);                         // TComRdCost::setLambda TComRdCost.cpp:109-122
+  cfg->qp_chroma = CHROMA_SCALE_420[qp];
+  cfg->chroma_weight = pow(2.0, (qp - cfg->qp_chroma) / 3.0);
+  cfg->lambda_chroma = cfg->lambda / cfg->chroma_weight;
+  for (int ch = 0; ch < 2; ch++) {
+    const int q = ch ? cfg->qp_chroma : qp, rem = q % 6, per = q / 6;
+    for (int l = 0; l < 4; l++) {                               // TComTrQuant::setErrScaleCoeff TComTrQuant.cpp:3096-3126
+      const int tshift = 15 - 8 - (l + 2);
+      double s = (double)(1 << 15);
+      s = s * pow(2.0, -2.0 * tshift);
+      cfg->err_scale[ch][l] = s / QUANT_SCALES[rem] / QUANT_SCALES[rem] / (1 << 0);
+    }
+    const double inv = (double)INV_QUANT_SCALES[rem], lam = ch ? cfg->lambda_chroma : cfg->lambda;
+    cfg->sbh_rd_factor[ch] = (int64_t)(inv * inv * (1 << (2 * per)) / lam / 16 / (1 << 0) + 0.5);   // TComTrQuant.cpp:2532-2535
+  }
+  return HEVCDL_OK;
+}
+
+// state_dict order of the reference checkpoint (fp32 tensors): offsets in floats
+enum { B_C1W = 0, B_C1B = 1200, B_C1G = 1216, B_C1BE = 1232, B_C2W = 1280, B_C2B = 19712, B_C2G = 19776, B_C2BE = 19840,
+       B_C3W = 20032, B_C3B = 93760, B_C3G = 93888, B_C3BE = 94016, B_F1W = 94400, B_F1B = 618688, B_F2W = 618944, B_F2B = 635328,
+       B_F3W = 635392, B_F3B = 636416, B_C64W = 636432, B_C64B = 637632, B_C64G = 637648, B_C64BE = 637664 };
+
+static void pack_conv(const float *w, const float *b, const float *g, const float *be, int oc, int taps, float *dst)
+{ // [oc][taps] -> [taps][oc], then bias, gamma, beta
+  for (int o = 0; o < oc; o++) for (int k = 0; k < taps; k++) dst[k * oc + o] = w[o * taps + k];
+  memcpy(dst + taps * oc, b, oc * sizeof(float)); memcpy(dst + taps * oc + oc, g, oc * sizeof(float)); memcpy(dst + taps * oc + 2 * oc, be, oc * sizeof(float));
+}
+static void pack_fc(const float *w, const float *b, int out, int in, float *dst)
+{ for (int j = 0; j < out; j++) for (int k = 0; k < in; k++) dst[(size_t)k * out + j] = w[(size_t)j * in + k]; memcpy(dst + (size_t)in * out, b, out * sizeof(float)); }
+
+extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *weights, size_t n_floats, hevcdl_ctx **out)
+{
+  if (!cfg || !out || !weights || cfg->struct_size != sizeof(hevcdl_config)) return HEVCDL_ERR_INVALID_ARG;
+  if (n_floats != HEVCDL_WEIGHT_FLOATS) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51 || cfg->max_frames < 1) return HEVCDL_ERR_INVALID_ARG;
+  // keys that would change the path are rejected, not ignored
+  if (cfg->bit_depth != 8 || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
+      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || cfg->bn_mode != HEVCDL_BN_REFERENCE ||
+      cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA))
+    return HEVCDL_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return HEVCDL_ERR_NO_DEVICE;
+  hevcdl_ctx *ctx = new (std::nothrow) hevcdl_ctx();
+  if (!ctx) return HEVCDL_ERR_OOM;
+  ctx->cfg = *cfg; ctx->err[0] = 0; ctx->profile = false;
+  ctx->ctus_x = (cfg->width + 63) >> 6; ctx->ctus_y = (cfg->height + 63) >> 6; ctx->ctus = ctx->ctus_x * ctx->ctus_y;
+  ctx->frame_bytes = hevcdl_frame_bytes(cfg->width, cfg->height);
+  ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
+  ctx->d_logits = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr;
+  hipError_t e;
+#define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
+  CK(hipSetDevice(cfg->device));
+  std::vector<float> pk(HEVCDL_W_TOTAL);
+  pack_conv(weights + B_C1W, weights + B_C1B, weights + B_C1G, weights + B_C1BE, 16, 75, pk.data() + HEVCDL_W_C1);
+  pack_conv(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, 16, 75, pk.data() + HEVCDL_W_C64);
+  pack_conv(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 288, pk.data() + HEVCDL_W_C2);
+  pack_conv(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 576, pk.data() + HEVCDL_W_C3);
+  pack_fc(weights + B_F1W, weights + B_F1B, 256, 2048, pk.data() + HEVCDL_W_FC1);
+  pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
+  pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
+  CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
+  CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
+  ctx->scratch_per_frame = hevcdl_rd_scratch_bytes();
+  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames));
+  CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
+  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes()));
+#undef CK
+  *out = ctx;
+  return HEVCDL_OK;
+}
+
+extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
+{
+  if (!ctx) return;
+  hipSetDevice(ctx->cfg.device);
+  hipDeviceSynchronize();
+  for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
+  hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_rgb);
+  delete ctx;
+}
+
+extern "C" const char *hevcdl_last_error(const hevcdl_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+static hevcdl_status ensure_staging(hevcdl_ctx *ctx)
+{
+  if (ctx->d_yuv) return HEVCDL_OK;
+  const size_t nf = (size_t)ctx->cfg.max_frames;
+  HIPCHK(hipMalloc(&ctx->d_yuv, ctx->frame_bytes * nf));
+  HIPCHK(hipMalloc(&ctx->d_recon, ctx->frame_bytes * nf));
+  HIPCHK(hipMalloc(&ctx->d_labels, (size_t)ctx->ctus * 16 * nf));
+  HIPCHK(hipMalloc(&ctx->d_logits, (size_t)ctx->ctus * 64 * sizeof(float) * nf));
+  HIPCHK(hipMalloc(&ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * nf));
+  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(hevcdl_frame_stats) * nf));
+  return HEVCDL_OK;
+}
+
+static void prof_begin(hevcdl_ctx *ctx, std::vector<hipEvent_t> &v, hipStream_t s)
+{
+  if (!ctx->profile) return;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a, s); v.push_back(a); v.push_back(b);
+}
+static void prof_end(hevcdl_ctx *ctx, std::vector<hipEvent_t> &v, hipStream_t s) { if (ctx->profile) hipEventRecord(v.back(), s); }
+
+static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int n_ctus, int clamp, void *d_labels, void *d_logits, hipStream_t s)
+{
+  hevcdl_cnn_params p;
+  p.input = (const uint8_t *)d_in; p.weights = ctx->d_weights; p.labels = (uint8_t *)d_labels; p.logits = (float *)d_logits;
+  p.input_mode = mode; p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.clamp = clamp;
+  if (mode == HEVCDL_DEV_INPUT_RGB_CTU) { p.ctus_per_frame = n_ctus > 0 ? n_ctus : 1; p.ctus_x = p.ctus_per_frame; }
+  prof_begin(ctx, ctx->ev_cnn, s);
+  hipLaunchKernelGGL(hevcdl_cnn_ctu_kernel, dim3(n_ctus), dim3(256), hevcdl_cnn_smem_bytes(), s, p);
+  prof_end(ctx, ctx->ev_cnn, s);
+  HIPCHK(hipGetLastError());
+  return HEVCDL_OK;
+}
+
+static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s)
+{
+  hevcdl_rd_params p;
+  memset(&p, 0, sizeof p);
+  p.yuv = (const uint8_t *)d_yuv; p.labels = (const uint8_t *)d_labels; p.records = (unsigned char *)d_records; p.recon = (uint8_t *)d_recon;
+  p.stats = (unsigned char *)d_stats; p.scratch = ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
+  p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_y = ctx->ctus_y; p.n_frames = n_frames;
+  p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
+  memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
+  p.k.sbh_rd_factor[0] = ctx->cfg.sbh_rd_factor[0]; p.k.sbh_rd_factor[1] = ctx->cfg.sbh_rd_factor[1];
+  p.k.qp = ctx->cfg.qp; p.k.qp_chroma = ctx->cfg.qp_chroma;
+  p.debug = getenv("HEVCDL_DEBUG") ? atoi(getenv("HEVCDL_DEBUG")) : 0;
+  prof_begin(ctx, ctx->ev_rd, s);
+  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames), dim3(64), hevcdl_rd_smem_bytes(), s, p);
+  prof_end(ctx, ctx->ev_rd, s);
+  HIPCHK(hipGetLastError());
+  return HEVCDL_OK;
+}
+
+static hevcdl_status check_frames(hevcdl_ctx *ctx, int n_frames)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  if (n_frames < 0 || n_frames > ctx->cfg.max_frames) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "n_frames out of range (cfg.max_frames)");
+  hipError_t e = hipSetDevice(ctx->cfg.device);
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "hipSetDevice", e);
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!d_yuv || !d_labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  return launch_cnn(ctx, d_yuv, ctx->cfg.cnn_input == HEVCDL_CNN_INPUT_LUMA ? HEVCDL_DEV_INPUT_LUMA : HEVCDL_DEV_INPUT_RGB601,
+                    n_frames * ctx->ctus, 1, d_labels, d_logits_opt, (hipStream_t)stream);
+}
+
+extern "C" hevcdl_status hevcdl_compress_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels,
+                                                    void *d_records, void *d_recon, void *d_stats, void *stream)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!d_yuv || !d_labels || !d_records || !d_recon) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  return launch_rd(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, (hipStream_t)stream);
+}
+
+extern "C" hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels,
+                                                  void *d_records, void *d_recon, void *d_stats, void *stream)
+{
+  hevcdl_status st = hevcdl_predict_depth_dev(ctx, d_yuv, n_frames, d_labels, nullptr, stream); if (st) return st;
+  return hevcdl_compress_frames_dev(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, stream);
+}
+
+extern "C" hevcdl_status hevcdl_predict_depth(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, uint8_t *labels, float *logits_opt)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!yuv || !labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  st = ensure_staging(ctx); if (st) return st;
+  HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, logits_opt ? ctx->d_logits : nullptr, nullptr); if (st) return st;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(labels, ctx->d_labels, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyDeviceToHost));
+  if (logits_opt) HIPCHK(hipMemcpy(logits_opt, ctx->d_logits, (size_t)ctx->ctus * 64 * sizeof(float) * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t *ctu_rgb, int n_ctus, uint8_t *labels, float *logits_opt)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  if (n_ctus < 0) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "n_ctus < 0");
+  if (n_ctus == 0) return HEVCDL_OK;
+  if (!ctu_rgb || !labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  HIPCHK(hipSetDevice(ctx->cfg.device));
+  uint8_t *d_in = nullptr, *d_lab = nullptr; float *d_lg = nullptr;
+  HIPCHK(hipMalloc(&d_in, (size_t)n_ctus * 12288));
+  HIPCHK(hipMalloc(&d_lab, (size_t)n_ctus * 16));
+  HIPCHK(hipMalloc(&d_lg, (size_t)n_ctus * 64 * sizeof(float)));
+  HIPCHK(hipMemcpy(d_in, ctu_rgb, (size_t)n_ctus * 12288, hipMemcpyHostToDevice));
+  hevcdl_status st = launch_cnn(ctx, d_in, HEVCDL_DEV_INPUT_RGB_CTU, n_ctus, 0, d_lab, d_lg, nullptr);
+  if (st == HEVCDL_OK) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) st = fail(ctx, HEVCDL_ERR_HIP, "cnn kernel", e);
+  }
+  if (st == HEVCDL_OK) {
+    hipMemcpy(labels, d_lab, (size_t)n_ctus * 16, hipMemcpyDeviceToHost);
+    if (logits_opt) hipMemcpy(logits_opt, d_lg, (size_t)n_ctus * 64 * sizeof(float), hipMemcpyDeviceToHost);
+  }
+  hipFree(d_in); hipFree(d_lab); hipFree(d_lg);
+  return st;
+}
+
+extern "C" hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,
+                                                hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!yuv || !records) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  st = ensure_staging(ctx); if (st) return st;
+  HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice));
+  else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
+  st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "rd kernel", e);
+  HIPCHK(hipMemcpy(records, ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames, hipMemcpyDeviceToHost));
+  if (recon_opt) HIPCHK(hipMemcpy(recon_opt, ctx->d_recon, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
+  if (stats_opt) HIPCHK(hipMemcpy(stats_opt, ctx->d_stats, sizeof(hevcdl_frame_stats) * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_profile_enable(hevcdl_ctx *ctx, int enable)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  ctx->profile = enable != 0;
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_profile_get(hevcdl_ctx *ctx, hevcdl_profile *out)
+{
+  if (!ctx || !out) return HEVCDL_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(ctx->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  memset(out, 0, sizeof *out);
+  for (int which = 0; which < 2; which++) {
+    std::vector<hipEvent_t> &v = which ? ctx->ev_rd : ctx->ev_cnn;
+    double ms = 0; unsigned n = 0;
+    for (size_t i = 0; i + 1 < v.size(); i += 2) { float t = 0; if (hipEventElapsedTime(&t, v[i], v[i + 1]) == hipSuccess) { ms += t; n++; } hipEventDestroy(v[i]); hipEventDestroy(v[i + 1]); }
+    v.clear();
+    if (which) { out->rd_ms = ms; out->rd_launches = n; } else { out->cnn_ms = ms; out->cnn_launches = n; }
+  }
+  return HEVCDL_OK;
+}

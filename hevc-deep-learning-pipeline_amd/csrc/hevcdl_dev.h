@@ -1,0 +1,58 @@
+// hevcdl_dev.h -- internal host<->kernel parameter blocks (not part of the C ABI).
+#ifndef HEVCDL_DEV_H
+#define HEVCDL_DEV_H
+#include <stdint.h>
+#include <stddef.h>
+
+#define HEVCDL_DEV_INPUT_RGB601  0
+#define HEVCDL_DEV_INPUT_LUMA    1
+#define HEVCDL_DEV_INPUT_RGB_CTU 2
+
+// packed CNN weights (floats): every conv is [tap k][oc] + bias + gamma + beta, every fc is [k][j] + bias
+#define HEVCDL_W_C1   0            // 75*16 + 3*16
+#define HEVCDL_W_C64  1248
+#define HEVCDL_W_C2   2496         // 288*64 + 3*64
+#define HEVCDL_W_C3   21120        // 576*128 + 3*128
+#define HEVCDL_W_FC1  95232        // 2048*256 + 256
+#define HEVCDL_W_FC2  619776       // 256*64 + 64
+#define HEVCDL_W_FC3  636224       // 64*16 + 16
+#define HEVCDL_W_TOTAL 637264
+
+struct hevcdl_cnn_params {
+  const uint8_t *input;            // planar 4:2:0 frames, or packed RGB CTUs (input_mode 2)
+  const float *weights;            // packed, HEVCDL_W_TOTAL floats
+  uint8_t *labels;                 // [ctu][16]
+  float *logits;                   // [ctu][4][16] or NULL
+  int input_mode, width, height, ctus_x, ctus_per_frame, clamp;
+};
+
+// decision constants (bit patterns computed on the host, see include/hevcdl.h)
+struct hevcdl_rd_consts {
+  double lambda, sqrt_lambda, chroma_weight, lambda_chroma;
+  double err_scale[2][4];
+  long long sbh_rd_factor[2];
+  int qp, qp_chroma;
+};
+
+struct hevcdl_rd_params {
+  const uint8_t *yuv;              // [frame] planar 4:2:0 originals
+  const uint8_t *labels;           // [frame][ctu][16]
+  unsigned char *records;          // [frame][ctu] hevcdl_ctu_record
+  uint8_t *recon;                  // [frame] planar 4:2:0 reconstruction (also the neighbour source)
+  unsigned char *stats;            // [frame] hevcdl_frame_stats or NULL
+  unsigned char *scratch;          // [frame] per-frame workspace
+  size_t scratch_per_frame;
+  int width, height, ctus_x, ctus_y, n_frames, debug;
+  hevcdl_rd_consts k;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+size_t hevcdl_cnn_smem_bytes(void);
+size_t hevcdl_rd_smem_bytes(void);
+size_t hevcdl_rd_scratch_bytes(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1683 @@
+// rd_kernel.hip -- depth-pruned all-intra CTU decision kernel for gfx950 (MI355X).
+//
+// Replaces, behind include/hevcdl.h, the reference's per-CTU CPU loop
+//   TEncSlice::compressSlice   HM_dl/source/Lib/TLibEncoder/TEncSlice.cpp:698-983
+//   TEncCu::compressCtu        TEncCu.cpp:234-287  -> xCompressCU :470-1104 -> xCheckRDCostIntra :1600-1665
+//   TEncSearch::estIntraPredLumaQT / estIntraPredChromaQT   TEncSearch.cpp:2203-2737 and everything below them
+// (reference-sample gather/filter TComPattern.cpp:119-570, prediction TComPrediction.cpp:183-817, SATD/SSE
+//  TComRdCost.cpp, DCT/DST/RDOQ/dequant TComTrQuant.cpp, CABAC-as-rate-estimator TEncSbac.cpp / ContextModel.cpp).
+//
+// Execution model: the CTUs of one slice are a strict serial chain (reconstructed neighbours + the adaptive CABAC
+// state advanced by the final encode of every previous CTU), all-intra frames are independent.  One wavefront
+// (64 lanes) therefore walks one frame; the grid is the batch of frames.  Inside the wave
+//   * pixel work is lane-parallel: reference gather, the 35-mode rough mode decision (one lane per
+//     (mode, 8x8 block) task: predict + Hadamard), prediction, residual, DCT/DST, dequant, reconstruction, SSE;
+//   * the inherently sequential parts (RDOQ reverse scan, CABAC bin counting) run on lane 0 out of LDS.
+// All decision arithmetic is the reference's: int32 transforms, fp64 costs without contraction (-ffp-contract=off),
+// lambda family computed on the host and passed as bits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hevcdl.h"
+#include "hevcdl_dev.h"
+
+namespace {
+
+#define DEV __device__ __forceinline__
+#define DEVN __device__ __noinline__
+constexpr double MAX_DOUBLE = 1.7e+308;
+enum { PLANAR = 0, DC = 1, HOR = 10, VER = 26, DM_CHROMA = 36 };
+enum { SIZE_2Nx2N = 0, SIZE_NxN = 3, SIZE_NONE = 8 };
+enum { SCAN_DIAG = 0, SCAN_HOR = 1, SCAN_VER = 2 };
+enum { A_DEPTH = 0, A_PART, A_LDIR, A_CDIR, A_TRIDX, A_CBF, A_TSKIP = 8 };
+// record field byte offsets (hevcdl_ctu_record)
+enum { REC_BITS = 11 * 256, REC_DIST = REC_BITS + 4, REC_COST = REC_BITS + 8, REC_COEF = REC_BITS + 16, REC_SIZE = 15120 };
+
+// ---- CABAC context layout (I-slice values: ContextTables.h:181-480; reference order TEncSbac.cpp:62-92) ----
+enum { CTX_SPLIT = 0, CTX_PART_SIZE = 3, CTX_INTRA_PRED = 4, CTX_CHROMA_PRED = 5, CTX_QT_CBF = 6, CTX_SUBDIV = 16, CTX_SIG_CG = 19,
+       CTX_SIG = 23, CTX_LAST_X = 67, CTX_LAST_Y = 97, CTX_ONE = 127, CTX_ABS = 151, CTX_TSKIP = 157, NUM_CTX = 159 };
+
+__constant__ uint8_t c_ctx_init[NUM_CTX] = {
+  139, 141, 157, 184, 184, 63,
+  111, 141, 154, 154, 154, 94, 138, 182, 154, 154,
+  153, 138, 138, 91, 171, 134, 141,
+  111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 141,
+  140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 111,
+  110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
+  138, 153, 136, 167, 152, 152, 139, 139 };
+// ContextModel.cpp:68-101
+__constant__ uint8_t c_next_mps[128] = {
+  2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
+  34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65,
+  66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97,
+  98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 124, 125, 126, 127 };
+__constant__ uint8_t c_next_lps[128] = {
+  1, 0, 0, 1, 2, 3, 4, 5, 4, 5, 8, 9, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 18, 19, 22, 23, 22, 23, 24, 25,
+  26, 27, 26, 27, 30, 31, 30, 31, 32, 33, 32, 33, 36, 37, 36, 37, 38, 39, 38, 39, 42, 43, 42, 43, 44, 45, 44, 45, 46, 47, 48, 49,
+  48, 49, 50, 51, 52, 53, 52, 53, 54, 55, 54, 55, 56, 57, 58, 59, 58, 59, 60, 61, 60, 61, 60, 61, 62, 63, 64, 65, 64, 65, 66, 67,
+  66, 67, 66, 67, 68, 69, 68, 69, 70, 71, 70, 71, 70, 71, 72, 73, 72, 73, 72, 73, 74, 75, 74, 75, 74, 75, 76, 77, 76, 77, 126, 127 };
+// ContextModel.cpp:103-112 (FAST_BIT_EST)
+__constant__ int32_t c_entropy_bits[128] = {
+  0x07b23, 0x085f9, 0x074a0, 0x08cbc, 0x06ee4, 0x09354, 0x067f4, 0x09c1b, 0x060b0, 0x0a62a, 0x05a9c, 0x0af5b, 0x0548d, 0x0b955, 0x04f56, 0x0c2a9,
+  0x04a87, 0x0cbf7, 0x045d6, 0x0d5c3, 0x04144, 0x0e01b, 0x03d88, 0x0e937, 0x039e0, 0x0f2cd, 0x03663, 0x0fc9e, 0x03347, 0x10600, 0x03050, 0x10f95,
+  0x02d4d, 0x11a02, 0x02ad3, 0x12333, 0x0286e, 0x12cad, 0x02604, 0x136df, 0x02425, 0x13f48, 0x021f4, 0x149c4, 0x0203e, 0x1527b, 0x01e4d, 0x15d00,
+  0x01c99, 0x166de, 0x01b18, 0x17017, 0x019a5, 0x17988, 0x01841, 0x18327, 0x016df, 0x18d50, 0x015d9, 0x19547, 0x0147c, 0x1a083, 0x0138e, 0x1a8a3,
+  0x01251, 0x1b418, 0x01166, 0x1bd27, 0x01068, 0x1c77b, 0x00f7f, 0x1d18e, 0x00eda, 0x1d91a, 0x00e19, 0x1e254, 0x00d4f, 0x1ec9a, 0x00c90, 0x1f6e0,
+  0x00c01, 0x1fef8, 0x00b5f, 0x208b1, 0x00ab6, 0x21362, 0x00a15, 0x21e46, 0x00988, 0x2285d, 0x00934, 0x22ea8, 0x008a8, 0x239b2, 0x0081d, 0x24577,
+  0x007c9, 0x24ce6, 0x00763, 0x25663, 0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5, 0x0055e, 0x29057,
+  0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f, 0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb };
+__constant__ int c_quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };        // TComRom.cpp:354-357
+__constant__ int c_inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };                        // TComRom.cpp:359-362
+__constant__ uint8_t c_group_idx[32] = { 0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9 };   // TComRom.cpp:598
+__constant__ uint8_t c_ctx_ind_map_4x4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };   // TComRom.cpp:589-595
+__constant__ uint8_t c_num_rd_cand[5] = { 8, 8, 3, 3, 3 };                                  // TComRom.cpp:545-553
+__constant__ uint8_t c_intra_filter_thr[5] = { 10, 7, 1, 0, 10 };                           // TComPrediction.cpp:50-58
+__constant__ int c_ang_table[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };                      // TComPrediction.cpp:265
+__constant__ int c_inv_ang_table[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };     // TComPrediction.cpp:266
+__constant__ int8_t c_dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };   // TComRom.cpp:368-374
+__constant__ int8_t c_dct_mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                      61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };   // TComRom.cpp:376-517
+
+struct __attribute__((aligned(8))) Cabac { uint8_t ctx[160]; unsigned long long frac; };   // 168 bytes
+struct Rd { double cost; uint32_t bits, dist; };
+struct Cu { int x, y, log2, depth, zbase, nparts, part; };
+struct Tu { int x, y, log2, trd, zrel, nparts; };
+
+struct RdSmem {
+  Cabac go, curr[5], next[5], temp[5], root[5], test[5], tbest[5], truec;
+  uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
+  uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
+  int16_t line[264], fline[264];      // reference samples: bottom-left ... corner(2n) ... top-right
+  int32_t tc[1024];                   // transform coefficients (RDOQ input) / dequantised coefficients
+  int16_t resi[1024];
+  int16_t lvl[1024];                  // quantised levels of the current TU (TU raster)
+  uint8_t pred[1024];                 // prediction, then reconstruction, of the current TU
+  uint16_t scan[1024];                // grouped-4x4 coefficient scan of the current TU (TComRom.cpp:179-260)
+  uint8_t scan_cg[64];
+  int16_t dct[32 * 32];               // T32[k][n]; T_N[k][n] = T32[k*32/N][n]
+  union {
+    int32_t tmp[1024];                // transform intermediate
+    struct { double cost_coeff[1024], cost_sig[1024]; int32_t rate_up[1024], rate_down[1024], sig_delta[1024], delta_u[1024]; } q;
+  } u;
+  uint8_t sv_tr[256], sv_cbf[3][256], sv_ts[3][256];
+  uint8_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
+  unsigned int satd[36];
+  double rmd_cost[36];
+  unsigned int rd_list[16];
+  unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
+  unsigned int red_u32;
+  unsigned long long est_bits, sse_acc[3];
+  uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];
+  int stop, stage;
+  double cg_cost[64];                 // RDOQ per-CG sig-flag cost
+  uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
+  int last_bits[2][12];   // saved 2Nx2N candidate of an 8x8 CU
+};
+
+struct K {                             // wave-uniform kernel context
+  RdSmem *s;
+  int lane;
+  int W, H, cw, ctus_x, addr, cx, cy, nctu;
+  const uint8_t *org[3];
+  uint8_t *rec[3];
+  unsigned char *records;              // frame's records (global)
+  const uint8_t *labels;               // frame's labels
+  int16_t *coef_l;                     // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
+  uint8_t *rec_l;                      // scratch: [4 layers][6144] CTU-relative reconstruction
+  uint8_t *best_rec;                   // scratch: [6144] best reconstruction of the CU under test
+  double lambda, sqrt_lambda, cweight, lambda_c;
+  double err_scale[2][4];
+  long long sbh[2];
+  int qp, qp_c;
+  int dbg;
+};
+#define STAGE(k) do { wsync(); if ((k).lane == 0) { (k).s->stage++; if ((k).dbg > 1 && (k).s->stage >= (k).dbg) (k).s->stop = 1; } wsync(); } while (0)
+#define STOPPED(k) (((k).dbg > 1 || (k).dbg <= -17) && (k).s->stop)
+#define DBG(k, ...) do { if ((k).dbg && (k).lane == 0) printf(__VA_ARGS__); } while (0)
+
+DEV void wsync() { __syncthreads(); }
+DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV int comp_off(int c) { return c == 0 ? 0 : (c == 1 ? 4096 : 5120); }
+DEV int cstride(int c) { return c ? 32 : 64; }
+DEV int pstride(const K &k, int c) { return c ? k.cw : k.W; }
+DEV int boff(const K &k, int c, int x, int y) { const int s = c ? 32 : 64; return (y - k.cy * s) * s + (x - k.cx * s); }
+// log2 of a block size in {4,8,16,32,64}.  NOT 31-clz(n): that form let the compiler fold the constant part of a
+// dynamic index into a FLAT instruction's immediate offset with a base BELOW the indexed private object; gfx9-family
+// hardware picks the aperture from the base alone (offset ignored) -> HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
+DEV int ilog2(int n) { return n >= 32 ? (n >= 64 ? 6 : 5) : (n >= 16 ? 4 : (n >= 8 ? 3 : 2)); }
+DEV int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+DEV int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+// ---------------------------------------------------------------------------------------------------
+// CABAC estimator (TEncBinCoderCABACCounter.cpp:60-140); the coder state lives in LDS and is touched by lane 0 only
+// ---------------------------------------------------------------------------------------------------
+DEV void enc_bin(Cabac *c, int ctx, int bin)
+{
+  const uint8_t st = c->ctx[ctx];
+  c->frac += (unsigned long long)c_entropy_bits[st ^ bin];
+  c->ctx[ctx] = ((st & 1) == bin) ? c_next_mps[st] : c_next_lps[st];
+}
+DEV void enc_ep(Cabac *c, int n) { c->frac += 32768ull * (unsigned long long)n; }
+DEV void reset_bits(Cabac *c) { c->frac &= 32767ull; }
+DEV uint32_t get_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
+DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return c_entropy_bits[c->ctx[ctx] ^ bin]; }
+DEV void cabac_copy(const K &k, Cabac *dst, const Cabac *src)
+{ // wave-parallel 168-byte snapshot copy (TEncSbac::load/store, TEncSbac.cpp:396-425)
+  wsync();
+  if (k.lane < 21) reinterpret_cast<unsigned long long *>(dst)[k.lane] = reinterpret_cast<const unsigned long long *>(src)[k.lane];
+  wsync();
+}
+DEV double calc_rd_cost(const K &k, uint32_t bits, uint32_t dist) { return (double)dist + ((double)bits * k.lambda); }   // TComRdCost.cpp:62-107
+
+DEV void set_parts(const K &k, uint8_t *a, int z0, int n, int v)
+{
+  for (int i = k.lane; i < n; i += 64) a[z0 + i] = (uint8_t)v;
+}
+
+// attribute of the 4x4 partition (x4,y4) of the picture: current CTU from LDS, earlier CTUs from their records
+DEV int part_attr(const K &k, int field, int x4, int y4)
+{
+  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), z = k.s->r2z[((y4 & 15) << 4) | (x4 & 15)];
+  if (a == k.addr) return k.s->a[field][z];
+  return k.records[(size_t)a * REC_SIZE + field * 256 + z];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reference samples (TComPattern.cpp:119-543)
+// ---------------------------------------------------------------------------------------------------
+DEV int unit_avail(const K &k, int x4, int y4, int cur_x4, int cur_y4)
+{ // inside the picture and already coded: earlier CTU, or earlier z-order in this CTU (TComDataCU.cpp:985-1200)
+  if (x4 < 0 || y4 < 0 || x4 * 4 >= k.W || y4 * 4 >= k.H) return 0;
+  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4);
+  if (a != k.addr) return a < k.addr;
+  return k.s->r2z[((y4 & 15) << 4) | (x4 & 15)] < k.s->r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
+}
+
+DEVN void build_refs(const K &k, int c, int x, int y, int n)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n / u;
+  const int x4 = x >> sh, y4 = y >> sh, total = 4 * nu + 1;
+  // availability of the <= 65 units: lanes 0..63 + unit 64 (only for a 64x64 luma block) on lane 0's second pass
+  auto unit_flag = [&](int kk) -> int {
+    if (kk < 2 * nu) return unit_avail(k, x4 - 1, y4 + (2 * nu - 1 - kk), x4, y4);
+    if (kk == 2 * nu) return unit_avail(k, x4 - 1, y4 - 1, x4, y4);
+    return unit_avail(k, x4 + (kk - 2 * nu - 1), y4 - 1, x4, y4);
+  };
+  const int f0 = (k.lane < total) ? unit_flag(k.lane) : 0;
+  const unsigned long long m0 = __ballot(f0);
+  const int f64 = (total > 64) ? unit_flag(64) : 0;          // uniform
+  const int st = pstride(k, c);
+  const uint8_t *p = k.rec[c];
+  auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
+  auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
+  auto sample = [&](int i) -> int {                          // picture sample behind line index i
+    if (i < 2 * n) return p[(size_t)(y + 2 * n - 1 - i) * st + x - 1];
+    if (i == 2 * n) return p[(size_t)(y - 1) * st + x - 1];
+    return p[(size_t)(y - 1) * st + x + (i - 2 * n - 1)];
+  };
+  for (int i = k.lane; i <= 4 * n; i += 64) {
+    int kk = i < 2 * n ? i / u : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / u);
+    int v;
+    const int fl = kk < 64 ? (int)((m0 >> kk) & 1) : f64;
+    if (fl) v = sample(i);
+    else {
+      // nearest available unit below (its last sample), else the first available unit above (its first sample)
+      unsigned long long below = kk >= 64 ? m0 : (m0 & ((1ull << kk) - 1ull));
+      if (below) { const int j = 63 - __clzll(below); v = sample(unit_start(j) + unit_len(j) - 1); }
+      else {
+        unsigned long long above = kk >= 63 ? 0ull : (m0 & ~((2ull << kk) - 1ull));
+        if (above) { const int j = __ffsll((long long)above) - 1; v = sample(unit_start(j)); }
+        else if (f64) v = sample(unit_start(64));
+        else v = 128;
+      }
+    }
+    k.s->line[i] = (int16_t)v;
+  }
+  wsync();
+}
+
+DEVN void filter_refs(const K &k, int n)
+{
+  STAGE(k); if (STOPPED(k)) return; // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
+  const int16_t *src = k.s->line; int16_t *dst = k.s->fline;
+  const int n2 = 2 * n, last = 4 * n;
+  int strong = 0;
+  const int bl = src[0], tl = src[n2], tr = src[last];
+  if (n >= 32) strong = (abs(bl + tl - 2 * src[n]) < 8) && (abs(tl + tr - 2 * src[n2 + n]) < 8);
+  for (int i = k.lane; i <= last; i += 64) {
+    int v;
+    if (i == 0 || i == last) v = src[i];
+    else if (strong) {
+      const int shift = (n == 32) ? 6 : 7;
+      if (i < n2) v = ((n2 - i) * bl + i * tl + n) >> shift;
+      else if (i == n2) v = src[n2];
+      else v = ((n2 - (i - n2)) * tl + (i - n2) * tr + n) >> shift;
+    } else v = (src[i - 1] + 2 * src[i] + src[i + 1] + 2) >> 2;
+    dst[i] = (int16_t)v;
+  }
+  wsync();
+}
+
+DEV int use_filtered_refs(int c, int mode, int n)
+{ // TComPattern.cpp:545-570; chroma never in 4:2:0
+  if (c || mode == DC) return 0;
+  const int d1 = abs(mode - HOR), d2 = abs(mode - VER), diff = d1 < d2 ? d1 : d2;
+  return diff > c_intra_filter_thr[ilog2(n) - 2];
+}
+
+// closed-form intra prediction of one sample (TComPrediction.cpp:183-473, 731-817); dcval only for DC
+DEV int pred_pixel(const int16_t *line, int c, int mode, int n, int log2n, int px, int py, int dcval)
+{
+  const int n2 = 2 * n;
+  if (mode == PLANAR) {
+    const int left = line[n2 - 1 - py], top = line[n2 + 1 + px], bl = line[n2 - 1 - n], tr = line[n2 + 1 + n];
+    return ((n - 1 - px) * left + (px + 1) * tr + (n - 1 - py) * top + (py + 1) * bl + n) >> (log2n + 1);
+  }
+  if (mode == DC) {
+    if (!c && n <= 16) {
+      if (px == 0 && py == 0) return (line[n2 + 1] + line[n2 - 1] + 2 * dcval + 2) >> 2;
+      if (py == 0) return (line[n2 + 1 + px] + 3 * dcval + 2) >> 2;
+      if (px == 0) return (line[n2 - 1 - py] + 3 * dcval + 2) >> 2;
+    }
+    return dcval;
+  }
+  const int is_ver = mode >= 18;
+  const int ang_mode = is_ver ? mode - VER : -(mode - HOR);
+  const int abs_ang = abs(ang_mode);
+  const int angle = (ang_mode < 0 ? -1 : 1) * c_ang_table[abs_ang];
+  const int inv_angle = c_inv_ang_table[abs_ang];
+  const int x = is_ver ? px : py, y = is_ver ? py : px;
+  auto ref = [&](int i) -> int {
+    if (i >= 0) return is_ver ? line[n2 + i] : line[n2 - i];
+    const int j = (128 + (-i) * inv_angle) >> 8;
+    return is_ver ? line[n2 - j] : line[n2 + j];
+  };
+  if (angle == 0) {
+    int v = ref(x + 1);
+    if (!c && n <= 16 && x == 0) { const int s1 = is_ver ? line[n2 - (y + 1)] : line[n2 + (y + 1)], s0 = line[n2]; v = clip8(v + ((s1 - s0) >> 1)); }
+    return v;
+  }
+  const int dpos = (y + 1) * angle, di = dpos >> 5, df = dpos & 31;
+  if (df) return ((32 - df) * ref(x + di + 1) + df * ref(x + di + 2) + 16) >> 5;
+  return ref(x + di + 1);
+}
+
+DEV int dc_value(const K &k, const int16_t *line, int n)
+{ // predIntraGetPredValDC TComPrediction.cpp:183-201
+  const int n2 = 2 * n;
+  int s = 0;
+  for (int i = k.lane; i < n; i += 64) s += line[n2 + 1 + i] + line[n2 - 1 - i];
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  return (s + n) / (n + n);
+}
+
+// prediction of an n x n TU (n <= 32) into s->pred (stride n)
+DEVN void predict_block(const K &k, int c, int mode, int n)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  const int16_t *line = use_filtered_refs(c, mode, n) ? k.s->fline : k.s->line;
+  const int log2n = ilog2(n);
+  const int dcv = (mode == DC) ? dc_value(k, line, n) : 0;
+  for (int i = k.lane; i < n * n; i += 64) k.s->pred[i] = (uint8_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
+  wsync();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transforms (TComTrQuant.cpp:388-987): lane-parallel dot products, matrices in LDS
+// ---------------------------------------------------------------------------------------------------
+DEV int tmat(const K &k, int use_dst, int log2n, int kk, int i)
+{
+  return use_dst ? (int)c_dst4[kk * 4 + i] : (int)k.s->dct[(kk << (5 - log2n)) * 32 + i];
+}
+DEVN void fwd_transform(const K &k, int n, int use_dst)
+{
+  STAGE(k); if (STOPPED(k)) return; // s->resi (stride n) -> s->tc
+  const int log2n = ilog2(n), s1 = log2n + 8 - 9, s2 = log2n + 6;
+  const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
+  for (int o = k.lane; o < n * n; o += 64) {
+    const int kk = o >> log2n, j = o & (n - 1);
+    int acc = 0;
+    for (int i = 0; i < n; i++) acc += tmat(k, use_dst, log2n, kk, i) * k.s->resi[j * n + i];
+    k.s->u.tmp[kk * n + j] = (acc + a1) >> s1;
+  }
+  wsync();
+  for (int o = k.lane; o < n * n; o += 64) {
+    const int kk = o >> log2n, j = o & (n - 1);
+    int acc = 0;
+    for (int i = 0; i < n; i++) acc += tmat(k, use_dst, log2n, kk, i) * k.s->u.tmp[j * n + i];
+    k.s->tc[kk * n + j] = (acc + a2) >> s2;
+  }
+  wsync();
+}
+DEVN void inv_transform(const K &k, int n, int use_dst)
+{
+  STAGE(k); if (STOPPED(k)) return; // s->tc (dequantised) -> s->resi
+  const int log2n = ilog2(n);
+  for (int o = k.lane; o < n * n; o += 64) {
+    const int j = o >> log2n, x = o & (n - 1);
+    int acc = 0;
+    for (int kk = 0; kk < n; kk++) acc += tmat(k, use_dst, log2n, kk, x) * k.s->tc[kk * n + j];
+    k.s->u.tmp[j * n + x] = clip16((acc + 64) >> 7);
+  }
+  wsync();
+  for (int o = k.lane; o < n * n; o += 64) {
+    const int j = o >> log2n, x = o & (n - 1);
+    int acc = 0;
+    for (int kk = 0; kk < n; kk++) acc += tmat(k, use_dst, log2n, kk, x) * k.s->u.tmp[kk * n + j];
+    k.s->resi[j * n + x] = (int16_t)clip16((acc + 2048) >> 12);
+  }
+  wsync();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// coefficient-coding geometry shared by RDOQ and the bit counter
+// ---------------------------------------------------------------------------------------------------
+struct CParam { int log2, n, ch, scan_type, wg, first_sig_ctx; };
+
+DEV int coef_scan_idx(int c, int n, int dir_mode)
+{ // TComDataCU.cpp:3150-3209
+  if (n > (c ? 4 : 8)) return SCAN_DIAG;
+  if (abs(dir_mode - VER) <= 4) return SCAN_HOR;
+  if (abs(dir_mode - HOR) <= 4) return SCAN_VER;
+  return SCAN_DIAG;
+}
+DEV void get_cparam(CParam &cp, int c, int n, int dir_mode)
+{ // TComChromaFormat.cpp:96-160
+  cp.n = n; cp.log2 = ilog2(n); cp.ch = c ? 1 : 0; cp.scan_type = coef_scan_idx(c, n, dir_mode); cp.wg = n >> 2;
+  if (n == 4) cp.first_sig_ctx = 0;
+  else if (n == 8) cp.first_sig_ctx = 9 + ((cp.scan_type != SCAN_DIAG) ? (cp.ch ? 0 : 6) : 0);
+  else cp.first_sig_ctx = cp.ch ? 12 : 21;
+}
+DEV void scan_next(int type, int bw, int bh, int &line, int &col)
+{ // ScanGenerator::GetNextIndex TComRom.cpp:100-160
+  if (type == SCAN_DIAG) {
+    if (col == bw - 1 || line == 0) { line += col + 1; col = 0; if (line >= bh) { col += line - (bh - 1); line = bh - 1; } }
+    else { col++; line--; }
+  } else if (type == SCAN_HOR) { if (col == bw - 1) { line++; col = 0; } else col++; }
+  else { if (line == bh - 1) { col++; line = 0; } else line++; }
+}
+// fill s->scan / s->scan_cg for (scan type, n): the CG order is generated by lane 0 (<= 64 steps), the 16 positions
+// inside each CG by one lane per CG
+DEVN void load_scan(const K &k, int scan_type, int n)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  const int wg = n >> 2, ng = wg * wg;
+  wsync();
+  if (k.lane == 0) { int l = 0, c = 0; for (int g = 0; g < ng; g++) { k.s->scan_cg[g] = (uint8_t)(l * wg + c); scan_next(scan_type, wg, wg, l, c); } }
+  wsync();
+  for (int g = k.lane; g < ng; g += 64) {
+    const int cg = k.s->scan_cg[g], gl = cg / wg, gc = cg - gl * wg;
+    int l2 = 0, c2 = 0;
+    for (int p = 0; p < 16; p++) { k.s->scan[g * 16 + p] = (uint16_t)((l2 + gl * 4) * n + c2 + gc * 4); scan_next(scan_type, 4, 4, l2, c2); }
+  }
+  wsync();
+}
+DEV int pattern_sig_ctx(const uint8_t *cgf, int gx, int gy, int wg)
+{ // TComTrQuant.cpp:2672-2705
+  if (wg <= 1) return 0;
+  const int r = (gx < wg - 1) ? (cgf[gy * wg + gx + 1] != 0) : 0, l = (gy < wg - 1) ? (cgf[(gy + 1) * wg + gx] != 0) : 0;
+  return r + (l << 1);
+}
+DEV int sig_cg_ctx(const uint8_t *cgf, int gx, int gy, int wg)
+{ // TComTrQuant.cpp:3023-3049
+  const int r = (gx < wg - 1) ? (cgf[gy * wg + gx + 1] != 0) : 0, l = (gy < wg - 1) ? (cgf[(gy + 1) * wg + gx] != 0) : 0;
+  return (r + l) != 0;
+}
+DEV int sig_ctx_inc(const CParam &cp, const uint16_t *scan, int pat, int scan_pos)
+{ // TComTrQuant.cpp:2707-2803
+  const int raster = scan[scan_pos], py = raster >> cp.log2, px = raster - (py << cp.log2);
+  if (px + py == 0) return 0;
+  int offset;
+  if (cp.log2 == 2) offset = c_ctx_ind_map_4x4[4 * py + px];
+  else {
+    int cnt; const int xs = px & 3, ys = py & 3;
+    if (pat == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
+    else if (pat == 1) cnt = (ys >= 2) ? 0 : ((ys >= 1) ? 1 : 2);
+    else if (pat == 2) cnt = (xs >= 2) ? 0 : ((xs >= 1) ? 1 : 2);
+    else cnt = 2;
+    const int not_first = ((px >> 2) + (py >> 2)) > 0;
+    offset = (not_first ? (cp.ch ? 0 : 3) : 0) + cnt;
+  }
+  return cp.first_sig_ctx + offset;
+}
+DEV int ctx_set_index(int ch, int subset, int found_gt1) { return (ch ? 4 : 0) + ((!ch && subset > 0) ? 2 : 0) + (found_gt1 ? 1 : 0); }   // TComChromaFormat.h:243-251
+DEV void last_ctx_params(int ch, int n, int &off, int &shift)
+{ // TComChromaFormat.h:211-226
+  const int cw = ilog2(n) - 2;
+  off = ch ? 0 : (cw * 3 + ((cw + 1) >> 2));
+  shift = ch ? cw : ((cw + 3) >> 2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RDOQ (TComTrQuant.cpp:2119-2661, helpers :2812-2996); executed by lane 0 on LDS data.
+// Rate tables (estBitsSbacStruct, TEncSbac.cpp:1726-1970) are read straight from the frozen contexts of `cab`.
+// ---------------------------------------------------------------------------------------------------
+DEV int ic_rate(const Cabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, int go_rice, uint32_t c1idx, uint32_t c2idx)
+{ // xGetICRate TComTrQuant.cpp:2881-2955
+  int rate = 32768;
+  const uint32_t base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
+  if (abs_level >= base) {
+    uint32_t symbol = abs_level - base, length;
+    if (symbol < (3u << go_rice)) { length = symbol >> go_rice; rate += (int)(length + 1 + go_rice) << 15; }
+    else {
+      length = go_rice; symbol -= (3u << go_rice);
+      while (symbol >= (1u << length)) symbol -= (1u << (length++));
+      rate += (int)(3 + length + 1 - go_rice + length) << 15;
+    }
+    if (c1idx < 8) { rate += ctx_bits(cab, CTX_ONE + ctx_one, 1); if (c2idx < 1) rate += ctx_bits(cab, CTX_ABS + ctx_abs, 1); }
+  } else if (abs_level == 1) rate += ctx_bits(cab, CTX_ONE + ctx_one, 0);
+  else if (abs_level == 2) { rate += ctx_bits(cab, CTX_ONE + ctx_one, 1); rate += ctx_bits(cab, CTX_ABS + ctx_abs, 0); }
+  else rate = 0;
+  return rate;
+}
+
+DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mode, int cbf_ctx)
+{ // s->tc -> s->lvl ; returns uiAbsSum
+  if (k.dbg == -19) return 0;
+  RdSmem &s = *k.s;
+  const int ch = c ? 1 : 0, log2n = ilog2(n);
+  const int qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
+  const int tshift = 15 - 8 - log2n, qbits = 14 + per + tshift;
+  const double lambda = c ? k.lambda_c : k.lambda;
+  const double err_scale = k.err_scale[ch][log2n - 2];
+  const int qcoef = c_quant_scales[rem];
+  const int ncoef = n * n;
+  CParam cp; get_cparam(cp, c, n, dir_mode);
+  const uint16_t *scan = s.scan;
+  const int32_t *src = s.tc; int16_t *dst = s.lvl;
+  double *cost_coeff = s.u.q.cost_coeff, *cost_sig = s.u.q.cost_sig;
+  int32_t *rate_inc_up = s.u.q.rate_up, *rate_inc_down = s.u.q.rate_down, *sig_rate_delta = s.u.q.sig_delta, *delta_u = s.u.q.delta_u;
+  double *cost_cg_sig = s.cg_cost; uint8_t *cgf = s.cgf;
+  if (k.dbg == -196) return 0;
+  for (int i = 0; i < ncoef; i++) { cost_coeff[i] = 0; cost_sig[i] = 0; rate_inc_up[i] = 0; rate_inc_down[i] = 0; sig_rate_delta[i] = 0; delta_u[i] = 0; }
+  if (k.dbg == -197) return 0;
+  for (int i = 0; i < 64; i++) { cost_cg_sig[i] = 0; cgf[i] = 0; }
+  if (k.dbg == -20) return 0;
+  const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
+  auto level_double = [&](int blk) -> int32_t {
+    const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
+    return (int32_t)(tmpl < lim ? tmpl : lim);
+  };
+  auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
+  double block_uncoded = 0, base_cost = 0;
+  int cg_last = -1, last_pos = -1, ctx_set = 0, c1 = 1, c2 = 0, go_rice = 0; uint32_t c1idx = 0, c2idx = 0;
+  const int ncg = ncoef >> 4;
+  for (int cgpos = ncg - 1; cgpos >= 0; cgpos--) {
+    const int cgblk = s.scan_cg[cgpos], gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
+    double st_sig_cost = 0, st_sig_cost0 = 0, st_coded = 0, st_uncoded = 0; int st_nnz_before0 = 0;
+    const int pat = pattern_sig_ctx(cgf, gx, gy, cp.wg);
+    for (int pin = 15; pin >= 0; pin--) {
+      const int sp = cgpos * 16 + pin, blk = scan[sp];
+      const int32_t ld = level_double(blk);
+      uint32_t max_abs = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
+      if (max_abs > 32767u) max_abs = 32767u;
+      const double derr = (double)ld;
+      const double c0 = derr * derr * err_scale;
+      block_uncoded += c0;
+      dst[blk] = (int16_t)max_abs;
+      if (max_abs > 0 && last_pos < 0) { last_pos = sp; ctx_set = ctx_set_index(ch, sp >> 4, 0); cg_last = cgpos; }
+      if (last_pos >= 0) {
+        uint32_t level;
+        const int one_ctx = 4 * ctx_set + c1, abs_ctx = ctx_set + c2;
+        { // xGetCodedLevel TComTrQuant.cpp:2812-2879
+          const int is_last = (sp == last_pos);
+          int sig_ctx = 0; double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0; int done = 0;
+          if (!is_last) sig_ctx = sig_off + sig_ctx_inc(cp, scan, pat, sp);
+          if (!is_last && max_abs < 3) {
+            cost_sig[sp] = lambda * (double)ctx_bits(cab, sig_ctx, 0);
+            best = c0 + cost_sig[sp];
+            if (max_abs == 0) done = 1;
+          }
+          if (!done) {
+            if (!is_last) cur_sig = lambda * (double)ctx_bits(cab, sig_ctx, 1);
+            const uint32_t min_abs = max_abs > 1 ? max_abs - 1 : 1;
+            for (int al = (int)max_abs; al >= (int)min_abs; al--) {
+              const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
+              double cur = err * err * err_scale + lambda * (double)ic_rate(cab, (uint32_t)al, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
+              cur += cur_sig;
+              if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_sig[sp] = cur_sig; }
+            }
+          }
+          cost_coeff[sp] = best;
+          level = best_lvl;
+          if (!is_last) sig_rate_delta[blk] = ctx_bits(cab, sig_ctx, 1) - ctx_bits(cab, sig_ctx, 0);
+        }
+        delta_u[blk] = (int32_t)((ld - (int32_t)(level << qbits)) >> (qbits - 8));
+        if (level > 0) {
+          const int now = ic_rate(cab, level, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
+          rate_inc_up[blk] = ic_rate(cab, level + 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
+          rate_inc_down[blk] = ic_rate(cab, level - 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
+        } else rate_inc_up[blk] = ctx_bits(cab, CTX_ONE + one_ctx, 0);
+        dst[blk] = (int16_t)level;
+        base_cost += cost_coeff[sp];
+        const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
+        if (level >= base_level) { if (level > 3u * (1u << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4; }
+        if (level >= 1) c1idx++;
+        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2idx++; }
+        else if (c1 < 3 && c1 > 0 && level) c1++;
+        if ((sp & 15) == 0 && sp > 0) { ctx_set = ctx_set_index(ch, (sp - 1) >> 4, c1 == 0); c1 = 1; c2 = 0; c1idx = 0; c2idx = 0; go_rice = 0; }
+      } else base_cost += c0;
+      st_sig_cost += cost_sig[sp];
+      if (pin == 0) st_sig_cost0 = cost_sig[sp];
+      if (dst[blk]) {
+        cgf[cgblk] = 1;
+        st_coded += cost_coeff[sp] - cost_sig[sp];
+        st_uncoded += c0;
+        if (pin != 0) st_nnz_before0++;
+      }
+    }
+    if (cg_last >= 0) {
+      if (cgpos) {
+        if (cgf[cgblk] == 0) {
+          const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
+          const double r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
+          base_cost += r0 - st_sig_cost;
+          cost_cg_sig[cgpos] = r0;
+        } else if (cgpos < cg_last) {
+          if (st_nnz_before0 == 0) { base_cost -= st_sig_cost0; st_sig_cost -= st_sig_cost0; }
+          double zero_cost = base_cost;
+          const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
+          const double r1 = lambda * (double)ctx_bits(cab, cg_off + cs, 1), r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
+          base_cost += r1; zero_cost += r0; cost_cg_sig[cgpos] = r1;
+          zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
+          if (zero_cost < base_cost) {
+            cgf[cgblk] = 0; base_cost = zero_cost; cost_cg_sig[cgpos] = r0;
+            for (int pin = 15; pin >= 0; pin--) {
+              const int sp = cgpos * 16 + pin, blk = scan[sp];
+              if (dst[blk]) { dst[blk] = 0; cost_coeff[sp] = cost0_of(blk); cost_sig[sp] = 0; }
+            }
+          }
+        }
+      } else cgf[cgblk] = 1;
+    }
+  }
+  if (k.dbg == -21) return 0;
+  if (last_pos < 0) return 0;
+  double best_cost;
+  {
+    const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
+    best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
+    base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
+  }
+  int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
+  { // TEncSbac.cpp:1910-1930
+    int off, shift; last_ctx_params(ch, n, off, shift);
+    const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
+    int accx = 0, accy = 0, kk; const int ng = c_group_idx[n - 1];
+    for (kk = 0; kk < ng; kk++) {
+      last_x_bits[kk] = accx + ctx_bits(cab, bx + off + (kk >> shift), 0); accx += ctx_bits(cab, bx + off + (kk >> shift), 1);
+      last_y_bits[kk] = accy + ctx_bits(cab, by + off + (kk >> shift), 0); accy += ctx_bits(cab, by + off + (kk >> shift), 1);
+    }
+    last_x_bits[kk] = accx; last_y_bits[kk] = accy;
+  }
+  if (k.dbg == -22) return 0;
+  int best_last_p1 = 0, found_last = 0;
+  for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
+    const int cgblk = s.scan_cg[cgpos];
+    base_cost -= cost_cg_sig[cgpos];
+    if (!cgf[cgblk]) continue;
+    for (int pin = 15; pin >= 0; pin--) {
+      const int sp = cgpos * 16 + pin;
+      if (sp > last_pos) continue;
+      const int blk = scan[sp];
+      if (dst[blk]) {
+        int py = blk >> log2n, px = blk - (py << log2n);
+        if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
+        const int gx2 = c_group_idx[px], gy2 = c_group_idx[py];
+        double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
+        if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
+        if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
+        const double cost_last = lambda * lc;
+        const double total = base_cost + cost_last - cost_sig[sp];
+        if (total < best_cost) { best_last_p1 = sp + 1; best_cost = total; }
+        if (dst[blk] > 1) { found_last = 1; break; }
+        base_cost -= cost_coeff[sp]; base_cost += cost0_of(blk);
+      } else base_cost -= cost_sig[sp];
+    }
+  }
+  if (k.dbg == -23) return 0;
+  uint32_t abs_sum = 0;
+  for (int sp = 0; sp < best_last_p1; sp++) {
+    const int blk = scan[sp]; const int lv = dst[blk];
+    abs_sum += (uint32_t)lv;
+    dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv);
+  }
+  for (int sp = best_last_p1; sp <= last_pos; sp++) dst[scan[sp]] = 0;
+  if (k.dbg == -24) return abs_sum;
+  if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660
+    const long long rd_factor = k.sbh[ch];
+    int last_cg = -1;
+    for (int subset = (ncoef - 1) >> 4; subset >= 0; subset--) {
+      const int sub_pos = subset << 4; int first_nz = 16, last_nz = -1, sum = 0, kk;
+      for (kk = 15; kk >= 0; --kk) if (dst[scan[kk + sub_pos]]) { last_nz = kk; break; }
+      for (kk = 0; kk < 16; kk++) if (dst[scan[kk + sub_pos]]) { first_nz = kk; break; }
+      for (kk = first_nz; kk <= last_nz; kk++) sum += dst[scan[kk + sub_pos]];
+      if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+      if (last_nz - first_nz >= 4) {
+        const uint32_t signbit = dst[scan[sub_pos + first_nz]] > 0 ? 0 : 1;
+        if (signbit != ((uint32_t)sum & 1u)) {
+          long long min_cost = 0x7fffffffffffffffll, cur_cost = 0x7fffffffffffffffll; int min_pos = -1, final_change = 0, cur_change = 0;
+          for (kk = (last_cg == 1 ? last_nz : 15); kk >= 0; --kk) {
+            const int blk = scan[kk + sub_pos];
+            if (dst[blk] != 0) {
+              const long long up = rd_factor * (-(long long)delta_u[blk]) + rate_inc_up[blk];
+              long long down = rd_factor * ((long long)delta_u[blk]) + rate_inc_down[blk] - ((abs(dst[blk]) == 1) ? sig_rate_delta[blk] : 0);
+              if (last_cg == 1 && last_nz == kk && abs(dst[blk]) == 1) down -= (4 << 15);
+              if (up < down) { cur_cost = up; cur_change = 1; }
+              else { cur_change = -1; cur_cost = (kk == first_nz && abs(dst[blk]) == 1) ? 0x7fffffffffffffffll : down; }
+            } else {
+              cur_cost = rd_factor * (-(long long)abs(delta_u[blk])) + (1 << 15) + rate_inc_up[blk] + sig_rate_delta[blk];
+              cur_change = 1;
+              if (kk < first_nz) { const uint32_t ts = src[blk] >= 0 ? 0 : 1; if (ts != signbit) cur_cost = 0x7fffffffffffffffll; }
+            }
+            if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = blk; }
+          }
+          if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
+          if (src[min_pos] >= 0) dst[min_pos] = (int16_t)(dst[min_pos] + final_change); else dst[min_pos] = (int16_t)(dst[min_pos] - final_change);
+        }
+      }
+      if (last_cg == 1) last_cg = 0;
+    }
+  }
+  return abs_sum;
+}
+
+DEVN void dequant(const K &k, int c, int n)
+{
+  STAGE(k); if (STOPPED(k)) return; // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
+  const int log2n = ilog2(n), qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
+  const int tshift = 15 - 8 - log2n, rshift = 6 - (tshift + per), scale = c_inv_quant_scales[rem];
+  for (int i = k.lane; i < n * n; i += 64) {
+    const int q = k.s->lvl[i];                       // already inside the 16-bit clip range
+    int v;
+    if (rshift > 0) v = (q * scale + (1 << (rshift - 1))) >> rshift;
+    else v = (int)((unsigned)(q * scale) << (-rshift));
+    k.s->tc[i] = clip16(v);
+  }
+  wsync();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// residual syntax bit counting on lane 0 (TEncSbac.cpp:1115-1541); coefficients in s->lvl (TU raster)
+// ---------------------------------------------------------------------------------------------------
+DEV void code_last_xy(Cabac *c, int px, int py, int n, int ch, int scan_type)
+{
+  if (scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
+  const int gx = c_group_idx[px], gy = c_group_idx[py]; int off, shift, kk;
+  last_ctx_params(ch, n, off, shift);
+  const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
+  for (kk = 0; kk < gx; kk++) enc_bin(c, bx + (kk >> shift), 1);
+  if (gx < c_group_idx[n - 1]) enc_bin(c, bx + (kk >> shift), 0);
+  for (kk = 0; kk < gy; kk++) enc_bin(c, by + (kk >> shift), 1);
+  if (gy < c_group_idx[n - 1]) enc_bin(c, by + (kk >> shift), 0);
+  if (gx > 3) enc_ep(c, (gx - 2) >> 1);
+  if (gy > 3) enc_ep(c, (gy - 2) >> 1);
+}
+DEV void code_coef_remain(Cabac *c, uint32_t symbol, int rparam)
+{ // xWriteCoefRemainExGolomb TEncSbac.cpp:337-394 (bit count only)
+  if (symbol < (3u << rparam)) { enc_ep(c, (int)(symbol >> rparam) + 1); enc_ep(c, rparam); }
+  else {
+    uint32_t len = (uint32_t)rparam, cn = symbol - (3u << rparam);
+    while (cn >= (1u << len)) cn -= (1u << (len++));
+    enc_ep(c, (int)(3 + len + 1 - rparam)); enc_ep(c, (int)len);
+  }
+}
+DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp, int n, int dir_mode, int tskip_flag)
+{
+  RdSmem &s = *k.s;
+  const int ch = comp ? 1 : 0;
+  CParam cp; get_cparam(cp, comp, n, dir_mode);
+  const int log2n = cp.log2;
+  const int16_t *coef = s.lvl; const uint16_t *scan = s.scan;
+  int num_sig = 0;
+  for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
+  if (num_sig == 0) return;                                   // never called for an empty TU (cbf checked by the caller)
+  if (n == 4) enc_bin(c, CTX_TSKIP + ch, tskip_flag);         // codeTransformSkipFlags :997-1032
+  uint8_t *cgf = s.cgf; for (int i = 0; i < 64; i++) cgf[i] = 0;
+  int scan_last = -1, pos_last;
+  do {
+    pos_last = scan[++scan_last];
+    if (coef[pos_last] != 0) { const int py = pos_last >> log2n, px = pos_last - (py << log2n); cgf[cp.wg * (py >> 2) + (px >> 2)] = 1; num_sig--; }
+  } while (num_sig > 0);
+  { const int py = pos_last >> log2n, px = pos_last - (py << log2n); code_last_xy(c, px, py, n, ch, cp.scan_type); }
+  const int cg_off = CTX_SIG_CG + (ch ? 2 : 0), sig_off = CTX_SIG + (ch ? 28 : 0);
+  const int last_set = scan_last >> 4;
+  uint32_t c1 = 1; int go_rice = 0, sp = scan_last;
+  for (int subset = last_set; subset >= 0; subset--) {
+    int num_nz = 0; const int sub_pos = subset << 4;
+    go_rice = 0;
+    int abs_coeff[16], last_nz = -1, first_nz = 16, escape = 0;
+    if (sp == scan_last) { abs_coeff[0] = abs(coef[pos_last]); num_nz = 1; last_nz = sp; first_nz = sp; sp--; }
+    const int cgblk = s.scan_cg[subset], gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
+    if (subset == last_set || subset == 0) cgf[cgblk] = 1;
+    else enc_bin(c, cg_off + sig_cg_ctx(cgf, gx, gy, cp.wg), cgf[cgblk] != 0);
+    if (cgf[cgblk]) {
+      const int pat = pattern_sig_ctx(cgf, gx, gy, cp.wg);
+      for (; sp >= sub_pos; sp--) {
+        const int blk = scan[sp], sig = coef[blk] != 0;
+        if (sp > sub_pos || subset == 0 || num_nz) enc_bin(c, sig_off + sig_ctx_inc(cp, scan, pat, sp), sig);
+        if (sig) { abs_coeff[num_nz++] = abs(coef[blk]); if (last_nz == -1) last_nz = sp; first_nz = sp; }
+      }
+    } else sp = sub_pos - 1;
+    if (num_nz > 0) {
+      const int sign_hidden = (last_nz - first_nz >= 4);
+      const int cset = ctx_set_index(ch, subset, c1 == 0);
+      c1 = 1;
+      const int n_c1 = num_nz < 8 ? num_nz : 8; int first_c2 = -1;
+      for (int i = 0; i < n_c1; i++) {
+        const int sym = abs_coeff[i] > 1;
+        enc_bin(c, CTX_ONE + 4 * cset + (int)c1, sym);
+        if (sym) { c1 = 0; if (first_c2 == -1) first_c2 = i; else escape = 1; }
+        else if (c1 < 3 && c1 > 0) c1++;
+      }
+      if (c1 == 0 && first_c2 != -1) { const int sym = abs_coeff[first_c2] > 2; enc_bin(c, CTX_ABS + cset, sym); if (sym) escape = 1; }
+      escape = escape || (num_nz > 8);
+      enc_ep(c, sign_hidden ? num_nz - 1 : num_nz);
+      int first_coeff2 = 1;
+      if (escape) for (int i = 0; i < num_nz; i++) {
+        const int base = (i < 8) ? (2 + first_coeff2) : 1;
+        if (abs_coeff[i] >= base) {
+          code_coef_remain(c, (uint32_t)(abs_coeff[i] - base), go_rice);
+          if (abs_coeff[i] > (3 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+        }
+        if (abs_coeff[i] >= 2) first_coeff2 = 0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode syntax (TEncSbac.cpp:613-726, TComDataCU.cpp:1334-1461); uniform control flow, bins on lane 0
+// ---------------------------------------------------------------------------------------------------
+DEV void get_mpm(const K &k, int x, int y, int preds[3], int *nmode)
+{ // getIntraDirPredictor TComDataCU.cpp:1362-1445
+  int left = DC, above = DC;
+  if (x > 0) left = part_attr(k, A_LDIR, (x >> 2) - 1, y >> 2);
+  if ((y & 63) != 0) above = part_attr(k, A_LDIR, x >> 2, (y >> 2) - 1);
+  if (left == above) {
+    if (nmode) *nmode = 1;
+    if (left > 1) { preds[0] = left; preds[1] = ((left + 29) % 32) + 2; preds[2] = ((left - 1) % 32) + 2; }
+    else { preds[0] = PLANAR; preds[1] = DC; preds[2] = VER; }
+  } else {
+    if (nmode) *nmode = 2;
+    preds[0] = left; preds[1] = above;
+    if (left && above) preds[2] = PLANAR; else preds[2] = (left + above) < 2 ? VER : DC;
+  }
+}
+DEV void code_luma_dirs(const K &k, Cabac *c, const Cu &cu, int first_pu, int npu)
+{ // codeIntraDirLumaAng TEncSbac.cpp:643-696
+  int idx[4];
+  const int pu_size = (cu.part == SIZE_NxN) ? (1 << (cu.log2 - 1)) : (1 << cu.log2);
+  for (int j = 0; j < npu; j++) {
+    const int pu = first_pu + j, px = cu.x + (pu & 1) * pu_size, py = cu.y + (pu >> 1) * pu_size;
+    const int dir = k.s->a[A_LDIR][cu.zbase + pu * (cu.nparts >> 2) * (cu.part == SIZE_NxN)];
+    int preds[3]; get_mpm(k, px, py, preds, nullptr);
+    idx[j] = -1;
+    for (int i = 0; i < 3; i++) if (dir == preds[i]) idx[j] = i;
+    if (k.lane == 0) enc_bin(c, CTX_INTRA_PRED, idx[j] != -1);
+  }
+  if (k.lane == 0) for (int j = 0; j < npu; j++) enc_ep(c, idx[j] != -1 ? (idx[j] ? 2 : 1) : 5);
+}
+DEV void code_chroma_dir(const K &k, Cabac *c, const Cu &cu)
+{ // codeIntraDirChroma TEncSbac.cpp:698-726
+  if (k.lane != 0) return;
+  if (k.s->a[A_CDIR][cu.zbase] == DM_CHROMA) enc_bin(c, CTX_CHROMA_PRED, 0);
+  else { enc_bin(c, CTX_CHROMA_PRED, 1); enc_ep(c, 2); }
+}
+DEV int split_ctx(const K &k, int x, int y, int depth)
+{ // getCtxSplitFlag TComDataCU.cpp:1447-1461
+  int ctx = 0;
+  if (x > 0) ctx += part_attr(k, A_DEPTH, (x >> 2) - 1, y >> 2) > depth;
+  if (y > 0) ctx += part_attr(k, A_DEPTH, x >> 2, (y >> 2) - 1) > depth;
+  return ctx;
+}
+DEV int min_tu_log2(const Cu &cu)
+{ // getQuadtreeTULog2MinSizeInCU TComDataCU.cpp:1478-1503 (TU log2 2..5, intra TU depth 3)
+  const int split = cu.part == SIZE_NxN; int r;
+  if (cu.log2 < 2 + 3 - 1 + split) r = 2; else { r = cu.log2 - (3 - 1 + split); if (r > 5) r = 5; }
+  return r;
+}
+DEV int tu_has_chroma_first(const Tu &tu) { return tu.log2 > 2 || (tu.zrel & 3) == 0; }
+DEV int tu_has_chroma_last(const Tu &tu) { return tu.log2 > 2 || (tu.zrel & 3) == 3; }
+DEV int tu_csize(const Tu &tu) { return tu.log2 > 2 ? 1 << (tu.log2 - 1) : 4; }
+DEV int tu_czrel(const Tu &tu) { return tu.log2 > 2 ? tu.zrel : (tu.zrel & ~3); }
+DEV int tu_cnparts(const Tu &tu) { return tu.log2 > 2 ? tu.nparts : 4; }
+DEV Tu tu_child(const Tu &p, int i)
+{
+  Tu ch; const int h = 1 << (p.log2 - 1);
+  ch.log2 = p.log2 - 1; ch.trd = p.trd + 1; ch.nparts = p.nparts >> 2;
+  ch.x = p.x + (i & 1) * h; ch.y = p.y + (i >> 1) * h; ch.zrel = p.zrel + i * ch.nparts;
+  return ch;
+}
+DEV int mode_of(const K &k, const Cu &cu, int c, int zrel)
+{ // TEncSearch.cpp:1178-1181
+  if (!c) return k.s->a[A_LDIR][cu.zbase + zrel];
+  const int m = k.s->a[A_CDIR][cu.zbase + zrel];
+  return m == DM_CHROMA ? k.s->a[A_LDIR][cu.zbase + (zrel & ~3)] : m;
+}
+DEV void code_qt_cbf(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int lowest)
+{ // codeQtCbf TEncSbac.cpp:920-995 + getCtxQtCbf TComDataCU.cpp:1463-1476
+  const int ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
+  const int w = comp ? tu_csize(tu) : (1 << tu.log2);
+  const int d = tu.trd + ((!lowest && !(w >= 8)) ? 1 : 0);
+  const int z = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
+  const int cbf = (k.s->a[A_CBF + comp][z] >> d) & 1;
+  if (k.lane == 0) enc_bin(c, CTX_QT_CBF + (comp ? 5 : 0) + ctx, cbf);
+}
+
+// coefficients of one TU -> s->lvl (lane-parallel), source = QT layer buffer or the CTU record
+DEV void load_tu_coef(const K &k, int real, int comp, int log2_luma, int zabs_comp, int n)
+{
+  const int off = comp ? (zabs_comp * 16) >> 2 : zabs_comp * 16;
+  const int16_t *src = real ? reinterpret_cast<const int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + comp_off(comp) + off
+                            : k.coef_l + (5 - log2_luma) * 6144 + comp_off(comp) + off;
+  wsync();
+  for (int i = k.lane; i < n * n; i += 64) k.s->lvl[i] = src[i];
+  wsync();
+}
+// bit-count one coded TU block (cbf already known to be set)
+DEV void code_tu_coeffs(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int real)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  const int zc = comp ? tu_czrel(tu) : tu.zrel;
+  const int n = comp ? tu_csize(tu) : (1 << tu.log2);
+  const int mode = mode_of(k, cu, comp, zc);
+  load_scan(k, coef_scan_idx(comp, n, mode), n);
+  load_tu_coef(k, real, comp, tu.log2, cu.zbase + zc, n);
+  if (k.lane == 0) code_coeff_lane0(k, c, comp, n, mode, k.s->a[A_TSKIP + comp][cu.zbase + zc]);
+  wsync();
+}
+
+template <int LOG2> DEV void enc_subdiv_cbf(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int luma, int chroma)
+{ // xEncSubdivCbfQT TEncSearch.cpp:907-972
+  const int subdiv = uni(k.s->a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd;
+  if (cu.part == SIZE_NxN && tu.trd == 0) { }
+  else if (LOG2 > 5) { }
+  else if (LOG2 == 2) { }
+  else if (LOG2 == min_tu_log2(cu)) { }
+  else if (luma && k.lane == 0) enc_bin(c, CTX_SUBDIV + 5 - LOG2, subdiv);
+  if (chroma) for (int comp = 1; comp < 3; comp++)
+    if (LOG2 > 2 && (tu.trd == 0 || ((k.s->a[A_CBF + comp][cu.zbase + tu.zrel] >> (tu.trd - 1)) & 1)))
+      code_qt_cbf(k, c, cu, tu, comp, !subdiv);
+  if (subdiv) { if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) enc_subdiv_cbf<LOG2 - 1>(k, c, cu, tu_child(tu, i), luma, chroma); }
+  else if (luma) code_qt_cbf(k, c, cu, tu, 0, 1);
+}
+template <int LOG2> DEV void enc_coeff_qt(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int real)
+{ // xEncCoeffQT TEncSearch.cpp:978-1012 (+ cbf test of TEncEntropy::encodeCoeffNxN :654-690)
+  if (uni(k.s->a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
+    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) enc_coeff_qt<LOG2 - 1>(k, c, cu, tu_child(tu, i), comp, real);
+    return;
+  }
+  if (comp && !tu_has_chroma_first(tu)) return;
+  if (!((uni(k.s->a[A_CBF + comp][cu.zbase + tu.zrel]) >> tu.trd) & 1)) return;
+  code_tu_coeffs(k, c, cu, tu, comp, real);
+}
+DEV void enc_intra_header(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int luma, int chroma)
+{ // xEncIntraHeader TEncSearch.cpp:1018-1087
+  if (luma) {
+    if (tu.zrel == 0 && cu.depth == 3 && k.lane == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
+    if (cu.part == SIZE_2Nx2N) { if (tu.zrel == 0) code_luma_dirs(k, c, cu, 0, 1); }
+    else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel % q) == 0) code_luma_dirs(k, c, cu, tu.zrel / q, 1); }
+  }
+  if (chroma && tu.zrel == 0) code_chroma_dir(k, c, cu);
+}
+template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu, const Tu &tu, int luma, int chroma)
+{
+  STAGE(k); if (STOPPED(k)) return 0; // xGetIntraBitsQT TEncSearch.cpp:1093-1117
+  Cabac *c = &k.s->go;
+  wsync();
+  if (k.lane == 0) reset_bits(c);
+  enc_intra_header(k, c, cu, tu, luma, chroma);
+  enc_subdiv_cbf<LOG2>(k, c, cu, tu, luma, chroma);
+  if (luma) enc_coeff_qt<LOG2>(k, c, cu, tu, 0, 0);
+  if (chroma) { enc_coeff_qt<LOG2>(k, c, cu, tu, 1, 0); enc_coeff_qt<LOG2>(k, c, cu, tu, 2, 0); }
+  wsync();
+  return uni((int)get_bits(c));
+}
+template <int LOG2> DEV void enc_transform(const K &k, Cabac *c, const Cu &cu, const Tu &tu)
+{ // TEncEntropy::xEncodeTransform TEncEntropy.cpp:200-398 (real coefficients; chroma of a 4x4 quad with its LAST block)
+  const int z = cu.zbase + tu.zrel;
+  const int subdiv = uni(k.s->a[A_TRIDX][z]) > tu.trd;
+  if (cu.part == SIZE_NxN && tu.trd == 0) { }
+  else if (LOG2 > 5) { }
+  else if (LOG2 == 2) { }
+  else if (LOG2 == min_tu_log2(cu)) { }
+  else if (k.lane == 0) enc_bin(c, CTX_SUBDIV + 5 - LOG2, subdiv);
+  const int first = tu.trd == 0;
+  for (int comp = 1; comp < 3; comp++)
+    if (first || LOG2 > 2)
+      if (first || ((k.s->a[A_CBF + comp][z] >> (tu.trd - 1)) & 1)) code_qt_cbf(k, c, cu, tu, comp, !subdiv);
+  if (subdiv) { if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) enc_transform<LOG2 - 1>(k, c, cu, tu_child(tu, i)); return; }
+  code_qt_cbf(k, c, cu, tu, 0, 1);
+  for (int comp = 0; comp < 3; comp++) {
+    if (comp && !tu_has_chroma_last(tu)) continue;
+    if (!((uni(k.s->a[A_CBF + comp][z]) >> tu.trd) & 1)) continue;
+    code_tu_coeffs(k, c, cu, tu, comp, 1);
+  }
+}
+DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu)
+{
+  STAGE(k); if (STOPPED(k)) return; // TEncCu.cpp:1636-1654 (RD) and xEncodeCU :1222-1270 (state-advancing encode); I-slice, no PCM/TQB/DQP
+  wsync();
+  if (cu.depth == 3 && k.lane == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
+  code_luma_dirs(k, c, cu, 0, cu.part == SIZE_NxN ? 4 : 1);
+  code_chroma_dir(k, c, cu);
+  const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
+  switch (cu.log2) {
+    case 6: enc_transform<6>(k, c, cu, root); break;
+    case 5: enc_transform<5>(k, c, cu, root); break;
+    case 4: enc_transform<4>(k, c, cu, root); break;
+    default: enc_transform<3>(k, c, cu, root); break;
+  }
+  wsync();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved)
+// ---------------------------------------------------------------------------------------------------
+DEVN void code_tu_block(const K &k, const Cu &cu, const Tu &tu, int comp, int mode012, uint32_t *dist)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  RdSmem &s = *k.s;
+  const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
+  const int zrel = comp ? tu_czrel(tu) : tu.zrel, zabs = cu.zbase + zrel;
+  const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y;
+  const int cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
+  const int mode = mode_of(k, cu, comp, zrel);
+  const int tskip = uni(s.a[A_TSKIP + comp][zabs]);
+  if (mode012 != 2) {
+    build_refs(k, comp, x, y, n);
+    if (use_filtered_refs(comp, mode, n)) filter_refs(k, n);
+    predict_block(k, comp, mode, n);
+    if (mode012 == 1 && k.lane < 16) s.ts_pred[comp][k.lane] = s.pred[k.lane];
+  } else { wsync(); if (k.lane < 16) s.pred[k.lane] = s.ts_pred[comp][k.lane]; }
+  wsync();
+  const uint8_t *org = k.org[comp] + (size_t)y * ps + x;
+  for (int i = k.lane; i < n * n; i += 64) s.resi[i] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
+  if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
+  wsync();
+  if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[i] << 5; wsync(); }
+  else fwd_transform(k, n, !comp && n == 4);
+  const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
+  if (k.dbg == -17) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
+  load_scan(k, coef_scan_idx(comp, n, mode), n);
+  if (k.dbg == -18) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
+  STAGE(k); if (STOPPED(k)) return;
+  { const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (k.lane == 0) s.bc_u32[0] = as_; }
+  STAGE(k); if (STOPPED(k)) return;
+  wsync();
+  const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
+  if (k.dbg == -30) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
+  set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
+  int16_t *cl = k.coef_l + (5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
+  if (abs_sum > 0) {
+    for (int i = k.lane; i < n * n; i += 64) cl[i] = s.lvl[i];
+    dequant(k, comp, n);
+    if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.resi[i] = (int16_t)((s.tc[i] + 16) >> 5); wsync(); }
+    else inv_transform(k, n, !comp && n == 4);
+  } else {
+    for (int i = k.lane; i < n * n; i += 64) { cl[i] = 0; s.resi[i] = 0; }
+    wsync();
+  }
+  if (k.dbg == -31) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
+  uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
+  uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  uint32_t d = 0;
+  for (int i = k.lane; i < n * n; i += 64) {
+    const int r = i >> log2n, cc = i & (n - 1);
+    const int v = clip8((int)s.pred[i] + (int)s.resi[i]);
+    s.pred[i] = (uint8_t)v; rq[r * cs + cc] = (uint8_t)v; rp[(size_t)r * ps + cc] = (uint8_t)v;
+    const int df = v - (int)org[(size_t)r * ps + cc];
+    d += (uint32_t)(df * df);
+  }
+  for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m);
+  if (k.dbg == -32) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
+  if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
+  *dist += d;
+  wsync();
+  if (k.dbg == -33) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
+}
+
+DEV void store_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
+{ // xStoreIntraResultQT TEncSearch.cpp:1784-1816 (4x4 blocks); s->lvl / s->pred still hold the block just coded
+  wsync();
+  if (k.lane < 16) { k.s->ts_coef[comp][k.lane] = ((uni((int)((k.s->a[A_CBF + comp][cu.zbase + (comp ? tu_czrel(tu) : tu.zrel)] >> tu.trd) & 1)) ? k.s->lvl[k.lane] : (int16_t)0)); k.s->ts_rec[comp][k.lane] = k.s->pred[k.lane]; }
+  wsync();
+}
+DEV void load_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
+{ // xLoadIntraResultQT TEncSearch.cpp:1819-1870
+  const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
+  const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
+  wsync();
+  if (k.lane < 16) {
+    k.coef_l[(5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16) + k.lane] = k.s->ts_coef[comp][k.lane];
+    const int r = k.lane >> 2, cc = k.lane & 3; const uint8_t v = k.s->ts_rec[comp][k.lane];
+    k.rec_l[(5 - tu.log2) * 6144 + comp_off(comp) + bo + r * cs + cc] = v;
+    k.rec[comp][(size_t)(y + r) * ps + x + cc] = v;
+  }
+  wsync();
+}
+
+// xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
+template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu, const Tu &tu, int check_first, uint32_t *dist_out, double *cost_out)
+{
+  if (STOPPED(k)) return;
+  RdSmem &s = *k.s;
+  const int full_depth = cu.depth + tu.trd, zabs = cu.zbase + tu.zrel;
+  const int check_full = LOG2 <= 5;
+  int check_split = LOG2 > min_tu_log2(cu);
+  if (check_first && check_full) check_split = 0;
+  double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
+  const int check_ts = (LOG2 == 2) && (cu.part == SIZE_NxN);
+  if (check_full) {
+    if (check_ts) {
+      cabac_copy(k, &s.root[full_depth], &s.go);
+      for (int m = 0; m < 2; m++) {
+        uint32_t d = 0; double cost;
+        set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, m); wsync();
+        code_tu_block(k, cu, tu, 0, m == 0 ? 1 : 2, &d);
+        const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
+        if (m == 1 && cbf == 0) cost = MAX_DOUBLE;
+        else {
+          if (m == 0) store_ts_result(k, cu, tu, 0);           // before the bit count reuses s->lvl
+          const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0); cost = calc_rd_cost(k, bits, d);
+        }
+        if (cost < single_cost) {
+          single_cost = cost; single_dist = d; single_cbf = cbf; best_ts = m;
+          if (m == 0) cabac_copy(k, &s.tbest[full_depth], &s.go);
+        }
+        if (m == 0) cabac_copy(k, &s.go, &s.root[full_depth]);
+      }
+      set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts); wsync();
+      if (best_ts == 0) {
+        load_ts_result(k, cu, tu, 0);
+        set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd)); wsync();
+        cabac_copy(k, &s.go, &s.tbest[full_depth]);
+      }
+    } else {
+      if (check_split) cabac_copy(k, &s.root[full_depth], &s.go);
+      set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, 0); wsync();
+      code_tu_block(k, cu, tu, 0, 0, &single_dist);
+      if (check_split) single_cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
+      const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
+      single_cost = calc_rd_cost(k, bits, single_dist);
+    }
+  }
+  if constexpr (LOG2 > 2) {
+    if (check_split) {
+      if (check_full) { cabac_copy(k, &s.test[full_depth], &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
+      else cabac_copy(k, &s.root[full_depth], &s.go);
+      double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
+      for (int i = 0; i < 4; i++) {
+        const Tu ch = tu_child(tu, i);
+        recur_luma<LOG2 - 1>(k, cu, ch, check_first, &split_dist, &split_cost);
+        split_cbf |= (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
+      }
+      if (split_cbf) { for (int i = k.lane; i < tu.nparts; i += 64) s.a[A_CBF][zabs + i] |= (uint8_t)(1 << tu.trd); }
+      cabac_copy(k, &s.go, &s.root[full_depth]);
+      const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
+      split_cost = calc_rd_cost(k, bits, split_dist);
+      if (split_cost < single_cost) { *dist_out += split_dist; *cost_out += split_cost; return; }
+      cabac_copy(k, &s.go, &s.test[full_depth]);
+      set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
+      set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
+      set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
+      const int n = 1 << LOG2, bo = boff(k, 0, tu.x, tu.y);
+      const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo;
+      uint8_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
+      wsync();
+      for (int i = k.lane; i < n * n; i += 64) rp[(size_t)(i >> LOG2) * k.W + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
+      wsync();
+    }
+  }
+  *dist_out += single_dist; *cost_out += single_cost;
+}
+
+// xSetIntraResultLumaQT / xSetIntraResultChromaQT TEncSearch.cpp:1741-1781, 2150-2198
+template <int LOG2> DEV void set_result(const K &k, const Cu &cu, const Tu &tu, int comp)
+{
+  if (uni(k.s->a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
+    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp);
+    return;
+  }
+  if (comp && !tu_has_chroma_first(tu)) return;
+  const int n = comp ? tu_csize(tu) : (1 << LOG2), log2n = ilog2(n);
+  const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
+  const int off = comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
+  int16_t *dstc = reinterpret_cast<int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + off;
+  const int16_t *srcc = k.coef_l + (5 - LOG2) * 6144 + off;
+  const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = comp_off(comp) + boff(k, comp, x, y);
+  const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; uint8_t *br = k.best_rec + bo;
+  for (int i = k.lane; i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
+}
+DEVN void set_result_cu(const K &k, const Cu &cu, const Tu &tu, int comp)
+{
+  if (STOPPED(k)) return;
+  wsync();
+  switch (tu.log2) {
+    case 6: set_result<6>(k, cu, tu, comp); break;
+    case 5: set_result<5>(k, cu, tu, comp); break;
+    case 4: set_result<4>(k, cu, tu, comp); break;
+    case 3: set_result<3>(k, cu, tu, comp); break;
+    default: set_result<2>(k, cu, tu, comp); break;
+  }
+  wsync();
+}
+DEV void recur_luma_any(const K &k, const Cu &cu, const Tu &tu, int check_first, uint32_t *d, double *c)
+{
+  switch (tu.log2) {
+    case 6: recur_luma<6>(k, cu, tu, check_first, d, c); break;
+    case 5: recur_luma<5>(k, cu, tu, check_first, d, c); break;
+    case 4: recur_luma<4>(k, cu, tu, check_first, d, c); break;
+    case 3: recur_luma<3>(k, cu, tu, check_first, d, c); break;
+    default: recur_luma<2>(k, cu, tu, check_first, d, c); break;
+  }
+}
+
+// rough mode decision for one PU: 35 predictions + SATD (TEncSearch.cpp:2266-2346).  One lane per
+// (mode, 8x8 block) task (4x4 blocks for a 4x4 PU): predict the block in registers, Hadamard, add into satd[mode].
+DEVN void rmd_satd(const K &k, int x, int y, int pn)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  RdSmem &s = *k.s;
+  const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
+  if (k.lane < 36) s.satd[k.lane] = 0;
+  int dcv[2];
+  dcv[0] = dc_value(k, s.line, pn); dcv[1] = 0;
+  wsync();
+  for (int t0 = 0; t0 < ntask; t0 += 64) {
+    const int t = t0 + k.lane;
+    if (t < ntask) {
+      const int mode = t / nblk, blk = t - mode * nblk, bx = (blk % nbx) * b, by = (blk / nbx) * b;
+      const int16_t *line = use_filtered_refs(0, mode, pn) ? s.fline : s.line;
+      const uint8_t *org = k.org[0] + (size_t)(y + by) * k.W + x + bx;
+      unsigned int sum = 0;
+      if (b == 8) {
+        int m[64];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          int d[8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) d[c] = (int)org[(size_t)r * k.W + c] - pred_pixel(line, 0, mode, pn, log2n, bx + c, by + r, dcv[0]);
+          // 8-point Hadamard butterflies (TComRdCost.cpp:1645-1750; |coefficients| are order independent)
+          int e[8];
+          e[0] = d[0] + d[4]; e[1] = d[1] + d[5]; e[2] = d[2] + d[6]; e[3] = d[3] + d[7]; e[4] = d[0] - d[4]; e[5] = d[1] - d[5]; e[6] = d[2] - d[6]; e[7] = d[3] - d[7];
+          d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
+          m[r * 8 + 0] = d[0] + d[1]; m[r * 8 + 1] = d[0] - d[1]; m[r * 8 + 2] = d[2] + d[3]; m[r * 8 + 3] = d[2] - d[3];
+          m[r * 8 + 4] = d[4] + d[5]; m[r * 8 + 5] = d[4] - d[5]; m[r * 8 + 6] = d[6] + d[7]; m[r * 8 + 7] = d[6] - d[7];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          int e[8], d[8];
+          e[0] = m[c] + m[32 + c]; e[1] = m[8 + c] + m[40 + c]; e[2] = m[16 + c] + m[48 + c]; e[3] = m[24 + c] + m[56 + c];
+          e[4] = m[c] - m[32 + c]; e[5] = m[8 + c] - m[40 + c]; e[6] = m[16 + c] - m[48 + c]; e[7] = m[24 + c] - m[56 + c];
+          d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
+          sum += (unsigned)(abs(d[0] + d[1]) + abs(d[0] - d[1]) + abs(d[2] + d[3]) + abs(d[2] - d[3]) + abs(d[4] + d[5]) + abs(d[4] - d[5]) + abs(d[6] + d[7]) + abs(d[6] - d[7]));
+        }
+        sum = (sum + 2) >> 2;
+      } else {
+        int m[16];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int d[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) d[c] = (int)org[(size_t)r * k.W + c] - pred_pixel(line, 0, mode, pn, log2n, bx + c, by + r, dcv[0]);
+          const int a0 = d[0] + d[3], a1 = d[1] + d[2], a2 = d[1] - d[2], a3 = d[0] - d[3];
+          m[r * 4] = a0 + a1; m[r * 4 + 1] = a0 - a1; m[r * 4 + 2] = a2 + a3; m[r * 4 + 3] = a3 - a2;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int a0 = m[c] + m[12 + c], a1 = m[4 + c] + m[8 + c], a2 = m[4 + c] - m[8 + c], a3 = m[c] - m[12 + c];
+          sum += (unsigned)(abs(a0 + a1) + abs(a0 - a1) + abs(a2 + a3) + abs(a3 - a2));
+        }
+        sum = (sum + 1) >> 1;
+      }
+      atomicAdd(&s.satd[mode], sum);
+    }
+  }
+  wsync();
+}
+
+// estIntraPredLumaQT TEncSearch.cpp:2203-2582
+DEVN void est_intra_luma(const K &k, const Cu &cu, uint32_t *cu_dist)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  RdSmem &s = *k.s;
+  const int init_trd = cu.part == SIZE_NxN ? 1 : 0, npu = init_trd ? 4 : 1;
+  const int pu_log2 = cu.log2 - init_trd, pn = 1 << pu_log2, pu_parts = cu.nparts >> (2 * init_trd);
+  uint32_t overall = 0;
+  for (int pu = 0; pu < npu; pu++) {
+    const int poff = pu * pu_parts, zp = cu.zbase + poff;
+    const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
+    // ---- rough mode decision ----
+    build_refs(k, 0, ptu.x, ptu.y, pn);
+    DBG(k, "  refs ok\n");
+    if (pn >= 8 && pn <= 32) filter_refs(k, pn);
+    rmd_satd(k, ptu.x, ptu.y, pn);
+    DBG(k, "  rmd ok satd0 %u\n", s.satd[0]);
+    int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
+    int nfull = c_num_rd_cand[pu_log2 - 2];
+    { // mode bits (xModeBitsIntra :5530-5557): 3 possible values, from the [depth][CI_CURR_BEST] snapshot
+      const Cabac *cur = &s.curr[cu.depth];
+      const unsigned long long f0 = cur->frac & 32767ull; const int st = cur->ctx[CTX_INTRA_PRED];
+      if (k.lane < 35) {
+        const int mode = k.lane;
+        int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
+        const unsigned long long fr = f0 + (unsigned long long)c_entropy_bits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
+        s.rmd_cost[mode] = (double)s.satd[mode] + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
+      }
+      wsync();
+      // xUpdateCandList :5562-5585 == stable sort by (cost, mode); keep the nfull best
+      if (k.lane < 35) {
+        const double mc = s.rmd_cost[k.lane]; int rank = 0;
+        for (int j = 0; j < 35; j++) { const double oc = s.rmd_cost[j]; rank += (oc < mc) || (oc == mc && j < k.lane); }
+        if (rank < nfull) s.rd_list[rank] = (unsigned)k.lane;
+      }
+      wsync();
+      if (k.lane == 0) {
+        int nf = nfull;
+        for (int j = 0; j < nm; j++) { int inc = 0; for (int i = 0; i < nf; i++) inc |= (preds[j] == (int)s.rd_list[i]); if (!inc) s.rd_list[nf++] = (unsigned)preds[j]; }
+        s.bc_u32[1] = (unsigned)nf;
+      }
+      wsync();
+      nfull = uni((int)s.bc_u32[1]);
+    }
+    // ---- RD pass 1 (:2355-2443) and pass 2 (:2445-2512) ----
+    uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
+    for (int m = 0; m <= nfull; m++) {
+      if (STOPPED(k)) break;
+      const int second = (m == nfull);
+      const uint32_t org_mode = second ? best_mode : (uint32_t)uni((int)s.rd_list[m]);
+      set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)org_mode);
+      cabac_copy(k, &s.go, &s.curr[cu.depth]);
+      uint32_t d = 0; double cost = 0.0;
+      DBG(k, "  cand %d mode %u\n", m, org_mode);
+      recur_luma_any(k, cu, ptu, !second, &d, &cost);
+      DBG(k, "   -> dist %u cost %f\n", d, cost);
+      if (cost < best_cost) {
+        best_mode = org_mode; best_dist = d; best_cost = cost;
+        set_result_cu(k, cu, ptu, 0);
+        for (int i = k.lane; i < pu_parts; i += 64) {
+          s.sv_tr[i] = s.a[A_TRIDX][zp + i];
+          for (int c = 0; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][zp + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][zp + i]; }
+        }
+        wsync();
+      }
+    }
+    overall += best_dist;
+    wsync();
+    for (int i = k.lane; i < pu_parts; i += 64) {
+      s.a[A_TRIDX][zp + i] = s.sv_tr[i];
+      for (int c = 0; c < 3; c++) { s.a[A_CBF + c][zp + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][zp + i] = s.sv_ts[c][i]; }
+    }
+    if (pu != npu - 1) {
+      uint8_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; const uint8_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
+      for (int i = k.lane; i < pn * pn; i += 64) rp[(size_t)(i >> pu_log2) * k.W + (i & (pn - 1))] = br[(i >> pu_log2) * 64 + (i & (pn - 1))];
+    }
+    set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)best_mode);
+    wsync();
+  }
+  if (npu > 1) {
+    int comb[3] = { 0, 0, 0 };
+    for (int p = 0; p < 4; p++) for (int c = 0; c < 3; c++) comb[c] |= (s.a[A_CBF + c][cu.zbase + p * pu_parts] >> 1) & 1;
+    wsync();
+    for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 0; c < 3; c++) s.a[A_CBF + c][cu.zbase + i] |= (uint8_t)comb[c];
+    wsync();
+  }
+  cabac_copy(k, &s.go, &s.curr[cu.depth]);
+  *cu_dist = overall;
+}
+
+// xRecurIntraChromaCodingQT TEncSearch.cpp:1941-2145
+template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu, const Tu &tu, uint32_t *dist_out)
+{
+  if (STOPPED(k)) return;
+  RdSmem &s = *k.s;
+  const int z = cu.zbase + tu.zrel;
+  if (uni(s.a[A_TRIDX][z]) == tu.trd) {
+    if (!tu_has_chroma_first(tu)) return;
+    const int full_depth = cu.depth + tu.trd;
+    int check_ts = (LOG2 == 2);
+    if (check_ts) { int nb = 0; for (int i = 0; i < 4; i++) nb += s.a[A_TSKIP + 0][z + i]; check_ts = uni(nb) > 0; }
+    const int zc = cu.zbase + tu_czrel(tu), np = tu_cnparts(tu);
+    for (int comp = 1; comp < 3; comp++) {
+      cabac_copy(k, &s.root[full_depth], &s.go);
+      double single_cost = MAX_DOUBLE, cost_tmp = 0; int best_id = 0, best_ts = 0; uint32_t single_dist = 0, single_cbf = 0;
+      const int total = check_ts ? 2 : 1; int cur_id = 0;
+      for (int ts = 0; ts < total; ts++) {
+        set_parts(k, s.a[A_TSKIP + comp], zc, np, ts); wsync();
+        cur_id++;
+        const int one = (total == 1), last = (cur_id == total);
+        const int m012 = one ? 0 : (ts == 0 ? 1 : 2);
+        uint32_t d = 0;
+        code_tu_block(k, cu, tu, comp, m012, &d);
+        const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF + comp][zc]) >> tu.trd) & 1;
+        if (!one && !last) store_ts_result(k, cu, tu, comp);   // before the bit count reuses s->lvl
+        if (ts == 1 && cbf == 0) cost_tmp = MAX_DOUBLE;
+        else if (!one) { // xGetIntraBitsQTChroma :1119-1127
+          wsync(); if (k.lane == 0) reset_bits(&s.go);
+          enc_coeff_qt<LOG2>(k, &s.go, cu, tu, comp, 0);
+          wsync(); cost_tmp = calc_rd_cost(k, (uint32_t)uni((int)get_bits(&s.go)), d);
+        }
+        if (cost_tmp < single_cost) {
+          single_cost = cost_tmp; single_dist = d; best_ts = ts; best_id = cur_id; single_cbf = cbf;
+          if (!one && !last) cabac_copy(k, &s.tbest[full_depth], &s.go);
+        }
+        if (!one && !last) cabac_copy(k, &s.go, &s.root[full_depth]);
+      }
+      if (best_id < total) {
+        load_ts_result(k, cu, tu, comp);
+        set_parts(k, s.a[A_CBF + comp], zc, np, (int)(single_cbf << tu.trd)); wsync();
+        cabac_copy(k, &s.go, &s.tbest[full_depth]);
+      }
+      set_parts(k, s.a[A_TSKIP + comp], zc, np, best_ts); wsync();
+      *dist_out += single_dist;
+    }
+  } else {
+    if constexpr (LOG2 > 2) {
+      uint32_t split_cbf[3] = { 0, 0, 0 };
+      for (int i = 0; i < 4; i++) {
+        const Tu ch = tu_child(tu, i);
+        recur_chroma<LOG2 - 1>(k, cu, ch, dist_out);
+        for (int comp = 1; comp < 3; comp++) split_cbf[comp] |= (uint32_t)(uni(s.a[A_CBF + comp][cu.zbase + ch.zrel]) >> ch.trd) & 1;
+      }
+      wsync();
+      for (int comp = 1; comp < 3; comp++) if (split_cbf[comp])
+        for (int i = k.lane; i < tu.nparts; i += 64) s.a[A_CBF + comp][z + i] |= (uint8_t)(1 << tu.trd);
+      wsync();
+    }
+  }
+}
+
+// estIntraPredChromaQT TEncSearch.cpp:2588-2737 (4:2:0: one chroma PU per CU)
+DEVN void est_intra_chroma(const K &k, const Cu &cu, uint32_t *cu_dist)
+{
+  STAGE(k); if (STOPPED(k)) return;
+  RdSmem &s = *k.s;
+  const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
+  uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+  const int luma_mode = uni(s.a[A_LDIR][cu.zbase]);
+  for (int i = 0; i < 4; i++) if ((int)mode_list[i] == luma_mode) { mode_list[i] = 34; break; }   // getAllowedChromaDir TComDataCU.cpp:1334-1353
+  uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
+  for (int m = 0; m < 5; m++) {
+    cabac_copy(k, &s.go, &s.curr[cu.depth]);
+    uint32_t d = 0;
+    set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)mode_list[m]); wsync();
+    uint32_t bits;
+    switch (cu.log2) {
+      case 6: recur_chroma<6>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<6>(k, cu, root, 0, 1); break;
+      case 5: recur_chroma<5>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<5>(k, cu, root, 0, 1); break;
+      case 4: recur_chroma<4>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<4>(k, cu, root, 0, 1); break;
+      default: recur_chroma<3>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<3>(k, cu, root, 0, 1); break;
+    }
+    const double cost = calc_rd_cost(k, bits, d);
+    if (cost < best_cost) {
+      best_cost = cost; best_dist = d; best_mode = mode_list[m];
+      set_result_cu(k, cu, root, 1); set_result_cu(k, cu, root, 2);
+      for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
+      wsync();
+    }
+  }
+  for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv_ts[c][i]; }
+  set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
+  *cu_dist += best_dist;
+  cabac_copy(k, &s.go, &s.curr[cu.depth]);
+}
+
+DEV void copy_best_rec_to_pic(const K &k, const Cu &cu, int comp)
+{
+  const int n = (1 << cu.log2) >> (comp ? 1 : 0), log2n = ilog2(n), x = cu.x >> (comp ? 1 : 0), y = cu.y >> (comp ? 1 : 0);
+  const int cs = cstride(comp), ps = pstride(k, comp);
+  const uint8_t *br = k.best_rec + comp_off(comp) + boff(k, comp, x, y);
+  uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  wsync();
+  for (int i = k.lane; i < n * n; i += 64) rp[(size_t)(i >> log2n) * ps + (i & (n - 1))] = br[(i >> log2n) * cs + (i & (n - 1))];
+  wsync();
+}
+
+// xCheckRDCostIntra TEncCu.cpp:1600-1665; the end state of the CU syntax is left in s->temp[depth]
+DEVN Rd check_rd_cost_intra(const K &k, Cu &cu, int part)
+{
+  if (STOPPED(k)) { Rd r0 = {1, 0, 0}; return r0; }
+  RdSmem &s = *k.s;
+  cu.part = part;
+  wsync();
+  for (int i = k.lane; i < cu.nparts; i += 64) { // initEstData TComDataCU.cpp:525-592 + part size / pred mode
+    const int z = cu.zbase + i;
+    s.a[A_DEPTH][z] = (uint8_t)cu.depth; s.a[A_PART][z] = (uint8_t)part; s.a[A_LDIR][z] = DC; s.a[A_CDIR][z] = 0; s.a[A_TRIDX][z] = 0;
+    for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
+  }
+  wsync();
+  uint32_t dist = 0;
+  if (k.dbg == -8) { Rd r0 = {1, 0, 0}; return r0; }
+  DBG(k, "cu %d %d log2 %d part %d luma\n", cu.x, cu.y, cu.log2, part);
+  est_intra_luma(k, cu, &dist);
+  DBG(k, " luma done dist %u\n", dist);
+  copy_best_rec_to_pic(k, cu, 0);
+  est_intra_chroma(k, cu, &dist);
+  DBG(k, " chroma done dist %u\n", dist);
+  wsync();
+  if (k.lane == 0) reset_bits(&s.go);
+  enc_cu_syntax(k, &s.go, cu);
+  cabac_copy(k, &s.temp[cu.depth], &s.go);
+  Rd r; r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
+  return r;
+}
+
+DEV void save_cand8(const K &k, const Cu &cu)
+{
+  RdSmem &s = *k.s;
+  const int16_t *rc = reinterpret_cast<const int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
+  wsync();
+  if (k.lane < 44) s.c8a[k.lane >> 2][k.lane & 3] = s.a[k.lane >> 2][cu.zbase + (k.lane & 3)];
+  for (int i = k.lane; i < 96; i += 64) {
+    const int c = i < 64 ? 0 : (i < 80 ? 1 : 2), j = i < 64 ? i : (i - 64) & 15;
+    s.c8coef[i] = rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j];
+    const int n = c ? 4 : 8, sx = c ? 32 : 64, bo = comp_off(c) + boff(k, c, cu.x >> (c ? 1 : 0), cu.y >> (c ? 1 : 0));
+    s.c8rec[i] = k.best_rec[bo + (j / n) * sx + (j % n)];
+  }
+  wsync();
+}
+DEV void load_cand8(const K &k, const Cu &cu)
+{
+  RdSmem &s = *k.s;
+  int16_t *rc = reinterpret_cast<int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
+  wsync();
+  if (k.lane < 44) s.a[k.lane >> 2][cu.zbase + (k.lane & 3)] = s.c8a[k.lane >> 2][k.lane & 3];
+  for (int i = k.lane; i < 96; i += 64) {
+    const int c = i < 64 ? 0 : (i < 80 ? 1 : 2), j = i < 64 ? i : (i - 64) & 15;
+    rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j] = s.c8coef[i];
+    const int n = c ? 4 : 8, sx = c ? 32 : 64, bo = comp_off(c) + boff(k, c, cu.x >> (c ? 1 : 0), cu.y >> (c ? 1 : 0));
+    k.best_rec[bo + (j / n) * sx + (j % n)] = s.c8rec[i];
+  }
+  wsync();
+}
+
+// xCompressCU TEncCu.cpp:470-1104 with the reference's label-pruning edits (:496-520, 815-834, 947-965)
+template <int DEPTH> DEVN Rd compress_cu(const K &k, int x, int y)
+{
+  RdSmem &s = *k.s;
+  const int log2 = 6 - DEPTH, size = 1 << log2;
+  Cu cu = { x, y, log2, DEPTH, (int)s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)], 256 >> (2 * DEPTH), SIZE_2Nx2N };
+  const int boundary = !(x + size <= k.W && y + size <= k.H);
+  const int pred_depth = k.labels[k.addr * 16 + 4 * ((y & 63) / 16) + (x & 63) / 16];
+  const int check_cur = pred_depth == DEPTH, check_next = pred_depth > DEPTH;
+  Rd best = { MAX_DOUBLE, 0, 0 };
+  if (k.dbg == -3 - DEPTH) { best.cost = 1; return best; }
+  int best_is_real = 0;
+  if (!boundary) {
+    if (check_cur) {
+      Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N);
+      if (t.cost < best.cost) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
+      if (DEPTH == 3) {
+        save_cand8(k, cu);
+        Rd t2 = check_rd_cost_intra(k, cu, SIZE_NxN);
+        if (t2.cost < best.cost) { best = t2; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+        else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
+      }
+    } else { best.cost = MAX_DOUBLE / 16; best.dist = 0xffffffffu >> 3; best.bits = 0xffffffffu >> 3; }
+    // split flag of the unsplit candidate (:858-867); for the dummy candidate the loaded state is stale and irrelevant
+    cabac_copy(k, &s.go, &s.next[DEPTH]);
+    const int sctx = (DEPTH < 3) ? split_ctx(k, x, y, DEPTH) : 0;
+    if (k.lane == 0) { reset_bits(&s.go); if (DEPTH < 3) enc_bin(&s.go, CTX_SPLIT + sctx, 0); }
+    wsync();
+    best.bits += (uint32_t)uni((int)get_bits(&s.go));
+    best.cost = calc_rd_cost(k, best.bits, best.dist);
+    cabac_copy(k, &s.next[DEPTH], &s.go);
+  }
+  if (best_is_real) for (int c = 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093
+  if constexpr (DEPTH < 3) {
+    Rd temp = { 0, 0, 0 };
+    const int h = size >> 1, qn = cu.nparts >> 2;
+    for (int i = 0; i < 4; i++) {
+      const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
+      if (sx < k.W && sy < k.H) {
+        cabac_copy(k, &s.curr[DEPTH + 1], (i == 0) ? &s.curr[DEPTH] : &s.next[DEPTH + 1]);
+        Rd sub;
+        if (check_next) sub = compress_cu<DEPTH + 1>(k, sx, sy);
+        else { sub.cost = MAX_DOUBLE / 16; sub.dist = 0xffffffffu >> 3; sub.bits = 0xffffffffu >> 3; }
+        temp.cost += sub.cost; temp.dist += sub.dist; temp.bits += sub.bits;
+      } else if (check_next || boundary) { // initSubCU defaults copied to the picture (:989)
+        const int z0 = cu.zbase + i * qn;
+        wsync();
+        for (int j = k.lane; j < qn; j += 64) {
+          s.a[A_DEPTH][z0 + j] = DEPTH + 1; s.a[A_PART][z0 + j] = SIZE_NONE; s.a[A_LDIR][z0 + j] = DC; s.a[A_CDIR][z0 + j] = 0; s.a[A_TRIDX][z0 + j] = 0;
+          for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z0 + j] = 0; s.a[A_TSKIP + c][z0 + j] = 0; }
+        }
+        wsync();
+      }
+    }
+    cabac_copy(k, &s.go, &s.next[DEPTH + 1]);
+    if (!boundary) {
+      const int sctx = split_ctx(k, x, y, DEPTH);
+      if (k.lane == 0) { reset_bits(&s.go); enc_bin(&s.go, CTX_SPLIT + sctx, 1); }
+      wsync();
+      temp.bits += (uint32_t)uni((int)get_bits(&s.go));
+    }
+    temp.cost = calc_rd_cost(k, temp.bits, temp.dist);
+    cabac_copy(k, &s.temp[DEPTH], &s.go);
+    if (temp.cost < best.cost) { best = temp; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+  }
+  return best;
+}
+
+// state-advancing encode of the decided CTU: encodeCtu/xEncodeCU TEncCu.cpp:290-304,1167-1271
+template <int DEPTH> DEVN void encode_cu_tree(const K &k, Cabac *c, int x, int y)
+{
+  RdSmem &s = *k.s;
+  const int size = 64 >> DEPTH;
+  const int z = s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)];
+  int boundary = 0;
+  const int dz = uni(s.a[A_DEPTH][z]);
+  if (x + size <= k.W && y + size <= k.H) {
+    if (DEPTH < 3) { const int sctx = split_ctx(k, x, y, DEPTH); if (k.lane == 0) enc_bin(c, CTX_SPLIT + sctx, dz > DEPTH); }
+  } else boundary = 1;
+  if constexpr (DEPTH < 3) {
+    if (DEPTH < dz || boundary) {
+      const int h = size >> 1;
+      for (int i = 0; i < 4; i++) { const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h; if (sx < k.W && sy < k.H) encode_cu_tree<DEPTH + 1>(k, c, sx, sy); }
+      return;
+    }
+  }
+  const Cu cu = { x, y, 6 - DEPTH, DEPTH, z, 256 >> (2 * DEPTH), uni(s.a[A_PART][z]) };
+  enc_cu_syntax(k, c, cu);
+}
+
+} // namespace
+
+extern "C" __global__ __launch_bounds__(64)
+void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RdSmem &s = *reinterpret_cast<RdSmem *>(smem_raw);
+  const int frame = blockIdx.x;
+  if (frame >= p.n_frames) return;
+  K k;
+  k.s = &s; k.lane = threadIdx.x;
+  k.W = p.width; k.H = p.height; k.cw = p.width >> 1; k.ctus_x = p.ctus_x; k.nctu = p.ctus_x * p.ctus_y;
+  const size_t ysz = (size_t)p.width * p.height, csz = ysz >> 2, fsz = ysz + 2 * csz;
+  k.org[0] = p.yuv + (size_t)frame * fsz; k.org[1] = k.org[0] + ysz; k.org[2] = k.org[1] + csz;
+  k.rec[0] = p.recon + (size_t)frame * fsz; k.rec[1] = k.rec[0] + ysz; k.rec[2] = k.rec[1] + csz;
+  k.records = p.records + (size_t)frame * k.nctu * REC_SIZE;
+  k.labels = p.labels + (size_t)frame * k.nctu * 16;
+  unsigned char *scr = p.scratch + (size_t)frame * p.scratch_per_frame;
+  k.coef_l = reinterpret_cast<int16_t *>(scr); k.rec_l = scr + 4 * 6144 * 2; k.best_rec = k.rec_l + 4 * 6144;
+  k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
+  for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
+  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug;
+  DBG(k, "rd kernel start frame %d smem %d\n", frame, (int)sizeof(RdSmem));
+
+  // tables into LDS: z-scan map, 32-point DCT matrix
+  for (int r = k.lane; r < 256; r += 64) {
+    const int x = r & 15, y = r >> 4; int z = 0;
+    for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+    s.r2z[r] = (uint8_t)z;
+  }
+  for (int i = k.lane; i < 1024; i += 64) {
+    const int kk = i >> 5, n = i & 31; int m = ((2 * n + 1) * kk) & 127;
+    if (m > 64) m = 128 - m;
+    s.dct[i] = (int16_t)(m <= 32 ? c_dct_mag[m] : -c_dct_mag[64 - m]);
+  }
+  if (k.lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; s.stop = 0; s.stage = 0; }
+  wsync();
+  if (k.dbg == 2) return;
+  // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719
+  Cabac *truec = &s.truec;
+  for (int i = k.lane; i < NUM_CTX; i += 64) {
+    const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
+    int st = ((slope * k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+    const int mps = st >= 64;
+    truec->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
+  }
+  if (k.lane == 0) truec->frac = 0;
+  wsync();
+  if (k.dbg == -1) return;
+
+  for (int a = 0; a < k.nctu; a++) {
+    k.addr = a; k.cx = a % k.ctus_x; k.cy = a / k.ctus_x;
+    // initCtu TComDataCU.cpp:420-500
+    for (int i = k.lane; i < 256; i += 64) {
+      for (int f = 0; f < 11; f++) s.a[f][i] = 0;
+      s.a[A_PART][i] = SIZE_NONE; s.a[A_LDIR][i] = DC;
+    }
+    { // coefficient arrays of the record start at zero (initCtu memset)
+      uint32_t *rc = reinterpret_cast<uint32_t *>(k.records + (size_t)a * REC_SIZE + REC_COEF);
+      for (int i = k.lane; i < 6144 / 2; i += 64) rc[i] = 0;
+    }
+    cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
+    cabac_copy(k, &s.go, truec);
+    if (k.dbg == -2) return;
+    DBG(k, "ctu %d compress\n", a);
+    const Rd best = compress_cu<0>(k, k.cx * 64, k.cy * 64);
+    DBG(k, "ctu %d encode\n", a);
+    // the state-advancing encode (TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
+    wsync();
+    if (k.lane == 0) reset_bits(truec);
+    encode_cu_tree<0>(k, truec, k.cx * 64, k.cy * 64);
+    wsync();
+    if (k.lane == 0) { if (a != k.nctu - 1) truec->frac += (unsigned long long)c_entropy_bits[126]; s.est_bits += truec->frac >> 15; }
+    // flush the CTU record
+    unsigned char *rec = k.records + (size_t)a * REC_SIZE;
+    for (int i = k.lane; i < 11 * 256 / 4; i += 64) reinterpret_cast<uint32_t *>(rec)[i] = reinterpret_cast<const uint32_t *>(&s.a[0][0])[i];
+    if (k.lane == 0) {
+      *reinterpret_cast<uint32_t *>(rec + REC_BITS) = best.bits; *reinterpret_cast<uint32_t *>(rec + REC_DIST) = best.dist;
+      *reinterpret_cast<double *>(rec + REC_COST) = best.cost;
+    }
+    wsync();
+  }
+  if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits
+    hevcdl_frame_stats *st = reinterpret_cast<hevcdl_frame_stats *>(p.stats) + frame;
+    for (int c = 0; c < 3; c++) {
+      const size_t npx = c ? csz : ysz; unsigned long long acc = 0;
+      for (size_t i = k.lane; i < npx; i += 64) { const int d = (int)k.org[c][i] - (int)k.rec[c][i]; acc += (unsigned long long)(d * d); }
+      for (int m = 32; m >= 1; m >>= 1) { unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32); lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m); acc += ((unsigned long long)hi << 32) | lo; }
+      if (k.lane == 0) st->sse[c] = acc;
+    }
+    if (k.lane == 0) { st->est_bits = s.est_bits; st->ctus = (uint32_t)k.nctu; st->pad = 0; }
+  }
+}
+
+extern "C" size_t hevcdl_rd_smem_bytes(void) { return sizeof(RdSmem); }
+extern "C" size_t hevcdl_rd_scratch_bytes(void) { return 4 * 6144 * 2 + 4 * 6144 + 6144 + 1024; }

@@ -1,0 +1,139 @@
+/* include/hevcdl.h -- C ABI of the MI355X-native all-intra CU-partition hot path.
+ *
+ * Drop-in boundary: the reference's
+ *     Void TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)
+ *       HM_dl/source/Lib/TLibEncoder/TEncCu.h:120, TEncCu.cpp:234, single call site TEncSlice.cpp:879
+ * together with the label producer it busy-waits for (use_model.py / gen_frames.py, file IPC at
+ * TEncCu.cpp:244-253).  The reference walks CTUs one at a time on one CPU thread; CTUs of one slice
+ * are strictly serial (reconstructed neighbours + adaptive CABAC state), frames of an all-intra
+ * sequence are independent, so the GPU entry points are per BATCH OF FRAMES.  Everything crossing this
+ * boundary is plain pointers and sizes; no torch / C++ types.
+ *
+ * Threading: one hevcdl_ctx per device; a ctx is not thread-safe; different ctxs are independent.
+ * Ownership: the caller owns every buffer it passes; the library owns only its internal workspace.
+ * Errors: every function returns a status code; nothing aborts or waits forever (the reference hangs at
+ * TEncCu.cpp:245 when the label file never appears).
+ */
+#ifndef HEVCDL_H
+#define HEVCDL_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  HEVCDL_OK = 0,
+  HEVCDL_ERR_INVALID_ARG = 1,
+  HEVCDL_ERR_UNSUPPORTED = 2,   /* a cfg key that would change the path and is not implemented */
+  HEVCDL_ERR_NO_DEVICE = 3,
+  HEVCDL_ERR_HIP = 4,
+  HEVCDL_ERR_OOM = 5
+} hevcdl_status;
+
+/* tool flags (reference cfg: encoder_intra_main.cfg:37-38,53-54 + TAppEncCfg.cpp defaults :978,950,1007) */
+#define HEVCDL_TOOL_RDOQ            (1u << 0)
+#define HEVCDL_TOOL_RDOQTS          (1u << 1)
+#define HEVCDL_TOOL_TSKIP           (1u << 2)
+#define HEVCDL_TOOL_TSKIP_FAST      (1u << 3)
+#define HEVCDL_TOOL_SIGN_HIDE       (1u << 4)
+#define HEVCDL_TOOL_STRONG_INTRA    (1u << 5)
+#define HEVCDL_TOOL_FAST_UDI_MPM    (1u << 6)
+#define HEVCDL_TOOLS_REFERENCE      0x7fu
+
+#define HEVCDL_CNN_INPUT_RGB601 0   /* BT.601 limited-range YUV -> RGB, nearest chroma (defined by this project) */
+#define HEVCDL_CNN_INPUT_LUMA   1   /* R = G = B = Y */
+#define HEVCDL_BN_REFERENCE     0   /* training-mode BatchNorm, as use_model.py:61-63 runs it */
+#define HEVCDL_BOUNDARY_CLAMP   0   /* clamp labels to the picture */
+
+#define HEVCDL_WEIGHT_FLOATS 637712 /* state_dict order of rec/hevc_encoder_model.pt, fp32 tensors only */
+
+typedef struct hevcdl_config {
+  uint32_t struct_size;          /* sizeof(hevcdl_config) */
+  int32_t  width, height;        /* luma samples, multiples of 8 (min CU) */
+  int32_t  bit_depth;            /* 8 */
+  int32_t  chroma_format;        /* 420 */
+  int32_t  qp;                   /* slice QP, 0..51 */
+  int32_t  ctu_size;             /* 64   (MaxCUWidth/Height)          */
+  int32_t  max_partition_depth;  /* 4    (MaxPartitionDepth)          */
+  int32_t  tu_log2_min, tu_log2_max, tu_max_depth_intra;   /* 2, 5, 3 */
+  uint32_t tools;                /* HEVCDL_TOOL_* ; must equal HEVCDL_TOOLS_REFERENCE for now */
+  int32_t  bn_mode, boundary_policy, cnn_input;
+  int32_t  device;               /* HIP device ordinal */
+  int32_t  max_frames;           /* frames per call the workspace is sized for */
+  /* decision constants computed ON THE HOST in IEEE double exactly as the reference does
+   * (TEncSlice.cpp:112-140,433-527; TComTrQuant.cpp:3096-3126,2532-2535) and passed as bits: */
+  double   lambda, sqrt_lambda, chroma_weight, lambda_chroma;
+  double   err_scale[2][4];      /* [luma/chroma][log2(TU)-2] */
+  int64_t  sbh_rd_factor[2];     /* [luma/chroma] */
+  int32_t  qp_chroma;
+  int32_t  reserved;
+} hevcdl_config;
+
+/* One CTU of decisions: what compressCtu leaves in the picture's CTU record (TEncCu.cpp:1091 copyToPic).
+ * 256 entries = 4x4 luma partitions in z-scan order (TComRom.cpp:284-352).  Coefficients use the
+ * reference's TComDataCU::m_pcTrCoeff layout: the TU whose first partition is p starts at 16*p (luma)
+ * or 4*p (chroma) and is stored row-major with its own width as stride. */
+typedef struct hevcdl_ctu_record {
+  uint8_t  depth[256], part_size[256], luma_dir[256], chroma_dir[256], tr_idx[256];
+  uint8_t  cbf[3][256], tskip[3][256];
+  uint32_t bits, dist;           /* pCtu->getTotalBits() / getTotalDistortion() (TEncSlice.cpp:959-961) */
+  double   cost;                 /* pCtu->getTotalCost() */
+  int16_t  coeff_y[4096], coeff_cb[1024], coeff_cr[1024];
+} hevcdl_ctu_record;             /* 15120 bytes */
+
+typedef struct hevcdl_frame_stats {
+  uint64_t sse[3];               /* reconstruction SSE per plane before in-loop filters */
+  uint64_t est_bits;             /* CABAC-estimated bits of the state-advancing encode (TEncSlice.cpp:886-893) */
+  uint32_t ctus, pad;
+} hevcdl_frame_stats;
+
+typedef struct hevcdl_profile {
+  double   cnn_ms, rd_ms;        /* accumulated kernel time measured with HIP events on the launch stream */
+  uint32_t cnn_launches, rd_launches;
+} hevcdl_profile;
+
+typedef struct hevcdl_ctx hevcdl_ctx;
+
+/* Fill cfg from (width, height, qp) with the reference configuration (encoder_intra_main.cfg) and the
+ * host-computed lambda family.  Replaces TEncSlice::setUpLambda / calculateLambda for this path. */
+hevcdl_status hevcdl_config_default(hevcdl_config *cfg, int width, int height, int qp);
+
+/* weights: flat fp32 blob, HEVCDL_WEIGHT_FLOATS values (replaces torch.load at use_model.py:62). */
+hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *weights, size_t n_floats, hevcdl_ctx **out);
+void          hevcdl_destroy(hevcdl_ctx *ctx);
+const char   *hevcdl_last_error(const hevcdl_ctx *ctx);
+
+/* ---- host-buffer entry points (copy in, run, copy out) ------------------------------------- */
+/* Replaces gen_frames.py + use_model.py: planar 8-bit 4:2:0 frames -> labels[n_frames][ctus][16]
+ * (clamped to the picture); logits_opt[n_frames][ctus][4][16] may be NULL. */
+hevcdl_status hevcdl_predict_depth(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, uint8_t *labels, float *logits_opt);
+/* Fixture entry: n_ctus RGB CTUs [n][64][64][3] (the tensor the reference feeds ConvNet2) -> raw labels
+ * (use_model.py:101-119, no clamping) and logits[n][4][16]. */
+hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t *ctu_rgb, int n_ctus, uint8_t *labels, float *logits_opt);
+/* Replaces the compressCtu loop of TEncSlice::compressSlice for n_frames independent frames.
+ * labels_opt == NULL -> labels come from the on-device CNN.  recon_opt / stats_opt may be NULL. */
+hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,
+                                     hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt);
+
+/* ---- device-buffer entry points (inputs/outputs already resident in HBM, asynchronous on `stream`) ---- */
+/* All pointers are device pointers; stream is a hipStream_t (NULL = default stream). */
+hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream);
+hevcdl_status hevcdl_compress_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels,
+                                         void *d_records, void *d_recon, void *d_stats, void *stream);
+/* CNN + RD search back to back: the whole hot path for one batch of frames. */
+hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels,
+                                       void *d_records, void *d_recon, void *d_stats, void *stream);
+
+/* kernel timing with HIP events recorded on the launch stream */
+hevcdl_status hevcdl_profile_enable(hevcdl_ctx *ctx, int enable);
+hevcdl_status hevcdl_profile_get(hevcdl_ctx *ctx, hevcdl_profile *out);   /* synchronises, returns and resets */
+
+/* sizes */
+int      hevcdl_ctus_per_frame(int width, int height);
+size_t   hevcdl_frame_bytes(int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
