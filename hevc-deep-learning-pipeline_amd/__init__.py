@@ -64,6 +64,7 @@ def build_ext(force=False, verbose=False):
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-unused-value",
+           "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + srcs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -184,10 +184,17 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   p.k.sbh_rd_factor[0] = ctx->cfg.sbh_rd_factor[0]; p.k.sbh_rd_factor[1] = ctx->cfg.sbh_rd_factor[1];
   p.k.qp = ctx->cfg.qp; p.k.qp_chroma = ctx->cfg.qp_chroma;
   p.debug = getenv("HEVCDL_DEBUG") ? atoi(getenv("HEVCDL_DEBUG")) : 0;
+  unsigned int *d_dbg = nullptr;
+  if (getenv("HEVCDL_DBGBUF")) { hipMalloc(&d_dbg, 8004 * 4); hipMemset(d_dbg, 0, 8004 * 4); p.dbgbuf = d_dbg; }
   prof_begin(ctx, ctx->ev_rd, s);
   hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames), dim3(64), hevcdl_rd_smem_bytes(), s, p);
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
+  if (d_dbg) {
+    std::vector<unsigned int> hb(8004); hipDeviceSynchronize(); hipMemcpy(hb.data(), d_dbg, 8004 * 4, hipMemcpyDeviceToHost);
+    for (unsigned i = 0; i < hb[0] && i < 4000; i++) printf("DBGV %u %u\n", hb[1 + 2 * i], hb[2 + 2 * i]);
+    fflush(stdout); hipFree(d_dbg);
+  }
   return HEVCDL_OK;
 }
 

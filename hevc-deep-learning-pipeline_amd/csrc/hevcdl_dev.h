@@ -42,6 +42,7 @@ struct hevcdl_rd_params {
   unsigned char *stats;            // [frame] hevcdl_frame_stats or NULL
   unsigned char *scratch;          // [frame] per-frame workspace
   size_t scratch_per_frame;
+  unsigned int *dbgbuf;
   int width, height, ctus_x, ctus_y, n_frames, debug;
   hevcdl_rd_consts k;
 };

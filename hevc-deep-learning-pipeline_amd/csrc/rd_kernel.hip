@@ -83,6 +83,8 @@ struct __attribute__((aligned(8))) Cabac { uint8_t ctx[160]; unsigned long long 
 struct Rd { double cost; uint32_t bits, dist; };
 struct Cu { int x, y, log2, depth, zbase, nparts, part; };
 struct Tu { int x, y, log2, trd, zrel, nparts; };
+DEV int uni(int v);
+
 
 struct RdSmem {
   Cabac go, curr[5], next[5], temp[5], root[5], test[5], tbest[5], truec;
@@ -109,7 +111,6 @@ struct RdSmem {
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
   uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];
-  int stop, stage;
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
   int last_bits[2][12];   // saved 2Nx2N candidate of an 8x8 CU
@@ -131,13 +132,16 @@ struct K {                             // wave-uniform kernel context
   long long sbh[2];
   int qp, qp_c;
   int dbg;
+  unsigned int *dbgbuf;
 };
-#define STAGE(k) do { wsync(); if ((k).lane == 0) { (k).s->stage++; if ((k).dbg > 1 && (k).s->stage >= (k).dbg) (k).s->stop = 1; } wsync(); } while (0)
-#define STOPPED(k) (((k).dbg > 1 || (k).dbg <= -17) && (k).s->stop)
-#define DBG(k, ...) do { if ((k).dbg && (k).lane == 0) printf(__VA_ARGS__); } while (0)
 
 DEV void wsync() { __syncthreads(); }
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Every lane of the wave follows the same control path by construction; the values that steer it are copied to
+// SGPRs (readfirstlane) so that branches enclosing barriers / calls are scalar branches, not EXEC-masked regions.
+DEV bool ub(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+DEV Cu ucu(const Cu &c) { Cu r = { uni(c.x), uni(c.y), uni(c.log2), uni(c.depth), uni(c.zbase), uni(c.nparts), uni(c.part) }; return r; }
+DEV Tu utu(const Tu &t) { Tu r = { uni(t.x), uni(t.y), uni(t.log2), uni(t.trd), uni(t.zrel), uni(t.nparts) }; return r; }
 DEV int comp_off(int c) { return c == 0 ? 0 : (c == 1 ? 4096 : 5120); }
 DEV int cstride(int c) { return c ? 32 : 64; }
 DEV int pstride(const K &k, int c) { return c ? k.cw : k.W; }
@@ -168,7 +172,13 @@ DEV void cabac_copy(const K &k, Cabac *dst, const Cabac *src)
   if (k.lane < 21) reinterpret_cast<unsigned long long *>(dst)[k.lane] = reinterpret_cast<const unsigned long long *>(src)[k.lane];
   wsync();
 }
-DEV double calc_rd_cost(const K &k, uint32_t bits, uint32_t dist) { return (double)dist + ((double)bits * k.lambda); }   // TComRdCost.cpp:62-107
+DEV double calc_rd_cost(const K &k, uint32_t bits, uint32_t dist)
+{ // TComRdCost.cpp:62-107
+#ifdef HEVCDL_KERNEL_DEBUG
+  if (k.dbgbuf && k.lane == 0) { unsigned int n_ = k.dbgbuf[0]; if (n_ < 100000) { k.dbgbuf[1 + 2 * n_] = bits; k.dbgbuf[2 + 2 * n_] = dist; k.dbgbuf[0] = n_ + 1; } }
+#endif
+  return (double)dist + ((double)bits * k.lambda);
+}
 
 DEV void set_parts(const K &k, uint8_t *a, int z0, int n, int v)
 {
@@ -194,9 +204,9 @@ DEV int unit_avail(const K &k, int x4, int y4, int cur_x4, int cur_y4)
   return k.s->r2z[((y4 & 15) << 4) | (x4 & 15)] < k.s->r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
 }
 
-DEVN void build_refs(const K &k, int c, int x, int y, int n)
+DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const int c = uni(c_), x = uni(x_), y = uni(y_), n = uni(n_);
   const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n / u;
   const int x4 = x >> sh, y4 = y >> sh, total = 4 * nu + 1;
   // availability of the <= 65 units: lanes 0..63 + unit 64 (only for a 64x64 luma block) on lane 0's second pass
@@ -238,9 +248,9 @@ DEVN void build_refs(const K &k, int c, int x, int y, int n)
   wsync();
 }
 
-DEVN void filter_refs(const K &k, int n)
+DEVN void filter_refs(const K &k, int n_)
 {
-  STAGE(k); if (STOPPED(k)) return; // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
+  const int n = uni(n_); // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
   const int16_t *src = k.s->line; int16_t *dst = k.s->fline;
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
@@ -314,9 +324,9 @@ DEV int dc_value(const K &k, const int16_t *line, int n)
 }
 
 // prediction of an n x n TU (n <= 32) into s->pred (stride n)
-DEVN void predict_block(const K &k, int c, int mode, int n)
+DEVN void predict_block(const K &k, int c_, int mode_, int n_)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const int c = uni(c_), mode = uni(mode_), n = uni(n_);
   const int16_t *line = use_filtered_refs(c, mode, n) ? k.s->fline : k.s->line;
   const int log2n = ilog2(n);
   const int dcv = (mode == DC) ? dc_value(k, line, n) : 0;
@@ -331,9 +341,9 @@ DEV int tmat(const K &k, int use_dst, int log2n, int kk, int i)
 {
   return use_dst ? (int)c_dst4[kk * 4 + i] : (int)k.s->dct[(kk << (5 - log2n)) * 32 + i];
 }
-DEVN void fwd_transform(const K &k, int n, int use_dst)
+DEVN void fwd_transform(const K &k, int n_, int use_dst_)
 {
-  STAGE(k); if (STOPPED(k)) return; // s->resi (stride n) -> s->tc
+  const int n = uni(n_), use_dst = uni(use_dst_); // s->resi (stride n) -> s->tc
   const int log2n = ilog2(n), s1 = log2n + 8 - 9, s2 = log2n + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
   for (int o = k.lane; o < n * n; o += 64) {
@@ -351,9 +361,9 @@ DEVN void fwd_transform(const K &k, int n, int use_dst)
   }
   wsync();
 }
-DEVN void inv_transform(const K &k, int n, int use_dst)
+DEVN void inv_transform(const K &k, int n_, int use_dst_)
 {
-  STAGE(k); if (STOPPED(k)) return; // s->tc (dequantised) -> s->resi
+  const int n = uni(n_), use_dst = uni(use_dst_); // s->tc (dequantised) -> s->resi
   const int log2n = ilog2(n);
   for (int o = k.lane; o < n * n; o += 64) {
     const int j = o >> log2n, x = o & (n - 1);
@@ -400,9 +410,9 @@ DEV void scan_next(int type, int bw, int bh, int &line, int &col)
 }
 // fill s->scan / s->scan_cg for (scan type, n): the CG order is generated by lane 0 (<= 64 steps), the 16 positions
 // inside each CG by one lane per CG
-DEVN void load_scan(const K &k, int scan_type, int n)
+DEVN void load_scan(const K &k, int scan_type_, int n_)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const int scan_type = uni(scan_type_), n = uni(n_);
   const int wg = n >> 2, ng = wg * wg;
   wsync();
   if (k.lane == 0) { int l = 0, c = 0; for (int g = 0; g < ng; g++) { k.s->scan_cg[g] = (uint8_t)(l * wg + c); scan_next(scan_type, wg, wg, l, c); } }
@@ -473,9 +483,9 @@ DEV int ic_rate(const Cabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, 
   return rate;
 }
 
-DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mode, int cbf_ctx)
-{ // s->tc -> s->lvl ; returns uiAbsSum
-  if (k.dbg == -19) return 0;
+DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
+{
+  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_); // s->tc -> s->lvl ; returns uiAbsSum
   RdSmem &s = *k.s;
   const int ch = c ? 1 : 0, log2n = ilog2(n);
   const int qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
@@ -490,11 +500,8 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mod
   double *cost_coeff = s.u.q.cost_coeff, *cost_sig = s.u.q.cost_sig;
   int32_t *rate_inc_up = s.u.q.rate_up, *rate_inc_down = s.u.q.rate_down, *sig_rate_delta = s.u.q.sig_delta, *delta_u = s.u.q.delta_u;
   double *cost_cg_sig = s.cg_cost; uint8_t *cgf = s.cgf;
-  if (k.dbg == -196) return 0;
   for (int i = 0; i < ncoef; i++) { cost_coeff[i] = 0; cost_sig[i] = 0; rate_inc_up[i] = 0; rate_inc_down[i] = 0; sig_rate_delta[i] = 0; delta_u[i] = 0; }
-  if (k.dbg == -197) return 0;
   for (int i = 0; i < 64; i++) { cost_cg_sig[i] = 0; cgf[i] = 0; }
-  if (k.dbg == -20) return 0;
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
   auto level_double = [&](int blk) -> int32_t {
     const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
@@ -593,7 +600,6 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mod
       } else cgf[cgblk] = 1;
     }
   }
-  if (k.dbg == -21) return 0;
   if (last_pos < 0) return 0;
   double best_cost;
   {
@@ -612,7 +618,6 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mod
     }
     last_x_bits[kk] = accx; last_y_bits[kk] = accy;
   }
-  if (k.dbg == -22) return 0;
   int best_last_p1 = 0, found_last = 0;
   for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
     const int cgblk = s.scan_cg[cgpos];
@@ -637,7 +642,6 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mod
       } else base_cost -= cost_sig[sp];
     }
   }
-  if (k.dbg == -23) return 0;
   uint32_t abs_sum = 0;
   for (int sp = 0; sp < best_last_p1; sp++) {
     const int blk = scan[sp]; const int lv = dst[blk];
@@ -645,7 +649,6 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mod
     dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv);
   }
   for (int sp = best_last_p1; sp <= last_pos; sp++) dst[scan[sp]] = 0;
-  if (k.dbg == -24) return abs_sum;
   if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660
     const long long rd_factor = k.sbh[ch];
     int last_cg = -1;
@@ -684,9 +687,9 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c, int n, int dir_mod
   return abs_sum;
 }
 
-DEVN void dequant(const K &k, int c, int n)
+DEVN void dequant(const K &k, int c_, int n_)
 {
-  STAGE(k); if (STOPPED(k)) return; // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
+  const int c = uni(c_), n = uni(n_); // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
   const int log2n = ilog2(n), qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
   const int tshift = 15 - 8 - log2n, rshift = 6 - (tshift + per), scale = c_inv_quant_scales[rem];
   for (int i = k.lane; i < n * n; i += 64) {
@@ -724,8 +727,9 @@ DEV void code_coef_remain(Cabac *c, uint32_t symbol, int rparam)
     enc_ep(c, (int)(3 + len + 1 - rparam)); enc_ep(c, (int)len);
   }
 }
-DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp, int n, int dir_mode, int tskip_flag)
+DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_)
 {
+  const int comp = uni(comp_), n = uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_);
   RdSmem &s = *k.s;
   const int ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
@@ -880,10 +884,9 @@ DEV void load_tu_coef(const K &k, int real, int comp, int log2_luma, int zabs_co
 // bit-count one coded TU block (cbf already known to be set)
 DEV void code_tu_coeffs(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int real)
 {
-  STAGE(k); if (STOPPED(k)) return;
   const int zc = comp ? tu_czrel(tu) : tu.zrel;
   const int n = comp ? tu_csize(tu) : (1 << tu.log2);
-  const int mode = mode_of(k, cu, comp, zc);
+  const int mode = uni(mode_of(k, cu, comp, zc));
   load_scan(k, coef_scan_idx(comp, n, mode), n);
   load_tu_coef(k, real, comp, tu.log2, cu.zbase + zc, n);
   if (k.lane == 0) code_coeff_lane0(k, c, comp, n, mode, k.s->a[A_TSKIP + comp][cu.zbase + zc]);
@@ -923,9 +926,9 @@ DEV void enc_intra_header(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int 
   }
   if (chroma && tu.zrel == 0) code_chroma_dir(k, c, cu);
 }
-template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu, const Tu &tu, int luma, int chroma)
+template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu_, const Tu &tu_, int luma_, int chroma_)
 {
-  STAGE(k); if (STOPPED(k)) return 0; // xGetIntraBitsQT TEncSearch.cpp:1093-1117
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int luma = uni(luma_), chroma = uni(chroma_); // xGetIntraBitsQT TEncSearch.cpp:1093-1117
   Cabac *c = &k.s->go;
   wsync();
   if (k.lane == 0) reset_bits(c);
@@ -957,9 +960,9 @@ template <int LOG2> DEV void enc_transform(const K &k, Cabac *c, const Cu &cu, c
     code_tu_coeffs(k, c, cu, tu, comp, 1);
   }
 }
-DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu)
+DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu_)
 {
-  STAGE(k); if (STOPPED(k)) return; // TEncCu.cpp:1636-1654 (RD) and xEncodeCU :1222-1270 (state-advancing encode); I-slice, no PCM/TQB/DQP
+  const Cu cu = ucu(cu_); // TEncCu.cpp:1636-1654 (RD) and xEncodeCU :1222-1270 (state-advancing encode); I-slice, no PCM/TQB/DQP
   wsync();
   if (cu.depth == 3 && k.lane == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
   code_luma_dirs(k, c, cu, 0, cu.part == SIZE_NxN ? 4 : 1);
@@ -977,19 +980,19 @@ DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu)
 // ---------------------------------------------------------------------------------------------------
 // TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved)
 // ---------------------------------------------------------------------------------------------------
-DEVN void code_tu_block(const K &k, const Cu &cu, const Tu &tu, int comp, int mode012, uint32_t *dist)
+DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int mode012_, uint32_t *dist)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_);
   RdSmem &s = *k.s;
   const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
   const int zrel = comp ? tu_czrel(tu) : tu.zrel, zabs = cu.zbase + zrel;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y;
   const int cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
-  const int mode = mode_of(k, cu, comp, zrel);
+  const int mode = uni(mode_of(k, cu, comp, zrel));
   const int tskip = uni(s.a[A_TSKIP + comp][zabs]);
   if (mode012 != 2) {
     build_refs(k, comp, x, y, n);
-    if (use_filtered_refs(comp, mode, n)) filter_refs(k, n);
+    if (ub(use_filtered_refs(comp, mode, n))) filter_refs(k, n);
     predict_block(k, comp, mode, n);
     if (mode012 == 1 && k.lane < 16) s.ts_pred[comp][k.lane] = s.pred[k.lane];
   } else { wsync(); if (k.lane < 16) s.pred[k.lane] = s.ts_pred[comp][k.lane]; }
@@ -1001,15 +1004,10 @@ DEVN void code_tu_block(const K &k, const Cu &cu, const Tu &tu, int comp, int mo
   if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[i] << 5; wsync(); }
   else fwd_transform(k, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
-  if (k.dbg == -17) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
   load_scan(k, coef_scan_idx(comp, n, mode), n);
-  if (k.dbg == -18) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
-  STAGE(k); if (STOPPED(k)) return;
   { const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (k.lane == 0) s.bc_u32[0] = as_; }
-  STAGE(k); if (STOPPED(k)) return;
   wsync();
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
-  if (k.dbg == -30) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
   set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
   int16_t *cl = k.coef_l + (5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
   if (abs_sum > 0) {
@@ -1021,7 +1019,6 @@ DEVN void code_tu_block(const K &k, const Cu &cu, const Tu &tu, int comp, int mo
     for (int i = k.lane; i < n * n; i += 64) { cl[i] = 0; s.resi[i] = 0; }
     wsync();
   }
-  if (k.dbg == -31) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
   uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
   uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
   uint32_t d = 0;
@@ -1033,11 +1030,9 @@ DEVN void code_tu_block(const K &k, const Cu &cu, const Tu &tu, int comp, int mo
     d += (uint32_t)(df * df);
   }
   for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m);
-  if (k.dbg == -32) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
   *dist += d;
   wsync();
-  if (k.dbg == -33) { if (k.lane == 0) k.s->stop = 1; wsync(); return; }
 }
 
 DEV void store_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
@@ -1061,9 +1056,9 @@ DEV void load_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
 }
 
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
-template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu, const Tu &tu, int check_first, uint32_t *dist_out, double *cost_out)
+template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu_, const Tu &tu_, int check_first_, uint32_t *dist_out, double *cost_out)
 {
-  if (STOPPED(k)) return;
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int check_first = uni(check_first_);
   RdSmem &s = *k.s;
   const int full_depth = cu.depth + tu.trd, zabs = cu.zbase + tu.zrel;
   const int check_full = LOG2 <= 5;
@@ -1084,7 +1079,7 @@ template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu, const Tu &tu,
           if (m == 0) store_ts_result(k, cu, tu, 0);           // before the bit count reuses s->lvl
           const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0); cost = calc_rd_cost(k, bits, d);
         }
-        if (cost < single_cost) {
+        if (ub(cost < single_cost)) {
           single_cost = cost; single_dist = d; single_cbf = cbf; best_ts = m;
           if (m == 0) cabac_copy(k, &s.tbest[full_depth], &s.go);
         }
@@ -1119,7 +1114,7 @@ template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu, const Tu &tu,
       cabac_copy(k, &s.go, &s.root[full_depth]);
       const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
       split_cost = calc_rd_cost(k, bits, split_dist);
-      if (split_cost < single_cost) { *dist_out += split_dist; *cost_out += split_cost; return; }
+      if (ub(split_cost < single_cost)) { *dist_out += split_dist; *cost_out += split_cost; return; }
       cabac_copy(k, &s.go, &s.test[full_depth]);
       set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
       set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
@@ -1152,9 +1147,9 @@ template <int LOG2> DEV void set_result(const K &k, const Cu &cu, const Tu &tu, 
   const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; uint8_t *br = k.best_rec + bo;
   for (int i = k.lane; i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
 }
-DEVN void set_result_cu(const K &k, const Cu &cu, const Tu &tu, int comp)
+DEVN void set_result_cu(const K &k, const Cu &cu_, const Tu &tu_, int comp_)
 {
-  if (STOPPED(k)) return;
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_);
   wsync();
   switch (tu.log2) {
     case 6: set_result<6>(k, cu, tu, comp); break;
@@ -1178,9 +1173,9 @@ DEV void recur_luma_any(const K &k, const Cu &cu, const Tu &tu, int check_first,
 
 // rough mode decision for one PU: 35 predictions + SATD (TEncSearch.cpp:2266-2346).  One lane per
 // (mode, 8x8 block) task (4x4 blocks for a 4x4 PU): predict the block in registers, Hadamard, add into satd[mode].
-DEVN void rmd_satd(const K &k, int x, int y, int pn)
+DEVN void rmd_satd(const K &k, int x_, int y_, int pn_)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const int x = uni(x_), y = uni(y_), pn = uni(pn_);
   RdSmem &s = *k.s;
   const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
   if (k.lane < 36) s.satd[k.lane] = 0;
@@ -1241,9 +1236,9 @@ DEVN void rmd_satd(const K &k, int x, int y, int pn)
 }
 
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
-DEVN void est_intra_luma(const K &k, const Cu &cu, uint32_t *cu_dist)
+DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const Cu cu = ucu(cu_);
   RdSmem &s = *k.s;
   const int init_trd = cu.part == SIZE_NxN ? 1 : 0, npu = init_trd ? 4 : 1;
   const int pu_log2 = cu.log2 - init_trd, pn = 1 << pu_log2, pu_parts = cu.nparts >> (2 * init_trd);
@@ -1253,10 +1248,8 @@ DEVN void est_intra_luma(const K &k, const Cu &cu, uint32_t *cu_dist)
     const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
     // ---- rough mode decision ----
     build_refs(k, 0, ptu.x, ptu.y, pn);
-    DBG(k, "  refs ok\n");
     if (pn >= 8 && pn <= 32) filter_refs(k, pn);
     rmd_satd(k, ptu.x, ptu.y, pn);
-    DBG(k, "  rmd ok satd0 %u\n", s.satd[0]);
     int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
     int nfull = c_num_rd_cand[pu_log2 - 2];
     { // mode bits (xModeBitsIntra :5530-5557): 3 possible values, from the [depth][CI_CURR_BEST] snapshot
@@ -1287,16 +1280,13 @@ DEVN void est_intra_luma(const K &k, const Cu &cu, uint32_t *cu_dist)
     // ---- RD pass 1 (:2355-2443) and pass 2 (:2445-2512) ----
     uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
     for (int m = 0; m <= nfull; m++) {
-      if (STOPPED(k)) break;
       const int second = (m == nfull);
       const uint32_t org_mode = second ? best_mode : (uint32_t)uni((int)s.rd_list[m]);
       set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)org_mode);
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
       uint32_t d = 0; double cost = 0.0;
-      DBG(k, "  cand %d mode %u\n", m, org_mode);
       recur_luma_any(k, cu, ptu, !second, &d, &cost);
-      DBG(k, "   -> dist %u cost %f\n", d, cost);
-      if (cost < best_cost) {
+      if (ub(cost < best_cost)) {
         best_mode = org_mode; best_dist = d; best_cost = cost;
         set_result_cu(k, cu, ptu, 0);
         for (int i = k.lane; i < pu_parts; i += 64) {
@@ -1331,9 +1321,9 @@ DEVN void est_intra_luma(const K &k, const Cu &cu, uint32_t *cu_dist)
 }
 
 // xRecurIntraChromaCodingQT TEncSearch.cpp:1941-2145
-template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu, const Tu &tu, uint32_t *dist_out)
+template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu_, const Tu &tu_, uint32_t *dist_out)
 {
-  if (STOPPED(k)) return;
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   RdSmem &s = *k.s;
   const int z = cu.zbase + tu.zrel;
   if (uni(s.a[A_TRIDX][z]) == tu.trd) {
@@ -1361,13 +1351,13 @@ template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu, const Tu &t
           enc_coeff_qt<LOG2>(k, &s.go, cu, tu, comp, 0);
           wsync(); cost_tmp = calc_rd_cost(k, (uint32_t)uni((int)get_bits(&s.go)), d);
         }
-        if (cost_tmp < single_cost) {
+        if (ub(cost_tmp < single_cost)) {
           single_cost = cost_tmp; single_dist = d; best_ts = ts; best_id = cur_id; single_cbf = cbf;
           if (!one && !last) cabac_copy(k, &s.tbest[full_depth], &s.go);
         }
         if (!one && !last) cabac_copy(k, &s.go, &s.root[full_depth]);
       }
-      if (best_id < total) {
+      if (ub(best_id < total)) {
         load_ts_result(k, cu, tu, comp);
         set_parts(k, s.a[A_CBF + comp], zc, np, (int)(single_cbf << tu.trd)); wsync();
         cabac_copy(k, &s.go, &s.tbest[full_depth]);
@@ -1392,9 +1382,9 @@ template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu, const Tu &t
 }
 
 // estIntraPredChromaQT TEncSearch.cpp:2588-2737 (4:2:0: one chroma PU per CU)
-DEVN void est_intra_chroma(const K &k, const Cu &cu, uint32_t *cu_dist)
+DEVN void est_intra_chroma(const K &k, const Cu &cu_, uint32_t *cu_dist)
 {
-  STAGE(k); if (STOPPED(k)) return;
+  const Cu cu = ucu(cu_);
   RdSmem &s = *k.s;
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
   uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
@@ -1413,7 +1403,7 @@ DEVN void est_intra_chroma(const K &k, const Cu &cu, uint32_t *cu_dist)
       default: recur_chroma<3>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<3>(k, cu, root, 0, 1); break;
     }
     const double cost = calc_rd_cost(k, bits, d);
-    if (cost < best_cost) {
+    if (ub(cost < best_cost)) {
       best_cost = cost; best_dist = d; best_mode = mode_list[m];
       set_result_cu(k, cu, root, 1); set_result_cu(k, cu, root, 2);
       for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
@@ -1438,11 +1428,11 @@ DEV void copy_best_rec_to_pic(const K &k, const Cu &cu, int comp)
 }
 
 // xCheckRDCostIntra TEncCu.cpp:1600-1665; the end state of the CU syntax is left in s->temp[depth]
-DEVN Rd check_rd_cost_intra(const K &k, Cu &cu, int part)
+DEVN Rd check_rd_cost_intra(const K &k, const Cu &cu_, int part_)
 {
-  if (STOPPED(k)) { Rd r0 = {1, 0, 0}; return r0; }
   RdSmem &s = *k.s;
-  cu.part = part;
+  const int part = uni(part_);
+  Cu cu = ucu(cu_); cu.part = part;
   wsync();
   for (int i = k.lane; i < cu.nparts; i += 64) { // initEstData TComDataCU.cpp:525-592 + part size / pred mode
     const int z = cu.zbase + i;
@@ -1451,13 +1441,9 @@ DEVN Rd check_rd_cost_intra(const K &k, Cu &cu, int part)
   }
   wsync();
   uint32_t dist = 0;
-  if (k.dbg == -8) { Rd r0 = {1, 0, 0}; return r0; }
-  DBG(k, "cu %d %d log2 %d part %d luma\n", cu.x, cu.y, cu.log2, part);
   est_intra_luma(k, cu, &dist);
-  DBG(k, " luma done dist %u\n", dist);
   copy_best_rec_to_pic(k, cu, 0);
   est_intra_chroma(k, cu, &dist);
-  DBG(k, " chroma done dist %u\n", dist);
   wsync();
   if (k.lane == 0) reset_bits(&s.go);
   enc_cu_syntax(k, &s.go, cu);
@@ -1496,25 +1482,25 @@ DEV void load_cand8(const K &k, const Cu &cu)
 }
 
 // xCompressCU TEncCu.cpp:470-1104 with the reference's label-pruning edits (:496-520, 815-834, 947-965)
-template <int DEPTH> DEVN Rd compress_cu(const K &k, int x, int y)
+template <int DEPTH> DEVN Rd compress_cu(const K &k, int x_, int y_)
 {
+  const int x = uni(x_), y = uni(y_);
   RdSmem &s = *k.s;
   const int log2 = 6 - DEPTH, size = 1 << log2;
   Cu cu = { x, y, log2, DEPTH, (int)s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)], 256 >> (2 * DEPTH), SIZE_2Nx2N };
-  const int boundary = !(x + size <= k.W && y + size <= k.H);
-  const int pred_depth = k.labels[k.addr * 16 + 4 * ((y & 63) / 16) + (x & 63) / 16];
+  const int boundary = uni(!(x + size <= k.W && y + size <= k.H));
+  const int pred_depth = uni(k.labels[k.addr * 16 + 4 * ((y & 63) / 16) + (x & 63) / 16]);
   const int check_cur = pred_depth == DEPTH, check_next = pred_depth > DEPTH;
   Rd best = { MAX_DOUBLE, 0, 0 };
-  if (k.dbg == -3 - DEPTH) { best.cost = 1; return best; }
   int best_is_real = 0;
   if (!boundary) {
     if (check_cur) {
       Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N);
-      if (t.cost < best.cost) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
+      if (ub(t.cost < best.cost)) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
       if (DEPTH == 3) {
         save_cand8(k, cu);
         Rd t2 = check_rd_cost_intra(k, cu, SIZE_NxN);
-        if (t2.cost < best.cost) { best = t2; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+        if (ub(t2.cost < best.cost)) { best = t2; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
         else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
       }
     } else { best.cost = MAX_DOUBLE / 16; best.dist = 0xffffffffu >> 3; best.bits = 0xffffffffu >> 3; }
@@ -1533,7 +1519,7 @@ template <int DEPTH> DEVN Rd compress_cu(const K &k, int x, int y)
     const int h = size >> 1, qn = cu.nparts >> 2;
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
-      if (sx < k.W && sy < k.H) {
+      if (ub(sx < k.W && sy < k.H)) {
         cabac_copy(k, &s.curr[DEPTH + 1], (i == 0) ? &s.curr[DEPTH] : &s.next[DEPTH + 1]);
         Rd sub;
         if (check_next) sub = compress_cu<DEPTH + 1>(k, sx, sy);
@@ -1558,26 +1544,27 @@ template <int DEPTH> DEVN Rd compress_cu(const K &k, int x, int y)
     }
     temp.cost = calc_rd_cost(k, temp.bits, temp.dist);
     cabac_copy(k, &s.temp[DEPTH], &s.go);
-    if (temp.cost < best.cost) { best = temp; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+    if (ub(temp.cost < best.cost)) { best = temp; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
   }
   return best;
 }
 
 // state-advancing encode of the decided CTU: encodeCtu/xEncodeCU TEncCu.cpp:290-304,1167-1271
-template <int DEPTH> DEVN void encode_cu_tree(const K &k, Cabac *c, int x, int y)
+template <int DEPTH> DEVN void encode_cu_tree(const K &k, Cabac *c, int x_, int y_)
 {
+  const int x = uni(x_), y = uni(y_);
   RdSmem &s = *k.s;
   const int size = 64 >> DEPTH;
   const int z = s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)];
   int boundary = 0;
   const int dz = uni(s.a[A_DEPTH][z]);
-  if (x + size <= k.W && y + size <= k.H) {
+  if (ub(x + size <= k.W && y + size <= k.H)) {
     if (DEPTH < 3) { const int sctx = split_ctx(k, x, y, DEPTH); if (k.lane == 0) enc_bin(c, CTX_SPLIT + sctx, dz > DEPTH); }
   } else boundary = 1;
   if constexpr (DEPTH < 3) {
     if (DEPTH < dz || boundary) {
       const int h = size >> 1;
-      for (int i = 0; i < 4; i++) { const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h; if (sx < k.W && sy < k.H) encode_cu_tree<DEPTH + 1>(k, c, sx, sy); }
+      for (int i = 0; i < 4; i++) { const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h; if (ub(sx < k.W && sy < k.H)) encode_cu_tree<DEPTH + 1>(k, c, sx, sy); }
       return;
     }
   }
@@ -1606,8 +1593,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   k.coef_l = reinterpret_cast<int16_t *>(scr); k.rec_l = scr + 4 * 6144 * 2; k.best_rec = k.rec_l + 4 * 6144;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
-  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug;
-  DBG(k, "rd kernel start frame %d smem %d\n", frame, (int)sizeof(RdSmem));
+  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = p.dbgbuf;
 
   // tables into LDS: z-scan map, 32-point DCT matrix
   for (int r = k.lane; r < 256; r += 64) {
@@ -1620,9 +1606,8 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     if (m > 64) m = 128 - m;
     s.dct[i] = (int16_t)(m <= 32 ? c_dct_mag[m] : -c_dct_mag[64 - m]);
   }
-  if (k.lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; s.stop = 0; s.stage = 0; }
+  if (k.lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
   wsync();
-  if (k.dbg == 2) return;
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719
   Cabac *truec = &s.truec;
   for (int i = k.lane; i < NUM_CTX; i += 64) {
@@ -1633,7 +1618,6 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   }
   if (k.lane == 0) truec->frac = 0;
   wsync();
-  if (k.dbg == -1) return;
 
   for (int a = 0; a < k.nctu; a++) {
     k.addr = a; k.cx = a % k.ctus_x; k.cy = a / k.ctus_x;
@@ -1648,10 +1632,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (k.dbg == -2) return;
-    DBG(k, "ctu %d compress\n", a);
     const Rd best = compress_cu<0>(k, k.cx * 64, k.cy * 64);
-    DBG(k, "ctu %d encode\n", a);
     // the state-advancing encode (TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
     wsync();
     if (k.lane == 0) reset_bits(truec);
