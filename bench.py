@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- all-intra CTUs/s of the hot path (on-device CNN depth predictor + depth-pruned CTU decision kernel).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run, one rank per GPU.
+A step = one pass of the whole hot path (hevcdl_encode_frames_dev: CNN + RD search) over one batch of synthetic frames
+that is already resident in HBM.  Frames are independent, so ranks shard by frame with no data-path collective; RCCL
+only gathers the per-frame rate/SSE records (weak scaling: per-GPU work is fixed).
+Prints ONE JSON line on rank 0 (metric of BASELINE.json + roofline + cpu_baseline).
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+ALGO_BYTES_PER_CTU = 27408        # orig 6144 + recon 6144 + levels 12288 + record 2816 + labels 16
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_frames_torch(torch, dev, width, height, n_frames, seed):
+    """Synthetic planar 4:2:0 frames generated on the device (generator of SURVEY.md section 8d)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    y = torch.arange(height, device=dev, dtype=torch.float32).view(1, height, 1)
+    x = torch.arange(width, device=dev, dtype=torch.float32).view(1, 1, width)
+    f = torch.arange(n_frames, device=dev, dtype=torch.float32).view(n_frames, 1, 1)
+    out = torch.empty((n_frames, width * height * 3 // 2), dtype=torch.uint8, device=dev)
+    chunk = 8
+    for s in range(0, n_frames, chunk):
+        e = min(n_frames, s + chunk)
+        ff = f[s:e]
+        Y = 128 + 50 * torch.sin(x / 57) * torch.cos(y / 43) + 30 * torch.sin((x + y + 3 * ff) / 19)
+        Y = Y + torch.randn((e - s, height, width), device=dev, generator=g) * 5
+        bw, bh = min(1200, width // 3), min(600, height // 3)
+        for k in range(s, e):
+            bx = (width // 5 + 4 * k) % max(1, width - bw)
+            by = height // 4
+            blk = Y[k - s, by:by + bh, bx:bx + bw]
+            Y[k - s, by:by + bh, bx:bx + bw] = torch.floor(blk / 24) * 24
+        Y = Y.clamp(0, 255).to(torch.uint8)
+        xc, yc = x[:, :, ::2], y[:, ::2, :]
+        U = (128 + 25 * torch.sin(xc / 61)).expand(e - s, height // 2, width // 2).clamp(0, 255).to(torch.uint8)
+        V = (128 + 25 * torch.cos(yc / 47)).expand(e - s, height // 2, width // 2).clamp(0, 255).to(torch.uint8)
+        out[s:e] = torch.cat([Y.reshape(e - s, -1), U.reshape(e - s, -1), V.reshape(e - s, -1)], dim=1)
+    return out
+
+
+def _cpu_worker(args):
+    yuv, w, h, qp, labels = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_tools
+    t = time.time()
+    ref_tools.run_oracle(yuv, w, h, qp, labels)
+    return time.time() - t
+
+
+def cpu_baseline(yuv_host, labels_host, width, height, qp, max_procs=None):
+    """Oracle (CPU port, bit-identical to the reference on the golden vectors) timed on the host cores of this node:
+    P processes, one distinct frame each (all-intra frames are independent), wall clock from first start to last exit."""
+    import __graft_entry__ as g
+    g.build_oracle()
+    cores = os.cpu_count() or 1
+    p = min(cores, yuv_host.shape[0], max_procs or cores)
+    jobs = [(yuv_host[i:i + 1], width, height, qp, labels_host[i:i + 1]) for i in range(p)]
+    t = time.time()
+    with mp.get_context("spawn").Pool(p) as pool:
+        per = pool.map(_cpu_worker, jobs)
+    wall = time.time() - t
+    ctus = p * labels_host.shape[1]
+    return {"value": ctus / wall, "unit": "CTUs/s", "cores": p, "kind": "port",
+            "sample": "%d frames %dx%d QP%d (1 per process, labels from the GPU CNN, CNN excluded), %.1f s wall, %.1f CTUs/s per core"
+                      % (p, width, height, qp, wall, ctus / sum(per) if sum(per) > 0 else 0.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import hevcdl_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, qp, F = a.width, a.height, a.qp, a.frames
+    enc = hevcdl_amd.Encoder(W, H, qp, max_frames=F, device=local)
+    ctus = enc.ctus
+    yuv = synth_frames_torch(torch, dev, W, H, F, seed=1000 + rank)
+    labels = torch.zeros((F, ctus, 16), dtype=torch.uint8, device=dev)
+    records = torch.zeros((F, ctus, hevcdl_amd.REC_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    recon = torch.zeros_like(yuv)
+    stats = torch.zeros((F, hevcdl_amd.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        enc.encode_frames_dev(yuv.data_ptr(), F, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    enc.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = enc.profile_get()
+    enc.profile_enable(False)
+
+    # per-frame summaries (bits, SSE) gathered to rank 0: the only collective of the path
+    st = torch.from_numpy(np.frombuffer(stats.cpu().numpy().tobytes(), dtype=hevcdl_amd.STATS_DTYPE)["est_bits"].astype(np.int64)).to(dev)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        gathered = [torch.zeros_like(st) for _ in range(world)] if rank == 0 else None
+        dist.gather(st, gathered, dst=0)
+        total_bits = int(sum(int(g.sum().item()) for g in gathered)) if rank == 0 else 0
+    else:
+        total_bits = int(st.sum().item())
+
+    if rank == 0:
+        total_ctus = world * F * ctus * a.steps
+        value = total_ctus / elapsed
+        rd_avg_s = (prof["rd_ms"] / max(1, prof["rd_launches"])) / 1e3
+        achieved = (ALGO_BYTES_PER_CTU * F * ctus / rd_avg_s) / 1e9 if rd_avg_s > 0 else 0.0
+        out = {
+            "metric": "all-intra CTUs/s at 2160p QP32", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int32/f64", "data": "synthetic",
+            "config": {"workload": "%dx%d 8-bit 4:2:0 all-intra QP%d, %d frames per GPU per step (frame-sharded; C4 of BASELINE.json is 75/GPU at 8 GPUs), on-device CNN labels + depth-pruned CTU decisions" % (W, H, qp, F),
+                       "frames_per_gpu": F, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
+                         "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU},
+            "est_bits_per_frame": total_bits / max(1, world * F),
+        }
+        if not a.no_cpu_baseline:
+            nb = min(F, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
+        print(json.dumps(out), flush=True)
+    enc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

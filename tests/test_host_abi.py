@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol of include/hevcdl.h, computes the host-side
+decision constants exactly like the reference, and fails loudly (no fallback) where it must.  No compute calls here."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import hevcdl_amd
+    hevcdl_amd.build_ext()
+    return hevcdl_amd.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    import hevcdl_amd
+    hdr = open(os.path.join(ROOT, "include", "hevcdl.h")).read()
+    declared = set(re.findall(r"\b(hevcdl_[a-z_]+)\s*\(", hdr))
+    declared -= {"hevcdl_ctx"}
+    assert declared, "no declarations parsed"
+    raw = ctypes.CDLL(hevcdl_amd.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "symbol %s declared in include/hevcdl.h is not exported" % name
+    assert declared == set(hevcdl_amd.EXPORTS)
+
+
+def test_struct_layouts_match_the_header(lib):
+    import hevcdl_amd
+    assert hevcdl_amd.REC_DTYPE.itemsize == 15120
+    assert ctypes.sizeof(hevcdl_amd.Config) == hevcdl_amd.default_config(64, 64, 32).struct_size
+
+
+@pytest.mark.parametrize("qp,lam,qpc,cw", [(22, 5.745, 22, 1.0), (27, 18.24, 27, 1.0), (32, 57.91, 31, 1.2599), (37, 183.9, 34, 2.0)])
+def test_lambda_family_matches_reference_values(lib, qp, lam, qpc, cw):
+    """lambda = 0.57*2^((QP-12)/3); chroma QP map; chroma weight 2^((QP-QPc)/3)."""
+    import hevcdl_amd
+    c = hevcdl_amd.default_config(1920, 1080, qp)
+    assert c.lambda_ == 0.57 * 2.0 ** ((qp - 12) / 3.0)
+    assert abs(c.lambda_ - lam) / lam < 1e-3
+    assert c.sqrt_lambda == math.sqrt(c.lambda_)
+    assert c.qp_chroma == qpc and abs(c.chroma_weight - cw) < 1e-4
+    assert c.lambda_chroma == c.lambda_ / c.chroma_weight
+    qs = [26214, 23302, 20560, 18396, 16384, 14564]
+    for ch, q in ((0, qp), (1, qpc)):
+        for l in range(4):
+            ts = 15 - 8 - (l + 2)
+            assert c.err_scale[ch][l] == (32768.0 * 2.0 ** (-2.0 * ts)) / qs[q % 6] / qs[q % 6] / 1
+    assert c.tools == 0x7f and c.ctu_size == 64 and c.tu_log2_max == 5
+
+
+def test_invalid_and_unsupported_configurations_are_rejected(lib):
+    import hevcdl_amd
+    cfg = hevcdl_amd.Config()
+    assert lib.hevcdl_config_default(ctypes.byref(cfg), 100, 64, 32) == 1       # not a multiple of 8
+    assert lib.hevcdl_config_default(ctypes.byref(cfg), 64, 64, 52) == 1        # QP out of range
+    assert lib.hevcdl_config_default(None, 64, 64, 32) == 1
+    cfg = hevcdl_amd.default_config(64, 64, 32)
+    h = ctypes.c_void_p()
+    w = hevcdl_amd.load_weights()
+    assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size - 1, ctypes.byref(h)) == 1    # wrong blob size
+    cfg.tools = 0x3f                                                                                # FastUDIUseMPM off: would change the path
+    assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size, ctypes.byref(h)) == 2
+    cfg = hevcdl_amd.default_config(64, 64, 32)
+    cfg.bit_depth = 10
+    assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size, ctypes.byref(h)) == 2
+    assert lib.hevcdl_ctus_per_frame(3840, 2160) == 2040 and lib.hevcdl_ctus_per_frame(416, 240) == 28
+    assert lib.hevcdl_frame_bytes(1920, 1080) == 1920 * 1080 * 3 // 2
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    """In a container without a GPU the product path must fail (NO_DEVICE), never route to a CPU implementation."""
+    import torch
+    import hevcdl_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hevcdl_amd.HevcdlError) as e:
+        hevcdl_amd.Encoder(64, 64, 32)
+    assert e.value.status == 3
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "oracle/" not in txt.replace("oracle/ is test", "").replace("under\noracle/", "") or fn == "__init__.py", fn
+                assert "hm_oracle" not in txt and "cnn_oracle" not in txt and "ref_tools" not in txt, fn
+
+
+def test_weight_blob_matches_manifest():
+    import json
+    import hevcdl_amd
+    man = json.load(open(os.path.splitext(hevcdl_amd.WEIGHTS_PATH)[0] + ".json"))
+    assert man["floats"] == hevcdl_amd.WEIGHT_FLOATS == hevcdl_amd.load_weights().size
+    names = [t["name"] for t in man["tensors"]]
+    assert names[0] == "conv1.0.weight" and names[-1] == "conv64.1.running_var" and len(names) == 30

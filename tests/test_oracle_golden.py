@@ -1,0 +1,96 @@
+"""CPU: the plain-C oracle and the numpy CNN oracle against the golden vectors generated from the reference
+(oracle/gen_fixtures.py ran the reference encoder build and the reference PyTorch model in the authoring container)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+FIELDS = ["depth", "part_size", "luma_dir", "chroma_dir", "tr_idx", "cbf", "tskip", "bits", "dist", "cost", "coeff_y", "coeff_cb", "coeff_cr"]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "rd_*.npz"))), ids=lambda p: os.path.basename(p)[3:-4])
+def test_rd_oracle_matches_reference_records(oracle_built, path):
+    import ref_tools
+    f = np.load(path)
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"])
+    for k in FIELDS:
+        assert np.array_equal(recs[k], f["records"][k]), k
+    for fr in range(f["yuv"].shape[0]):
+        for a in range(f["labels"].shape[1]):
+            y, u, v = ref_tools.ctu_recon_from_frame(recon[fr], w, h, a)
+            assert np.array_equal(y, f["rec_y"][fr, a]) and np.array_equal(u, f["rec_cb"][fr, a]) and np.array_equal(v, f["rec_cr"][fr, a])
+    # frame statistics are self-consistent with the reconstruction
+    yuv = f["yuv"].astype(np.int64)
+    assert int(stats["sse"].sum()) == int(((yuv - recon.astype(np.int64)) ** 2).sum())
+
+
+def test_fixtures_cover_the_decision_space():
+    """depths 0..3, both partition sizes, transform skip, split transforms and boundary CTUs all occur in the golden set."""
+    seen_depth, seen_part, ts, tr, outside = set(), set(), 0, 0, 0
+    for path in glob.glob(os.path.join(GOLD, "rd_*.npz")):
+        r = np.load(path)["records"]
+        seen_depth |= set(np.unique(r["depth"]).tolist())
+        seen_part |= set(np.unique(r["part_size"]).tolist())
+        ts += int(r["tskip"].sum())
+        tr += int((r["tr_idx"] > 0).sum())
+        outside += int((r["part_size"] == 8).sum())
+    assert seen_depth >= {0, 1, 2, 3} and seen_part >= {0, 3, 8} and ts > 0 and tr > 0 and outside > 0
+
+
+def test_cnn_oracle_matches_reference_logits_and_labels():
+    import cnn_oracle
+    import hevcdl_amd
+    w = cnn_oracle.load_weights(hevcdl_amd.WEIGHTS_PATH)
+    f = np.load(os.path.join(GOLD, "cnn_f1.npz"))
+    n = 24                                  # subset keeps the CPU suite short
+    lg = cnn_oracle.ctu_logits(w, f["ctu_rgb"][:n])
+    assert np.abs(lg - f["logits"][:n]).max() < 1e-4      # cpu oracle tolerance
+    assert np.array_equal(cnn_oracle.labels_from_logits(lg), f["labels"][:n])
+
+
+def test_label_postprocessing_matches_reference_lines():
+    import cnn_oracle
+    f = np.load(os.path.join(GOLD, "cnn_f2.npz"))
+    fake = np.zeros((len(f["digits"]), 4, 16), np.float32)
+    for k in range(4):
+        fake[:, :, 4 * k:4 * k + 4] = np.eye(4, dtype=np.float32)[f["digits"][:, :, k]]
+    assert np.array_equal(cnn_oracle.labels_from_logits(fake), f["labels"])
+
+
+@pytest.mark.parametrize("w,h", [(416, 240), (1920, 1080), (3840, 2160), (7680, 4320), (200, 136), (128, 128)])
+def test_boundary_clamp_table_and_validity(w, h):
+    """F-cnn-4: the clamp keeps every coded CU inside the picture and the labels a valid quadtree."""
+    import cnn_oracle
+    md = cnn_oracle.min_depth_table(w, h)
+    rng = np.random.default_rng(w + h)
+    raw = rng.integers(0, 4, (3, md.shape[0], 16)).astype(np.uint8)
+    lab = cnn_oracle.clamp_labels(raw, w, h)
+    assert (lab >= md[None]).all()
+    cx = (w + 63) // 64
+    for a in range(md.shape[0]):
+        for c in range(16):
+            px, py = (a % cx) * 64 + (c % 4) * 16, (a // cx) * 64 + (c // 4) * 16
+            if px < w and py < h:
+                s = 64 >> int(lab[0, a, c])
+                assert px // s * s + s <= w and py // s * s + s <= h
+        for q in cnn_oracle.QUADS:
+            v = lab[0, a, list(q)]
+            assert (v == 0).all() or (v == 1).all() or (v >= 2).all() or (lab[0, a].max() > 0 and (v >= 1).all())
+    if w % 64 == 0 and h % 64 == 0:
+        assert md.max() == 0
+    # known rows of SURVEY.md section 5 fact 2
+    if (w, h) == (1920, 1080):
+        assert md[-1].max() == 3
+    if (w, h) == (3840, 2160):
+        assert md[-1].max() == 2
+
+
+def test_rd_oracle_rejects_bad_arguments(oracle_built):
+    import ref_tools
+    lib = ref_tools.oracle_lib()
+    assert lib.hm_oracle_encode_frames(None, 100, 64, 1, 32, None, None, None, None) != 0     # width not a multiple of 8
+    assert lib.hm_oracle_encode_frames(None, 64, 64, 1, 99, None, None, None, None) != 0      # QP out of range

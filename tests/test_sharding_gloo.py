@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the bench (frame sharding with no data-path collective, gather of the
+per-frame summary records to rank 0) -- exercised with the oracle standing in for the per-rank work."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as tmp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def shard_frames(n_frames, world, rank):
+    """Contiguous frame ranges (better for file reads)."""
+    per = (n_frames + world - 1) // world
+    return range(min(n_frames, rank * per), min(n_frames, (rank + 1) * per))
+
+
+def _worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_tools
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, qp = 64, 64, 32
+    yuv = ref_tools.synth_yuv(w, h, n_frames, seed=77)
+    labels = ref_tools.make_labels(w, h, n_frames, "rand", 78)
+    mine = list(shard_frames(n_frames, world, rank))
+    recs, recon, stats = ref_tools.run_oracle(yuv[mine], w, h, qp, labels[mine])
+    rec = torch.zeros((len(shard_frames(n_frames, world, 0)), 5), dtype=torch.int64)     # poc, bits, sseY, sseU, sseV
+    for i, f in enumerate(mine):
+        rec[i] = torch.tensor([f, int(stats["est_bits"][i])] + [int(v) for v in stats["sse"][i]])
+    out = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
+    dist.gather(rec, out, dst=0)
+    if rank == 0:
+        allrec = torch.cat(out)[:n_frames].numpy()
+        _, _, full = ref_tools.run_oracle(yuv, w, h, qp, labels)
+        q.put((allrec.tolist(), [[i, int(full["est_bits"][i])] + [int(v) for v in full["sse"][i]] for i in range(n_frames)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_gather_world2(oracle_built):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    n_frames = 4
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, want = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == want                       # frame-sharded == single-process, in POC order
+
+
+def test_shard_ranges_cover_every_frame_once():
+    for n in (1, 7, 75, 600):
+        for world in (1, 2, 4, 8):
+            seen = [f for r in range(world) for f in shard_frames(n, world, r)]
+            assert seen == list(range(n))
