@@ -17,7 +17,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
+LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
 SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "hevcdl_api.hip"]
@@ -55,21 +55,22 @@ class Profile(ctypes.Structure):
     _fields_ = [("cnn_ms", ctypes.c_double), ("rd_ms", ctypes.c_double), ("cnn_launches", ctypes.c_uint32), ("rd_launches", ctypes.c_uint32)]
 
 
-def build_ext(force=False, verbose=False):
+def build_ext(force=False, verbose=False, defines=(), out=None):
     """Compile every HIP source for gfx950 into lib/libhevcdl_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(PKG_DIR, "csrc", s) for s in SOURCES]
     deps = srcs + [os.path.join(PKG_DIR, "csrc", "hevcdl_dev.h"), os.path.join(ROOT, "include", "hevcdl.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    out = out or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-unused-value",
            "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + srcs + ["-o", LIB_PATH]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + ["-D" + d for d in defines] + srcs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 _lib = None

@@ -95,9 +95,13 @@ struct RdSmem {
   int16_t resi[1024];
   int16_t lvl[1024];                  // quantised levels of the current TU (TU raster)
   uint8_t pred[1024];                 // prediction, then reconstruction, of the current TU
-  uint16_t scan[1024];                // grouped-4x4 coefficient scan of the current TU (TComRom.cpp:179-260)
-  uint8_t scan_cg[64];
+  uint16_t scan_all[3][1360];         // grouped-4x4 coefficient scans (TComRom.cpp:179-260): [type][4x4 | 8x8 | 16x16 | 32x32]
+  uint8_t scan_cg_all[3][88];         // CG order per [type][1 | 4 | 16 | 64 groups]
   int16_t dct[32 * 32];               // T32[k][n]; T_N[k][n] = T32[k*32/N][n]
+  // small constant tables copied to LDS once per kernel: the serial RDOQ / bin-counting code reads them with
+  // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
+  int32_t t_ebits[128]; uint8_t t_next[2][128];
+  int t_ang[9], t_inv_ang[9]; int8_t t_dst4[16]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
   union {
     int32_t tmp[1024];                // transform intermediate
     struct { double cost_coeff[1024], cost_sig[1024]; int32_t rate_up[1024], rate_down[1024], sig_delta[1024], delta_u[1024]; } q;
@@ -111,6 +115,9 @@ struct RdSmem {
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
   uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];
+#ifdef HEVCDL_KERNEL_PROF
+  unsigned long long prof[24]; unsigned int prof_n[24];
+#endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
   int last_bits[2][12];   // saved 2Nx2N candidate of an 8x8 CU
@@ -135,7 +142,16 @@ struct K {                             // wave-uniform kernel context
   unsigned int *dbgbuf;
 };
 
+// the workgroup's RdSmem sits at dynamic-LDS offset 0: constant tables are reachable without threading a pointer through
+DEV const RdSmem *smem_of() { extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[]; return reinterpret_cast<const RdSmem *>(smem_raw_); }
 DEV void wsync() { __syncthreads(); }
+#ifdef HEVCDL_KERNEL_PROF
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(k, id) do { if ((k).lane == 0) { (k).s->prof[id] += __builtin_readcyclecounter() - prof_t0_; (k).s->prof_n[id]++; } } while (0)
+#else
+#define PROF_T0() do { } while (0)
+#define PROF_ADD(k, id) do { } while (0)
+#endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Every lane of the wave follows the same control path by construction; the values that steer it are copied to
 // SGPRs (readfirstlane) so that branches enclosing barriers / calls are scalar branches, not EXEC-masked regions.
@@ -158,19 +174,22 @@ DEV int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 // ---------------------------------------------------------------------------------------------------
 DEV void enc_bin(Cabac *c, int ctx, int bin)
 {
+  const RdSmem *t = smem_of();
   const uint8_t st = c->ctx[ctx];
-  c->frac += (unsigned long long)c_entropy_bits[st ^ bin];
-  c->ctx[ctx] = ((st & 1) == bin) ? c_next_mps[st] : c_next_lps[st];
+  c->frac += (unsigned long long)t->t_ebits[st ^ bin];
+  c->ctx[ctx] = t->t_next[(st & 1) == bin][st];
 }
 DEV void enc_ep(Cabac *c, int n) { c->frac += 32768ull * (unsigned long long)n; }
 DEV void reset_bits(Cabac *c) { c->frac &= 32767ull; }
 DEV uint32_t get_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
-DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return c_entropy_bits[c->ctx[ctx] ^ bin]; }
+DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return smem_of()->t_ebits[c->ctx[ctx] ^ bin]; }
 DEV void cabac_copy(const K &k, Cabac *dst, const Cabac *src)
 { // wave-parallel 168-byte snapshot copy (TEncSbac::load/store, TEncSbac.cpp:396-425)
+  PROF_T0();
   wsync();
   if (k.lane < 21) reinterpret_cast<unsigned long long *>(dst)[k.lane] = reinterpret_cast<const unsigned long long *>(src)[k.lane];
   wsync();
+  PROF_ADD(k, 12);
 }
 DEV double calc_rd_cost(const K &k, uint32_t bits, uint32_t dist)
 { // TComRdCost.cpp:62-107
@@ -206,6 +225,7 @@ DEV int unit_avail(const K &k, int x4, int y4, int cur_x4, int cur_y4)
 
 DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
 {
+  PROF_T0();
   const int c = uni(c_), x = uni(x_), y = uni(y_), n = uni(n_);
   const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n / u;
   const int x4 = x >> sh, y4 = y >> sh, total = 4 * nu + 1;
@@ -246,10 +266,12 @@ DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
     k.s->line[i] = (int16_t)v;
   }
   wsync();
+  PROF_ADD(k, 0);
 }
 
 DEVN void filter_refs(const K &k, int n_)
 {
+  PROF_T0();
   const int n = uni(n_); // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
   const int16_t *src = k.s->line; int16_t *dst = k.s->fline;
   const int n2 = 2 * n, last = 4 * n;
@@ -268,13 +290,14 @@ DEVN void filter_refs(const K &k, int n_)
     dst[i] = (int16_t)v;
   }
   wsync();
+  PROF_ADD(k, 1);
 }
 
 DEV int use_filtered_refs(int c, int mode, int n)
 { // TComPattern.cpp:545-570; chroma never in 4:2:0
   if (c || mode == DC) return 0;
   const int d1 = abs(mode - HOR), d2 = abs(mode - VER), diff = d1 < d2 ? d1 : d2;
-  return diff > c_intra_filter_thr[ilog2(n) - 2];
+  return diff > smem_of()->t_filter_thr[ilog2(n) - 2];
 }
 
 // closed-form intra prediction of one sample (TComPrediction.cpp:183-473, 731-817); dcval only for DC
@@ -296,8 +319,8 @@ DEV int pred_pixel(const int16_t *line, int c, int mode, int n, int log2n, int p
   const int is_ver = mode >= 18;
   const int ang_mode = is_ver ? mode - VER : -(mode - HOR);
   const int abs_ang = abs(ang_mode);
-  const int angle = (ang_mode < 0 ? -1 : 1) * c_ang_table[abs_ang];
-  const int inv_angle = c_inv_ang_table[abs_ang];
+  const int angle = (ang_mode < 0 ? -1 : 1) * smem_of()->t_ang[abs_ang];
+  const int inv_angle = smem_of()->t_inv_ang[abs_ang];
   const int x = is_ver ? px : py, y = is_ver ? py : px;
   auto ref = [&](int i) -> int {
     if (i >= 0) return is_ver ? line[n2 + i] : line[n2 - i];
@@ -326,12 +349,14 @@ DEV int dc_value(const K &k, const int16_t *line, int n)
 // prediction of an n x n TU (n <= 32) into s->pred (stride n)
 DEVN void predict_block(const K &k, int c_, int mode_, int n_)
 {
+  PROF_T0();
   const int c = uni(c_), mode = uni(mode_), n = uni(n_);
   const int16_t *line = use_filtered_refs(c, mode, n) ? k.s->fline : k.s->line;
   const int log2n = ilog2(n);
   const int dcv = (mode == DC) ? dc_value(k, line, n) : 0;
   for (int i = k.lane; i < n * n; i += 64) k.s->pred[i] = (uint8_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
   wsync();
+  PROF_ADD(k, 3);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -339,10 +364,11 @@ DEVN void predict_block(const K &k, int c_, int mode_, int n_)
 // ---------------------------------------------------------------------------------------------------
 DEV int tmat(const K &k, int use_dst, int log2n, int kk, int i)
 {
-  return use_dst ? (int)c_dst4[kk * 4 + i] : (int)k.s->dct[(kk << (5 - log2n)) * 32 + i];
+  return use_dst ? (int)k.s->t_dst4[kk * 4 + i] : (int)k.s->dct[(kk << (5 - log2n)) * 32 + i];
 }
 DEVN void fwd_transform(const K &k, int n_, int use_dst_)
 {
+  PROF_T0();
   const int n = uni(n_), use_dst = uni(use_dst_); // s->resi (stride n) -> s->tc
   const int log2n = ilog2(n), s1 = log2n + 8 - 9, s2 = log2n + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
@@ -360,9 +386,11 @@ DEVN void fwd_transform(const K &k, int n_, int use_dst_)
     k.s->tc[kk * n + j] = (acc + a2) >> s2;
   }
   wsync();
+  PROF_ADD(k, 4);
 }
 DEVN void inv_transform(const K &k, int n_, int use_dst_)
 {
+  PROF_T0();
   const int n = uni(n_), use_dst = uni(use_dst_); // s->tc (dequantised) -> s->resi
   const int log2n = ilog2(n);
   for (int o = k.lane; o < n * n; o += 64) {
@@ -379,6 +407,7 @@ DEVN void inv_transform(const K &k, int n_, int use_dst_)
     k.s->resi[j * n + x] = (int16_t)clip16((acc + 2048) >> 12);
   }
   wsync();
+  PROF_ADD(k, 8);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -408,22 +437,6 @@ DEV void scan_next(int type, int bw, int bh, int &line, int &col)
   } else if (type == SCAN_HOR) { if (col == bw - 1) { line++; col = 0; } else col++; }
   else { if (line == bh - 1) { col++; line = 0; } else line++; }
 }
-// fill s->scan / s->scan_cg for (scan type, n): the CG order is generated by lane 0 (<= 64 steps), the 16 positions
-// inside each CG by one lane per CG
-DEVN void load_scan(const K &k, int scan_type_, int n_)
-{
-  const int scan_type = uni(scan_type_), n = uni(n_);
-  const int wg = n >> 2, ng = wg * wg;
-  wsync();
-  if (k.lane == 0) { int l = 0, c = 0; for (int g = 0; g < ng; g++) { k.s->scan_cg[g] = (uint8_t)(l * wg + c); scan_next(scan_type, wg, wg, l, c); } }
-  wsync();
-  for (int g = k.lane; g < ng; g += 64) {
-    const int cg = k.s->scan_cg[g], gl = cg / wg, gc = cg - gl * wg;
-    int l2 = 0, c2 = 0;
-    for (int p = 0; p < 16; p++) { k.s->scan[g * 16 + p] = (uint16_t)((l2 + gl * 4) * n + c2 + gc * 4); scan_next(scan_type, 4, 4, l2, c2); }
-  }
-  wsync();
-}
 DEV int pattern_sig_ctx(const uint8_t *cgf, int gx, int gy, int wg)
 { // TComTrQuant.cpp:2672-2705
   if (wg <= 1) return 0;
@@ -440,7 +453,7 @@ DEV int sig_ctx_inc(const CParam &cp, const uint16_t *scan, int pat, int scan_po
   const int raster = scan[scan_pos], py = raster >> cp.log2, px = raster - (py << cp.log2);
   if (px + py == 0) return 0;
   int offset;
-  if (cp.log2 == 2) offset = c_ctx_ind_map_4x4[4 * py + px];
+  if (cp.log2 == 2) offset = smem_of()->t_ctx_map4[4 * py + px];
   else {
     int cnt; const int xs = px & 3, ys = py & 3;
     if (pat == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
@@ -452,6 +465,8 @@ DEV int sig_ctx_inc(const CParam &cp, const uint16_t *scan, int pat, int scan_po
   }
   return cp.first_sig_ctx + offset;
 }
+DEV const uint16_t *scan_of(const RdSmem &s, int type, int log2n) { return s.scan_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 16 : (log2n == 4 ? 80 : 336))); }
+DEV const uint8_t *scan_cg_of(const RdSmem &s, int type, int log2n) { return s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); }
 DEV int ctx_set_index(int ch, int subset, int found_gt1) { return (ch ? 4 : 0) + ((!ch && subset > 0) ? 2 : 0) + (found_gt1 ? 1 : 0); }   // TComChromaFormat.h:243-251
 DEV void last_ctx_params(int ch, int n, int &off, int &shift)
 { // TComChromaFormat.h:211-226
@@ -483,212 +498,290 @@ DEV int ic_rate(const Cabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, 
   return rate;
 }
 
+DEV double rl_d(double v, int l)
+{ // value of lane l (wave-uniform l) of a per-lane double
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// RDOQ, whole wave.  s->tc -> s->lvl ; returns uiAbsSum.
+//   phase A (lane-parallel over scan positions): |coef|*scale, the clipped rounding level (-> s->lvl) and the
+//     zero-level cost err^2*errScale (-> cost_coeff[sp]); wave-max gives the last nonzero scan position; everything
+//     above it only adds its zero-level cost to the running totals, in the reference's order;
+//   phase B, per 4x4 coefficient group (CG) in reverse scan order: lanes 0..15 own the 16 positions and compute
+//     everything that does not depend on the c1/c2/Rice state machine (level, significance context and its two
+//     rates, zero-level costs); the state machine then walks the 16 positions with wave-uniform control flow and
+//     reads those per-position values with v_readlane -- zero levels cost three fp64 adds, nonzero levels run the
+//     reference's level decision; per-position results go back to LDS lane-parallel;
+//   phase C: last-position search on lane 0, sign-data hiding with lane-parallel candidate costs.
+// Every fp64 accumulation is performed in the reference's order (the sums are not associative).
 DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
 {
-  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_); // s->tc -> s->lvl ; returns uiAbsSum
+  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
   RdSmem &s = *k.s;
+  const int lane = k.lane;
   const int ch = c ? 1 : 0, log2n = ilog2(n);
-  const int qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
+  const int qp = uni(c ? k.qp_c : k.qp), per = qp / 6, rem = qp % 6;
   const int tshift = 15 - 8 - log2n, qbits = 14 + per + tshift;
   const double lambda = c ? k.lambda_c : k.lambda;
   const double err_scale = k.err_scale[ch][log2n - 2];
-  const int qcoef = c_quant_scales[rem];
+  const int qcoef = uni(c_quant_scales[rem]);
   const int ncoef = n * n;
   CParam cp; get_cparam(cp, c, n, dir_mode);
-  const uint16_t *scan = s.scan;
+  const uint16_t *scan = scan_of(s, cp.scan_type, log2n); const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   const int32_t *src = s.tc; int16_t *dst = s.lvl;
   double *cost_coeff = s.u.q.cost_coeff, *cost_sig = s.u.q.cost_sig;
   int32_t *rate_inc_up = s.u.q.rate_up, *rate_inc_down = s.u.q.rate_down, *sig_rate_delta = s.u.q.sig_delta, *delta_u = s.u.q.delta_u;
   double *cost_cg_sig = s.cg_cost; uint8_t *cgf = s.cgf;
-  for (int i = 0; i < ncoef; i++) { cost_coeff[i] = 0; cost_sig[i] = 0; rate_inc_up[i] = 0; rate_inc_down[i] = 0; sig_rate_delta[i] = 0; delta_u[i] = 0; }
-  for (int i = 0; i < 64; i++) { cost_cg_sig[i] = 0; cgf[i] = 0; }
-  const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
   auto level_double = [&](int blk) -> int32_t {
     const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
     return (int32_t)(tmpl < lim ? tmpl : lim);
   };
   auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
-  double block_uncoded = 0, base_cost = 0;
-  int cg_last = -1, last_pos = -1, ctx_set = 0, c1 = 1, c2 = 0, go_rice = 0; uint32_t c1idx = 0, c2idx = 0;
-  const int ncg = ncoef >> 4;
-  for (int cgpos = ncg - 1; cgpos >= 0; cgpos--) {
-    const int cgblk = s.scan_cg[cgpos], gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
-    double st_sig_cost = 0, st_sig_cost0 = 0, st_coded = 0, st_uncoded = 0; int st_nnz_before0 = 0;
-    const int pat = pattern_sig_ctx(cgf, gx, gy, cp.wg);
-    for (int pin = 15; pin >= 0; pin--) {
-      const int sp = cgpos * 16 + pin, blk = scan[sp];
-      const int32_t ld = level_double(blk);
-      uint32_t max_abs = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
-      if (max_abs > 32767u) max_abs = 32767u;
-      const double derr = (double)ld;
-      const double c0 = derr * derr * err_scale;
+  // ---- phase A ----
+  int my_last = -1;
+  for (int sp = lane; sp < ncoef; sp += 64) {
+    const int blk = scan[sp];
+    const int32_t ld = level_double(blk);
+    uint32_t ma = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
+    if (ma > 32767u) ma = 32767u;
+    dst[blk] = (int16_t)ma;
+    const double de = (double)ld;
+    cost_coeff[sp] = de * de * err_scale;
+    if (ma > 0) my_last = sp;
+  }
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(my_last, m); my_last = o > my_last ? o : my_last; }
+  cost_cg_sig[lane] = 0; cgf[lane] = 0;
+  wsync();
+  const int last_pos = uni(my_last);
+  if (last_pos < 0) return 0;
+  const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
+  double block_uncoded = 0;
+#pragma unroll 8
+  for (int sp = ncoef - 1; sp > last_pos; sp--) block_uncoded += cost_coeff[sp];      // zero-level costs above the last position
+  double base_cost = block_uncoded;
+  const int cg_last = last_pos >> 4;
+  int ctx_set = ctx_set_index(ch, cg_last, 0), c1 = 1, c2 = 0, go_rice = 0; uint32_t c1idx = 0, c2idx = 0;
+  // ---- phase B ----
+  for (int cgpos = cg_last; cgpos >= 0; cgpos--) {
+    const int cgblk = uni(scan_cg[cgpos]), gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
+    const int pat = uni(pattern_sig_ctx(cgf, gx, gy, cp.wg));
+    const int start_pin = (cgpos == cg_last) ? (last_pos & 15) : 15;
+    const int cg_ctx_set = ctx_set;
+    // per-position, state-independent part (lane j <-> scan position cgpos*16 + j)
+    const int j = lane & 15, sp_j = cgpos * 16 + j, blk_j = scan[sp_j];
+    const int32_t ld_j = level_double(blk_j);
+    const int ma_j = dst[blk_j];
+    const double c0_j = cost_coeff[sp_j];
+    const int is_last_j = (sp_j == last_pos);
+    const int sigctx_j = is_last_j ? 0 : sig_off + sig_ctx_inc(cp, scan, pat, sp_j);
+    const int b0_j = is_last_j ? 0 : ctx_bits(cab, sigctx_j, 0), b1_j = is_last_j ? 0 : ctx_bits(cab, sigctx_j, 1);
+    const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
+    // per-position results, filled for lane == pin while the state machine walks the group
+    int lvl_j = 0, c1_j = 1, ru_j = 0, rd_j = 0;
+    double cc_j = c0_j + cs0_j, cs_j = cs0_j;                       // the zero-level outcome
+    double st_sig_cost = 0, st_sig_cost0 = 0, st_coded = 0, st_uncoded = 0; int st_nnz_before0 = 0, cg_nonzero = 0;
+    for (int pin = start_pin; pin >= 0; pin--) {
+      const int sp = cgpos * 16 + pin;
+      const int max_abs = __builtin_amdgcn_readlane(ma_j, pin);
+      const double c0 = rl_d(c0_j, pin);
       block_uncoded += c0;
-      dst[blk] = (int16_t)max_abs;
-      if (max_abs > 0 && last_pos < 0) { last_pos = sp; ctx_set = ctx_set_index(ch, sp >> 4, 0); cg_last = cgpos; }
-      if (last_pos >= 0) {
-        uint32_t level;
+      double cost_c, cost_s;
+      uint32_t level = 0;
+      if (max_abs == 0) {                                          // never the last position
+        cost_s = rl_d(cs0_j, pin); cost_c = c0 + cost_s;
+        if (lane == pin) c1_j = c1;
+      } else {
+        const int32_t ld = __builtin_amdgcn_readlane(ld_j, pin);
         const int one_ctx = 4 * ctx_set + c1, abs_ctx = ctx_set + c2;
+        const int is_last = (sp == last_pos);
         { // xGetCodedLevel TComTrQuant.cpp:2812-2879
-          const int is_last = (sp == last_pos);
-          int sig_ctx = 0; double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0; int done = 0;
-          if (!is_last) sig_ctx = sig_off + sig_ctx_inc(cp, scan, pat, sp);
-          if (!is_last && max_abs < 3) {
-            cost_sig[sp] = lambda * (double)ctx_bits(cab, sig_ctx, 0);
-            best = c0 + cost_sig[sp];
-            if (max_abs == 0) done = 1;
+          double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0;
+          cost_s = 0;
+          if (!is_last && max_abs < 3) { cost_s = rl_d(cs0_j, pin); best = c0 + cost_s; }
+          if (!is_last) cur_sig = rl_d(cs1_j, pin);
+          const uint32_t min_abs = max_abs > 1 ? (uint32_t)max_abs - 1 : 1;
+          for (int al = max_abs; al >= (int)min_abs; al--) {
+            const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
+            double cur = err * err * err_scale + lambda * (double)ic_rate(cab, (uint32_t)al, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
+            cur += cur_sig;
+            if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_s = cur_sig; }
           }
-          if (!done) {
-            if (!is_last) cur_sig = lambda * (double)ctx_bits(cab, sig_ctx, 1);
-            const uint32_t min_abs = max_abs > 1 ? max_abs - 1 : 1;
-            for (int al = (int)max_abs; al >= (int)min_abs; al--) {
-              const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
-              double cur = err * err * err_scale + lambda * (double)ic_rate(cab, (uint32_t)al, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
-              cur += cur_sig;
-              if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_sig[sp] = cur_sig; }
-            }
-          }
-          cost_coeff[sp] = best;
-          level = best_lvl;
-          if (!is_last) sig_rate_delta[blk] = ctx_bits(cab, sig_ctx, 1) - ctx_bits(cab, sig_ctx, 0);
+          cost_c = best; level = best_lvl;
         }
-        delta_u[blk] = (int32_t)((ld - (int32_t)(level << qbits)) >> (qbits - 8));
+        int rup, rdn = 0;
         if (level > 0) {
           const int now = ic_rate(cab, level, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
-          rate_inc_up[blk] = ic_rate(cab, level + 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
-          rate_inc_down[blk] = ic_rate(cab, level - 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
-        } else rate_inc_up[blk] = ctx_bits(cab, CTX_ONE + one_ctx, 0);
-        dst[blk] = (int16_t)level;
-        base_cost += cost_coeff[sp];
+          rup = ic_rate(cab, level + 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
+          rdn = ic_rate(cab, level - 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
+        } else rup = ctx_bits(cab, CTX_ONE + one_ctx, 0);
+        if (lane == pin) { lvl_j = (int)level; cc_j = cost_c; cs_j = cost_s; ru_j = rup; rd_j = rdn; c1_j = -1; }
         const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
         if (level >= base_level) { if (level > 3u * (1u << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4; }
         if (level >= 1) c1idx++;
         if (level > 1) { c1 = 0; c2 += (c2 < 2); c2idx++; }
         else if (c1 < 3 && c1 > 0 && level) c1++;
-        if ((sp & 15) == 0 && sp > 0) { ctx_set = ctx_set_index(ch, (sp - 1) >> 4, c1 == 0); c1 = 1; c2 = 0; c1idx = 0; c2idx = 0; go_rice = 0; }
-      } else base_cost += c0;
-      st_sig_cost += cost_sig[sp];
-      if (pin == 0) st_sig_cost0 = cost_sig[sp];
-      if (dst[blk]) {
-        cgf[cgblk] = 1;
-        st_coded += cost_coeff[sp] - cost_sig[sp];
+      }
+      base_cost += cost_c;
+      if (pin == 0 && sp > 0) { ctx_set = ctx_set_index(ch, (sp - 1) >> 4, c1 == 0); c1 = 1; c2 = 0; c1idx = 0; c2idx = 0; go_rice = 0; }
+      st_sig_cost += cost_s;
+      if (pin == 0) st_sig_cost0 = cost_s;
+      if (level) {
+        cg_nonzero = 1;
+        st_coded += cost_c - cost_s;
         st_uncoded += c0;
         if (pin != 0) st_nnz_before0++;
       }
     }
-    if (cg_last >= 0) {
-      if (cgpos) {
-        if (cgf[cgblk] == 0) {
-          const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
-          const double r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
-          base_cost += r0 - st_sig_cost;
-          cost_cg_sig[cgpos] = r0;
-        } else if (cgpos < cg_last) {
-          if (st_nnz_before0 == 0) { base_cost -= st_sig_cost0; st_sig_cost -= st_sig_cost0; }
-          double zero_cost = base_cost;
-          const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
-          const double r1 = lambda * (double)ctx_bits(cab, cg_off + cs, 1), r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
-          base_cost += r1; zero_cost += r0; cost_cg_sig[cgpos] = r1;
-          zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
-          if (zero_cost < base_cost) {
-            cgf[cgblk] = 0; base_cost = zero_cost; cost_cg_sig[cgpos] = r0;
-            for (int pin = 15; pin >= 0; pin--) {
-              const int sp = cgpos * 16 + pin, blk = scan[sp];
-              if (dst[blk]) { dst[blk] = 0; cost_coeff[sp] = cost0_of(blk); cost_sig[sp] = 0; }
-            }
-          }
+    // lane-parallel write-back of the group
+    if (lane < 16 && j <= start_pin) {
+      dst[blk_j] = (int16_t)lvl_j;
+      cost_coeff[sp_j] = cc_j; cost_sig[sp_j] = cs_j;
+      sig_rate_delta[blk_j] = b1_j - b0_j;                         // 0 at the last position
+      delta_u[blk_j] = (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8));
+      rate_inc_up[blk_j] = (c1_j >= 0) ? ctx_bits(cab, CTX_ONE + 4 * cg_ctx_set + c1_j, 0) : ru_j;
+      rate_inc_down[blk_j] = rd_j;
+    }
+    if (cg_nonzero) cgf[cgblk] = 1;
+    wsync();
+    if (cgpos) {
+      if (!cg_nonzero) {
+        const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
+        const double r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
+        base_cost += r0 - st_sig_cost;
+        if (lane == 0) cost_cg_sig[cgpos] = r0;
+      } else if (cgpos < cg_last) {
+        if (st_nnz_before0 == 0) { base_cost -= st_sig_cost0; st_sig_cost -= st_sig_cost0; }
+        double zero_cost = base_cost;
+        const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
+        const double r1 = lambda * (double)ctx_bits(cab, cg_off + cs, 1), r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
+        base_cost += r1; zero_cost += r0;
+        double cgc = r1;
+        zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
+        if (zero_cost < base_cost) {
+          base_cost = zero_cost; cgc = r0;
+          if (lane < 16 && lvl_j) { dst[blk_j] = 0; cost_coeff[sp_j] = c0_j; cost_sig[sp_j] = 0; }
+          if (lane == 0) cgf[cgblk] = 0;
         }
-      } else cgf[cgblk] = 1;
+        if (lane == 0) cost_cg_sig[cgpos] = cgc;
+      }
+    } else if (lane == 0) cgf[cgblk] = 1;
+    wsync();
+  }
+  // ---- phase C: last position (lane 0), TComTrQuant.cpp:2440-2528 ----
+  if (lane == 0) {
+    double best_cost;
+    {
+      const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
+      best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
+      base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
     }
-  }
-  if (last_pos < 0) return 0;
-  double best_cost;
-  {
-    const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
-    best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
-    base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
-  }
-  int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
-  { // TEncSbac.cpp:1910-1930
-    int off, shift; last_ctx_params(ch, n, off, shift);
-    const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
-    int accx = 0, accy = 0, kk; const int ng = c_group_idx[n - 1];
-    for (kk = 0; kk < ng; kk++) {
-      last_x_bits[kk] = accx + ctx_bits(cab, bx + off + (kk >> shift), 0); accx += ctx_bits(cab, bx + off + (kk >> shift), 1);
-      last_y_bits[kk] = accy + ctx_bits(cab, by + off + (kk >> shift), 0); accy += ctx_bits(cab, by + off + (kk >> shift), 1);
+    int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
+    { // TEncSbac.cpp:1910-1930
+      int off, shift; last_ctx_params(ch, n, off, shift);
+      const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
+      int accx = 0, accy = 0, kk; const int ng = s.t_group_idx[n - 1];
+      for (kk = 0; kk < ng; kk++) {
+        last_x_bits[kk] = accx + ctx_bits(cab, bx + off + (kk >> shift), 0); accx += ctx_bits(cab, bx + off + (kk >> shift), 1);
+        last_y_bits[kk] = accy + ctx_bits(cab, by + off + (kk >> shift), 0); accy += ctx_bits(cab, by + off + (kk >> shift), 1);
+      }
+      last_x_bits[kk] = accx; last_y_bits[kk] = accy;
     }
-    last_x_bits[kk] = accx; last_y_bits[kk] = accy;
-  }
-  int best_last_p1 = 0, found_last = 0;
-  for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
-    const int cgblk = s.scan_cg[cgpos];
-    base_cost -= cost_cg_sig[cgpos];
-    if (!cgf[cgblk]) continue;
-    for (int pin = 15; pin >= 0; pin--) {
-      const int sp = cgpos * 16 + pin;
-      if (sp > last_pos) continue;
-      const int blk = scan[sp];
-      if (dst[blk]) {
-        int py = blk >> log2n, px = blk - (py << log2n);
-        if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-        const int gx2 = c_group_idx[px], gy2 = c_group_idx[py];
-        double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
-        if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
-        if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
-        const double cost_last = lambda * lc;
-        const double total = base_cost + cost_last - cost_sig[sp];
-        if (total < best_cost) { best_last_p1 = sp + 1; best_cost = total; }
-        if (dst[blk] > 1) { found_last = 1; break; }
-        base_cost -= cost_coeff[sp]; base_cost += cost0_of(blk);
-      } else base_cost -= cost_sig[sp];
+    int best_last_p1 = 0, found_last = 0;
+    for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
+      const int cgblk = scan_cg[cgpos];
+      base_cost -= cost_cg_sig[cgpos];
+      if (!cgf[cgblk]) continue;
+      for (int pin = 15; pin >= 0; pin--) {
+        const int sp = cgpos * 16 + pin;
+        if (sp > last_pos) continue;
+        const int blk = scan[sp];
+        if (dst[blk]) {
+          int py = blk >> log2n, px = blk - (py << log2n);
+          if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
+          const int gx2 = s.t_group_idx[px], gy2 = s.t_group_idx[py];
+          double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
+          if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
+          if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
+          const double cost_last = lambda * lc;
+          const double total = base_cost + cost_last - cost_sig[sp];
+          if (total < best_cost) { best_last_p1 = sp + 1; best_cost = total; }
+          if (dst[blk] > 1) { found_last = 1; break; }
+          base_cost -= cost_coeff[sp]; base_cost += cost0_of(blk);
+        } else base_cost -= cost_sig[sp];
+      }
     }
+    s.bc_u32[3] = (unsigned)best_last_p1;
   }
+  wsync();
+  const int best_last_p1 = uni((int)s.bc_u32[3]);
+  // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact)
   uint32_t abs_sum = 0;
-  for (int sp = 0; sp < best_last_p1; sp++) {
-    const int blk = scan[sp]; const int lv = dst[blk];
-    abs_sum += (uint32_t)lv;
-    dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv);
+  for (int sp = lane; sp <= last_pos; sp += 64) {
+    const int blk = scan[sp];
+    if (sp < best_last_p1) { const int lv = dst[blk]; abs_sum += (uint32_t)lv; dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv); }
+    else dst[blk] = 0;
   }
-  for (int sp = best_last_p1; sp <= last_pos; sp++) dst[scan[sp]] = 0;
-  if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660
+  for (int m = 32; m >= 1; m >>= 1) abs_sum += __shfl_xor(abs_sum, m);
+  wsync();
+  if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660; lanes 0..15 own the positions of the current CG
     const long long rd_factor = k.sbh[ch];
+    const long long I64MAX = 0x7fffffffffffffffll;
     int last_cg = -1;
-    for (int subset = (ncoef - 1) >> 4; subset >= 0; subset--) {
-      const int sub_pos = subset << 4; int first_nz = 16, last_nz = -1, sum = 0, kk;
-      for (kk = 15; kk >= 0; --kk) if (dst[scan[kk + sub_pos]]) { last_nz = kk; break; }
-      for (kk = 0; kk < 16; kk++) if (dst[scan[kk + sub_pos]]) { first_nz = kk; break; }
-      for (kk = first_nz; kk <= last_nz; kk++) sum += dst[scan[kk + sub_pos]];
-      if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+    for (int subset = cg_last; subset >= 0; subset--) {
+      const int sub_pos = subset << 4, j = lane & 15, blk_j = scan[sub_pos + j];
+      const int lv_j = dst[blk_j];
+      const unsigned nzmask = (unsigned)(__ballot(lv_j != 0) & 0xffffull);
+      if (!nzmask) continue;                                       // lastCG stays -1 until the first CG with levels
+      const int last_nz = 31 - __clz((int)nzmask), first_nz = __ffs((int)nzmask) - 1;
+      if (last_cg == -1) last_cg = 1;
       if (last_nz - first_nz >= 4) {
-        const uint32_t signbit = dst[scan[sub_pos + first_nz]] > 0 ? 0 : 1;
+        int sum = (j >= first_nz && j <= last_nz) ? lv_j : 0;
+        for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+        const int lv_first = __builtin_amdgcn_readlane(lv_j, first_nz);
+        const uint32_t signbit = lv_first > 0 ? 0 : 1;
         if (signbit != ((uint32_t)sum & 1u)) {
-          long long min_cost = 0x7fffffffffffffffll, cur_cost = 0x7fffffffffffffffll; int min_pos = -1, final_change = 0, cur_change = 0;
-          for (kk = (last_cg == 1 ? last_nz : 15); kk >= 0; --kk) {
-            const int blk = scan[kk + sub_pos];
-            if (dst[blk] != 0) {
-              const long long up = rd_factor * (-(long long)delta_u[blk]) + rate_inc_up[blk];
-              long long down = rd_factor * ((long long)delta_u[blk]) + rate_inc_down[blk] - ((abs(dst[blk]) == 1) ? sig_rate_delta[blk] : 0);
-              if (last_cg == 1 && last_nz == kk && abs(dst[blk]) == 1) down -= (4 << 15);
+          long long cur_cost = I64MAX; int cur_change = 0;
+          const int nmax = (last_cg == 1) ? last_nz : 15;
+          if (j <= nmax) {
+            if (lv_j != 0) {
+              const long long up = rd_factor * (-(long long)delta_u[blk_j]) + rate_inc_up[blk_j];
+              long long down = rd_factor * ((long long)delta_u[blk_j]) + rate_inc_down[blk_j] - ((abs(lv_j) == 1) ? sig_rate_delta[blk_j] : 0);
+              if (last_cg == 1 && last_nz == j && abs(lv_j) == 1) down -= (4 << 15);
               if (up < down) { cur_cost = up; cur_change = 1; }
-              else { cur_change = -1; cur_cost = (kk == first_nz && abs(dst[blk]) == 1) ? 0x7fffffffffffffffll : down; }
+              else { cur_change = -1; cur_cost = (j == first_nz && abs(lv_j) == 1) ? I64MAX : down; }
             } else {
-              cur_cost = rd_factor * (-(long long)abs(delta_u[blk])) + (1 << 15) + rate_inc_up[blk] + sig_rate_delta[blk];
+              cur_cost = rd_factor * (-(long long)abs(delta_u[blk_j])) + (1 << 15) + rate_inc_up[blk_j] + sig_rate_delta[blk_j];
               cur_change = 1;
-              if (kk < first_nz) { const uint32_t ts = src[blk] >= 0 ? 0 : 1; if (ts != signbit) cur_cost = 0x7fffffffffffffffll; }
+              if (j < first_nz) { const uint32_t ts = src[blk_j] >= 0 ? 0 : 1; if (ts != signbit) cur_cost = I64MAX; }
             }
-            if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = blk; }
           }
-          if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
-          if (src[min_pos] >= 0) dst[min_pos] = (int16_t)(dst[min_pos] + final_change); else dst[min_pos] = (int16_t)(dst[min_pos] - final_change);
+          // the reference scans n = nmax..0 and keeps the first strict minimum: smallest cost, ties -> largest n
+          long long bc = cur_cost; int bn = (j <= nmax && cur_cost != I64MAX) ? j : -1;
+          for (int m = 8; m >= 1; m >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)bc, m), hi = (unsigned)__shfl_xor((int)(unsigned)(bc >> 32), m);
+            const long long oc = (long long)(((unsigned long long)hi << 32) | lo); const int on = __shfl_xor(bn, m);
+            if (on >= 0 && (bn < 0 || oc < bc || (oc == bc && on > bn))) { bc = oc; bn = on; }
+          }
+          const int min_n = __builtin_amdgcn_readlane(bn, 0);
+          if (min_n >= 0) {
+            int final_change = __builtin_amdgcn_readlane(cur_change, min_n);
+            const int lv_min = __builtin_amdgcn_readlane(lv_j, min_n);
+            if (lv_min == 32767 || lv_min == -32768) final_change = -1;
+            if (lane == min_n) { if (src[blk_j] >= 0) dst[blk_j] = (int16_t)(lv_j + final_change); else dst[blk_j] = (int16_t)(lv_j - final_change); }
+          }
         }
       }
       if (last_cg == 1) last_cg = 0;
     }
   }
-  return abs_sum;
+  wsync();
+  return (uint32_t)uni((int)abs_sum);
 }
 
 DEVN void dequant(const K &k, int c_, int n_)
 {
+  PROF_T0();
   const int c = uni(c_), n = uni(n_); // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
   const int log2n = ilog2(n), qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
   const int tshift = 15 - 8 - log2n, rshift = 6 - (tshift + per), scale = c_inv_quant_scales[rem];
@@ -700,6 +793,7 @@ DEVN void dequant(const K &k, int c_, int n_)
     k.s->tc[i] = clip16(v);
   }
   wsync();
+  PROF_ADD(k, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -708,13 +802,13 @@ DEVN void dequant(const K &k, int c_, int n_)
 DEV void code_last_xy(Cabac *c, int px, int py, int n, int ch, int scan_type)
 {
   if (scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-  const int gx = c_group_idx[px], gy = c_group_idx[py]; int off, shift, kk;
+  const int gx = smem_of()->t_group_idx[px], gy = smem_of()->t_group_idx[py]; int off, shift, kk;
   last_ctx_params(ch, n, off, shift);
   const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
   for (kk = 0; kk < gx; kk++) enc_bin(c, bx + (kk >> shift), 1);
-  if (gx < c_group_idx[n - 1]) enc_bin(c, bx + (kk >> shift), 0);
+  if (gx < smem_of()->t_group_idx[n - 1]) enc_bin(c, bx + (kk >> shift), 0);
   for (kk = 0; kk < gy; kk++) enc_bin(c, by + (kk >> shift), 1);
-  if (gy < c_group_idx[n - 1]) enc_bin(c, by + (kk >> shift), 0);
+  if (gy < smem_of()->t_group_idx[n - 1]) enc_bin(c, by + (kk >> shift), 0);
   if (gx > 3) enc_ep(c, (gx - 2) >> 1);
   if (gy > 3) enc_ep(c, (gy - 2) >> 1);
 }
@@ -734,7 +828,7 @@ DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp_, int n_, int dir_mode
   const int ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
   const int log2n = cp.log2;
-  const int16_t *coef = s.lvl; const uint16_t *scan = s.scan;
+  const int16_t *coef = s.lvl; const uint16_t *scan = scan_of(s, cp.scan_type, log2n); const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   int num_sig = 0;
   for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
   if (num_sig == 0) return;                                   // never called for an empty TU (cbf checked by the caller)
@@ -754,7 +848,7 @@ DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp_, int n_, int dir_mode
     go_rice = 0;
     int abs_coeff[16], last_nz = -1, first_nz = 16, escape = 0;
     if (sp == scan_last) { abs_coeff[0] = abs(coef[pos_last]); num_nz = 1; last_nz = sp; first_nz = sp; sp--; }
-    const int cgblk = s.scan_cg[subset], gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
+    const int cgblk = scan_cg[subset], gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
     if (subset == last_set || subset == 0) cgf[cgblk] = 1;
     else enc_bin(c, cg_off + sig_cg_ctx(cgf, gx, gy, cp.wg), cgf[cgblk] != 0);
     if (cgf[cgblk]) {
@@ -887,9 +981,8 @@ DEV void code_tu_coeffs(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int co
   const int zc = comp ? tu_czrel(tu) : tu.zrel;
   const int n = comp ? tu_csize(tu) : (1 << tu.log2);
   const int mode = uni(mode_of(k, cu, comp, zc));
-  load_scan(k, coef_scan_idx(comp, n, mode), n);
   load_tu_coef(k, real, comp, tu.log2, cu.zbase + zc, n);
-  if (k.lane == 0) code_coeff_lane0(k, c, comp, n, mode, k.s->a[A_TSKIP + comp][cu.zbase + zc]);
+  { PROF_T0(); if (k.lane == 0) code_coeff_lane0(k, c, comp, n, mode, k.s->a[A_TSKIP + comp][cu.zbase + zc]); PROF_ADD(k, 11); }
   wsync();
 }
 
@@ -928,6 +1021,7 @@ DEV void enc_intra_header(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int 
 }
 template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu_, const Tu &tu_, int luma_, int chroma_)
 {
+  PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int luma = uni(luma_), chroma = uni(chroma_); // xGetIntraBitsQT TEncSearch.cpp:1093-1117
   Cabac *c = &k.s->go;
   wsync();
@@ -937,6 +1031,7 @@ template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu_, const
   if (luma) enc_coeff_qt<LOG2>(k, c, cu, tu, 0, 0);
   if (chroma) { enc_coeff_qt<LOG2>(k, c, cu, tu, 1, 0); enc_coeff_qt<LOG2>(k, c, cu, tu, 2, 0); }
   wsync();
+  PROF_ADD(k, 10);
   return uni((int)get_bits(c));
 }
 template <int LOG2> DEV void enc_transform(const K &k, Cabac *c, const Cu &cu, const Tu &tu)
@@ -962,6 +1057,7 @@ template <int LOG2> DEV void enc_transform(const K &k, Cabac *c, const Cu &cu, c
 }
 DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu_)
 {
+  PROF_T0();
   const Cu cu = ucu(cu_); // TEncCu.cpp:1636-1654 (RD) and xEncodeCU :1222-1270 (state-advancing encode); I-slice, no PCM/TQB/DQP
   wsync();
   if (cu.depth == 3 && k.lane == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
@@ -975,6 +1071,7 @@ DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu_)
     default: enc_transform<3>(k, c, cu, root); break;
   }
   wsync();
+  PROF_ADD(k, 13);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -982,6 +1079,7 @@ DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu_)
 // ---------------------------------------------------------------------------------------------------
 DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int mode012_, uint32_t *dist)
 {
+  PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_);
   RdSmem &s = *k.s;
   const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
@@ -1004,8 +1102,7 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
   if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[i] << 5; wsync(); }
   else fwd_transform(k, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
-  load_scan(k, coef_scan_idx(comp, n, mode), n);
-  { const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (k.lane == 0) s.bc_u32[0] = as_; }
+  { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (k.lane == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
   wsync();
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
   set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
@@ -1033,6 +1130,7 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
   *dist += d;
   wsync();
+  PROF_ADD(k, 9);
 }
 
 DEV void store_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
@@ -1149,6 +1247,7 @@ template <int LOG2> DEV void set_result(const K &k, const Cu &cu, const Tu &tu, 
 }
 DEVN void set_result_cu(const K &k, const Cu &cu_, const Tu &tu_, int comp_)
 {
+  PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_);
   wsync();
   switch (tu.log2) {
@@ -1159,6 +1258,7 @@ DEVN void set_result_cu(const K &k, const Cu &cu_, const Tu &tu_, int comp_)
     default: set_result<2>(k, cu, tu, comp); break;
   }
   wsync();
+  PROF_ADD(k, 15);
 }
 DEV void recur_luma_any(const K &k, const Cu &cu, const Tu &tu, int check_first, uint32_t *d, double *c)
 {
@@ -1175,6 +1275,7 @@ DEV void recur_luma_any(const K &k, const Cu &cu, const Tu &tu, int check_first,
 // (mode, 8x8 block) task (4x4 blocks for a 4x4 PU): predict the block in registers, Hadamard, add into satd[mode].
 DEVN void rmd_satd(const K &k, int x_, int y_, int pn_)
 {
+  PROF_T0();
   const int x = uni(x_), y = uni(y_), pn = uni(pn_);
   RdSmem &s = *k.s;
   const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
@@ -1233,11 +1334,13 @@ DEVN void rmd_satd(const K &k, int x_, int y_, int pn_)
     }
   }
   wsync();
+  PROF_ADD(k, 2);
 }
 
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
 DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
 {
+  PROF_T0();
   const Cu cu = ucu(cu_);
   RdSmem &s = *k.s;
   const int init_trd = cu.part == SIZE_NxN ? 1 : 0, npu = init_trd ? 4 : 1;
@@ -1258,7 +1361,7 @@ DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
       if (k.lane < 35) {
         const int mode = k.lane;
         int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
-        const unsigned long long fr = f0 + (unsigned long long)c_entropy_bits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
+        const unsigned long long fr = f0 + (unsigned long long)s.t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
         s.rmd_cost[mode] = (double)s.satd[mode] + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
       }
       wsync();
@@ -1318,6 +1421,7 @@ DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
   }
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
   *cu_dist = overall;
+  PROF_ADD(k, 16);
 }
 
 // xRecurIntraChromaCodingQT TEncSearch.cpp:1941-2145
@@ -1384,6 +1488,7 @@ template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu_, const Tu &
 // estIntraPredChromaQT TEncSearch.cpp:2588-2737 (4:2:0: one chroma PU per CU)
 DEVN void est_intra_chroma(const K &k, const Cu &cu_, uint32_t *cu_dist)
 {
+  PROF_T0();
   const Cu cu = ucu(cu_);
   RdSmem &s = *k.s;
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
@@ -1414,6 +1519,7 @@ DEVN void est_intra_chroma(const K &k, const Cu &cu_, uint32_t *cu_dist)
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
   *cu_dist += best_dist;
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
+  PROF_ADD(k, 17);
 }
 
 DEV void copy_best_rec_to_pic(const K &k, const Cu &cu, int comp)
@@ -1606,7 +1712,31 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     if (m > 64) m = 128 - m;
     s.dct[i] = (int16_t)(m <= 32 ? c_dct_mag[m] : -c_dct_mag[64 - m]);
   }
+  for (int i = k.lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
+  if (k.lane < 9) { s.t_ang[k.lane] = c_ang_table[k.lane]; s.t_inv_ang[k.lane] = c_inv_ang_table[k.lane]; }
+  if (k.lane < 16) { s.t_dst4[k.lane] = c_dst4[k.lane]; s.t_ctx_map4[k.lane] = c_ctx_ind_map_4x4[k.lane]; }
+  if (k.lane < 32) s.t_group_idx[k.lane] = c_group_idx[k.lane];
+  if (k.lane < 5) s.t_filter_thr[k.lane] = c_intra_filter_thr[k.lane];
+  if (k.lane < 12) { // CG order of every (scan type, block size)
+    const int type = k.lane >> 2, l = k.lane & 3, wg = 1 << l, ng = wg * wg;
+    uint8_t *cg = s.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
+    int ln = 0, c = 0;
+    for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
+  }
+  wsync();
+  for (int t = k.lane; t < 3 * 85; t += 64) { // the 16 positions of every CG
+    const int type = t / 85, r = t - type * 85, l = r < 1 ? 0 : (r < 5 ? 1 : (r < 21 ? 2 : 3));
+    const int g = r - (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21))), wg = 1 << l, n = 4 << l;
+    const int cgb = s.scan_cg_all[type][r], gl = cgb / wg, gc = cgb - gl * wg;
+    uint16_t *sc = s.scan_all[type] + (l == 0 ? 0 : (l == 1 ? 16 : (l == 2 ? 80 : 336))) + g * 16;
+    int l2 = 0, c2 = 0;
+    for (int q = 0; q < 16; q++) { sc[q] = (uint16_t)((l2 + gl * 4) * n + c2 + gc * 4); scan_next(type, 4, 4, l2, c2); }
+  }
   if (k.lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
+#ifdef HEVCDL_KERNEL_PROF
+  if (k.lane < 24) { s.prof[k.lane] = 0; s.prof_n[k.lane] = 0; }
+  const unsigned long long prof_start_ = __builtin_readcyclecounter();
+#endif
   wsync();
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719
   Cabac *truec = &s.truec;
@@ -1638,7 +1768,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     if (k.lane == 0) reset_bits(truec);
     encode_cu_tree<0>(k, truec, k.cx * 64, k.cy * 64);
     wsync();
-    if (k.lane == 0) { if (a != k.nctu - 1) truec->frac += (unsigned long long)c_entropy_bits[126]; s.est_bits += truec->frac >> 15; }
+    if (k.lane == 0) { if (a != k.nctu - 1) truec->frac += (unsigned long long)s.t_ebits[126]; s.est_bits += truec->frac >> 15; }
     // flush the CTU record
     unsigned char *rec = k.records + (size_t)a * REC_SIZE;
     for (int i = k.lane; i < 11 * 256 / 4; i += 64) reinterpret_cast<uint32_t *>(rec)[i] = reinterpret_cast<const uint32_t *>(&s.a[0][0])[i];
@@ -1648,6 +1778,14 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     }
     wsync();
   }
+#ifdef HEVCDL_KERNEL_PROF
+  wsync();
+  if (frame == 0 && p.dbgbuf && k.lane < 24) {
+    if (k.lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
+    p.dbgbuf[1 + 2 * k.lane] = (unsigned int)(s.prof[k.lane] >> 10); p.dbgbuf[2 + 2 * k.lane] = s.prof_n[k.lane];
+    if (k.lane == 0) p.dbgbuf[0] = 24;
+  }
+#endif
   if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits
     hevcdl_frame_stats *st = reinterpret_cast<hevcdl_frame_stats *>(p.stats) + frame;
     for (int c = 0; c < 3; c++) {
