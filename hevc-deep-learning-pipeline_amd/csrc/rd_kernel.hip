@@ -102,10 +102,7 @@ struct RdSmem {
   // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
   int32_t t_ebits[128]; uint8_t t_next[2][128];
   int t_ang[9], t_inv_ang[9]; int8_t t_dst4[16]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
-  union {
-    int32_t tmp[1024];                // transform intermediate
-    struct { double cost_coeff[1024], cost_sig[1024]; int32_t rate_up[1024], rate_down[1024], sig_delta[1024], delta_u[1024]; } q;
-  } u;
+  struct { int32_t tmp[1024]; } u;   // transform intermediate
   uint8_t sv_tr[256], sv_cbf[3][256], sv_ts[3][256];
   uint8_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
   unsigned int satd[36];
@@ -134,6 +131,8 @@ struct K {                             // wave-uniform kernel context
   int16_t *coef_l;                     // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
   uint8_t *rec_l;                      // scratch: [4 layers][6144] CTU-relative reconstruction
   uint8_t *best_rec;                   // scratch: [6144] best reconstruction of the CU under test
+  double *q_cost;                      // scratch: RDOQ per-position costs [2][1024] (coded cost, sig cost); written/read lane-parallel,
+  int32_t *q_rate;                     //          and SBH inputs [4][1024] (rateIncUp, rateIncDown, sigRateDelta, deltaU)
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
   long long sbh[2];
@@ -530,8 +529,8 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
   CParam cp; get_cparam(cp, c, n, dir_mode);
   const uint16_t *scan = scan_of(s, cp.scan_type, log2n); const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   const int32_t *src = s.tc; int16_t *dst = s.lvl;
-  double *cost_coeff = s.u.q.cost_coeff, *cost_sig = s.u.q.cost_sig;
-  int32_t *rate_inc_up = s.u.q.rate_up, *rate_inc_down = s.u.q.rate_down, *sig_rate_delta = s.u.q.sig_delta, *delta_u = s.u.q.delta_u;
+  double *cost_coeff = k.q_cost, *cost_sig = k.q_cost + 1024;
+  int32_t *rate_inc_up = k.q_rate, *rate_inc_down = k.q_rate + 1024, *sig_rate_delta = k.q_rate + 2048, *delta_u = k.q_rate + 3072;
   double *cost_cg_sig = s.cg_cost; uint8_t *cgf = s.cgf;
   auto level_double = [&](int blk) -> int32_t {
     const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
@@ -1697,6 +1696,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   k.labels = p.labels + (size_t)frame * k.nctu * 16;
   unsigned char *scr = p.scratch + (size_t)frame * p.scratch_per_frame;
   k.coef_l = reinterpret_cast<int16_t *>(scr); k.rec_l = scr + 4 * 6144 * 2; k.best_rec = k.rec_l + 4 * 6144;
+  k.q_cost = reinterpret_cast<double *>(scr + 81920); k.q_rate = reinterpret_cast<int32_t *>(scr + 81920 + 16384);
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = p.dbgbuf;
@@ -1799,4 +1799,4 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
 }
 
 extern "C" size_t hevcdl_rd_smem_bytes(void) { return sizeof(RdSmem); }
-extern "C" size_t hevcdl_rd_scratch_bytes(void) { return 4 * 6144 * 2 + 4 * 6144 + 6144 + 1024; }
+extern "C" size_t hevcdl_rd_scratch_bytes(void) { return 81920 + 16384 + 16384; }   // layers 79872 (padded) + RDOQ costs + SBH inputs
