@@ -92,17 +92,16 @@ struct RdSmem {
   uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
   int16_t line[264], fline[264];      // reference samples: bottom-left ... corner(2n) ... top-right
   int32_t tc[1024];                   // transform coefficients (RDOQ input) / dequantised coefficients
-  int16_t resi[1024];
+  int16_t resi[32 * 34];              // residual, row stride n+2 (bank-conflict-free column access)
   int16_t lvl[1024];                  // quantised levels of the current TU (TU raster)
   uint8_t pred[1024];                 // prediction, then reconstruction, of the current TU
   uint16_t scan_all[3][1360];         // grouped-4x4 coefficient scans (TComRom.cpp:179-260): [type][4x4 | 8x8 | 16x16 | 32x32]
   uint8_t scan_cg_all[3][88];         // CG order per [type][1 | 4 | 16 | 64 groups]
-  int16_t dct[32 * 32];               // T32[k][n]; T_N[k][n] = T32[k*32/N][n]
   // small constant tables copied to LDS once per kernel: the serial RDOQ / bin-counting code reads them with
   // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
   int32_t t_ebits[128]; uint8_t t_next[2][128];
-  int t_ang[9], t_inv_ang[9]; int8_t t_dst4[16]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
-  struct { int32_t tmp[1024]; } u;   // transform intermediate
+  int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
+  struct { int32_t tmp[32 * 33]; } u; // transform intermediate, row stride n+1
   uint8_t sv_tr[256], sv_cbf[3][256], sv_ts[3][256];
   uint8_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
   unsigned int satd[36];
@@ -361,52 +360,126 @@ DEVN void predict_block(const K &k, int c_, int mode_, int n_)
 // ---------------------------------------------------------------------------------------------------
 // transforms (TComTrQuant.cpp:388-987): lane-parallel dot products, matrices in LDS
 // ---------------------------------------------------------------------------------------------------
-DEV int tmat(const K &k, int use_dst, int log2n, int kk, int i)
-{
-  return use_dst ? (int)k.s->t_dst4[kk * 4 + i] : (int)k.s->dct[(kk << (5 - log2n)) * 32 + i];
+// ---- transform kernels ----------------------------------------------------------------------------------
+// One lane per row/column runs the 1-D transform of the reference as its partial-butterfly factorisation
+// (TComTrQuant.cpp:388-855) with compile-time matrix entries; integer arithmetic is exact, so the factorisation
+// equals the matrix product the oracle uses.  LDS layouts are padded so that every access is conflict-free:
+//   resi  int16  row stride n+2      tmp  int32  row stride n+1      tc  int32  raster (stride n)
+constexpr int DCT_MAG[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                              61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+constexpr int dct32(int k, int n) { int m = ((2 * n + 1) * k) & 127; if (m > 64) m = 128 - m; return m <= 32 ? DCT_MAG[m] : -DCT_MAG[64 - m]; }
+template <int N> constexpr int dctn(int k, int n) { return dct32(k * (32 / N), n); }     // T_N[k][n]
+constexpr int DST4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+DEV int RS(int n) { return n + 2; }
+DEV int TS(int n) { return n + 1; }
+
+template <int N> DEV void fwd1d(const int (&x)[N], int (&y)[N])
+{ // y[k] = sum_n T_N[k][n] x[n]
+  if constexpr (N == 2) { y[0] = 64 * (x[0] + x[1]); y[1] = 64 * (x[0] - x[1]); }
+  else {
+    int e[N / 2], o[N / 2], ye[N / 2];
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) { e[k] = x[k] + x[N - 1 - k]; o[k] = x[k] - x[N - 1 - k]; }
+    fwd1d<N / 2>(e, ye);
+#pragma unroll
+    for (int r = 0; r < N / 2; r++) {
+      y[2 * r] = ye[r];
+      int acc = 0;
+#pragma unroll
+      for (int k = 0; k < N / 2; k++) acc += dctn<N>(2 * r + 1, k) * o[k];
+      y[2 * r + 1] = acc;
+    }
+  }
+}
+template <int N> DEV void inv1d(const int (&c)[N], int (&x)[N])
+{ // x[n] = sum_k T_N[k][n] c[k]
+  if constexpr (N == 2) { x[0] = 64 * (c[0] + c[1]); x[1] = 64 * (c[0] - c[1]); }
+  else {
+    int ce[N / 2], e[N / 2];
+#pragma unroll
+    for (int r = 0; r < N / 2; r++) ce[r] = c[2 * r];
+    inv1d<N / 2>(ce, e);
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+      int o = 0;
+#pragma unroll
+      for (int r = 0; r < N / 2; r++) o += dctn<N>(2 * r + 1, k) * c[2 * r + 1];
+      x[k] = e[k] + o; x[N - 1 - k] = e[k] - o;
+    }
+  }
+}
+DEV void dst4_fwd(const int (&x)[4], int (&y)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) y[k] = DST4[k][0] * x[0] + DST4[k][1] * x[1] + DST4[k][2] * x[2] + DST4[k][3] * x[3];
+}
+DEV void dst4_inv(const int (&c)[4], int (&x)[4]) {
+#pragma unroll
+  for (int n = 0; n < 4; n++) x[n] = DST4[0][n] * c[0] + DST4[1][n] * c[1] + DST4[2][n] * c[2] + DST4[3][n] * c[3];
+}
+
+template <int N, bool DST> DEV void fwd_transform_n(const K &k)
+{ // s->resi (stride RS) -> s->tc (raster); xTrMxN TComTrQuant.cpp:860-915
+  constexpr int LOG2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
+  constexpr int s1 = LOG2 + 8 - 9, s2 = LOG2 + 6, a1 = 1 << (s1 - 1), a2 = 1 << (s2 - 1);
+  RdSmem &s = *k.s;
+  if (k.lane < N) {
+    int x[N], y[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = s.resi[k.lane * (N + 2) + i];
+    if constexpr (DST) dst4_fwd(x, y); else fwd1d<N>(x, y);
+#pragma unroll
+    for (int kk = 0; kk < N; kk++) s.u.tmp[k.lane * (N + 1) + kk] = (y[kk] + a1) >> s1;       // tmp[j][kk]
+  }
+  wsync();
+  if (k.lane < N) {
+    int x[N], y[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = s.u.tmp[j * (N + 1) + k.lane];                          // column kk = lane
+    if constexpr (DST) dst4_fwd(x, y); else fwd1d<N>(x, y);
+#pragma unroll
+    for (int k2 = 0; k2 < N; k2++) s.tc[k2 * N + k.lane] = (y[k2] + a2) >> s2;
+  }
+  wsync();
+}
+template <int N, bool DST> DEV void inv_transform_n(const K &k)
+{ // s->tc (dequantised, raster) -> s->resi (stride RS); xITrMxN TComTrQuant.cpp:927-987
+  RdSmem &s = *k.s;
+  if (k.lane < N) {
+    int c[N], x[N];
+#pragma unroll
+    for (int kk = 0; kk < N; kk++) c[kk] = s.tc[kk * N + k.lane];                               // column j = lane
+    if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
+#pragma unroll
+    for (int i = 0; i < N; i++) s.u.tmp[k.lane * (N + 1) + i] = clip16((x[i] + 64) >> 7);       // tmp[j][x]
+  }
+  wsync();
+  if (k.lane < N) {
+    int c[N], x[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) c[u] = s.u.tmp[u * (N + 1) + k.lane];                           // row y = lane
+    if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
+#pragma unroll
+    for (int i = 0; i < N; i++) s.resi[k.lane * (N + 2) + i] = (int16_t)clip16((x[i] + 2048) >> 12);
+  }
+  wsync();
 }
 DEVN void fwd_transform(const K &k, int n_, int use_dst_)
 {
-  PROF_T0();
-  const int n = uni(n_), use_dst = uni(use_dst_); // s->resi (stride n) -> s->tc
-  const int log2n = ilog2(n), s1 = log2n + 8 - 9, s2 = log2n + 6;
-  const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
-  for (int o = k.lane; o < n * n; o += 64) {
-    const int kk = o >> log2n, j = o & (n - 1);
-    int acc = 0;
-    for (int i = 0; i < n; i++) acc += tmat(k, use_dst, log2n, kk, i) * k.s->resi[j * n + i];
-    k.s->u.tmp[kk * n + j] = (acc + a1) >> s1;
-  }
-  wsync();
-  for (int o = k.lane; o < n * n; o += 64) {
-    const int kk = o >> log2n, j = o & (n - 1);
-    int acc = 0;
-    for (int i = 0; i < n; i++) acc += tmat(k, use_dst, log2n, kk, i) * k.s->u.tmp[j * n + i];
-    k.s->tc[kk * n + j] = (acc + a2) >> s2;
-  }
-  wsync();
-  PROF_ADD(k, 4);
+  const int n = uni(n_), use_dst = uni(use_dst_);
+  if (n == 32) fwd_transform_n<32, false>(k);
+  else if (n == 16) fwd_transform_n<16, false>(k);
+  else if (n == 8) fwd_transform_n<8, false>(k);
+  else if (use_dst) fwd_transform_n<4, true>(k);
+  else fwd_transform_n<4, false>(k);
 }
 DEVN void inv_transform(const K &k, int n_, int use_dst_)
 {
-  PROF_T0();
-  const int n = uni(n_), use_dst = uni(use_dst_); // s->tc (dequantised) -> s->resi
-  const int log2n = ilog2(n);
-  for (int o = k.lane; o < n * n; o += 64) {
-    const int j = o >> log2n, x = o & (n - 1);
-    int acc = 0;
-    for (int kk = 0; kk < n; kk++) acc += tmat(k, use_dst, log2n, kk, x) * k.s->tc[kk * n + j];
-    k.s->u.tmp[j * n + x] = clip16((acc + 64) >> 7);
-  }
-  wsync();
-  for (int o = k.lane; o < n * n; o += 64) {
-    const int j = o >> log2n, x = o & (n - 1);
-    int acc = 0;
-    for (int kk = 0; kk < n; kk++) acc += tmat(k, use_dst, log2n, kk, x) * k.s->u.tmp[kk * n + j];
-    k.s->resi[j * n + x] = (int16_t)clip16((acc + 2048) >> 12);
-  }
-  wsync();
-  PROF_ADD(k, 8);
+  const int n = uni(n_), use_dst = uni(use_dst_);
+  if (n == 32) inv_transform_n<32, false>(k);
+  else if (n == 16) inv_transform_n<16, false>(k);
+  else if (n == 8) inv_transform_n<8, false>(k);
+  else if (use_dst) inv_transform_n<4, true>(k);
+  else inv_transform_n<4, false>(k);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1095,10 +1168,10 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
   } else { wsync(); if (k.lane < 16) s.pred[k.lane] = s.ts_pred[comp][k.lane]; }
   wsync();
   const uint8_t *org = k.org[comp] + (size_t)y * ps + x;
-  for (int i = k.lane; i < n * n; i += 64) s.resi[i] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
+  for (int i = k.lane; i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
   wsync();
-  if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[i] << 5; wsync(); }
+  if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5; wsync(); }
   else fwd_transform(k, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
   { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (k.lane == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
@@ -1109,10 +1182,10 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
   if (abs_sum > 0) {
     for (int i = k.lane; i < n * n; i += 64) cl[i] = s.lvl[i];
     dequant(k, comp, n);
-    if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.resi[i] = (int16_t)((s.tc[i] + 16) >> 5); wsync(); }
+    if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((s.tc[i] + 16) >> 5); wsync(); }
     else inv_transform(k, n, !comp && n == 4);
   } else {
-    for (int i = k.lane; i < n * n; i += 64) { cl[i] = 0; s.resi[i] = 0; }
+    for (int i = k.lane; i < n * n; i += 64) { cl[i] = 0; s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = 0; }
     wsync();
   }
   uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
@@ -1120,7 +1193,7 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
   uint32_t d = 0;
   for (int i = k.lane; i < n * n; i += 64) {
     const int r = i >> log2n, cc = i & (n - 1);
-    const int v = clip8((int)s.pred[i] + (int)s.resi[i]);
+    const int v = clip8((int)s.pred[i] + (int)s.resi[r * RS(n) + cc]);
     s.pred[i] = (uint8_t)v; rq[r * cs + cc] = (uint8_t)v; rp[(size_t)r * ps + cc] = (uint8_t)v;
     const int df = v - (int)org[(size_t)r * ps + cc];
     d += (uint32_t)(df * df);
@@ -1701,20 +1774,15 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = p.dbgbuf;
 
-  // tables into LDS: z-scan map, 32-point DCT matrix
+  // tables into LDS: z-scan map, CABAC tables, scans
   for (int r = k.lane; r < 256; r += 64) {
     const int x = r & 15, y = r >> 4; int z = 0;
     for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
     s.r2z[r] = (uint8_t)z;
   }
-  for (int i = k.lane; i < 1024; i += 64) {
-    const int kk = i >> 5, n = i & 31; int m = ((2 * n + 1) * kk) & 127;
-    if (m > 64) m = 128 - m;
-    s.dct[i] = (int16_t)(m <= 32 ? c_dct_mag[m] : -c_dct_mag[64 - m]);
-  }
   for (int i = k.lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
   if (k.lane < 9) { s.t_ang[k.lane] = c_ang_table[k.lane]; s.t_inv_ang[k.lane] = c_inv_ang_table[k.lane]; }
-  if (k.lane < 16) { s.t_dst4[k.lane] = c_dst4[k.lane]; s.t_ctx_map4[k.lane] = c_ctx_ind_map_4x4[k.lane]; }
+  if (k.lane < 16) s.t_ctx_map4[k.lane] = c_ctx_ind_map_4x4[k.lane];
   if (k.lane < 32) s.t_group_idx[k.lane] = c_group_idx[k.lane];
   if (k.lane < 5) s.t_filter_thr[k.lane] = c_intra_filter_thr[k.lane];
   if (k.lane < 12) { // CG order of every (scan type, block size)
