@@ -570,6 +570,27 @@ DEV int ic_rate(const Cabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, 
   return rate;
 }
 
+// xGetICRate (TComTrQuant.cpp:2881-2955) with the group's greater-1 / greater-2 rates held in a wave register:
+// lane 2*c1+bin = m_greaterOneBits[4*ctxSet + c1][bin], lane 8+bin = m_levelAbsBits[ctxSet][bin] (the greater-2 rate
+// is only ever read while c2 == 0, i.e. before the first level > 1 of the group)
+DEV int ic_rate_r(int rtab, uint32_t abs_level, int c1, int go_rice, uint32_t c1idx, uint32_t c2idx)
+{
+  int rate = 32768;
+  const uint32_t base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
+  if (abs_level >= base) {
+    uint32_t symbol = abs_level - base, length;
+    if (symbol < (3u << go_rice)) { length = symbol >> go_rice; rate += (int)(length + 1 + go_rice) << 15; }
+    else {
+      length = go_rice; symbol -= (3u << go_rice);
+      while (symbol >= (1u << length)) symbol -= (1u << (length++));
+      rate += (int)(3 + length + 1 - go_rice + length) << 15;
+    }
+    if (c1idx < 8) { rate += __builtin_amdgcn_readlane(rtab, 2 * c1 + 1); if (c2idx < 1) rate += __builtin_amdgcn_readlane(rtab, 9); }
+  } else if (abs_level == 1) rate += __builtin_amdgcn_readlane(rtab, 2 * c1);
+  else if (abs_level == 2) { rate += __builtin_amdgcn_readlane(rtab, 2 * c1 + 1); rate += __builtin_amdgcn_readlane(rtab, 8); }
+  else rate = 0;
+  return rate;
+}
 DEV double rl_d(double v, int l)
 { // value of lane l (wave-uniform l) of a per-lane double
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -611,6 +632,12 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
   };
   auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
   // ---- phase A ----
+#ifdef HEVCDL_KERNEL_PROF
+  unsigned long long pt_ = __builtin_readcyclecounter();
+#define RDOQ_MARK(id) do { if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.prof[id] += n_ - pt_; s.prof_n[id]++; pt_ = n_; } } while (0)
+#else
+#define RDOQ_MARK(id) do { } while (0)
+#endif
   int my_last = -1;
   for (int sp = lane; sp < ncoef; sp += 64) {
     const int blk = scan[sp];
@@ -627,11 +654,13 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
   wsync();
   const int last_pos = uni(my_last);
   if (last_pos < 0) return 0;
+  RDOQ_MARK(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
   double block_uncoded = 0;
 #pragma unroll 8
   for (int sp = ncoef - 1; sp > last_pos; sp--) block_uncoded += cost_coeff[sp];      // zero-level costs above the last position
   double base_cost = block_uncoded;
+  RDOQ_MARK(19);
   const int cg_last = last_pos >> 4;
   int ctx_set = ctx_set_index(ch, cg_last, 0), c1 = 1, c2 = 0, go_rice = 0; uint32_t c1idx = 0, c2idx = 0;
   // ---- phase B ----
@@ -644,11 +673,13 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
     const int j = lane & 15, sp_j = cgpos * 16 + j, blk_j = scan[sp_j];
     const int32_t ld_j = level_double(blk_j);
     const int ma_j = dst[blk_j];
-    const double c0_j = cost_coeff[sp_j];
+    const double c0_j = (double)ld_j * (double)ld_j * err_scale;         // same arithmetic as phase A
     const int is_last_j = (sp_j == last_pos);
     const int sigctx_j = is_last_j ? 0 : sig_off + sig_ctx_inc(cp, scan, pat, sp_j);
     const int b0_j = is_last_j ? 0 : ctx_bits(cab, sigctx_j, 0), b1_j = is_last_j ? 0 : ctx_bits(cab, sigctx_j, 1);
     const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
+    const int rtab = (lane < 8) ? ctx_bits(cab, CTX_ONE + 4 * ctx_set + (lane >> 1), lane & 1)
+                   : ((lane < 10) ? ctx_bits(cab, CTX_ABS + ctx_set, lane & 1) : 0);
     // per-position results, filled for lane == pin while the state machine walks the group
     int lvl_j = 0, c1_j = 1, ru_j = 0, rd_j = 0;
     double cc_j = c0_j + cs0_j, cs_j = cs0_j;                       // the zero-level outcome
@@ -665,7 +696,6 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
         if (lane == pin) c1_j = c1;
       } else {
         const int32_t ld = __builtin_amdgcn_readlane(ld_j, pin);
-        const int one_ctx = 4 * ctx_set + c1, abs_ctx = ctx_set + c2;
         const int is_last = (sp == last_pos);
         { // xGetCodedLevel TComTrQuant.cpp:2812-2879
           double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0;
@@ -675,7 +705,7 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
           const uint32_t min_abs = max_abs > 1 ? (uint32_t)max_abs - 1 : 1;
           for (int al = max_abs; al >= (int)min_abs; al--) {
             const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
-            double cur = err * err * err_scale + lambda * (double)ic_rate(cab, (uint32_t)al, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
+            double cur = err * err * err_scale + lambda * (double)ic_rate_r(rtab, (uint32_t)al, c1, go_rice, c1idx, c2idx);
             cur += cur_sig;
             if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_s = cur_sig; }
           }
@@ -683,10 +713,10 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
         }
         int rup, rdn = 0;
         if (level > 0) {
-          const int now = ic_rate(cab, level, one_ctx, abs_ctx, go_rice, c1idx, c2idx);
-          rup = ic_rate(cab, level + 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
-          rdn = ic_rate(cab, level - 1, one_ctx, abs_ctx, go_rice, c1idx, c2idx) - now;
-        } else rup = ctx_bits(cab, CTX_ONE + one_ctx, 0);
+          const int now = ic_rate_r(rtab, level, c1, go_rice, c1idx, c2idx);
+          rup = ic_rate_r(rtab, level + 1, c1, go_rice, c1idx, c2idx) - now;
+          rdn = ic_rate_r(rtab, level - 1, c1, go_rice, c1idx, c2idx) - now;
+        } else rup = __builtin_amdgcn_readlane(rtab, 2 * c1);
         if (lane == pin) { lvl_j = (int)level; cc_j = cost_c; cs_j = cost_s; ru_j = rup; rd_j = rdn; c1_j = -1; }
         const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
         if (level >= base_level) { if (level > 3u * (1u << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4; }
@@ -705,13 +735,14 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
         if (pin != 0) st_nnz_before0++;
       }
     }
-    // lane-parallel write-back of the group
+    // lane-parallel write-back of the group (the bpermute runs with all lanes enabled: a disabled source lane reads 0)
+    const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
     if (lane < 16 && j <= start_pin) {
       dst[blk_j] = (int16_t)lvl_j;
       cost_coeff[sp_j] = cc_j; cost_sig[sp_j] = cs_j;
       sig_rate_delta[blk_j] = b1_j - b0_j;                         // 0 at the last position
       delta_u[blk_j] = (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8));
-      rate_inc_up[blk_j] = (c1_j >= 0) ? ctx_bits(cab, CTX_ONE + 4 * cg_ctx_set + c1_j, 0) : ru_j;
+      rate_inc_up[blk_j] = (c1_j >= 0) ? ru0_j : ru_j;
       rate_inc_down[blk_j] = rd_j;
     }
     if (cg_nonzero) cgf[cgblk] = 1;
@@ -740,8 +771,11 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
     } else if (lane == 0) cgf[cgblk] = 1;
     wsync();
   }
-  // ---- phase C: last position (lane 0), TComTrQuant.cpp:2440-2528 ----
-  if (lane == 0) {
+  RDOQ_MARK(20);
+  // ---- phase C: last position, TComTrQuant.cpp:2440-2528.  Per CG the 16 positions' costs are fetched
+  // lane-parallel, the walk itself is wave-uniform (readlane) and usually ends inside the first group ----
+  int best_last_p1 = 0;
+  {
     double best_cost;
     {
       const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
@@ -749,44 +783,48 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
       base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
     }
     int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
-    { // TEncSbac.cpp:1910-1930
+    { // TEncSbac.cpp:1910-1930 (prefix sums are integers: any evaluation order)
       int off, shift; last_ctx_params(ch, n, off, shift);
       const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
-      int accx = 0, accy = 0, kk; const int ng = s.t_group_idx[n - 1];
-      for (kk = 0; kk < ng; kk++) {
-        last_x_bits[kk] = accx + ctx_bits(cab, bx + off + (kk >> shift), 0); accx += ctx_bits(cab, bx + off + (kk >> shift), 1);
-        last_y_bits[kk] = accy + ctx_bits(cab, by + off + (kk >> shift), 0); accy += ctx_bits(cab, by + off + (kk >> shift), 1);
+      const int ng = s.t_group_idx[n - 1];
+      if (lane == 0) {
+        int accx = 0, accy = 0, kk;
+        for (kk = 0; kk < ng; kk++) {
+          last_x_bits[kk] = accx + ctx_bits(cab, bx + off + (kk >> shift), 0); accx += ctx_bits(cab, bx + off + (kk >> shift), 1);
+          last_y_bits[kk] = accy + ctx_bits(cab, by + off + (kk >> shift), 0); accy += ctx_bits(cab, by + off + (kk >> shift), 1);
+        }
+        last_x_bits[kk] = accx; last_y_bits[kk] = accy;
       }
-      last_x_bits[kk] = accx; last_y_bits[kk] = accy;
+      wsync();
     }
-    int best_last_p1 = 0, found_last = 0;
+    int found_last = 0;
     for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
-      const int cgblk = scan_cg[cgpos];
+      const int cgblk = uni(scan_cg[cgpos]);
       base_cost -= cost_cg_sig[cgpos];
-      if (!cgf[cgblk]) continue;
-      for (int pin = 15; pin >= 0; pin--) {
-        const int sp = cgpos * 16 + pin;
-        if (sp > last_pos) continue;
-        const int blk = scan[sp];
-        if (dst[blk]) {
-          int py = blk >> log2n, px = blk - (py << log2n);
-          if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-          const int gx2 = s.t_group_idx[px], gy2 = s.t_group_idx[py];
-          double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
-          if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
-          if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
-          const double cost_last = lambda * lc;
-          const double total = base_cost + cost_last - cost_sig[sp];
-          if (total < best_cost) { best_last_p1 = sp + 1; best_cost = total; }
-          if (dst[blk] > 1) { found_last = 1; break; }
-          base_cost -= cost_coeff[sp]; base_cost += cost0_of(blk);
-        } else base_cost -= cost_sig[sp];
+      if (!uni(cgf[cgblk])) continue;
+      const int j = lane & 15, sp_j = cgpos * 16 + j, blk_j = scan[sp_j];
+      const int lv_j = dst[blk_j];
+      const double cc_j = cost_coeff[sp_j], cs_j = cost_sig[sp_j], c0_j = cost0_of(blk_j);
+      int py = blk_j >> log2n, px = blk_j - (py << log2n);
+      if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
+      const int gx2 = s.t_group_idx[px], gy2 = s.t_group_idx[py];
+      double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
+      if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
+      if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
+      const double cl_j = lambda * lc;
+      for (int pin = (cgpos == cg_last) ? (last_pos & 15) : 15; pin >= 0; pin--) {
+        const int lv = __builtin_amdgcn_readlane(lv_j, pin);
+        if (lv) {
+          const double total = base_cost + rl_d(cl_j, pin) - rl_d(cs_j, pin);
+          if (total < best_cost) { best_last_p1 = cgpos * 16 + pin + 1; best_cost = total; }
+          if (lv > 1) { found_last = 1; break; }
+          base_cost -= rl_d(cc_j, pin); base_cost += rl_d(c0_j, pin);
+        } else base_cost -= rl_d(cs_j, pin);
       }
     }
-    s.bc_u32[3] = (unsigned)best_last_p1;
   }
-  wsync();
-  const int best_last_p1 = uni((int)s.bc_u32[3]);
+
+  RDOQ_MARK(21);
   // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact)
   uint32_t abs_sum = 0;
   for (int sp = lane; sp <= last_pos; sp += 64) {
@@ -848,6 +886,7 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
     }
   }
   wsync();
+  RDOQ_MARK(22);
   return (uint32_t)uni((int)abs_sum);
 }
 
