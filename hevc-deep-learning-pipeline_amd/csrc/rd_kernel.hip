@@ -79,14 +79,40 @@ __constant__ int8_t c_dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74,
 __constant__ int8_t c_dct_mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
                                       61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };   // TComRom.cpp:376-517
 
+// Address spaces are spelled out: a generic pointer would make every LDS access a FLAT instruction (longer latency,
+// and it ties LDS traffic to vmcnt, i.e. to every outstanding global store).
+#define LDS __attribute__((address_space(3)))
+#define GLB __attribute__((address_space(1)))
 struct __attribute__((aligned(8))) Cabac { uint8_t ctx[160]; unsigned long long frac; };   // 168 bytes
+typedef LDS Cabac LCabac;
 struct Rd { double cost; uint32_t bits, dist; };
+struct DistCost { uint32_t dist; double cost; };
 struct Cu { int x, y, log2, depth, zbase, nparts, part; };
 struct Tu { int x, y, log2, trd, zrel, nparts; };
 DEV int uni(int v);
 
+struct K {                             // wave-uniform kernel context (lives in LDS)
+  int W, H, cw, ctus_x, addr, cx, cy, nctu;
+  GLB const uint8_t *org[3];
+  GLB uint8_t *rec[3];
+  GLB unsigned char *records;          // frame's records (global)
+  GLB const uint8_t *labels;           // frame's labels
+  GLB int16_t *coef_l;                 // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
+  GLB uint8_t *rec_l;                  // scratch: [4 layers][6144] CTU-relative reconstruction
+  GLB uint8_t *best_rec;               // scratch: [6144] best reconstruction of the CU under test
+  GLB double *q_cost;                  // scratch: RDOQ per-position costs [2][1024] (coded cost, sig cost); written/read lane-parallel,
+  GLB int32_t *q_rate;                 //          and SBH inputs [4][1024] (rateIncUp, rateIncDown, sigRateDelta, deltaU)
+  double lambda, sqrt_lambda, cweight, lambda_c;
+  double err_scale[2][4];
+  long long sbh[2];
+  int qp, qp_c;
+  int dbg;
+  GLB unsigned int *dbgbuf;
+};
+typedef const LDS K &KR;
 
 struct RdSmem {
+  K k;
   Cabac go, curr[5], next[5], temp[5], root[5], test[5], tbest[5], truec;
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
   uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
@@ -110,42 +136,31 @@ struct RdSmem {
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
-  uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];
+  uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
   unsigned long long prof[24]; unsigned int prof_n[24];
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
-  int last_bits[2][12];   // saved 2Nx2N candidate of an 8x8 CU
+  int last_bits[2][12];
 };
+typedef LDS RdSmem LSmem;
 
-struct K {                             // wave-uniform kernel context
-  RdSmem *s;
-  int lane;
-  int W, H, cw, ctus_x, addr, cx, cy, nctu;
-  const uint8_t *org[3];
-  uint8_t *rec[3];
-  unsigned char *records;              // frame's records (global)
-  const uint8_t *labels;               // frame's labels
-  int16_t *coef_l;                     // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
-  uint8_t *rec_l;                      // scratch: [4 layers][6144] CTU-relative reconstruction
-  uint8_t *best_rec;                   // scratch: [6144] best reconstruction of the CU under test
-  double *q_cost;                      // scratch: RDOQ per-position costs [2][1024] (coded cost, sig cost); written/read lane-parallel,
-  int32_t *q_rate;                     //          and SBH inputs [4][1024] (rateIncUp, rateIncDown, sigRateDelta, deltaU)
-  double lambda, sqrt_lambda, cweight, lambda_c;
-  double err_scale[2][4];
-  long long sbh[2];
-  int qp, qp_c;
-  int dbg;
-  unsigned int *dbgbuf;
-};
-
-// the workgroup's RdSmem sits at dynamic-LDS offset 0: constant tables are reachable without threading a pointer through
-DEV const RdSmem *smem_of() { extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[]; return reinterpret_cast<const RdSmem *>(smem_raw_); }
-DEV void wsync() { __syncthreads(); }
+// the workgroup's RdSmem sits at dynamic-LDS offset 0 (single-wave workgroups): every function reaches it directly
+DEV LSmem &lds() { extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[]; return *(LSmem *)smem_raw_; }
+DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// Single-wave workgroup: "barrier" = ordering of this wave's own memory operations as seen by its other lanes.
+// The hardware keeps a wave's LDS operations, and its vector-memory operations to one address, in program order, so
+// a wavefront-scope fence (a compiler-only constraint: no s_waitcnt vmcnt(0), no cache action) is sufficient.
+DEV void wsync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #ifdef HEVCDL_KERNEL_PROF
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
-#define PROF_ADD(k, id) do { if ((k).lane == 0) { (k).s->prof[id] += __builtin_readcyclecounter() - prof_t0_; (k).s->prof_n[id]++; } } while (0)
+#define PROF_ADD(k, id) do { if (lane_id() == 0) { lds().prof[id] += __builtin_readcyclecounter() - prof_t0_; lds().prof_n[id]++; } } while (0)
 #else
 #define PROF_T0() do { } while (0)
 #define PROF_ADD(k, id) do { } while (0)
@@ -158,8 +173,8 @@ DEV Cu ucu(const Cu &c) { Cu r = { uni(c.x), uni(c.y), uni(c.log2), uni(c.depth)
 DEV Tu utu(const Tu &t) { Tu r = { uni(t.x), uni(t.y), uni(t.log2), uni(t.trd), uni(t.zrel), uni(t.nparts) }; return r; }
 DEV int comp_off(int c) { return c == 0 ? 0 : (c == 1 ? 4096 : 5120); }
 DEV int cstride(int c) { return c ? 32 : 64; }
-DEV int pstride(const K &k, int c) { return c ? k.cw : k.W; }
-DEV int boff(const K &k, int c, int x, int y) { const int s = c ? 32 : 64; return (y - k.cy * s) * s + (x - k.cx * s); }
+DEV int pstride(KR k, int c) { return c ? k.cw : k.W; }
+DEV int boff(KR k, int c, int x, int y) { const int s = c ? 32 : 64; return (y - k.cy * s) * s + (x - k.cx * s); }
 // log2 of a block size in {4,8,16,32,64}.  NOT 31-clz(n): that form let the compiler fold the constant part of a
 // dynamic index into a FLAT instruction's immediate offset with a base BELOW the indexed private object; gfx9-family
 // hardware picks the aperture from the base alone (offset ignored) -> HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
@@ -170,58 +185,58 @@ DEV int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 // ---------------------------------------------------------------------------------------------------
 // CABAC estimator (TEncBinCoderCABACCounter.cpp:60-140); the coder state lives in LDS and is touched by lane 0 only
 // ---------------------------------------------------------------------------------------------------
-DEV void enc_bin(Cabac *c, int ctx, int bin)
+DEV void enc_bin(LCabac *c, int ctx, int bin)
 {
-  const RdSmem *t = smem_of();
+  LSmem &t = lds();
   const uint8_t st = c->ctx[ctx];
-  c->frac += (unsigned long long)t->t_ebits[st ^ bin];
-  c->ctx[ctx] = t->t_next[(st & 1) == bin][st];
+  c->frac += (unsigned long long)t.t_ebits[st ^ bin];
+  c->ctx[ctx] = t.t_next[(st & 1) == bin][st];
 }
-DEV void enc_ep(Cabac *c, int n) { c->frac += 32768ull * (unsigned long long)n; }
-DEV void reset_bits(Cabac *c) { c->frac &= 32767ull; }
-DEV uint32_t get_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
-DEV int ctx_bits(const Cabac *c, int ctx, int bin) { return smem_of()->t_ebits[c->ctx[ctx] ^ bin]; }
-DEV void cabac_copy(const K &k, Cabac *dst, const Cabac *src)
+DEV void enc_ep(LCabac *c, int n) { c->frac += 32768ull * (unsigned long long)n; }
+DEV void reset_bits(LCabac *c) { c->frac &= 32767ull; }
+DEV uint32_t get_bits(const LCabac *c) { return (uint32_t)(c->frac >> 15); }
+DEV int ctx_bits(const LCabac *c, int ctx, int bin) { return lds().t_ebits[c->ctx[ctx] ^ bin]; }
+DEV void cabac_copy(KR k, LCabac *dst, const LCabac *src)
 { // wave-parallel 168-byte snapshot copy (TEncSbac::load/store, TEncSbac.cpp:396-425)
   PROF_T0();
   wsync();
-  if (k.lane < 21) reinterpret_cast<unsigned long long *>(dst)[k.lane] = reinterpret_cast<const unsigned long long *>(src)[k.lane];
+  if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()];
   wsync();
   PROF_ADD(k, 12);
 }
-DEV double calc_rd_cost(const K &k, uint32_t bits, uint32_t dist)
+DEV double calc_rd_cost(KR k, uint32_t bits, uint32_t dist)
 { // TComRdCost.cpp:62-107
 #ifdef HEVCDL_KERNEL_DEBUG
-  if (k.dbgbuf && k.lane == 0) { unsigned int n_ = k.dbgbuf[0]; if (n_ < 100000) { k.dbgbuf[1 + 2 * n_] = bits; k.dbgbuf[2 + 2 * n_] = dist; k.dbgbuf[0] = n_ + 1; } }
+  if (k.dbgbuf && lane_id() == 0) { unsigned int n_ = k.dbgbuf[0]; if (n_ < 100000) { k.dbgbuf[1 + 2 * n_] = bits; k.dbgbuf[2 + 2 * n_] = dist; k.dbgbuf[0] = n_ + 1; } }
 #endif
   return (double)dist + ((double)bits * k.lambda);
 }
 
-DEV void set_parts(const K &k, uint8_t *a, int z0, int n, int v)
+DEV void set_parts(KR k, LDS uint8_t *a, int z0, int n, int v)
 {
-  for (int i = k.lane; i < n; i += 64) a[z0 + i] = (uint8_t)v;
+  for (int i = lane_id(); i < n; i += 64) a[z0 + i] = (uint8_t)v;
 }
 
 // attribute of the 4x4 partition (x4,y4) of the picture: current CTU from LDS, earlier CTUs from their records
-DEV int part_attr(const K &k, int field, int x4, int y4)
+DEV int part_attr(KR k, int field, int x4, int y4)
 {
-  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), z = k.s->r2z[((y4 & 15) << 4) | (x4 & 15)];
-  if (a == k.addr) return k.s->a[field][z];
+  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), z = lds().r2z[((y4 & 15) << 4) | (x4 & 15)];
+  if (a == k.addr) return lds().a[field][z];
   return k.records[(size_t)a * REC_SIZE + field * 256 + z];
 }
 
 // ---------------------------------------------------------------------------------------------------
 // reference samples (TComPattern.cpp:119-543)
 // ---------------------------------------------------------------------------------------------------
-DEV int unit_avail(const K &k, int x4, int y4, int cur_x4, int cur_y4)
+DEV int unit_avail(KR k, int x4, int y4, int cur_x4, int cur_y4)
 { // inside the picture and already coded: earlier CTU, or earlier z-order in this CTU (TComDataCU.cpp:985-1200)
   if (x4 < 0 || y4 < 0 || x4 * 4 >= k.W || y4 * 4 >= k.H) return 0;
   const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4);
   if (a != k.addr) return a < k.addr;
-  return k.s->r2z[((y4 & 15) << 4) | (x4 & 15)] < k.s->r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
+  return lds().r2z[((y4 & 15) << 4) | (x4 & 15)] < lds().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
 }
 
-DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
+DEVN void build_refs(KR k, int c_, int x_, int y_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), x = uni(x_), y = uni(y_), n = uni(n_);
@@ -233,11 +248,11 @@ DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
     if (kk == 2 * nu) return unit_avail(k, x4 - 1, y4 - 1, x4, y4);
     return unit_avail(k, x4 + (kk - 2 * nu - 1), y4 - 1, x4, y4);
   };
-  const int f0 = (k.lane < total) ? unit_flag(k.lane) : 0;
+  const int f0 = (lane_id() < total) ? unit_flag(lane_id()) : 0;
   const unsigned long long m0 = __ballot(f0);
   const int f64 = (total > 64) ? unit_flag(64) : 0;          // uniform
   const int st = pstride(k, c);
-  const uint8_t *p = k.rec[c];
+  GLB const uint8_t *p = k.rec[c];
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
   auto sample = [&](int i) -> int {                          // picture sample behind line index i
@@ -245,7 +260,7 @@ DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
     if (i == 2 * n) return p[(size_t)(y - 1) * st + x - 1];
     return p[(size_t)(y - 1) * st + x + (i - 2 * n - 1)];
   };
-  for (int i = k.lane; i <= 4 * n; i += 64) {
+  for (int i = lane_id(); i <= 4 * n; i += 64) {
     int kk = i < 2 * n ? i / u : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / u);
     int v;
     const int fl = kk < 64 ? (int)((m0 >> kk) & 1) : f64;
@@ -261,22 +276,22 @@ DEVN void build_refs(const K &k, int c_, int x_, int y_, int n_)
         else v = 128;
       }
     }
-    k.s->line[i] = (int16_t)v;
+    lds().line[i] = (int16_t)v;
   }
   wsync();
   PROF_ADD(k, 0);
 }
 
-DEVN void filter_refs(const K &k, int n_)
+DEVN void filter_refs(KR k, int n_)
 {
   PROF_T0();
   const int n = uni(n_); // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
-  const int16_t *src = k.s->line; int16_t *dst = k.s->fline;
+  LDS const int16_t *src = lds().line; LDS int16_t *dst = lds().fline;
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
   const int bl = src[0], tl = src[n2], tr = src[last];
   if (n >= 32) strong = (abs(bl + tl - 2 * src[n]) < 8) && (abs(tl + tr - 2 * src[n2 + n]) < 8);
-  for (int i = k.lane; i <= last; i += 64) {
+  for (int i = lane_id(); i <= last; i += 64) {
     int v;
     if (i == 0 || i == last) v = src[i];
     else if (strong) {
@@ -295,11 +310,11 @@ DEV int use_filtered_refs(int c, int mode, int n)
 { // TComPattern.cpp:545-570; chroma never in 4:2:0
   if (c || mode == DC) return 0;
   const int d1 = abs(mode - HOR), d2 = abs(mode - VER), diff = d1 < d2 ? d1 : d2;
-  return diff > smem_of()->t_filter_thr[ilog2(n) - 2];
+  return diff > lds().t_filter_thr[ilog2(n) - 2];
 }
 
 // closed-form intra prediction of one sample (TComPrediction.cpp:183-473, 731-817); dcval only for DC
-DEV int pred_pixel(const int16_t *line, int c, int mode, int n, int log2n, int px, int py, int dcval)
+DEV int pred_pixel(LDS const int16_t *line, int c, int mode, int n, int log2n, int px, int py, int dcval)
 {
   const int n2 = 2 * n;
   if (mode == PLANAR) {
@@ -317,8 +332,8 @@ DEV int pred_pixel(const int16_t *line, int c, int mode, int n, int log2n, int p
   const int is_ver = mode >= 18;
   const int ang_mode = is_ver ? mode - VER : -(mode - HOR);
   const int abs_ang = abs(ang_mode);
-  const int angle = (ang_mode < 0 ? -1 : 1) * smem_of()->t_ang[abs_ang];
-  const int inv_angle = smem_of()->t_inv_ang[abs_ang];
+  const int angle = (ang_mode < 0 ? -1 : 1) * lds().t_ang[abs_ang];
+  const int inv_angle = lds().t_inv_ang[abs_ang];
   const int x = is_ver ? px : py, y = is_ver ? py : px;
   auto ref = [&](int i) -> int {
     if (i >= 0) return is_ver ? line[n2 + i] : line[n2 - i];
@@ -335,24 +350,24 @@ DEV int pred_pixel(const int16_t *line, int c, int mode, int n, int log2n, int p
   return ref(x + di + 1);
 }
 
-DEV int dc_value(const K &k, const int16_t *line, int n)
+DEV int dc_value(KR k, LDS const int16_t *line, int n)
 { // predIntraGetPredValDC TComPrediction.cpp:183-201
   const int n2 = 2 * n;
   int s = 0;
-  for (int i = k.lane; i < n; i += 64) s += line[n2 + 1 + i] + line[n2 - 1 - i];
+  for (int i = lane_id(); i < n; i += 64) s += line[n2 + 1 + i] + line[n2 - 1 - i];
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
   return (s + n) / (n + n);
 }
 
 // prediction of an n x n TU (n <= 32) into s->pred (stride n)
-DEVN void predict_block(const K &k, int c_, int mode_, int n_)
+DEVN void predict_block(KR k, int c_, int mode_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), mode = uni(mode_), n = uni(n_);
-  const int16_t *line = use_filtered_refs(c, mode, n) ? k.s->fline : k.s->line;
+  LDS const int16_t *line = use_filtered_refs(c, mode, n) ? lds().fline : lds().line;
   const int log2n = ilog2(n);
   const int dcv = (mode == DC) ? dc_value(k, line, n) : 0;
-  for (int i = k.lane; i < n * n; i += 64) k.s->pred[i] = (uint8_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
+  for (int i = lane_id(); i < n * n; i += 64) lds().pred[i] = (uint8_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
   wsync();
   PROF_ADD(k, 3);
 }
@@ -417,53 +432,53 @@ DEV void dst4_inv(const int (&c)[4], int (&x)[4]) {
   for (int n = 0; n < 4; n++) x[n] = DST4[0][n] * c[0] + DST4[1][n] * c[1] + DST4[2][n] * c[2] + DST4[3][n] * c[3];
 }
 
-template <int N, bool DST> DEV void fwd_transform_n(const K &k)
+template <int N, bool DST> DEV void fwd_transform_n(KR k)
 { // s->resi (stride RS) -> s->tc (raster); xTrMxN TComTrQuant.cpp:860-915
   constexpr int LOG2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
   constexpr int s1 = LOG2 + 8 - 9, s2 = LOG2 + 6, a1 = 1 << (s1 - 1), a2 = 1 << (s2 - 1);
-  RdSmem &s = *k.s;
-  if (k.lane < N) {
+  LSmem &s = lds();
+  if (lane_id() < N) {
     int x[N], y[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) x[i] = s.resi[k.lane * (N + 2) + i];
+    for (int i = 0; i < N; i++) x[i] = s.resi[lane_id() * (N + 2) + i];
     if constexpr (DST) dst4_fwd(x, y); else fwd1d<N>(x, y);
 #pragma unroll
-    for (int kk = 0; kk < N; kk++) s.u.tmp[k.lane * (N + 1) + kk] = (y[kk] + a1) >> s1;       // tmp[j][kk]
+    for (int kk = 0; kk < N; kk++) s.u.tmp[lane_id() * (N + 1) + kk] = (y[kk] + a1) >> s1;       // tmp[j][kk]
   }
   wsync();
-  if (k.lane < N) {
+  if (lane_id() < N) {
     int x[N], y[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) x[j] = s.u.tmp[j * (N + 1) + k.lane];                          // column kk = lane
+    for (int j = 0; j < N; j++) x[j] = s.u.tmp[j * (N + 1) + lane_id()];                          // column kk = lane
     if constexpr (DST) dst4_fwd(x, y); else fwd1d<N>(x, y);
 #pragma unroll
-    for (int k2 = 0; k2 < N; k2++) s.tc[k2 * N + k.lane] = (y[k2] + a2) >> s2;
+    for (int k2 = 0; k2 < N; k2++) s.tc[k2 * N + lane_id()] = (y[k2] + a2) >> s2;
   }
   wsync();
 }
-template <int N, bool DST> DEV void inv_transform_n(const K &k)
+template <int N, bool DST> DEV void inv_transform_n(KR k)
 { // s->tc (dequantised, raster) -> s->resi (stride RS); xITrMxN TComTrQuant.cpp:927-987
-  RdSmem &s = *k.s;
-  if (k.lane < N) {
+  LSmem &s = lds();
+  if (lane_id() < N) {
     int c[N], x[N];
 #pragma unroll
-    for (int kk = 0; kk < N; kk++) c[kk] = s.tc[kk * N + k.lane];                               // column j = lane
+    for (int kk = 0; kk < N; kk++) c[kk] = s.tc[kk * N + lane_id()];                               // column j = lane
     if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
 #pragma unroll
-    for (int i = 0; i < N; i++) s.u.tmp[k.lane * (N + 1) + i] = clip16((x[i] + 64) >> 7);       // tmp[j][x]
+    for (int i = 0; i < N; i++) s.u.tmp[lane_id() * (N + 1) + i] = clip16((x[i] + 64) >> 7);       // tmp[j][x]
   }
   wsync();
-  if (k.lane < N) {
+  if (lane_id() < N) {
     int c[N], x[N];
 #pragma unroll
-    for (int u = 0; u < N; u++) c[u] = s.u.tmp[u * (N + 1) + k.lane];                           // row y = lane
+    for (int u = 0; u < N; u++) c[u] = s.u.tmp[u * (N + 1) + lane_id()];                           // row y = lane
     if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
 #pragma unroll
-    for (int i = 0; i < N; i++) s.resi[k.lane * (N + 2) + i] = (int16_t)clip16((x[i] + 2048) >> 12);
+    for (int i = 0; i < N; i++) s.resi[lane_id() * (N + 2) + i] = (int16_t)clip16((x[i] + 2048) >> 12);
   }
   wsync();
 }
-DEVN void fwd_transform(const K &k, int n_, int use_dst_)
+DEVN void fwd_transform(KR k, int n_, int use_dst_)
 {
   const int n = uni(n_), use_dst = uni(use_dst_);
   if (n == 32) fwd_transform_n<32, false>(k);
@@ -472,7 +487,7 @@ DEVN void fwd_transform(const K &k, int n_, int use_dst_)
   else if (use_dst) fwd_transform_n<4, true>(k);
   else fwd_transform_n<4, false>(k);
 }
-DEVN void inv_transform(const K &k, int n_, int use_dst_)
+DEVN void inv_transform(KR k, int n_, int use_dst_)
 {
   const int n = uni(n_), use_dst = uni(use_dst_);
   if (n == 32) inv_transform_n<32, false>(k);
@@ -509,23 +524,23 @@ DEV void scan_next(int type, int bw, int bh, int &line, int &col)
   } else if (type == SCAN_HOR) { if (col == bw - 1) { line++; col = 0; } else col++; }
   else { if (line == bh - 1) { col++; line = 0; } else line++; }
 }
-DEV int pattern_sig_ctx(const uint8_t *cgf, int gx, int gy, int wg)
+DEV int pattern_sig_ctx(LDS const uint8_t *cgf, int gx, int gy, int wg)
 { // TComTrQuant.cpp:2672-2705
   if (wg <= 1) return 0;
   const int r = (gx < wg - 1) ? (cgf[gy * wg + gx + 1] != 0) : 0, l = (gy < wg - 1) ? (cgf[(gy + 1) * wg + gx] != 0) : 0;
   return r + (l << 1);
 }
-DEV int sig_cg_ctx(const uint8_t *cgf, int gx, int gy, int wg)
+DEV int sig_cg_ctx(LDS const uint8_t *cgf, int gx, int gy, int wg)
 { // TComTrQuant.cpp:3023-3049
   const int r = (gx < wg - 1) ? (cgf[gy * wg + gx + 1] != 0) : 0, l = (gy < wg - 1) ? (cgf[(gy + 1) * wg + gx] != 0) : 0;
   return (r + l) != 0;
 }
-DEV int sig_ctx_inc(const CParam &cp, const uint16_t *scan, int pat, int scan_pos)
+DEV int sig_ctx_inc(const CParam &cp, LDS const uint16_t *scan, int pat, int scan_pos)
 { // TComTrQuant.cpp:2707-2803
   const int raster = scan[scan_pos], py = raster >> cp.log2, px = raster - (py << cp.log2);
   if (px + py == 0) return 0;
   int offset;
-  if (cp.log2 == 2) offset = smem_of()->t_ctx_map4[4 * py + px];
+  if (cp.log2 == 2) offset = lds().t_ctx_map4[4 * py + px];
   else {
     int cnt; const int xs = px & 3, ys = py & 3;
     if (pat == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
@@ -537,8 +552,8 @@ DEV int sig_ctx_inc(const CParam &cp, const uint16_t *scan, int pat, int scan_po
   }
   return cp.first_sig_ctx + offset;
 }
-DEV const uint16_t *scan_of(const RdSmem &s, int type, int log2n) { return s.scan_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 16 : (log2n == 4 ? 80 : 336))); }
-DEV const uint8_t *scan_cg_of(const RdSmem &s, int type, int log2n) { return s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); }
+DEV LDS const uint16_t *scan_of(const LSmem &s, int type, int log2n) { return s.scan_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 16 : (log2n == 4 ? 80 : 336))); }
+DEV LDS const uint8_t *scan_cg_of(const LSmem &s, int type, int log2n) { return s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); }
 DEV int ctx_set_index(int ch, int subset, int found_gt1) { return (ch ? 4 : 0) + ((!ch && subset > 0) ? 2 : 0) + (found_gt1 ? 1 : 0); }   // TComChromaFormat.h:243-251
 DEV void last_ctx_params(int ch, int n, int &off, int &shift)
 { // TComChromaFormat.h:211-226
@@ -551,7 +566,7 @@ DEV void last_ctx_params(int ch, int n, int &off, int &shift)
 // RDOQ (TComTrQuant.cpp:2119-2661, helpers :2812-2996); executed by lane 0 on LDS data.
 // Rate tables (estBitsSbacStruct, TEncSbac.cpp:1726-1970) are read straight from the frozen contexts of `cab`.
 // ---------------------------------------------------------------------------------------------------
-DEV int ic_rate(const Cabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, int go_rice, uint32_t c1idx, uint32_t c2idx)
+DEV int ic_rate(const LCabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, int go_rice, uint32_t c1idx, uint32_t c2idx)
 { // xGetICRate TComTrQuant.cpp:2881-2955
   int rate = 32768;
   const uint32_t base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
@@ -608,11 +623,11 @@ DEV double rl_d(double v, int l)
 //     reference's level decision; per-position results go back to LDS lane-parallel;
 //   phase C: last-position search on lane 0, sign-data hiding with lane-parallel candidate costs.
 // Every fp64 accumulation is performed in the reference's order (the sums are not associative).
-DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
+DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
 {
   const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
-  RdSmem &s = *k.s;
-  const int lane = k.lane;
+  LSmem &s = lds();
+  const int lane = lane_id();
   const int ch = c ? 1 : 0, log2n = ilog2(n);
   const int qp = uni(c ? k.qp_c : k.qp), per = qp / 6, rem = qp % 6;
   const int tshift = 15 - 8 - log2n, qbits = 14 + per + tshift;
@@ -621,11 +636,11 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
   const int qcoef = uni(c_quant_scales[rem]);
   const int ncoef = n * n;
   CParam cp; get_cparam(cp, c, n, dir_mode);
-  const uint16_t *scan = scan_of(s, cp.scan_type, log2n); const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
-  const int32_t *src = s.tc; int16_t *dst = s.lvl;
-  double *cost_coeff = k.q_cost, *cost_sig = k.q_cost + 1024;
-  int32_t *rate_inc_up = k.q_rate, *rate_inc_down = k.q_rate + 1024, *sig_rate_delta = k.q_rate + 2048, *delta_u = k.q_rate + 3072;
-  double *cost_cg_sig = s.cg_cost; uint8_t *cgf = s.cgf;
+  LDS const uint16_t *scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
+  LDS const int32_t *src = s.tc; LDS int16_t *dst = s.lvl;
+  GLB double *cost_coeff = k.q_cost, *cost_sig = k.q_cost + 1024;
+  GLB int32_t *rate_inc_up = k.q_rate, *rate_inc_down = k.q_rate + 1024, *sig_rate_delta = k.q_rate + 2048, *delta_u = k.q_rate + 3072;
+  LDS double *cost_cg_sig = s.cg_cost; LDS uint8_t *cgf = s.cgf;
   auto level_double = [&](int blk) -> int32_t {
     const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
     return (int32_t)(tmpl < lim ? tmpl : lim);
@@ -684,6 +699,7 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
     int lvl_j = 0, c1_j = 1, ru_j = 0, rd_j = 0;
     double cc_j = c0_j + cs0_j, cs_j = cs0_j;                       // the zero-level outcome
     double st_sig_cost = 0, st_sig_cost0 = 0, st_coded = 0, st_uncoded = 0; int st_nnz_before0 = 0, cg_nonzero = 0;
+    RDOQ_MARK(4);
     for (int pin = start_pin; pin >= 0; pin--) {
       const int sp = cgpos * 16 + pin;
       const int max_abs = __builtin_amdgcn_readlane(ma_j, pin);
@@ -735,6 +751,7 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
         if (pin != 0) st_nnz_before0++;
       }
     }
+    RDOQ_MARK(5);
     // lane-parallel write-back of the group (the bpermute runs with all lanes enabled: a disabled source lane reads 0)
     const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
     if (lane < 16 && j <= start_pin) {
@@ -770,6 +787,7 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
       }
     } else if (lane == 0) cgf[cgblk] = 1;
     wsync();
+    RDOQ_MARK(8);
   }
   RDOQ_MARK(20);
   // ---- phase C: last position, TComTrQuant.cpp:2440-2528.  Per CG the 16 positions' costs are fetched
@@ -782,7 +800,7 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
       best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
       base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
     }
-    int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
+    LDS int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
     { // TEncSbac.cpp:1910-1930 (prefix sums are integers: any evaluation order)
       int off, shift; last_ctx_params(ch, n, off, shift);
       const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
@@ -890,18 +908,18 @@ DEVN uint32_t rdoq_lane0(const K &k, const Cabac *cab, int c_, int n_, int dir_m
   return (uint32_t)uni((int)abs_sum);
 }
 
-DEVN void dequant(const K &k, int c_, int n_)
+DEVN void dequant(KR k, int c_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), n = uni(n_); // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
   const int log2n = ilog2(n), qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
   const int tshift = 15 - 8 - log2n, rshift = 6 - (tshift + per), scale = c_inv_quant_scales[rem];
-  for (int i = k.lane; i < n * n; i += 64) {
-    const int q = k.s->lvl[i];                       // already inside the 16-bit clip range
+  for (int i = lane_id(); i < n * n; i += 64) {
+    const int q = lds().lvl[i];                       // already inside the 16-bit clip range
     int v;
     if (rshift > 0) v = (q * scale + (1 << (rshift - 1))) >> rshift;
     else v = (int)((unsigned)(q * scale) << (-rshift));
-    k.s->tc[i] = clip16(v);
+    lds().tc[i] = clip16(v);
   }
   wsync();
   PROF_ADD(k, 7);
@@ -910,20 +928,20 @@ DEVN void dequant(const K &k, int c_, int n_)
 // ---------------------------------------------------------------------------------------------------
 // residual syntax bit counting on lane 0 (TEncSbac.cpp:1115-1541); coefficients in s->lvl (TU raster)
 // ---------------------------------------------------------------------------------------------------
-DEV void code_last_xy(Cabac *c, int px, int py, int n, int ch, int scan_type)
+DEV void code_last_xy(LCabac *c, int px, int py, int n, int ch, int scan_type)
 {
   if (scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-  const int gx = smem_of()->t_group_idx[px], gy = smem_of()->t_group_idx[py]; int off, shift, kk;
+  const int gx = lds().t_group_idx[px], gy = lds().t_group_idx[py]; int off, shift, kk;
   last_ctx_params(ch, n, off, shift);
   const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
   for (kk = 0; kk < gx; kk++) enc_bin(c, bx + (kk >> shift), 1);
-  if (gx < smem_of()->t_group_idx[n - 1]) enc_bin(c, bx + (kk >> shift), 0);
+  if (gx < lds().t_group_idx[n - 1]) enc_bin(c, bx + (kk >> shift), 0);
   for (kk = 0; kk < gy; kk++) enc_bin(c, by + (kk >> shift), 1);
-  if (gy < smem_of()->t_group_idx[n - 1]) enc_bin(c, by + (kk >> shift), 0);
+  if (gy < lds().t_group_idx[n - 1]) enc_bin(c, by + (kk >> shift), 0);
   if (gx > 3) enc_ep(c, (gx - 2) >> 1);
   if (gy > 3) enc_ep(c, (gy - 2) >> 1);
 }
-DEV void code_coef_remain(Cabac *c, uint32_t symbol, int rparam)
+DEV void code_coef_remain(LCabac *c, uint32_t symbol, int rparam)
 { // xWriteCoefRemainExGolomb TEncSbac.cpp:337-394 (bit count only)
   if (symbol < (3u << rparam)) { enc_ep(c, (int)(symbol >> rparam) + 1); enc_ep(c, rparam); }
   else {
@@ -932,19 +950,19 @@ DEV void code_coef_remain(Cabac *c, uint32_t symbol, int rparam)
     enc_ep(c, (int)(3 + len + 1 - rparam)); enc_ep(c, (int)len);
   }
 }
-DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_)
+DEVN void code_coeff_lane0(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_)
 {
   const int comp = uni(comp_), n = uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
   const int log2n = cp.log2;
-  const int16_t *coef = s.lvl; const uint16_t *scan = scan_of(s, cp.scan_type, log2n); const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
+  LDS const int16_t *coef = s.lvl; LDS const uint16_t *scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   int num_sig = 0;
   for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
   if (num_sig == 0) return;                                   // never called for an empty TU (cbf checked by the caller)
   if (n == 4) enc_bin(c, CTX_TSKIP + ch, tskip_flag);         // codeTransformSkipFlags :997-1032
-  uint8_t *cgf = s.cgf; for (int i = 0; i < 64; i++) cgf[i] = 0;
+  LDS uint8_t *cgf = s.cgf; for (int i = 0; i < 64; i++) cgf[i] = 0;
   int scan_last = -1, pos_last;
   do {
     pos_last = scan[++scan_last];
@@ -1000,7 +1018,7 @@ DEVN void code_coeff_lane0(const K &k, Cabac *c, int comp_, int n_, int dir_mode
 // ---------------------------------------------------------------------------------------------------
 // mode syntax (TEncSbac.cpp:613-726, TComDataCU.cpp:1334-1461); uniform control flow, bins on lane 0
 // ---------------------------------------------------------------------------------------------------
-DEV void get_mpm(const K &k, int x, int y, int preds[3], int *nmode)
+DEV void get_mpm(KR k, int x, int y, int preds[3], int *nmode)
 { // getIntraDirPredictor TComDataCU.cpp:1362-1445
   int left = DC, above = DC;
   if (x > 0) left = part_attr(k, A_LDIR, (x >> 2) - 1, y >> 2);
@@ -1015,27 +1033,27 @@ DEV void get_mpm(const K &k, int x, int y, int preds[3], int *nmode)
     if (left && above) preds[2] = PLANAR; else preds[2] = (left + above) < 2 ? VER : DC;
   }
 }
-DEV void code_luma_dirs(const K &k, Cabac *c, const Cu &cu, int first_pu, int npu)
+DEV void code_luma_dirs(KR k, LCabac *c, const Cu &cu, int first_pu, int npu)
 { // codeIntraDirLumaAng TEncSbac.cpp:643-696
   int idx[4];
   const int pu_size = (cu.part == SIZE_NxN) ? (1 << (cu.log2 - 1)) : (1 << cu.log2);
   for (int j = 0; j < npu; j++) {
     const int pu = first_pu + j, px = cu.x + (pu & 1) * pu_size, py = cu.y + (pu >> 1) * pu_size;
-    const int dir = k.s->a[A_LDIR][cu.zbase + pu * (cu.nparts >> 2) * (cu.part == SIZE_NxN)];
+    const int dir = lds().a[A_LDIR][cu.zbase + pu * (cu.nparts >> 2) * (cu.part == SIZE_NxN)];
     int preds[3]; get_mpm(k, px, py, preds, nullptr);
     idx[j] = -1;
     for (int i = 0; i < 3; i++) if (dir == preds[i]) idx[j] = i;
-    if (k.lane == 0) enc_bin(c, CTX_INTRA_PRED, idx[j] != -1);
+    if (lane_id() == 0) enc_bin(c, CTX_INTRA_PRED, idx[j] != -1);
   }
-  if (k.lane == 0) for (int j = 0; j < npu; j++) enc_ep(c, idx[j] != -1 ? (idx[j] ? 2 : 1) : 5);
+  if (lane_id() == 0) for (int j = 0; j < npu; j++) enc_ep(c, idx[j] != -1 ? (idx[j] ? 2 : 1) : 5);
 }
-DEV void code_chroma_dir(const K &k, Cabac *c, const Cu &cu)
+DEV void code_chroma_dir(KR k, LCabac *c, const Cu &cu)
 { // codeIntraDirChroma TEncSbac.cpp:698-726
-  if (k.lane != 0) return;
-  if (k.s->a[A_CDIR][cu.zbase] == DM_CHROMA) enc_bin(c, CTX_CHROMA_PRED, 0);
+  if (lane_id() != 0) return;
+  if (lds().a[A_CDIR][cu.zbase] == DM_CHROMA) enc_bin(c, CTX_CHROMA_PRED, 0);
   else { enc_bin(c, CTX_CHROMA_PRED, 1); enc_ep(c, 2); }
 }
-DEV int split_ctx(const K &k, int x, int y, int depth)
+DEV int split_ctx(KR k, int x, int y, int depth)
 { // getCtxSplitFlag TComDataCU.cpp:1447-1461
   int ctx = 0;
   if (x > 0) ctx += part_attr(k, A_DEPTH, (x >> 2) - 1, y >> 2) > depth;
@@ -1060,83 +1078,83 @@ DEV Tu tu_child(const Tu &p, int i)
   ch.x = p.x + (i & 1) * h; ch.y = p.y + (i >> 1) * h; ch.zrel = p.zrel + i * ch.nparts;
   return ch;
 }
-DEV int mode_of(const K &k, const Cu &cu, int c, int zrel)
+DEV int mode_of(KR k, const Cu &cu, int c, int zrel)
 { // TEncSearch.cpp:1178-1181
-  if (!c) return k.s->a[A_LDIR][cu.zbase + zrel];
-  const int m = k.s->a[A_CDIR][cu.zbase + zrel];
-  return m == DM_CHROMA ? k.s->a[A_LDIR][cu.zbase + (zrel & ~3)] : m;
+  if (!c) return lds().a[A_LDIR][cu.zbase + zrel];
+  const int m = lds().a[A_CDIR][cu.zbase + zrel];
+  return m == DM_CHROMA ? lds().a[A_LDIR][cu.zbase + (zrel & ~3)] : m;
 }
-DEV void code_qt_cbf(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int lowest)
+DEV void code_qt_cbf(KR k, LCabac *c, const Cu &cu, const Tu &tu, int comp, int lowest)
 { // codeQtCbf TEncSbac.cpp:920-995 + getCtxQtCbf TComDataCU.cpp:1463-1476
   const int ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
   const int w = comp ? tu_csize(tu) : (1 << tu.log2);
   const int d = tu.trd + ((!lowest && !(w >= 8)) ? 1 : 0);
   const int z = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
-  const int cbf = (k.s->a[A_CBF + comp][z] >> d) & 1;
-  if (k.lane == 0) enc_bin(c, CTX_QT_CBF + (comp ? 5 : 0) + ctx, cbf);
+  const int cbf = (lds().a[A_CBF + comp][z] >> d) & 1;
+  if (lane_id() == 0) enc_bin(c, CTX_QT_CBF + (comp ? 5 : 0) + ctx, cbf);
 }
 
 // coefficients of one TU -> s->lvl (lane-parallel), source = QT layer buffer or the CTU record
-DEV void load_tu_coef(const K &k, int real, int comp, int log2_luma, int zabs_comp, int n)
+DEV void load_tu_coef(KR k, int real, int comp, int log2_luma, int zabs_comp, int n)
 {
   const int off = comp ? (zabs_comp * 16) >> 2 : zabs_comp * 16;
-  const int16_t *src = real ? reinterpret_cast<const int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + comp_off(comp) + off
+  GLB const int16_t *src = real ? (GLB const int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + comp_off(comp) + off
                             : k.coef_l + (5 - log2_luma) * 6144 + comp_off(comp) + off;
   wsync();
-  for (int i = k.lane; i < n * n; i += 64) k.s->lvl[i] = src[i];
+  for (int i = lane_id(); i < n * n; i += 64) lds().lvl[i] = src[i];
   wsync();
 }
 // bit-count one coded TU block (cbf already known to be set)
-DEV void code_tu_coeffs(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int real)
+DEV void code_tu_coeffs(KR k, LCabac *c, const Cu &cu, const Tu &tu, int comp, int real)
 {
   const int zc = comp ? tu_czrel(tu) : tu.zrel;
   const int n = comp ? tu_csize(tu) : (1 << tu.log2);
   const int mode = uni(mode_of(k, cu, comp, zc));
   load_tu_coef(k, real, comp, tu.log2, cu.zbase + zc, n);
-  { PROF_T0(); if (k.lane == 0) code_coeff_lane0(k, c, comp, n, mode, k.s->a[A_TSKIP + comp][cu.zbase + zc]); PROF_ADD(k, 11); }
+  { PROF_T0(); if (lane_id() == 0) code_coeff_lane0(k, c, comp, n, mode, lds().a[A_TSKIP + comp][cu.zbase + zc]); PROF_ADD(k, 11); }
   wsync();
 }
 
-template <int LOG2> DEV void enc_subdiv_cbf(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int luma, int chroma)
+template <int LOG2> DEV void enc_subdiv_cbf(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma, int chroma)
 { // xEncSubdivCbfQT TEncSearch.cpp:907-972
-  const int subdiv = uni(k.s->a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd;
+  const int subdiv = uni(lds().a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd;
   if (cu.part == SIZE_NxN && tu.trd == 0) { }
   else if (LOG2 > 5) { }
   else if (LOG2 == 2) { }
   else if (LOG2 == min_tu_log2(cu)) { }
-  else if (luma && k.lane == 0) enc_bin(c, CTX_SUBDIV + 5 - LOG2, subdiv);
+  else if (luma && lane_id() == 0) enc_bin(c, CTX_SUBDIV + 5 - LOG2, subdiv);
   if (chroma) for (int comp = 1; comp < 3; comp++)
-    if (LOG2 > 2 && (tu.trd == 0 || ((k.s->a[A_CBF + comp][cu.zbase + tu.zrel] >> (tu.trd - 1)) & 1)))
+    if (LOG2 > 2 && (tu.trd == 0 || ((lds().a[A_CBF + comp][cu.zbase + tu.zrel] >> (tu.trd - 1)) & 1)))
       code_qt_cbf(k, c, cu, tu, comp, !subdiv);
   if (subdiv) { if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) enc_subdiv_cbf<LOG2 - 1>(k, c, cu, tu_child(tu, i), luma, chroma); }
   else if (luma) code_qt_cbf(k, c, cu, tu, 0, 1);
 }
-template <int LOG2> DEV void enc_coeff_qt(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int comp, int real)
+template <int LOG2> DEV void enc_coeff_qt(KR k, LCabac *c, const Cu &cu, const Tu &tu, int comp, int real)
 { // xEncCoeffQT TEncSearch.cpp:978-1012 (+ cbf test of TEncEntropy::encodeCoeffNxN :654-690)
-  if (uni(k.s->a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
+  if (uni(lds().a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
     if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) enc_coeff_qt<LOG2 - 1>(k, c, cu, tu_child(tu, i), comp, real);
     return;
   }
   if (comp && !tu_has_chroma_first(tu)) return;
-  if (!((uni(k.s->a[A_CBF + comp][cu.zbase + tu.zrel]) >> tu.trd) & 1)) return;
+  if (!((uni(lds().a[A_CBF + comp][cu.zbase + tu.zrel]) >> tu.trd) & 1)) return;
   code_tu_coeffs(k, c, cu, tu, comp, real);
 }
-DEV void enc_intra_header(const K &k, Cabac *c, const Cu &cu, const Tu &tu, int luma, int chroma)
+DEV void enc_intra_header(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma, int chroma)
 { // xEncIntraHeader TEncSearch.cpp:1018-1087
   if (luma) {
-    if (tu.zrel == 0 && cu.depth == 3 && k.lane == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
+    if (tu.zrel == 0 && cu.depth == 3 && lane_id() == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
     if (cu.part == SIZE_2Nx2N) { if (tu.zrel == 0) code_luma_dirs(k, c, cu, 0, 1); }
     else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel % q) == 0) code_luma_dirs(k, c, cu, tu.zrel / q, 1); }
   }
   if (chroma && tu.zrel == 0) code_chroma_dir(k, c, cu);
 }
-template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu_, const Tu &tu_, int luma_, int chroma_)
+template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_, int luma_, int chroma_)
 {
   PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int luma = uni(luma_), chroma = uni(chroma_); // xGetIntraBitsQT TEncSearch.cpp:1093-1117
-  Cabac *c = &k.s->go;
+  LCabac *c = &lds().go;
   wsync();
-  if (k.lane == 0) reset_bits(c);
+  if (lane_id() == 0) reset_bits(c);
   enc_intra_header(k, c, cu, tu, luma, chroma);
   enc_subdiv_cbf<LOG2>(k, c, cu, tu, luma, chroma);
   if (luma) enc_coeff_qt<LOG2>(k, c, cu, tu, 0, 0);
@@ -1145,33 +1163,33 @@ template <int LOG2> DEVN uint32_t intra_bits_qt(const K &k, const Cu &cu_, const
   PROF_ADD(k, 10);
   return uni((int)get_bits(c));
 }
-template <int LOG2> DEV void enc_transform(const K &k, Cabac *c, const Cu &cu, const Tu &tu)
+template <int LOG2> DEV void enc_transform(KR k, LCabac *c, const Cu &cu, const Tu &tu)
 { // TEncEntropy::xEncodeTransform TEncEntropy.cpp:200-398 (real coefficients; chroma of a 4x4 quad with its LAST block)
   const int z = cu.zbase + tu.zrel;
-  const int subdiv = uni(k.s->a[A_TRIDX][z]) > tu.trd;
+  const int subdiv = uni(lds().a[A_TRIDX][z]) > tu.trd;
   if (cu.part == SIZE_NxN && tu.trd == 0) { }
   else if (LOG2 > 5) { }
   else if (LOG2 == 2) { }
   else if (LOG2 == min_tu_log2(cu)) { }
-  else if (k.lane == 0) enc_bin(c, CTX_SUBDIV + 5 - LOG2, subdiv);
+  else if (lane_id() == 0) enc_bin(c, CTX_SUBDIV + 5 - LOG2, subdiv);
   const int first = tu.trd == 0;
   for (int comp = 1; comp < 3; comp++)
     if (first || LOG2 > 2)
-      if (first || ((k.s->a[A_CBF + comp][z] >> (tu.trd - 1)) & 1)) code_qt_cbf(k, c, cu, tu, comp, !subdiv);
+      if (first || ((lds().a[A_CBF + comp][z] >> (tu.trd - 1)) & 1)) code_qt_cbf(k, c, cu, tu, comp, !subdiv);
   if (subdiv) { if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) enc_transform<LOG2 - 1>(k, c, cu, tu_child(tu, i)); return; }
   code_qt_cbf(k, c, cu, tu, 0, 1);
   for (int comp = 0; comp < 3; comp++) {
     if (comp && !tu_has_chroma_last(tu)) continue;
-    if (!((uni(k.s->a[A_CBF + comp][z]) >> tu.trd) & 1)) continue;
+    if (!((uni(lds().a[A_CBF + comp][z]) >> tu.trd) & 1)) continue;
     code_tu_coeffs(k, c, cu, tu, comp, 1);
   }
 }
-DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu_)
+DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 {
   PROF_T0();
   const Cu cu = ucu(cu_); // TEncCu.cpp:1636-1654 (RD) and xEncodeCU :1222-1270 (state-advancing encode); I-slice, no PCM/TQB/DQP
   wsync();
-  if (cu.depth == 3 && k.lane == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
+  if (cu.depth == 3 && lane_id() == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
   code_luma_dirs(k, c, cu, 0, cu.part == SIZE_NxN ? 4 : 1);
   code_chroma_dir(k, c, cu);
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
@@ -1188,11 +1206,11 @@ DEVN void enc_cu_syntax(const K &k, Cabac *c, const Cu &cu_)
 // ---------------------------------------------------------------------------------------------------
 // TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved)
 // ---------------------------------------------------------------------------------------------------
-DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int mode012_, uint32_t *dist)
+DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
 {
   PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
   const int zrel = comp ? tu_czrel(tu) : tu.zrel, zabs = cu.zbase + zrel;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y;
@@ -1203,34 +1221,34 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
     build_refs(k, comp, x, y, n);
     if (ub(use_filtered_refs(comp, mode, n))) filter_refs(k, n);
     predict_block(k, comp, mode, n);
-    if (mode012 == 1 && k.lane < 16) s.ts_pred[comp][k.lane] = s.pred[k.lane];
-  } else { wsync(); if (k.lane < 16) s.pred[k.lane] = s.ts_pred[comp][k.lane]; }
+    if (mode012 == 1 && lane_id() < 16) s.ts_pred[comp][lane_id()] = s.pred[lane_id()];
+  } else { wsync(); if (lane_id() < 16) s.pred[lane_id()] = s.ts_pred[comp][lane_id()]; }
   wsync();
-  const uint8_t *org = k.org[comp] + (size_t)y * ps + x;
-  for (int i = k.lane; i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
+  GLB const uint8_t *org = k.org[comp] + (size_t)y * ps + x;
+  for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
   wsync();
-  if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5; wsync(); }
+  if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5; wsync(); }
   else fwd_transform(k, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
-  { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (k.lane == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
+  { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
   wsync();
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
   set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
-  int16_t *cl = k.coef_l + (5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
+  GLB int16_t *cl = k.coef_l + (5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
   if (abs_sum > 0) {
-    for (int i = k.lane; i < n * n; i += 64) cl[i] = s.lvl[i];
+    for (int i = lane_id(); i < n * n; i += 64) cl[i] = s.lvl[i];
     dequant(k, comp, n);
-    if (tskip) { for (int i = k.lane; i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((s.tc[i] + 16) >> 5); wsync(); }
+    if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((s.tc[i] + 16) >> 5); wsync(); }
     else inv_transform(k, n, !comp && n == 4);
   } else {
-    for (int i = k.lane; i < n * n; i += 64) { cl[i] = 0; s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = 0; }
+    for (int i = lane_id(); i < n * n; i += 64) { cl[i] = 0; s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = 0; }
     wsync();
   }
-  uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
-  uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  GLB uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
+  GLB uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
   uint32_t d = 0;
-  for (int i = k.lane; i < n * n; i += 64) {
+  for (int i = lane_id(); i < n * n; i += 64) {
     const int r = i >> log2n, cc = i & (n - 1);
     const int v = clip8((int)s.pred[i] + (int)s.resi[r * RS(n) + cc]);
     s.pred[i] = (uint8_t)v; rq[r * cs + cc] = (uint8_t)v; rp[(size_t)r * ps + cc] = (uint8_t)v;
@@ -1239,25 +1257,25 @@ DEVN void code_tu_block(const K &k, const Cu &cu_, const Tu &tu_, int comp_, int
   }
   for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m);
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
-  *dist += d;
   wsync();
   PROF_ADD(k, 9);
+  return d;
 }
 
-DEV void store_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
+DEV void store_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
 { // xStoreIntraResultQT TEncSearch.cpp:1784-1816 (4x4 blocks); s->lvl / s->pred still hold the block just coded
   wsync();
-  if (k.lane < 16) { k.s->ts_coef[comp][k.lane] = ((uni((int)((k.s->a[A_CBF + comp][cu.zbase + (comp ? tu_czrel(tu) : tu.zrel)] >> tu.trd) & 1)) ? k.s->lvl[k.lane] : (int16_t)0)); k.s->ts_rec[comp][k.lane] = k.s->pred[k.lane]; }
+  if (lane_id() < 16) { lds().ts_coef[comp][lane_id()] = ((uni((int)((lds().a[A_CBF + comp][cu.zbase + (comp ? tu_czrel(tu) : tu.zrel)] >> tu.trd) & 1)) ? lds().lvl[lane_id()] : (int16_t)0)); lds().ts_rec[comp][lane_id()] = lds().pred[lane_id()]; }
   wsync();
 }
-DEV void load_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
+DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
 { // xLoadIntraResultQT TEncSearch.cpp:1819-1870
   const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
   wsync();
-  if (k.lane < 16) {
-    k.coef_l[(5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16) + k.lane] = k.s->ts_coef[comp][k.lane];
-    const int r = k.lane >> 2, cc = k.lane & 3; const uint8_t v = k.s->ts_rec[comp][k.lane];
+  if (lane_id() < 16) {
+    k.coef_l[(5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16) + lane_id()] = lds().ts_coef[comp][lane_id()];
+    const int r = lane_id() >> 2, cc = lane_id() & 3; const uint8_t v = lds().ts_rec[comp][lane_id()];
     k.rec_l[(5 - tu.log2) * 6144 + comp_off(comp) + bo + r * cs + cc] = v;
     k.rec[comp][(size_t)(y + r) * ps + x + cc] = v;
   }
@@ -1265,10 +1283,10 @@ DEV void load_ts_result(const K &k, const Cu &cu, const Tu &tu, int comp)
 }
 
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
-template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu_, const Tu &tu_, int check_first_, uint32_t *dist_out, double *cost_out)
+template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, int check_first_)
 {
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int check_first = uni(check_first_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int full_depth = cu.depth + tu.trd, zabs = cu.zbase + tu.zrel;
   const int check_full = LOG2 <= 5;
   int check_split = LOG2 > min_tu_log2(cu);
@@ -1281,7 +1299,7 @@ template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu_, const Tu &tu
       for (int m = 0; m < 2; m++) {
         uint32_t d = 0; double cost;
         set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, m); wsync();
-        code_tu_block(k, cu, tu, 0, m == 0 ? 1 : 2, &d);
+        d = code_tu_block(k, cu, tu, 0, m == 0 ? 1 : 2);
         const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
         if (m == 1 && cbf == 0) cost = MAX_DOUBLE;
         else {
@@ -1303,7 +1321,7 @@ template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu_, const Tu &tu
     } else {
       if (check_split) cabac_copy(k, &s.root[full_depth], &s.go);
       set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, 0); wsync();
-      code_tu_block(k, cu, tu, 0, 0, &single_dist);
+      single_dist = code_tu_block(k, cu, tu, 0, 0);
       if (check_split) single_cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
       const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
       single_cost = calc_rd_cost(k, bits, single_dist);
@@ -1316,33 +1334,34 @@ template <int LOG2> DEVN void recur_luma(const K &k, const Cu &cu_, const Tu &tu
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       for (int i = 0; i < 4; i++) {
         const Tu ch = tu_child(tu, i);
-        recur_luma<LOG2 - 1>(k, cu, ch, check_first, &split_dist, &split_cost);
+        { const DistCost r = recur_luma<LOG2 - 1>(k, cu, ch, check_first); split_dist += r.dist; split_cost += r.cost; }
         split_cbf |= (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
       }
-      if (split_cbf) { for (int i = k.lane; i < tu.nparts; i += 64) s.a[A_CBF][zabs + i] |= (uint8_t)(1 << tu.trd); }
+      if (split_cbf) { for (int i = lane_id(); i < tu.nparts; i += 64) s.a[A_CBF][zabs + i] |= (uint8_t)(1 << tu.trd); }
       cabac_copy(k, &s.go, &s.root[full_depth]);
       const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
       split_cost = calc_rd_cost(k, bits, split_dist);
-      if (ub(split_cost < single_cost)) { *dist_out += split_dist; *cost_out += split_cost; return; }
+      if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost }; return r; }
       cabac_copy(k, &s.go, &s.test[full_depth]);
       set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
       set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
       set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
       const int n = 1 << LOG2, bo = boff(k, 0, tu.x, tu.y);
-      const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo;
-      uint8_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
+      GLB const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo;
+      GLB uint8_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
       wsync();
-      for (int i = k.lane; i < n * n; i += 64) rp[(size_t)(i >> LOG2) * k.W + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
+      for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * k.W + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
       wsync();
     }
   }
-  *dist_out += single_dist; *cost_out += single_cost;
+  const DistCost r = { single_dist, single_cost };
+  return r;
 }
 
 // xSetIntraResultLumaQT / xSetIntraResultChromaQT TEncSearch.cpp:1741-1781, 2150-2198
-template <int LOG2> DEV void set_result(const K &k, const Cu &cu, const Tu &tu, int comp)
+template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp)
 {
-  if (uni(k.s->a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
+  if (uni(lds().a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
     if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp);
     return;
   }
@@ -1350,13 +1369,13 @@ template <int LOG2> DEV void set_result(const K &k, const Cu &cu, const Tu &tu, 
   const int n = comp ? tu_csize(tu) : (1 << LOG2), log2n = ilog2(n);
   const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
   const int off = comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
-  int16_t *dstc = reinterpret_cast<int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + off;
-  const int16_t *srcc = k.coef_l + (5 - LOG2) * 6144 + off;
+  GLB int16_t *dstc = (GLB int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + off;
+  GLB const int16_t *srcc = k.coef_l + (5 - LOG2) * 6144 + off;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = comp_off(comp) + boff(k, comp, x, y);
-  const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; uint8_t *br = k.best_rec + bo;
-  for (int i = k.lane; i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
+  GLB const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; GLB uint8_t *br = k.best_rec + bo;
+  for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
 }
-DEVN void set_result_cu(const K &k, const Cu &cu_, const Tu &tu_, int comp_)
+DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_)
 {
   PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_);
@@ -1371,35 +1390,35 @@ DEVN void set_result_cu(const K &k, const Cu &cu_, const Tu &tu_, int comp_)
   wsync();
   PROF_ADD(k, 15);
 }
-DEV void recur_luma_any(const K &k, const Cu &cu, const Tu &tu, int check_first, uint32_t *d, double *c)
+DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first)
 {
   switch (tu.log2) {
-    case 6: recur_luma<6>(k, cu, tu, check_first, d, c); break;
-    case 5: recur_luma<5>(k, cu, tu, check_first, d, c); break;
-    case 4: recur_luma<4>(k, cu, tu, check_first, d, c); break;
-    case 3: recur_luma<3>(k, cu, tu, check_first, d, c); break;
-    default: recur_luma<2>(k, cu, tu, check_first, d, c); break;
+    case 6: return recur_luma<6>(k, cu, tu, check_first);
+    case 5: return recur_luma<5>(k, cu, tu, check_first);
+    case 4: return recur_luma<4>(k, cu, tu, check_first);
+    case 3: return recur_luma<3>(k, cu, tu, check_first);
+    default: return recur_luma<2>(k, cu, tu, check_first);
   }
 }
 
 // rough mode decision for one PU: 35 predictions + SATD (TEncSearch.cpp:2266-2346).  One lane per
 // (mode, 8x8 block) task (4x4 blocks for a 4x4 PU): predict the block in registers, Hadamard, add into satd[mode].
-DEVN void rmd_satd(const K &k, int x_, int y_, int pn_)
+DEVN void rmd_satd(KR k, int x_, int y_, int pn_)
 {
   PROF_T0();
   const int x = uni(x_), y = uni(y_), pn = uni(pn_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
-  if (k.lane < 36) s.satd[k.lane] = 0;
+  if (lane_id() < 36) s.satd[lane_id()] = 0;
   int dcv[2];
   dcv[0] = dc_value(k, s.line, pn); dcv[1] = 0;
   wsync();
   for (int t0 = 0; t0 < ntask; t0 += 64) {
-    const int t = t0 + k.lane;
+    const int t = t0 + lane_id();
     if (t < ntask) {
       const int mode = t / nblk, blk = t - mode * nblk, bx = (blk % nbx) * b, by = (blk / nbx) * b;
-      const int16_t *line = use_filtered_refs(0, mode, pn) ? s.fline : s.line;
-      const uint8_t *org = k.org[0] + (size_t)(y + by) * k.W + x + bx;
+      LDS const int16_t *line = use_filtered_refs(0, mode, pn) ? s.fline : s.line;
+      GLB const uint8_t *org = k.org[0] + (size_t)(y + by) * k.W + x + bx;
       unsigned int sum = 0;
       if (b == 8) {
         int m[64];
@@ -1441,7 +1460,7 @@ DEVN void rmd_satd(const K &k, int x_, int y_, int pn_)
         }
         sum = (sum + 1) >> 1;
       }
-      atomicAdd(&s.satd[mode], sum);
+      __hip_atomic_fetch_add(&s.satd[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   wsync();
@@ -1449,11 +1468,11 @@ DEVN void rmd_satd(const K &k, int x_, int y_, int pn_)
 }
 
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
-DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
+DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 {
   PROF_T0();
   const Cu cu = ucu(cu_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int init_trd = cu.part == SIZE_NxN ? 1 : 0, npu = init_trd ? 4 : 1;
   const int pu_log2 = cu.log2 - init_trd, pn = 1 << pu_log2, pu_parts = cu.nparts >> (2 * init_trd);
   uint32_t overall = 0;
@@ -1467,23 +1486,23 @@ DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
     int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
     int nfull = c_num_rd_cand[pu_log2 - 2];
     { // mode bits (xModeBitsIntra :5530-5557): 3 possible values, from the [depth][CI_CURR_BEST] snapshot
-      const Cabac *cur = &s.curr[cu.depth];
+      const LCabac *cur = &s.curr[cu.depth];
       const unsigned long long f0 = cur->frac & 32767ull; const int st = cur->ctx[CTX_INTRA_PRED];
-      if (k.lane < 35) {
-        const int mode = k.lane;
+      if (lane_id() < 35) {
+        const int mode = lane_id();
         int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
         const unsigned long long fr = f0 + (unsigned long long)s.t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
         s.rmd_cost[mode] = (double)s.satd[mode] + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
       }
       wsync();
       // xUpdateCandList :5562-5585 == stable sort by (cost, mode); keep the nfull best
-      if (k.lane < 35) {
-        const double mc = s.rmd_cost[k.lane]; int rank = 0;
-        for (int j = 0; j < 35; j++) { const double oc = s.rmd_cost[j]; rank += (oc < mc) || (oc == mc && j < k.lane); }
-        if (rank < nfull) s.rd_list[rank] = (unsigned)k.lane;
+      if (lane_id() < 35) {
+        const double mc = s.rmd_cost[lane_id()]; int rank = 0;
+        for (int j = 0; j < 35; j++) { const double oc = s.rmd_cost[j]; rank += (oc < mc) || (oc == mc && j < lane_id()); }
+        if (rank < nfull) s.rd_list[rank] = (unsigned)lane_id();
       }
       wsync();
-      if (k.lane == 0) {
+      if (lane_id() == 0) {
         int nf = nfull;
         for (int j = 0; j < nm; j++) { int inc = 0; for (int i = 0; i < nf; i++) inc |= (preds[j] == (int)s.rd_list[i]); if (!inc) s.rd_list[nf++] = (unsigned)preds[j]; }
         s.bc_u32[1] = (unsigned)nf;
@@ -1498,12 +1517,12 @@ DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
       const uint32_t org_mode = second ? best_mode : (uint32_t)uni((int)s.rd_list[m]);
       set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)org_mode);
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
-      uint32_t d = 0; double cost = 0.0;
-      recur_luma_any(k, cu, ptu, !second, &d, &cost);
+      const DistCost dc = recur_luma_any(k, cu, ptu, !second);
+      const uint32_t d = dc.dist; const double cost = dc.cost;
       if (ub(cost < best_cost)) {
         best_mode = org_mode; best_dist = d; best_cost = cost;
         set_result_cu(k, cu, ptu, 0);
-        for (int i = k.lane; i < pu_parts; i += 64) {
+        for (int i = lane_id(); i < pu_parts; i += 64) {
           s.sv_tr[i] = s.a[A_TRIDX][zp + i];
           for (int c = 0; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][zp + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][zp + i]; }
         }
@@ -1512,13 +1531,13 @@ DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
     }
     overall += best_dist;
     wsync();
-    for (int i = k.lane; i < pu_parts; i += 64) {
+    for (int i = lane_id(); i < pu_parts; i += 64) {
       s.a[A_TRIDX][zp + i] = s.sv_tr[i];
       for (int c = 0; c < 3; c++) { s.a[A_CBF + c][zp + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][zp + i] = s.sv_ts[c][i]; }
     }
     if (pu != npu - 1) {
-      uint8_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; const uint8_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
-      for (int i = k.lane; i < pn * pn; i += 64) rp[(size_t)(i >> pu_log2) * k.W + (i & (pn - 1))] = br[(i >> pu_log2) * 64 + (i & (pn - 1))];
+      GLB uint8_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; GLB const uint8_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
+      for (int i = lane_id(); i < pn * pn; i += 64) rp[(size_t)(i >> pu_log2) * k.W + (i & (pn - 1))] = br[(i >> pu_log2) * 64 + (i & (pn - 1))];
     }
     set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)best_mode);
     wsync();
@@ -1527,22 +1546,23 @@ DEVN void est_intra_luma(const K &k, const Cu &cu_, uint32_t *cu_dist)
     int comb[3] = { 0, 0, 0 };
     for (int p = 0; p < 4; p++) for (int c = 0; c < 3; c++) comb[c] |= (s.a[A_CBF + c][cu.zbase + p * pu_parts] >> 1) & 1;
     wsync();
-    for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 0; c < 3; c++) s.a[A_CBF + c][cu.zbase + i] |= (uint8_t)comb[c];
+    for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 3; c++) s.a[A_CBF + c][cu.zbase + i] |= (uint8_t)comb[c];
     wsync();
   }
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
-  *cu_dist = overall;
   PROF_ADD(k, 16);
+  return overall;
 }
 
 // xRecurIntraChromaCodingQT TEncSearch.cpp:1941-2145
-template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu_, const Tu &tu_, uint32_t *dist_out)
+template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
 {
+  uint32_t dist_sum = 0;
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int z = cu.zbase + tu.zrel;
   if (uni(s.a[A_TRIDX][z]) == tu.trd) {
-    if (!tu_has_chroma_first(tu)) return;
+    if (!tu_has_chroma_first(tu)) return 0;
     const int full_depth = cu.depth + tu.trd;
     int check_ts = (LOG2 == 2);
     if (check_ts) { int nb = 0; for (int i = 0; i < 4; i++) nb += s.a[A_TSKIP + 0][z + i]; check_ts = uni(nb) > 0; }
@@ -1556,13 +1576,12 @@ template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu_, const Tu &
         cur_id++;
         const int one = (total == 1), last = (cur_id == total);
         const int m012 = one ? 0 : (ts == 0 ? 1 : 2);
-        uint32_t d = 0;
-        code_tu_block(k, cu, tu, comp, m012, &d);
+        const uint32_t d = code_tu_block(k, cu, tu, comp, m012);
         const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF + comp][zc]) >> tu.trd) & 1;
         if (!one && !last) store_ts_result(k, cu, tu, comp);   // before the bit count reuses s->lvl
         if (ts == 1 && cbf == 0) cost_tmp = MAX_DOUBLE;
         else if (!one) { // xGetIntraBitsQTChroma :1119-1127
-          wsync(); if (k.lane == 0) reset_bits(&s.go);
+          wsync(); if (lane_id() == 0) reset_bits(&s.go);
           enc_coeff_qt<LOG2>(k, &s.go, cu, tu, comp, 0);
           wsync(); cost_tmp = calc_rd_cost(k, (uint32_t)uni((int)get_bits(&s.go)), d);
         }
@@ -1578,30 +1597,31 @@ template <int LOG2> DEVN void recur_chroma(const K &k, const Cu &cu_, const Tu &
         cabac_copy(k, &s.go, &s.tbest[full_depth]);
       }
       set_parts(k, s.a[A_TSKIP + comp], zc, np, best_ts); wsync();
-      *dist_out += single_dist;
+      dist_sum += single_dist;
     }
   } else {
     if constexpr (LOG2 > 2) {
       uint32_t split_cbf[3] = { 0, 0, 0 };
       for (int i = 0; i < 4; i++) {
         const Tu ch = tu_child(tu, i);
-        recur_chroma<LOG2 - 1>(k, cu, ch, dist_out);
+        dist_sum += recur_chroma<LOG2 - 1>(k, cu, ch);
         for (int comp = 1; comp < 3; comp++) split_cbf[comp] |= (uint32_t)(uni(s.a[A_CBF + comp][cu.zbase + ch.zrel]) >> ch.trd) & 1;
       }
       wsync();
       for (int comp = 1; comp < 3; comp++) if (split_cbf[comp])
-        for (int i = k.lane; i < tu.nparts; i += 64) s.a[A_CBF + comp][z + i] |= (uint8_t)(1 << tu.trd);
+        for (int i = lane_id(); i < tu.nparts; i += 64) s.a[A_CBF + comp][z + i] |= (uint8_t)(1 << tu.trd);
       wsync();
     }
   }
+  return dist_sum;
 }
 
 // estIntraPredChromaQT TEncSearch.cpp:2588-2737 (4:2:0: one chroma PU per CU)
-DEVN void est_intra_chroma(const K &k, const Cu &cu_, uint32_t *cu_dist)
+DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
 {
   PROF_T0();
   const Cu cu = ucu(cu_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
   uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
   const int luma_mode = uni(s.a[A_LDIR][cu.zbase]);
@@ -1609,73 +1629,72 @@ DEVN void est_intra_chroma(const K &k, const Cu &cu_, uint32_t *cu_dist)
   uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
   for (int m = 0; m < 5; m++) {
     cabac_copy(k, &s.go, &s.curr[cu.depth]);
-    uint32_t d = 0;
+    uint32_t d;
     set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)mode_list[m]); wsync();
     uint32_t bits;
     switch (cu.log2) {
-      case 6: recur_chroma<6>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<6>(k, cu, root, 0, 1); break;
-      case 5: recur_chroma<5>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<5>(k, cu, root, 0, 1); break;
-      case 4: recur_chroma<4>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<4>(k, cu, root, 0, 1); break;
-      default: recur_chroma<3>(k, cu, root, &d); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<3>(k, cu, root, 0, 1); break;
+      case 6: d = recur_chroma<6>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<6>(k, cu, root, 0, 1); break;
+      case 5: d = recur_chroma<5>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<5>(k, cu, root, 0, 1); break;
+      case 4: d = recur_chroma<4>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<4>(k, cu, root, 0, 1); break;
+      default: d = recur_chroma<3>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<3>(k, cu, root, 0, 1); break;
     }
     const double cost = calc_rd_cost(k, bits, d);
     if (ub(cost < best_cost)) {
       best_cost = cost; best_dist = d; best_mode = mode_list[m];
       set_result_cu(k, cu, root, 1); set_result_cu(k, cu, root, 2);
-      for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
+      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
       wsync();
     }
   }
-  for (int i = k.lane; i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv_ts[c][i]; }
+  for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv_ts[c][i]; }
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
-  *cu_dist += best_dist;
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
   PROF_ADD(k, 17);
+  return best_dist;
 }
 
-DEV void copy_best_rec_to_pic(const K &k, const Cu &cu, int comp)
+DEV void copy_best_rec_to_pic(KR k, const Cu &cu, int comp)
 {
   const int n = (1 << cu.log2) >> (comp ? 1 : 0), log2n = ilog2(n), x = cu.x >> (comp ? 1 : 0), y = cu.y >> (comp ? 1 : 0);
   const int cs = cstride(comp), ps = pstride(k, comp);
-  const uint8_t *br = k.best_rec + comp_off(comp) + boff(k, comp, x, y);
-  uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  GLB const uint8_t *br = k.best_rec + comp_off(comp) + boff(k, comp, x, y);
+  GLB uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
   wsync();
-  for (int i = k.lane; i < n * n; i += 64) rp[(size_t)(i >> log2n) * ps + (i & (n - 1))] = br[(i >> log2n) * cs + (i & (n - 1))];
+  for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> log2n) * ps + (i & (n - 1))] = br[(i >> log2n) * cs + (i & (n - 1))];
   wsync();
 }
 
 // xCheckRDCostIntra TEncCu.cpp:1600-1665; the end state of the CU syntax is left in s->temp[depth]
-DEVN Rd check_rd_cost_intra(const K &k, const Cu &cu_, int part_)
+DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
 {
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int part = uni(part_);
   Cu cu = ucu(cu_); cu.part = part;
   wsync();
-  for (int i = k.lane; i < cu.nparts; i += 64) { // initEstData TComDataCU.cpp:525-592 + part size / pred mode
+  for (int i = lane_id(); i < cu.nparts; i += 64) { // initEstData TComDataCU.cpp:525-592 + part size / pred mode
     const int z = cu.zbase + i;
     s.a[A_DEPTH][z] = (uint8_t)cu.depth; s.a[A_PART][z] = (uint8_t)part; s.a[A_LDIR][z] = DC; s.a[A_CDIR][z] = 0; s.a[A_TRIDX][z] = 0;
     for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
   }
   wsync();
-  uint32_t dist = 0;
-  est_intra_luma(k, cu, &dist);
+  uint32_t dist = est_intra_luma(k, cu);
   copy_best_rec_to_pic(k, cu, 0);
-  est_intra_chroma(k, cu, &dist);
+  dist += est_intra_chroma(k, cu);
   wsync();
-  if (k.lane == 0) reset_bits(&s.go);
+  if (lane_id() == 0) reset_bits(&s.go);
   enc_cu_syntax(k, &s.go, cu);
   cabac_copy(k, &s.temp[cu.depth], &s.go);
   Rd r; r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
   return r;
 }
 
-DEV void save_cand8(const K &k, const Cu &cu)
+DEV void save_cand8(KR k, const Cu &cu)
 {
-  RdSmem &s = *k.s;
-  const int16_t *rc = reinterpret_cast<const int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
+  LSmem &s = lds();
+  GLB const int16_t *rc = (GLB const int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
   wsync();
-  if (k.lane < 44) s.c8a[k.lane >> 2][k.lane & 3] = s.a[k.lane >> 2][cu.zbase + (k.lane & 3)];
-  for (int i = k.lane; i < 96; i += 64) {
+  if (lane_id() < 44) s.c8a[lane_id() >> 2][lane_id() & 3] = s.a[lane_id() >> 2][cu.zbase + (lane_id() & 3)];
+  for (int i = lane_id(); i < 96; i += 64) {
     const int c = i < 64 ? 0 : (i < 80 ? 1 : 2), j = i < 64 ? i : (i - 64) & 15;
     s.c8coef[i] = rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j];
     const int n = c ? 4 : 8, sx = c ? 32 : 64, bo = comp_off(c) + boff(k, c, cu.x >> (c ? 1 : 0), cu.y >> (c ? 1 : 0));
@@ -1683,13 +1702,13 @@ DEV void save_cand8(const K &k, const Cu &cu)
   }
   wsync();
 }
-DEV void load_cand8(const K &k, const Cu &cu)
+DEV void load_cand8(KR k, const Cu &cu)
 {
-  RdSmem &s = *k.s;
-  int16_t *rc = reinterpret_cast<int16_t *>(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
+  LSmem &s = lds();
+  GLB int16_t *rc = (GLB int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
   wsync();
-  if (k.lane < 44) s.a[k.lane >> 2][cu.zbase + (k.lane & 3)] = s.c8a[k.lane >> 2][k.lane & 3];
-  for (int i = k.lane; i < 96; i += 64) {
+  if (lane_id() < 44) s.a[lane_id() >> 2][cu.zbase + (lane_id() & 3)] = s.c8a[lane_id() >> 2][lane_id() & 3];
+  for (int i = lane_id(); i < 96; i += 64) {
     const int c = i < 64 ? 0 : (i < 80 ? 1 : 2), j = i < 64 ? i : (i - 64) & 15;
     rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j] = s.c8coef[i];
     const int n = c ? 4 : 8, sx = c ? 32 : 64, bo = comp_off(c) + boff(k, c, cu.x >> (c ? 1 : 0), cu.y >> (c ? 1 : 0));
@@ -1699,10 +1718,10 @@ DEV void load_cand8(const K &k, const Cu &cu)
 }
 
 // xCompressCU TEncCu.cpp:470-1104 with the reference's label-pruning edits (:496-520, 815-834, 947-965)
-template <int DEPTH> DEVN Rd compress_cu(const K &k, int x_, int y_)
+template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
 {
   const int x = uni(x_), y = uni(y_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int log2 = 6 - DEPTH, size = 1 << log2;
   Cu cu = { x, y, log2, DEPTH, (int)s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)], 256 >> (2 * DEPTH), SIZE_2Nx2N };
   const int boundary = uni(!(x + size <= k.W && y + size <= k.H));
@@ -1724,7 +1743,7 @@ template <int DEPTH> DEVN Rd compress_cu(const K &k, int x_, int y_)
     // split flag of the unsplit candidate (:858-867); for the dummy candidate the loaded state is stale and irrelevant
     cabac_copy(k, &s.go, &s.next[DEPTH]);
     const int sctx = (DEPTH < 3) ? split_ctx(k, x, y, DEPTH) : 0;
-    if (k.lane == 0) { reset_bits(&s.go); if (DEPTH < 3) enc_bin(&s.go, CTX_SPLIT + sctx, 0); }
+    if (lane_id() == 0) { reset_bits(&s.go); if (DEPTH < 3) enc_bin(&s.go, CTX_SPLIT + sctx, 0); }
     wsync();
     best.bits += (uint32_t)uni((int)get_bits(&s.go));
     best.cost = calc_rd_cost(k, best.bits, best.dist);
@@ -1745,7 +1764,7 @@ template <int DEPTH> DEVN Rd compress_cu(const K &k, int x_, int y_)
       } else if (check_next || boundary) { // initSubCU defaults copied to the picture (:989)
         const int z0 = cu.zbase + i * qn;
         wsync();
-        for (int j = k.lane; j < qn; j += 64) {
+        for (int j = lane_id(); j < qn; j += 64) {
           s.a[A_DEPTH][z0 + j] = DEPTH + 1; s.a[A_PART][z0 + j] = SIZE_NONE; s.a[A_LDIR][z0 + j] = DC; s.a[A_CDIR][z0 + j] = 0; s.a[A_TRIDX][z0 + j] = 0;
           for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z0 + j] = 0; s.a[A_TSKIP + c][z0 + j] = 0; }
         }
@@ -1755,7 +1774,7 @@ template <int DEPTH> DEVN Rd compress_cu(const K &k, int x_, int y_)
     cabac_copy(k, &s.go, &s.next[DEPTH + 1]);
     if (!boundary) {
       const int sctx = split_ctx(k, x, y, DEPTH);
-      if (k.lane == 0) { reset_bits(&s.go); enc_bin(&s.go, CTX_SPLIT + sctx, 1); }
+      if (lane_id() == 0) { reset_bits(&s.go); enc_bin(&s.go, CTX_SPLIT + sctx, 1); }
       wsync();
       temp.bits += (uint32_t)uni((int)get_bits(&s.go));
     }
@@ -1767,16 +1786,16 @@ template <int DEPTH> DEVN Rd compress_cu(const K &k, int x_, int y_)
 }
 
 // state-advancing encode of the decided CTU: encodeCtu/xEncodeCU TEncCu.cpp:290-304,1167-1271
-template <int DEPTH> DEVN void encode_cu_tree(const K &k, Cabac *c, int x_, int y_)
+template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
 {
   const int x = uni(x_), y = uni(y_);
-  RdSmem &s = *k.s;
+  LSmem &s = lds();
   const int size = 64 >> DEPTH;
   const int z = s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)];
   int boundary = 0;
   const int dz = uni(s.a[A_DEPTH][z]);
   if (ub(x + size <= k.W && y + size <= k.H)) {
-    if (DEPTH < 3) { const int sctx = split_ctx(k, x, y, DEPTH); if (k.lane == 0) enc_bin(c, CTX_SPLIT + sctx, dz > DEPTH); }
+    if (DEPTH < 3) { const int sctx = split_ctx(k, x, y, DEPTH); if (lane_id() == 0) enc_bin(c, CTX_SPLIT + sctx, dz > DEPTH); }
   } else boundary = 1;
   if constexpr (DEPTH < 3) {
     if (DEPTH < dz || boundary) {
@@ -1794,114 +1813,120 @@ template <int DEPTH> DEVN void encode_cu_tree(const K &k, Cabac *c, int x_, int 
 extern "C" __global__ __launch_bounds__(64)
 void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  RdSmem &s = *reinterpret_cast<RdSmem *>(smem_raw);
+  LSmem &s = lds();
   const int frame = blockIdx.x;
   if (frame >= p.n_frames) return;
-  K k;
-  k.s = &s; k.lane = threadIdx.x;
+  LDS K &k = s.k;                       // every lane stores the same values
+  const int lane = lane_id();
   k.W = p.width; k.H = p.height; k.cw = p.width >> 1; k.ctus_x = p.ctus_x; k.nctu = p.ctus_x * p.ctus_y;
   const size_t ysz = (size_t)p.width * p.height, csz = ysz >> 2, fsz = ysz + 2 * csz;
-  k.org[0] = p.yuv + (size_t)frame * fsz; k.org[1] = k.org[0] + ysz; k.org[2] = k.org[1] + csz;
-  k.rec[0] = p.recon + (size_t)frame * fsz; k.rec[1] = k.rec[0] + ysz; k.rec[2] = k.rec[1] + csz;
-  k.records = p.records + (size_t)frame * k.nctu * REC_SIZE;
-  k.labels = p.labels + (size_t)frame * k.nctu * 16;
-  unsigned char *scr = p.scratch + (size_t)frame * p.scratch_per_frame;
-  k.coef_l = reinterpret_cast<int16_t *>(scr); k.rec_l = scr + 4 * 6144 * 2; k.best_rec = k.rec_l + 4 * 6144;
-  k.q_cost = reinterpret_cast<double *>(scr + 81920); k.q_rate = reinterpret_cast<int32_t *>(scr + 81920 + 16384);
+  const int nctu = p.ctus_x * p.ctus_y;
+  GLB const uint8_t *org0 = (GLB const uint8_t *)p.yuv + (size_t)frame * fsz;
+  GLB uint8_t *rec0 = (GLB uint8_t *)p.recon + (size_t)frame * fsz;
+  k.org[0] = org0; k.org[1] = org0 + ysz; k.org[2] = org0 + ysz + csz;
+  k.rec[0] = rec0; k.rec[1] = rec0 + ysz; k.rec[2] = rec0 + ysz + csz;
+  GLB unsigned char *records = (GLB unsigned char *)p.records + (size_t)frame * nctu * REC_SIZE;
+  k.records = records;
+  k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
+  GLB unsigned char *scr = (GLB unsigned char *)p.scratch + (size_t)frame * p.scratch_per_frame;
+  k.coef_l = (GLB int16_t *)scr; k.rec_l = scr + 4 * 6144 * 2; k.best_rec = scr + 4 * 6144 * 2 + 4 * 6144;
+  k.q_cost = (GLB double *)(scr + 81920); k.q_rate = (GLB int32_t *)(scr + 81920 + 16384);
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
-  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = p.dbgbuf;
+  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
 
   // tables into LDS: z-scan map, CABAC tables, scans
-  for (int r = k.lane; r < 256; r += 64) {
+  for (int r = lane; r < 256; r += 64) {
     const int x = r & 15, y = r >> 4; int z = 0;
     for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
     s.r2z[r] = (uint8_t)z;
   }
-  for (int i = k.lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
-  if (k.lane < 9) { s.t_ang[k.lane] = c_ang_table[k.lane]; s.t_inv_ang[k.lane] = c_inv_ang_table[k.lane]; }
-  if (k.lane < 16) s.t_ctx_map4[k.lane] = c_ctx_ind_map_4x4[k.lane];
-  if (k.lane < 32) s.t_group_idx[k.lane] = c_group_idx[k.lane];
-  if (k.lane < 5) s.t_filter_thr[k.lane] = c_intra_filter_thr[k.lane];
-  if (k.lane < 12) { // CG order of every (scan type, block size)
-    const int type = k.lane >> 2, l = k.lane & 3, wg = 1 << l, ng = wg * wg;
-    uint8_t *cg = s.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
+  for (int i = lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
+  if (lane < 9) { s.t_ang[lane] = c_ang_table[lane]; s.t_inv_ang[lane] = c_inv_ang_table[lane]; }
+  if (lane < 16) s.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
+  if (lane < 32) s.t_group_idx[lane] = c_group_idx[lane];
+  if (lane < 5) s.t_filter_thr[lane] = c_intra_filter_thr[lane];
+  if (lane < 12) { // CG order of every (scan type, block size)
+    const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
+    LDS uint8_t *cg = s.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
     int ln = 0, c = 0;
     for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
   }
   wsync();
-  for (int t = k.lane; t < 3 * 85; t += 64) { // the 16 positions of every CG
+  for (int t = lane; t < 3 * 85; t += 64) { // the 16 positions of every CG
     const int type = t / 85, r = t - type * 85, l = r < 1 ? 0 : (r < 5 ? 1 : (r < 21 ? 2 : 3));
     const int g = r - (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21))), wg = 1 << l, n = 4 << l;
     const int cgb = s.scan_cg_all[type][r], gl = cgb / wg, gc = cgb - gl * wg;
-    uint16_t *sc = s.scan_all[type] + (l == 0 ? 0 : (l == 1 ? 16 : (l == 2 ? 80 : 336))) + g * 16;
+    LDS uint16_t *sc = s.scan_all[type] + (l == 0 ? 0 : (l == 1 ? 16 : (l == 2 ? 80 : 336))) + g * 16;
     int l2 = 0, c2 = 0;
     for (int q = 0; q < 16; q++) { sc[q] = (uint16_t)((l2 + gl * 4) * n + c2 + gc * 4); scan_next(type, 4, 4, l2, c2); }
   }
-  if (k.lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
+  if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
 #ifdef HEVCDL_KERNEL_PROF
-  if (k.lane < 24) { s.prof[k.lane] = 0; s.prof_n[k.lane] = 0; }
+  if (lane < 24) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   wsync();
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719
-  Cabac *truec = &s.truec;
-  for (int i = k.lane; i < NUM_CTX; i += 64) {
+  LCabac *truec = &s.truec;
+  for (int i = lane; i < NUM_CTX; i += 64) {
     const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
-    int st = ((slope * k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+    int st = ((slope * p.k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
     const int mps = st >= 64;
     truec->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
   }
-  if (k.lane == 0) truec->frac = 0;
+  if (lane == 0) truec->frac = 0;
   wsync();
 
-  for (int a = 0; a < k.nctu; a++) {
-    k.addr = a; k.cx = a % k.ctus_x; k.cy = a / k.ctus_x;
+  for (int a = 0; a < nctu; a++) {
+    const int cx = a % p.ctus_x, cy = a / p.ctus_x;
+    wsync();
+    k.addr = a; k.cx = cx; k.cy = cy;
     // initCtu TComDataCU.cpp:420-500
-    for (int i = k.lane; i < 256; i += 64) {
+    for (int i = lane; i < 256; i += 64) {
       for (int f = 0; f < 11; f++) s.a[f][i] = 0;
       s.a[A_PART][i] = SIZE_NONE; s.a[A_LDIR][i] = DC;
     }
     { // coefficient arrays of the record start at zero (initCtu memset)
-      uint32_t *rc = reinterpret_cast<uint32_t *>(k.records + (size_t)a * REC_SIZE + REC_COEF);
-      for (int i = k.lane; i < 6144 / 2; i += 64) rc[i] = 0;
+      GLB uint32_t *rc = (GLB uint32_t *)(records + (size_t)a * REC_SIZE + REC_COEF);
+      for (int i = lane; i < 6144 / 2; i += 64) rc[i] = 0;
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    const Rd best = compress_cu<0>(k, k.cx * 64, k.cy * 64);
+    const Rd best = compress_cu<0>(k, cx * 64, cy * 64);
     // the state-advancing encode (TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
     wsync();
-    if (k.lane == 0) reset_bits(truec);
-    encode_cu_tree<0>(k, truec, k.cx * 64, k.cy * 64);
+    if (lane == 0) reset_bits(truec);
+    encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
     wsync();
-    if (k.lane == 0) { if (a != k.nctu - 1) truec->frac += (unsigned long long)s.t_ebits[126]; s.est_bits += truec->frac >> 15; }
+    if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)s.t_ebits[126]; s.est_bits += truec->frac >> 15; }
     // flush the CTU record
-    unsigned char *rec = k.records + (size_t)a * REC_SIZE;
-    for (int i = k.lane; i < 11 * 256 / 4; i += 64) reinterpret_cast<uint32_t *>(rec)[i] = reinterpret_cast<const uint32_t *>(&s.a[0][0])[i];
-    if (k.lane == 0) {
-      *reinterpret_cast<uint32_t *>(rec + REC_BITS) = best.bits; *reinterpret_cast<uint32_t *>(rec + REC_DIST) = best.dist;
-      *reinterpret_cast<double *>(rec + REC_COST) = best.cost;
+    GLB unsigned char *rec = records + (size_t)a * REC_SIZE;
+    for (int i = lane; i < 11 * 256 / 4; i += 64) ((GLB uint32_t *)rec)[i] = ((LDS const uint32_t *)&s.a[0][0])[i];
+    if (lane == 0) {
+      *(GLB uint32_t *)(rec + REC_BITS) = best.bits; *(GLB uint32_t *)(rec + REC_DIST) = best.dist;
+      *(GLB double *)(rec + REC_COST) = best.cost;
     }
     wsync();
   }
 #ifdef HEVCDL_KERNEL_PROF
   wsync();
-  if (frame == 0 && p.dbgbuf && k.lane < 24) {
-    if (k.lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
-    p.dbgbuf[1 + 2 * k.lane] = (unsigned int)(s.prof[k.lane] >> 10); p.dbgbuf[2 + 2 * k.lane] = s.prof_n[k.lane];
-    if (k.lane == 0) p.dbgbuf[0] = 24;
+  if (frame == 0 && p.dbgbuf && lane < 24) {
+    if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
+    p.dbgbuf[1 + 2 * lane] = (unsigned int)(s.prof[lane] >> 10); p.dbgbuf[2 + 2 * lane] = s.prof_n[lane];
+    if (lane == 0) p.dbgbuf[0] = 24;
   }
 #endif
   if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits
-    hevcdl_frame_stats *st = reinterpret_cast<hevcdl_frame_stats *>(p.stats) + frame;
+    GLB hevcdl_frame_stats *st = (GLB hevcdl_frame_stats *)p.stats + frame;
     for (int c = 0; c < 3; c++) {
       const size_t npx = c ? csz : ysz; unsigned long long acc = 0;
-      for (size_t i = k.lane; i < npx; i += 64) { const int d = (int)k.org[c][i] - (int)k.rec[c][i]; acc += (unsigned long long)(d * d); }
+      GLB const uint8_t *po = org0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz)); GLB const uint8_t *pr = rec0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz));
+      for (size_t i = lane; i < npx; i += 64) { const int d = (int)po[i] - (int)pr[i]; acc += (unsigned long long)(d * d); }
       for (int m = 32; m >= 1; m >>= 1) { unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32); lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m); acc += ((unsigned long long)hi << 32) | lo; }
-      if (k.lane == 0) st->sse[c] = acc;
+      if (lane == 0) st->sse[c] = acc;
     }
-    if (k.lane == 0) { st->est_bits = s.est_bits; st->ctus = (uint32_t)k.nctu; st->pad = 0; }
+    if (lane == 0) { st->est_bits = s.est_bits; st->ctus = (uint32_t)nctu; st->pad = 0; }
   }
 }
 

@@ -1,5 +1,5 @@
 import sys, os, subprocess
-names=["build_refs","filter_refs","rmd_satd","predict_block","fwd_transform","load_scan","rdoq","dequant","inv_transform","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh"]
+names=["build_refs","filter_refs","rmd_satd","predict_block","rdoq:cg-prologue","rdoq:cg-walk","rdoq","dequant","rdoq:cg-epilogue","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh"]
 code="""
 import sys
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
