@@ -141,6 +141,7 @@ struct RdSmem {
   unsigned long long prof[24]; unsigned int prof_n[24];
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
+  double chain[5][17];                // RDOQ per-position addends of the five ordered sums (rows padded)
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
   int last_bits[2][12];
 };
@@ -695,62 +696,77 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
     const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
     const int rtab = (lane < 8) ? ctx_bits(cab, CTX_ONE + 4 * ctx_set + (lane >> 1), lane & 1)
                    : ((lane < 10) ? ctx_bits(cab, CTX_ABS + ctx_set, lane & 1) : 0);
-    // per-position results, filled for lane == pin while the state machine walks the group
+    // per-position results: the zero-level outcome, overwritten at lane == pin for the positions the state machine visits
+    const int valid_j = (lane < 16) && (j <= start_pin);
     int lvl_j = 0, c1_j = 1, ru_j = 0, rd_j = 0;
-    double cc_j = c0_j + cs0_j, cs_j = cs0_j;                       // the zero-level outcome
-    double st_sig_cost = 0, st_sig_cost0 = 0, st_coded = 0, st_uncoded = 0; int st_nnz_before0 = 0, cg_nonzero = 0;
+    double cc_j = c0_j + cs0_j, cs_j = cs0_j;
     RDOQ_MARK(4);
-    for (int pin = start_pin; pin >= 0; pin--) {
+    // Only positions whose rounded level is nonzero touch the c1/c2/Rice state (TComTrQuant.cpp:2300-2380): walk those,
+    // highest scan position first.  c1 is 1 at the start of every group; zero positions below a visited one see its c1.
+    unsigned nzmask = (unsigned)(__ballot(valid_j && ma_j > 0) & 0xffffull);
+    while (nzmask) {
+      const int pin = 31 - __clz((int)nzmask);
+      nzmask &= ~(1u << pin);
       const int sp = cgpos * 16 + pin;
       const int max_abs = __builtin_amdgcn_readlane(ma_j, pin);
       const double c0 = rl_d(c0_j, pin);
-      block_uncoded += c0;
-      double cost_c, cost_s;
-      uint32_t level = 0;
-      if (max_abs == 0) {                                          // never the last position
-        cost_s = rl_d(cs0_j, pin); cost_c = c0 + cost_s;
-        if (lane == pin) c1_j = c1;
-      } else {
-        const int32_t ld = __builtin_amdgcn_readlane(ld_j, pin);
-        const int is_last = (sp == last_pos);
-        { // xGetCodedLevel TComTrQuant.cpp:2812-2879
-          double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0;
-          cost_s = 0;
-          if (!is_last && max_abs < 3) { cost_s = rl_d(cs0_j, pin); best = c0 + cost_s; }
-          if (!is_last) cur_sig = rl_d(cs1_j, pin);
-          const uint32_t min_abs = max_abs > 1 ? (uint32_t)max_abs - 1 : 1;
-          for (int al = max_abs; al >= (int)min_abs; al--) {
-            const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
-            double cur = err * err * err_scale + lambda * (double)ic_rate_r(rtab, (uint32_t)al, c1, go_rice, c1idx, c2idx);
-            cur += cur_sig;
-            if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_s = cur_sig; }
-          }
-          cost_c = best; level = best_lvl;
+      const int32_t ld = __builtin_amdgcn_readlane(ld_j, pin);
+      const int is_last = (sp == last_pos);
+      double cost_c, cost_s = 0;
+      uint32_t level;
+      { // xGetCodedLevel TComTrQuant.cpp:2812-2879
+        double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0;
+        if (!is_last && max_abs < 3) { cost_s = rl_d(cs0_j, pin); best = c0 + cost_s; }
+        if (!is_last) cur_sig = rl_d(cs1_j, pin);
+        const uint32_t min_abs = max_abs > 1 ? (uint32_t)max_abs - 1 : 1;
+        for (int al = max_abs; al >= (int)min_abs; al--) {
+          const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
+          double cur = err * err * err_scale + lambda * (double)ic_rate_r(rtab, (uint32_t)al, c1, go_rice, c1idx, c2idx);
+          cur += cur_sig;
+          if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_s = cur_sig; }
         }
-        int rup, rdn = 0;
-        if (level > 0) {
-          const int now = ic_rate_r(rtab, level, c1, go_rice, c1idx, c2idx);
-          rup = ic_rate_r(rtab, level + 1, c1, go_rice, c1idx, c2idx) - now;
-          rdn = ic_rate_r(rtab, level - 1, c1, go_rice, c1idx, c2idx) - now;
-        } else rup = __builtin_amdgcn_readlane(rtab, 2 * c1);
-        if (lane == pin) { lvl_j = (int)level; cc_j = cost_c; cs_j = cost_s; ru_j = rup; rd_j = rdn; c1_j = -1; }
-        const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
-        if (level >= base_level) { if (level > 3u * (1u << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4; }
-        if (level >= 1) c1idx++;
-        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2idx++; }
-        else if (c1 < 3 && c1 > 0 && level) c1++;
+        cost_c = best; level = best_lvl;
       }
-      base_cost += cost_c;
-      if (pin == 0 && sp > 0) { ctx_set = ctx_set_index(ch, (sp - 1) >> 4, c1 == 0); c1 = 1; c2 = 0; c1idx = 0; c2idx = 0; go_rice = 0; }
-      st_sig_cost += cost_s;
-      if (pin == 0) st_sig_cost0 = cost_s;
-      if (level) {
-        cg_nonzero = 1;
-        st_coded += cost_c - cost_s;
-        st_uncoded += c0;
-        if (pin != 0) st_nnz_before0++;
-      }
+      int rup, rdn = 0;
+      if (level > 0) {
+        const int now = ic_rate_r(rtab, level, c1, go_rice, c1idx, c2idx);
+        rup = ic_rate_r(rtab, level + 1, c1, go_rice, c1idx, c2idx) - now;
+        rdn = ic_rate_r(rtab, level - 1, c1, go_rice, c1idx, c2idx) - now;
+      } else rup = __builtin_amdgcn_readlane(rtab, 2 * c1);
+      if (lane == pin) { lvl_j = (int)level; cc_j = cost_c; cs_j = cost_s; ru_j = rup; rd_j = rdn; c1_j = -1; }
+      const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
+      if (level >= base_level) { if (level > 3u * (1u << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4; }
+      if (level >= 1) c1idx++;
+      if (level > 1) { c1 = 0; c2 += (c2 < 2); c2idx++; }
+      else if (c1 < 3 && c1 > 0 && level) c1++;
+      if (lane < pin) c1_j = c1;
     }
+    if (cgpos > 0) { ctx_set = ctx_set_index(ch, cgpos - 1, c1 == 0); c1 = 1; c2 = 0; c1idx = 0; c2idx = 0; go_rice = 0; }
+    // The five running fp64 sums of the group (each in scan order, pin = 15..0, as the reference accumulates them)
+    // run side by side on lanes 0..4: the per-position addends are transposed through LDS, then 16 dependent adds.
+    //   0 block_uncoded += c0      1 base_cost += cost_c      2 sig_cost += cost_s
+    //   3 coded += cost_c - cost_s (nonzero levels)           4 uncoded += c0 (nonzero levels)
+    // A position that does not contribute adds +0.0, which leaves a sum unchanged.
+    const int nz_j = valid_j && lvl_j != 0;
+    if (lane < 16) {
+      s.chain[0][j] = valid_j ? c0_j : 0.0; s.chain[1][j] = valid_j ? cc_j : 0.0; s.chain[2][j] = valid_j ? cs_j : 0.0;
+      s.chain[3][j] = nz_j ? cc_j - cs_j : 0.0; s.chain[4][j] = nz_j ? c0_j : 0.0;
+    }
+    wsync();
+    double st_sig_cost, st_sig_cost0, st_coded, st_uncoded;
+    {
+      const int row = lane < 4 ? lane : 4;
+      double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) v[t] = s.chain[row][t];
+#pragma unroll
+      for (int t = 15; t >= 0; t--) acc += v[t];
+      block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1); st_sig_cost = rl_d(acc, 2); st_coded = rl_d(acc, 3); st_uncoded = rl_d(acc, 4);
+      st_sig_cost0 = rl_d(cs_j, 0);
+    }
+    const unsigned nzfinal = (unsigned)(__ballot(nz_j) & 0xffffull);
+    const int st_nnz_before0 = __popc(nzfinal & 0xfffeu), cg_nonzero = nzfinal != 0;
     RDOQ_MARK(5);
     // lane-parallel write-back of the group (the bpermute runs with all lanes enabled: a disabled source lane reads 0)
     const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
