@@ -118,7 +118,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   ctx->scratch_per_frame = hevcdl_rd_scratch_bytes();
   CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames));
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
-  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes()));
+  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0)));
 #undef CK
   *out = ctx;
   return HEVCDL_OK;
@@ -187,7 +187,8 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   unsigned int *d_dbg = nullptr;
   if (getenv("HEVCDL_DBGBUF")) { hipMalloc(&d_dbg, 8004 * 4); hipMemset(d_dbg, 0, 8004 * 4); p.dbgbuf = d_dbg; }
   prof_begin(ctx, ctx->ev_rd, s);
-  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames), dim3(64), hevcdl_rd_smem_bytes(), s, p);
+  // HEVCDL_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the number of resident waves per CU
+  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
   if (d_dbg) {

@@ -113,25 +113,27 @@ typedef const LDS K &KR;
 
 struct RdSmem {
   K k;
-  Cabac go, curr[5], next[5], temp[5], root[5], test[5], tbest[5], truec;
+  Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
   uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
   int16_t line[264], fline[264];      // reference samples: bottom-left ... corner(2n) ... top-right
-  int32_t tc[1024];                   // transform coefficients (RDOQ input) / dequantised coefficients
-  int16_t resi[32 * 34];              // residual, row stride n+2 (bank-conflict-free column access)
-  int16_t lvl[1024];                  // quantised levels of the current TU (TU raster)
+  // residual (row stride n+2: conflict-free column access) and transform / dequantised coefficients (raster) share
+  // storage: the residual is dead once the forward transform has consumed it and is rebuilt by the inverse transform.
+  // Every value fits 16 bits (HEVC transform dynamic range; the reference clips the inverse stages explicitly).
+  union { int16_t resi[32 * 34]; int16_t tc[1024]; };
+  // quantised levels of the current TU (raster); the transform intermediate (row stride n+1) lives behind the first 16
+  // entries, i.e. a 4x4 block of levels survives the inverse transform (transform-skip bookkeeping needs it)
+  int16_t lvl[16 + 32 * 33];
   uint8_t pred[1024];                 // prediction, then reconstruction, of the current TU
-  uint16_t scan_all[3][1360];         // grouped-4x4 coefficient scans (TComRom.cpp:179-260): [type][4x4 | 8x8 | 16x16 | 32x32]
+  // grouped-4x4 coefficient scans (TComRom.cpp:179-260) = CG order x order inside a CG, composed on the fly
   uint8_t scan_cg_all[3][88];         // CG order per [type][1 | 4 | 16 | 64 groups]
+  uint8_t scan_in_cg[3][16];          // (y << 2) | x of the 16 positions of a CG, per scan type
   // small constant tables copied to LDS once per kernel: the serial RDOQ / bin-counting code reads them with
   // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
   int32_t t_ebits[128]; uint8_t t_next[2][128];
   int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
-  struct { int32_t tmp[32 * 33]; } u; // transform intermediate, row stride n+1
   uint8_t sv_tr[256], sv_cbf[3][256], sv_ts[3][256];
   uint8_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
-  unsigned int satd[36];
-  double rmd_cost[36];
   unsigned int rd_list[16];
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
   unsigned int red_u32;
@@ -141,7 +143,10 @@ struct RdSmem {
   unsigned long long prof[24]; unsigned int prof_n[24];
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
-  double chain[5][17];                // RDOQ per-position addends of the five ordered sums (rows padded)
+  union {
+    double chain[5][17];              // RDOQ per-position addends of the five ordered sums (rows padded)
+    struct { double rmd_cost[36]; unsigned int satd[36]; };   // rough mode decision (never live during RDOQ)
+  };
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
   int last_bits[2][12];
 };
@@ -438,41 +443,43 @@ template <int N, bool DST> DEV void fwd_transform_n(KR k)
   constexpr int LOG2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
   constexpr int s1 = LOG2 + 8 - 9, s2 = LOG2 + 6, a1 = 1 << (s1 - 1), a2 = 1 << (s2 - 1);
   LSmem &s = lds();
+  LDS int16_t *tmp_ = s.lvl + 16;
   if (lane_id() < N) {
     int x[N], y[N];
 #pragma unroll
     for (int i = 0; i < N; i++) x[i] = s.resi[lane_id() * (N + 2) + i];
     if constexpr (DST) dst4_fwd(x, y); else fwd1d<N>(x, y);
 #pragma unroll
-    for (int kk = 0; kk < N; kk++) s.u.tmp[lane_id() * (N + 1) + kk] = (y[kk] + a1) >> s1;       // tmp[j][kk]
+    for (int kk = 0; kk < N; kk++) tmp_[lane_id() * (N + 1) + kk] = (int16_t)((y[kk] + a1) >> s1);       // tmp[j][kk]
   }
   wsync();
   if (lane_id() < N) {
     int x[N], y[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) x[j] = s.u.tmp[j * (N + 1) + lane_id()];                          // column kk = lane
+    for (int j = 0; j < N; j++) x[j] = tmp_[j * (N + 1) + lane_id()];                          // column kk = lane
     if constexpr (DST) dst4_fwd(x, y); else fwd1d<N>(x, y);
 #pragma unroll
-    for (int k2 = 0; k2 < N; k2++) s.tc[k2 * N + lane_id()] = (y[k2] + a2) >> s2;
+    for (int k2 = 0; k2 < N; k2++) s.tc[k2 * N + lane_id()] = (int16_t)((y[k2] + a2) >> s2);
   }
   wsync();
 }
 template <int N, bool DST> DEV void inv_transform_n(KR k)
 { // s->tc (dequantised, raster) -> s->resi (stride RS); xITrMxN TComTrQuant.cpp:927-987
   LSmem &s = lds();
+  LDS int16_t *tmp_ = s.lvl + 16;
   if (lane_id() < N) {
     int c[N], x[N];
 #pragma unroll
     for (int kk = 0; kk < N; kk++) c[kk] = s.tc[kk * N + lane_id()];                               // column j = lane
     if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
 #pragma unroll
-    for (int i = 0; i < N; i++) s.u.tmp[lane_id() * (N + 1) + i] = clip16((x[i] + 64) >> 7);       // tmp[j][x]
+    for (int i = 0; i < N; i++) tmp_[lane_id() * (N + 1) + i] = (int16_t)clip16((x[i] + 64) >> 7);       // tmp[j][x]
   }
   wsync();
   if (lane_id() < N) {
     int c[N], x[N];
 #pragma unroll
-    for (int u = 0; u < N; u++) c[u] = s.u.tmp[u * (N + 1) + lane_id()];                           // row y = lane
+    for (int u = 0; u < N; u++) c[u] = tmp_[u * (N + 1) + lane_id()];                           // row y = lane
     if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
 #pragma unroll
     for (int i = 0; i < N; i++) s.resi[lane_id() * (N + 2) + i] = (int16_t)clip16((x[i] + 2048) >> 12);
@@ -502,6 +509,15 @@ DEVN void inv_transform(KR k, int n_, int use_dst_)
 // coefficient-coding geometry shared by RDOQ and the bit counter
 // ---------------------------------------------------------------------------------------------------
 struct CParam { int log2, n, ch, scan_type, wg, first_sig_ctx; };
+// scan position -> raster position of an n x n block: CG order (LDS) composed with the order inside a CG (LDS)
+struct ScanFn {
+  LDS const uint8_t *cg; LDS const uint8_t *in; int log2n, l;
+  DEV int operator[](int sp) const
+  {
+    const int g = cg[sp >> 4], p = in[sp & 15], gy = g >> l, gx = g - (gy << l);
+    return (((gy << 2) + (p >> 2)) << log2n) + (gx << 2) + (p & 3);
+  }
+};
 
 DEV int coef_scan_idx(int c, int n, int dir_mode)
 { // TComDataCU.cpp:3150-3209
@@ -536,7 +552,7 @@ DEV int sig_cg_ctx(LDS const uint8_t *cgf, int gx, int gy, int wg)
   const int r = (gx < wg - 1) ? (cgf[gy * wg + gx + 1] != 0) : 0, l = (gy < wg - 1) ? (cgf[(gy + 1) * wg + gx] != 0) : 0;
   return (r + l) != 0;
 }
-DEV int sig_ctx_inc(const CParam &cp, LDS const uint16_t *scan, int pat, int scan_pos)
+DEV int sig_ctx_inc(const CParam &cp, const ScanFn &scan, int pat, int scan_pos)
 { // TComTrQuant.cpp:2707-2803
   const int raster = scan[scan_pos], py = raster >> cp.log2, px = raster - (py << cp.log2);
   if (px + py == 0) return 0;
@@ -553,7 +569,11 @@ DEV int sig_ctx_inc(const CParam &cp, LDS const uint16_t *scan, int pat, int sca
   }
   return cp.first_sig_ctx + offset;
 }
-DEV LDS const uint16_t *scan_of(const LSmem &s, int type, int log2n) { return s.scan_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 16 : (log2n == 4 ? 80 : 336))); }
+DEV ScanFn scan_of(const LSmem &s, int type, int log2n)
+{
+  ScanFn f; f.cg = s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); f.in = s.scan_in_cg[type]; f.log2n = log2n; f.l = log2n - 2;
+  return f;
+}
 DEV LDS const uint8_t *scan_cg_of(const LSmem &s, int type, int log2n) { return s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); }
 DEV int ctx_set_index(int ch, int subset, int found_gt1) { return (ch ? 4 : 0) + ((!ch && subset > 0) ? 2 : 0) + (found_gt1 ? 1 : 0); }   // TComChromaFormat.h:243-251
 DEV void last_ctx_params(int ch, int n, int &off, int &shift)
@@ -637,8 +657,8 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
   const int qcoef = uni(c_quant_scales[rem]);
   const int ncoef = n * n;
   CParam cp; get_cparam(cp, c, n, dir_mode);
-  LDS const uint16_t *scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
-  LDS const int32_t *src = s.tc; LDS int16_t *dst = s.lvl;
+  const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
+  LDS const int16_t *src = s.tc; LDS int16_t *dst = s.lvl;
   GLB double *cost_coeff = k.q_cost, *cost_sig = k.q_cost + 1024;
   GLB int32_t *rate_inc_up = k.q_rate, *rate_inc_down = k.q_rate + 1024, *sig_rate_delta = k.q_rate + 2048, *delta_u = k.q_rate + 3072;
   LDS double *cost_cg_sig = s.cg_cost; LDS uint8_t *cgf = s.cgf;
@@ -935,7 +955,7 @@ DEVN void dequant(KR k, int c_, int n_)
     int v;
     if (rshift > 0) v = (q * scale + (1 << (rshift - 1))) >> rshift;
     else v = (int)((unsigned)(q * scale) << (-rshift));
-    lds().tc[i] = clip16(v);
+    lds().tc[i] = (int16_t)clip16(v);
   }
   wsync();
   PROF_ADD(k, 7);
@@ -973,7 +993,7 @@ DEVN void code_coeff_lane0(KR k, LCabac *c, int comp_, int n_, int dir_mode_, in
   const int ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
   const int log2n = cp.log2;
-  LDS const int16_t *coef = s.lvl; LDS const uint16_t *scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
+  LDS const int16_t *coef = s.lvl; const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   int num_sig = 0;
   for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
   if (num_sig == 0) return;                                   // never called for an empty TU (cbf checked by the caller)
@@ -1244,7 +1264,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
   wsync();
-  if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int32_t)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5; wsync(); }
+  if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int16_t)((int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5); wsync(); }   // n == 4: one pass, every lane reads before any writes
   else fwd_transform(k, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
   { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
@@ -1324,7 +1344,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
         }
         if (ub(cost < single_cost)) {
           single_cost = cost; single_dist = d; single_cbf = cbf; best_ts = m;
-          if (m == 0) cabac_copy(k, &s.tbest[full_depth], &s.go);
+          if (m == 0) cabac_copy(k, &s.tbest, &s.go);
         }
         if (m == 0) cabac_copy(k, &s.go, &s.root[full_depth]);
       }
@@ -1332,7 +1352,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       if (best_ts == 0) {
         load_ts_result(k, cu, tu, 0);
         set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd)); wsync();
-        cabac_copy(k, &s.go, &s.tbest[full_depth]);
+        cabac_copy(k, &s.go, &s.tbest);
       }
     } else {
       if (check_split) cabac_copy(k, &s.root[full_depth], &s.go);
@@ -1603,14 +1623,14 @@ template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
         }
         if (ub(cost_tmp < single_cost)) {
           single_cost = cost_tmp; single_dist = d; best_ts = ts; best_id = cur_id; single_cbf = cbf;
-          if (!one && !last) cabac_copy(k, &s.tbest[full_depth], &s.go);
+          if (!one && !last) cabac_copy(k, &s.tbest, &s.go);
         }
         if (!one && !last) cabac_copy(k, &s.go, &s.root[full_depth]);
       }
       if (ub(best_id < total)) {
         load_ts_result(k, cu, tu, comp);
         set_parts(k, s.a[A_CBF + comp], zc, np, (int)(single_cbf << tu.trd)); wsync();
-        cabac_copy(k, &s.go, &s.tbest[full_depth]);
+        cabac_copy(k, &s.go, &s.tbest);
       }
       set_parts(k, s.a[A_TSKIP + comp], zc, np, best_ts); wsync();
       dist_sum += single_dist;
@@ -1869,13 +1889,9 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
   }
   wsync();
-  for (int t = lane; t < 3 * 85; t += 64) { // the 16 positions of every CG
-    const int type = t / 85, r = t - type * 85, l = r < 1 ? 0 : (r < 5 ? 1 : (r < 21 ? 2 : 3));
-    const int g = r - (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21))), wg = 1 << l, n = 4 << l;
-    const int cgb = s.scan_cg_all[type][r], gl = cgb / wg, gc = cgb - gl * wg;
-    LDS uint16_t *sc = s.scan_all[type] + (l == 0 ? 0 : (l == 1 ? 16 : (l == 2 ? 80 : 336))) + g * 16;
+  if (lane < 3) { // order inside a CG, per scan type
     int l2 = 0, c2 = 0;
-    for (int q = 0; q < 16; q++) { sc[q] = (uint16_t)((l2 + gl * 4) * n + c2 + gc * 4); scan_next(type, 4, 4, l2, c2); }
+    for (int q = 0; q < 16; q++) { s.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
   }
   if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
 #ifdef HEVCDL_KERNEL_PROF
