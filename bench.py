@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--frames", type=int, default=2048, help="frames per GPU per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0)
     a = ap.parse_args()
