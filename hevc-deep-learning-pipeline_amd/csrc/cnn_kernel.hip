@@ -7,32 +7,45 @@
 //   label file IPC                        use_model.py:121-125 <-> TEncCu.cpp:244-253   (labels stay in HBM)
 // plus the YUV->RGB input transform and the boundary clamp defined by this project.
 //
-// Whole network for the 4 quadrants of one CTU runs inside one workgroup with all activations in LDS
-// (~122 KB): conv+BN+ReLU+pool are fused (BN statistics are per sample = per workgroup, so no global
-// reduction exists); the conv64 branch is evaluated once and shared by the 4 quadrants (identical input,
-// identical per-sample statistics).  Weights are pre-packed [k][oc] so that the oc run of one tap is
-// contiguous: taps are wave-uniform and come through the scalar cache (s_load), activations come from LDS.
+// The four convolutions are im2col GEMMs on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate,
+// bit-identical to an fmaf chain).  M = output positions (16 per tile, ordered so that the 4 accumulator registers
+// of a lane are the members of one max-pool window), N = 16 output channels per tile, K = taps x input channels.
+//   A operand: one ds_read_b32 per lane and MFMA out of zero-halo'd fp32 activation maps in LDS
+//   B operand: weights pre-packed on the host in lane order ([N-tile][k-step][64 lanes]) -> one coalesced dword load
+// conv+BN(train)+ReLU+pool are fused: BN statistics are per sample = per workgroup, so no global reduction exists;
+// x -> relu(x*alpha+beta) is monotone, so the pool runs before the affine map (max or min by the sign of gamma).
+// The conv64 branch is evaluated once and shared by the 4 quadrants (identical input, identical statistics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hevcdl_dev.h"
 
 namespace {
 
-// weights are read-only and tap-uniform: constant address space -> scalar loads (s_load_dwordx*)
-typedef __attribute__((address_space(4))) const float cfloat;
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define LDS __attribute__((address_space(3)))
+#define GLB __attribute__((address_space(1)))
 
-constexpr int A_STRIDE = 18;               // 16x16 map + 1-pixel zero halo
-constexpr int A2_STRIDE = 10;              // 8x8 map + halo
+constexpr int A_CH = 328;                  // 18x18 halo'd 16x16 map, channel stride == 8 (mod 32 banks)
+constexpr int A_ROW = 18;
+constexpr int A2_CH = 104;                 // 10x10 halo'd 8x8 map
+constexpr int A2_ROW = 10;
+constexpr int T64_ROW = 72, T64_CH = 68 * 72;   // fp32 input tile of the CTU, halo 2, row pitch == 8 (mod 32)
+constexpr int T32_ROW = 40, T32_CH = 36 * 40;   // fp32 input tile of one quadrant, halo 2
 
 struct CnnSmem {
   uint8_t in[3][64][64];                   // RGB planes of the CTU (zero past the picture edge)
   float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95)
-  float a64[16][A_STRIDE * A_STRIDE];      // conv64 branch output (shared by the 4 quadrants)
-  float a1[16][A_STRIDE * A_STRIDE];       // conv1 output of the current quadrant
-  float a2[64][A2_STRIDE * A2_STRIDE];     // conv2 output of the current quadrant
-  float a3[2048][4];                       // conv3 outputs, [flatten index][quadrant]
-  double red[2][4][64];                    // per-wave partial sums / sums of squares
-  float alpha[128], beta[128];             // BN folded to y = x*alpha + beta
+  int koff64[76], koff32[76];              // im2col offset of tap k = (c*5+ky)*5+kx inside the input tiles
+  float act12[32 * A_CH];                  // conv1 output (channels 0..15) ++ conv64 output (16..31): cat of use_model.py:50
+  union {
+    float t64[3 * T64_CH];                 // conv64 input tile (only live before the quadrant loop)
+    struct {
+      union { float t32[3 * T32_CH]; float a2[64 * A2_CH]; };   // conv1 input tile | conv2 output
+      float a3[2048][4];                   // conv3 outputs, [flatten index][quadrant]
+    } q;
+  };
+  double red[2][4][16];                    // per-wave partial sums / sums of squares
+  float alpha[16], beta[16];               // BN folded to y = x*alpha + beta (conv1 / conv64)
   float h1[4][256], h2[4][64], lg[4][16];
 };
 
@@ -41,30 +54,6 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m)
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
   return __hiloint2double(hi, lo);
-}
-
-// transposing butterfly: every lane holds N per-channel values; afterwards lane l holds in v[0] the
-// wave-wide sum of channel (l % N).  N = 64 or 32, wave = 64 lanes.
-template <int N>
-__device__ __forceinline__ void wave_channel_sums(double (&v)[N], int lane)
-{
-  if (N == 32) {
-#pragma unroll
-    for (int i = 0; i < 32; i++) v[i] += shfl_xor_d(v[i], 32);
-  }
-  int count = N;
-#pragma unroll
-  for (int mask = N / 2; mask >= 1; mask >>= 1) {
-    const int half = count / 2;
-    const bool up = (lane & mask) != 0;
-#pragma unroll
-    for (int i = 0; i < half; i++) {
-      double keep = up ? v[i + half] : v[i];
-      double send = up ? v[i] : v[i + half];
-      v[i] = keep + shfl_xor_d(send, mask);
-    }
-    count = half;
-  }
 }
 
 // BN in training mode folded to an affine map (nn.BatchNorm2d defaults: biased variance, eps 1e-5)
@@ -78,69 +67,75 @@ __device__ __forceinline__ void bn_fold(double s, double ss, double n, float gam
   betap = (float)((double)beta - mean * inv * (double)gamma);
 }
 
-// 5x5 conv (3 -> 16, pad 2 relative to the REGION) + BN(train) + ReLU + POOLxPOOL max pool -> 16 x 16x16.
-// Region = size x size square of the CTU at (rx, ry); zero padding outside the region (the reference crops the
-// 32x32 quadrant first, use_model.py:92, so the padding is not the neighbouring CTU pixels).
+__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// 5x5 conv (3 -> 16, zero pad 2 relative to the region) + BN(train) + ReLU + POOLxPOOL max pool -> 16 maps of 16x16.
+// tile: fp32 region with a 2-pixel zero halo (row pitch ROW, channel stride CH); koff: im2col offsets for that pitch.
+// POOL == 4 (conv64, 64x64 region): one M-tile = one 4x4 pool window.   POOL == 2 (conv1, 32x32 quadrant): one
+// M-tile = 4 horizontally adjacent 2x2 windows, lane group g = lane >> 4 ends up with window g in its 4 registers.
+// The pooled extreme (max for gamma >= 0, min otherwise) is written straight into the halo'd destination map and
+// rescaled in place once the statistics of the whole map are known.
 template <int POOL>
-__device__ __noinline__ void conv5_block(CnnSmem &sm, cfloat *w, cfloat *bias, cfloat *gamma, cfloat *betaw,
-                            int rx, int ry, float (*out)[A_STRIDE * A_STRIDE], int tid)
+__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *out, int tid)
 {
-  constexpr int SIZE = 16 * POOL;
-  const int py = tid >> 4, px = tid & 15;
-  float mx[16], mn[16]; double s[16], ss[16];
+  constexpr int ROW = (POOL == 4) ? T64_ROW : T32_ROW;
+  constexpr int TILES = (POOL == 4) ? 64 : 16;      // per wave
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  float bw[19];
 #pragma unroll
-  for (int o = 0; o < 16; o++) { mx[o] = -3.4e38f; mn[o] = 3.4e38f; s[o] = 0; ss[o] = 0; }
+  for (int ks = 0; ks < 19; ks++) bw[ks] = w[ks * 64 + lane];
+  const float bias = w[1216 + i], gamma = w[1232 + i];
+  int ko[19];
+#pragma unroll
+  for (int ks = 0; ks < 19; ks++) ko[ks] = koff[ks * 4 + g];
+  double s = 0, ss = 0;
 #pragma unroll 1
-  for (int wy = 0; wy < POOL; wy++)
-#pragma unroll 1
-    for (int wx = 0; wx < POOL; wx++) {
-      const int y = py * POOL + wy, x = px * POOL + wx;
-      float acc[16];
+  for (int t0 = 0; t0 < TILES; t0 += 4) {
+    v4f acc[4]; int base[4];
 #pragma unroll
-      for (int o = 0; o < 16; o++) acc[o] = bias[o];
-#pragma unroll 1
-      for (int c = 0; c < 3; c++)
-#pragma unroll 1
-        for (int ky = 0; ky < 5; ky++) {
-          const int yy = y + ky - 2;
-          const bool yok = (yy >= 0) && (yy < SIZE);
-#pragma unroll
-          for (int kx = 0; kx < 5; kx++) {
-            const int xx = x + kx - 2;
-            float v = 0.f;
-            if (yok && xx >= 0 && xx < SIZE) v = sm.lut[sm.in[c][ry + yy][rx + xx]];
-            cfloat *wp = w + ((c * 5 + ky) * 5 + kx) * 16;
-#pragma unroll
-            for (int o = 0; o < 16; o++) acc[o] = fmaf(v, wp[o], acc[o]);
-          }
-        }
-#pragma unroll
-      for (int o = 0; o < 16; o++) {
-        mx[o] = fmaxf(mx[o], acc[o]); mn[o] = fminf(mn[o], acc[o]);
-        s[o] += (double)acc[o]; ss[o] += (double)acc[o] * (double)acc[o];
-      }
+    for (int u = 0; u < 4; u++) {
+      const int t = wave * TILES + t0 + u;
+      int y, x;
+      if (POOL == 4) { y = 4 * (t >> 4) + (i >> 2); x = 4 * (t & 15) + (i & 3); }
+      else { y = 2 * (t >> 2) + ((i >> 1) & 1); x = 2 * (4 * (t & 3) + (i >> 2)) + (i & 1); }
+      base[u] = y * ROW + x;
+      acc[u] = (v4f){ bias, bias, bias, bias };
     }
-  // block-wide per-channel sums
-  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-  for (int o = 0; o < 16; o++) {
-    double a = s[o], b = ss[o];
+    for (int ks = 0; ks < 19; ks++)
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { a += shfl_xor_d(a, m); b += shfl_xor_d(b, m); }
-    if (lane == 0) { sm.red[0][wave][o] = a; sm.red[1][wave][o] = b; }
+      for (int u = 0; u < 4; u++) acc[u] = mfma4(tile[base[u] + ko[ks]], bw[ks], acc[u]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = wave * TILES + t0 + u;
+      const v4f a = acc[u];
+      s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+      ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+      float e = (gamma >= 0.f) ? fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)) : fminf(fminf(a.x, a.y), fminf(a.z, a.w));
+      if (POOL == 4) {
+        const float o1 = __shfl_xor(e, 16); e = (gamma >= 0.f) ? fmaxf(e, o1) : fminf(e, o1);
+        const float o2 = __shfl_xor(e, 32); e = (gamma >= 0.f) ? fmaxf(e, o2) : fminf(e, o2);
+        if (g == 0) out[i * A_CH + ((t >> 4) + 1) * A_ROW + (t & 15) + 1] = e;
+      } else out[i * A_CH + ((t >> 2) + 1) * A_ROW + 4 * (t & 3) + g + 1] = e;
+    }
   }
+  // per-channel statistics over the whole map: lane groups, then waves
+  s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
+  if (lane < 16) { sm.red[0][wave][lane] = s; sm.red[1][wave][lane] = ss; }
   __syncthreads();
   if (tid < 16) {
     double a = 0, b = 0;
     for (int k = 0; k < 4; k++) { a += sm.red[0][k][tid]; b += sm.red[1][k][tid]; }
-    bn_fold(a, b, (double)(SIZE * SIZE), gamma[tid], betaw[tid], sm.alpha[tid], sm.beta[tid]);
+    constexpr int SIZE = 16 * POOL;
+    float al, be;
+    bn_fold(a, b, (double)(SIZE * SIZE), w[1232 + tid], w[1248 + tid], al, be);
+    sm.alpha[tid] = al; sm.beta[tid] = be;
   }
   __syncthreads();
+  { // in-place affine + ReLU of the 16 pooled maps: thread = pixel
+    const int py = tid >> 4, px = tid & 15;
 #pragma unroll
-  for (int o = 0; o < 16; o++) {
-    const float al = sm.alpha[o], be = sm.beta[o];
-    const float v = (al >= 0.f) ? mx[o] : mn[o];     // x -> relu(x*al+be) is monotone: pool before the affine map
-    out[o][(py + 1) * A_STRIDE + px + 1] = fmaxf(v * al + be, 0.f);
+    for (int o = 0; o < 16; o++) { float LDS *d = out + o * A_CH + (py + 1) * A_ROW + px + 1; *d = fmaxf(*d * sm.alpha[o] + sm.beta[o], 0.f); }
   }
   __syncthreads();
 }
@@ -151,22 +146,26 @@ extern "C" __global__ __launch_bounds__(256)
 void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  CnnSmem &sm = *reinterpret_cast<CnnSmem *>(smem_raw);
+  CnnSmem LDS &sm = *(CnnSmem LDS *)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gctu = blockIdx.x;                       // global CTU index over all frames
   const int frame = gctu / p.ctus_per_frame, addr = gctu - frame * p.ctus_per_frame;
   const int x0 = (addr % p.ctus_x) * 64, y0 = (addr / p.ctus_x) * 64;
-  cfloat *W = (cfloat *)p.weights;
+  const float GLB *W = (const float GLB *)p.weights;
 
-  // ---- stage 0: CTU input -> LDS (coalesced rows of the planes), LUT, zero the halo'd maps -------------
+  // ---- stage 0: CTU input -> LDS (coalesced rows of the planes), LUT, im2col tables, zeroed halo'd maps --------
   sm.lut[tid] = (float)tid / 255.0f;
+  if (tid < 76) {
+    const int k = tid < 75 ? tid : 0, c = k / 25, r = k - c * 25, ky = r / 5, kx = r - ky * 5;   // tap 75 is padding (zero weight)
+    sm.koff64[tid] = c * T64_CH + ky * T64_ROW + kx; sm.koff32[tid] = c * T32_CH + ky * T32_ROW + kx;
+  }
   if (p.input_mode == HEVCDL_DEV_INPUT_RGB_CTU) {
-    const uint8_t *src = p.input + (size_t)gctu * (64 * 64 * 3);
+    const uint8_t GLB *src = (const uint8_t GLB *)p.input + (size_t)gctu * (64 * 64 * 3);
     for (int i = tid; i < 64 * 64 * 3; i += 256) { int pix = i / 3, c = i - pix * 3; sm.in[c][pix >> 6][pix & 63] = src[i]; }
   } else {
     const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
-    const uint8_t *Y = p.input + (size_t)frame * fsz, *U = Y + ysz, *V = U + (ysz >> 2);
+    const uint8_t GLB *Y = (const uint8_t GLB *)p.input + (size_t)frame * fsz, *U = Y + ysz, *V = U + (ysz >> 2);
     const int cw = p.width >> 1;
     for (int i = tid; i < 64 * 64; i += 256) {
       const int y = i >> 6, x = i & 63, gx = x0 + x, gy = y0 + y;
@@ -183,101 +182,116 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       sm.in[0][y][x] = (uint8_t)r; sm.in[1][y][x] = (uint8_t)g; sm.in[2][y][x] = (uint8_t)b;
     }
   }
-  for (int i = tid; i < 16 * A_STRIDE * A_STRIDE; i += 256) { (&sm.a64[0][0])[i] = 0.f; (&sm.a1[0][0])[i] = 0.f; }
-  for (int i = tid; i < 64 * A2_STRIDE * A2_STRIDE; i += 256) (&sm.a2[0][0])[i] = 0.f;
+  for (int i = tid; i < 32 * A_CH; i += 256) sm.act12[i] = 0.f;
+  for (int i = tid; i < 3 * T64_CH; i += 256) sm.t64[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < 3 * 64 * 64; i += 256) {
+    const int c = i >> 12, y = (i >> 6) & 63, x = i & 63;
+    sm.t64[c * T64_CH + (y + 2) * T64_ROW + x + 2] = sm.lut[sm.in[c][y][x]];
+  }
   __syncthreads();
 
   // ---- conv64 branch, once per CTU (use_model.py:38-43) --------------------------------------------
-  conv5_block<4>(sm, W + HEVCDL_W_C64, W + HEVCDL_W_C64 + 1200, W + HEVCDL_W_C64 + 1216, W + HEVCDL_W_C64 + 1232, 0, 0, sm.a64, tid);
+  conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12 + 16 * A_CH, tid);
 
+  const int i16 = lane & 15, g4 = lane >> 4;
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
-    // ---- conv1 on the 32x32 quadrant (use_model.py:20-25) ------------------------------------------
-    conv5_block<2>(sm, W + HEVCDL_W_C1, W + HEVCDL_W_C1 + 1200, W + HEVCDL_W_C1 + 1216, W + HEVCDL_W_C1 + 1232,
-                   (q & 1) * 32, (q >> 1) * 32, sm.a1, tid);
+    // ---- conv1 on the 32x32 quadrant (use_model.py:20-25); its input tile shares storage with conv2's output ----
+    for (int i = tid; i < 3 * T32_CH; i += 256) sm.q.t32[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < 3 * 32 * 32; i += 256) {
+      const int c = i >> 10, y = (i >> 5) & 31, x = i & 31;
+      sm.q.t32[c * T32_CH + (y + 2) * T32_ROW + x + 2] = sm.lut[sm.in[c][(q >> 1) * 32 + y][(q & 1) * 32 + x]];
+    }
+    __syncthreads();
+    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, tid);
+    for (int i = tid; i < 64 * A2_CH; i += 256) sm.q.a2[i] = 0.f;      // the input tile is dead: halo of conv2's output
+    __syncthreads();
 
     // ---- conv2: 32 -> 64, 3x3, on cat(conv1, conv64) (use_model.py:26-31, 50) ----------------------
-    // wave w owns output channels [16w, 16w+16); lane = one 2x2 pool window (its 4 positions), so the
-    // pool is register-local and the BN statistics of a channel live inside one wave.
+    // wave w owns output channels [16w, 16w+16) (one N-tile) and all 16 M-tiles of the 16x16 map, so the BN
+    // statistics of its channels never leave the wave.  k = tap * 32 + ic.
     {
-      const int wy = lane >> 3, wx = lane & 7;
-      cfloat *w2 = W + HEVCDL_W_C2 + wave * 16, *b2 = W + HEVCDL_W_C2 + 18432;
-      float acc[4][16];
+      const float GLB *w2 = W + HEVCDL_W_C2 + wave * (72 * 64) + lane, *b2 = W + HEVCDL_W_C2 + 18432;
+      const int ch = wave * 16 + i16;
+      const float bias = b2[ch];
+      v4f acc[16];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int o = 0; o < 16; o++) acc[i][o] = b2[wave * 16 + o];
+      for (int t = 0; t < 16; t++) acc[t] = (v4f){ bias, bias, bias, bias };
+      // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4
+      const float LDS *abase = sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1);
 #pragma unroll 1
-      for (int ic = 0; ic < 32; ic++) {
-        const float *src = ((ic < 16) ? sm.a1[ic] : sm.a64[ic - 16]) + (2 * wy) * A_STRIDE + 2 * wx;
-        float patch[4][4];
+      for (int tap = 0; tap < 9; tap++) {
+        const float LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int kk = 0; kk < 8; kk++) {
+          const float b = w2[(tap * 8 + kk) * 64];
 #pragma unroll
-          for (int c = 0; c < 4; c++) patch[r][c] = src[r * A_STRIDE + c];
+          for (int t = 0; t < 16; t++) acc[t] = mfma4(ap[kk * 4 * A_CH + (2 * (t >> 1)) * A_ROW + 8 * (t & 1)], b, acc[t]);
+        }
+      }
+      double s = 0, ss = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-          cfloat *wp = w2 + (ic * 9 + k) * 64;
+      for (int t = 0; t < 16; t++) {
+        const v4f a = acc[t];
+        s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+        ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+      }
+      s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
+      float al, be;
+      bn_fold(s, ss, 256.0, b2[64 + ch], b2[128 + ch], al, be);
 #pragma unroll
-          for (int o = 0; o < 16; o++) {
-            const float wv = wp[o];
+      for (int t = 0; t < 16; t++) {
+        const v4f a = acc[t];
+        const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
+        sm.q.a2[ch * A2_CH + ((t >> 1) + 1) * A2_ROW + 4 * (t & 1) + g4 + 1] = fmaxf(v, 0.f);
+      }
+      __syncthreads();
+    }
+    // ---- conv3: 64 -> 128, 3x3 (use_model.py:32-37); wave w owns output channels [32w, 32w+32) = 2 N-tiles, 4 M-tiles ----
+    {
+      const float GLB *w3 = W + HEVCDL_W_C3 + (2 * wave) * (144 * 64) + lane, *b3 = W + HEVCDL_W_C3 + 73728;
+      v4f acc[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][o] = fmaf(patch[(i >> 1) + k / 3][(i & 1) + k % 3], wv, acc[i][o]);
+      for (int n = 0; n < 2; n++) {
+        const float bias = b3[wave * 32 + n * 16 + i16];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[n][t] = (v4f){ bias, bias, bias, bias };
+      }
+      const float LDS *abase = sm.q.a2 + g4 * A2_CH + ((i16 >> 1) & 1) * A2_ROW + 2 * (i16 >> 2) + (i16 & 1);
+#pragma unroll 1
+      for (int tap = 0; tap < 9; tap++) {
+        const float LDS *ap = abase + (tap / 3) * A2_ROW + (tap % 3);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+          const float b0 = w3[(tap * 16 + kk) * 64], b1 = w3[(144 + tap * 16 + kk) * 64];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const float a = ap[kk * 4 * A2_CH + 2 * t * A2_ROW];
+            acc[0][t] = mfma4(a, b0, acc[0][t]); acc[1][t] = mfma4(a, b1, acc[1][t]);
           }
         }
       }
 #pragma unroll
-      for (int o = 0; o < 16; o++) {
-        double a = 0, b = 0;
+      for (int n = 0; n < 2; n++) {
+        const int ch = wave * 32 + n * 16 + i16;
+        double s = 0, ss = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a += (double)acc[i][o]; b += (double)acc[i][o] * (double)acc[i][o]; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { a += shfl_xor_d(a, m); b += shfl_xor_d(b, m); }
-        const int ch = wave * 16 + o;
-        float al, be;
-        bn_fold(a, b, 256.0, b2[64 + ch], b2[128 + ch], al, be);
-        float v = fmaxf(fmaxf(acc[0][o] * al + be, acc[1][o] * al + be), fmaxf(acc[2][o] * al + be, acc[3][o] * al + be));
-        sm.a2[ch][(wy + 1) * A2_STRIDE + wx + 1] = fmaxf(v, 0.f);
-      }
-      __syncthreads();
-    }
-    // ---- conv3: 64 -> 128, 3x3 (use_model.py:32-37); wave w owns output channels [32w, 32w+32) -----
-    {
-      const int widx = lane >> 2;
-      const int y = 2 * (widx >> 2) + ((lane >> 1) & 1), x = 2 * (widx & 3) + (lane & 1);
-      cfloat *w3 = W + HEVCDL_W_C3 + wave * 32, *b3 = W + HEVCDL_W_C3 + 73728;
-      float acc[32];
-#pragma unroll
-      for (int o = 0; o < 32; o++) acc[o] = b3[wave * 32 + o];
-#pragma unroll 1
-      for (int ic = 0; ic < 64; ic++) {
-#pragma unroll 3
-        for (int k = 0; k < 9; k++) {
-          const float v = sm.a2[ic][(y + k / 3) * A2_STRIDE + x + (k % 3)];
-          cfloat *wp = w3 + (ic * 9 + k) * 128;
-#pragma unroll
-          for (int o = 0; o < 32; o++) acc[o] = fmaf(v, wp[o], acc[o]);
+        for (int t = 0; t < 4; t++) {
+          const v4f a = acc[n][t];
+          s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+          ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
         }
-      }
-      double d[32];
+        s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
+        float al, be;
+        bn_fold(s, ss, 64.0, b3[128 + ch], b3[256 + ch], al, be);
 #pragma unroll
-      for (int o = 0; o < 32; o++) d[o] = (double)acc[o];
-      wave_channel_sums<32>(d, lane);
-      const double s = d[0];
-#pragma unroll
-      for (int o = 0; o < 32; o++) d[o] = (double)acc[o] * (double)acc[o];
-      wave_channel_sums<32>(d, lane);
-      if (lane < 32) {
-        const int ch = wave * 32 + lane;
-        bn_fold(s, d[0], 64.0, b3[128 + ch], b3[256 + ch], sm.alpha[ch], sm.beta[ch]);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int o = 0; o < 32; o++) {
-        const int ch = wave * 32 + o;
-        float v = fmaxf(acc[o] * sm.alpha[ch] + sm.beta[ch], 0.f);
-        v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-        if ((lane & 3) == 0) sm.a3[ch * 16 + widx][q] = v;       // flatten order (C,H,W), use_model.py:53
+        for (int t = 0; t < 4; t++) {
+          const v4f a = acc[n][t];
+          const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
+          sm.q.a3[ch * 16 + t * 4 + g4][q] = fmaxf(v, 0.f);      // flatten order (C,H,W), use_model.py:53
+        }
       }
       __syncthreads();
     }
@@ -285,12 +299,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 
   // ---- fc1 (2048 -> 256) for the 4 quadrants at once; weights pre-transposed [k][j] ---------------------
   {
-    const float *f1 = p.weights + HEVCDL_W_FC1;
+    const float GLB *f1 = W + HEVCDL_W_FC1;
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 4
     for (int k = 0; k < 2048; k++) {
       const float w = f1[(size_t)k * 256 + tid];
-      const float4 xv = *reinterpret_cast<const float4 *>(sm.a3[k]);
+      const v4f xv = *(const v4f LDS *)sm.q.a3[k];
       a0 = fmaf(w, xv.x, a0); a1 = fmaf(w, xv.y, a1); a2 = fmaf(w, xv.z, a2); a3 = fmaf(w, xv.w, a3);
     }
     const float b = f1[2048 * 256 + tid];
@@ -299,19 +313,19 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
   }
   __syncthreads();
   {
-    const float *f2 = p.weights + HEVCDL_W_FC2; const int q = tid >> 6, j = tid & 63;
+    const float GLB *f2 = W + HEVCDL_W_FC2; const int q = tid >> 6, j = tid & 63;
     float a = 0;
     for (int k = 0; k < 256; k++) a = fmaf(sm.h1[q][k], f2[k * 64 + j], a);
     sm.h2[q][j] = fmaxf(a + f2[256 * 64 + j], 0.f);
   }
   __syncthreads();
   if (tid < 64) {
-    const float *f3 = p.weights + HEVCDL_W_FC3; const int q = tid >> 4, j = tid & 15;
+    const float GLB *f3 = W + HEVCDL_W_FC3; const int q = tid >> 4, j = tid & 15;
     float a = 0;
     for (int k = 0; k < 64; k++) a = fmaf(sm.h2[q][k], f3[k * 16 + j], a);
     a += f3[64 * 16 + j];
     sm.lg[q][j] = a;
-    if (p.logits) p.logits[(size_t)gctu * 64 + q * 16 + j] = a;
+    if (p.logits) ((float GLB *)p.logits)[(size_t)gctu * 64 + q * 16 + j] = a;
   }
   __syncthreads();
 
@@ -353,7 +367,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         if (m >= 2) for (int k = 0; k < 4; k++) if (lab[quads[q][k]] < 2) lab[quads[q][k]] = 2;
       }
     }
-    for (int c = 0; c < 16; c++) p.labels[(size_t)gctu * 16 + c] = lab[c];
+    for (int c = 0; c < 16; c++) ((uint8_t GLB *)p.labels)[(size_t)gctu * 16 + c] = lab[c];
   }
 }
 

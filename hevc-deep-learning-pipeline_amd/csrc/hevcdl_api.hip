@@ -75,10 +75,22 @@ enum { B_C1W = 0, B_C1B = 1200, B_C1G = 1216, B_C1BE = 1232, B_C2W = 1280, B_C2B
        B_C3W = 20032, B_C3B = 93760, B_C3G = 93888, B_C3BE = 94016, B_F1W = 94400, B_F1B = 618688, B_F2W = 618944, B_F2B = 635328,
        B_F3W = 635392, B_F3B = 636416, B_C64W = 636432, B_C64B = 637632, B_C64G = 637648, B_C64BE = 637664 };
 
-static void pack_conv(const float *w, const float *b, const float *g, const float *be, int oc, int taps, float *dst)
-{ // [oc][taps] -> [taps][oc], then bias, gamma, beta
-  for (int o = 0; o < oc; o++) for (int k = 0; k < taps; k++) dst[k * oc + o] = w[o * taps + k];
-  memcpy(dst + taps * oc, b, oc * sizeof(float)); memcpy(dst + taps * oc + oc, g, oc * sizeof(float)); memcpy(dst + taps * oc + 2 * oc, be, oc * sizeof(float));
+// MFMA B-operand packing (v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][n = l & 15]): one k-step of one
+// 16-channel N-tile is 64 consecutive floats in lane order, then bias, gamma, beta.
+static void pack_conv5(const float *w, const float *b, const float *g, const float *be, float *dst)
+{ // [16][3*5*5] -> [19 k-steps][64]; tap 75 is zero padding
+  for (int ks = 0; ks < 19; ks++) for (int l = 0; l < 64; l++) { const int k = ks * 4 + (l >> 4), oc = l & 15; dst[ks * 64 + l] = k < 75 ? w[oc * 75 + k] : 0.f; }
+  memcpy(dst + 1216, b, 16 * sizeof(float)); memcpy(dst + 1232, g, 16 * sizeof(float)); memcpy(dst + 1248, be, 16 * sizeof(float));
+}
+static void pack_conv3(const float *w, const float *b, const float *g, const float *be, int oc, int ic, float *dst)
+{ // [oc][ic][3][3] -> [oc/16 N-tiles][9*ic/4 k-steps][64] with k = tap * ic + input channel
+  const int ksn = 9 * ic / 4;
+  for (int nt = 0; nt < oc / 16; nt++) for (int ks = 0; ks < ksn; ks++) for (int l = 0; l < 64; l++) {
+    const int k = ks * 4 + (l >> 4), tap = k / ic, c = k % ic, o = nt * 16 + (l & 15);
+    dst[((size_t)nt * ksn + ks) * 64 + l] = w[((size_t)o * ic + c) * 9 + tap];
+  }
+  float *t = dst + (size_t)9 * ic * oc;
+  memcpy(t, b, oc * sizeof(float)); memcpy(t + oc, g, oc * sizeof(float)); memcpy(t + 2 * oc, be, oc * sizeof(float));
 }
 static void pack_fc(const float *w, const float *b, int out, int in, float *dst)
 { for (int j = 0; j < out; j++) for (int k = 0; k < in; k++) dst[(size_t)k * out + j] = w[(size_t)j * in + k]; memcpy(dst + (size_t)in * out, b, out * sizeof(float)); }
@@ -106,10 +118,10 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
   std::vector<float> pk(HEVCDL_W_TOTAL);
-  pack_conv(weights + B_C1W, weights + B_C1B, weights + B_C1G, weights + B_C1BE, 16, 75, pk.data() + HEVCDL_W_C1);
-  pack_conv(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, 16, 75, pk.data() + HEVCDL_W_C64);
-  pack_conv(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 288, pk.data() + HEVCDL_W_C2);
-  pack_conv(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 576, pk.data() + HEVCDL_W_C3);
+  pack_conv5(weights + B_C1W, weights + B_C1B, weights + B_C1G, weights + B_C1BE, pk.data() + HEVCDL_W_C1);
+  pack_conv5(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, pk.data() + HEVCDL_W_C64);
+  pack_conv3(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 32, pk.data() + HEVCDL_W_C2);
+  pack_conv3(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 64, pk.data() + HEVCDL_W_C3);
   pack_fc(weights + B_F1W, weights + B_F1B, 256, 2048, pk.data() + HEVCDL_W_FC1);
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);

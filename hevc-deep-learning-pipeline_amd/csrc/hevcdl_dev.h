@@ -8,15 +8,16 @@
 #define HEVCDL_DEV_INPUT_LUMA    1
 #define HEVCDL_DEV_INPUT_RGB_CTU 2
 
-// packed CNN weights (floats): every conv is [tap k][oc] + bias + gamma + beta, every fc is [k][j] + bias
-#define HEVCDL_W_C1   0            // 75*16 + 3*16
-#define HEVCDL_W_C64  1248
-#define HEVCDL_W_C2   2496         // 288*64 + 3*64
-#define HEVCDL_W_C3   21120        // 576*128 + 3*128
-#define HEVCDL_W_FC1  95232        // 2048*256 + 256
-#define HEVCDL_W_FC2  619776       // 256*64 + 64
-#define HEVCDL_W_FC3  636224       // 64*16 + 16
-#define HEVCDL_W_TOTAL 637264
+// packed CNN weights (floats): every conv is [N-tile][k-step][64 lanes] (MFMA B-operand order) + bias + gamma + beta,
+// every fc is [k][j] + bias
+#define HEVCDL_W_C1   0            // 19*64 + 3*16
+#define HEVCDL_W_C64  1264
+#define HEVCDL_W_C2   2528         // 4*72*64 + 3*64
+#define HEVCDL_W_C3   21152        // 8*144*64 + 3*128
+#define HEVCDL_W_FC1  95264        // 2048*256 + 256
+#define HEVCDL_W_FC2  619808       // 256*64 + 64
+#define HEVCDL_W_FC3  636256       // 64*16 + 16
+#define HEVCDL_W_TOTAL 637296
 
 struct hevcdl_cnn_params {
   const uint8_t *input;            // planar 4:2:0 frames, or packed RGB CTUs (input_mode 2)
