@@ -964,91 +964,122 @@ DEVN void dequant(KR k, int c_, int n_)
 // ---------------------------------------------------------------------------------------------------
 // residual syntax bit counting on lane 0 (TEncSbac.cpp:1115-1541); coefficients in s->lvl (TU raster)
 // ---------------------------------------------------------------------------------------------------
-DEV void code_last_xy(LCabac *c, int px, int py, int n, int ch, int scan_type)
-{
-  if (scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-  const int gx = lds().t_group_idx[px], gy = lds().t_group_idx[py]; int off, shift, kk;
-  last_ctx_params(ch, n, off, shift);
-  const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
-  for (kk = 0; kk < gx; kk++) enc_bin(c, bx + (kk >> shift), 1);
-  if (gx < lds().t_group_idx[n - 1]) enc_bin(c, bx + (kk >> shift), 0);
-  for (kk = 0; kk < gy; kk++) enc_bin(c, by + (kk >> shift), 1);
-  if (gy < lds().t_group_idx[n - 1]) enc_bin(c, by + (kk >> shift), 0);
-  if (gx > 3) enc_ep(c, (gx - 2) >> 1);
-  if (gy > 3) enc_ep(c, (gy - 2) >> 1);
-}
-DEV void code_coef_remain(LCabac *c, uint32_t symbol, int rparam)
-{ // xWriteCoefRemainExGolomb TEncSbac.cpp:337-394 (bit count only)
-  if (symbol < (3u << rparam)) { enc_ep(c, (int)(symbol >> rparam) + 1); enc_ep(c, rparam); }
-  else {
-    uint32_t len = (uint32_t)rparam, cn = symbol - (3u << rparam);
-    while (cn >= (1u << len)) cn -= (1u << (len++));
-    enc_ep(c, (int)(3 + len + 1 - rparam)); enc_ep(c, (int)len);
-  }
-}
-DEVN void code_coeff_lane0(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_)
+// Whole-wave version: the coder state is pulled into registers for the duration of the call -- lane L holds contexts
+// L, 64+L, 128+L and the matching slices of the rate / transition tables -- so that one bin is a handful of
+// v_readlane / v_cndmask and scalar operations instead of five dependent LDS round trips.  Everything a bin
+// needs from the coefficients (significance, context increments, magnitudes of a coefficient group) is computed
+// lane-parallel first; control flow is wave-uniform.
+DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_)
 {
   const int comp = uni(comp_), n = uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_);
   LSmem &s = lds();
-  const int ch = comp ? 1 : 0;
+  const int lane = lane_id(), ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
-  const int log2n = cp.log2;
+  const int log2n = cp.log2, ncoef = n * n;
   LDS const int16_t *coef = s.lvl; const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
-  int num_sig = 0;
-  for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
-  if (num_sig == 0) return;                                   // never called for an empty TU (cbf checked by the caller)
-  if (n == 4) enc_bin(c, CTX_TSKIP + ch, tskip_flag);         // codeTransformSkipFlags :997-1032
-  LDS uint8_t *cgf = s.cgf; for (int i = 0; i < 64; i++) cgf[i] = 0;
-  int scan_last = -1, pos_last;
-  do {
-    pos_last = scan[++scan_last];
-    if (coef[pos_last] != 0) { const int py = pos_last >> log2n, px = pos_last - (py << log2n); cgf[cp.wg * (py >> 2) + (px >> 2)] = 1; num_sig--; }
-  } while (num_sig > 0);
-  { const int py = pos_last >> log2n, px = pos_last - (py << log2n); code_last_xy(c, px, py, n, ch, cp.scan_type); }
+  LDS uint8_t *cgf = s.cgf;
+  cgf[lane] = 0;
+  wsync();
+  // last significant scan position and the significant-CG flags (TEncSbac.cpp:1170-1200)
+  int my_last = -1;
+  for (int sp = lane; sp < ncoef; sp += 64) if (coef[scan[sp]] != 0) { my_last = sp; cgf[scan_cg[sp >> 4]] = 1; }
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(my_last, m); my_last = o > my_last ? o : my_last; }
+  const int scan_last = uni(my_last);
+  if (scan_last < 0) return;                                    // never called for an empty TU (cbf checked by the caller)
+  wsync();
+  int cx0 = c->ctx[lane], cx1 = c->ctx[64 + lane], cx2 = c->ctx[128 + (lane & 31)];
+  const int eb0 = s.t_ebits[lane], eb1 = s.t_ebits[64 + lane];
+  const int nx = (int)((unsigned)s.t_next[0][lane] | ((unsigned)s.t_next[0][64 + lane] << 8) | ((unsigned)s.t_next[1][lane] << 16) | ((unsigned)s.t_next[1][64 + lane] << 24));
+  unsigned long long frac;
+  { const unsigned long long f = c->frac; frac = ((unsigned long long)(unsigned)uni((int)(f >> 32)) << 32) | (unsigned)uni((int)f); }
+  auto bin = [&](int ctx, int b) { // TEncBinCABACCounter::encodeBin TEncBinCoderCABACCounter.cpp:90-105
+    int st;
+    if (ctx < 64) st = __builtin_amdgcn_readlane(cx0, ctx); else if (ctx < 128) st = __builtin_amdgcn_readlane(cx1, ctx - 64); else st = __builtin_amdgcn_readlane(cx2, ctx - 128);
+    const int x = st ^ b;
+    frac += (unsigned)(x < 64 ? __builtin_amdgcn_readlane(eb0, x) : __builtin_amdgcn_readlane(eb1, x - 64));
+    const int nxt = (__builtin_amdgcn_readlane(nx, st & 63) >> (((st >> 6) << 3) + (((st & 1) == b) ? 16 : 0))) & 0xff;
+    if (ctx < 64) cx0 = (lane == ctx) ? nxt : cx0; else if (ctx < 128) cx1 = (lane == ctx - 64) ? nxt : cx1; else cx2 = (lane == ctx - 128) ? nxt : cx2;
+  };
+  auto ep = [&](int cnt) { frac += 32768ull * (unsigned long long)cnt; };
+  if (n == 4) bin(CTX_TSKIP + ch, tskip_flag);                  // codeTransformSkipFlags :997-1032
+  { // codeLastSignificantXY TEncSbac.cpp:1051-1113
+    const int pos_last = uni(scan[scan_last]);
+    int py = pos_last >> log2n, px = pos_last - (py << log2n);
+    if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
+    const int gx = uni(s.t_group_idx[px]), gy = uni(s.t_group_idx[py]), gmax = uni(s.t_group_idx[n - 1]); int off, shift, kk;
+    last_ctx_params(ch, n, off, shift);
+    const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
+    for (kk = 0; kk < gx; kk++) bin(bx + (kk >> shift), 1);
+    if (gx < gmax) bin(bx + (kk >> shift), 0);
+    for (kk = 0; kk < gy; kk++) bin(by + (kk >> shift), 1);
+    if (gy < gmax) bin(by + (kk >> shift), 0);
+    if (gx > 3) ep((gx - 2) >> 1);
+    if (gy > 3) ep((gy - 2) >> 1);
+  }
   const int cg_off = CTX_SIG_CG + (ch ? 2 : 0), sig_off = CTX_SIG + (ch ? 28 : 0);
   const int last_set = scan_last >> 4;
-  uint32_t c1 = 1; int go_rice = 0, sp = scan_last;
+  int c1 = 1;
   for (int subset = last_set; subset >= 0; subset--) {
-    int num_nz = 0; const int sub_pos = subset << 4;
-    go_rice = 0;
-    int abs_coeff[16], last_nz = -1, first_nz = 16, escape = 0;
-    if (sp == scan_last) { abs_coeff[0] = abs(coef[pos_last]); num_nz = 1; last_nz = sp; first_nz = sp; sp--; }
-    const int cgblk = scan_cg[subset], gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
-    if (subset == last_set || subset == 0) cgf[cgblk] = 1;
-    else enc_bin(c, cg_off + sig_cg_ctx(cgf, gx, gy, cp.wg), cgf[cgblk] != 0);
-    if (cgf[cgblk]) {
-      const int pat = pattern_sig_ctx(cgf, gx, gy, cp.wg);
-      for (; sp >= sub_pos; sp--) {
-        const int blk = scan[sp], sig = coef[blk] != 0;
-        if (sp > sub_pos || subset == 0 || num_nz) enc_bin(c, sig_off + sig_ctx_inc(cp, scan, pat, sp), sig);
-        if (sig) { abs_coeff[num_nz++] = abs(coef[blk]); if (last_nz == -1) last_nz = sp; first_nz = sp; }
-      }
-    } else sp = sub_pos - 1;
+    const int sub_pos = subset << 4;
+    const int cgblk = uni(scan_cg[subset]), gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
+    int cg_sig;
+    if (subset == last_set || subset == 0) { wsync(); if (lane == 0) cgf[cgblk] = 1; wsync(); cg_sig = 1; }
+    else { cg_sig = uni(cgf[cgblk]) != 0; bin(cg_off + uni(sig_cg_ctx(cgf, gx, gy, cp.wg)), cg_sig); }
+    if (!cg_sig) continue;
+    // lane-parallel: the 16 positions of the group
+    const int j = lane & 15, sp_j = sub_pos + j, blk_j = scan[sp_j];
+    const int cf_j = (sp_j <= scan_last) ? (int)coef[blk_j] : 0, abs_j = abs(cf_j);
+    const unsigned sigmask = (unsigned)(__ballot(lane < 16 && cf_j != 0) & 0xffffull);
+    const int pat = uni(pattern_sig_ctx(cgf, gx, gy, cp.wg));
+    const int sigctx_j = sig_off + sig_ctx_inc(cp, scan, pat, sp_j);
+    int num_nz = 0, jstart = 15;
+    if (subset == last_set) { num_nz = 1; jstart = (scan_last & 15) - 1; }
+    for (int jj = jstart; jj >= 0; jj--) {
+      const int sig = (sigmask >> jj) & 1;
+      if (jj > 0 || subset == 0 || num_nz) bin(__builtin_amdgcn_readlane(sigctx_j, jj), sig);
+      num_nz += sig;
+    }
     if (num_nz > 0) {
+      const int last_nz = 31 - __clz((int)sigmask), first_nz = __ffs((int)sigmask) - 1;
       const int sign_hidden = (last_nz - first_nz >= 4);
       const int cset = ctx_set_index(ch, subset, c1 == 0);
       c1 = 1;
-      const int n_c1 = num_nz < 8 ? num_nz : 8; int first_c2 = -1;
-      for (int i = 0; i < n_c1; i++) {
-        const int sym = abs_coeff[i] > 1;
-        enc_bin(c, CTX_ONE + 4 * cset + (int)c1, sym);
-        if (sym) { c1 = 0; if (first_c2 == -1) first_c2 = i; else escape = 1; }
+      int escape = 0, abs_c2 = -1; unsigned m = sigmask;
+      for (int i = 0; i < 8 && m; i++) { // greater-1 flags of the first 8 levels, highest scan position first
+        const int p = 31 - __clz((int)m); m &= ~(1u << p);
+        const int av = __builtin_amdgcn_readlane(abs_j, p), sym = av > 1;
+        bin(CTX_ONE + 4 * cset + c1, sym);
+        if (sym) { c1 = 0; if (abs_c2 < 0) abs_c2 = av; else escape = 1; }
         else if (c1 < 3 && c1 > 0) c1++;
       }
-      if (c1 == 0 && first_c2 != -1) { const int sym = abs_coeff[first_c2] > 2; enc_bin(c, CTX_ABS + cset, sym); if (sym) escape = 1; }
+      if (c1 == 0 && abs_c2 >= 0) { const int sym = abs_c2 > 2; bin(CTX_ABS + cset, sym); if (sym) escape = 1; }
       escape = escape || (num_nz > 8);
-      enc_ep(c, sign_hidden ? num_nz - 1 : num_nz);
-      int first_coeff2 = 1;
-      if (escape) for (int i = 0; i < num_nz; i++) {
-        const int base = (i < 8) ? (2 + first_coeff2) : 1;
-        if (abs_coeff[i] >= base) {
-          code_coef_remain(c, (uint32_t)(abs_coeff[i] - base), go_rice);
-          if (abs_coeff[i] > (3 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+      ep(sign_hidden ? num_nz - 1 : num_nz);
+      if (escape) {
+        int first_coeff2 = 1, go_rice = 0, i = 0;
+        for (m = sigmask; m; i++) {
+          const int p = 31 - __clz((int)m); m &= ~(1u << p);
+          const int av = __builtin_amdgcn_readlane(abs_j, p);
+          const int base = (i < 8) ? (2 + first_coeff2) : 1;
+          if (av >= base) { // xWriteCoefRemainExGolomb TEncSbac.cpp:337-394 (bit count only)
+            const uint32_t symbol = (uint32_t)(av - base);
+            if (symbol < (3u << go_rice)) ep((int)(symbol >> go_rice) + 1 + go_rice);
+            else {
+              uint32_t len = (uint32_t)go_rice, cn = symbol - (3u << go_rice);
+              while (cn >= (1u << len)) cn -= (1u << (len++));
+              ep((int)(3 + len + 1 - go_rice) + (int)len);
+            }
+            if (av > (3 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+          }
+          if (av >= 2) first_coeff2 = 0;
         }
-        if (abs_coeff[i] >= 2) first_coeff2 = 0;
       }
     }
   }
+  wsync();
+  c->ctx[lane] = (uint8_t)cx0; c->ctx[64 + lane] = (uint8_t)cx1; if (lane < 32) c->ctx[128 + lane] = (uint8_t)cx2;
+  if (lane == 0) c->frac = frac;
+  wsync();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1147,7 +1178,7 @@ DEV void code_tu_coeffs(KR k, LCabac *c, const Cu &cu, const Tu &tu, int comp, i
   const int n = comp ? tu_csize(tu) : (1 << tu.log2);
   const int mode = uni(mode_of(k, cu, comp, zc));
   load_tu_coef(k, real, comp, tu.log2, cu.zbase + zc, n);
-  { PROF_T0(); if (lane_id() == 0) code_coeff_lane0(k, c, comp, n, mode, lds().a[A_TSKIP + comp][cu.zbase + zc]); PROF_ADD(k, 11); }
+  { PROF_T0(); code_coeff_wave(k, c, comp, n, mode, lds().a[A_TSKIP + comp][cu.zbase + zc]); PROF_ADD(k, 11); }
   wsync();
 }
 
