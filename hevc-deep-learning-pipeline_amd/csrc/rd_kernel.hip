@@ -177,6 +177,25 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV bool ub(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 DEV Cu ucu(const Cu &c) { Cu r = { uni(c.x), uni(c.y), uni(c.log2), uni(c.depth), uni(c.zbase), uni(c.nparts), uni(c.part) }; return r; }
 DEV Tu utu(const Tu &t) { Tu r = { uni(t.x), uni(t.y), uni(t.log2), uni(t.trd), uni(t.zrel), uni(t.nparts) }; return r; }
+// Wave reductions on the DPP crossbar (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane ends up with
+// the result of its row of 16), rows combined through v_readlane -> scalar.  An order of magnitude less latency than
+// a butterfly of ds_bpermute shuffles; results are wave-uniform.
+#define DPP_ROW_REDUCE(v, OP) do { \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false)); v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false)); \
+    v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); } while (0)
+DEV int op_add_(int a, int b) { return a + b; }
+DEV int op_max_(int a, int b) { return a > b ? a : b; }
+DEV int row_sum_i(int v) { DPP_ROW_REDUCE(v, op_add_); return v; }
+DEV int wave_sum_i(int v)
+{
+  DPP_ROW_REDUCE(v, op_add_);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+DEV int wave_max_i(int v)
+{
+  DPP_ROW_REDUCE(v, op_max_);
+  return op_max_(op_max_(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), op_max_(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 DEV int comp_off(int c) { return c == 0 ? 0 : (c == 1 ? 4096 : 5120); }
 DEV int cstride(int c) { return c ? 32 : 64; }
 DEV int pstride(KR k, int c) { return c ? k.cw : k.W; }
@@ -361,7 +380,7 @@ DEV int dc_value(KR k, LDS const int16_t *line, int n)
   const int n2 = 2 * n;
   int s = 0;
   for (int i = lane_id(); i < n; i += 64) s += line[n2 + 1 + i] + line[n2 - 1 - i];
-  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  s = wave_sum_i(s);
   return (s + n) / (n + n);
 }
 
@@ -685,10 +704,9 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
     cost_coeff[sp] = de * de * err_scale;
     if (ma > 0) my_last = sp;
   }
-  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(my_last, m); my_last = o > my_last ? o : my_last; }
+  const int last_pos = wave_max_i(my_last);
   cost_cg_sig[lane] = 0; cgf[lane] = 0;
   wsync();
-  const int last_pos = uni(my_last);
   if (last_pos < 0) return 0;
   RDOQ_MARK(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
@@ -886,7 +904,7 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
     if (sp < best_last_p1) { const int lv = dst[blk]; abs_sum += (uint32_t)lv; dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv); }
     else dst[blk] = 0;
   }
-  for (int m = 32; m >= 1; m >>= 1) abs_sum += __shfl_xor(abs_sum, m);
+  abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
   wsync();
   if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660; lanes 0..15 own the positions of the current CG
     const long long rd_factor = k.sbh[ch];
@@ -901,7 +919,7 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
       if (last_cg == -1) last_cg = 1;
       if (last_nz - first_nz >= 4) {
         int sum = (j >= first_nz && j <= last_nz) ? lv_j : 0;
-        for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+        sum = row_sum_i(sum);
         const int lv_first = __builtin_amdgcn_readlane(lv_j, first_nz);
         const uint32_t signbit = lv_first > 0 ? 0 : 1;
         if (signbit != ((uint32_t)sum & 1u)) {
@@ -983,8 +1001,7 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
   // last significant scan position and the significant-CG flags (TEncSbac.cpp:1170-1200)
   int my_last = -1;
   for (int sp = lane; sp < ncoef; sp += 64) if (coef[scan[sp]] != 0) { my_last = sp; cgf[scan_cg[sp >> 4]] = 1; }
-  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(my_last, m); my_last = o > my_last ? o : my_last; }
-  const int scan_last = uni(my_last);
+  const int scan_last = wave_max_i(my_last);
   if (scan_last < 0) return;                                    // never called for an empty TU (cbf checked by the caller)
   wsync();
   int cx0 = c->ctx[lane], cx1 = c->ctx[64 + lane], cx2 = c->ctx[128 + (lane & 31)];
@@ -1322,7 +1339,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
     const int df = v - (int)org[(size_t)r * ps + cc];
     d += (uint32_t)(df * df);
   }
-  for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m);
+  d = (uint32_t)wave_sum_i((int)d);
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
   wsync();
   PROF_ADD(k, 9);
