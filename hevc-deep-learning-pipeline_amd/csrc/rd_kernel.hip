@@ -116,7 +116,11 @@ struct RdSmem {
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
   uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
-  int16_t line[264], fline[264];      // reference samples: bottom-left ... corner(2n) ... top-right
+  int16_t line[264], fline[264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
+  int16_t cline[2][132];              // chroma reference samples (n <= 32, never filtered in 4:2:0)
+  // the reference lines are kept across consecutive TU codings of the same block (candidate modes of one PU share
+  // their neighbours): key = (log2 n, y, x) of the block each line currently holds, -1 = none
+  int ref_key[3], fline_key;
   // residual (row stride n+2: conflict-free column access) and transform / dequantised coefficients (raster) share
   // storage: the residual is dead once the forward transform has consumed it and is rebuilt by the inverse transform.
   // Every value fits 16 bits (HEVC transform dynamic range; the reference clips the inverse stages explicitly).
@@ -261,10 +265,16 @@ DEV int unit_avail(KR k, int x4, int y4, int cur_x4, int cur_y4)
   return lds().r2z[((y4 & 15) << 4) | (x4 & 15)] < lds().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
 }
 
-DEVN void build_refs(KR k, int c_, int x_, int y_, int n_)
+DEV LDS int16_t *ref_line(int c) { return c ? lds().cline[c - 1] : lds().line; }
+DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
 {
   PROF_T0();
   const int c = uni(c_), x = uni(x_), y = uni(y_), n = uni(n_);
+  const int key = (ilog2(n) << 24) | (y << 12) | x;
+  if (!uni(force_) && uni(lds().ref_key[c]) == key) { PROF_ADD(k, 0); return; }
+  wsync();
+  if (lane_id() == 0) { lds().ref_key[c] = key; if (!c) lds().fline_key = -1; }
+  LDS int16_t *line_out = ref_line(c);
   const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n / u;
   const int x4 = x >> sh, y4 = y >> sh, total = 4 * nu + 1;
   // availability of the <= 65 units: lanes 0..63 + unit 64 (only for a 64x64 luma block) on lane 0's second pass
@@ -301,7 +311,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_)
         else v = 128;
       }
     }
-    lds().line[i] = (int16_t)v;
+    line_out[i] = (int16_t)v;
   }
   wsync();
   PROF_ADD(k, 0);
@@ -311,6 +321,9 @@ DEVN void filter_refs(KR k, int n_)
 {
   PROF_T0();
   const int n = uni(n_); // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
+  if (uni(lds().fline_key) == uni(lds().ref_key[0])) { PROF_ADD(k, 1); return; }
+  wsync();
+  if (lane_id() == 0) lds().fline_key = lds().ref_key[0];
   LDS const int16_t *src = lds().line; LDS int16_t *dst = lds().fline;
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
@@ -389,7 +402,7 @@ DEVN void predict_block(KR k, int c_, int mode_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), mode = uni(mode_), n = uni(n_);
-  LDS const int16_t *line = use_filtered_refs(c, mode, n) ? lds().fline : lds().line;
+  LDS const int16_t *line = use_filtered_refs(c, mode, n) ? lds().fline : ref_line(c);
   const int log2n = ilog2(n);
   const int dcv = (mode == DC) ? dc_value(k, line, n) : 0;
   for (int i = lane_id(); i < n * n; i += 64) lds().pred[i] = (uint8_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
@@ -1302,7 +1315,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   const int mode = uni(mode_of(k, cu, comp, zrel));
   const int tskip = uni(s.a[A_TSKIP + comp][zabs]);
   if (mode012 != 2) {
-    build_refs(k, comp, x, y, n);
+    build_refs(k, comp, x, y, n, 0);
     if (ub(use_filtered_refs(comp, mode, n))) filter_refs(k, n);
     predict_block(k, comp, mode, n);
     if (mode012 == 1 && lane_id() < 16) s.ts_pred[comp][lane_id()] = s.pred[lane_id()];
@@ -1564,7 +1577,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     const int poff = pu * pu_parts, zp = cu.zbase + poff;
     const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
     // ---- rough mode decision ----
-    build_refs(k, 0, ptu.x, ptu.y, pn);
+    build_refs(k, 0, ptu.x, ptu.y, pn, 1);
     if (pn >= 8 && pn <= 32) filter_refs(k, pn);
     rmd_satd(k, ptu.x, ptu.y, pn);
     int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
@@ -1708,6 +1721,9 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   LSmem &s = lds();
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
   uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+  wsync();
+  if (lane_id() < 2) s.ref_key[1 + lane_id()] = -1;
+  wsync();
   const int luma_mode = uni(s.a[A_LDIR][cu.zbase]);
   for (int i = 0; i < 4; i++) if ((int)mode_list[i] == luma_mode) { mode_list[i] = 34; break; }   // getAllowedChromaDir TComDataCU.cpp:1334-1353
   uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
@@ -1755,6 +1771,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
   const int part = uni(part_);
   Cu cu = ucu(cu_); cu.part = part;
   wsync();
+  if (lane_id() < 3) s.ref_key[lane_id()] = -1;
   for (int i = lane_id(); i < cu.nparts; i += 64) { // initEstData TComDataCU.cpp:525-592 + part size / pred mode
     const int z = cu.zbase + i;
     s.a[A_DEPTH][z] = (uint8_t)cu.depth; s.a[A_PART][z] = (uint8_t)part; s.a[A_LDIR][z] = DC; s.a[A_CDIR][z] = 0; s.a[A_TRIDX][z] = 0;
