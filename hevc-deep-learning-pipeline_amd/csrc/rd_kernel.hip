@@ -1500,6 +1500,116 @@ DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first)
 
 // rough mode decision for one PU: 35 predictions + SATD (TEncSearch.cpp:2266-2346).  One lane per
 // (mode, 8x8 block) task (4x4 blocks for a 4x4 PU): predict the block in registers, Hadamard, add into satd[mode].
+// Angular modes are evaluated row by row in the mode's own orientation (the horizontal family on the transposed
+// block: the sum of absolute Hadamard coefficients is transpose-invariant), so the 8 samples of a row share one
+// (iIdx, iFact) pair and 9 consecutive reference samples (TComPrediction.cpp:731-817).
+template <int B> DEV unsigned rmd_block(KR k, const LSmem &s, int mode, int pn, int log2n, int x, int y, int bx, int by, int dcv)
+{
+  constexpr int NW = B / 4;                                   // dwords per row of the block
+  const int W = k.W, n2 = 2 * pn;
+  GLB const uint32_t *org = (GLB const uint32_t *)(k.org[0] + (size_t)(y + by) * W + x + bx);
+  uint32_t o[B][NW];
+#pragma unroll
+  for (int r = 0; r < B; r++)
+#pragma unroll
+    for (int w = 0; w < NW; w++) o[r][w] = org[((size_t)r * W >> 2) + w];
+  auto opix = [&](int r, int c) -> int { return (int)((o[r][c >> 2] >> (8 * (c & 3))) & 255u); };
+  LDS const int16_t *line = use_filtered_refs(0, mode, pn) ? s.fline : s.line;
+  int m[B * B];
+  if (mode >= 2) {
+    const int is_ver = mode >= 18, sgn = is_ver ? 1 : -1;
+    const int ang_mode = is_ver ? mode - VER : -(mode - HOR);
+    const int abs_ang = abs(ang_mode);
+    const int angle = (ang_mode < 0 ? -1 : 1) * s.t_ang[abs_ang], inv_angle = s.t_inv_ang[abs_ang];
+    const int x0 = is_ver ? bx : by, y0 = is_ver ? by : bx;   // block origin in the mode's orientation
+    const int edge = (angle == 0) && (pn <= 16) && (x0 == 0);
+    const int s0 = line[n2];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+      const int dpos = (y0 + r + 1) * angle, di = dpos >> 5, df = dpos & 31;
+      int R[B + 1];
+#pragma unroll
+      for (int t = 0; t <= B; t++) {
+        const int i = x0 + t + di + 1;
+        const int off = (i >= 0) ? i : -((128 + (-i) * inv_angle) >> 8);
+        R[t] = line[n2 + sgn * off];
+      }
+      int d[B];
+#pragma unroll
+      for (int c = 0; c < B; c++) {
+        int v = ((32 - df) * R[c] + df * R[c + 1] + 16) >> 5;
+        if (c == 0 && edge) v = clip8(v + (((int)line[n2 - sgn * (y0 + r + 1)] - s0) >> 1));
+        d[c] = (is_ver ? opix(r, c) : opix(c, r)) - v;
+      }
+      if (B == 8) {
+        int e[8];
+        e[0] = d[0] + d[4]; e[1] = d[1] + d[5]; e[2] = d[2] + d[6]; e[3] = d[3] + d[7]; e[4] = d[0] - d[4]; e[5] = d[1] - d[5]; e[6] = d[2] - d[6]; e[7] = d[3] - d[7];
+        d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
+        m[r * B + 0] = d[0] + d[1]; m[r * B + 1] = d[0] - d[1]; m[r * B + 2] = d[2] + d[3]; m[r * B + 3] = d[2] - d[3];
+        m[r * B + 4] = d[4] + d[5]; m[r * B + 5] = d[4] - d[5]; m[r * B + 6] = d[6] + d[7]; m[r * B + 7] = d[6] - d[7];
+      } else {
+        const int a0 = d[0] + d[3], a1 = d[1] + d[2], a2 = d[1] - d[2], a3 = d[0] - d[3];
+        m[r * B] = a0 + a1; m[r * B + 1] = a0 - a1; m[r * B + 2] = a2 + a3; m[r * B + 3] = a3 - a2;
+      }
+    }
+  } else {
+    // planar / DC (TComPrediction.cpp:183-201, 403-473)
+    int top[B];
+#pragma unroll
+    for (int c = 0; c < B; c++) top[c] = line[n2 + 1 + bx + c];
+    const int bl = line[n2 - 1 - pn], tr = line[n2 + 1 + pn];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+      const int py = by + r, left = line[n2 - 1 - py];
+      int d[B];
+#pragma unroll
+      for (int c = 0; c < B; c++) {
+        const int px = bx + c;
+        int v;
+        if (mode == PLANAR) v = ((pn - 1 - px) * left + (px + 1) * tr + (pn - 1 - py) * top[c] + (py + 1) * bl + pn) >> (log2n + 1);
+        else {
+          v = dcv;
+          if (pn <= 16) {
+            if (px == 0 && py == 0) v = (top[0] + left + 2 * dcv + 2) >> 2;
+            else if (py == 0) v = (top[c] + 3 * dcv + 2) >> 2;
+            else if (px == 0) v = (left + 3 * dcv + 2) >> 2;
+          }
+        }
+        d[c] = opix(r, c) - v;
+      }
+      if (B == 8) {
+        int e[8];
+        e[0] = d[0] + d[4]; e[1] = d[1] + d[5]; e[2] = d[2] + d[6]; e[3] = d[3] + d[7]; e[4] = d[0] - d[4]; e[5] = d[1] - d[5]; e[6] = d[2] - d[6]; e[7] = d[3] - d[7];
+        d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
+        m[r * B + 0] = d[0] + d[1]; m[r * B + 1] = d[0] - d[1]; m[r * B + 2] = d[2] + d[3]; m[r * B + 3] = d[2] - d[3];
+        m[r * B + 4] = d[4] + d[5]; m[r * B + 5] = d[4] - d[5]; m[r * B + 6] = d[6] + d[7]; m[r * B + 7] = d[6] - d[7];
+      } else {
+        const int a0 = d[0] + d[3], a1 = d[1] + d[2], a2 = d[1] - d[2], a3 = d[0] - d[3];
+        m[r * B] = a0 + a1; m[r * B + 1] = a0 - a1; m[r * B + 2] = a2 + a3; m[r * B + 3] = a3 - a2;
+      }
+    }
+  }
+  // second (column) pass of the Hadamard transform (TComRdCost.cpp:1561-1750; |coefficients| are order independent)
+  unsigned sum = 0;
+  if (B == 8) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      int e[8], d[8];
+      e[0] = m[c] + m[32 + c]; e[1] = m[8 + c] + m[40 + c]; e[2] = m[16 + c] + m[48 + c]; e[3] = m[24 + c] + m[56 + c];
+      e[4] = m[c] - m[32 + c]; e[5] = m[8 + c] - m[40 + c]; e[6] = m[16 + c] - m[48 + c]; e[7] = m[24 + c] - m[56 + c];
+      d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
+      sum += (unsigned)(abs(d[0] + d[1]) + abs(d[0] - d[1]) + abs(d[2] + d[3]) + abs(d[2] - d[3]) + abs(d[4] + d[5]) + abs(d[4] - d[5]) + abs(d[6] + d[7]) + abs(d[6] - d[7]));
+    }
+    return (sum + 2) >> 2;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int a0 = m[c] + m[12 + c], a1 = m[4 + c] + m[8 + c], a2 = m[4 + c] - m[8 + c], a3 = m[c] - m[12 + c];
+      sum += (unsigned)(abs(a0 + a1) + abs(a0 - a1) + abs(a2 + a3) + abs(a3 - a2));
+    }
+    return (sum + 1) >> 1;
+  }
+}
 DEVN void rmd_satd(KR k, int x_, int y_, int pn_)
 {
   PROF_T0();
@@ -1507,56 +1617,14 @@ DEVN void rmd_satd(KR k, int x_, int y_, int pn_)
   LSmem &s = lds();
   const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
   if (lane_id() < 36) s.satd[lane_id()] = 0;
-  int dcv[2];
-  dcv[0] = dc_value(k, s.line, pn); dcv[1] = 0;
+  const int dcv = dc_value(k, s.line, pn);
   wsync();
+#pragma unroll 1
   for (int t0 = 0; t0 < ntask; t0 += 64) {
     const int t = t0 + lane_id();
     if (t < ntask) {
       const int mode = t / nblk, blk = t - mode * nblk, bx = (blk % nbx) * b, by = (blk / nbx) * b;
-      LDS const int16_t *line = use_filtered_refs(0, mode, pn) ? s.fline : s.line;
-      GLB const uint8_t *org = k.org[0] + (size_t)(y + by) * k.W + x + bx;
-      unsigned int sum = 0;
-      if (b == 8) {
-        int m[64];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          int d[8];
-#pragma unroll
-          for (int c = 0; c < 8; c++) d[c] = (int)org[(size_t)r * k.W + c] - pred_pixel(line, 0, mode, pn, log2n, bx + c, by + r, dcv[0]);
-          // 8-point Hadamard butterflies (TComRdCost.cpp:1645-1750; |coefficients| are order independent)
-          int e[8];
-          e[0] = d[0] + d[4]; e[1] = d[1] + d[5]; e[2] = d[2] + d[6]; e[3] = d[3] + d[7]; e[4] = d[0] - d[4]; e[5] = d[1] - d[5]; e[6] = d[2] - d[6]; e[7] = d[3] - d[7];
-          d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
-          m[r * 8 + 0] = d[0] + d[1]; m[r * 8 + 1] = d[0] - d[1]; m[r * 8 + 2] = d[2] + d[3]; m[r * 8 + 3] = d[2] - d[3];
-          m[r * 8 + 4] = d[4] + d[5]; m[r * 8 + 5] = d[4] - d[5]; m[r * 8 + 6] = d[6] + d[7]; m[r * 8 + 7] = d[6] - d[7];
-        }
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          int e[8], d[8];
-          e[0] = m[c] + m[32 + c]; e[1] = m[8 + c] + m[40 + c]; e[2] = m[16 + c] + m[48 + c]; e[3] = m[24 + c] + m[56 + c];
-          e[4] = m[c] - m[32 + c]; e[5] = m[8 + c] - m[40 + c]; e[6] = m[16 + c] - m[48 + c]; e[7] = m[24 + c] - m[56 + c];
-          d[0] = e[0] + e[2]; d[1] = e[1] + e[3]; d[2] = e[0] - e[2]; d[3] = e[1] - e[3]; d[4] = e[4] + e[6]; d[5] = e[5] + e[7]; d[6] = e[4] - e[6]; d[7] = e[5] - e[7];
-          sum += (unsigned)(abs(d[0] + d[1]) + abs(d[0] - d[1]) + abs(d[2] + d[3]) + abs(d[2] - d[3]) + abs(d[4] + d[5]) + abs(d[4] - d[5]) + abs(d[6] + d[7]) + abs(d[6] - d[7]));
-        }
-        sum = (sum + 2) >> 2;
-      } else {
-        int m[16];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int d[4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) d[c] = (int)org[(size_t)r * k.W + c] - pred_pixel(line, 0, mode, pn, log2n, bx + c, by + r, dcv[0]);
-          const int a0 = d[0] + d[3], a1 = d[1] + d[2], a2 = d[1] - d[2], a3 = d[0] - d[3];
-          m[r * 4] = a0 + a1; m[r * 4 + 1] = a0 - a1; m[r * 4 + 2] = a2 + a3; m[r * 4 + 3] = a3 - a2;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int a0 = m[c] + m[12 + c], a1 = m[4 + c] + m[8 + c], a2 = m[4 + c] - m[8 + c], a3 = m[c] - m[12 + c];
-          sum += (unsigned)(abs(a0 + a1) + abs(a0 - a1) + abs(a2 + a3) + abs(a3 - a2));
-        }
-        sum = (sum + 1) >> 1;
-      }
+      const unsigned sum = (b == 8) ? rmd_block<8>(k, s, mode, pn, log2n, x, y, bx, by, dcv) : rmd_block<4>(k, s, mode, pn, log2n, x, y, bx, by, dcv);
       __hip_atomic_fetch_add(&s.satd[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
