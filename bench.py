@@ -161,6 +161,12 @@ def main():
         value = total_ctus / elapsed
         rd_avg_s = (prof["rd_ms"] / max(1, prof["rd_launches"])) / 1e3
         achieved = (ALGO_BYTES_PER_CTU * F * ctus / rd_avg_s) / 1e9 if rd_avg_s > 0 else 0.0
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01b_traffic.json")
+        if os.path.exists(tpath):   # PMC counters cannot be collected from inside the process: per-CTU bytes of the committed rocprofv3 passes
+            tj = json.load(open(tpath))
+            traffic = (tj["fetch_bytes_per_ctu"] + tj["write_bytes_per_ctu"]) * F * ctus
+            traffic_src = tj["source"] + "; " + tj["note"]
         out = {
             "metric": "all-intra CTUs/s at 2160p QP32", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
@@ -168,7 +174,7 @@ def main():
             "config": {"workload": "%dx%d 8-bit 4:2:0 all-intra QP%d, %d frames per GPU per step (frame-sharded; C4 of BASELINE.json is 75/GPU at 8 GPUs), on-device CNN labels + depth-pruned CTU decisions" % (W, H, qp, F),
                        "frames_per_gpu": F, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
                          "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU},
             "est_bits_per_frame": total_bits / max(1, world * F),
         }
