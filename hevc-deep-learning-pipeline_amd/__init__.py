@@ -30,7 +30,8 @@ REC_DTYPE = np.dtype([
     ("bits", "<u4"), ("dist", "<u4"), ("cost", "<f8"),
     ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024)])
 STATS_DTYPE = np.dtype([("sse", "<u8", 3), ("est_bits", "<u8"), ("ctus", "<u4"), ("pad", "<u4")])
-assert REC_DTYPE.itemsize == 15120 and STATS_DTYPE.itemsize == 40
+CABAC_DTYPE = np.dtype([("ctx", "u1", 160), ("frac", "<u8")])      # hevcdl_cabac_state
+assert REC_DTYPE.itemsize == 15120 and STATS_DTYPE.itemsize == 40 and CABAC_DTYPE.itemsize == 168
 
 
 class HevcdlError(RuntimeError):
@@ -95,6 +96,9 @@ def load_library():
     lib.hevcdl_predict_depth.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_predict_depth_rgb.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_compress_frames.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.hevcdl_begin_frames.argtypes = [vp, vp, ci, vp, vp]
+    lib.hevcdl_compress_ctu.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.hevcdl_get_recon.argtypes = [vp, ci, vp]
     lib.hevcdl_predict_depth_dev.argtypes = [vp, vp, ci, vp, vp, vp]
     lib.hevcdl_compress_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_encode_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
@@ -109,7 +113,8 @@ def load_library():
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes"]
+           "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
+           "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon"]
 
 
 def load_weights(path=WEIGHTS_PATH):
@@ -187,6 +192,33 @@ class Encoder:
             lab_ptr = labels.ctypes.data
         self._check(self.lib.hevcdl_compress_frames(self._h, yuv.ctypes.data, n, lab_ptr, recs.ctypes.data, recon.ctypes.data, stats.ctypes.data))
         return recs, recon, stats
+
+    # ---- per-CTU session: compressCtu + encodeCtu of the reference, one CTU per call (TEncSlice.cpp:879,893) ----
+    def begin_frames(self, yuv, labels=None):
+        """Upload frames, take / predict labels -> labels [n, ctus, 16] actually used."""
+        yuv, n = self._frames(yuv)
+        out = np.zeros((n, self.ctus, 16), np.uint8)
+        lab_ptr = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, np.uint8).reshape(n, self.ctus, 16)
+            lab_ptr = labels.ctypes.data
+        self._check(self.lib.hevcdl_begin_frames(self._h, yuv.ctypes.data, n, lab_ptr, out.ctypes.data))
+        return out
+
+    def compress_ctu(self, frame, ctu_addr, state_in=None):
+        """-> (record REC_DTYPE scalar array, cabac state after the CTU CABAC_DTYPE scalar array)."""
+        rec = np.zeros(1, REC_DTYPE)
+        st_out = np.zeros(1, CABAC_DTYPE)
+        st_in = None
+        if state_in is not None:
+            st_in = np.ascontiguousarray(state_in, CABAC_DTYPE).reshape(1)
+        self._check(self.lib.hevcdl_compress_ctu(self._h, frame, ctu_addr, None if st_in is None else st_in.ctypes.data, rec.ctypes.data, st_out.ctypes.data))
+        return rec, st_out
+
+    def get_recon(self, frame):
+        out = np.zeros(self.frame_bytes, np.uint8)
+        self._check(self.lib.hevcdl_get_recon(self._h, frame, out.ctypes.data))
+        return out
 
     # ---- device-resident entry points: arguments are raw device pointers (ints), e.g. torch.Tensor.data_ptr() ----
     def predict_depth_dev(self, d_yuv, n, d_labels, d_logits=None, stream=None):

@@ -21,6 +21,8 @@ struct hevcdl_ctx {
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
   hipStream_t stream;
+  // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
+  unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
   bool profile;
   std::vector<hipEvent_t> ev_cnn, ev_rd;       // start/stop pairs
   char err[256];
@@ -113,7 +115,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   ctx->ctus_x = (cfg->width + 63) >> 6; ctx->ctus_y = (cfg->height + 63) >> 6; ctx->ctus = ctx->ctus_x * ctx->ctus_y;
   ctx->frame_bytes = hevcdl_frame_bytes(cfg->width, cfg->height);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr;
+  ctx->d_logits = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -144,7 +146,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_rgb);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac);
   delete ctx;
 }
 
@@ -184,12 +186,14 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   return HEVCDL_OK;
 }
 
-static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s)
+static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s,
+                               int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr, void *d_scratch = nullptr)
 {
   hevcdl_rd_params p;
   memset(&p, 0, sizeof p);
+  p.ctu_begin = ctu_begin; p.ctu_end = ctu_end < 0 ? ctx->ctus : ctu_end; p.cabac_in = (const unsigned char *)d_cabac_in; p.cabac_out = (unsigned char *)d_cabac_out;
   p.yuv = (const uint8_t *)d_yuv; p.labels = (const uint8_t *)d_labels; p.records = (unsigned char *)d_records; p.recon = (uint8_t *)d_recon;
-  p.stats = (unsigned char *)d_stats; p.scratch = ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
+  p.stats = (unsigned char *)d_stats; p.scratch = d_scratch ? (unsigned char *)d_scratch : ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_y = ctx->ctus_y; p.n_frames = n_frames;
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
@@ -300,6 +304,58 @@ extern "C" hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *
   HIPCHK(hipMemcpy(records, ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames, hipMemcpyDeviceToHost));
   if (recon_opt) HIPCHK(hipMemcpy(recon_opt, ctx->d_recon, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
   if (stats_opt) HIPCHK(hipMemcpy(stats_opt, ctx->d_stats, sizeof(hevcdl_frame_stats) * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
+// ---- per-CTU session: the semantic drop-in for TEncCu::compressCtu + encodeCtu (TEncSlice.cpp:879,893) ----------------
+extern "C" hevcdl_status hevcdl_begin_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt, uint8_t *labels_out_opt)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0 || !yuv) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "begin_frames: no frames");
+  st = ensure_staging(ctx); if (st) return st;
+  if (!ctx->d_cabac) HIPCHK(hipMalloc(&ctx->d_cabac, (size_t)168 * ctx->cfg.max_frames));
+  HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice));
+  else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
+  HIPCHK(hipMemset(ctx->d_recon, 0, ctx->frame_bytes * n_frames));
+  HIPCHK(hipMemset(ctx->d_records, 0, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames));
+  HIPCHK(hipDeviceSynchronize());
+  if (labels_out_opt) HIPCHK(hipMemcpy(labels_out_opt, ctx->d_labels, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyDeviceToHost));
+  ctx->next_ctu.assign(n_frames, 0); ctx->session_frames = n_frames;
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_compress_ctu(hevcdl_ctx *ctx, int frame, int ctu_addr, const hevcdl_cabac_state *state_in_opt,
+                                             hevcdl_ctu_record *record, hevcdl_cabac_state *state_out_opt)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  if (frame < 0 || frame >= ctx->session_frames) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "compress_ctu: frame outside the session (hevcdl_begin_frames)");
+  if (ctu_addr < 0 || ctu_addr >= ctx->ctus || !record) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "compress_ctu: bad CTU address / null record");
+  // the CTUs of a slice are a chain: neighbours' reconstruction and records must exist
+  if (ctu_addr > ctx->next_ctu[frame]) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "compress_ctu: CTUs must be submitted in coding order");
+  if (ctu_addr < ctx->next_ctu[frame] && !state_in_opt) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "compress_ctu: re-coding an earlier CTU needs its entry state");
+  HIPCHK(hipSetDevice(ctx->cfg.device));
+  unsigned char *cab = ctx->d_cabac + (size_t)168 * frame;
+  if (state_in_opt) HIPCHK(hipMemcpy(cab, state_in_opt, 168, hipMemcpyHostToDevice));
+  const void *cab_in = (state_in_opt || ctu_addr > 0) ? cab : nullptr;      // NULL: slice-start contexts from the QP
+  hevcdl_status st = launch_rd(ctx, ctx->d_yuv + ctx->frame_bytes * frame, 1, ctx->d_labels + (size_t)ctx->ctus * 16 * frame,
+                               ctx->d_records + (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * frame, ctx->d_recon + ctx->frame_bytes * frame, nullptr, nullptr,
+                               ctu_addr, ctu_addr + 1, cab_in, cab, ctx->d_scratch + ctx->scratch_per_frame * frame);
+  if (st) return st;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "rd kernel", e);
+  HIPCHK(hipMemcpy(record, ctx->d_records + ((size_t)ctx->ctus * frame + ctu_addr) * sizeof(hevcdl_ctu_record), sizeof(hevcdl_ctu_record), hipMemcpyDeviceToHost));
+  if (state_out_opt) HIPCHK(hipMemcpy(state_out_opt, cab, 168, hipMemcpyDeviceToHost));
+  if (ctu_addr == ctx->next_ctu[frame]) ctx->next_ctu[frame] = ctu_addr + 1;
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_get_recon(hevcdl_ctx *ctx, int frame, uint8_t *recon)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  if (frame < 0 || frame >= ctx->session_frames || !recon) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "get_recon: frame outside the session / null pointer");
+  HIPCHK(hipSetDevice(ctx->cfg.device));
+  HIPCHK(hipMemcpy(recon, ctx->d_recon + ctx->frame_bytes * frame, ctx->frame_bytes, hipMemcpyDeviceToHost));
   return HEVCDL_OK;
 }
 

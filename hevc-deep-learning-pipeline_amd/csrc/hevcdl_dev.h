@@ -44,6 +44,9 @@ struct hevcdl_rd_params {
   unsigned char *scratch;          // [frame] per-frame workspace
   size_t scratch_per_frame;
   unsigned int *dbgbuf;
+  const unsigned char *cabac_in;   // [frame] 168-byte coder state to start from, or NULL: slice-start state (only with ctu_begin == 0)
+  unsigned char *cabac_out;        // [frame] coder state after the last CTU processed, or NULL
+  int ctu_begin, ctu_end;          // CTU address range [begin, end) in coding order
   int width, height, ctus_x, ctus_y, n_frames, debug;
   hevcdl_rd_consts k;
 };

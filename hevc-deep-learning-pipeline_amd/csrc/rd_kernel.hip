@@ -2032,18 +2032,24 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   wsync();
-  // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719
+  // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719.
+  // A per-CTU call (hevcdl_compress_ctu) resumes from the state the previous call left instead.
   LCabac *truec = &s.truec;
-  for (int i = lane; i < NUM_CTX; i += 64) {
-    const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
-    int st = ((slope * p.k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
-    const int mps = st >= 64;
-    truec->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
+  if (p.cabac_in) {
+    GLB const unsigned long long *src = (GLB const unsigned long long *)p.cabac_in + (size_t)frame * 21;
+    if (lane < 21) ((LDS unsigned long long *)truec)[lane] = src[lane];
+  } else {
+    for (int i = lane; i < NUM_CTX; i += 64) {
+      const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
+      int st = ((slope * p.k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+      const int mps = st >= 64;
+      truec->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
+    }
+    if (lane == 0) { truec->ctx[159] = 0; truec->frac = 0; }
   }
-  if (lane == 0) truec->frac = 0;
   wsync();
 
-  for (int a = 0; a < nctu; a++) {
+  for (int a = p.ctu_begin; a < p.ctu_end; a++) {
     const int cx = a % p.ctus_x, cy = a / p.ctus_x;
     wsync();
     k.addr = a; k.cx = cx; k.cy = cy;
@@ -2073,6 +2079,11 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
       *(GLB double *)(rec + REC_COST) = best.cost;
     }
     wsync();
+  }
+  if (p.cabac_out) {
+    wsync();
+    GLB unsigned long long *dstc = (GLB unsigned long long *)p.cabac_out + (size_t)frame * 21;
+    if (lane < 21) dstc[lane] = ((LDS const unsigned long long *)truec)[lane];
   }
 #ifdef HEVCDL_KERNEL_PROF
   wsync();

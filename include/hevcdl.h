@@ -116,6 +116,27 @@ hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t *ctu_rgb, 
 hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,
                                      hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt);
 
+/* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------
+ *   TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)   TEncCu.h:120, called at TEncSlice.cpp:879
+ *   TEncCu::encodeCtu(TComDataCU* pCtu)                   TEncCu.h:123, called at TEncSlice.cpp:893
+ * One call = both (decide the CTU, then advance the true CABAC state over it).  For CPU-side diff testing against
+ * the reference's loop; the batched entry points above are what feeds the GPU.
+ *   hevcdl_begin_frames   uploads the frames, takes / predicts their labels (labels_out_opt may be NULL) and clears
+ *                         reconstruction and records: the replacement of the label-file poll at TEncCu.cpp:244-253.
+ *   hevcdl_compress_ctu   CTUs of a frame must arrive in coding order (neighbours' reconstruction and records live
+ *                         in the context).  state_in_opt == NULL: continue from the state the previous call left
+ *                         (CTU 0: slice-start contexts of the QP, ContextModel.cpp:56-66); otherwise the caller's
+ *                         TEncSbac state (TEncSlice.cpp:826-832).  state_out_opt receives the state after encodeCtu.
+ *                         Never hangs and never aborts: ordering / range errors come back as HEVCDL_ERR_INVALID_ARG. */
+typedef struct hevcdl_cabac_state {
+  uint8_t  ctx[160];    /* (state << 1) | mps of the 159 I-slice contexts in TEncSbac.cpp:62-92 order, 1 pad byte */
+  uint64_t frac;        /* TEncBinCABACCounter fractional bit accumulator (15 fractional bits) */
+} hevcdl_cabac_state;
+hevcdl_status hevcdl_begin_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt, uint8_t *labels_out_opt);
+hevcdl_status hevcdl_compress_ctu(hevcdl_ctx *ctx, int frame, int ctu_addr, const hevcdl_cabac_state *state_in_opt,
+                                  hevcdl_ctu_record *record, hevcdl_cabac_state *state_out_opt);
+hevcdl_status hevcdl_get_recon(hevcdl_ctx *ctx, int frame, uint8_t *recon);
+
 /* ---- device-buffer entry points (inputs/outputs already resident in HBM, asynchronous on `stream`) ---- */
 /* All pointers are device pointers; stream is a hipStream_t (NULL = default stream). */
 hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream);

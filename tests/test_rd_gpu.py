@@ -54,3 +54,73 @@ def test_matches_oracle_on_seeded_inputs(oracle_built, w, h, qp, nf, seed):
     assert_records_equal(recs, o_recs, "oracle %dx%d" % (w, h))
     assert np.array_equal(recon, o_recon)
     assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
+
+
+def test_per_ctu_session_equals_batch_and_rejects_disorder():
+    """hevcdl_compress_ctu (compressCtu + encodeCtu of one CTU) called in coding order reproduces the batched path
+    bit for bit; the coder state it returns can be fed back; out-of-order submission is an error, not a hang."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf = 192, 128, 32, 2
+    yuv = ref_tools.synth_yuv(w, h, nf, seed=21)
+    labels = ref_tools.make_labels(w, h, nf, "rand", 22)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    recs, recon, stats = e.compress_frames(yuv, labels)
+    used = e.begin_frames(yuv, labels)
+    assert np.array_equal(used.reshape(labels.shape), labels)
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        e.compress_ctu(0, 1)                                  # CTU 0 not coded yet
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        e.compress_ctu(nf, 0)                                 # frame outside the session
+    for f in range(nf):
+        state = None
+        for a in range(e.ctus):
+            # frame 0 continues from the context's own state, frame 1 feeds the returned state back explicitly
+            rec, state = e.compress_ctu(f, a, state_in=(state if (f == 1 and a > 0) else None))
+            for name in hevcdl_amd.REC_DTYPE.names:
+                assert np.array_equal(rec[0][name], recs[f, a][name]), (f, a, name)
+        assert np.array_equal(e.get_recon(f), recon[f].reshape(-1))
+        assert int(state["frac"][0]) >> 15 >= 0
+    # re-coding an earlier CTU is allowed only with its entry state
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        e.compress_ctu(0, 2)
+    e.close()
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_full_size_properties(w, h):
+    """BASELINE.json sizes, where the oracle would take minutes: size-independent properties of the path.
+    frame independence (batch == frame by frame), determinism, decided CU depth == CNN label (the reference evaluates
+    a CU only at its labelled depth), NxN only in 8x8 CUs, cbf <-> coefficients, statistics == recomputed SSE."""
+    import hevcdl_amd
+    import ref_tools
+    qp, nf = 32, 2
+    yuv = ref_tools.synth_yuv(w, h, nf, seed=1000)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    labels = e.predict_depth(yuv)
+    recs, recon, stats = e.compress_frames(yuv, labels)
+    recs1, recon1, stats1 = e.compress_frames(yuv[1:2], labels[1:2])
+    assert recs1.tobytes() == recs[1:2].tobytes() and np.array_equal(recon1, recon[1:2]) and stats1.tobytes() == stats[1:2].tobytes()
+    # depth map == labels: partition z -> 16x16 block of the CTU (z >> 4 in z-order, mapped to raster 4x4 grid)
+    z16 = np.arange(16); zx = (z16 & 1) | ((z16 >> 1) & 2); zy = ((z16 >> 1) & 1) | ((z16 >> 2) & 2)
+    blk_of_z = (zy * 4 + zx)[np.arange(256) >> 4]
+    cx, cy = (w + 63) // 64, (h + 63) // 64
+    inside = np.zeros((cy * cx, 256), bool)
+    z = np.arange(256); px = np.zeros(256, int); py = np.zeros(256, int)
+    for b in range(4):
+        px |= ((z >> (2 * b)) & 1) << b; py |= ((z >> (2 * b + 1)) & 1) << b
+    for a in range(cy * cx):
+        inside[a] = ((a % cx) * 64 + px * 4 < w) & ((a // cx) * 64 + py * 4 < h)
+    lab_z = labels.reshape(nf, -1, 16)[:, :, blk_of_z]
+    assert np.array_equal(recs["depth"][:, inside], lab_z[:, inside])
+    assert (recs["part_size"][:, inside][recs["depth"][:, inside] < 3] == 0).all()
+    # a CTU without coded coefficients carries no cbf, and vice versa
+    nz = (recs["coeff_y"] != 0).any(axis=2) | (recs["coeff_cb"] != 0).any(axis=2) | (recs["coeff_cr"] != 0).any(axis=2)
+    assert np.array_equal(nz, (recs["cbf"] != 0).any(axis=(2, 3)))
+    ysz = w * h
+    for f in range(nf):
+        d = yuv[f].astype(np.int64) - recon[f].reshape(-1).astype(np.int64)
+        sse = [int((d[:ysz] ** 2).sum()), int((d[ysz:ysz + ysz // 4] ** 2).sum()), int((d[ysz + ysz // 4:] ** 2).sum())]
+        assert [int(v) for v in stats["sse"][f]] == sse
+        assert int(stats["ctus"][f]) == cx * cy and int(stats["est_bits"][f]) > 0
+    e.close()
