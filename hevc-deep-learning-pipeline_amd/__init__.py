@@ -74,6 +74,22 @@ def build_ext(force=False, verbose=False, defines=(), out=None):
     return out
 
 
+APP_PATH = os.path.join(PKG_DIR, "bin", "TAppEncoderHevcdl")
+
+
+def build_app(force=False):
+    """Compile the command-line front end (csrc/hevcdl_app.cpp, host C++ over the C ABI) into bin/TAppEncoderHevcdl."""
+    src = os.path.join(PKG_DIR, "csrc", "hevcdl_app.cpp")
+    lib = build_ext()
+    if not force and os.path.exists(APP_PATH) and os.path.getmtime(APP_PATH) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return APP_PATH
+    os.makedirs(os.path.dirname(APP_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-x", "c++", src, "-x", "none", "-I" + os.path.join(ROOT, "include"), "-L" + os.path.dirname(lib), "-lhevcdl_hip",
+                    "-Wl,-rpath,$ORIGIN/../lib", "-o", APP_PATH], check=True)
+    return APP_PATH
+
+
 _lib = None
 
 

@@ -1,0 +1,250 @@
+// hevcdl_app.cpp -- command-line front end with the reference application's surface.
+//
+// Accepts what the reference is started with,  TAppEncoder -c encoder_intra_main.cfg -c bitstream.cfg [-q QP ...]
+//   option syntax                HM_dl/source/Lib/TAppCommon/program_options_lite.cpp (cfg "Key : value  # comment",
+//                                "--Key=value" / "--Key value", short options)
+//   option names / short forms   HM_dl/source/App/TAppEncoder/TAppEncCfg.cpp:730-1290
+//   planar YUV reader            HM_dl/source/Lib/TLibVideoIO/TVideoIOYuv.cpp:249,675 (8-bit 4:2:0 file, FrameSkip)
+//   picture log line / summary   TEncGOP.cpp:2500-2541, TEncAnalyze.h:163-370
+// and drives the GPU path through the C ABI of include/hevcdl.h only.  Keys that would change the path are checked
+// against what the path implements (rejected, not ignored); keys of stages that are not built (entropy coder / NAL
+// writer, in-loop filters) are accepted and listed.  Labels come from the on-device CNN, or -- the reference's own
+// file IPC format -- from --LabelDir <dir>/<frame>/ctu<addr>.txt (16 integers, TEncCu.cpp:255-262).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "hevcdl.h"
+
+namespace {
+
+enum Kind { USED, PATH, STAGE, NOEFFECT };
+struct Key { const char *name; const char *shortopt; Kind kind; const char *required; };   // required: value the path implements (PATH)
+
+const Key KEYS[] = {
+  // used by this front end
+  { "InputFile", "i", USED, 0 }, { "BitstreamFile", "b", STAGE, 0 }, { "ReconFile", "o", USED, 0 }, { "SourceWidth", "wdt", USED, 0 },
+  { "SourceHeight", "hgt", USED, 0 }, { "FrameRate", "fr", USED, 0 }, { "FrameSkip", "fs", USED, 0 }, { "FramesToBeEncoded", "f", USED, 0 },
+  { "QP", "q", USED, 0 },
+  // extensions of this front end
+  { "LabelDir", 0, USED, 0 }, { "BatchFrames", 0, USED, 0 }, { "Device", 0, USED, 0 }, { "Weights", 0, USED, 0 }, { "RecordFile", 0, USED, 0 },
+  { "CnnInput", 0, USED, 0 }, { "PrintConfig", 0, USED, 0 },
+  // keys that define the path: only the implemented value is accepted
+  { "InputBitDepth", 0, PATH, "8" }, { "InternalBitDepth", 0, PATH, "8" }, { "InputChromaFormat", 0, PATH, "420" }, { "Profile", 0, PATH, "main" },
+  { "MaxCUWidth", 0, PATH, "64" }, { "MaxCUHeight", 0, PATH, "64" }, { "MaxPartitionDepth", 0, PATH, "4" },
+  { "QuadtreeTULog2MaxSize", 0, PATH, "5" }, { "QuadtreeTULog2MinSize", 0, PATH, "2" }, { "QuadtreeTUMaxDepthIntra", 0, PATH, "3" },
+  { "IntraPeriod", 0, PATH, "1" }, { "GOPSize", 0, PATH, "1" }, { "MaxDeltaQP", 0, PATH, "0" }, { "DeltaQpRD", 0, PATH, "0" },
+  { "RDOQ", 0, PATH, "1" }, { "RDOQTS", 0, PATH, "1" }, { "TransformSkip", 0, PATH, "1" }, { "TransformSkipFast", 0, PATH, "1" },
+  { "SignHideFlag", "SBH", PATH, "1" }, { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, PATH, "0" },
+  { "NumTileRowsMinus1", 0, PATH, "0" }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
+  { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
+  // stages that are not built: accepted, reported once
+  { "Level", 0, STAGE, 0 }, { "DecodingRefreshType", 0, STAGE, 0 }, { "ReWriteParamSetsFlag", 0, STAGE, 0 }, { "LoopFilterOffsetInPPS", 0, STAGE, 0 },
+  { "LoopFilterDisable", 0, STAGE, 0 }, { "LoopFilterBetaOffset_div2", 0, STAGE, 0 }, { "LoopFilterTcOffset_div2", 0, STAGE, 0 },
+  { "DeblockingFilterMetric", 0, STAGE, 0 }, { "SAO", 0, STAGE, 0 }, { "SAOLcuBoundary", 0, STAGE, 0 }, { "LFCrossSliceBoundaryFlag", 0, STAGE, 0 },
+  { "LFCrossTileBoundaryFlag", 0, STAGE, 0 }, { "SEIDecodedPictureHash", 0, STAGE, 0 },
+  // no effect on an all-intra slice with the settings above
+  { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
+  { "FEN", 0, NOEFFECT, 0 }, { "FDM", 0, NOEFFECT, 0 }, { "AMP", 0, NOEFFECT, 0 }, { "MaxCuDQPDepth", 0, NOEFFECT, 0 }, { "SliceArgument", 0, NOEFFECT, 0 },
+  { "PCMLog2MaxSize", 0, NOEFFECT, 0 }, { "PCMLog2MinSize", 0, NOEFFECT, 0 }, { "PCMInputBitDepthFlag", 0, NOEFFECT, 0 },
+  { "PCMFilterDisableFlag", 0, NOEFFECT, 0 }, { "TileUniformSpacing", 0, NOEFFECT, 0 }, { "TileColumnWidthArray", 0, NOEFFECT, 0 },
+  { "TileRowHeightArray", 0, NOEFFECT, 0 }, { "ScalingListFile", 0, NOEFFECT, 0 },
+};
+
+const Key *find_key(const std::string &name, bool shortform)
+{
+  for (const Key &k : KEYS) if (shortform ? (k.shortopt && name == k.shortopt) : name == k.name) return &k;
+  return nullptr;
+}
+
+std::string trim(const std::string &s)
+{
+  size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+  return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+}
+
+struct Options {
+  std::map<std::string, std::string> v;
+  std::vector<std::string> errors;
+  void set(const std::string &name, const std::string &val, bool shortform, const std::string &where)
+  {
+    const Key *k = find_key(name, shortform);
+    if (!k) { errors.push_back(where + ": unknown option '" + name + "'"); return; }
+    v[k->name] = val;
+  }
+  bool parse_cfg(const std::string &path)
+  { // program_options_lite::scanFile: "name : value", '#' starts a comment, blank lines ignored
+    std::ifstream f(path);
+    if (!f) { errors.push_back("cannot open configuration file '" + path + "'"); return false; }
+    std::string line; int ln = 0;
+    while (std::getline(f, line)) {
+      ln++;
+      const size_t h = line.find('#'); if (h != std::string::npos) line.erase(h);
+      line = trim(line); if (line.empty()) continue;
+      const size_t c = line.find(':');
+      if (c == std::string::npos) { errors.push_back(path + ":" + std::to_string(ln) + ": expected 'name : value'"); continue; }
+      set(trim(line.substr(0, c)), trim(line.substr(c + 1)), false, path + ":" + std::to_string(ln));
+    }
+    return true;
+  }
+  void parse_argv(int argc, char **argv)
+  {
+    for (int i = 1; i < argc; i++) {
+      std::string a = argv[i];
+      if (a == "-c") { if (i + 1 < argc) parse_cfg(argv[++i]); else errors.push_back("-c needs a file"); continue; }
+      if (a.rfind("--", 0) == 0) {
+        const size_t e = a.find('=');
+        if (e != std::string::npos) set(a.substr(2, e - 2), a.substr(e + 1), false, "command line");
+        else if (a.substr(2) == "PrintConfig") set("PrintConfig", "1", false, "command line");
+        else if (i + 1 < argc) { set(a.substr(2), argv[i + 1], false, "command line"); i++; }
+        else errors.push_back("option '" + a + "' needs a value");
+      } else if (a.size() > 1 && a[0] == '-') {
+        if (i + 1 < argc) { set(a.substr(1), argv[i + 1], true, "command line"); i++; }
+        else errors.push_back("option '" + a + "' needs a value");
+      } else errors.push_back("stray argument '" + a + "'");
+    }
+  }
+  std::string get(const char *k, const char *dflt = "") const { auto it = v.find(k); return it == v.end() ? dflt : it->second; }
+  long geti(const char *k, long dflt) const { auto it = v.find(k); return it == v.end() ? dflt : strtol(it->second.c_str(), nullptr, 10); }
+};
+
+std::string native_path(std::string p)
+{ // the reference's cfg files carry Windows paths (".\rec\rec.yuv")
+  std::replace(p.begin(), p.end(), '\\', '/');
+  return p;
+}
+
+double psnr_of(unsigned long long sse, double n) { return sse == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 * n / (double)sse); }   // TEncGOP.cpp:2391-2393
+
+std::string json_escape(const std::string &s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o; }
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+  Options opt;
+  opt.parse_argv(argc, argv);
+  // keys that define the path must carry the implemented value
+  std::vector<std::string> stage_keys;
+  for (const auto &kv : opt.v) {
+    const Key *k = find_key(kv.first, false);
+    if (k->kind == PATH && kv.second != k->required)
+      opt.errors.push_back(std::string(k->name) + " = " + kv.second + " is not implemented by this path (only " + k->required + ")");
+    if (k->kind == STAGE) stage_keys.push_back(k->name);
+  }
+  const int width = (int)opt.geti("SourceWidth", 0), height = (int)opt.geti("SourceHeight", 0), qp = (int)opt.geti("QP", 30);
+  const long frame_skip = opt.geti("FrameSkip", 0); long n_frames = opt.geti("FramesToBeEncoded", 0);
+  const double fps = atof(opt.get("FrameRate", "30").c_str());
+  const std::string input = native_path(opt.get("InputFile")), recon_path = native_path(opt.get("ReconFile")), label_dir = native_path(opt.get("LabelDir"));
+  const std::string cnn_input = opt.get("CnnInput", "rgb601");
+  if (opt.v.count("PrintConfig")) {
+    printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
+           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
+           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str());
+    for (size_t i = 0; i < stage_keys.size(); i++) printf("%s\"%s\"", i ? ", " : "", stage_keys[i].c_str());
+    printf("], \"errors\": [");
+    for (size_t i = 0; i < opt.errors.size(); i++) printf("%s\"%s\"", i ? ", " : "", json_escape(opt.errors[i]).c_str());
+    printf("]}\n");
+    return opt.errors.empty() ? 0 : 2;
+  }
+  if (input.empty()) opt.errors.push_back("InputFile (-i) is required");
+  if (width <= 0 || height <= 0) opt.errors.push_back("SourceWidth / SourceHeight (-wdt / -hgt) are required");
+  if (cnn_input != "rgb601" && cnn_input != "luma") opt.errors.push_back("CnnInput must be rgb601 or luma");
+  if (!opt.errors.empty()) { for (const auto &e : opt.errors) fprintf(stderr, "Error: %s\n", e.c_str()); return 2; }
+
+  const size_t frame_bytes = hevcdl_frame_bytes(width, height);
+  FILE *fin = fopen(input.c_str(), "rb");
+  if (!fin) { fprintf(stderr, "Error: cannot open input file '%s'\n", input.c_str()); return 2; }
+  fseek(fin, 0, SEEK_END); const long long fsize = ftell(fin);
+  const long avail = (long)(fsize / (long long)frame_bytes) - frame_skip;
+  if (avail <= 0) { fprintf(stderr, "Error: input holds no frame after FrameSkip\n"); return 2; }
+  if (n_frames <= 0 || n_frames > avail) n_frames = avail;                    // TAppEncTop: stops at end of file
+  const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", 64)));
+
+  hevcdl_config cfg;
+  hevcdl_status st = hevcdl_config_default(&cfg, width, height, qp);
+  if (st != HEVCDL_OK) { fprintf(stderr, "Error: unsupported picture size / QP (status %d)\n", (int)st); return 2; }
+  cfg.max_frames = batch; cfg.device = (int)opt.geti("Device", 0);
+  cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
+  std::string wpath = opt.get("Weights");
+  if (wpath.empty()) { // next to the library: <pkg>/weights/hevc_encoder_model.f32, this binary lives in <pkg>/bin
+    std::string self = argv[0]; const size_t s1 = self.find_last_of('/'); self = s1 == std::string::npos ? "." : self.substr(0, s1);
+    wpath = self + "/../weights/hevc_encoder_model.f32";
+  }
+  std::vector<float> weights(HEVCDL_WEIGHT_FLOATS);
+  { FILE *fw = fopen(wpath.c_str(), "rb");
+    if (!fw || fread(weights.data(), sizeof(float), weights.size(), fw) != weights.size()) { fprintf(stderr, "Error: cannot read %d weights from '%s'\n", (int)HEVCDL_WEIGHT_FLOATS, wpath.c_str()); return 2; }
+    fclose(fw); }
+  hevcdl_ctx *ctx = nullptr;
+  st = hevcdl_create(&cfg, weights.data(), weights.size(), &ctx);
+  if (st != HEVCDL_OK) { fprintf(stderr, "Error: hevcdl_create failed with status %d (no GPU / unsupported configuration); there is no CPU path\n", (int)st); return 3; }
+
+  printf("HEVC-DL MI355X path: %dx%d  QP %d  frames %ld (skip %ld)  batch %d  labels: %s\n", width, height, qp, n_frames, frame_skip, batch,
+         label_dir.empty() ? (cnn_input == "luma" ? "on-device CNN (luma input)" : "on-device CNN (BT.601 RGB input)") : ("files under " + label_dir).c_str());
+  if (!stage_keys.empty()) {
+    printf("Accepted, but their stages are not part of this path (no bitstream is written, reconstruction and PSNR are before the in-loop filters):");
+    for (const auto &k : stage_keys) printf(" %s", k.c_str());
+    printf("\n");
+  }
+  const int ctus = hevcdl_ctus_per_frame(width, height);
+  std::vector<uint8_t> yuv(frame_bytes * batch), recon(frame_bytes * batch), labels((size_t)ctus * 16 * batch);
+  std::vector<hevcdl_ctu_record> recs((size_t)ctus * batch);
+  std::vector<hevcdl_frame_stats> stats(batch);
+  FILE *frec = recon_path.empty() ? nullptr : fopen(recon_path.c_str(), "wb");
+  if (!recon_path.empty() && !frec) { fprintf(stderr, "Error: cannot open reconstruction file '%s'\n", recon_path.c_str()); return 2; }
+  const std::string record_path = native_path(opt.get("RecordFile"));
+  FILE *frecords = record_path.empty() ? nullptr : fopen(record_path.c_str(), "wb");
+  const double ny = (double)width * height, nc = ny / 4;
+  double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;
+  int rc = 0;
+  for (long f0 = 0; f0 < n_frames && rc == 0; f0 += batch) {
+    const int nb = (int)std::min<long>(batch, n_frames - f0);
+    fseek(fin, (long)((frame_skip + f0) * (long long)frame_bytes), SEEK_SET);
+    if (fread(yuv.data(), frame_bytes, nb, fin) != (size_t)nb) { fprintf(stderr, "Error: short read of '%s'\n", input.c_str()); rc = 2; break; }
+    const uint8_t *lab = nullptr;
+    if (!label_dir.empty()) {
+      for (int i = 0; i < nb && rc == 0; i++) for (int a = 0; a < ctus; a++) {
+        const std::string p = label_dir + "/" + std::to_string(f0 + i) + "/ctu" + std::to_string(a) + ".txt";
+        std::ifstream lf(p); int v;
+        for (int j = 0; j < 16; j++) { if (!(lf >> v) || v < 0 || v > 3) { fprintf(stderr, "Error: label file '%s' must hold 16 depths 0..3\n", p.c_str()); rc = 2; break; } labels[((size_t)i * ctus + a) * 16 + j] = (uint8_t)v; }
+        if (rc) break;
+      }
+      lab = labels.data();
+    }
+    if (rc) break;
+    const auto t0 = std::chrono::steady_clock::now();
+    st = hevcdl_compress_frames(ctx, yuv.data(), nb, lab, recs.data(), recon.data(), stats.data());
+    const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / nb;
+    if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
+    for (int i = 0; i < nb; i++) {
+      const double p[3] = { psnr_of(stats[i].sse[0], ny), psnr_of(stats[i].sse[1], nc), psnr_of(stats[i].sse[2], nc) };
+      printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]\n", f0 + i, 0, 'I', qp,
+             (unsigned long long)stats[i].est_bits, p[0], p[1], p[2], et);
+      sum_bits += (double)stats[i].est_bits;
+      for (int c = 0; c < 3; c++) { sum_psnr[c] += p[c]; sum_mse[c] += (double)stats[i].sse[c] / (c ? nc : ny); }
+      done++;
+    }
+    if (frec) fwrite(recon.data(), frame_bytes, nb, frec);
+    if (frecords) fwrite(recs.data(), sizeof(hevcdl_ctu_record), (size_t)ctus * nb, frecords);
+  }
+  if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
+    const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
+    printf("\n\nSUMMARY (bits: CABAC estimate of the decisions; PSNR before the in-loop filters) ------------------------\n");
+    printf("\tTotal Frames |   Bitrate     Y-PSNR    U-PSNR    V-PSNR    YUV-PSNR  \n");
+    printf("\t %8ld    %c %12.4lf  %8.4lf  %8.4lf  %8.4lf  %8.4lf  \n", done, 'a', sum_bits * (fps / 1000.0 / done), sum_psnr[0] / done, sum_psnr[1] / done,
+           sum_psnr[2] / done, mse_yuv == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 / mse_yuv));
+  }
+  if (frec) fclose(frec);
+  if (frecords) fclose(frecords);
+  fclose(fin);
+  hevcdl_destroy(ctx);
+  return rc;
+}

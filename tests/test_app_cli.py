@@ -1,0 +1,120 @@
+"""Row f-4: the command-line front end (reference CLI / .cfg surface, planar YUV reader, label files)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+CFG_MAIN = """#======== Profile / unit definition ========
+Profile                       : main
+MaxCUWidth                    : 64          # Maximum coding unit width in pixel
+MaxCUHeight                   : 64
+MaxPartitionDepth             : 4
+QuadtreeTULog2MaxSize         : 5           # Log2 of maximum transform size
+QuadtreeTULog2MinSize         : 2
+QuadtreeTUMaxDepthInter       : 3
+QuadtreeTUMaxDepthIntra       : 3
+IntraPeriod                   : 1
+GOPSize                       : 1
+QP                            : 37
+RDOQ                          : 1
+RDOQTS                        : 1
+TransformSkip                 : 1
+TransformSkipFast             : 1
+SAO                           : 1
+LoopFilterDisable             : 0
+InternalBitDepth              : 8
+"""
+CFG_SEQ = """InputFile : .\\in_192x128.yuv
+InputBitDepth : 8
+InputChromaFormat : 420
+FrameRate : 30
+FrameSkip : 0
+SourceWidth : 192
+SourceHeight : 128
+FramesToBeEncoded : 2
+Level : 3.1
+BitstreamFile : .\\rec\\str.bin
+ReconFile : .\\rec\\rec.yuv
+"""
+
+
+@pytest.fixture(scope="module")
+def app():
+    import hevcdl_amd
+    return hevcdl_amd.build_app()
+
+
+def run(app, args, cwd):
+    return subprocess.run([app] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def write_cfgs(tmp_path):
+    (tmp_path / "main.cfg").write_text(CFG_MAIN)
+    (tmp_path / "seq.cfg").write_text(CFG_SEQ)
+
+
+def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
+    write_cfgs(tmp_path)
+    r = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", "32", "-f", "1", "--LabelDir=pred", "--PrintConfig"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    c = json.loads(r.stdout)
+    assert c["InputFile"] == "./in_192x128.yuv" and c["ReconFile"] == "./rec/rec.yuv"       # Windows paths of the reference cfgs
+    assert (c["SourceWidth"], c["SourceHeight"], c["QP"], c["FramesToBeEncoded"], c["LabelDir"]) == (192, 128, 32, 1, "pred")
+    assert set(c["stage_keys"]) == {"BitstreamFile", "Level", "SAO", "LoopFilterDisable"} and c["errors"] == []
+
+
+def test_keys_that_change_the_path_are_rejected(app, tmp_path):
+    write_cfgs(tmp_path)
+    for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
+                          (["--WaveFrontSynchro=1"], "WaveFrontSynchro")):
+        r = run(app, ["-c", "main.cfg", "-c", "seq.cfg"] + extra + ["--PrintConfig"], tmp_path)
+        assert r.returncode == 2 and needle in " ".join(json.loads(r.stdout)["errors"])
+    r = run(app, ["-c", "missing.cfg"], tmp_path)
+    assert r.returncode == 2 and "cannot open configuration file" in r.stderr
+
+
+def test_without_a_gpu_the_encode_fails_loudly(app, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    write_cfgs(tmp_path)
+    np.zeros(192 * 128 * 3 // 2 * 2, np.uint8).tofile(tmp_path / "in_192x128.yuv")
+    r = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-o", "rec.yuv"], tmp_path)
+    assert r.returncode == 3 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_encode_matches_the_api(app, tmp_path):
+    import sys
+    import hevcdl_amd
+    import hevcdl_amd.metrics as metrics
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_tools
+    write_cfgs(tmp_path)
+    w, h, nf, skip, qp = 192, 128, 2, 1, 32
+    yuv = ref_tools.synth_yuv(w, h, nf + skip, seed=31)
+    yuv.tofile(tmp_path / "in_192x128.yuv")
+    labels = ref_tools.make_labels(w, h, nf, "rand", 32)
+    for f in range(nf):                                        # the reference's label files: pred/<frame>/ctu<addr>.txt
+        os.makedirs(tmp_path / "pred" / str(f))
+        for a in range(labels.shape[1]):
+            (tmp_path / "pred" / str(f) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in labels[f, a]))
+    os.makedirs(tmp_path / "rec")
+    r = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-fs", str(skip), "--LabelDir=pred", "--RecordFile=records.bin", "--BatchFrames=1"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    recs, recon, stats = e.compress_frames(yuv[skip:], labels)
+    e.close()
+    assert np.array_equal(np.fromfile(tmp_path / "rec" / "rec.yuv", np.uint8), recon.reshape(-1))
+    assert np.fromfile(tmp_path / "records.bin", np.uint8).tobytes() == recs.tobytes()
+    lines = [l for l in r.stdout.splitlines() if l.startswith("POC")]
+    s = metrics.Summary(w, h, 30)
+    for f in range(nf):
+        p = s.add(int(stats["est_bits"][f]), stats["sse"][f])
+        assert lines[f].rsplit(" [ET", 1)[0] == metrics.frame_line(f, qp, int(stats["est_bits"][f]), p).rsplit(" [ET", 1)[0]
+    assert s.text().splitlines()[1].rstrip() in [l.rstrip() for l in r.stdout.splitlines()]
+    # CNN labels when no label directory is given
+    r2 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-o", "rec_cnn.yuv"], tmp_path)
+    assert r2.returncode == 0 and "on-device CNN" in r2.stdout and os.path.getsize(tmp_path / "rec_cnn.yuv") == w * h * 3 // 2 * nf
