@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
-SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "hevcdl_api.hip"]
+SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "deblock_kernel.hip", "hevcdl_api.hip"]
 
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
 
@@ -112,6 +112,8 @@ def load_library():
     lib.hevcdl_predict_depth.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_predict_depth_rgb.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_compress_frames.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.hevcdl_deblock_frames.argtypes = [vp, vp, ci, vp, vp]
+    lib.hevcdl_deblock_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp]
     lib.hevcdl_begin_frames.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_compress_ctu.argtypes = [vp, ci, ci, vp, vp, vp]
     lib.hevcdl_get_recon.argtypes = [vp, ci, vp]
@@ -130,7 +132,7 @@ def load_library():
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
-           "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon"]
+           "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev"]
 
 
 def load_weights(path=WEIGHTS_PATH):
@@ -208,6 +210,18 @@ class Encoder:
             lab_ptr = labels.ctypes.data
         self._check(self.lib.hevcdl_compress_frames(self._h, yuv.ctypes.data, n, lab_ptr, recs.ctypes.data, recon.ctypes.data, stats.ctypes.data))
         return recs, recon, stats
+
+    # ---- deblocking filter (TComLoopFilter::loopFilterPic) ----
+    def deblock_frames(self, recon, records):
+        """recon [n, frame_bytes] (before the in-loop filters) + records [n, ctus] -> deblocked pictures."""
+        recon, n = self._frames(recon)
+        records = np.ascontiguousarray(records).reshape(n, self.ctus)
+        out = np.zeros_like(recon)
+        self._check(self.lib.hevcdl_deblock_frames(self._h, recon.ctypes.data, n, records.ctypes.data, out.ctypes.data))
+        return out
+
+    def deblock_frames_dev(self, d_recon, n, d_records, d_out, stream=None):
+        self._check(self.lib.hevcdl_deblock_frames_dev(self._h, d_recon, n, d_records, d_out, stream))
 
     # ---- per-CTU session: compressCtu + encodeCtu of the reference, one CTU per call (TEncSlice.cpp:879,893) ----
     def begin_frames(self, yuv, labels=None):

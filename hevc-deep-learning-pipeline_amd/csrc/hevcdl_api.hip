@@ -307,6 +307,40 @@ extern "C" hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *
   return HEVCDL_OK;
 }
 
+// ---- deblocking (row f-2, first half): TComLoopFilter::loopFilterPic, TComLoopFilter.cpp:130, called at TEncGOP.cpp:1742 ----
+static const unsigned char DBK_TC[54] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,5,5,6,6,7,8,9,10,11,13,14,16,18,20,22,24 };   // :59-62
+static const unsigned char DBK_BETA[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,6,7,8,9,10,11,12,13,14,15,16,17,18,20,22,24,26,28,30,32,34,36,38,40,42,44,46,48,50,52,54,56,58,60,62,64 };   // :64-67
+
+extern "C" hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *d_recon, int n_frames, const void *d_records, void *d_out, void *stream)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!d_recon || !d_records || !d_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  hevcdl_dbk_params p;
+  p.in = (const uint8_t *)d_recon; p.out = (uint8_t *)d_out; p.records = (const unsigned char *)d_records;
+  p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames;
+  const int qp = ctx->cfg.qp, qpc = CHROMA_SCALE_420[qp < 0 ? 0 : (qp > 57 ? 57 : qp)];      // TComLoopFilter.cpp:782-797, cQpOffset 0
+  p.tc = DBK_TC[qp + 2 > 53 ? 53 : qp + 2]; p.beta = DBK_BETA[qp]; p.tc_c = DBK_TC[qpc + 2 > 53 ? 53 : qpc + 2];
+  hevcdl_launch_deblock(&p, stream);
+  HIPCHK(hipGetLastError());
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *recon, int n_frames, const hevcdl_ctu_record *records, uint8_t *out)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!recon || !records || !out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  st = ensure_staging(ctx); if (st) return st;
+  HIPCHK(hipMemcpy(ctx->d_recon, recon, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_records, records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames, hipMemcpyHostToDevice));
+  st = hevcdl_deblock_frames_dev(ctx, ctx->d_recon, n_frames, ctx->d_records, ctx->d_yuv, nullptr); if (st) return st;   // d_yuv: free staging plane set
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "deblock kernels", e);
+  HIPCHK(hipMemcpy(out, ctx->d_yuv, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
 // ---- per-CTU session: the semantic drop-in for TEncCu::compressCtu + encodeCtu (TEncSlice.cpp:879,893) ----------------
 extern "C" hevcdl_status hevcdl_begin_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt, uint8_t *labels_out_opt)
 {

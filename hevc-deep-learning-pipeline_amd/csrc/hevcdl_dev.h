@@ -51,9 +51,19 @@ struct hevcdl_rd_params {
   hevcdl_rd_consts k;
 };
 
+// deblocking passes (deblock_kernel.hip); tc / beta / chroma tc looked up on the host (TComLoopFilter.cpp:59-67, Bs 2, offsets 0)
+struct hevcdl_dbk_params {
+  const uint8_t *in;               // [frame] planar 4:2:0 reconstruction before the in-loop filters
+  uint8_t *out;                    // [frame] deblocked picture (may alias in)
+  const unsigned char *records;    // [frame][ctu] hevcdl_ctu_record (depth, trIdx give the TU grid)
+  int width, height, ctus_x, ctus_per_frame, n_frames;
+  int tc, beta, tc_c;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+void hevcdl_launch_deblock(const struct hevcdl_dbk_params *p, void *stream);
 size_t hevcdl_cnn_smem_bytes(void);
 size_t hevcdl_rd_smem_bytes(void);
 size_t hevcdl_rd_scratch_bytes(void);

@@ -116,6 +116,13 @@ hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t *ctu_rgb, 
 hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,
                                      hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt);
 
+/* ---- deblocking filter (first in-loop filter of the reference) -------------------------------------
+ * Replaces TComLoopFilter::loopFilterPic(TComPic*) (TLibCommon/TComLoopFilter.cpp:130, called at TEncGOP.cpp:1742) for
+ * the pictures this library decides: recon = what hevcdl_compress_frames returned, records = its CTU records (the
+ * TU grid), out = the picture the reference hands to SAO (may alias recon in the device variant). */
+hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *recon, int n_frames, const hevcdl_ctu_record *records, uint8_t *out);
+hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *d_recon, int n_frames, const void *d_records, void *d_out, void *stream);
+
 /* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------
  *   TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)   TEncCu.h:120, called at TEncSlice.cpp:879
  *   TEncCu::encodeCtu(TComDataCU* pCtu)                   TEncCu.h:123, called at TEncSlice.cpp:893

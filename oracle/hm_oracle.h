@@ -37,6 +37,9 @@ int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_fra
                             const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
                             hm_frame_stats *stats);
 
+/* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
+int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);
+
 /* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */
 void hm_oracle_set_trace(const char *path);
 

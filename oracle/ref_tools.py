@@ -195,6 +195,20 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None):
     return recs, recon, stats
 
 
+def run_deblock(recon, width, height, qp, recs):
+    """Oracle deblocking of pre-filter reconstructions [frames][w*h*3/2] given the records [frames][ctus] -> filtered copy."""
+    lib = oracle_lib()
+    lib.hm_oracle_deblock_frame.restype = ctypes.c_int
+    lib.hm_oracle_deblock_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    out = np.ascontiguousarray(recon, np.uint8).copy().reshape(recs.shape[0], -1)
+    recs = np.ascontiguousarray(recs)
+    for f in range(out.shape[0]):
+        rc = lib.hm_oracle_deblock_frame(out[f].ctypes.data, width, height, qp, recs[f].ctypes.data)
+        if rc != 0:
+            raise RuntimeError("oracle deblock failed rc=%d" % rc)
+    return out
+
+
 def ctu_recon_from_frame(recon_frame, width, height, addr):
     """Cut the 64x64 / 32x32 / 32x32 CTU blocks (zeros outside the picture) out of one planar frame."""
     cx = (width + 63) // 64
