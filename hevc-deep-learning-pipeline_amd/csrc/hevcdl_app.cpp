@@ -36,7 +36,7 @@ const Key KEYS[] = {
   { "QP", "q", USED, 0 },
   // extensions of this front end
   { "LabelDir", 0, USED, 0 }, { "BatchFrames", 0, USED, 0 }, { "Device", 0, USED, 0 }, { "Weights", 0, USED, 0 }, { "RecordFile", 0, USED, 0 },
-  { "CnnInput", 0, USED, 0 }, { "PrintConfig", 0, USED, 0 },
+  { "CnnInput", 0, USED, 0 }, { "PrintConfig", 0, USED, 0 }, { "LoopFilterDisable", 0, USED, 0 },
   // keys that define the path: only the implemented value is accepted
   { "InputBitDepth", 0, PATH, "8" }, { "InternalBitDepth", 0, PATH, "8" }, { "InputChromaFormat", 0, PATH, "420" }, { "Profile", 0, PATH, "main" },
   { "MaxCUWidth", 0, PATH, "64" }, { "MaxCUHeight", 0, PATH, "64" }, { "MaxPartitionDepth", 0, PATH, "4" },
@@ -48,7 +48,7 @@ const Key KEYS[] = {
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stages that are not built: accepted, reported once
   { "Level", 0, STAGE, 0 }, { "DecodingRefreshType", 0, STAGE, 0 }, { "ReWriteParamSetsFlag", 0, STAGE, 0 }, { "LoopFilterOffsetInPPS", 0, STAGE, 0 },
-  { "LoopFilterDisable", 0, STAGE, 0 }, { "LoopFilterBetaOffset_div2", 0, STAGE, 0 }, { "LoopFilterTcOffset_div2", 0, STAGE, 0 },
+  { "LoopFilterBetaOffset_div2", 0, STAGE, 0 }, { "LoopFilterTcOffset_div2", 0, STAGE, 0 },
   { "DeblockingFilterMetric", 0, STAGE, 0 }, { "SAO", 0, STAGE, 0 }, { "SAOLcuBoundary", 0, STAGE, 0 }, { "LFCrossSliceBoundaryFlag", 0, STAGE, 0 },
   { "LFCrossTileBoundaryFlag", 0, STAGE, 0 }, { "SEIDecodedPictureHash", 0, STAGE, 0 },
   // no effect on an all-intra slice with the settings above
@@ -145,6 +145,7 @@ int main(int argc, char **argv)
   const double fps = atof(opt.get("FrameRate", "30").c_str());
   const std::string input = native_path(opt.get("InputFile")), recon_path = native_path(opt.get("ReconFile")), label_dir = native_path(opt.get("LabelDir"));
   const std::string cnn_input = opt.get("CnnInput", "rgb601");
+  const bool deblock = opt.geti("LoopFilterDisable", 0) == 0;
   if (opt.v.count("PrintConfig")) {
     printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
            "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
@@ -190,7 +191,7 @@ int main(int argc, char **argv)
   printf("HEVC-DL MI355X path: %dx%d  QP %d  frames %ld (skip %ld)  batch %d  labels: %s\n", width, height, qp, n_frames, frame_skip, batch,
          label_dir.empty() ? (cnn_input == "luma" ? "on-device CNN (luma input)" : "on-device CNN (BT.601 RGB input)") : ("files under " + label_dir).c_str());
   if (!stage_keys.empty()) {
-    printf("Accepted, but their stages are not part of this path (no bitstream is written, reconstruction and PSNR are before the in-loop filters):");
+    printf("Accepted, but their stages are not part of this path (no bitstream is written; reconstruction and PSNR are %s, without SAO):", deblock ? "after deblocking" : "before the in-loop filters");
     for (const auto &k : stage_keys) printf(" %s", k.c_str());
     printf("\n");
   }
@@ -223,6 +224,15 @@ int main(int argc, char **argv)
     const auto t0 = std::chrono::steady_clock::now();
     st = hevcdl_compress_frames(ctx, yuv.data(), nb, lab, recs.data(), recon.data(), stats.data());
     const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / nb;
+    if (st == HEVCDL_OK && deblock) { // TComLoopFilter::loopFilterPic (TEncGOP.cpp:1742); the picture statistics follow the filtered picture
+      st = hevcdl_deblock_frames(ctx, recon.data(), nb, recs.data(), recon.data());
+      for (int i = 0; i < nb && st == HEVCDL_OK; i++) {
+        const uint8_t *o = yuv.data() + frame_bytes * i, *r = recon.data() + frame_bytes * i;
+        const size_t n[3] = { (size_t)width * height, (size_t)width * height / 4, (size_t)width * height / 4 };
+        size_t off = 0;
+        for (int c = 0; c < 3; c++) { unsigned long long sse = 0; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o[off + k] - (int)r[off + k]; sse += (unsigned long long)(d * d); } stats[i].sse[c] = sse; off += n[c]; }
+      }
+    }
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
     for (int i = 0; i < nb; i++) {
       const double p[3] = { psnr_of(stats[i].sse[0], ny), psnr_of(stats[i].sse[1], nc), psnr_of(stats[i].sse[2], nc) };
@@ -237,7 +247,7 @@ int main(int argc, char **argv)
   }
   if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
     const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
-    printf("\n\nSUMMARY (bits: CABAC estimate of the decisions; PSNR before the in-loop filters) ------------------------\n");
+    printf("\n\nSUMMARY (bits: CABAC estimate of the decisions; PSNR without SAO) -----------------------------------------\n");
     printf("\tTotal Frames |   Bitrate     Y-PSNR    U-PSNR    V-PSNR    YUV-PSNR  \n");
     printf("\t %8ld    %c %12.4lf  %8.4lf  %8.4lf  %8.4lf  %8.4lf  \n", done, 'a', sum_bits * (fps / 1000.0 / done), sum_psnr[0] / done, sum_psnr[1] / done,
            sum_psnr[2] / done, mse_yuv == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 / mse_yuv));

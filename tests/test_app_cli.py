@@ -62,7 +62,7 @@ def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
     c = json.loads(r.stdout)
     assert c["InputFile"] == "./in_192x128.yuv" and c["ReconFile"] == "./rec/rec.yuv"       # Windows paths of the reference cfgs
     assert (c["SourceWidth"], c["SourceHeight"], c["QP"], c["FramesToBeEncoded"], c["LabelDir"]) == (192, 128, 32, 1, "pred")
-    assert set(c["stage_keys"]) == {"BitstreamFile", "Level", "SAO", "LoopFilterDisable"} and c["errors"] == []
+    assert set(c["stage_keys"]) == {"BitstreamFile", "Level", "SAO"} and c["errors"] == []
 
 
 def test_keys_that_change_the_path_are_rejected(app, tmp_path):
@@ -106,15 +106,20 @@ def test_cli_encode_matches_the_api(app, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
     recs, recon, stats = e.compress_frames(yuv[skip:], labels)
+    dbk = e.deblock_frames(recon, recs)
     e.close()
-    assert np.array_equal(np.fromfile(tmp_path / "rec" / "rec.yuv", np.uint8), recon.reshape(-1))
+    assert np.array_equal(np.fromfile(tmp_path / "rec" / "rec.yuv", np.uint8), dbk.reshape(-1))    # LoopFilterDisable : 0 in the cfg
     assert np.fromfile(tmp_path / "records.bin", np.uint8).tobytes() == recs.tobytes()
     lines = [l for l in r.stdout.splitlines() if l.startswith("POC")]
     s = metrics.Summary(w, h, 30)
+    ysz = w * h
     for f in range(nf):
-        p = s.add(int(stats["est_bits"][f]), stats["sse"][f])
+        d = (yuv[skip + f].astype(np.int64) - dbk[f].astype(np.int64)) ** 2
+        p = s.add(int(stats["est_bits"][f]), (d[:ysz].sum(), d[ysz:ysz + ysz // 4].sum(), d[ysz + ysz // 4:].sum()))
         assert lines[f].rsplit(" [ET", 1)[0] == metrics.frame_line(f, qp, int(stats["est_bits"][f]), p).rsplit(" [ET", 1)[0]
     assert s.text().splitlines()[1].rstrip() in [l.rstrip() for l in r.stdout.splitlines()]
+    r3 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-fs", str(skip), "--LabelDir=pred", "--LoopFilterDisable=1", "-o", "rec_nofilter.yuv"], tmp_path)
+    assert r3.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "rec_nofilter.yuv", np.uint8), recon.reshape(-1))
     # CNN labels when no label directory is given
     r2 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-o", "rec_cnn.yuv"], tmp_path)
     assert r2.returncode == 0 and "on-device CNN" in r2.stdout and os.path.getsize(tmp_path / "rec_cnn.yuv") == w * h * 3 // 2 * nf
