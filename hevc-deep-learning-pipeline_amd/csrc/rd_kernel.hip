@@ -144,11 +144,12 @@ struct RdSmem {
   unsigned long long est_bits, sse_acc[3];
   uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
-  unsigned long long prof[24]; unsigned int prof_n[24];
+  unsigned long long prof[40]; unsigned int prof_n[40];
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   union {
     double chain[5][17];              // RDOQ per-position addends of the five ordered sums (rows padded)
+    double zb[2][64];                 // RDOQ, run of all-zero groups: zero-level costs / significance costs of 4 groups
     struct { double rmd_cost[36]; unsigned int satd[36]; };   // rough mode decision (never live during RDOQ)
   };
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
@@ -170,9 +171,13 @@ DEV void wsync()
 }
 #ifdef HEVCDL_KERNEL_PROF
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_MARK0() unsigned long long prof_m_ = __builtin_readcyclecounter()
+#define PROF_MARK(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); lds().prof[id] += n_ - prof_m_; lds().prof_n[id]++; prof_m_ = n_; } else prof_m_ = 0; } while (0)
 #define PROF_ADD(k, id) do { if (lane_id() == 0) { lds().prof[id] += __builtin_readcyclecounter() - prof_t0_; lds().prof_n[id]++; } } while (0)
 #else
 #define PROF_T0() do { } while (0)
+#define PROF_MARK0() do { } while (0)
+#define PROF_MARK(id) do { } while (0)
 #define PROF_ADD(k, id) do { } while (0)
 #endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -732,6 +737,52 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
   int ctx_set = ctx_set_index(ch, cg_last, 0), c1 = 1, c2 = 0, go_rice = 0; uint32_t c1idx = 0, c2idx = 0;
   // ---- phase B ----
   for (int cgpos = cg_last; cgpos >= 0; cgpos--) {
+    if (cgpos != cg_last && cgpos >= 1) {
+      // Run of up to 4 groups (cgpos, cgpos-1, ...) without a nonzero rounded level: their levels stay zero, the state
+      // machine is not touched, and nothing per position is read again (phase C and sign hiding skip groups without
+      // levels) -- only the ordered sums and the group's sig-flag cost matter (TComTrQuant.cpp:2385-2412).  Lane group
+      // g = lane >> 4 owns group cgpos - g; block_uncoded runs on lane 0, base_cost on lane 1, the group's
+      // significance-cost sum on lane 2 + g, all in scan order.
+      const int g = lane >> 4, jj = lane & 15, cg_g = cgpos - g;
+      const bool gvalid = cg_g >= 1;
+      const int sp_b = (gvalid ? cg_g : 1) * 16 + jj, blk_b = scan[sp_b];
+      const unsigned long long nzb = __ballot(!gvalid || dst[blk_b] > 0);
+      int run = 0;
+      while (run < 4 && ((nzb >> (16 * run)) & 0xffffull) == 0) run++;
+      RDOQ_MARK(34);
+      if (run > 0) {
+        const bool act = g < run;
+        const int cgblk_b = scan_cg[gvalid ? cg_g : 1], gy_b = cgblk_b / cp.wg, gx_b = cgblk_b - gy_b * cp.wg;
+        const int32_t ld_b = level_double(blk_b);
+        const double c0_b = (double)ld_b * (double)ld_b * err_scale;
+        const int sigctx_b = sig_off + sig_ctx_inc(cp, scan, pattern_sig_ctx(cgf, gx_b, gy_b, cp.wg), sp_b);
+        const double cs0_b = lambda * (double)ctx_bits(cab, sigctx_b, 0);
+        const double r0_b = lambda * (double)ctx_bits(cab, cg_off + sig_cg_ctx(cgf, gx_b, gy_b, cp.wg), 0);
+        s.zb[0][lane] = act ? c0_b : 0.0; s.zb[1][lane] = act ? cs0_b : 0.0;
+        wsync();
+        double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
+        for (int gg = 0; gg < run; gg++) {
+          const bool on = lane < 2 || lane == 2 + gg;
+          double v0[16], v1[16];
+#pragma unroll
+          for (int t = 0; t < 16; t++) { v0[t] = s.zb[0][gg * 16 + 15 - t]; v1[t] = s.zb[1][gg * 16 + 15 - t]; }
+#pragma unroll
+          for (int t = 0; t < 16; t++) {
+            const double add = lane == 0 ? v0[t] : (lane == 1 ? v0[t] + v1[t] : v1[t]);      // c0 | c0 + cs0 | cs0
+            acc += on ? add : 0.0;
+          }
+          const double r0 = rl_d(r0_b, 16 * gg), adj = r0 - rl_d(acc, 2 + gg);                  // base_cost += r0 - sig_cost of the group
+          acc += (lane == 1) ? adj : 0.0;
+          if (lane == 0) cost_cg_sig[cgpos - gg] = r0;
+        }
+        block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1);
+        cgpos -= run - 1;
+        ctx_set = ctx_set_index(ch, cgpos - 1, 0);                  // the group before the next one had no level > 1
+        wsync();
+        RDOQ_MARK(35);
+        continue;
+      }
+    }
     const int cgblk = uni(scan_cg[cgpos]), gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
     const int pat = uni(pattern_sig_ctx(cgf, gx, gy, cp.wg));
     const int start_pin = (cgpos == cg_last) ? (last_pos & 15) : 15;
@@ -755,6 +806,9 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
     // Only positions whose rounded level is nonzero touch the c1/c2/Rice state (TComTrQuant.cpp:2300-2380): walk those,
     // highest scan position first.  c1 is 1 at the start of every group; zero positions below a visited one see its c1.
     unsigned nzmask = (unsigned)(__ballot(valid_j && ma_j > 0) & 0xffffull);
+#ifdef HEVCDL_KERNEL_PROF
+    if (lane == 0) { s.prof_n[31]++; if (!nzmask) { s.prof_n[32]++; if (s.prof[33]) s.prof_n[33]++; } s.prof[33] = !nzmask && cgpos != cg_last; }
+#endif
     while (nzmask) {
       const int pin = 31 - __clz((int)nzmask);
       nzmask &= ~(1u << pin);
@@ -765,6 +819,7 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
       const int is_last = (sp == last_pos);
       double cost_c, cost_s = 0;
       uint32_t level;
+      int r_hi = 0, r_lo = 0;
       { // xGetCodedLevel TComTrQuant.cpp:2812-2879
         double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0;
         if (!is_last && max_abs < 3) { cost_s = rl_d(cs0_j, pin); best = c0 + cost_s; }
@@ -772,17 +827,20 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
         const uint32_t min_abs = max_abs > 1 ? (uint32_t)max_abs - 1 : 1;
         for (int al = max_abs; al >= (int)min_abs; al--) {
           const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
-          double cur = err * err * err_scale + lambda * (double)ic_rate_r(rtab, (uint32_t)al, c1, go_rice, c1idx, c2idx);
+          const int rate = ic_rate_r(rtab, (uint32_t)al, c1, go_rice, c1idx, c2idx);
+          if (al == max_abs) r_hi = rate; else r_lo = rate;
+          double cur = err * err * err_scale + lambda * (double)rate;
           cur += cur_sig;
           if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_s = cur_sig; }
         }
         cost_c = best; level = best_lvl;
       }
       int rup, rdn = 0;
-      if (level > 0) {
-        const int now = ic_rate_r(rtab, level, c1, go_rice, c1idx, c2idx);
-        rup = ic_rate_r(rtab, level + 1, c1, go_rice, c1idx, c2idx) - now;
-        rdn = ic_rate_r(rtab, level - 1, c1, go_rice, c1idx, c2idx) - now;
+      if (level > 0) { // rate deltas of level +-1 for sign hiding; the candidates' rates are reused (level is max_abs or max_abs - 1)
+        const bool top = (int)level == max_abs;
+        const int now = top ? r_hi : r_lo;
+        rup = (top ? ic_rate_r(rtab, level + 1, c1, go_rice, c1idx, c2idx) : r_hi) - now;
+        rdn = (level == 1 ? 0 : (top ? r_lo : ic_rate_r(rtab, level - 1, c1, go_rice, c1idx, c2idx))) - now;
       } else rup = __builtin_amdgcn_readlane(rtab, 2 * c1);
       if (lane == pin) { lvl_j = (int)level; cc_j = cost_c; cs_j = cost_s; ru_j = rup; rd_j = rdn; c1_j = -1; }
       const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
@@ -872,13 +930,16 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
       int off, shift; last_ctx_params(ch, n, off, shift);
       const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
       const int ng = s.t_group_idx[n - 1];
-      if (lane == 0) {
-        int accx = 0, accy = 0, kk;
-        for (kk = 0; kk < ng; kk++) {
-          last_x_bits[kk] = accx + ctx_bits(cab, bx + off + (kk >> shift), 0); accx += ctx_bits(cab, bx + off + (kk >> shift), 1);
-          last_y_bits[kk] = accy + ctx_bits(cab, by + off + (kk >> shift), 0); accy += ctx_bits(cab, by + off + (kk >> shift), 1);
-        }
-        last_x_bits[kk] = accx; last_y_bits[kk] = accy;
+      { // lanes 0..15: X, lanes 16..31: Y; entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar
+        const int kk = lane & 15, isy = (lane >> 4) & 1;
+        const int cx_ = (isy ? by : bx) + off + (kk >> shift);
+        const int b1 = (kk < ng) ? ctx_bits(cab, cx_, 1) : 0, b0 = (kk < ng) ? ctx_bits(cab, cx_, 0) : 0;
+        int inc = b1;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        if (lane < 32 && kk <= ng) s.last_bits[isy][kk] = inc - b1 + b0;
       }
       wsync();
     }
@@ -1197,9 +1258,11 @@ DEV void load_tu_coef(KR k, int real, int comp, int log2_luma, int zabs_comp, in
   const int off = comp ? (zabs_comp * 16) >> 2 : zabs_comp * 16;
   GLB const int16_t *src = real ? (GLB const int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + comp_off(comp) + off
                             : k.coef_l + (5 - log2_luma) * 6144 + comp_off(comp) + off;
+  PROF_T0();
   wsync();
   for (int i = lane_id(); i < n * n; i += 64) lds().lvl[i] = src[i];
   wsync();
+  PROF_ADD(k, 30);
 }
 // bit-count one coded TU block (cbf already known to be set)
 DEV void code_tu_coeffs(KR k, LCabac *c, const Cu &cu, const Tu &tu, int comp, int real)
@@ -1306,6 +1369,7 @@ DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
 {
   PROF_T0();
+  PROF_MARK0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_);
   LSmem &s = lds();
   const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
@@ -1321,15 +1385,19 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
     if (mode012 == 1 && lane_id() < 16) s.ts_pred[comp][lane_id()] = s.pred[lane_id()];
   } else { wsync(); if (lane_id() < 16) s.pred[lane_id()] = s.ts_pred[comp][lane_id()]; }
   wsync();
+  PROF_MARK(24);
   GLB const uint8_t *org = k.org[comp] + (size_t)y * ps + x;
   for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
   wsync();
+  PROF_MARK(25);
   if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int16_t)((int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5); wsync(); }   // n == 4: one pass, every lane reads before any writes
   else fwd_transform(k, n, !comp && n == 4);
+  PROF_MARK(26);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
   { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
   wsync();
+  PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
   set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
   GLB int16_t *cl = k.coef_l + (5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
@@ -1342,6 +1410,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
     for (int i = lane_id(); i < n * n; i += 64) { cl[i] = 0; s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = 0; }
     wsync();
   }
+  PROF_MARK(28);
   GLB uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
   GLB uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
   uint32_t d = 0;
@@ -1355,6 +1424,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   d = (uint32_t)wave_sum_i((int)d);
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
   wsync();
+  PROF_MARK(29);
   PROF_ADD(k, 9);
   return d;
 }
@@ -2028,7 +2098,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   }
   if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
 #ifdef HEVCDL_KERNEL_PROF
-  if (lane < 24) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
+  if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   wsync();
@@ -2087,10 +2157,10 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   }
 #ifdef HEVCDL_KERNEL_PROF
   wsync();
-  if (frame == 0 && p.dbgbuf && lane < 24) {
+  if (frame == 0 && p.dbgbuf && lane < 40) {
     if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
     p.dbgbuf[1 + 2 * lane] = (unsigned int)(s.prof[lane] >> 10); p.dbgbuf[2 + 2 * lane] = s.prof_n[lane];
-    if (lane == 0) p.dbgbuf[0] = 24;
+    if (lane == 0) p.dbgbuf[0] = 40;
   }
 #endif
   if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits

@@ -1,5 +1,5 @@
 import sys, os, subprocess
-names=["build_refs","filter_refs","rmd_satd","predict_block","rdoq:cg-prologue","rdoq:cg-walk","rdoq","dequant","rdoq:cg-epilogue","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh"]
+names=["build_refs","filter_refs","rmd_satd","predict_block","rdoq:cg-prologue","rdoq:cg-walk","rdoq","dequant","rdoq:cg-epilogue","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh","-","tu:refs+pred","tu:org+residual","tu:fwd","tu:rdoq(mark)","tu:store+dequant+inv","tu:recon+sse","load_tu_coef","n:CGs","n:allzeroCGs","n:allzero-after-allzero","rdoq:lookahead","rdoq:zero-run batch"]
 code="""
 import sys
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
@@ -11,6 +11,6 @@ enc=hevcdl_amd.Encoder(W,H,32,max_frames=1); lab=enc.predict_depth(yuv); enc.com
 out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_DBGBUF='1',HEVCDL_LIB='/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so'),capture_output=True,text=True)
 rows=[l.split()[1:] for l in out.stdout.splitlines() if l.startswith('DBGV')]
 tot=int(rows[14][0]) if len(rows)>14 else 1
-for i,r in enumerate(rows[:23]):
+for i,r in enumerate(rows[:len(names)]):
     print("%-24s kcycles %10d  calls %8d  %5.1f%%  cyc/call %d"%(names[i],int(r[0]),int(r[1]),100.0*int(r[0])/tot, 1024*int(r[0])//max(1,int(r[1]))))
 print(out.stderr[-500:])
