@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
-SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "deblock_kernel.hip", "hevcdl_api.hip"]
+SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "deblock_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
 
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
 
@@ -50,6 +50,11 @@ class Config(ctypes.Structure):
                 ("lambda_", ctypes.c_double), ("sqrt_lambda", ctypes.c_double), ("chroma_weight", ctypes.c_double),
                 ("lambda_chroma", ctypes.c_double), ("err_scale", (ctypes.c_double * 4) * 2),
                 ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class StreamConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("qp", ctypes.c_int32),
+                ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -112,6 +117,10 @@ def load_library():
     lib.hevcdl_predict_depth.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_predict_depth_rgb.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_compress_frames.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.hevcdl_stream_config_default.argtypes = [ctypes.POINTER(StreamConfig), ci, ci, ci]
+    lib.hevcdl_access_unit_bound.argtypes = [ci, ci]
+    lib.hevcdl_access_unit_bound.restype = ctypes.c_size_t
+    lib.hevcdl_write_access_unit.argtypes = [ctypes.POINTER(StreamConfig), ci, vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     lib.hevcdl_deblock_frames.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_deblock_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp]
     lib.hevcdl_begin_frames.argtypes = [vp, vp, ci, vp, vp]
@@ -132,7 +141,8 @@ def load_library():
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
-           "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev"]
+           "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
+           "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit"]
 
 
 def load_weights(path=WEIGHTS_PATH):
@@ -150,6 +160,24 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0):
         raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
     cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
     return cfg
+
+
+def write_access_unit(width, height, qp, poc, records, level_idc=186):
+    """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
+    lib = load_library()
+    cfg = StreamConfig()
+    st = lib.hevcdl_stream_config_default(ctypes.byref(cfg), width, height, qp)
+    if st != 0:
+        raise HevcdlError(st, "stream config")
+    cfg.level_idc = level_idc
+    records = np.ascontiguousarray(records)
+    cap = lib.hevcdl_access_unit_bound(width, height)
+    buf = np.zeros(cap, np.uint8)
+    n = ctypes.c_size_t(0)
+    st = lib.hevcdl_write_access_unit(ctypes.byref(cfg), int(poc), records.ctypes.data, buf.ctypes.data, cap, ctypes.byref(n))
+    if st != 0:
+        raise HevcdlError(st, "write_access_unit")
+    return buf[:n.value].tobytes()
 
 
 class Encoder:

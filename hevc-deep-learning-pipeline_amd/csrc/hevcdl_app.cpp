@@ -7,8 +7,8 @@
 //   planar YUV reader            HM_dl/source/Lib/TLibVideoIO/TVideoIOYuv.cpp:249,675 (8-bit 4:2:0 file, FrameSkip)
 //   picture log line / summary   TEncGOP.cpp:2500-2541, TEncAnalyze.h:163-370
 // and drives the GPU path through the C ABI of include/hevcdl.h only.  Keys that would change the path are checked
-// against what the path implements (rejected, not ignored); keys of stages that are not built (entropy coder / NAL
-// writer, in-loop filters) are accepted and listed.  Labels come from the on-device CNN, or -- the reference's own
+// against what the path implements (rejected, not ignored); keys of the one stage that is not built (SAO) are
+// accepted and listed: the bitstream (-b) signals SAO off.  Labels come from the on-device CNN, or -- the reference's own
 // file IPC format -- from --LabelDir <dir>/<frame>/ctu<addr>.txt (16 integers, TEncCu.cpp:255-262).
 #include <algorithm>
 #include <chrono>
@@ -31,7 +31,7 @@ struct Key { const char *name; const char *shortopt; Kind kind; const char *requ
 
 const Key KEYS[] = {
   // used by this front end
-  { "InputFile", "i", USED, 0 }, { "BitstreamFile", "b", STAGE, 0 }, { "ReconFile", "o", USED, 0 }, { "SourceWidth", "wdt", USED, 0 },
+  { "InputFile", "i", USED, 0 }, { "BitstreamFile", "b", USED, 0 }, { "ReconFile", "o", USED, 0 }, { "SourceWidth", "wdt", USED, 0 },
   { "SourceHeight", "hgt", USED, 0 }, { "FrameRate", "fr", USED, 0 }, { "FrameSkip", "fs", USED, 0 }, { "FramesToBeEncoded", "f", USED, 0 },
   { "QP", "q", USED, 0 },
   // extensions of this front end
@@ -47,10 +47,10 @@ const Key KEYS[] = {
   { "NumTileRowsMinus1", 0, PATH, "0" }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stages that are not built: accepted, reported once
-  { "Level", 0, STAGE, 0 }, { "DecodingRefreshType", 0, STAGE, 0 }, { "ReWriteParamSetsFlag", 0, STAGE, 0 }, { "LoopFilterOffsetInPPS", 0, STAGE, 0 },
-  { "LoopFilterBetaOffset_div2", 0, STAGE, 0 }, { "LoopFilterTcOffset_div2", 0, STAGE, 0 },
-  { "DeblockingFilterMetric", 0, STAGE, 0 }, { "SAO", 0, STAGE, 0 }, { "SAOLcuBoundary", 0, STAGE, 0 }, { "LFCrossSliceBoundaryFlag", 0, STAGE, 0 },
-  { "LFCrossTileBoundaryFlag", 0, STAGE, 0 }, { "SEIDecodedPictureHash", 0, STAGE, 0 },
+  { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, PATH, "1" }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
+  { "LoopFilterBetaOffset_div2", 0, PATH, "0" }, { "LoopFilterTcOffset_div2", 0, PATH, "0" },
+  { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, STAGE, 0 }, { "SAOLcuBoundary", 0, STAGE, 0 }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
+  { "LFCrossTileBoundaryFlag", 0, NOEFFECT, 0 }, { "SEIDecodedPictureHash", 0, PATH, "0" },
   // no effect on an all-intra slice with the settings above
   { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
   { "FEN", 0, NOEFFECT, 0 }, { "FDM", 0, NOEFFECT, 0 }, { "AMP", 0, NOEFFECT, 0 }, { "MaxCuDQPDepth", 0, NOEFFECT, 0 }, { "SliceArgument", 0, NOEFFECT, 0 },
@@ -145,11 +145,13 @@ int main(int argc, char **argv)
   const double fps = atof(opt.get("FrameRate", "30").c_str());
   const std::string input = native_path(opt.get("InputFile")), recon_path = native_path(opt.get("ReconFile")), label_dir = native_path(opt.get("LabelDir"));
   const std::string cnn_input = opt.get("CnnInput", "rgb601");
+  const std::string bitstream_path = native_path(opt.get("BitstreamFile"));
+  const int level_idc = (int)(atof(opt.get("Level", "6.2").c_str()) * 30.0 + 0.5);      // general_level_idc
   const bool deblock = opt.geti("LoopFilterDisable", 0) == 0;
   if (opt.v.count("PrintConfig")) {
     printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
-           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
-           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str());
+           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"BitstreamFile\": \"%s\", \"level_idc\": %d, \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
+           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str(), json_escape(bitstream_path).c_str(), level_idc);
     for (size_t i = 0; i < stage_keys.size(); i++) printf("%s\"%s\"", i ? ", " : "", stage_keys[i].c_str());
     printf("], \"errors\": [");
     for (size_t i = 0; i < opt.errors.size(); i++) printf("%s\"%s\"", i ? ", " : "", json_escape(opt.errors[i]).c_str());
@@ -191,7 +193,7 @@ int main(int argc, char **argv)
   printf("HEVC-DL MI355X path: %dx%d  QP %d  frames %ld (skip %ld)  batch %d  labels: %s\n", width, height, qp, n_frames, frame_skip, batch,
          label_dir.empty() ? (cnn_input == "luma" ? "on-device CNN (luma input)" : "on-device CNN (BT.601 RGB input)") : ("files under " + label_dir).c_str());
   if (!stage_keys.empty()) {
-    printf("Accepted, but their stages are not part of this path (no bitstream is written; reconstruction and PSNR are %s, without SAO):", deblock ? "after deblocking" : "before the in-loop filters");
+    printf("Accepted, but their stage is not part of this path (the bitstream signals SAO off; reconstruction and PSNR are %s, without SAO):", deblock ? "after deblocking" : "before the in-loop filters");
     for (const auto &k : stage_keys) printf(" %s", k.c_str());
     printf("\n");
   }
@@ -203,6 +205,11 @@ int main(int argc, char **argv)
   if (!recon_path.empty() && !frec) { fprintf(stderr, "Error: cannot open reconstruction file '%s'\n", recon_path.c_str()); return 2; }
   const std::string record_path = native_path(opt.get("RecordFile"));
   FILE *frecords = record_path.empty() ? nullptr : fopen(record_path.c_str(), "wb");
+  FILE *fbits = bitstream_path.empty() ? nullptr : fopen(bitstream_path.c_str(), "wb");
+  if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
+  if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
+  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc;
+  std::vector<uint8_t> au(hevcdl_access_unit_bound(width, height));
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;
   int rc = 0;
@@ -236,9 +243,14 @@ int main(int argc, char **argv)
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
     for (int i = 0; i < nb; i++) {
       const double p[3] = { psnr_of(stats[i].sse[0], ny), psnr_of(stats[i].sse[1], nc), psnr_of(stats[i].sse[2], nc) };
+      // the access unit: VPS+SPS+PPS+slice, written to -b; its size is the picture's bit count (TEncGOP.cpp:2420-2447)
+      size_t au_len = 0;
+      st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, au.data(), au.size(), &au_len);
+      if (st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)st); rc = 3; break; }
+      if (fbits) fwrite(au.data(), 1, au_len, fbits);
       printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]\n", f0 + i, 0, 'I', qp,
-             (unsigned long long)stats[i].est_bits, p[0], p[1], p[2], et);
-      sum_bits += (double)stats[i].est_bits;
+             (unsigned long long)au_len * 8, p[0], p[1], p[2], et);
+      sum_bits += (double)au_len * 8;
       for (int c = 0; c < 3; c++) { sum_psnr[c] += p[c]; sum_mse[c] += (double)stats[i].sse[c] / (c ? nc : ny); }
       done++;
     }
@@ -247,13 +259,14 @@ int main(int argc, char **argv)
   }
   if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
     const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
-    printf("\n\nSUMMARY (bits: CABAC estimate of the decisions; PSNR without SAO) -----------------------------------------\n");
+    printf("\n\nSUMMARY (PSNR without SAO) --------------------------------------------------------\n");
     printf("\tTotal Frames |   Bitrate     Y-PSNR    U-PSNR    V-PSNR    YUV-PSNR  \n");
     printf("\t %8ld    %c %12.4lf  %8.4lf  %8.4lf  %8.4lf  %8.4lf  \n", done, 'a', sum_bits * (fps / 1000.0 / done), sum_psnr[0] / done, sum_psnr[1] / done,
            sum_psnr[2] / done, mse_yuv == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 / mse_yuv));
   }
   if (frec) fclose(frec);
   if (frecords) fclose(frecords);
+  if (fbits) fclose(fbits);
   fclose(fin);
   hevcdl_destroy(ctx);
   return rc;

@@ -123,6 +123,29 @@ hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_
 hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *recon, int n_frames, const hevcdl_ctu_record *records, uint8_t *out);
 hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *d_recon, int n_frames, const void *d_records, void *d_out, void *stream);
 
+/* ---- bitstream writer (host side; no GPU needed) ---------------------------------------------------
+ * One access unit per picture exactly as the reference emits it for its all-intra configuration: VPS, SPS, PPS
+ * (ReWriteParamSetsFlag 1), then one slice NAL (IDR_W_RADL for POC 0, CRA afterwards), Annex B start codes.
+ * Replaces TEncGOP::compressGOP's parameter-set / slice writing (TEncGOP.cpp:1751-1756, 1895-1935), TEncCavlc::codeVPS /
+ * codeSPS / codePPS / codeSliceHeader (TEncCavlc.cpp:677, 500, 189, 755), TEncSlice::encodeSlice (TEncSlice.cpp:985) and
+ * the arithmetic coder TEncBinCABAC (TEncBinCoderCABAC.cpp:187-446) for the CTU records hevcdl_compress_frames
+ * returns.  SAO is signalled off (sample_adaptive_offset_enabled_flag 0): that stage is not built; sao_enabled or
+ * loop_filter_disable != 0 is answered with HEVCDL_ERR_UNSUPPORTED. */
+typedef struct hevcdl_stream_config {
+  uint32_t struct_size;          /* sizeof(hevcdl_stream_config) */
+  int32_t  width, height, qp;    /* as in hevcdl_config */
+  int32_t  level_idc;            /* general_level_idc = 30 x Level (cfg key Level, TAppEncCfg.cpp:850): 6.2 -> 186, 3.1 -> 93 */
+  int32_t  sao_enabled;          /* must be 0 */
+  int32_t  loop_filter_disable;  /* must be 0 (LoopFilterDisable 0: deblocking on, zero offsets, no PPS control fields) */
+  int32_t  reserved;
+} hevcdl_stream_config;
+hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
+size_t        hevcdl_access_unit_bound(int width, int height);
+/* records: the [ctus] records of picture `poc` (= frame index; POC lsb is 8 bits).  out_len is set even when the
+ * buffer is too small (HEVCDL_ERR_INVALID_ARG), so the call can be repeated. */
+hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc, const hevcdl_ctu_record *records,
+                                       uint8_t *out, size_t capacity, size_t *out_len);
+
 /* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------
  *   TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)   TEncCu.h:120, called at TEncSlice.cpp:879
  *   TEncCu::encodeCtu(TComDataCU* pCtu)                   TEncCu.h:123, called at TEncSlice.cpp:893

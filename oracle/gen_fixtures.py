@@ -47,7 +47,7 @@ def gen_rd():
         lab = rt.make_labels(w, h, nf, kind, seed + 100)
         dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab)
         # deblocked-only reconstruction: the same run with SAO switched off (decisions are untouched by the in-loop filters)
-        dump2, _, _, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--SAO=0"])
+        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--SAO=0", "--SEIDecodedPictureHash=0"])
         assert dump2.tobytes() == dump.tobytes()
         order = np.lexsort((dump["addr"], dump["frame"]))
         dump = dump[order]
@@ -57,7 +57,7 @@ def gen_rd():
         np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab,
                             records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
                             rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
-                            bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8),
+                            bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),
                             summary=np.array(summary))
         cases.append(name)
         print("rd fixture", name, "ctus", nf * nctu, summary[0][:60] if summary else "")

@@ -62,7 +62,7 @@ def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
     c = json.loads(r.stdout)
     assert c["InputFile"] == "./in_192x128.yuv" and c["ReconFile"] == "./rec/rec.yuv"       # Windows paths of the reference cfgs
     assert (c["SourceWidth"], c["SourceHeight"], c["QP"], c["FramesToBeEncoded"], c["LabelDir"]) == (192, 128, 32, 1, "pred")
-    assert set(c["stage_keys"]) == {"BitstreamFile", "Level", "SAO"} and c["errors"] == []
+    assert set(c["stage_keys"]) == {"SAO"} and c["errors"] == [] and c["level_idc"] == 93 and c["BitstreamFile"] == "./rec/str.bin"
 
 
 def test_keys_that_change_the_path_are_rejected(app, tmp_path):
@@ -113,12 +113,17 @@ def test_cli_encode_matches_the_api(app, tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("POC")]
     s = metrics.Summary(w, h, 30)
     ysz = w * h
+    bits, stream = [], b""
     for f in range(nf):
         d = (yuv[skip + f].astype(np.int64) - dbk[f].astype(np.int64)) ** 2
-        p = s.add(int(stats["est_bits"][f]), (d[:ysz].sum(), d[ysz:ysz + ysz // 4].sum(), d[ysz + ysz // 4:].sum()))
-        assert lines[f].rsplit(" [ET", 1)[0] == metrics.frame_line(f, qp, int(stats["est_bits"][f]), p).rsplit(" [ET", 1)[0]
+        p = s.add(0, (d[:ysz].sum(), d[ysz:ysz + ysz // 4].sum(), d[ysz + ysz // 4:].sum()))
+        au = hevcdl_amd.write_access_unit(w, h, qp, f, recs[f], level_idc=93)
+        bits.append(len(au) * 8); stream += au
+        assert lines[f].rsplit(" [ET", 1)[0] == metrics.frame_line(f, qp, len(au) * 8, p).rsplit(" [ET", 1)[0]
+    s.bits = float(sum(bits))
     assert s.text().splitlines()[1].rstrip() in [l.rstrip() for l in r.stdout.splitlines()]
-    r3 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-fs", str(skip), "--LabelDir=pred", "--LoopFilterDisable=1", "-o", "rec_nofilter.yuv"], tmp_path)
+    assert (tmp_path / "rec" / "str.bin").read_bytes() == stream                       # -b from the cfg: the HM-format bitstream
+    r3 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-fs", str(skip), "--LabelDir=pred", "--LoopFilterDisable=1", "--BitstreamFile=", "-o", "rec_nofilter.yuv"], tmp_path)
     assert r3.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "rec_nofilter.yuv", np.uint8), recon.reshape(-1))
     # CNN labels when no label directory is given
     r2 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-o", "rec_cnn.yuv"], tmp_path)

@@ -1,0 +1,76 @@
+"""Row f-1: the bitstream writer (host code, no GPU): byte-exact against the reference's streams, decodable by the
+reference decoder to the deblocked reconstruction."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
+REF_DEC = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder_ref")
+
+
+def stream_of(f):
+    import hevcdl_amd
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
+    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc]) for poc in range(recs.shape[0]))
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
+def test_stream_is_byte_exact_with_the_reference(path):
+    """Same decisions (the fixture's records) -> the very bytes the reference encoder wrote with --SAO=0:
+    parameter sets, slice headers, CABAC payload, emulation prevention, start codes."""
+    f = np.load(path)
+    assert stream_of(f) == f["bitstream_nosao"].tobytes()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DEC), reason="reference decoder build (oracle/_ref) only exists in the survey container")
+@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r"))],
+                         ids=lambda p: os.path.basename(p)[3:-4])
+def test_reference_decoder_reconstructs_the_deblocked_picture(path, tmp_path):
+    f = np.load(path)
+    (tmp_path / "s.bin").write_bytes(stream_of(f))
+    r = subprocess.run([REF_DEC, "-b", "s.bin", "-o", "dec.yuv"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ERROR" not in r.stdout, r.stdout[-500:]
+    assert np.array_equal(np.fromfile(tmp_path / "dec.yuv", np.uint8), f["recon_deblocked"])
+
+
+def test_parameter_sets_and_headers_parse_back():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hevc_parse as hp
+    import hevcdl_amd
+    recs = np.zeros(15 * 8, hevcdl_amd.REC_DTYPE)          # 960x512, all-zero records: one 64x64 CU per CTU, no residual
+    recs["luma_dir"][:] = 1; recs["chroma_dir"][:] = 36; recs["tr_idx"][:] = 1
+    for poc in (0, 3, 300):
+        au = hevcdl_amd.write_access_unit(960, 512, 37, poc, recs, level_idc=93)
+        nals = hp.split_annexb(au)
+        assert [(n[0] >> 1) & 63 for _, n in nals] == [32, 33, 34, 19 if poc == 0 else 21] and [sc for sc, _ in nals] == [4, 4, 4, 3]
+        sps, pps = hp.parse_sps(nals[1][1]), hp.parse_pps(nals[2][1])
+        assert (sps["width"], sps["height"], sps["level_idc"], sps["sao"], sps["log2_diff_cb"], sps["log2_diff_tb"]) == (960, 512, 93, 0, 3, 3)
+        assert (pps["sign_hiding"], pps["tskip"], pps["init_qp_m26"], pps["cu_qp_delta"]) == (1, 1, 0, 0)
+        hdr, _ = hp.parse_slice_header(nals[3][1], sps, pps)
+        assert hdr["qp_delta"] == 11 and hdr["slice_type"] == 2 and (poc == 0 or hdr["poc_lsb"] == poc % 256)
+        # Annex B: no start-code emulation inside a NAL
+        for _, n in nals:
+            assert b"\x00\x00\x00" not in n and b"\x00\x00\x01" not in n and b"\x00\x00\x02" not in n
+
+
+def test_writer_rejects_what_it_does_not_implement():
+    import ctypes
+    import hevcdl_amd
+    lib = hevcdl_amd.load_library()
+    cfg = hevcdl_amd.StreamConfig()
+    assert lib.hevcdl_stream_config_default(ctypes.byref(cfg), 64, 64, 32) == 0
+    assert lib.hevcdl_stream_config_default(ctypes.byref(cfg), 60, 64, 32) != 0
+    rec = np.zeros(1, hevcdl_amd.REC_DTYPE); buf = np.zeros(4096, np.uint8); n = ctypes.c_size_t(0)
+    cfg.sao_enabled = 1
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, buf.ctypes.data, 4096, ctypes.byref(n)) == 2    # UNSUPPORTED
+    cfg.sao_enabled = 0
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, buf.ctypes.data, 8, ctypes.byref(n)) == 1 and n.value > 8
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, buf.ctypes.data, 4096, ctypes.byref(n)) == 0
