@@ -101,10 +101,23 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
       base[u] = y * ROW + x;
       acc[u] = (v4f){ bias, bias, bias, bias };
     }
+    // A operands ping-pong between two register sets of 4 k-steps x 4 tiles: the LDS reads of chunk c+1 are issued
+    // before the MFMAs of chunk c (see conv2)
+    float a0[16], a1[16];
 #pragma unroll
-    for (int ks = 0; ks < 19; ks++)
+    for (int q = 0; q < 16; q++) a0[q] = tile[base[q & 3] + ko[q >> 2]];
 #pragma unroll
-      for (int u = 0; u < 4; u++) acc[u] = mfma4(tile[base[u] + ko[ks]], bw[ks], acc[u]);
+    for (int c4 = 0; c4 < 5; c4++) {
+      float (&ac)[16] = (c4 & 1) ? a1 : a0; float (&an)[16] = (c4 & 1) ? a0 : a1;
+      if (c4 < 4) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) if ((c4 + 1) * 4 + (q >> 2) < 19) an[q] = tile[base[q & 3] + ko[(c4 + 1) * 4 + (q >> 2)]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; q++) if (c4 * 4 + (q >> 2) < 19) acc[q & 3] = mfma4(ac[q], bw[c4 * 4 + (q >> 2)], acc[q & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int t = wave * TILES + t0 + u;
@@ -153,6 +166,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
   const int frame = gctu / p.ctus_per_frame, addr = gctu - frame * p.ctus_per_frame;
   const int x0 = (addr % p.ctus_x) * 64, y0 = (addr / p.ctus_x) * 64;
   const float GLB *W = (const float GLB *)p.weights;
+#ifdef HEVCDL_CNN_PROF
+  unsigned long long pt_[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_readcyclecounter();
+#define CNN_MARK(i) do { __syncthreads(); const unsigned long long n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pl_; pl_ = n_; } while (0)
+#else
+#define CNN_MARK(i) do { } while (0)
+#endif
 
   // ---- stage 0: CTU input -> LDS (coalesced rows of the planes), LUT, im2col tables, zeroed halo'd maps --------
   sm.lut[tid] = (float)tid / 255.0f;
@@ -182,31 +201,54 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       sm.in[0][y][x] = (uint8_t)r; sm.in[1][y][x] = (uint8_t)g; sm.in[2][y][x] = (uint8_t)b;
     }
   }
-  for (int i = tid; i < 32 * A_CH; i += 256) sm.act12[i] = 0.f;
-  for (int i = tid; i < 3 * T64_CH; i += 256) sm.t64[i] = 0.f;
-  __syncthreads();
+  // zero halos only: the interiors of the maps / tiles are rewritten before they are read
+  for (int i = tid; i < 32 * 72; i += 256) {                       // 18x18 map + 4 pad words: 68 border words + 4 = 72 per channel
+    const int c = i / 72, r = i - c * 72;
+    const int o = r < 18 ? r : (r < 36 ? 17 * 18 + (r - 18) : (r < 52 ? (r - 35) * 18 : (r < 68 ? (r - 51) * 18 + 17 : 324 + (r - 68))));
+    sm.act12[c * A_CH + o] = 0.f;
+  }
+  for (int i = tid; i < 3 * (4 * T64_ROW + 64 * 8); i += 256) {       // 2 rows top + 2 bottom (full pitch), 64 rows x (2 left + 2+4 right incl. pitch padding)
+    const int c = i / (4 * T64_ROW + 512), r = i - c * (4 * T64_ROW + 512);
+    int o;
+    if (r < 2 * T64_ROW) o = r; else if (r < 4 * T64_ROW) o = 66 * T64_ROW + (r - 2 * T64_ROW);
+    else { const int q = r - 4 * T64_ROW, y = q >> 3, k = q & 7; o = (y + 2) * T64_ROW + (k < 2 ? k : 64 + k); }
+    sm.t64[c * T64_CH + o] = 0.f;
+  }
   for (int i = tid; i < 3 * 64 * 64; i += 256) {
     const int c = i >> 12, y = (i >> 6) & 63, x = i & 63;
     sm.t64[c * T64_CH + (y + 2) * T64_ROW + x + 2] = sm.lut[sm.in[c][y][x]];
   }
   __syncthreads();
 
+  CNN_MARK(0);
   // ---- conv64 branch, once per CTU (use_model.py:38-43) --------------------------------------------
   conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12 + 16 * A_CH, tid);
 
+  CNN_MARK(1);
   const int i16 = lane & 15, g4 = lane >> 4;
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     // ---- conv1 on the 32x32 quadrant (use_model.py:20-25); its input tile shares storage with conv2's output ----
-    for (int i = tid; i < 3 * T32_CH; i += 256) sm.q.t32[i] = 0.f;
-    __syncthreads();
+    for (int i = tid; i < 3 * (4 * T32_ROW + 32 * 8); i += 256) {     // halo of the quadrant tile (storage is shared with conv2's output: rewritten per quadrant)
+      const int c = i / (4 * T32_ROW + 256), r = i - c * (4 * T32_ROW + 256);
+      int o;
+      if (r < 2 * T32_ROW) o = r; else if (r < 4 * T32_ROW) o = 34 * T32_ROW + (r - 2 * T32_ROW);
+      else { const int q2 = r - 4 * T32_ROW, y = q2 >> 3, k = q2 & 7; o = (y + 2) * T32_ROW + (k < 2 ? k : 32 + k); }
+      sm.q.t32[c * T32_CH + o] = 0.f;
+    }
     for (int i = tid; i < 3 * 32 * 32; i += 256) {
       const int c = i >> 10, y = (i >> 5) & 31, x = i & 31;
       sm.q.t32[c * T32_CH + (y + 2) * T32_ROW + x + 2] = sm.lut[sm.in[c][(q >> 1) * 32 + y][(q & 1) * 32 + x]];
     }
     __syncthreads();
+    CNN_MARK(2);
     conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, tid);
-    for (int i = tid; i < 64 * A2_CH; i += 256) sm.q.a2[i] = 0.f;      // the input tile is dead: halo of conv2's output
+    CNN_MARK(3);
+    for (int i = tid; i < 64 * 40; i += 256) {                        // the input tile is dead: zero the halo of conv2's output (36 border words + 4 pad per channel)
+      const int c = i / 40, r = i - c * 40;
+      const int o = r < 10 ? r : (r < 20 ? 90 + (r - 10) : (r < 28 ? (r - 19) * 10 : (r < 36 ? (r - 27) * 10 + 9 : 100 + (r - 36))));
+      sm.q.a2[c * A2_CH + o] = 0.f;
+    }
     __syncthreads();
 
     // ---- conv2: 32 -> 64, 3x3, on cat(conv1, conv64) (use_model.py:26-31, 50) ----------------------
@@ -221,15 +263,35 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       for (int t = 0; t < 16; t++) acc[t] = (v4f){ bias, bias, bias, bias };
       // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4
       const float LDS *abase = sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1);
+      float bq[8];                                                    // B operands of the current tap; the next tap's are in flight
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) bq[kk] = w2[kk * 64];
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
         const float LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
+        float bn[8];
+        const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) bn[kk] = w2[(tn * 8 + kk) * 64];
+        // A operands double-buffered in registers: the 16 LDS reads of k-step kk+1 are issued before the 16 MFMAs of kk
+        // (left alone the compiler reads two operands, waits, issues two MFMAs: the LDS latency is exposed every 64 cycles)
+        float a0[16], a1[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) a0[t] = ap[(2 * (t >> 1)) * A_ROW + 8 * (t & 1)];
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
-          const float b = w2[(tap * 8 + kk) * 64];
+          float (&ac)[16] = (kk & 1) ? a1 : a0; float (&an)[16] = (kk & 1) ? a0 : a1;
+          if (kk < 7) {
 #pragma unroll
-          for (int t = 0; t < 16; t++) acc[t] = mfma4(ap[kk * 4 * A_CH + (2 * (t >> 1)) * A_ROW + 8 * (t & 1)], b, acc[t]);
+            for (int t = 0; t < 16; t++) an[t] = ap[(kk + 1) * 4 * A_CH + (2 * (t >> 1)) * A_ROW + 8 * (t & 1)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 16; t++) acc[t] = mfma4(ac[t], bq[kk], acc[t]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) bq[kk] = bn[kk];
       }
       double s = 0, ss = 0;
 #pragma unroll
@@ -249,6 +311,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       }
       __syncthreads();
     }
+    CNN_MARK(4);
     // ---- conv3: 64 -> 128, 3x3 (use_model.py:32-37); wave w owns output channels [32w, 32w+32) = 2 N-tiles, 4 M-tiles ----
     {
       const float GLB *w3 = W + HEVCDL_W_C3 + (2 * wave) * (144 * 64) + lane, *b3 = W + HEVCDL_W_C3 + 73728;
@@ -260,18 +323,36 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) acc[n][t] = (v4f){ bias, bias, bias, bias };
       }
       const float LDS *abase = sm.q.a2 + g4 * A2_CH + ((i16 >> 1) & 1) * A2_ROW + 2 * (i16 >> 2) + (i16 & 1);
+      float bq[32];
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) { bq[kk] = w3[kk * 64]; bq[16 + kk] = w3[(144 + kk) * 64]; }
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
         const float LDS *ap = abase + (tap / 3) * A2_ROW + (tap % 3);
+        float bn[32];
+        const int tn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-          const float b0 = w3[(tap * 16 + kk) * 64], b1 = w3[(144 + tap * 16 + kk) * 64];
+        for (int kk = 0; kk < 16; kk++) { bn[kk] = w3[(tn * 16 + kk) * 64]; bn[16 + kk] = w3[(144 + tn * 16 + kk) * 64]; }
+        float a0[8], a1[8];                                        // two k-steps of A operands per buffer
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const float a = ap[kk * 4 * A2_CH + 2 * t * A2_ROW];
-            acc[0][t] = mfma4(a, b0, acc[0][t]); acc[1][t] = mfma4(a, b1, acc[1][t]);
+        for (int u = 0; u < 8; u++) a0[u] = ap[(u >> 2) * 4 * A2_CH + 2 * (u & 3) * A2_ROW];
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) {
+          float (&ac)[8] = (k2 & 1) ? a1 : a0; float (&an)[8] = (k2 & 1) ? a0 : a1;
+          if (k2 < 7) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) an[u] = ap[(2 * (k2 + 1) + (u >> 2)) * 4 * A2_CH + 2 * (u & 3) * A2_ROW];
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int kk = 2 * k2 + (u >> 2), t = u & 3;
+            acc[0][t] = mfma4(ac[u], bq[kk], acc[0][t]); acc[1][t] = mfma4(ac[u], bq[16 + kk], acc[1][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int kk = 0; kk < 32; kk++) bq[kk] = bn[kk];
       }
 #pragma unroll
       for (int n = 0; n < 2; n++) {
@@ -295,34 +376,53 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       }
       __syncthreads();
     }
+    CNN_MARK(5);
   }
 
   // ---- fc1 (2048 -> 256) for the 4 quadrants at once; weights pre-transposed [k][j] ---------------------
   {
     const float GLB *f1 = W + HEVCDL_W_FC1;
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll 4
-    for (int k = 0; k < 2048; k++) {
-      const float w = f1[(size_t)k * 256 + tid];
-      const v4f xv = *(const v4f LDS *)sm.q.a3[k];
-      a0 = fmaf(w, xv.x, a0); a1 = fmaf(w, xv.y, a1); a2 = fmaf(w, xv.z, a2); a3 = fmaf(w, xv.w, a3);
+    // 2 MB of weights stream through every workgroup: 32 loads in flight per lane hide the L2 latency that one wave per
+    // SIMD cannot hide by itself; the accumulation order per output stays k = 0..2047
+#pragma unroll 1
+    for (int k0 = 0; k0 < 2048; k0 += 32) {
+      float w[32];
+#pragma unroll
+      for (int u = 0; u < 32; u++) w[u] = f1[(size_t)(k0 + u) * 256 + tid];
+#pragma unroll
+      for (int u = 0; u < 32; u++) {
+        const v4f xv = *(const v4f LDS *)sm.q.a3[k0 + u];
+        a0 = fmaf(w[u], xv.x, a0); a1 = fmaf(w[u], xv.y, a1); a2 = fmaf(w[u], xv.z, a2); a3 = fmaf(w[u], xv.w, a3);
+      }
     }
     const float b = f1[2048 * 256 + tid];
     sm.h1[0][tid] = fmaxf(a0 + b, 0.f); sm.h1[1][tid] = fmaxf(a1 + b, 0.f);
     sm.h1[2][tid] = fmaxf(a2 + b, 0.f); sm.h1[3][tid] = fmaxf(a3 + b, 0.f);
   }
   __syncthreads();
+  CNN_MARK(6);
   {
     const float GLB *f2 = W + HEVCDL_W_FC2; const int q = tid >> 6, j = tid & 63;
     float a = 0;
-    for (int k = 0; k < 256; k++) a = fmaf(sm.h1[q][k], f2[k * 64 + j], a);
+#pragma unroll 1
+    for (int k0 = 0; k0 < 256; k0 += 32) {
+      float w[32];
+#pragma unroll
+      for (int u = 0; u < 32; u++) w[u] = f2[(k0 + u) * 64 + j];
+#pragma unroll
+      for (int u = 0; u < 32; u++) a = fmaf(sm.h1[q][k0 + u], w[u], a);
+    }
     sm.h2[q][j] = fmaxf(a + f2[256 * 64 + j], 0.f);
   }
   __syncthreads();
   if (tid < 64) {
     const float GLB *f3 = W + HEVCDL_W_FC3; const int q = tid >> 4, j = tid & 15;
-    float a = 0;
-    for (int k = 0; k < 64; k++) a = fmaf(sm.h2[q][k], f3[k * 16 + j], a);
+    float a = 0, w[64];
+#pragma unroll
+    for (int u = 0; u < 64; u++) w[u] = f3[u * 16 + j];
+#pragma unroll
+    for (int u = 0; u < 64; u++) a = fmaf(sm.h2[q][u], w[u], a);
     a += f3[64 * 16 + j];
     sm.lg[q][j] = a;
     if (p.logits) ((float GLB *)p.logits)[(size_t)gctu * 64 + q * 16 + j] = a;
@@ -369,6 +469,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     }
     for (int c = 0; c < 16; c++) ((uint8_t GLB *)p.labels)[(size_t)gctu * 16 + c] = lab[c];
   }
+#ifdef HEVCDL_CNN_PROF
+  CNN_MARK(7);
+  if (tid == 0 && gctu == 0 && p.logits) for (int i = 0; i < 8; i++) ((float GLB *)p.logits)[i] = (float)pt_[i];
+#endif
 }
 
+#ifdef HEVCDL_CNN_PROF
+#endif
 extern "C" size_t hevcdl_cnn_smem_bytes(void) { return sizeof(CnnSmem); }
