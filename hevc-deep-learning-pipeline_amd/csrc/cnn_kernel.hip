@@ -381,24 +381,38 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 
   // ---- fc1 (2048 -> 256) for the 4 quadrants at once; weights pre-transposed [k][j] ---------------------
   {
-    const float GLB *f1 = W + HEVCDL_W_FC1;
-    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    // 2 MB of weights stream through every workgroup: 32 loads in flight per lane hide the L2 latency that one wave per
-    // SIMD cannot hide by itself; the accumulation order per output stays k = 0..2047
+    // fc1 as 16 independent 4x4 outer products per instruction: v_mfma_f32_4x4x1_16b_f32, block b of lane group
+    // l >> 2: D[quadrant i][channel 4b + j] += x[k][i] * W[k][4b + j]; A = lane (l & 3)'s quadrant activation, B = the
+    // lane's own output channel (weights row k is one coalesced 256-byte read per wave), result register i = quadrant i
+    // of channel 64*wave + lane.  Four accumulator sets (k mod 4) keep dependent MFMAs apart.
+    const float GLB *f1 = W + HEVCDL_W_FC1 + tid;
+    const float LDS *xa = &sm.q.a3[0][lane & 3];
+    v4f acc[4] = { {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0} };
+    // the 2 MB of weights stream from L2 with one wave per SIMD: 64 loads of the next chunk are in flight while the
+    // current chunk's 64 MFMAs run (two register sets of 64)
+    float wa[64], wb[64];
+#pragma unroll
+    for (int u = 0; u < 64; u++) wa[u] = f1[(size_t)u * 256];
 #pragma unroll 1
-    for (int k0 = 0; k0 < 2048; k0 += 32) {
-      float w[32];
+    for (int k0 = 0; k0 < 2048; k0 += 128) {
 #pragma unroll
-      for (int u = 0; u < 32; u++) w[u] = f1[(size_t)(k0 + u) * 256 + tid];
+      for (int u = 0; u < 64; u++) wb[u] = f1[(size_t)(k0 + 64 + u) * 256];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 32; u++) {
-        const v4f xv = *(const v4f LDS *)sm.q.a3[k0 + u];
-        a0 = fmaf(w[u], xv.x, a0); a1 = fmaf(w[u], xv.y, a1); a2 = fmaf(w[u], xv.z, a2); a3 = fmaf(w[u], xv.w, a3);
-      }
+      for (int u = 0; u < 64; u++) acc[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[(k0 + u) * 4], wa[u], acc[u & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kn = k0 + 128 < 2048 ? k0 + 128 : 0;
+#pragma unroll
+      for (int u = 0; u < 64; u++) wa[u] = f1[(size_t)(kn + u) * 256];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 64; u++) acc[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[(k0 + 64 + u) * 4], wb[u], acc[u & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const float b = f1[2048 * 256 + tid];
-    sm.h1[0][tid] = fmaxf(a0 + b, 0.f); sm.h1[1][tid] = fmaxf(a1 + b, 0.f);
-    sm.h1[2][tid] = fmaxf(a2 + b, 0.f); sm.h1[3][tid] = fmaxf(a3 + b, 0.f);
+    const v4f r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    const float b = W[HEVCDL_W_FC1 + 2048 * 256 + tid];
+    sm.h1[0][tid] = fmaxf(r.x + b, 0.f); sm.h1[1][tid] = fmaxf(r.y + b, 0.f);
+    sm.h1[2][tid] = fmaxf(r.z + b, 0.f); sm.h1[3][tid] = fmaxf(r.w + b, 0.f);
   }
   __syncthreads();
   CNN_MARK(6);
