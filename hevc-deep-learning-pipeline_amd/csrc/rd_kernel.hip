@@ -729,8 +729,25 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
   RDOQ_MARK(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
   double block_uncoded = 0;
-#pragma unroll 8
-  for (int sp = ncoef - 1; sp > last_pos; sp--) block_uncoded += cost_coeff[sp];      // zero-level costs above the last position
+  // zero-level costs above the last position, summed in scan order from the top: 64 positions per round, costs
+  // recomputed lane-parallel (a zero coefficient costs exactly 0.0: rounds without any are skipped), the ordered sum
+  // itself runs out of LDS
+  for (int top = ncoef - 1; top > last_pos; top -= 64) {
+    const int sp = top - lane;
+    const double c0 = (sp > last_pos) ? cost0_of(scan[sp]) : 0.0;
+    if (!__ballot(c0 != 0.0)) continue;
+    wsync();
+    s.zb[0][lane] = c0;
+    wsync();
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) v[t] = s.zb[0][h * 16 + t];
+#pragma unroll
+      for (int t = 0; t < 16; t++) block_uncoded += v[t];
+    }
+  }
   double base_cost = block_uncoded;
   RDOQ_MARK(19);
   const int cg_last = last_pos >> 4;
@@ -958,15 +975,36 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
       if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
       if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
       const double cl_j = lambda * lc;
-      for (int pin = (cgpos == cg_last) ? (last_pos & 15) : 15; pin >= 0; pin--) {
-        const int lv = __builtin_amdgcn_readlane(lv_j, pin);
-        if (lv) {
-          const double total = base_cost + rl_d(cl_j, pin) - rl_d(cs_j, pin);
-          if (total < best_cost) { best_last_p1 = cgpos * 16 + pin + 1; best_cost = total; }
-          if (lv > 1) { found_last = 1; break; }
-          base_cost -= rl_d(cc_j, pin); base_cost += rl_d(c0_j, pin);
-        } else base_cost -= rl_d(cs_j, pin);
+      // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
+      // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
+      // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
+      // lane-parallel, then only the positions with a level are compared, highest scan position first.
+      const int start_pin = (cgpos == cg_last) ? (last_pos & 15) : 15;
+      const bool in_j = j <= start_pin;
+      const double a1_j = in_j ? (lv_j ? -cc_j : -cs_j) : 0.0, a2_j = (in_j && lv_j) ? c0_j : 0.0;
+      wsync();
+      if (lane < 16) { s.zb[0][j] = a1_j; s.zb[1][j] = a2_j; }
+      wsync();
+      double mine = base_cost, acc = base_cost;
+      {
+        double v1[16], v2[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) { v1[t] = s.zb[0][15 - t]; v2[t] = s.zb[1][15 - t]; }
+#pragma unroll
+        for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
       }
+      const double total_j = (mine + cl_j) - cs_j;
+      const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
+      const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
+      unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
+      while (cand) {
+        const int pin = 31 - __clz((int)cand);
+        cand &= ~(1u << pin);
+        const double total = rl_d(total_j, pin);
+        if (total < best_cost) { best_last_p1 = cgpos * 16 + pin + 1; best_cost = total; }
+      }
+      if (gt1) found_last = 1;
+      base_cost = acc;
     }
   }
 
