@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
-SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "deblock_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
+SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
 
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
 
@@ -30,6 +30,7 @@ REC_DTYPE = np.dtype([
     ("bits", "<u4"), ("dist", "<u4"), ("cost", "<f8"),
     ("coeff_y", "<i2", 4096), ("coeff_cb", "<i2", 1024), ("coeff_cr", "<i2", 1024)])
 STATS_DTYPE = np.dtype([("sse", "<u8", 3), ("est_bits", "<u8"), ("ctus", "<u4"), ("pad", "<u4")])
+SAO_DTYPE = np.dtype([("mode", "<i4"), ("type", "<i4"), ("aux", "<i4"), ("offset", "<i4", 32)])       # hevcdl_sao_offset; a CTU has 3 (Y, Cb, Cr)
 CABAC_DTYPE = np.dtype([("ctx", "u1", 160), ("frac", "<u8")])      # hevcdl_cabac_state
 assert REC_DTYPE.itemsize == 15120 and STATS_DTYPE.itemsize == 40 and CABAC_DTYPE.itemsize == 168
 
@@ -120,7 +121,9 @@ def load_library():
     lib.hevcdl_stream_config_default.argtypes = [ctypes.POINTER(StreamConfig), ci, ci, ci]
     lib.hevcdl_access_unit_bound.argtypes = [ci, ci]
     lib.hevcdl_access_unit_bound.restype = ctypes.c_size_t
-    lib.hevcdl_write_access_unit.argtypes = [ctypes.POINTER(StreamConfig), ci, vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.hevcdl_write_access_unit.argtypes = [ctypes.POINTER(StreamConfig), ci, vp, vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.hevcdl_sao_frames.argtypes = [vp, vp, vp, ci, vp, vp]
+    lib.hevcdl_sao_frames_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp]
     lib.hevcdl_deblock_frames.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_deblock_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp]
     lib.hevcdl_begin_frames.argtypes = [vp, vp, ci, vp, vp]
@@ -142,7 +145,7 @@ EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_l
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
-           "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit"]
+           "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit"]
 
 
 def load_weights(path=WEIGHTS_PATH):
@@ -162,7 +165,7 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0):
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -170,11 +173,16 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186):
     if st != 0:
         raise HevcdlError(st, "stream config")
     cfg.level_idc = level_idc
+    sao_ptr = None
+    if sao is not None:
+        sao = np.ascontiguousarray(sao, SAO_DTYPE)
+        cfg.sao_enabled = 1
+        sao_ptr = sao.ctypes.data
     records = np.ascontiguousarray(records)
     cap = lib.hevcdl_access_unit_bound(width, height)
     buf = np.zeros(cap, np.uint8)
     n = ctypes.c_size_t(0)
-    st = lib.hevcdl_write_access_unit(ctypes.byref(cfg), int(poc), records.ctypes.data, buf.ctypes.data, cap, ctypes.byref(n))
+    st = lib.hevcdl_write_access_unit(ctypes.byref(cfg), int(poc), records.ctypes.data, sao_ptr, buf.ctypes.data, cap, ctypes.byref(n))
     if st != 0:
         raise HevcdlError(st, "write_access_unit")
     return buf[:n.value].tobytes()
@@ -247,6 +255,18 @@ class Encoder:
         out = np.zeros_like(recon)
         self._check(self.lib.hevcdl_deblock_frames(self._h, recon.ctypes.data, n, records.ctypes.data, out.ctypes.data))
         return out
+
+    def sao_frames(self, org, deblocked):
+        """original + deblocked frames -> (SAO parameters [n, ctus, 3] SAO_DTYPE, final reconstruction)."""
+        org, n = self._frames(org)
+        dbk, _ = self._frames(deblocked)
+        params = np.zeros((n, self.ctus, 3), SAO_DTYPE)
+        out = np.zeros_like(org)
+        self._check(self.lib.hevcdl_sao_frames(self._h, org.ctypes.data, dbk.ctypes.data, n, params.ctypes.data, out.ctypes.data))
+        return params, out
+
+    def sao_frames_dev(self, d_org, d_deblocked, n, d_params, d_out, stream=None):
+        self._check(self.lib.hevcdl_sao_frames_dev(self._h, d_org, d_deblocked, n, d_params, d_out, stream))
 
     def deblock_frames_dev(self, d_recon, n, d_records, d_out, stream=None):
         self._check(self.lib.hevcdl_deblock_frames_dev(self._h, d_recon, n, d_records, d_out, stream))

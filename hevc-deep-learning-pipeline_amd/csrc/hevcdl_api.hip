@@ -23,6 +23,7 @@ struct hevcdl_ctx {
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
+  unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params;   // SAO workspace
   bool profile;
   std::vector<hipEvent_t> ev_cnn, ev_rd;       // start/stop pairs
   char err[256];
@@ -115,7 +116,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   ctx->ctus_x = (cfg->width + 63) >> 6; ctx->ctus_y = (cfg->height + 63) >> 6; ctx->ctus = ctx->ctus_x * ctx->ctus_y;
   ctx->frame_bytes = hevcdl_frame_bytes(cfg->width, cfg->height);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0;
+  ctx->d_logits = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -146,7 +147,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
   delete ctx;
 }
 
@@ -338,6 +339,43 @@ extern "C" hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *r
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "deblock kernels", e);
   HIPCHK(hipMemcpy(out, ctx->d_yuv, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
+// ---- SAO (row f-2, second half): TEncSampleAdaptiveOffset::SAOProcess, TEncSampleAdaptiveOffset.cpp:244, called at TEncGOP.cpp:1797 ----
+extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_org, const void *d_deblocked, int n_frames, void *d_params, void *d_out, void *stream)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!d_org || !d_deblocked || !d_params || !d_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  const size_t nf = (size_t)ctx->cfg.max_frames;
+  if (!ctx->d_sao_stats) HIPCHK(hipMalloc(&ctx->d_sao_stats, (size_t)ctx->ctus * 3 * 5 * 256 * nf));
+  if (!ctx->d_sao_recon) HIPCHK(hipMalloc(&ctx->d_sao_recon, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * nf));
+  hevcdl_sao_params p;
+  p.org = (const uint8_t *)d_org; p.deblocked = (const uint8_t *)d_deblocked; p.out = (uint8_t *)d_out;
+  p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon;
+  p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames; p.qp = ctx->cfg.qp;
+  p.lambda = ctx->cfg.lambda; p.lambda_chroma = ctx->cfg.lambda_chroma;          // slice lambdas per component, TEncSlice.cpp:112-140
+  hevcdl_launch_sao(&p, stream);
+  HIPCHK(hipGetLastError());
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_sao_frames(hevcdl_ctx *ctx, const uint8_t *org, const uint8_t *deblocked, int n_frames, hevcdl_sao_blk *params, uint8_t *out)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!org || !deblocked || !params || !out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  st = ensure_staging(ctx); if (st) return st;
+  if (!ctx->d_sao_params) HIPCHK(hipMalloc(&ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * ctx->cfg.max_frames));
+  HIPCHK(hipMemcpy(ctx->d_yuv, org, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_recon, deblocked, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  // the records staging area is free here and large enough for one more picture set (15120 B per CTU >= 6144)
+  st = hevcdl_sao_frames_dev(ctx, ctx->d_yuv, ctx->d_recon, n_frames, ctx->d_sao_params, ctx->d_records, nullptr); if (st) return st;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "sao kernels", e);
+  HIPCHK(hipMemcpy(params, ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * n_frames, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, ctx->d_records, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
   return HEVCDL_OK;
 }
 

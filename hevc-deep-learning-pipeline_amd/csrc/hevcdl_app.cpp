@@ -7,8 +7,7 @@
 //   planar YUV reader            HM_dl/source/Lib/TLibVideoIO/TVideoIOYuv.cpp:249,675 (8-bit 4:2:0 file, FrameSkip)
 //   picture log line / summary   TEncGOP.cpp:2500-2541, TEncAnalyze.h:163-370
 // and drives the GPU path through the C ABI of include/hevcdl.h only.  Keys that would change the path are checked
-// against what the path implements (rejected, not ignored); keys of the one stage that is not built (SAO) are
-// accepted and listed: the bitstream (-b) signals SAO off.  Labels come from the on-device CNN, or -- the reference's own
+// against what the path implements (rejected, not ignored).  Labels come from the on-device CNN, or -- the reference's own
 // file IPC format -- from --LabelDir <dir>/<frame>/ctu<addr>.txt (16 integers, TEncCu.cpp:255-262).
 #include <algorithm>
 #include <chrono>
@@ -49,7 +48,7 @@ const Key KEYS[] = {
   // stages that are not built: accepted, reported once
   { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, PATH, "1" }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
   { "LoopFilterBetaOffset_div2", 0, PATH, "0" }, { "LoopFilterTcOffset_div2", 0, PATH, "0" },
-  { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, STAGE, 0 }, { "SAOLcuBoundary", 0, STAGE, 0 }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
+  { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, USED, 0 }, { "SAOLcuBoundary", 0, PATH, "0" }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
   { "LFCrossTileBoundaryFlag", 0, NOEFFECT, 0 }, { "SEIDecodedPictureHash", 0, PATH, "0" },
   // no effect on an all-intra slice with the settings above
   { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
@@ -148,6 +147,7 @@ int main(int argc, char **argv)
   const std::string bitstream_path = native_path(opt.get("BitstreamFile"));
   const int level_idc = (int)(atof(opt.get("Level", "6.2").c_str()) * 30.0 + 0.5);      // general_level_idc
   const bool deblock = opt.geti("LoopFilterDisable", 0) == 0;
+  const bool sao = opt.geti("SAO", 1) != 0;                                    // TAppEncCfg.cpp: SAO defaults to on
   if (opt.v.count("PrintConfig")) {
     printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
            "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"BitstreamFile\": \"%s\", \"level_idc\": %d, \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
@@ -193,7 +193,7 @@ int main(int argc, char **argv)
   printf("HEVC-DL MI355X path: %dx%d  QP %d  frames %ld (skip %ld)  batch %d  labels: %s\n", width, height, qp, n_frames, frame_skip, batch,
          label_dir.empty() ? (cnn_input == "luma" ? "on-device CNN (luma input)" : "on-device CNN (BT.601 RGB input)") : ("files under " + label_dir).c_str());
   if (!stage_keys.empty()) {
-    printf("Accepted, but their stage is not part of this path (the bitstream signals SAO off; reconstruction and PSNR are %s, without SAO):", deblock ? "after deblocking" : "before the in-loop filters");
+    printf("Accepted without effect on this path:");
     for (const auto &k : stage_keys) printf(" %s", k.c_str());
     printf("\n");
   }
@@ -208,7 +208,9 @@ int main(int argc, char **argv)
   FILE *fbits = bitstream_path.empty() ? nullptr : fopen(bitstream_path.c_str(), "wb");
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
   if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
-  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc;
+  if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
+  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao;
+  std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
   std::vector<uint8_t> au(hevcdl_access_unit_bound(width, height));
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;
@@ -233,6 +235,7 @@ int main(int argc, char **argv)
     const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / nb;
     if (st == HEVCDL_OK && deblock) { // TComLoopFilter::loopFilterPic (TEncGOP.cpp:1742); the picture statistics follow the filtered picture
       st = hevcdl_deblock_frames(ctx, recon.data(), nb, recs.data(), recon.data());
+      if (st == HEVCDL_OK && sao) st = hevcdl_sao_frames(ctx, yuv.data(), recon.data(), nb, sao_params.data(), recon.data());   // TEncGOP.cpp:1797
       for (int i = 0; i < nb && st == HEVCDL_OK; i++) {
         const uint8_t *o = yuv.data() + frame_bytes * i, *r = recon.data() + frame_bytes * i;
         const size_t n[3] = { (size_t)width * height, (size_t)width * height / 4, (size_t)width * height / 4 };
@@ -245,7 +248,7 @@ int main(int argc, char **argv)
       const double p[3] = { psnr_of(stats[i].sse[0], ny), psnr_of(stats[i].sse[1], nc), psnr_of(stats[i].sse[2], nc) };
       // the access unit: VPS+SPS+PPS+slice, written to -b; its size is the picture's bit count (TEncGOP.cpp:2420-2447)
       size_t au_len = 0;
-      st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, au.data(), au.size(), &au_len);
+      st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, sao ? sao_params.data() + (size_t)ctus * i : nullptr, au.data(), au.size(), &au_len);
       if (st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)st); rc = 3; break; }
       if (fbits) fwrite(au.data(), 1, au_len, fbits);
       printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]\n", f0 + i, 0, 'I', qp,
@@ -259,7 +262,7 @@ int main(int argc, char **argv)
   }
   if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
     const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
-    printf("\n\nSUMMARY (PSNR without SAO) --------------------------------------------------------\n");
+    printf("\n\nSUMMARY --------------------------------------------------------\n");
     printf("\tTotal Frames |   Bitrate     Y-PSNR    U-PSNR    V-PSNR    YUV-PSNR  \n");
     printf("\t %8ld    %c %12.4lf  %8.4lf  %8.4lf  %8.4lf  %8.4lf  \n", done, 'a', sum_bits * (fps / 1000.0 / done), sum_psnr[0] / done, sum_psnr[1] / done,
            sum_psnr[2] / done, mse_yuv == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 / mse_yuv));

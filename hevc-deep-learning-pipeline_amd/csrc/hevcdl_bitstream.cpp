@@ -1,15 +1,16 @@
 // hevcdl_bitstream.cpp -- HEVC bitstream writer for the pictures this library decides.
 // Host C++ (no GPU): the byte-producing half of the entropy coder is strictly serial per slice and tiny next to the
-// decision kernel (a 2160p frame is ~80 KB of output).
+// decision kernel (a 2160p frame is ~80 KB of output).  SAO parameters (hevcdl_sao_frames) are optional: without them
+// the stream signals SAO off.
 //
 // Mirrors, for the reference's all-intra configuration (one slice per picture, IntraPeriod 1, parameter sets with every
-// picture, deblocking on with zero offsets, sign data hiding, transform skip; SAO signalled OFF -- that stage is not built):
+// picture, deblocking on with zero offsets, sign data hiding, transform skip):
 //   access unit / NAL order, start codes     TEncGOP.cpp:1751-1756, AnnexBwrite.h:55-80, NALwrite.cpp:47-120
 //   VPS / SPS / PPS / slice segment header   TEncCavlc.cpp:677-753, 500-675, 189-341, 755-1109 (+ codePTL :1111-1229)
 //   slice data: CTU loop, end_of_slice flag  TEncSlice.cpp:985-1170, TEncCu.cpp:290-304, 1112-1128, 1167-1271
 //   CU / TU / residual syntax                TEncSbac.cpp:613-1541, TEncEntropy.cpp:200-398
 //   arithmetic coder                         TEncBinCoderCABAC.cpp:70-446, TComCABACTables.cpp:43-121, ContextModel.cpp:56-101
-// Pinned byte for byte by tests/golden/rd_*.npz:bitstream_nosao (the reference run with --SAO=0).
+// Pinned byte for byte by tests/golden/rd_*.npz:bitstream_nosao (the reference run with --SAO=0) and :bitstream (default run).
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +22,7 @@ namespace {
 enum { PLANAR = 0, DC = 1, HOR = 10, VER = 26, DM_CHROMA = 36, SIZE_2Nx2N = 0, SIZE_NxN = 3 };
 enum { SCAN_DIAG = 0, SCAN_HOR = 1, SCAN_VER = 2 };
 enum { CTX_SPLIT = 0, CTX_PART_SIZE = 3, CTX_INTRA_PRED = 4, CTX_CHROMA_PRED = 5, CTX_QT_CBF = 6, CTX_SUBDIV = 16, CTX_SIG_CG = 19,
-       CTX_SIG = 23, CTX_LAST_X = 67, CTX_LAST_Y = 97, CTX_ONE = 127, CTX_ABS = 151, CTX_TSKIP = 157, NUM_CTX = 159 };
+       CTX_SIG = 23, CTX_LAST_X = 67, CTX_LAST_Y = 97, CTX_ONE = 127, CTX_ABS = 151, CTX_TSKIP = 157, CTX_SAO_MERGE = 159, CTX_SAO_TYPE = 160, NUM_CTX = 161 };
 
 // I-slice context initialisation values in the order of the enum above (ContextTables.h:181-480)
 const uint8_t CTX_INIT[NUM_CTX] = {
@@ -33,7 +34,8 @@ const uint8_t CTX_INIT[NUM_CTX] = {
   110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
   110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
   140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-  138, 153, 136, 167, 152, 152, 139, 139 };
+  138, 153, 136, 167, 152, 152, 139, 139,
+  153, 200 };                  // sao_merge_flag, sao_type_idx (ContextTables.h:445-458)
 const uint8_t NEXT_MPS[128] = {
   2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
   34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65,
@@ -393,6 +395,34 @@ void code_transform(Cabac &c, const Cu &cu, const Tu &tu)
     code_coeff(c, coef, comp, n, mode, cu.r->tskip[comp][zabs]);
   }
 }
+// sao(): TEncSbac::codeSAOBlkParam / codeSAOOffsetParam TEncSbac.cpp:1543-1720, called before every CTU (TEncSlice.cpp:1075-1111)
+void code_sao_offset(Cabac &c, int comp, const hevcdl_sao_offset &p)
+{
+  const int first = comp != 2;
+  if (first) {
+    if (p.mode == 0) c.bin(CTX_SAO_TYPE, 0);
+    else { c.bin(CTX_SAO_TYPE, 1); c.ep(p.type == 4 ? 0 : 1); }
+  }
+  if (p.mode != 1) return;
+  int off[4], k = 0;
+  const int ncls = p.type == 4 ? 4 : 5;
+  for (int i = 0; i < ncls; i++) { if (p.type != 4 && i == 2) continue; off[k++] = p.offset[p.type == 4 ? (p.aux + i) % 32 : i]; }
+  for (int i = 0; i < 4; i++) { // codeSaoMaxUvlc, maximum 7
+    const int a = abs(off[i]);
+    if (a == 0) c.ep(0);
+    else { c.ep(1); for (int j = 0; j < a - 1; j++) c.ep(1); if (a < 7) c.ep(0); }
+  }
+  if (p.type == 4) { for (int i = 0; i < 4; i++) if (off[i]) c.ep(off[i] < 0); c.eps((uint32_t)p.aux, 5); }
+  else if (first) c.eps((uint32_t)p.type, 2);
+}
+void code_sao_blk(Cabac &c, const hevcdl_sao_blk &b, bool left_avail, bool above_avail)
+{
+  bool is_left = false, is_above = false;
+  if (left_avail) { is_left = b.c[0].mode == 2 && b.c[0].type == 0; c.bin(CTX_SAO_MERGE, is_left); }
+  if (above_avail && !is_left) { is_above = b.c[0].mode == 2 && b.c[0].type == 1; c.bin(CTX_SAO_MERGE, is_above); }
+  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_sao_offset(c, comp, b.c[comp]);
+}
+
 void code_cu_tree(Cabac &c, const Pic &p, int x, int y, int depth)
 { // xEncodeCU TEncCu.cpp:1167-1271 (I slice: no skip / pred-mode flags)
   const int size = 64 >> depth;
@@ -435,12 +465,13 @@ extern "C" size_t hevcdl_access_unit_bound(int width, int height)
   return (size_t)width * (size_t)height * 3 + 4096;
 }
 
-extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc, const hevcdl_ctu_record *records,
+extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc, const hevcdl_ctu_record *records, const hevcdl_sao_blk *sao,
                                                  uint8_t *out, size_t capacity, size_t *out_len)
 {
   if (!cfg || cfg->struct_size != sizeof *cfg || !records || !out || !out_len || poc < 0) return HEVCDL_ERR_INVALID_ARG;
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51) return HEVCDL_ERR_INVALID_ARG;
-  if (cfg->sao_enabled || cfg->loop_filter_disable) return HEVCDL_ERR_UNSUPPORTED;      // SAO is not built; the PPS below signals deblocking on
+  if (cfg->loop_filter_disable) return HEVCDL_ERR_UNSUPPORTED;                          // the PPS below signals deblocking on
+  if ((cfg->sao_enabled != 0) != (sao != nullptr)) return HEVCDL_ERR_INVALID_ARG;         // SAO parameters go with sample_adaptive_offset_enabled_flag
   std::vector<uint8_t> au;
   { // VPS  TEncCavlc.cpp:677-753
     BitOut w;
@@ -491,6 +522,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     const Pic pic(records, cfg->width, cfg->height);
     const int ctus = pic.ctus_x * ((cfg->height + 63) >> 6);
     for (int a = 0; a < ctus; a++) {
+      if (sao) code_sao_blk(c, sao[a], a % pic.ctus_x > 0, a / pic.ctus_x > 0);
       code_cu_tree(c, pic, (a % pic.ctus_x) * 64, (a / pic.ctus_x) * 64, 0);
       c.terminate(a == ctus - 1);                    // end_of_slice_segment_flag (TEncCu.cpp:1112-1128, TEncSlice.cpp:1136)
     }

@@ -60,9 +60,21 @@ struct hevcdl_dbk_params {
   int tc, beta, tc_c;
 };
 
+// sample adaptive offset (sao_kernel.hip)
+struct hevcdl_sao_params {
+  const uint8_t *org, *deblocked;  // [frame] planar 4:2:0
+  uint8_t *out;                    // [frame] final reconstruction
+  unsigned char *stats;            // [frame][ctu][3][5] {int32 diff[32], count[32]}  (3840 bytes per CTU)
+  unsigned char *params;           // [frame][ctu] hevcdl_sao_blk: coded parameters
+  unsigned char *recon_params;     // [frame][ctu] hevcdl_sao_blk: merge candidates resolved
+  int width, height, ctus_x, ctus_per_frame, n_frames, qp;
+  double lambda, lambda_chroma;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+void hevcdl_launch_sao(const struct hevcdl_sao_params *p, void *stream);
 void hevcdl_launch_deblock(const struct hevcdl_dbk_params *p, void *stream);
 size_t hevcdl_cnn_smem_bytes(void);
 size_t hevcdl_rd_smem_bytes(void);

@@ -1,0 +1,339 @@
+// sao_kernel.hip -- sample adaptive offset for gfx950 (MI355X): second half of row f-2 of SURVEY.md section 8.
+//
+// Replaces TEncSampleAdaptiveOffset::SAOProcess (HM_dl/source/Lib/TLibEncoder/TEncSampleAdaptiveOffset.cpp:244-273, called at
+// TEncGOP.cpp:1797) for the configuration of the hot path (8-bit 4:2:0, one slice, all-intra => SAO on at picture
+// level, SAOLcuBoundary 0, offset step 1):
+//   1. hevcdl_sao_stats_kernel   getStatistics / getBlkStats :295-341, 943-1335     one workgroup per (CTU, component); HBM bound
+//   2. hevcdl_sao_decide_kernel  decideBlkParams / deriveModeNewRDO / deriveModeMergeRDO / deriveOffsets :421-941 with the
+//                                counter coder of TEncSbac.cpp:1543-1720; the CTUs of a picture are a serial chain (merge
+//                                candidates + adaptive contexts), pictures are independent: one lane per picture
+//   3. hevcdl_sao_apply_kernel   TComSampleAdaptiveOffset::offsetCTU / offsetBlock  TComSampleAdaptiveOffset.cpp:316-620; HBM bound
+// Statistics: per (type, class) sum of (org - deblocked) and count over the samples of the CTU whose neighbours exist and
+// that lie outside the margin the reference leaves out next to a right / lower CTU (5/4 luma, 3/2 chroma columns/rows).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hevcdl.h"
+#include "hevcdl_dev.h"
+
+namespace {
+
+#define GLB __attribute__((address_space(1)))
+enum { EO_0 = 0, EO_90, EO_135, EO_45, BO, NTYPES, MODE_OFF = 0, MODE_NEW, MODE_MERGE, MERGE_LEFT = 0, MERGE_ABOVE };
+constexpr double MAX_DOUBLE = 1.7e+308;
+
+__constant__ int32_t s_entropy_bits[128] = { // ContextModel.cpp:103-112 (FAST_BIT_EST)
+  0x07b23, 0x085f9, 0x074a0, 0x08cbc, 0x06ee4, 0x09354, 0x067f4, 0x09c1b, 0x060b0, 0x0a62a, 0x05a9c, 0x0af5b, 0x0548d, 0x0b955, 0x04f56, 0x0c2a9,
+  0x04a87, 0x0cbf7, 0x045d6, 0x0d5c3, 0x04144, 0x0e01b, 0x03d88, 0x0e937, 0x039e0, 0x0f2cd, 0x03663, 0x0fc9e, 0x03347, 0x10600, 0x03050, 0x10f95,
+  0x02d4d, 0x11a02, 0x02ad3, 0x12333, 0x0286e, 0x12cad, 0x02604, 0x136df, 0x02425, 0x13f48, 0x021f4, 0x149c4, 0x0203e, 0x1527b, 0x01e4d, 0x15d00,
+  0x01c99, 0x166de, 0x01b18, 0x17017, 0x019a5, 0x17988, 0x01841, 0x18327, 0x016df, 0x18d50, 0x015d9, 0x19547, 0x0147c, 0x1a083, 0x0138e, 0x1a8a3,
+  0x01251, 0x1b418, 0x01166, 0x1bd27, 0x01068, 0x1c77b, 0x00f7f, 0x1d18e, 0x00eda, 0x1d91a, 0x00e19, 0x1e254, 0x00d4f, 0x1ec9a, 0x00c90, 0x1f6e0,
+  0x00c01, 0x1fef8, 0x00b5f, 0x208b1, 0x00ab6, 0x21362, 0x00a15, 0x21e46, 0x00988, 0x2285d, 0x00934, 0x22ea8, 0x008a8, 0x239b2, 0x0081d, 0x24577,
+  0x007c9, 0x24ce6, 0x00763, 0x25663, 0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5, 0x0055e, 0x29057,
+  0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f, 0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb };
+__constant__ uint8_t s_next_mps[128] = { // ContextModel.cpp:68-101
+  2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
+  34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65,
+  66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97,
+  98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 124, 125, 126, 127 };
+__constant__ uint8_t s_next_lps[128] = {
+  1, 0, 0, 1, 2, 3, 4, 5, 4, 5, 8, 9, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 18, 19, 22, 23, 22, 23, 24, 25,
+  26, 27, 26, 27, 30, 31, 30, 31, 32, 33, 32, 33, 36, 37, 36, 37, 38, 39, 38, 39, 42, 43, 42, 43, 44, 45, 44, 45, 46, 47, 48, 49,
+  48, 49, 50, 51, 52, 53, 52, 53, 54, 55, 54, 55, 56, 57, 58, 59, 58, 59, 60, 61, 60, 61, 60, 61, 62, 63, 64, 65, 64, 65, 66, 67,
+  66, 67, 66, 67, 68, 69, 68, 69, 70, 71, 70, 71, 70, 71, 72, 73, 72, 73, 72, 73, 74, 75, 74, 75, 74, 75, 76, 77, 76, 77, 126, 127 };
+
+struct Stat { int32_t diff[32], count[32]; };                   // one (type) of one (CTU, component): 256 bytes
+struct Sbac { uint8_t merge_ctx, type_ctx; unsigned long long frac; };
+
+__device__ __forceinline__ int sgn(int v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// edge / band class of sample p for SAO type t
+__device__ __forceinline__ int sao_class(int t, const uint8_t GLB *p, int stride)
+{
+  const int c = p[0];
+  switch (t) {
+    case EO_0:   return 2 + sgn(c - p[-1]) + sgn(c - p[1]);
+    case EO_90:  return 2 + sgn(c - p[-stride]) + sgn(c - p[stride]);
+    case EO_135: return 2 + sgn(c - p[-stride - 1]) + sgn(c - p[stride + 1]);
+    case EO_45:  return 2 + sgn(c - p[-stride + 1]) + sgn(c - p[stride - 1]);
+    default:     return c >> 3;
+  }
+}
+
+// ---- decision (serial per picture, one lane) --------------------------------------------------------------------------
+__device__ void sb_bin(Sbac &c, uint8_t &ctx, int bin)
+{
+  const uint8_t s = ctx;
+  c.frac += (unsigned long long)s_entropy_bits[s ^ bin];
+  ctx = bin == (s & 1) ? s_next_mps[s] : s_next_lps[s];
+}
+__device__ void sb_ep(Sbac &c, int n) { c.frac += 32768ull * (unsigned long long)n; }
+__device__ uint32_t sb_bits(const Sbac &c) { return (uint32_t)(c.frac >> 15); }
+__device__ void sb_reset(Sbac &c) { c.frac &= 32767ull; }
+
+__device__ void code_offset_param(Sbac &c, int comp, const hevcdl_sao_offset &p)
+{ // codeSAOOffsetParam TEncSbac.cpp:1605-1681
+  const int first = comp != 2;
+  if (first) {
+    const int sym = p.mode == MODE_OFF ? 0 : (p.type == BO ? 1 : 2);
+    if (sym == 0) sb_bin(c, c.type_ctx, 0); else { sb_bin(c, c.type_ctx, 1); sb_ep(c, 1); }
+  }
+  if (p.mode == MODE_NEW) {
+    int off[4], k = 0;
+    const int ncls = p.type == BO ? 4 : 5;
+    for (int i = 0; i < ncls; i++) { if (p.type != BO && i == 2) continue; off[k++] = p.offset[p.type == BO ? (p.aux + i) % 32 : i]; }
+    for (int i = 0; i < 4; i++) { const int a = abs(off[i]); sb_ep(c, a == 0 ? 1 : (a < 7 ? a + 1 : a)); }
+    if (p.type == BO) { for (int i = 0; i < 4; i++) if (off[i]) sb_ep(c, 1); sb_ep(c, 5); }
+    else if (first) sb_ep(c, 2);
+  }
+}
+__device__ void code_blk_param(Sbac &c, const hevcdl_sao_blk &b, int left_avail, int above_avail, int only_merge)
+{ // codeSAOBlkParam TEncSbac.cpp:1683-1720
+  int is_left = 0, is_above = 0;
+  if (left_avail) { is_left = b.c[0].mode == MODE_MERGE && b.c[0].type == MERGE_LEFT; sb_bin(c, c.merge_ctx, is_left); }
+  if (above_avail && !is_left) { is_above = b.c[0].mode == MODE_MERGE && b.c[0].type == MERGE_ABOVE; sb_bin(c, c.merge_ctx, is_above); }
+  if (only_merge) return;
+  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_offset_param(c, comp, b.c[comp]);
+}
+__device__ long long est_dist(long long count, long long offset, long long diff) { return count * offset * offset - diff * offset * 2; }
+__device__ int est_iter_offset(int type, double lambda, int offset_in, long long count, long long diff, long long &best_dist, double &best_cost)
+{ // estIterOffset :465-496
+  int it = offset_in, out = 0;
+  double min_cost = lambda;
+  while (it != 0) {
+    long long rate = type == BO ? abs(it) + 2 : abs(it) + 1;
+    if (abs(it) == 7) rate--;
+    const long long dist = est_dist(count, it, diff);
+    const double cost = (double)dist + lambda * (double)rate;
+    if (cost < min_cost) { min_cost = cost; out = it; best_dist = dist; best_cost = cost; }
+    it = it > 0 ? it - 1 : it + 1;
+  }
+  return out;
+}
+__device__ void derive_offsets(int type, double lambda, const Stat GLB &st, int32_t *q, int32_t &aux)
+{ // deriveOffsets :498-615
+  const int ncls = type == BO ? 32 : 5;
+  for (int i = 0; i < 32; i++) q[i] = 0;
+  for (int cls = 0; cls < ncls; cls++) {
+    if (type != BO && cls == 2) continue;
+    if (st.count[cls] == 0) continue;
+    const double x = (double)st.diff[cls] / (double)st.count[cls];
+    int v = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);
+    q[cls] = v < -7 ? -7 : (v > 7 ? 7 : v);
+  }
+  if (type != BO) {
+    for (int cls = 0; cls < 5; cls++) {
+      long long d; double c;
+      if ((cls == 0 || cls == 1) && q[cls] < 0) q[cls] = 0;
+      if ((cls == 3 || cls == 4) && q[cls] > 0) q[cls] = 0;
+      if (q[cls] != 0) q[cls] = est_iter_offset(type, lambda, q[cls], st.count[cls], st.diff[cls], d, c);
+    }
+    aux = 0;
+  } else {
+    double cost[32], min_cost = MAX_DOUBLE;
+    for (int cls = 0; cls < 32; cls++) {
+      long long d; cost[cls] = lambda;
+      if (q[cls] != 0) q[cls] = est_iter_offset(type, lambda, q[cls], st.count[cls], st.diff[cls], d, cost[cls]);
+    }
+    for (int band = 0; band < 29; band++) {
+      double c = cost[band]; c += cost[band + 1]; c += cost[band + 2]; c += cost[band + 3];
+      if (c < min_cost) { min_cost = c; aux = band; }
+    }
+    for (int i = 0; i < 32; i++) { const int r = (i - aux) & 31; if (r >= 4) q[i] = 0; }
+  }
+}
+__device__ long long get_dist(int type, int aux, const int32_t *off, const Stat GLB &st)
+{ // getDistortion :421-457
+  long long d = 0;
+  if (type != BO) for (int i = 0; i < 5; i++) d += est_dist(st.count[i], off[i], st.diff[i]);
+  else for (int i = aux; i < aux + 4; i++) d += est_dist(st.count[i % 32], off[i % 32], st.diff[i % 32]);
+  return d;
+}
+
+__device__ void load_off(hevcdl_sao_offset &d, const hevcdl_sao_offset GLB &s_) { d.mode = s_.mode; d.type = s_.type; d.aux = s_.aux; for (int i = 0; i < 32; i++) d.offset[i] = s_.offset[i]; }
+__device__ void store_off(hevcdl_sao_offset GLB &d, const hevcdl_sao_offset &s_) { d.mode = s_.mode; d.type = s_.type; d.aux = s_.aux; for (int i = 0; i < 32; i++) d.offset[i] = s_.offset[i]; }
+
+} // namespace
+
+// stats[(frame * ctus + ctu) * 3 + comp][type]
+__global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params p)
+{
+  __shared__ int acc[NTYPES][2][32];
+  const int tid = threadIdx.x, a = blockIdx.x, comp = blockIdx.y, frame = blockIdx.z;
+  for (int i = tid; i < NTYPES * 64; i += 256) (&acc[0][0][0])[i] = 0;
+  __syncthreads();
+  const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
+  const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
+  const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh;
+  const int left = x0 > 0, above = y0 > 0, right = x0 + 64 < p.width, below = y0 + 64 < p.height;
+  const int skip_r = comp ? 3 : 5, skip_b = comp ? 2 : 4;
+  const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
+  const size_t off = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2))) + (size_t)(y0 >> sh) * stride + (x0 >> sh);
+  const uint8_t GLB *src = (const uint8_t GLB *)p.deblocked + off, *org = (const uint8_t GLB *)p.org + off;
+  // edge classes: private counters (branch-free), reduced over the wave on the DPP crossbar, 40 LDS atomics per wave;
+  // bands (32 classes, little contention): LDS atomics per sample
+  int eo_d[4][5], eo_c[4][5];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) { eo_d[t][k] = 0; eo_c[t][k] = 0; }
+  for (int i = tid; i < w * h; i += 256) {
+    const int y = i / w, x = i - y * w;
+    const uint8_t GLB *s = src + (size_t)y * stride + x;
+    const int d = (int)org[(size_t)y * stride + x] - (int)s[0];
+#pragma unroll
+    for (int t = 0; t < NTYPES; t++) {
+      const bool need_lr = (t == EO_0 || t == EO_135 || t == EO_45), need_ab = (t == EO_90 || t == EO_135 || t == EO_45);
+      const int sx = need_lr ? (left ? 0 : 1) : 0, ex = right ? w - skip_r : (need_lr ? w - 1 : w);
+      const int sy = need_ab ? (above ? 0 : 1) : 0, ey = below ? h - skip_b : (need_ab ? h - 1 : h);
+      if (x >= sx && x < ex && y >= sy && y < ey) {
+        const int cls = sao_class(t, s, stride);
+        if (t == BO) { atomicAdd(&acc[BO][0][cls], d); atomicAdd(&acc[BO][1][cls], 1); }
+        else {
+#pragma unroll
+          for (int k = 0; k < 5; k++) { eo_c[t < 4 ? t : 0][k] += (cls == k); eo_d[t < 4 ? t : 0][k] += (cls == k) ? d : 0; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      int vd = eo_d[t][k], vc = eo_c[t][k];
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0xB1, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0xB1, 0xf, 0xf, false);
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0x4E, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x4E, 0xf, 0xf, false);
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0x141, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x141, 0xf, 0xf, false);
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0x140, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x140, 0xf, 0xf, false);
+      if ((tid & 15) == 0) { atomicAdd(&acc[t][0][k], vd); atomicAdd(&acc[t][1][k], vc); }
+    }
+  __syncthreads();
+  Stat GLB *dst = (Stat GLB *)p.stats + ((size_t)(frame * p.ctus_per_frame + a) * 3 + comp) * NTYPES;
+  for (int i = tid; i < NTYPES * 64; i += 256) { const int t = i >> 6, r = i & 63; if (r < 32) dst[t].diff[r] = acc[t][0][r]; else dst[t].count[r - 32] = acc[t][1][r - 32]; }
+}
+
+// one lane per picture: the CTU chain of decideBlkParams
+__global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params p)
+{
+  const int frame = blockIdx.x * 64 + threadIdx.x;
+  if (frame >= p.n_frames) return;
+  const int cx = p.ctus_x, nctu = p.ctus_per_frame;
+  const double lambda[3] = { p.lambda, p.lambda_chroma, p.lambda_chroma };
+  const Stat GLB *stats = (const Stat GLB *)p.stats + (size_t)frame * nctu * 3 * NTYPES;
+  hevcdl_sao_blk GLB *params = (hevcdl_sao_blk GLB *)p.params + (size_t)frame * nctu;      // coded parameters
+  hevcdl_sao_blk GLB *recon = (hevcdl_sao_blk GLB *)p.recon_params + (size_t)frame * nctu; // reconstructed (merge resolved)
+  Sbac go, cur, next, mid, temp;
+  { // initRDOCabacCoder: I-slice contexts at the slice QP (ContextTables.h:445-458)
+    const int init[2] = { 153, 200 };
+    for (int i = 0; i < 2; i++) {
+      const int v = init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
+      int s = ((slope * p.qp) >> 4) + offset; s = s < 1 ? 1 : (s > 126 ? 126 : s);
+      const int mps = s >= 64; const uint8_t st = (uint8_t)(((mps ? s - 64 : 63 - s) << 1) + mps);
+      if (i == 0) go.merge_ctx = st; else go.type_ctx = st;
+    }
+    go.frac = 0;
+  }
+  next = go;
+  for (int a = 0; a < nctu; a++) {
+    const Stat GLB *st = stats + (size_t)a * 3 * NTYPES;
+    const bool left_av = a % cx > 0, above_av = a / cx > 0;
+    hevcdl_sao_blk best, mode;
+    double min_cost = MAX_DOUBLE;
+    cur = go;
+    { // ---- deriveModeNewRDO :617-758 ----
+      hevcdl_sao_offset test[3];
+      long long dist[3], mode_dist[3] = { 0, 0, 0 };
+      for (int c = 0; c < 3; c++) { mode.c[c].mode = MODE_OFF; mode.c[c].type = 0; mode.c[c].aux = 0; for (int i = 0; i < 32; i++) mode.c[c].offset[i] = 0; }
+      go = cur; code_blk_param(go, mode, left_av, above_av, 1); mid = go;
+      sb_reset(go); code_offset_param(go, 0, mode.c[0]);
+      double mc = lambda[0] * (double)sb_bits(go), cost;
+      temp = go;
+      for (int type = 0; type < NTYPES; type++) {
+        test[0].mode = MODE_NEW; test[0].type = type;
+        derive_offsets(type, lambda[0], st[0 * NTYPES + type], test[0].offset, test[0].aux);
+        dist[0] = get_dist(type, test[0].aux, test[0].offset, st[0 * NTYPES + type]);
+        go = mid; sb_reset(go); code_offset_param(go, 0, test[0]);
+        cost = (double)dist[0] + lambda[0] * (double)(int)sb_bits(go);
+        if (cost < mc) { mc = cost; mode_dist[0] = dist[0]; mode.c[0] = test[0]; temp = go; }
+      }
+      go = temp; mid = go;
+      cost = 0; sb_reset(go);
+      { uint32_t prev = 0; for (int c = 1; c < 3; c++) { code_offset_param(go, c, mode.c[c]); const uint32_t b = sb_bits(go); cost += lambda[c] * (double)(b - prev); prev = b; } }
+      mc = cost;
+      for (int type = 0; type < NTYPES; type++) {
+        uint32_t prev = 0;
+        go = mid; sb_reset(go); cost = 0;
+        for (int c = 1; c < 3; c++) {
+          test[c].mode = MODE_NEW; test[c].type = type;
+          derive_offsets(type, lambda[c], st[c * NTYPES + type], test[c].offset, test[c].aux);
+          dist[c] = get_dist(type, test[c].aux, test[c].offset, st[c * NTYPES + type]);
+          code_offset_param(go, c, test[c]);
+          const uint32_t b = sb_bits(go);
+          cost += (double)dist[c] + (lambda[c] * (double)(b - prev));
+          prev = b;
+        }
+        if (cost < mc) { mc = cost; for (int c = 1; c < 3; c++) { mode_dist[c] = dist[c]; mode.c[c] = test[c]; } }
+      }
+      double norm = 0;
+      for (int c = 0; c < 3; c++) norm += (double)mode_dist[c] / lambda[c];
+      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0);
+      norm += (double)sb_bits(go);
+      if (norm < min_cost) { min_cost = norm; best = mode; next = go; }
+    }
+    // ---- deriveModeMergeRDO :760-812 ----
+    for (int mt = 0; mt < 2; mt++) {
+      if (!(mt == MERGE_LEFT ? left_av : above_av)) continue;
+      const hevcdl_sao_blk GLB &m = recon[mt == MERGE_LEFT ? a - 1 : a - cx];
+      double nd = 0;
+      for (int c = 0; c < 3; c++) {
+        load_off(mode.c[c], m.c[c]);
+        if (m.c[c].mode != MODE_OFF) nd += ((double)get_dist(m.c[c].type, m.c[c].aux, mode.c[c].offset, st[c * NTYPES + m.c[c].type])) / lambda[c];
+        mode.c[c].mode = MODE_MERGE; mode.c[c].type = mt;
+      }
+      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0);
+      const double cost = nd + (double)(int)sb_bits(go);
+      if (cost < min_cost) { min_cost = cost; best = mode; next = go; }
+    }
+    go = next;
+    for (int c = 0; c < 3; c++) store_off(params[a].c[c], best.c[c]);
+    for (int c = 0; c < 3; c++) { // reconstructBlkSAOParam (offset step 1)
+      if (best.c[c].mode == MODE_MERGE) { hevcdl_sao_offset t; load_off(t, recon[best.c[c].type == MERGE_LEFT ? a - 1 : a - cx].c[c]); store_off(recon[a].c[c], t); }
+      else store_off(recon[a].c[c], best.c[c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hevcdl_sao_apply_kernel(hevcdl_sao_params p)
+{
+  const int tid = threadIdx.x, a = blockIdx.x, comp = blockIdx.y, frame = blockIdx.z;
+  const hevcdl_sao_offset GLB &prm = ((const hevcdl_sao_blk GLB *)p.recon_params)[(size_t)frame * p.ctus_per_frame + a].c[comp];
+  const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
+  const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
+  const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh;
+  const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
+  const size_t off = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2))) + (size_t)(y0 >> sh) * stride + (x0 >> sh);
+  const uint8_t GLB *src = (const uint8_t GLB *)p.deblocked + off; uint8_t GLB *res = (uint8_t GLB *)p.out + off;
+  const int mode = prm.mode, type = prm.type;
+  __shared__ int offs[32];
+  if (tid < 32) offs[tid] = (mode != MODE_OFF && (type == BO || tid < 5)) ? prm.offset[tid] : 0;
+  __syncthreads();
+  const bool need_lr = (type == EO_0 || type == EO_135 || type == EO_45), need_ab = (type == EO_90 || type == EO_135 || type == EO_45);
+  const int sx = (need_lr && x0 == 0) ? 1 : 0, ex = (need_lr && x0 + 64 >= p.width) ? w - 1 : w;
+  const int sy = (need_ab && y0 == 0) ? 1 : 0, ey = (need_ab && y0 + 64 >= p.height) ? h - 1 : h;
+  for (int i = tid; i < w * h; i += 256) {
+    const int y = i / w, x = i - y * w;
+    const uint8_t GLB *s = src + (size_t)y * stride + x;
+    int v = s[0];
+    if (mode != MODE_OFF && x >= sx && x < ex && y >= sy && y < ey) v = clip8(v + offs[sao_class(type, s, stride)]);
+    res[(size_t)y * stride + x] = (uint8_t)v;
+  }
+}
+
+extern "C" void hevcdl_launch_sao(const hevcdl_sao_params *pp, void *stream)
+{
+  const hevcdl_sao_params p = *pp;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(hevcdl_sao_stats_kernel, dim3(p.ctus_per_frame, 3, p.n_frames), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(hevcdl_sao_decide_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(hevcdl_sao_apply_kernel, dim3(p.ctus_per_frame, 3, p.n_frames), dim3(256), 0, s, p);
+}

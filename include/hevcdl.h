@@ -123,19 +123,34 @@ hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_
 hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *recon, int n_frames, const hevcdl_ctu_record *records, uint8_t *out);
 hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *d_recon, int n_frames, const void *d_records, void *d_out, void *stream);
 
+/* ---- sample adaptive offset (second in-loop filter) ---------------------------------------------------
+ * Replaces TEncSampleAdaptiveOffset::SAOProcess (TLibEncoder/TEncSampleAdaptiveOffset.cpp:244, called at TEncGOP.cpp:1797):
+ * statistics, per-CTU parameter decision (new / merge-left / merge-up / off, edge or band offsets) and the offset
+ * reconstruction.  org = the original frames, deblocked = output of hevcdl_deblock_frames; params receives the coded
+ * parameters of every CTU (what TEncSbac::codeSAOBlkParam writes), out the final reconstruction. */
+typedef struct hevcdl_sao_offset {
+  int32_t mode;        /* 0 off, 1 new, 2 merge (SAOMode, TypeDef.h:539-545) */
+  int32_t type;        /* new: 0..3 edge offset 0/90/135/45 degrees, 4 band offset; merge: 0 left, 1 above */
+  int32_t aux;         /* band position */
+  int32_t offset[32];  /* per class: edge classes 0..4 (2 = plain, always 0) or bands 0..31 */
+} hevcdl_sao_offset;
+typedef struct hevcdl_sao_blk { hevcdl_sao_offset c[3]; } hevcdl_sao_blk;      /* Y, Cb, Cr */
+hevcdl_status hevcdl_sao_frames(hevcdl_ctx *ctx, const uint8_t *org, const uint8_t *deblocked, int n_frames, hevcdl_sao_blk *params, uint8_t *out);
+hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_org, const void *d_deblocked, int n_frames, void *d_params, void *d_out, void *stream);
+
 /* ---- bitstream writer (host side; no GPU needed) ---------------------------------------------------
  * One access unit per picture exactly as the reference emits it for its all-intra configuration: VPS, SPS, PPS
  * (ReWriteParamSetsFlag 1), then one slice NAL (IDR_W_RADL for POC 0, CRA afterwards), Annex B start codes.
  * Replaces TEncGOP::compressGOP's parameter-set / slice writing (TEncGOP.cpp:1751-1756, 1895-1935), TEncCavlc::codeVPS /
  * codeSPS / codePPS / codeSliceHeader (TEncCavlc.cpp:677, 500, 189, 755), TEncSlice::encodeSlice (TEncSlice.cpp:985) and
  * the arithmetic coder TEncBinCABAC (TEncBinCoderCABAC.cpp:187-446) for the CTU records hevcdl_compress_frames
- * returns.  SAO is signalled off (sample_adaptive_offset_enabled_flag 0): that stage is not built; sao_enabled or
- * loop_filter_disable != 0 is answered with HEVCDL_ERR_UNSUPPORTED. */
+ * returns.  sao == NULL (cfg.sao_enabled 0): sample_adaptive_offset_enabled_flag 0; otherwise the [ctus] parameters
+ * hevcdl_sao_frames returned are coded in front of every CTU.  loop_filter_disable != 0 -> HEVCDL_ERR_UNSUPPORTED. */
 typedef struct hevcdl_stream_config {
   uint32_t struct_size;          /* sizeof(hevcdl_stream_config) */
   int32_t  width, height, qp;    /* as in hevcdl_config */
   int32_t  level_idc;            /* general_level_idc = 30 x Level (cfg key Level, TAppEncCfg.cpp:850): 6.2 -> 186, 3.1 -> 93 */
-  int32_t  sao_enabled;          /* must be 0 */
+  int32_t  sao_enabled;          /* 1 iff SAO parameters are passed to hevcdl_write_access_unit */
   int32_t  loop_filter_disable;  /* must be 0 (LoopFilterDisable 0: deblocking on, zero offsets, no PPS control fields) */
   int32_t  reserved;
 } hevcdl_stream_config;
@@ -143,7 +158,7 @@ hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width,
 size_t        hevcdl_access_unit_bound(int width, int height);
 /* records: the [ctus] records of picture `poc` (= frame index; POC lsb is 8 bits).  out_len is set even when the
  * buffer is too small (HEVCDL_ERR_INVALID_ARG), so the call can be repeated. */
-hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc, const hevcdl_ctu_record *records,
+hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc, const hevcdl_ctu_record *records, const hevcdl_sao_blk *sao,
                                        uint8_t *out, size_t capacity, size_t *out_len);
 
 /* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------

@@ -40,6 +40,13 @@ int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_fra
 /* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
 int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);
 
+/* Sample adaptive offset (oracle/hm_sao.c).  mode 0 off / 1 new / 2 merge; type: new -> 0..3 edge offset 0/90/135/45 degrees,
+ * 4 band offset; merge -> 0 left, 1 above; aux = band position; offset[class] (edge classes 0..4, bands 0..31). */
+typedef struct { int32_t mode, type, aux; int32_t offset[32]; } hm_sao_offset;
+typedef struct { hm_sao_offset c[3]; } hm_sao_blk;
+/* org, deblocked, out: planar 4:2:0 frames; params: [ctus] coded parameters (as written to the bitstream). */
+int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out);
+
 /* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */
 void hm_oracle_set_trace(const char *path);
 

@@ -209,6 +209,26 @@ def run_deblock(recon, width, height, qp, recs):
     return out
 
 
+SAO_DTYPE = np.dtype([("mode", "<i4"), ("type", "<i4"), ("aux", "<i4"), ("offset", "<i4", 32)])      # hm_sao_offset
+
+
+def run_sao(org, deblocked, width, height, qp):
+    """Oracle SAO of frames [n][w*h*3/2] -> (params [n][ctus][3] SAO_DTYPE, final reconstruction)."""
+    lib = oracle_lib()
+    lib.hm_oracle_sao_frame.restype = ctypes.c_int
+    lib.hm_oracle_sao_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    org = np.ascontiguousarray(org, np.uint8).reshape(-1, width * height * 3 // 2)
+    dbk = np.ascontiguousarray(deblocked, np.uint8).reshape(org.shape)
+    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    params = np.zeros((org.shape[0], nctu, 3), SAO_DTYPE)
+    out = np.zeros_like(org)
+    for f in range(org.shape[0]):
+        rc = lib.hm_oracle_sao_frame(org[f].ctypes.data, dbk[f].ctypes.data, width, height, qp, params[f].ctypes.data, out[f].ctypes.data)
+        if rc != 0:
+            raise RuntimeError("oracle sao failed rc=%d" % rc)
+    return params, out
+
+
 def ctu_recon_from_frame(recon_frame, width, height, addr):
     """Cut the 64x64 / 32x32 / 32x32 CTU blocks (zeros outside the picture) out of one planar frame."""
     cx = (width + 63) // 64

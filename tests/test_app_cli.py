@@ -62,7 +62,7 @@ def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
     c = json.loads(r.stdout)
     assert c["InputFile"] == "./in_192x128.yuv" and c["ReconFile"] == "./rec/rec.yuv"       # Windows paths of the reference cfgs
     assert (c["SourceWidth"], c["SourceHeight"], c["QP"], c["FramesToBeEncoded"], c["LabelDir"]) == (192, 128, 32, 1, "pred")
-    assert set(c["stage_keys"]) == {"SAO"} and c["errors"] == [] and c["level_idc"] == 93 and c["BitstreamFile"] == "./rec/str.bin"
+    assert c["stage_keys"] == [] and c["errors"] == [] and c["level_idc"] == 93 and c["BitstreamFile"] == "./rec/str.bin"
 
 
 def test_keys_that_change_the_path_are_rejected(app, tmp_path):
@@ -107,8 +107,10 @@ def test_cli_encode_matches_the_api(app, tmp_path):
     e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
     recs, recon, stats = e.compress_frames(yuv[skip:], labels)
     dbk = e.deblock_frames(recon, recs)
+    sao, final = e.sao_frames(yuv[skip:], dbk)
     e.close()
-    assert np.array_equal(np.fromfile(tmp_path / "rec" / "rec.yuv", np.uint8), dbk.reshape(-1))    # LoopFilterDisable : 0 in the cfg
+    assert np.array_equal(np.fromfile(tmp_path / "rec" / "rec.yuv", np.uint8), final.reshape(-1))  # LoopFilterDisable : 0, SAO : 1 in the cfg
+    dbk = final
     assert np.fromfile(tmp_path / "records.bin", np.uint8).tobytes() == recs.tobytes()
     lines = [l for l in r.stdout.splitlines() if l.startswith("POC")]
     s = metrics.Summary(w, h, 30)
@@ -117,13 +119,13 @@ def test_cli_encode_matches_the_api(app, tmp_path):
     for f in range(nf):
         d = (yuv[skip + f].astype(np.int64) - dbk[f].astype(np.int64)) ** 2
         p = s.add(0, (d[:ysz].sum(), d[ysz:ysz + ysz // 4].sum(), d[ysz + ysz // 4:].sum()))
-        au = hevcdl_amd.write_access_unit(w, h, qp, f, recs[f], level_idc=93)
+        au = hevcdl_amd.write_access_unit(w, h, qp, f, recs[f], level_idc=93, sao=sao[f])
         bits.append(len(au) * 8); stream += au
         assert lines[f].rsplit(" [ET", 1)[0] == metrics.frame_line(f, qp, len(au) * 8, p).rsplit(" [ET", 1)[0]
     s.bits = float(sum(bits))
     assert s.text().splitlines()[1].rstrip() in [l.rstrip() for l in r.stdout.splitlines()]
     assert (tmp_path / "rec" / "str.bin").read_bytes() == stream                       # -b from the cfg: the HM-format bitstream
-    r3 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-fs", str(skip), "--LabelDir=pred", "--LoopFilterDisable=1", "--BitstreamFile=", "-o", "rec_nofilter.yuv"], tmp_path)
+    r3 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-fs", str(skip), "--LabelDir=pred", "--LoopFilterDisable=1", "--SAO=0", "--BitstreamFile=", "-o", "rec_nofilter.yuv"], tmp_path)
     assert r3.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "rec_nofilter.yuv", np.uint8), recon.reshape(-1))
     # CNN labels when no label directory is given
     r2 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-o", "rec_cnn.yuv"], tmp_path)

@@ -70,7 +70,9 @@ def test_writer_rejects_what_it_does_not_implement():
     assert lib.hevcdl_stream_config_default(ctypes.byref(cfg), 60, 64, 32) != 0
     rec = np.zeros(1, hevcdl_amd.REC_DTYPE); buf = np.zeros(4096, np.uint8); n = ctypes.c_size_t(0)
     cfg.sao_enabled = 1
-    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, buf.ctypes.data, 4096, ctypes.byref(n)) == 2    # UNSUPPORTED
-    cfg.sao_enabled = 0
-    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, buf.ctypes.data, 8, ctypes.byref(n)) == 1 and n.value > 8
-    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, buf.ctypes.data, 4096, ctypes.byref(n)) == 0
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 1    # SAO flag without parameters
+    cfg.sao_enabled = 0; cfg.loop_filter_disable = 1
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 2    # UNSUPPORTED
+    cfg.loop_filter_disable = 0
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 8, ctypes.byref(n)) == 1 and n.value > 8
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 0
