@@ -155,43 +155,62 @@ __device__ void store_off(hevcdl_sao_offset GLB &d, const hevcdl_sao_offset &s_)
 
 } // namespace
 
-// stats[(frame * ctus + ctu) * 3 + comp][type]
+// stats[(frame * ctus + ctu) * 3 + comp][type].  The deblocked CTU (+1 sample halo) is staged in LDS with dword loads
+// (sample x of row y at tile[y + 1][x + 4]: dword aligned); a thread handles 4 horizontally adjacent samples per step.
 __global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params p)
 {
   __shared__ int acc[NTYPES][2][32];
+  __shared__ uint32_t tile[66][18];                                 // 72 bytes per row: 4 left pad + 64 + 4 right
   const int tid = threadIdx.x, a = blockIdx.x, comp = blockIdx.y, frame = blockIdx.z;
   for (int i = tid; i < NTYPES * 64; i += 256) (&acc[0][0][0])[i] = 0;
-  __syncthreads();
   const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
   const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
-  const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh;
+  const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh, ph = p.height >> sh;
   const int left = x0 > 0, above = y0 > 0, right = x0 + 64 < p.width, below = y0 + 64 < p.height;
   const int skip_r = comp ? 3 : 5, skip_b = comp ? 2 : 4;
   const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
-  const size_t off = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2))) + (size_t)(y0 >> sh) * stride + (x0 >> sh);
-  const uint8_t GLB *src = (const uint8_t GLB *)p.deblocked + off, *org = (const uint8_t GLB *)p.org + off;
-  // edge classes: private counters (branch-free), reduced over the wave on the DPP crossbar, 40 LDS atomics per wave;
-  // bands (32 classes, little contention): LDS atomics per sample
+  const size_t plane = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2)));
+  const int bx = x0 >> sh, by = y0 >> sh;
+  const uint8_t GLB *src = (const uint8_t GLB *)p.deblocked + plane, *org = (const uint8_t GLB *)p.org + plane;
+  const int wd = w >> 2;                                            // dwords per row (w is a multiple of 4)
+  for (int i = tid; i < (h + 2) * (wd + 2); i += 256) {             // rows -1..h, dword columns -1..wd (clamped inside the picture: unused there)
+    const int r = i / (wd + 2), c = i - r * (wd + 2);
+    int yy = by + r - 1, xx = bx + (c - 1) * 4;
+    yy = yy < 0 ? 0 : (yy >= ph ? ph - 1 : yy); xx = xx < 0 ? 0 : (xx + 4 > stride ? stride - 4 : xx);
+    tile[r][c] = *(const uint32_t GLB *)(src + (size_t)yy * stride + xx);
+  }
+  __syncthreads();
   int eo_d[4][5], eo_c[4][5];
 #pragma unroll
   for (int t = 0; t < 4; t++)
 #pragma unroll
     for (int k = 0; k < 5; k++) { eo_d[t][k] = 0; eo_c[t][k] = 0; }
-  for (int i = tid; i < w * h; i += 256) {
-    const int y = i / w, x = i - y * w;
-    const uint8_t GLB *s = src + (size_t)y * stride + x;
-    const int d = (int)org[(size_t)y * stride + x] - (int)s[0];
+  for (int i = tid; i < h * wd; i += 256) {
+    const int y = i / wd, xd = i - y * wd;
+    const uint32_t o4 = *(const uint32_t GLB *)(org + (size_t)(by + y) * stride + bx + xd * 4);
+    uint32_t row[3][3];
 #pragma unroll
-    for (int t = 0; t < NTYPES; t++) {
-      const bool need_lr = (t == EO_0 || t == EO_135 || t == EO_45), need_ab = (t == EO_90 || t == EO_135 || t == EO_45);
-      const int sx = need_lr ? (left ? 0 : 1) : 0, ex = right ? w - skip_r : (need_lr ? w - 1 : w);
-      const int sy = need_ab ? (above ? 0 : 1) : 0, ey = below ? h - skip_b : (need_ab ? h - 1 : h);
-      if (x >= sx && x < ex && y >= sy && y < ey) {
-        const int cls = sao_class(t, s, stride);
-        if (t == BO) { atomicAdd(&acc[BO][0][cls], d); atomicAdd(&acc[BO][1][cls], 1); }
-        else {
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int k = 0; k < 5; k++) { eo_c[t < 4 ? t : 0][k] += (cls == k); eo_d[t < 4 ? t : 0][k] += (cls == k) ? d : 0; }
+      for (int c = 0; c < 3; c++) row[r][c] = tile[y + r][xd + c];
+    auto px = [&](int r, int k) -> int { const int b = 4 + k; return (int)((row[r][b >> 2] >> (8 * (b & 3))) & 255u); };   // sample (y - 1 + r, 4 xd + k), k = -1..4
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int x = xd * 4 + k, c0 = px(1, k), d = (int)((o4 >> (8 * k)) & 255u) - c0;
+#pragma unroll
+      for (int t = 0; t < NTYPES; t++) {
+        const bool need_lr = (t == EO_0 || t == EO_135 || t == EO_45), need_ab = (t == EO_90 || t == EO_135 || t == EO_45);
+        const int sx = need_lr ? (left ? 0 : 1) : 0, ex = right ? w - skip_r : (need_lr ? w - 1 : w);
+        const int sy = need_ab ? (above ? 0 : 1) : 0, ey = below ? h - skip_b : (need_ab ? h - 1 : h);
+        if (x >= sx && x < ex && y >= sy && y < ey) {
+          if (t == BO) { atomicAdd(&acc[BO][0][c0 >> 3], d); atomicAdd(&acc[BO][1][c0 >> 3], 1); }
+          else {
+            const int n0 = t == EO_0 ? px(1, k - 1) : (t == EO_90 ? px(0, k) : (t == EO_135 ? px(0, k - 1) : px(0, k + 1)));
+            const int n1 = t == EO_0 ? px(1, k + 1) : (t == EO_90 ? px(2, k) : (t == EO_135 ? px(2, k + 1) : px(2, k - 1)));
+            const int cls = 2 + sgn(c0 - n0) + sgn(c0 - n1);
+#pragma unroll
+            for (int q = 0; q < 5; q++) { eo_c[t < 4 ? t : 0][q] += (cls == q); eo_d[t < 4 ? t : 0][q] += (cls == q) ? d : 0; }
+          }
         }
       }
     }

@@ -36,6 +36,22 @@ b.record(s); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / REPS
 fb = W * H * 3 // 2
 algo = F * (2 * fb + 2 * (W // 4) * (H // 4))            # read picture + write picture + depth/trIdx bytes of the records
-print(json.dumps({"stage": "deblock", "frames": F, "ms_per_batch": ms, "frames_per_s": F / ms * 1e3, "ctus_per_s": F * enc.ctus / ms * 1e3,
+out_line = (json.dumps({"stage": "deblock", "frames": F, "ms_per_batch": ms, "frames_per_s": F / ms * 1e3, "ctus_per_s": F * enc.ctus / ms * 1e3,
                   "algorithmic_GB": algo / 1e9, "achieved_GBps": algo / ms / 1e6, "peak_GBps": 8000.0, "frac": algo / ms / 1e6 / 8000.0}))
+print(out_line)
+# ---- SAO on the deblocked pictures ----
+d_org = torch.from_numpy(yuv[idx].copy()).to(dev)
+d_params = torch.empty((F, enc.ctus, 3 * hevcdl_amd.SAO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+d_final = torch.empty_like(d_recon)
+enc.sao_frames_dev(d_org.data_ptr(), d_out.data_ptr(), F, d_params.data_ptr(), d_final.data_ptr(), s.cuda_stream)
+torch.cuda.synchronize()
+o_par, o_fin = ref_tools.run_sao(yuv[:1], d_out[:1].cpu().numpy(), W, H, QP)
+assert np.array_equal(d_final[0].cpu().numpy(), o_fin[0]) and d_params[0].cpu().numpy().tobytes() == o_par[0].tobytes(), "SAO differs from the oracle"
+a.record(s)
+for _ in range(REPS):
+    enc.sao_frames_dev(d_org.data_ptr(), d_out.data_ptr(), F, d_params.data_ptr(), d_final.data_ptr(), s.cuda_stream)
+b.record(s); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / REPS
+algo = F * 3 * fb                          # read original + read deblocked + write final (statistics re-read the two inputs: counted once)
+print(json.dumps({"stage": "sao", "frames": F, "ms_per_batch": ms, "frames_per_s": F / ms * 1e3, "algorithmic_GB": algo / 1e9, "achieved_GBps": algo / ms / 1e6, "peak_GBps": 8000.0, "frac": algo / ms / 1e6 / 8000.0}))
 enc.close()
