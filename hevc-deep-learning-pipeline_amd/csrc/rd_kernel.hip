@@ -322,7 +322,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   PROF_ADD(k, 0);
 }
 
-DEVN void filter_refs(KR k, int n_)
+DEV void filter_refs(KR k, int n_)
 {
   PROF_T0();
   const int n = uni(n_); // TComPattern.cpp:203-293 (luma; strong smoothing for n == 32)
@@ -403,7 +403,7 @@ DEV int dc_value(KR k, LDS const int16_t *line, int n)
 }
 
 // prediction of an n x n TU (n <= 32) into s->pred (stride n)
-DEVN void predict_block(KR k, int c_, int mode_, int n_)
+DEV void predict_block(KR k, int c_, int mode_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), mode = uni(mode_), n = uni(n_);
@@ -523,7 +523,7 @@ template <int N, bool DST> DEV void inv_transform_n(KR k)
   }
   wsync();
 }
-DEVN void fwd_transform(KR k, int n_, int use_dst_)
+DEV void fwd_transform(KR k, int n_, int use_dst_)
 {
   const int n = uni(n_), use_dst = uni(use_dst_);
   if (n == 32) fwd_transform_n<32, false>(k);
@@ -532,7 +532,7 @@ DEVN void fwd_transform(KR k, int n_, int use_dst_)
   else if (use_dst) fwd_transform_n<4, true>(k);
   else fwd_transform_n<4, false>(k);
 }
-DEVN void inv_transform(KR k, int n_, int use_dst_)
+DEV void inv_transform(KR k, int n_, int use_dst_)
 {
   const int n = uni(n_), use_dst = uni(use_dst_);
   if (n == 32) inv_transform_n<32, false>(k);
@@ -681,7 +681,7 @@ DEV double rl_d(double v, int l)
 //     reference's level decision; per-position results go back to LDS lane-parallel;
 //   phase C: last-position search on lane 0, sign-data hiding with lane-parallel candidate costs.
 // Every fp64 accumulation is performed in the reference's order (the sums are not associative).
-DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
+DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
 {
   const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
   LSmem &s = lds();
@@ -1074,7 +1074,7 @@ DEVN uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_,
   return (uint32_t)uni((int)abs_sum);
 }
 
-DEVN void dequant(KR k, int c_, int n_)
+DEV void dequant(KR k, int c_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), n = uni(n_); // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
