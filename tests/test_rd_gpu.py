@@ -56,6 +56,37 @@ def test_matches_oracle_on_seeded_inputs(oracle_built, w, h, qp, nf, seed):
     assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
 
 
+@pytest.mark.parametrize("kind,qp,seed", [("noise", 22, 61), ("noise", 32, 62), ("texture", 27, 63), ("texture", 37, 64), ("edges", 22, 65), ("edges", 32, 66),
+                                         ("flat", 37, 67), ("mix", 17, 68), ("mix", 45, 69)])
+def test_matches_oracle_on_hard_content(oracle_built, kind, qp, seed):
+    """Content that drives the rarely taken branches (escape codes, Rice adaptation, sign hiding, transform skip, large
+    last positions, all-zero blocks): every field bit-exact against the oracle at every label depth."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, nf = 256, 192, 1
+    rng = np.random.default_rng(seed)
+    base = ref_tools.synth_yuv(w, h, nf, seed).astype(np.int64)
+    if kind == "noise":
+        yuv = rng.integers(0, 256, base.shape)
+    elif kind == "texture":
+        yuv = base + rng.normal(0, 25, base.shape).astype(np.int64)
+    elif kind == "edges":
+        yuv = (base // 64) * 64 + ((np.arange(base.shape[1]) // 3) % 2) * 90
+    elif kind == "flat":
+        yuv = np.full(base.shape, 97) + (rng.integers(0, 2, base.shape))
+    else:
+        yuv = np.where(rng.integers(0, 2, base.shape) > 0, base, rng.integers(0, 256, base.shape))
+    yuv = np.clip(yuv, 0, 255).astype(np.uint8)
+    labels = ref_tools.make_labels(w, h, nf, "rand", seed + 1)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels)
+    assert_records_equal(recs, o_recs, "%s qp%d" % (kind, qp))
+    assert np.array_equal(recon, o_recon)
+    assert np.array_equal(stats["est_bits"], o_stats["est_bits"])
+
+
 def test_per_ctu_session_equals_batch_and_rejects_disorder():
     """hevcdl_compress_ctu (compressCtu + encodeCtu of one CTU) called in coding order reproduces the batched path
     bit for bit; the coder state it returns can be fed back; out-of-order submission is an error, not a hang."""
