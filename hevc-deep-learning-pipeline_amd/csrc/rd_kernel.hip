@@ -1488,9 +1488,12 @@ DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
 }
 
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
-template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, int check_first_)
+// memo != 0 (second RD pass, TU == PU): the unsplit coding of this TU with this mode was evaluated in the first pass from
+// the same coder state -- (memo_dist, memo_cost) are its results, bit for bit what a re-run would give -- so only the
+// split alternative is evaluated; if the unsplit TU wins, its arrays / reconstruction come back from the saved best.
+template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, int check_first_, int memo_ = 0, uint32_t memo_dist = 0, double memo_cost = 0.0)
 {
-  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int check_first = uni(check_first_);
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int check_first = uni(check_first_), memo = uni(memo_);
   LSmem &s = lds();
   const int full_depth = cu.depth + tu.trd, zabs = cu.zbase + tu.zrel;
   const int check_full = LOG2 <= 5;
@@ -1498,7 +1501,8 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
   const int check_ts = (LOG2 == 2) && (cu.part == SIZE_NxN);
-  if (check_full) {
+  if (memo) { single_cost = memo_cost; single_dist = memo_dist; cabac_copy(k, &s.root[full_depth], &s.go); }
+  else if (check_full) {
     if (check_ts) {
       cabac_copy(k, &s.root[full_depth], &s.go);
       for (int m = 0; m < 2; m++) {
@@ -1534,7 +1538,8 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
   }
   if constexpr (LOG2 > 2) {
     if (check_split) {
-      if (check_full) { cabac_copy(k, &s.test[full_depth], &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
+      if (memo) { }
+      else if (check_full) { cabac_copy(k, &s.test[full_depth], &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
       else cabac_copy(k, &s.root[full_depth], &s.go);
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       for (int i = 0; i < 4; i++) {
@@ -1547,12 +1552,17 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
       split_cost = calc_rd_cost(k, bits, split_dist);
       if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost }; return r; }
-      cabac_copy(k, &s.go, &s.test[full_depth]);
-      set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
-      set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
-      set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
+      if (memo) { // the saved best candidate of the first pass IS the unsplit coding (sv_* / best_rec, est_intra_luma)
+        wsync();
+        for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = s.sv_tr[i]; s.a[A_CBF][zabs + i] = s.sv_cbf[0][i]; s.a[A_TSKIP][zabs + i] = s.sv_ts[0][i]; }
+      } else {
+        cabac_copy(k, &s.go, &s.test[full_depth]);
+        set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
+        set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
+        set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
+      }
       const int n = 1 << LOG2, bo = boff(k, 0, tu.x, tu.y);
-      GLB const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo;
+      GLB const uint8_t *rq = memo ? k.best_rec + bo : k.rec_l + (5 - LOG2) * 6144 + bo;
       GLB uint8_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
       wsync();
       for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * k.W + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
@@ -1595,14 +1605,14 @@ DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_)
   wsync();
   PROF_ADD(k, 15);
 }
-DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first)
+DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first, int memo = 0, uint32_t md = 0, double mc = 0.0)
 {
   switch (tu.log2) {
-    case 6: return recur_luma<6>(k, cu, tu, check_first);
-    case 5: return recur_luma<5>(k, cu, tu, check_first);
-    case 4: return recur_luma<4>(k, cu, tu, check_first);
-    case 3: return recur_luma<3>(k, cu, tu, check_first);
-    default: return recur_luma<2>(k, cu, tu, check_first);
+    case 6: return recur_luma<6>(k, cu, tu, check_first, memo, md, mc);
+    case 5: return recur_luma<5>(k, cu, tu, check_first, memo, md, mc);
+    case 4: return recur_luma<4>(k, cu, tu, check_first, memo, md, mc);
+    case 3: return recur_luma<3>(k, cu, tu, check_first, memo, md, mc);
+    default: return recur_luma<2>(k, cu, tu, check_first, memo, md, mc);
   }
 }
 
@@ -1790,7 +1800,11 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       const uint32_t org_mode = second ? best_mode : (uint32_t)uni((int)s.rd_list[m]);
       set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)org_mode);
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
-      const DistCost dc = recur_luma_any(k, cu, ptu, !second);
+      // second pass = the best first-pass mode again, now with TU splitting allowed (TEncSearch.cpp:2445-2512).  Its unsplit
+      // coding is a bit-exact repeat of the first pass (same mode, same references, same coder state): reuse it.
+      const int memo = second && pu_log2 <= 5;
+      if (memo && !(pu_log2 > min_tu_log2(cu))) continue;          // no split possible: the pass cannot change anything
+      const DistCost dc = recur_luma_any(k, cu, ptu, !second, memo, best_dist, best_cost);
       const uint32_t d = dc.dist; const double cost = dc.cost;
       if (ub(cost < best_cost)) {
         best_mode = org_mode; best_dist = d; best_cost = cost;
