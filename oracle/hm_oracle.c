@@ -153,6 +153,7 @@ typedef struct {
   const uint8_t *labels;                     /* labels of the current frame */
   /* per CTU */
   int cx, cy, addr;
+  int tx0, ty0, tx1, ty1;                         /* luma rectangle of the current tile (TComPicSym.cpp xInitTiles) */
   irec_t *r;
   cabac_t go, curr[5], next[5], temp[5], root[5], test[5], tbest[5];
   /* CU scratch, CTU-relative addressing */
@@ -196,6 +197,9 @@ static int unit_avail(const enc_t *e, int x4, int y4, int cur_x4, int cur_y4)
 { /* TComPattern.cpp:572-749 + TComDataCU.cpp:985-1200: inside the picture and already coded
      (earlier CTU in raster order, or earlier z-order inside the current CTU). */
   if (x4 < 0 || y4 < 0 || x4 * 4 >= e->W || y4 * 4 >= e->H) return 0;
+  /* another tile is never available (getPULeft/Above/AboveLeft/AboveRight/BelowLeft, bEnforceTileRestriction, TComDataCU.cpp:985-1200);
+     inside one tile the coding order of CTUs is still their raster order */
+  if (x4 * 4 < e->tx0 || y4 * 4 < e->ty0 || x4 * 4 >= e->tx1 || y4 * 4 >= e->ty1) return 0;
   int a = (y4 >> 4) * e->ctus_x + (x4 >> 4);
   if (a != e->addr) return a < e->addr;
   return g_r2z[((y4 & 15) << 4) | (x4 & 15)] < g_r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
@@ -871,7 +875,7 @@ static void code_coeff_nxn(cabac_t *c, const int32_t *coef, int comp, int n, int
 static void get_mpm(const enc_t *e, int x, int y, int preds[3], int *nmode)
 { /* getIntraDirPredictor TComDataCU.cpp:1362-1445 for the luma PU whose top-left sample is (x,y) */
   int left = DC, above = DC, z;
-  if (x > 0) { irec_t *r = rec_of(e, (x >> 2) - 1, y >> 2, &z); left = r->a[A_LDIR][z]; }
+  if (x > e->tx0) { irec_t *r = rec_of(e, (x >> 2) - 1, y >> 2, &z); left = r->a[A_LDIR][z]; }
   if ((y & 63) != 0) { irec_t *r = rec_of(e, x >> 2, (y >> 2) - 1, &z); above = r->a[A_LDIR][z]; }
   if (left == above) {
     if (nmode) *nmode = 1;
@@ -909,8 +913,8 @@ static void code_chroma_dir(enc_t *e, cabac_t *c, const cu_t *cu)
 static int split_ctx(const enc_t *e, int x, int y, int depth)
 { /* getCtxSplitFlag TComDataCU.cpp:1447-1461 */
   int ctx = 0, z;
-  if (x > 0) { irec_t *r = rec_of(e, (x >> 2) - 1, y >> 2, &z); ctx += r->a[A_DEPTH][z] > depth; }
-  if (y > 0) { irec_t *r = rec_of(e, x >> 2, (y >> 2) - 1, &z); ctx += r->a[A_DEPTH][z] > depth; }
+  if (x > e->tx0) { irec_t *r = rec_of(e, (x >> 2) - 1, y >> 2, &z); ctx += r->a[A_DEPTH][z] > depth; }
+  if (y > e->ty0) { irec_t *r = rec_of(e, x >> 2, (y >> 2) - 1, &z); ctx += r->a[A_DEPTH][z] > depth; }
   return ctx;
 }
 static inline int min_tu_log2(const cu_t *cu)
@@ -1533,6 +1537,14 @@ int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_fra
                             const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
                             hm_frame_stats *stats)
 {
+  return hm_oracle_encode_frames_tiles(yuv, width, height, n_frames, qp, labels, out_recs, recon, stats, 1, 1);
+}
+
+int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int n_frames, int qp,
+                                  const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
+                                  hm_frame_stats *stats, int tile_cols, int tile_rows)
+{
+  if (tile_cols < 1 || tile_rows < 1 || tile_cols > (width + 63) >> 6 || tile_rows > (height + 63) >> 6) return -1;
   if (width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51) return -1;
   init_tables();
   enc_t *e = (enc_t *)calloc(1, sizeof *e);
@@ -1565,10 +1577,17 @@ int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_fra
     for (int c = 0; c < 3; c++) memset(e->rec[c], 0, sizeof(pel) * (c ? csz : ysz));
     e->labels = labels + (size_t)f * nctu * 16;
     e->est_bits = 0;
-    cabac_t truec; cabac_init(&truec, qp);                /* TEncSlice.cpp:719-720, 804-807 */
-    for (int a = 0; a < nctu; a++) {
-      e->addr = a; e->cx = a % e->ctus_x; e->cy = a / e->ctus_x;
-      compress_ctu(e, &truec, a == nctu - 1);
+    /* CTUs in tile scan (tiles in raster order, CTUs in raster order inside a tile; uniform spacing TComPicSym.cpp:220-260);
+       the coder is re-initialised at the first CTU of every tile (TEncSlice.cpp:719-720, 804-807) */
+    for (int tr = 0; tr < tile_rows; tr++) for (int tc = 0; tc < tile_cols; tc++) {
+      const int cx0 = (tc * e->ctus_x) / tile_cols, cx1 = ((tc + 1) * e->ctus_x) / tile_cols;
+      const int cy0 = (tr * e->ctus_y) / tile_rows, cy1 = ((tr + 1) * e->ctus_y) / tile_rows;
+      e->tx0 = cx0 * 64; e->ty0 = cy0 * 64; e->tx1 = cx1 * 64; e->ty1 = cy1 * 64;
+      cabac_t truec; cabac_init(&truec, qp);
+      for (int cy = cy0; cy < cy1; cy++) for (int cx = cx0; cx < cx1; cx++) {
+        e->addr = cy * e->ctus_x + cx; e->cx = cx; e->cy = cy;
+        compress_ctu(e, &truec, e->addr == nctu - 1);
+      }
     }
     for (int a = 0; a < nctu; a++) {
       hm_ctu_record *o = out_recs + (size_t)f * nctu + a; const irec_t *r = e->recs + a;

@@ -36,6 +36,11 @@ typedef struct {
 int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_frames, int qp,
                             const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
                             hm_frame_stats *stats);
+/* The same with tile_cols x tile_rows uniformly spaced tiles (one slice; TileUniformSpacing 1): each tile is coded from a fresh
+ * coder state and sees nothing of the other tiles.  Records stay in raster CTU order. */
+int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int n_frames, int qp,
+                                  const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
+                                  hm_frame_stats *stats, int tile_cols, int tile_rows);
 
 /* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
 int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);

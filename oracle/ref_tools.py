@@ -177,7 +177,12 @@ def oracle_lib():
     return _lib
 
 
-def run_oracle(yuv, width, height, qp, labels, trace_path=None):
+def tile_args(tiles):
+    """Reference command-line switches for tiles = (columns, rows), uniformly spaced."""
+    return ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (tiles[0] - 1), "--NumTileRowsMinus1=%d" % (tiles[1] - 1)]
+
+
+def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1)):
     """Returns (records [frames][ctus] REC_DTYPE, recon uint8 [frames][w*h*3/2], stats [frames])."""
     lib = oracle_lib()
     yuv = np.ascontiguousarray(yuv, np.uint8)
@@ -187,8 +192,11 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None):
     recon = np.zeros_like(yuv)
     stats = np.zeros(n_frames, STATS_DTYPE)
     lib.hm_oracle_set_trace(trace_path.encode() if trace_path else None)
-    rc = lib.hm_oracle_encode_frames(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
-                                     recs.ctypes.data, recon.ctypes.data, stats.ctypes.data)
+    lib.hm_oracle_encode_frames_tiles.restype = ctypes.c_int
+    lib.hm_oracle_encode_frames_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    rc = lib.hm_oracle_encode_frames_tiles(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
+                                           recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tiles[0], tiles[1])
     lib.hm_oracle_set_trace(None)
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
