@@ -50,12 +50,14 @@ class Config(ctypes.Structure):
                 ("cnn_input", ctypes.c_int32), ("device", ctypes.c_int32), ("max_frames", ctypes.c_int32),
                 ("lambda_", ctypes.c_double), ("sqrt_lambda", ctypes.c_double), ("chroma_weight", ctypes.c_double),
                 ("lambda_chroma", ctypes.c_double), ("err_scale", (ctypes.c_double * 4) * 2),
-                ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32),
+                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class StreamConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("qp", ctypes.c_int32),
-                ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
+                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -155,17 +157,18 @@ def load_weights(path=WEIGHTS_PATH):
     return w
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0):
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1)):
     lib = load_library()
     cfg = Config()
     st = lib.hevcdl_config_default(ctypes.byref(cfg), width, height, qp)
     if st:
         raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
     cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
+    cfg.tile_columns, cfg.tile_rows = int(tiles[0]), int(tiles[1])        # uniformly spaced (columns, rows)
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1)):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -173,6 +176,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None):
     if st != 0:
         raise HevcdlError(st, "stream config")
     cfg.level_idc = level_idc
+    cfg.tile_columns, cfg.tile_rows = int(tiles[0]), int(tiles[1])
     sao_ptr = None
     if sao is not None:
         sao = np.ascontiguousarray(sao, SAO_DTYPE)
@@ -191,9 +195,10 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None):
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1)):
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles)
+        self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)
         self.width, self.height, self.qp = self.cfg.width, self.cfg.height, self.cfg.qp
         self.ctus = self.lib.hevcdl_ctus_per_frame(self.width, self.height)
         self.frame_bytes = self.lib.hevcdl_frame_bytes(self.width, self.height)

@@ -52,7 +52,7 @@ extern "C" hevcdl_status hevcdl_config_default(hevcdl_config *cfg, int width, in
   cfg->width = width; cfg->height = height; cfg->bit_depth = 8; cfg->chroma_format = 420; cfg->qp = qp;
   cfg->ctu_size = 64; cfg->max_partition_depth = 4; cfg->tu_log2_min = 2; cfg->tu_log2_max = 5; cfg->tu_max_depth_intra = 3;
   cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->bn_mode = HEVCDL_BN_REFERENCE; cfg->boundary_policy = HEVCDL_BOUNDARY_CLAMP;
-  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1;
+  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1; cfg->tile_columns = 1; cfg->tile_rows = 1;
   // TEncSlice::calculateLambda (TEncSlice.cpp:433-527) for an all-intra GOP of 1, then setUpLambda (:112-140)
   cfg->lambda = 0.57 * 1.0 * pow(2.0, (qp - 12) / 3.0);
   cfg->sqrt_lambda = sqrt(cfg->lambda);                         // TComRdCost::setLambda TComRdCost.cpp:109-122
@@ -108,6 +108,11 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
       cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || cfg->bn_mode != HEVCDL_BN_REFERENCE ||
       cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA))
     return HEVCDL_ERR_UNSUPPORTED;
+  { // tiles: uniform spacing, every column at least 4 CTUs wide and every row 1 CTU high (TComPicSym.cpp:380-392), at most 20 x 22 (level 6.2)
+    const int cx = (cfg->width + 63) >> 6, cy = (cfg->height + 63) >> 6;
+    if (cfg->tile_columns < 1 || cfg->tile_rows < 1 || cfg->tile_columns > 20 || cfg->tile_rows > 22 || cfg->tile_rows > cy) return HEVCDL_ERR_INVALID_ARG;
+    if (cfg->tile_columns > 1 || cfg->tile_rows > 1) for (int c = 0; c < cfg->tile_columns; c++) if (((c + 1) * cx) / cfg->tile_columns - (c * cx) / cfg->tile_columns < 4) return HEVCDL_ERR_INVALID_ARG;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return HEVCDL_ERR_NO_DEVICE;
   hevcdl_ctx *ctx = new (std::nothrow) hevcdl_ctx();
@@ -131,7 +136,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
   ctx->scratch_per_frame = hevcdl_rd_scratch_bytes();
-  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames));
+  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames * cfg->tile_columns * cfg->tile_rows));    // one workspace per (frame, tile) wave
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0)));
 #undef CK
@@ -196,6 +201,8 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   p.yuv = (const uint8_t *)d_yuv; p.labels = (const uint8_t *)d_labels; p.records = (unsigned char *)d_records; p.recon = (uint8_t *)d_recon;
   p.stats = (unsigned char *)d_stats; p.scratch = d_scratch ? (unsigned char *)d_scratch : ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_y = ctx->ctus_y; p.n_frames = n_frames;
+  p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
+  if (d_stats) HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(hevcdl_frame_stats) * (size_t)n_frames, s));     // the tile waves of a frame add into its entry
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
   p.k.sbh_rd_factor[0] = ctx->cfg.sbh_rd_factor[0]; p.k.sbh_rd_factor[1] = ctx->cfg.sbh_rd_factor[1];
@@ -205,7 +212,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (getenv("HEVCDL_DBGBUF")) { hipMalloc(&d_dbg, 8004 * 4); hipMemset(d_dbg, 0, 8004 * 4); p.dbgbuf = d_dbg; }
   prof_begin(ctx, ctx->ev_rd, s);
   // HEVCDL_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the number of resident waves per CU
-  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
+  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames * p.tile_cols * p.tile_rows), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
   if (d_dbg) {
@@ -401,6 +408,7 @@ extern "C" hevcdl_status hevcdl_compress_ctu(hevcdl_ctx *ctx, int frame, int ctu
                                              hevcdl_ctu_record *record, hevcdl_cabac_state *state_out_opt)
 {
   if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  if (ctx->cfg.tile_columns * ctx->cfg.tile_rows != 1) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "compress_ctu: the per-CTU session walks the untiled raster scan; with tiles use hevcdl_compress_frames");
   if (frame < 0 || frame >= ctx->session_frames) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "compress_ctu: frame outside the session (hevcdl_begin_frames)");
   if (ctu_addr < 0 || ctu_addr >= ctx->ctus || !record) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "compress_ctu: bad CTU address / null record");
   // the CTUs of a slice are a chain: neighbours' reconstruction and records must exist

@@ -48,6 +48,7 @@ struct hevcdl_rd_params {
   unsigned char *cabac_out;        // [frame] coder state after the last CTU processed, or NULL
   int ctu_begin, ctu_end;          // CTU address range [begin, end) in coding order
   int width, height, ctus_x, ctus_y, n_frames, debug;
+  int tile_cols, tile_rows;        // uniformly spaced tiles (1 x 1: none); one wave per (frame, tile)
   hevcdl_rd_consts k;
 };
 

@@ -97,6 +97,7 @@ struct K {                             // wave-uniform kernel context (lives in 
   GLB uint8_t *rec[3];
   GLB unsigned char *records;          // frame's records (global)
   GLB const uint8_t *labels;           // frame's labels
+  int tx0, ty0, tx1, ty1;              // luma rectangle of the tile being coded (the whole picture without tiles)
   GLB int16_t *coef_l;                 // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
   GLB uint8_t *rec_l;                  // scratch: [4 layers][6144] CTU-relative reconstruction
   GLB uint8_t *best_rec;               // scratch: [6144] best reconstruction of the CU under test
@@ -265,8 +266,9 @@ DEV int part_attr(KR k, int field, int x4, int y4)
 DEV int unit_avail(KR k, int x4, int y4, int cur_x4, int cur_y4)
 { // inside the picture and already coded: earlier CTU, or earlier z-order in this CTU (TComDataCU.cpp:985-1200)
   if (x4 < 0 || y4 < 0 || x4 * 4 >= k.W || y4 * 4 >= k.H) return 0;
+  if (x4 * 4 < k.tx0 || y4 * 4 < k.ty0 || x4 * 4 >= k.tx1 || y4 * 4 >= k.ty1) return 0;   // another tile is never available (bEnforceTileRestriction)
   const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4);
-  if (a != k.addr) return a < k.addr;
+  if (a != k.addr) return a < k.addr;                   // CTUs of one tile are coded in raster order
   return lds().r2z[((y4 & 15) << 4) | (x4 & 15)] < lds().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
 }
 
@@ -1217,7 +1219,7 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
 DEV void get_mpm(KR k, int x, int y, int preds[3], int *nmode)
 { // getIntraDirPredictor TComDataCU.cpp:1362-1445
   int left = DC, above = DC;
-  if (x > 0) left = part_attr(k, A_LDIR, (x >> 2) - 1, y >> 2);
+  if (x > k.tx0) left = part_attr(k, A_LDIR, (x >> 2) - 1, y >> 2);
   if ((y & 63) != 0) above = part_attr(k, A_LDIR, x >> 2, (y >> 2) - 1);
   if (left == above) {
     if (nmode) *nmode = 1;
@@ -1252,8 +1254,8 @@ DEV void code_chroma_dir(KR k, LCabac *c, const Cu &cu)
 DEV int split_ctx(KR k, int x, int y, int depth)
 { // getCtxSplitFlag TComDataCU.cpp:1447-1461
   int ctx = 0;
-  if (x > 0) ctx += part_attr(k, A_DEPTH, (x >> 2) - 1, y >> 2) > depth;
-  if (y > 0) ctx += part_attr(k, A_DEPTH, x >> 2, (y >> 2) - 1) > depth;
+  if (x > k.tx0) ctx += part_attr(k, A_DEPTH, (x >> 2) - 1, y >> 2) > depth;
+  if (y > k.ty0) ctx += part_attr(k, A_DEPTH, x >> 2, (y >> 2) - 1) > depth;
   return ctx;
 }
 DEV int min_tu_log2(const Cu &cu)
@@ -2105,7 +2107,8 @@ extern "C" __global__ __launch_bounds__(64)
 void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
 {
   LSmem &s = lds();
-  const int frame = blockIdx.x;
+  // one wave per (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
+  const int ntiles = p.tile_cols * p.tile_rows, unit = blockIdx.x, frame = unit / ntiles, tile = unit - frame * ntiles;
   if (frame >= p.n_frames) return;
   LDS K &k = s.k;                       // every lane stores the same values
   const int lane = lane_id();
@@ -2119,7 +2122,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   GLB unsigned char *records = (GLB unsigned char *)p.records + (size_t)frame * nctu * REC_SIZE;
   k.records = records;
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
-  GLB unsigned char *scr = (GLB unsigned char *)p.scratch + (size_t)frame * p.scratch_per_frame;
+  GLB unsigned char *scr = (GLB unsigned char *)p.scratch + (size_t)unit * p.scratch_per_frame;
   k.coef_l = (GLB int16_t *)scr; k.rec_l = scr + 4 * 6144 * 2; k.best_rec = scr + 4 * 6144 * 2 + 4 * 6144;
   k.q_cost = (GLB double *)(scr + 81920); k.q_rate = (GLB int32_t *)(scr + 81920 + 16384);
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
@@ -2171,8 +2174,15 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   }
   wsync();
 
-  for (int a = p.ctu_begin; a < p.ctu_end; a++) {
-    const int cx = a % p.ctus_x, cy = a / p.ctus_x;
+  // uniform tile spacing (TComPicSym.cpp xInitTiles); CTUs of the tile in raster order.  Without tiles the caller may give a CTU range.
+  const int tcx = tile % p.tile_cols, tcy = tile / p.tile_cols;
+  const int cx0 = (tcx * p.ctus_x) / p.tile_cols, cx1 = ((tcx + 1) * p.ctus_x) / p.tile_cols;
+  const int cy0 = (tcy * p.ctus_y) / p.tile_rows, cy1 = ((tcy + 1) * p.ctus_y) / p.tile_rows;
+  const int tw = cx1 - cx0;
+  k.tx0 = cx0 * 64; k.ty0 = cy0 * 64; k.tx1 = cx1 * 64; k.ty1 = cy1 * 64;
+  const int i_begin = ntiles == 1 ? p.ctu_begin : 0, i_end = ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0);
+  for (int i = i_begin; i < i_end; i++) {
+    const int cx = cx0 + i % tw, cy = cy0 + i / tw, a = cy * p.ctus_x + cx;
     wsync();
     k.addr = a; k.cx = cx; k.cy = cy;
     // initCtu TComDataCU.cpp:420-500
@@ -2215,16 +2225,21 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
     if (lane == 0) p.dbgbuf[0] = 40;
   }
 #endif
-  if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits
+  if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits; every tile adds its rectangle (the host zeroed the entry)
     GLB hevcdl_frame_stats *st = (GLB hevcdl_frame_stats *)p.stats + frame;
     for (int c = 0; c < 3; c++) {
-      const size_t npx = c ? csz : ysz; unsigned long long acc = 0;
+      const int sh = c ? 1 : 0, ps = p.width >> sh, rx0 = k.tx0 >> sh, ry0 = k.ty0 >> sh;
+      const int rw = ((k.tx1 < p.width ? k.tx1 : p.width) >> sh) - rx0, rh = ((k.ty1 < p.height ? k.ty1 : p.height) >> sh) - ry0;
+      unsigned long long acc = 0;
       GLB const uint8_t *po = org0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz)); GLB const uint8_t *pr = rec0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz));
-      for (size_t i = lane; i < npx; i += 64) { const int d = (int)po[i] - (int)pr[i]; acc += (unsigned long long)(d * d); }
+      for (int yy = 0; yy < rh; yy++) {
+        const size_t o = (size_t)(ry0 + yy) * ps + rx0;
+        for (int xx = lane; xx < rw; xx += 64) { const int d = (int)po[o + xx] - (int)pr[o + xx]; acc += (unsigned long long)(d * d); }
+      }
       for (int m = 32; m >= 1; m >>= 1) { unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32); lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m); acc += ((unsigned long long)hi << 32) | lo; }
-      if (lane == 0) st->sse[c] = acc;
+      if (lane == 0) __hip_atomic_fetch_add(&st->sse[c], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) { st->est_bits = s.est_bits; st->ctus = (uint32_t)nctu; st->pad = 0; }
+    if (lane == 0) { __hip_atomic_fetch_add(&st->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tile == 0) { st->ctus = (uint32_t)nctu; st->pad = 0; } }
   }
 }
 

@@ -67,6 +67,10 @@ typedef struct hevcdl_config {
   double   err_scale[2][4];      /* [luma/chroma][log2(TU)-2] */
   int64_t  sbh_rd_factor[2];     /* [luma/chroma] */
   int32_t  qp_chroma;
+  /* uniformly spaced tiles (cfg keys TileUniformSpacing 1, NumTileColumnsMinus1 + 1, NumTileRowsMinus1 + 1; TAppEncCfg.cpp:1024-1028);
+   * 1 x 1 = no tiles.  Every tile is at least 4 CTUs wide (the reference's own limit, TComPicSym.cpp:388).  Tiles are independent
+   * units of the decision path: one wavefront per (frame, tile). */
+  int32_t  tile_columns, tile_rows;
   int32_t  reserved;
 } hevcdl_config;
 
@@ -152,6 +156,8 @@ typedef struct hevcdl_stream_config {
   int32_t  level_idc;            /* general_level_idc = 30 x Level (cfg key Level, TAppEncCfg.cpp:850): 6.2 -> 186, 3.1 -> 93 */
   int32_t  sao_enabled;          /* 1 iff SAO parameters are passed to hevcdl_write_access_unit */
   int32_t  loop_filter_disable;  /* must be 0 (LoopFilterDisable 0: deblocking on, zero offsets, no PPS control fields) */
+  int32_t  tile_columns, tile_rows; /* as in hevcdl_config: PPS tile syntax (loop_filter_across_tiles_enabled_flag 1), CTUs in tile scan,
+                                       one sub-stream per tile with entry points in the slice header */
   int32_t  reserved;
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);

@@ -31,7 +31,8 @@ def test_golden_records_bit_exact(path):
     f = np.load(path)
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     yuv, labels, ref = f["yuv"], f["labels"], f["records"]
-    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0])
+    tiles = tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)     # rd_t*: reference runs with tiles enabled
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles)
     recs, recon, stats = enc.compress_frames(yuv, labels)
     enc.close()
     assert_records_equal(recs, ref, os.path.basename(path))
@@ -54,6 +55,27 @@ def test_matches_oracle_on_seeded_inputs(oracle_built, w, h, qp, nf, seed):
     assert_records_equal(recs, o_recs, "oracle %dx%d" % (w, h))
     assert np.array_equal(recon, o_recon)
     assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
+
+
+@pytest.mark.parametrize("w,h,qp,nf,seed,tiles", [(768, 192, 32, 2, 44, (3, 2)), (520, 200, 25, 1, 45, (2, 4)), (1280, 64, 36, 1, 46, (5, 1))])
+def test_tiles_match_oracle(oracle_built, w, h, qp, nf, seed, tiles):
+    """Tiles (uniform spacing): one wave per (frame, tile); records, reconstruction and the per-frame sums equal the oracle's tile run."""
+    import hevcdl_amd
+    import ref_tools
+    yuv = ref_tools.synth_yuv(w, h, nf, seed)
+    labels = ref_tools.make_labels(w, h, nf, "rand", seed + 1)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    with pytest.raises(hevcdl_amd.HevcdlError):       # the per-CTU session is the untiled raster walk
+        enc.begin_frames(yuv, labels)
+        enc.compress_ctu(0, 0)
+    enc.close()
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels, tiles=tiles)
+    assert_records_equal(recs, o_recs, "oracle tiles %dx%d" % (w, h))
+    assert np.array_equal(recon, o_recon)
+    assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
+    u_recs, _, _ = ref_tools.run_oracle(yuv, w, h, qp, labels)
+    assert any(not np.array_equal(o_recs[k], u_recs[k]) for k in FIELDS)      # the tiling does change the decisions
 
 
 @pytest.mark.parametrize("kind,qp,seed", [("noise", 22, 61), ("noise", 32, 62), ("texture", 27, 63), ("texture", 37, 64), ("edges", 22, 65), ("edges", 32, 66),
