@@ -42,19 +42,19 @@ const Key KEYS[] = {
   { "QuadtreeTULog2MaxSize", 0, PATH, "5" }, { "QuadtreeTULog2MinSize", 0, PATH, "2" }, { "QuadtreeTUMaxDepthIntra", 0, PATH, "3" },
   { "IntraPeriod", 0, PATH, "1" }, { "GOPSize", 0, PATH, "1" }, { "MaxDeltaQP", 0, PATH, "0" }, { "DeltaQpRD", 0, PATH, "0" },
   { "RDOQ", 0, PATH, "1" }, { "RDOQTS", 0, PATH, "1" }, { "TransformSkip", 0, PATH, "1" }, { "TransformSkipFast", 0, PATH, "1" },
-  { "SignHideFlag", "SBH", PATH, "1" }, { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, PATH, "0" },
-  { "NumTileRowsMinus1", 0, PATH, "0" }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
+  { "SignHideFlag", "SBH", PATH, "1" }, { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, USED, 0 },
+  { "NumTileRowsMinus1", 0, USED, 0 }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stages that are not built: accepted, reported once
   { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, PATH, "1" }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
   { "LoopFilterBetaOffset_div2", 0, PATH, "0" }, { "LoopFilterTcOffset_div2", 0, PATH, "0" },
   { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, USED, 0 }, { "SAOLcuBoundary", 0, PATH, "0" }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
-  { "LFCrossTileBoundaryFlag", 0, NOEFFECT, 0 }, { "SEIDecodedPictureHash", 0, PATH, "0" },
+  { "LFCrossTileBoundaryFlag", 0, USED, 0 }, { "SEIDecodedPictureHash", 0, PATH, "0" },
   // no effect on an all-intra slice with the settings above
   { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
   { "FEN", 0, NOEFFECT, 0 }, { "FDM", 0, NOEFFECT, 0 }, { "AMP", 0, NOEFFECT, 0 }, { "MaxCuDQPDepth", 0, NOEFFECT, 0 }, { "SliceArgument", 0, NOEFFECT, 0 },
   { "PCMLog2MaxSize", 0, NOEFFECT, 0 }, { "PCMLog2MinSize", 0, NOEFFECT, 0 }, { "PCMInputBitDepthFlag", 0, NOEFFECT, 0 },
-  { "PCMFilterDisableFlag", 0, NOEFFECT, 0 }, { "TileUniformSpacing", 0, NOEFFECT, 0 }, { "TileColumnWidthArray", 0, NOEFFECT, 0 },
+  { "PCMFilterDisableFlag", 0, NOEFFECT, 0 }, { "TileUniformSpacing", 0, USED, 0 }, { "TileColumnWidthArray", 0, NOEFFECT, 0 },
   { "TileRowHeightArray", 0, NOEFFECT, 0 }, { "ScalingListFile", 0, NOEFFECT, 0 },
 };
 
@@ -148,10 +148,16 @@ int main(int argc, char **argv)
   const int level_idc = (int)(atof(opt.get("Level", "6.2").c_str()) * 30.0 + 0.5);      // general_level_idc
   const bool deblock = opt.geti("LoopFilterDisable", 0) == 0;
   const bool sao = opt.geti("SAO", 1) != 0;                                    // TAppEncCfg.cpp: SAO defaults to on
+  // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows; the in-loop filters cross tile borders (LFCrossTileBoundaryFlag 1, the default)
+  const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
+  if (tile_cols * tile_rows > 1) {
+    if (opt.geti("TileUniformSpacing", 0) != 1) opt.errors.push_back("tiles are implemented with TileUniformSpacing = 1 only");
+    if (opt.geti("LFCrossTileBoundaryFlag", 1) != 1) opt.errors.push_back("tiles are implemented with LFCrossTileBoundaryFlag = 1 only");
+  }
   if (opt.v.count("PrintConfig")) {
     printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
-           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"BitstreamFile\": \"%s\", \"level_idc\": %d, \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
-           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str(), json_escape(bitstream_path).c_str(), level_idc);
+           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"BitstreamFile\": \"%s\", \"level_idc\": %d, \"tiles\": [%d, %d], \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
+           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str(), json_escape(bitstream_path).c_str(), level_idc, tile_cols, tile_rows);
     for (size_t i = 0; i < stage_keys.size(); i++) printf("%s\"%s\"", i ? ", " : "", stage_keys[i].c_str());
     printf("], \"errors\": [");
     for (size_t i = 0; i < opt.errors.size(); i++) printf("%s\"%s\"", i ? ", " : "", json_escape(opt.errors[i]).c_str());
@@ -176,6 +182,7 @@ int main(int argc, char **argv)
   hevcdl_status st = hevcdl_config_default(&cfg, width, height, qp);
   if (st != HEVCDL_OK) { fprintf(stderr, "Error: unsupported picture size / QP (status %d)\n", (int)st); return 2; }
   cfg.max_frames = batch; cfg.device = (int)opt.geti("Device", 0);
+  cfg.tile_columns = tile_cols; cfg.tile_rows = tile_rows;
   cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
   std::string wpath = opt.get("Weights");
   if (wpath.empty()) { // next to the library: <pkg>/weights/hevc_encoder_model.f32, this binary lives in <pkg>/bin
@@ -188,6 +195,7 @@ int main(int argc, char **argv)
     fclose(fw); }
   hevcdl_ctx *ctx = nullptr;
   st = hevcdl_create(&cfg, weights.data(), weights.size(), &ctx);
+  if (st == HEVCDL_ERR_INVALID_ARG) { fprintf(stderr, "Error: invalid configuration (tiles must be at least 4 CTUs wide and 1 CTU high)\n"); return 2; }
   if (st != HEVCDL_OK) { fprintf(stderr, "Error: hevcdl_create failed with status %d (no GPU / unsupported configuration); there is no CPU path\n", (int)st); return 3; }
 
   printf("HEVC-DL MI355X path: %dx%d  QP %d  frames %ld (skip %ld)  batch %d  labels: %s\n", width, height, qp, n_frames, frame_skip, batch,
@@ -209,7 +217,7 @@ int main(int argc, char **argv)
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
   if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
-  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao;
+  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows;
   std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
   std::vector<uint8_t> au(hevcdl_access_unit_bound(width, height));
   const double ny = (double)width * height, nc = ny / 4;

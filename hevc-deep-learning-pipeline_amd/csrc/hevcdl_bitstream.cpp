@@ -86,6 +86,14 @@ void put_nal(std::vector<uint8_t> &out, int type, const std::vector<uint8_t> &rb
   if (!rbsp.empty() && rbsp.back() == 0) out.push_back(3);          // NALwrite.cpp:112-118 (cabac_zero_words guard)
 }
 
+// TComOutputBitstream::countStartCodeEmulations TComBitStream.cpp:198-228: emulation prevention bytes this byte string will receive
+uint32_t count_emulations(const std::vector<uint8_t> &b)
+{
+  uint32_t cnt = 0; int zeros = 0;
+  for (uint8_t v : b) { if (zeros >= 2 && v <= 3) { cnt++; zeros = 0; } zeros = v == 0 ? zeros + 1 : 0; }
+  return cnt;
+}
+
 void profile_tier_level(BitOut &w, int level_idc)
 { // codePTL / codeProfileTier, Main profile (TAppEncCfg: Profile main => compatibility flags 1 and 2)
   w.write(0, 2); w.flag(0); w.write(1, 5);
@@ -165,6 +173,7 @@ struct Cabac {
 // ---- picture-level view of the CTU records -----------------------------------------------------------------------------
 struct Pic {
   const hevcdl_ctu_record *recs; int W, H, ctus_x;
+  int tx0 = 0, ty0 = 0;                 // top-left luma sample of the tile being written: nothing left of / above it is a neighbour
   uint8_t r2z[256];
   Pic(const hevcdl_ctu_record *r, int w, int h) : recs(r), W(w), H(h), ctus_x((w + 63) >> 6)
   {
@@ -324,7 +333,7 @@ void code_luma_dirs(Cabac &c, const Pic &p, const Cu &cu, int npu)
     const int px = cu.x + (j & 1) * pu_size, py = cu.y + (j >> 1) * pu_size;
     dir[j] = cu.r->luma_dir[cu.zbase + j * (cu.nparts >> 2) * (cu.part == SIZE_NxN)];
     int left = DC, above = DC;
-    if (px > 0) left = luma_mode_at(p, (px >> 2) - 1, py >> 2);
+    if (px > p.tx0) left = luma_mode_at(p, (px >> 2) - 1, py >> 2);
     if ((py & 63) != 0) above = luma_mode_at(p, px >> 2, (py >> 2) - 1);
     if (left == above) {
       if (left > 1) { preds[j][0] = left; preds[j][1] = ((left + 29) % 32) + 2; preds[j][2] = ((left - 1) % 32) + 2; }
@@ -431,8 +440,8 @@ void code_cu_tree(Cabac &c, const Pic &p, int x, int y, int depth)
   if (x + size <= p.W && y + size <= p.H) {
     if (depth < 3) {
       int sctx = 0;
-      if (x > 0) sctx += depth_at(p, (x >> 2) - 1, y >> 2) > depth;
-      if (y > 0) sctx += depth_at(p, x >> 2, (y >> 2) - 1) > depth;
+      if (x > p.tx0) sctx += depth_at(p, (x >> 2) - 1, y >> 2) > depth;
+      if (y > p.ty0) sctx += depth_at(p, x >> 2, (y >> 2) - 1) > depth;
       c.bin(CTX_SPLIT + sctx, r.depth[z] > depth);
     }
   } else boundary = 1;
@@ -457,6 +466,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
+  cfg->tile_columns = 1; cfg->tile_rows = 1;
   return HEVCDL_OK;
 }
 
@@ -472,6 +482,9 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51) return HEVCDL_ERR_INVALID_ARG;
   if (cfg->loop_filter_disable) return HEVCDL_ERR_UNSUPPORTED;                          // the PPS below signals deblocking on
   if ((cfg->sao_enabled != 0) != (sao != nullptr)) return HEVCDL_ERR_INVALID_ARG;         // SAO parameters go with sample_adaptive_offset_enabled_flag
+  const int tcols = cfg->tile_columns, trows = cfg->tile_rows, tiled = tcols * trows > 1;
+  if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22 || trows > ((cfg->height + 63) >> 6)) return HEVCDL_ERR_INVALID_ARG;
+  if (tiled) for (int c = 0; c < tcols; c++) if (((c + 1) * ((cfg->width + 63) >> 6)) / tcols - (c * ((cfg->width + 63) >> 6)) / tcols < 4) return HEVCDL_ERR_INVALID_ARG;   // TComPicSym.cpp:388
   std::vector<uint8_t> au;
   { // VPS  TEncCavlc.cpp:677-753
     BitOut w;
@@ -503,7 +516,9 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     BitOut w;
     w.ue(0); w.ue(0); w.flag(0); w.flag(0); w.write(0, 3); w.flag(1); w.flag(1); w.ue(3); w.ue(3);
     w.se(0); w.flag(0); w.flag(1); w.flag(0);        // init_qp_minus26 0, constrained intra, transform skip, cu_qp_delta
-    w.se(0); w.se(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0);
+    w.se(0); w.se(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0);      // chroma qp offsets, slice chroma offsets present, weighted (bi)pred, transquant bypass
+    w.flag(tiled); w.flag(0);                        // tiles_enabled_flag, entropy_coding_sync_enabled_flag
+    if (tiled) { w.ue((uint32_t)tcols - 1); w.ue((uint32_t)trows - 1); w.flag(1); w.flag(1); }   // uniform_spacing_flag, loop_filter_across_tiles_enabled_flag (:228-246)
     w.flag(1); w.flag(0);                            // loop filter across slices, deblocking_filter_control_present
     w.flag(0); w.flag(0); w.ue(0); w.flag(0); w.flag(0);
     w.trailing();
@@ -517,17 +532,37 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     if (cfg->sao_enabled) { w.flag(1); w.flag(1); }
     w.se(cfg->qp - 26);
     w.flag(1);                                       // slice_loop_filter_across_slices_enabled_flag
-    w.trailing();                                    // byte_alignment()
-    Cabac c(w, cfg->qp);
-    const Pic pic(records, cfg->width, cfg->height);
-    const int ctus = pic.ctus_x * ((cfg->height + 63) >> 6);
-    for (int a = 0; a < ctus; a++) {
-      if (sao) code_sao_blk(c, sao[a], a % pic.ctus_x > 0, a / pic.ctus_x > 0);
-      code_cu_tree(c, pic, (a % pic.ctus_x) * 64, (a / pic.ctus_x) * 64, 0);
-      c.terminate(a == ctus - 1);                    // end_of_slice_segment_flag (TEncCu.cpp:1112-1128, TEncSlice.cpp:1136)
+    // slice data: one sub-stream per tile, tiles in raster order, CTUs in raster order inside a tile (TEncSlice.cpp:1030-1145).  Every
+    // sub-stream starts from the slice-start contexts and ends with a terminating 1 bin (end_of_slice_segment_flag of the last CTU /
+    // end_of_subset_one_bit of the others), the coder flush and byte_alignment().
+    Pic pic(records, cfg->width, cfg->height);
+    const int ctus_y = (cfg->height + 63) >> 6, ctus = pic.ctus_x * ctus_y;
+    std::vector<BitOut> sub((size_t)tcols * trows);
+    for (int tr = 0; tr < trows; tr++) for (int tc = 0; tc < tcols; tc++) {
+      const int cx0 = (tc * pic.ctus_x) / tcols, cx1 = ((tc + 1) * pic.ctus_x) / tcols, cy0 = (tr * ctus_y) / trows, cy1 = ((tr + 1) * ctus_y) / trows;
+      BitOut &sw = sub[(size_t)tr * tcols + tc];
+      Cabac c(sw, cfg->qp);
+      pic.tx0 = cx0 * 64; pic.ty0 = cy0 * 64;
+      for (int cy = cy0; cy < cy1; cy++) for (int cx = cx0; cx < cx1; cx++) {
+        const int a = cy * pic.ctus_x + cx;
+        if (sao) code_sao_blk(c, sao[a], cx > cx0, cy > cy0);      // merge candidates stay inside the tile (TComPic::getSAOMergeAvailability)
+        code_cu_tree(c, pic, cx * 64, cy * 64, 0);
+        if (a != ctus - 1) c.terminate(0);           // end_of_slice_segment_flag 0 (finishCU TEncCu.cpp:1112-1128)
+      }
+      c.terminate(1);                                // TEncSlice.cpp:1136
+      c.finish();
+      sw.trailing();
     }
-    c.finish();
-    w.trailing();
+    if (tiled) { // entry points: TEncCavlc::codeTilesWPPEntryPoint :1207-1240; a size counts the emulation prevention bytes of its sub-stream
+      std::vector<uint32_t> size(sub.size() - 1);
+      uint32_t max_size = 0;
+      for (size_t i = 0; i + 1 < sub.size(); i++) { size[i] = (uint32_t)sub[i].b.size() + count_emulations(sub[i].b); if (size[i] > max_size) max_size = size[i]; }
+      int len_m1 = 0; while (max_size >= (1u << (len_m1 + 1))) len_m1++;
+      w.ue((uint32_t)size.size());
+      if (!size.empty()) { w.ue((uint32_t)len_m1); for (uint32_t v : size) w.write(v - 1, len_m1 + 1); }
+    }
+    w.trailing();                                    // byte_alignment()
+    for (const BitOut &sw : sub) w.b.insert(w.b.end(), sw.b.begin(), sw.b.end());
     put_nal(au, idr ? 19 : 21, w.b, false);          // IDR_W_RADL, then CRA (DecodingRefreshType 1)
   }
   *out_len = au.size();

@@ -69,6 +69,7 @@ struct hevcdl_sao_params {
   unsigned char *params;           // [frame][ctu] hevcdl_sao_blk: coded parameters
   unsigned char *recon_params;     // [frame][ctu] hevcdl_sao_blk: merge candidates resolved
   int width, height, ctus_x, ctus_per_frame, n_frames, qp;
+  int tile_cols, tile_rows;        // merge candidates stay inside a tile
   double lambda, lambda_chroma;
 };
 

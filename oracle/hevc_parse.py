@@ -97,7 +97,11 @@ def parse_pps(n):
     if f["cu_qp_delta"]:
         f["diff_cu_qp_delta_depth"] = r.ue()
     f["cb_off"] = r.se(); f["cr_off"] = r.se(); f["slice_chroma_off"] = r.u(1); f["wp"] = r.u(1); f["wbp"] = r.u(1)
-    f["tq_bypass"] = r.u(1); f["tiles"] = r.u(1); f["wpp"] = r.u(1); assert not f["tiles"]
+    f["tq_bypass"] = r.u(1); f["tiles_enabled"] = r.u(1); f["wpp"] = r.u(1); assert not f["wpp"]
+    if f["tiles_enabled"]:
+        f["tile_columns"] = r.ue() + 1; f["tile_rows"] = r.ue() + 1; f["uniform_spacing"] = r.u(1)
+        assert f["uniform_spacing"]
+        f["lf_across_tiles"] = r.u(1)
     f["lf_across_slices"] = r.u(1); f["dbk_control"] = r.u(1)
     if f["dbk_control"]:
         f["dbk_override"] = r.u(1); f["dbk_disabled"] = r.u(1)
@@ -129,4 +133,16 @@ def parse_slice_header(n, sps, pps):
     if pps.get("dbk_override"):
         f["dbk_override_flag"] = r.u(1)
     f["header_bits"] = r.p
+    if pps["lf_across_slices"]:             # deblocking on (and / or SAO): slice_loop_filter_across_slices_enabled_flag
+        f["slice_lf_across_slices"] = r.u(1)
+    f["entry_points"] = []
+    if pps.get("tiles_enabled"):
+        n_entry = r.ue()
+        if n_entry:
+            bits = r.ue() + 1
+            f["entry_points"] = [r.u(bits) + 1 for _ in range(n_entry)]
+    assert r.u(1) == 1                      # byte_alignment()
+    while r.p % 8:
+        assert r.u(1) == 0
+    f["data_byte_pos"] = 2 + r.p // 8       # in the unescaped NAL (2-byte NAL header)
     return f, r

@@ -51,6 +51,7 @@ typedef struct { int32_t mode, type, aux; int32_t offset[32]; } hm_sao_offset;
 typedef struct { hm_sao_offset c[3]; } hm_sao_blk;
 /* org, deblocked, out: planar 4:2:0 frames; params: [ctus] coded parameters (as written to the bitstream). */
 int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out);
+int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out, int tile_cols, int tile_rows);
 
 /* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */
 void hm_oracle_set_trace(const char *path);

@@ -258,6 +258,19 @@ static void offset_block(int type, const int *offset, const uint8_t *src, uint8_
 
 int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out)
 {
+  return hm_oracle_sao_frame_tiles(org, deblocked, width, height, qp, params, out, 1, 1);
+}
+
+/* first CTU column / row of a uniformly spaced tile (TComPicSym.cpp xInitTiles) */
+static int tile_start(int pos, int n_ctus, int n_tiles)
+{
+  int t;
+  for (t = 0; t < n_tiles; t++) if ((t * n_ctus) / n_tiles == pos) return 1;
+  return 0;
+}
+
+int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out, int tile_cols, int tile_rows)
+{
   const int cx = (width + 63) >> 6, cy = (height + 63) >> 6, nctu = cx * cy, cw = width >> 1, ch = height >> 1;
   const size_t ysz = (size_t)width * height, csz = (size_t)cw * ch;
   double lambda[3];
@@ -300,8 +313,10 @@ int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width,
     const int x0 = (a % cx) * 64, y0 = (a / cx) * 64;
     const int w = x0 + 64 > width ? width - x0 : 64, h = y0 + 64 > height ? height - y0 : 64;
     cur = go;
-    if (a % cx > 0) ml[MERGE_LEFT] = &recon[a - 1];
-    if (a / cx > 0) ml[MERGE_ABOVE] = &recon[a - cx];
+    /* merge candidates come from the same tile only (TComPic::getSAOMergeAvailability; statistics and offsets do cross tiles:
+       LFCrossTileBoundaryFlag 1) */
+    if (!tile_start(a % cx, cx, tile_cols)) ml[MERGE_LEFT] = &recon[a - 1];
+    if (!tile_start(a / cx, cy, tile_rows)) ml[MERGE_ABOVE] = &recon[a - cx];
     mode_new((const stat_t (*)[NTYPES])st[a], lambda, ml, &mode, &cost, &cur, &go);
     if (cost < min_cost) { min_cost = cost; params[a] = mode; next = go; }
     mode_merge((const stat_t (*)[NTYPES])st[a], lambda, ml, &mode, &cost, &cur, &go);

@@ -68,7 +68,8 @@ def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
 def test_keys_that_change_the_path_are_rejected(app, tmp_path):
     write_cfgs(tmp_path)
     for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
-                          (["--WaveFrontSynchro=1"], "WaveFrontSynchro")):
+                          (["--WaveFrontSynchro=1"], "WaveFrontSynchro"), (["--NumTileColumnsMinus1=1"], "TileUniformSpacing"),
+                          (["--NumTileRowsMinus1=1", "--TileUniformSpacing=1", "--LFCrossTileBoundaryFlag=0"], "LFCrossTileBoundaryFlag")):
         r = run(app, ["-c", "main.cfg", "-c", "seq.cfg"] + extra + ["--PrintConfig"], tmp_path)
         assert r.returncode == 2 and needle in " ".join(json.loads(r.stdout)["errors"])
     r = run(app, ["-c", "missing.cfg"], tmp_path)
@@ -130,3 +131,28 @@ def test_cli_encode_matches_the_api(app, tmp_path):
     # CNN labels when no label directory is given
     r2 = run(app, ["-c", "main.cfg", "-c", "seq.cfg", "-q", str(qp), "-o", "rec_cnn.yuv"], tmp_path)
     assert r2.returncode == 0 and "on-device CNN" in r2.stdout and os.path.getsize(tmp_path / "rec_cnn.yuv") == w * h * 3 // 2 * nf
+
+
+@pytest.mark.gpu
+def test_cli_with_tiles_reproduces_the_reference_run(app, tmp_path):
+    """The reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) on the fixture the
+    reference encoder produced with the same switches: reconstruction file and bitstream (its picture-hash SEI aside) byte for byte."""
+    import sys
+    from conftest import GOLD
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import hevc_parse as hp
+    f = np.load(os.path.join(GOLD, "rd_t520_q37_2x2.npz"))
+    w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
+    f["yuv"].tofile(tmp_path / "in.yuv")
+    for fr in range(nf):
+        os.makedirs(tmp_path / "pred" / str(fr))
+        for a in range(f["labels"].shape[1]):
+            (tmp_path / "pred" / str(fr) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in f["labels"][fr, a]))
+    r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
+                  "--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (int(f["tiles"][0]) - 1), "--NumTileRowsMinus1=%d" % (int(f["tiles"][1]) - 1)], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_filtered"])
+    ref = b"".join((b"\x00" if sc == 4 else b"") + b"\x00\x00\x01" + n for sc, n in hp.split_annexb(f["bitstream"].tobytes()) if ((n[0] >> 1) & 63) != 40)
+    assert (tmp_path / "str.bin").read_bytes() == ref
+    r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "--TileUniformSpacing=1", "--NumTileColumnsMinus1=2"], tmp_path)
+    assert r.returncode == 2 and "4 CTUs wide" in r.stderr          # 9 CTU columns cannot hold three tiles of the minimum width

@@ -14,11 +14,15 @@ CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
 REF_DEC = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder_ref")
 
 
+def tiles_of(f):
+    return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)      # rd_t*: reference runs with tiles enabled
+
+
 def stream_of(f):
     import hevcdl_amd
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
-    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc]) for poc in range(recs.shape[0]))
+    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f)) for poc in range(recs.shape[0]))
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
@@ -30,7 +34,7 @@ def test_stream_is_byte_exact_with_the_reference(path):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_DEC), reason="reference decoder build (oracle/_ref) only exists in the survey container")
-@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r"))],
+@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r", "t520_q37_2x2", "t576_q27_2x3"))],
                          ids=lambda p: os.path.basename(p)[3:-4])
 def test_reference_decoder_reconstructs_the_deblocked_picture(path, tmp_path):
     f = np.load(path)
@@ -76,3 +80,20 @@ def test_writer_rejects_what_it_does_not_implement():
     cfg.loop_filter_disable = 0
     assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 8, ctypes.byref(n)) == 1 and n.value > 8
     assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 0
+    cfg.tile_columns = 2                                  # a 1-CTU picture cannot hold two tile columns (each at least 4 CTUs wide)
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 1
+    cfg.tile_columns = 1; cfg.tile_rows = 0
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 1
+
+
+def test_tile_syntax_parses_back():
+    """PPS tile fields and the slice header's entry points: the offsets add up to the slice data, every sub-stream ends byte aligned."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hevc_parse as hp
+    f = np.load(os.path.join(GOLD, "rd_t576_q27_2x3.npz"))
+    nals = hp.split_annexb(stream_of(f))
+    sps, pps = hp.parse_sps(nals[1][1]), hp.parse_pps(nals[2][1])
+    assert pps["tiles_enabled"] == 1 and (pps["tile_columns"], pps["tile_rows"], pps["uniform_spacing"], pps["lf_across_tiles"]) == (2, 3, 1, 1)
+    hdr, _ = hp.parse_slice_header(nals[3][1], sps, pps)
+    assert len(hdr["entry_points"]) == 5 and sum(hdr["entry_points"]) < len(nals[3][1]) - hdr["data_byte_pos"]

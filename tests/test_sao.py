@@ -26,6 +26,10 @@ def load(path):
     return f, w, h, qp, nf, f["yuv"].reshape(nf, fb), f["recon_deblocked"].reshape(nf, fb), f["recon_filtered"].reshape(nf, fb)
 
 
+def tiles_of(f):
+    return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)      # rd_t*: reference runs with tiles enabled
+
+
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
 def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     """Final reconstruction == the reference's output picture, and the decided parameters, written by the product's
@@ -34,10 +38,10 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     import hevcdl_amd
     import ref_tools
     f, w, h, qp, nf, org, dbk, final = load(path)
-    params, out = ref_tools.run_sao(org, dbk, w, h, qp)
+    params, out = ref_tools.run_sao(org, dbk, w, h, qp, tiles=tiles_of(f))
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE)) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 
@@ -46,12 +50,12 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
 def test_gpu_sao_matches_reference(path):
     import hevcdl_amd
     f, w, h, qp, nf, org, dbk, final = load(path)
-    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles_of(f))
     params, out = e.sao_frames(org, dbk)
     e.close()
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc]) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 
