@@ -134,6 +134,7 @@ def load_library():
     lib.hevcdl_predict_depth_dev.argtypes = [vp, vp, ci, vp, vp, vp]
     lib.hevcdl_compress_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_encode_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.hevcdl_compress_tiles_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, ci, vp]
     lib.hevcdl_profile_enable.argtypes = [vp, ci]
     lib.hevcdl_profile_get.argtypes = [vp, ctypes.POINTER(Profile)]
     lib.hevcdl_ctus_per_frame.argtypes = [ci, ci]
@@ -145,7 +146,7 @@ def load_library():
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
+           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit"]
 
@@ -309,6 +310,10 @@ class Encoder:
 
     def compress_frames_dev(self, d_yuv, n, d_labels, d_records, d_recon, d_stats=None, stream=None):
         self._check(self.lib.hevcdl_compress_frames_dev(self._h, d_yuv, n, d_labels, d_records, d_recon, d_stats, stream))
+
+    def compress_tiles_dev(self, d_yuv, n, d_labels, d_records, d_recon, d_stats, tile_begin, tile_count, stream=None):
+        """Tiles [tile_begin, tile_begin + tile_count) of every frame only (whole-frame device buffers): see sharding.py."""
+        self._check(self.lib.hevcdl_compress_tiles_dev(self._h, d_yuv, n, d_labels, d_records, d_recon, d_stats, tile_begin, tile_count, stream))
 
     def encode_frames_dev(self, d_yuv, n, d_labels, d_records, d_recon, d_stats=None, stream=None):
         self._check(self.lib.hevcdl_encode_frames_dev(self._h, d_yuv, n, d_labels, d_records, d_recon, d_stats, stream))

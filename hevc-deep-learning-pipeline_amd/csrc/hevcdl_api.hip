@@ -193,7 +193,8 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
 }
 
 static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s,
-                               int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr, void *d_scratch = nullptr)
+                               int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr, void *d_scratch = nullptr,
+                               int tile_begin = 0, int tile_count = -1)
 {
   hevcdl_rd_params p;
   memset(&p, 0, sizeof p);
@@ -202,6 +203,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   p.stats = (unsigned char *)d_stats; p.scratch = d_scratch ? (unsigned char *)d_scratch : ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_y = ctx->ctus_y; p.n_frames = n_frames;
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
+  p.tile_begin = tile_begin; p.tile_count = tile_count < 0 ? p.tile_cols * p.tile_rows : tile_count;
   if (d_stats) HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(hevcdl_frame_stats) * (size_t)n_frames, s));     // the tile waves of a frame add into its entry
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
@@ -212,7 +214,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (getenv("HEVCDL_DBGBUF")) { hipMalloc(&d_dbg, 8004 * 4); hipMemset(d_dbg, 0, 8004 * 4); p.dbgbuf = d_dbg; }
   prof_begin(ctx, ctx->ev_rd, s);
   // HEVCDL_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the number of resident waves per CU
-  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames * p.tile_cols * p.tile_rows), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
+  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames * p.tile_count), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
   if (d_dbg) {
@@ -248,6 +250,16 @@ extern "C" hevcdl_status hevcdl_compress_frames_dev(hevcdl_ctx *ctx, const void 
   if (n_frames == 0) return HEVCDL_OK;
   if (!d_yuv || !d_labels || !d_records || !d_recon) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
   return launch_rd(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, (hipStream_t)stream);
+}
+
+extern "C" hevcdl_status hevcdl_compress_tiles_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats,
+                                                   int tile_begin, int tile_count, void *stream)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > ctx->cfg.tile_columns * ctx->cfg.tile_rows) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "tile range outside the tile grid");
+  if (n_frames == 0 || tile_count == 0) return HEVCDL_OK;
+  if (!d_yuv || !d_labels || !d_records || !d_recon) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  return launch_rd(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, (hipStream_t)stream, 0, -1, nullptr, nullptr, nullptr, tile_begin, tile_count);
 }
 
 extern "C" hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels,

@@ -49,6 +49,7 @@ struct hevcdl_rd_params {
   int ctu_begin, ctu_end;          // CTU address range [begin, end) in coding order
   int width, height, ctus_x, ctus_y, n_frames, debug;
   int tile_cols, tile_rows;        // uniformly spaced tiles (1 x 1: none); one wave per (frame, tile)
+  int tile_begin, tile_count;      // tiles of every frame this launch covers (raster order of tiles)
   hevcdl_rd_consts k;
 };
 

@@ -2108,7 +2108,8 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
 {
   LSmem &s = lds();
   // one wave per (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
-  const int ntiles = p.tile_cols * p.tile_rows, unit = blockIdx.x, frame = unit / ntiles, tile = unit - frame * ntiles;
+  // (a launch may cover only tiles [tile_begin, tile_begin + tile_count) of every frame: tile sharding across GPUs)
+  const int ntiles = p.tile_cols * p.tile_rows, unit = blockIdx.x, frame = unit / p.tile_count, tile = p.tile_begin + (unit - frame * p.tile_count);
   if (frame >= p.n_frames) return;
   LDS K &k = s.k;                       // every lane stores the same values
   const int lane = lane_id();
@@ -2239,7 +2240,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
       for (int m = 32; m >= 1; m >>= 1) { unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32); lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m); acc += ((unsigned long long)hi << 32) | lo; }
       if (lane == 0) __hip_atomic_fetch_add(&st->sse[c], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) { __hip_atomic_fetch_add(&st->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tile == 0) { st->ctus = (uint32_t)nctu; st->pad = 0; } }
+    if (lane == 0) { __hip_atomic_fetch_add(&st->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tile == p.tile_begin) { st->ctus = (uint32_t)nctu; st->pad = 0; } }
   }
 }
 

@@ -193,6 +193,12 @@ hevcdl_status hevcdl_get_recon(hevcdl_ctx *ctx, int frame, uint8_t *recon);
 hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream);
 hevcdl_status hevcdl_compress_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels,
                                          void *d_records, void *d_recon, void *d_stats, void *stream);
+/* The same for tiles [tile_begin, tile_begin + tile_count) of every frame only (raster order of the cfg's tile grid): the unit of
+ * work when the tiles of a picture are spread over several GPUs.  Buffers are whole-frame buffers; only the records, reconstruction
+ * samples and statistics (partial sums) of the named tiles are written.  Tiles never read each other's results, so the launches of
+ * different ranks need no ordering; the in-loop filters need the assembled picture (hevc-deep-learning-pipeline_amd/sharding.py). */
+hevcdl_status hevcdl_compress_tiles_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels,
+                                        void *d_records, void *d_recon, void *d_stats, int tile_begin, int tile_count, void *stream);
 /* CNN + RD search back to back: the whole hot path for one batch of frames. */
 hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels,
                                        void *d_records, void *d_recon, void *d_stats, void *stream);

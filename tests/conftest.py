@@ -11,6 +11,14 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # tests that hand torch device tensors to the C ABI: torch's HIP runtime must come up before the library's first use of the
+    # GPU in this process (afterwards torch reports "No HIP GPUs are available")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

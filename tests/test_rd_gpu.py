@@ -78,6 +78,37 @@ def test_tiles_match_oracle(oracle_built, w, h, qp, nf, seed, tiles):
     assert any(not np.array_equal(o_recs[k], u_recs[k]) for k in FIELDS)      # the tiling does change the decisions
 
 
+def test_tile_ranges_assemble_to_the_whole_picture(oracle_built):
+    """hevcdl_compress_tiles_dev: the tiles of a picture decided by separate launches (as separate GPUs would) into the same
+    whole-frame buffers give exactly the single-launch result -- tiles never read each other."""
+    import torch
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf, tiles = 1024, 192, 30, 2, (4, 3)
+    yuv = ref_tools.synth_yuv(w, h, nf, 47)
+    labels = ref_tools.make_labels(w, h, nf, "rand", 48)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    dev = torch.device("cuda:0")
+    d_yuv = torch.from_numpy(yuv.reshape(nf, -1)).to(dev)
+    d_lab = torch.from_numpy(labels).to(dev)
+    d_recs = torch.zeros((nf, recs.shape[1] * recs.dtype.itemsize), dtype=torch.uint8, device=dev)
+    d_recon = torch.zeros_like(d_yuv)
+    sums = np.zeros(nf, hevcdl_amd.STATS_DTYPE)
+    for begin, count in ((5, 7), (0, 2), (2, 3)):              # any order: no launch depends on another
+        d_stats = torch.zeros((nf, hevcdl_amd.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        enc.compress_tiles_dev(d_yuv.data_ptr(), nf, d_lab.data_ptr(), d_recs.data_ptr(), d_recon.data_ptr(), d_stats.data_ptr(), begin, count)
+        torch.cuda.synchronize()
+        part = np.frombuffer(d_stats.cpu().numpy().tobytes(), hevcdl_amd.STATS_DTYPE)
+        sums["sse"] += part["sse"]; sums["est_bits"] += part["est_bits"]
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        enc.compress_tiles_dev(d_yuv.data_ptr(), nf, d_lab.data_ptr(), d_recs.data_ptr(), d_recon.data_ptr(), None, 10, 3)
+    enc.close()
+    assert d_recs.cpu().numpy().tobytes() == recs.tobytes()
+    assert np.array_equal(d_recon.cpu().numpy().reshape(recon.shape), recon)
+    assert np.array_equal(sums["sse"], stats["sse"]) and np.array_equal(sums["est_bits"], stats["est_bits"])
+
+
 @pytest.mark.parametrize("kind,qp,seed", [("noise", 22, 61), ("noise", 32, 62), ("texture", 27, 63), ("texture", 37, 64), ("edges", 22, 65), ("edges", 32, 66),
                                          ("flat", 37, 67), ("mix", 17, 68), ("mix", 45, 69)])
 def test_matches_oracle_on_hard_content(oracle_built, kind, qp, seed):

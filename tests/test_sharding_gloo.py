@@ -64,3 +64,61 @@ def test_shard_ranges_cover_every_frame_once():
         for world in (1, 2, 4, 8):
             seen = [f for r in range(world) for f in shard_frames(n, world, r)]
             assert seen == list(range(n))
+
+
+def _tile_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_tools
+    import hevcdl_amd.sharding as sh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, qp, nf, tiles = 520, 136, 32, 2, (2, 2)            # ragged right / bottom edge, uneven tile columns (4 + 5 CTUs)
+    yuv = ref_tools.synth_yuv(w, h, nf, seed=91)
+    labels = ref_tools.make_labels(w, h, nf, "rand", 92)
+    recs, recon, _ = ref_tools.run_oracle(yuv, w, h, qp, labels, tiles=tiles)          # stands in for the per-rank GPU work ...
+    full_recon = torch.from_numpy(recon.reshape(nf, -1).copy())
+    full_recs = torch.from_numpy(np.frombuffer(recs.tobytes(), np.uint8).reshape(nf, -1).copy())
+    grid = sh.tile_grid(w, h, tiles)
+    begin, count = sh.shard_tiles(len(grid), world, rank)
+    part_recon, part_recs = torch.full_like(full_recon, 0xAA), torch.full_like(full_recs, 0xAA)   # ... of which only this rank's tiles exist here
+    scratch = torch.zeros((nf, max(sh.tile_payload_bytes(w, h, g) for g in grid)), dtype=torch.uint8)
+    for t in range(begin, begin + count):
+        n = sh.pack_tile(full_recon, full_recs, w, h, grid[t], scratch)
+        assert n == sh.tile_payload_bytes(w, h, grid[t])
+        sh.unpack_tile(scratch, part_recon, part_recs, w, h, grid[t])
+    owned, got_recon, got_recs = sh.exchange_tiles_to_owners(part_recon, part_recs, w, h, tiles)
+    ok = owned == list(range(rank, nf, world)) and torch.equal(got_recon, full_recon[owned]) and torch.equal(got_recs, full_recs[owned])
+    rows = torch.tensor([[f, 100 + f] for f in owned] + [[-1, 0]], dtype=torch.int64)
+    summ = sh.gather_frame_summaries(rows)
+    if rank == 0:
+        ok = ok and summ.tolist() == [[f, 100 + f] for f in range(nf)]
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_sharding_exchange_world2(oracle_built):
+    """Tiles of one picture decided on different ranks, then assembled at the picture's owner for the in-loop filters: the
+    all-to-all of padded tile payloads (reconstruction rectangles + CTU records) reproduces the single-process picture."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_tile_shards_cover_every_tile_once():
+    import hevcdl_amd.sharding as sh
+    for n in (1, 2, 6, 8, 20):
+        for world in (1, 2, 4, 8):
+            seen = [t for r in range(world) for t in range(sh.shard_tiles(n, world, r)[0], sum(sh.shard_tiles(n, world, r)))]
+            assert seen == list(range(n))
+    assert sh.tile_grid(7680, 4320, (4, 2))[5] == (30, 34, 60, 68) and len(sh.tile_grid(520, 136, (2, 2))) == 4
