@@ -29,7 +29,7 @@ WDIR = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "weights")
 REF = "/root/reference"
 
 
-def gen_rd(tiled=False):
+def gen_rd(tiled=False, ten_bit=False):
     cases = []
     #        name            W    H   frames qp  labels seed
     spec = [("c128_q32_d0", 128, 128, 1, 32, 0, 11), ("c128_q32_d1", 128, 128, 1, 32, 1, 12),
@@ -45,23 +45,36 @@ def gen_rd(tiled=False):
         # edge and uneven columns (4 + 5 CTUs)
         spec = [("t512_q32_2x2", 512, 128, 1, 32, "rand", 31, (2, 2)), ("t576_q27_2x3", 576, 192, 1, 27, "rand", 32, (2, 3)),
                 ("t520_q37_2x2", 520, 136, 2, 37, "rand", 33, (2, 2)), ("t832_q32_3x1", 832, 128, 1, 32, "rand", 34, (3, 1))]
+    bd = 8
+    if ten_bit:
+        # InputBitDepth = InternalBitDepth = 10, Profile main10; samples = the 8-bit pattern * 4 + 2 bits of noise;
+        # the last case is C5 in miniature: 10-bit with tiles
+        bd = 10
+        spec = [("x128_q32_r", 128, 128, 1, 32, "rand", 71, (1, 1)), ("x200_q27_r", 200, 136, 1, 27, "rand", 72, (1, 1)),
+                ("x128_q22_d3", 128, 128, 1, 22, 3, 73, (1, 1)), ("x192_q37_r2", 192, 128, 2, 37, "rand", 74, (1, 1)),
+                ("x576_q30_2x3", 576, 192, 1, 30, "rand", 75, (2, 3))]
     for name, w, h, nf, qp, kind, seed, tiles in spec:
         targs = rt.tile_args(tiles) if tiles != (1, 1) else []
         yuv = rt.synth_yuv(w, h, nf, seed)
         if name.startswith("c128_q22"):            # one noisy case: transform skip, escapes, sign hiding
             rng = np.random.default_rng(seed)
             yuv = rng.integers(0, 256, yuv.shape).astype(np.uint8)
+        if ten_bit:
+            rng = np.random.default_rng(seed)
+            yuv = yuv.astype(np.uint16) * 4 + rng.integers(0, 4, yuv.shape).astype(np.uint16)
+            if name.startswith("x128_q22"):
+                yuv = rng.integers(0, 1024, yuv.shape).astype(np.uint16)
         lab = rt.make_labels(w, h, nf, kind, seed + 100)
-        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs)
+        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs, bit_depth=bd)
         # deblocked-only reconstruction: the same run with SAO switched off (decisions are untouched by the in-loop filters)
-        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"])
+        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)
         assert dump2.tobytes() == dump.tobytes()
         order = np.lexsort((dump["addr"], dump["frame"]))
         dump = dump[order]
         nctu = lab.shape[1]
         assert len(dump) == nf * nctu
         summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
-        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, tiles=np.array(tiles),
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, tiles=np.array(tiles), bit_depth=bd,
                             records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
                             rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
                             bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),
@@ -174,11 +187,13 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "cnn", "weights", "bd"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "cnn", "weights", "bd"]
     if "rd" in what:
         gen_rd()
     if "rdtiles" in what:
         gen_rd(tiled=True)
+    if "rd10" in what:
+        gen_rd(ten_bit=True)
     if "cnn" in what or "weights" in what:
         model, sd, src = load_ref_model()
         if "weights" in what:

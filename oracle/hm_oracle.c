@@ -141,6 +141,11 @@ typedef struct {
 enum { A_DEPTH = 0, A_PART, A_LDIR, A_CDIR, A_TRIDX, A_CBF, A_TSKIP = 8 };
 
 typedef struct { int x, y, log2, depth, zbase, nparts, part; } cu_t;
+/* sample bit depth of the run (8, or 10: InternalBitDepth 10 with RExt__HIGH_BIT_DEPTH_SUPPORT 0, i.e. FULL_NBIT 0, TypeDef.h:162-172).
+ * Not thread-safe, like the trace hook: one encode at a time per process. */
+static int g_bd = 8;
+#define DIST_ADJ(x) (x)          /* DISTORTION_PRECISION_ADJUSTMENT, TypeDef.h:170 */
+
 typedef struct { int x, y, log2, trd, zrel, nparts; } tu_t;   /* luma geometry; zrel relative to the CU */
 
 typedef struct {
@@ -222,7 +227,7 @@ static void build_refs(const enc_t *e, int c, int x, int y, int n, pel *line)
   for (int k = 0; k < 2 * nu; k++) {             /* above + above-right */
     fl[2 * nu + 1 + k] = (uint8_t)unit_avail(e, x4 + k, y4 - 1, x4, y4); navail += fl[2 * nu + 1 + k];
   }
-  const int dcv = 128;                           /* 1 << (bitDepth-1) */
+  const int dcv = 1 << (g_bd - 1);
   if (navail == 0) { for (int i = 0; i <= 4 * n; i++) line[i] = dcv; return; }
   const int st = pic_stride(e, c);
   const pel *p = e->rec[c];
@@ -255,7 +260,7 @@ static void filter_refs(const pel *src, pel *dst, int n)
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
   if (n >= 32) {
-    const int thr = 1 << (8 - 5);
+    const int thr = 1 << (g_bd - 5);
     int bl = src[0], tl = src[n2], tr = src[last];
     strong = abs(bl + tl - 2 * src[n]) < thr && abs(tl + tr - 2 * src[n2 + n]) < thr;
   }
@@ -282,7 +287,7 @@ static inline int use_filtered_refs(int c, int mode, int n)
 /* =====================================================================================
  * intra prediction (TComPrediction.cpp:183-473, 731-817); ref line as in build_refs
  * ===================================================================================== */
-static inline int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+static inline int clip8(int v) { const int mx = (1 << g_bd) - 1; return v < 0 ? 0 : (v > mx ? mx : v); }   /* ClipBD */
 
 static void predict_intra(int c, int mode, const pel *line, int n, pel *dst, int ds)
 {
@@ -396,12 +401,13 @@ static uint32_t satd(const pel *o, int os, const pel *p, int ps, int n)
   uint32_t s = 0;
   if (n >= 8) { for (int y = 0; y < n; y += 8) for (int x = 0; x < n; x += 8) s += had8(o + y * os + x, os, p + y * ps + x, ps); }
   else s = had4(o, os, p, ps);
-  return s;                                      /* >> (bitDepth-8) = 0 */
+  return s >> DIST_ADJ(g_bd - 8);                 /* TComRdCost.cpp xGetHADs */
 }
 static uint32_t sse(const pel *a, int as, const pel *b, int bs, int n)
 {
   uint32_t s = 0;
-  for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) { int d = a[y * as + x] - b[y * bs + x]; s += (uint32_t)(d * d); }
+  const int sh = DIST_ADJ((g_bd - 8) << 1);          /* per sample, TComRdCost.cpp xGetSSE* */
+  for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) { int d = a[y * as + x] - b[y * bs + x]; s += (uint32_t)(d * d) >> sh; }
   return s;
 }
 
@@ -411,7 +417,7 @@ static uint32_t sse(const pel *a, int as, const pel *b, int bs, int n)
 static void fwd_transform(const pel *resi, int rs, int32_t *coef, int n, int use_dst)
 {
   const int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
-  const int s1 = log2n + 8 - 9, s2 = log2n + 6;
+  const int s1 = log2n + g_bd - 9, s2 = log2n + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
   static int32_t tmp[32 * 32];
   for (int j = 0; j < n; j++)
@@ -431,7 +437,7 @@ static inline int32_t clip16(int32_t v) { return v < -32768 ? -32768 : (v > 3276
 static void inv_transform(const int32_t *coef, pel *resi, int rs, int n, int use_dst)
 {
   const int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
-  const int s1 = 7, s2 = 12;                     /* 20 - bitDepth */
+  const int s1 = 7, s2 = 20 - g_bd;
   static int32_t tmp[32 * 32];
   for (int j = 0; j < n; j++)                    /* column j of coef */
     for (int x = 0; x < n; x++) {
@@ -545,8 +551,8 @@ static uint32_t rdoq(const enc_t *e, const cabac_t *cab, int c, int n, int dir_m
 {
   const int ch = c ? 1 : 0;
   const int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
-  const int qp = c ? e->qp_c : e->qp, per = qp / 6, rem = qp % 6;
-  const int tshift = 15 - 8 - log2n;
+  const int qp = (c ? e->qp_c : e->qp) + 6 * (g_bd - 8), per = qp / 6, rem = qp % 6;      /* + qpBdOffset, TComTrQuant.cpp:71-100 */
+  const int tshift = 15 - g_bd - log2n;
   const int qbits = 14 + per + tshift;
   const double lambda = c ? e->lambda_c : e->lambda;
   const double err_scale = e->err_scale[ch][log2n - 2];
@@ -719,7 +725,7 @@ static uint32_t rdoq(const enc_t *e, const cabac_t *cab, int c, int n, int dir_m
   /* sign data hiding, TComTrQuant.cpp:2530-2660 */
   if (abs_sum >= 2) {
     const double inv = (double)g_inv_quant_scales[rem];
-    int64_t rd_factor = (int64_t)(inv * inv * (1 << (2 * per)) / lambda / 16 / (1 << 0) + 0.5);
+    int64_t rd_factor = (int64_t)(inv * inv * (1 << (2 * per)) / lambda / 16 / (1 << DIST_ADJ(2 * (g_bd - 8))) + 0.5);
     int last_cg = -1;
     for (int subset = (ncoef - 1) >> 4; subset >= 0; subset--) {
       int sub_pos = subset << 4, first_nz = 16, last_nz = -1, sum = 0, k;
@@ -759,8 +765,8 @@ static uint32_t rdoq(const enc_t *e, const cabac_t *cab, int c, int n, int dir_m
 static void dequant(const enc_t *e, int c, int n, const int32_t *src, int32_t *dst)
 { /* TComTrQuant.cpp:1308-1425, flat scaling */
   const int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
-  const int qp = c ? e->qp_c : e->qp, per = qp / 6, rem = qp % 6;
-  const int tshift = 15 - 8 - log2n;
+  const int qp = (c ? e->qp_c : e->qp) + 6 * (g_bd - 8), per = qp / 6, rem = qp % 6;
+  const int tshift = 15 - g_bd - log2n;
   const int rshift = 6 - (tshift + per);
   const int scale = g_inv_quant_scales[rem];
   int tbits = 32 + rshift - 7; if (tbits > 16) tbits = 16;
@@ -1078,14 +1084,14 @@ static void code_tu_block(enc_t *e, const cu_t *cu, const tu_t *tu, int comp, in
   /* transform + RDOQ (transformNxN TComTrQuant.cpp:1450-1534) */
   int32_t *coef = e->coef_l[5 - tu->log2][comp] + (comp ? (zabs * 16) >> 2 : zabs * 16);
   static int32_t tc[1024];
-  if (tskip) { for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) tc[j * n + i] = (int32_t)resi[j * s + i] << 5; }
+  if (tskip) { for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) tc[j * n + i] = (int32_t)resi[j * s + i] << (13 - g_bd); }   /* transform shift 15 - bitDepth - 2 */
   else fwd_transform(resi, s, tc, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu->trd : (tu->trd == 0 ? 1 : 0);
   uint32_t abs_sum = rdoq(e, &e->go, comp, n, mode, tskip, cbf_ctx, tc, coef);
   set_parts(e->r->a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu->nparts, (abs_sum > 0 ? 1 : 0) << tu->trd);
   if (abs_sum > 0) {
     dequant(e, comp, n, coef, tc);
-    if (tskip) { for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) resi[j * s + i] = (pel)((tc[j * n + i] + 16) >> 5); }
+    if (tskip) { for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) resi[j * s + i] = (pel)((tc[j * n + i] + (1 << (12 - g_bd))) >> (13 - g_bd)); }
     else inv_transform(tc, resi, s, n, !comp && n == 4);
   } else {
     memset(coef, 0, sizeof(int32_t) * n * n);
@@ -1544,6 +1550,17 @@ int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int
                                   const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
                                   hm_frame_stats *stats, int tile_cols, int tile_rows)
 {
+  return hm_oracle_encode_frames_ex(yuv, width, height, n_frames, qp, labels, out_recs, recon, stats, tile_cols, tile_rows, 8);
+}
+
+int hm_oracle_encode_frames_ex(const void *yuv_, int width, int height, int n_frames, int qp,
+                               const uint8_t *labels, hm_ctu_record *out_recs, void *recon_,
+                               hm_frame_stats *stats, int tile_cols, int tile_rows, int bit_depth)
+{
+  const uint8_t *yuv = (const uint8_t *)yuv_; uint8_t *recon = (uint8_t *)recon_;
+  const int wide = bit_depth > 8;                /* samples are uint16 (little endian) */
+  if (bit_depth != 8 && bit_depth != 10) return -1;
+  g_bd = bit_depth;
   if (tile_cols < 1 || tile_rows < 1 || tile_cols > (width + 63) >> 6 || tile_rows > (height + 63) >> 6) return -1;
   if (width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51) return -1;
   init_tables();
@@ -1559,10 +1576,10 @@ int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int
   e->cweight = pow(2.0, (qp - e->qp_c) / 3.0);
   e->lambda_c = e->lambda / e->cweight;
   for (int ch = 0; ch < 2; ch++) for (int l = 0; l < 4; l++) {
-    int tshift = 15 - 8 - (l + 2), rem = (ch ? e->qp_c : qp) % 6;
+    int tshift = 15 - g_bd - (l + 2), rem = (ch ? e->qp_c : qp) % 6;      /* (qp + 6k) % 6 == qp % 6 */
     double s = (double)(1 << 15);
     s = s * pow(2.0, -2.0 * tshift);
-    e->err_scale[ch][l] = s / g_quant_scales[rem] / g_quant_scales[rem] / (1 << 0);
+    e->err_scale[ch][l] = s / g_quant_scales[rem] / g_quant_scales[rem] / (1 << DIST_ADJ(2 * (g_bd - 8)));
   }
   const size_t ysz = (size_t)width * height, csz = ysz >> 2, fsz = ysz + 2 * csz;
   for (int c = 0; c < 3; c++) {
@@ -1571,9 +1588,10 @@ int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int
   }
   e->recs = (irec_t *)malloc(sizeof(irec_t) * nctu);
   for (int f = 0; f < n_frames; f++) {
-    const uint8_t *src = yuv + (size_t)f * fsz;
-    for (size_t i = 0; i < ysz; i++) e->org[0][i] = src[i];
-    for (size_t i = 0; i < csz; i++) { e->org[1][i] = src[ysz + i]; e->org[2][i] = src[ysz + csz + i]; }
+    const uint8_t *src = yuv + (size_t)f * fsz * (wide ? 2 : 1);
+    const uint16_t *src16 = (const uint16_t *)src;
+    for (size_t i = 0; i < ysz; i++) e->org[0][i] = wide ? (pel)src16[i] : (pel)src[i];
+    for (size_t i = 0; i < csz; i++) { e->org[1][i] = wide ? (pel)src16[ysz + i] : (pel)src[ysz + i]; e->org[2][i] = wide ? (pel)src16[ysz + csz + i] : (pel)src[ysz + csz + i]; }
     for (int c = 0; c < 3; c++) memset(e->rec[c], 0, sizeof(pel) * (c ? csz : ysz));
     e->labels = labels + (size_t)f * nctu * 16;
     e->est_bits = 0;
@@ -1599,9 +1617,15 @@ int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int
       for (int i = 0; i < 1024; i++) { o->coeff_cb[i] = (int16_t)r->coef[1][i]; o->coeff_cr[i] = (int16_t)r->coef[2][i]; }
     }
     if (recon) {
-      uint8_t *dst = recon + (size_t)f * fsz;
-      for (size_t i = 0; i < ysz; i++) dst[i] = (uint8_t)e->rec[0][i];
-      for (size_t i = 0; i < csz; i++) { dst[ysz + i] = (uint8_t)e->rec[1][i]; dst[ysz + csz + i] = (uint8_t)e->rec[2][i]; }
+      uint8_t *dst = recon + (size_t)f * fsz * (wide ? 2 : 1);
+      uint16_t *dst16 = (uint16_t *)dst;
+      if (wide) {
+        for (size_t i = 0; i < ysz; i++) dst16[i] = (uint16_t)e->rec[0][i];
+        for (size_t i = 0; i < csz; i++) { dst16[ysz + i] = (uint16_t)e->rec[1][i]; dst16[ysz + csz + i] = (uint16_t)e->rec[2][i]; }
+      } else {
+        for (size_t i = 0; i < ysz; i++) dst[i] = (uint8_t)e->rec[0][i];
+        for (size_t i = 0; i < csz; i++) { dst[ysz + i] = (uint8_t)e->rec[1][i]; dst[ysz + csz + i] = (uint8_t)e->rec[2][i]; }
+      }
     }
     if (stats) {
       hm_frame_stats *s = stats + f; memset(s, 0, sizeof *s);

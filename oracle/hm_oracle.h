@@ -41,6 +41,10 @@ int hm_oracle_encode_frames(const uint8_t *yuv, int width, int height, int n_fra
 int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int n_frames, int qp,
                                   const uint8_t *labels, hm_ctu_record *out_recs, uint8_t *recon,
                                   hm_frame_stats *stats, int tile_cols, int tile_rows);
+/* bit_depth 8 (uint8 samples) or 10 (uint16 samples, InputBitDepth = InternalBitDepth = 10, Profile main10). */
+int hm_oracle_encode_frames_ex(const void *yuv, int width, int height, int n_frames, int qp,
+                               const uint8_t *labels, hm_ctu_record *out_recs, void *recon,
+                               hm_frame_stats *stats, int tile_cols, int tile_rows, int bit_depth);
 
 /* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
 int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);

@@ -14,7 +14,8 @@
 // Output: appended to the file named by $HEVCDL_DUMP, one block per CTU:
 //   int32 frame, int32 ctuRsAddr,
 //   hevcdl_ctu_record (include/hevcdl.h layout, 15120 bytes),
-//   uint8 reconY[64*64], reconCb[32*32], reconCr[32*32]  (zeros outside the picture)
+//   uint8 reconY[64*64], reconCb[32*32], reconCr[32*32]  (zeros outside the picture); uint16 samples instead when
+//   $HEVCDL_DUMP16 is set (runs with InternalBitDepth > 8)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,8 @@ extern "C" void __wrap__ZN6TEncCu11compressCtuEiP10TComDataCU(TEncCu* self, int 
   }
   TComPicYuv* rec = ctu->getPic()->getPicYuvRec();
   static uint8_t px[4096];
+  static uint16_t px16[4096];
+  const bool wide = getenv("HEVCDL_DUMP16") != NULL;
   for (int c = 0; c < 3; c++)
   {
     const ComponentID id = ComponentID(c);
@@ -81,8 +84,11 @@ extern "C" void __wrap__ZN6TEncCu11compressCtuEiP10TComDataCU(TEncCu* self, int 
     const Pel* base = rec->getAddr(id);
     for (int y = 0; y < n; y++)
       for (int x = 0; x < n; x++)
-        px[y * n + x] = (x0 + x < W && y0 + y < H) ? (uint8_t)base[(y0 + y) * stride + x0 + x] : 0;
-    fwrite(px, 1, n * n, g_dump);
+      {
+        const Pel v = (x0 + x < W && y0 + y < H) ? base[(y0 + y) * stride + x0 + x] : 0;
+        px[y * n + x] = (uint8_t)v; px16[y * n + x] = (uint16_t)v;
+      }
+    if (wide) fwrite(px16, 2, n * n, g_dump); else fwrite(px, 1, n * n, g_dump);
   }
   fflush(g_dump);
 }

@@ -27,6 +27,8 @@ REC_DTYPE = np.dtype([
 assert REC_DTYPE.itemsize == 15120
 DUMP_DTYPE = np.dtype([("frame", "<i4"), ("addr", "<i4"), ("rec", REC_DTYPE),
                        ("rec_y", "u1", 4096), ("rec_cb", "u1", 1024), ("rec_cr", "u1", 1024)])
+DUMP16_DTYPE = np.dtype([("frame", "<i4"), ("addr", "<i4"), ("rec", REC_DTYPE),
+                         ("rec_y", "<u2", 4096), ("rec_cb", "<u2", 1024), ("rec_cr", "<u2", 1024)])      # runs with InternalBitDepth > 8
 STATS_DTYPE = np.dtype([("sse", "<u8", 3), ("est_bits", "<u8"), ("ctus", "<u4"), ("pad", "<u4")])
 
 
@@ -128,14 +130,15 @@ def make_labels(width, height, n_frames, kind, seed=0):
     return labs
 
 
-def run_reference(yuv, width, height, qp, labels, extra_args=(), keep_dir=None, trace=False):
-    """Run the reference encoder; returns (dump records array, stdout text, bitstream bytes, recon bytes)."""
+def run_reference(yuv, width, height, qp, labels, extra_args=(), keep_dir=None, trace=False, bit_depth=8):
+    """Run the reference encoder; returns (dump records array, stdout text, bitstream bytes, recon bytes).
+    bit_depth 10: yuv holds 10-bit samples (uint16), coded with InputBitDepth = InternalBitDepth = 10, Profile main10."""
     n_frames = yuv.shape[0]
     d = keep_dir or tempfile.mkdtemp(prefix="hmref_")
     os.makedirs(os.path.join(d, "rec"), exist_ok=True)
     if os.path.isdir(os.path.join(d, "pred")):
         shutil.rmtree(os.path.join(d, "pred"))
-    yuv.astype(np.uint8).tofile(os.path.join(d, "in.yuv"))
+    yuv.astype(np.uint8 if bit_depth == 8 else "<u2").tofile(os.path.join(d, "in.yuv"))
     for f in range(n_frames):
         os.makedirs(os.path.join(d, "pred", str(f)))
         for a in range(labels.shape[1]):
@@ -152,10 +155,13 @@ def run_reference(yuv, width, height, qp, labels, extra_args=(), keep_dir=None, 
     if os.path.exists(env["HEVCDL_DUMP"]):
         os.remove(env["HEVCDL_DUMP"])
     cmd = [REF_ENC, "-c", "enc.cfg", "-c", "bs.cfg", "-q", str(qp), "--SEIDecodedPictureHash=1"] + list(extra_args)
+    if bit_depth != 8:
+        cmd += ["--InputBitDepth=%d" % bit_depth, "--InternalBitDepth=%d" % bit_depth, "--Profile=main10"]
+        env["HEVCDL_DUMP16"] = "1"
     p = subprocess.run(cmd, cwd=d, env=env, capture_output=True, text=True)
     if p.returncode != 0:
         raise RuntimeError("reference encoder failed: " + p.stdout[-2000:] + p.stderr[-2000:])
-    dump = np.fromfile(env["HEVCDL_DUMP"], dtype=DUMP_DTYPE)
+    dump = np.fromfile(env["HEVCDL_DUMP"], dtype=DUMP_DTYPE if bit_depth == 8 else DUMP16_DTYPE)
     bitstream = open(os.path.join(d, "rec", "str.bin"), "rb").read()
     recon = open(os.path.join(d, "rec", "rec.yuv"), "rb").read()
     if keep_dir is None:
@@ -182,21 +188,21 @@ def tile_args(tiles):
     return ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (tiles[0] - 1), "--NumTileRowsMinus1=%d" % (tiles[1] - 1)]
 
 
-def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1)):
-    """Returns (records [frames][ctus] REC_DTYPE, recon uint8 [frames][w*h*3/2], stats [frames])."""
+def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bit_depth=8):
+    """Returns (records [frames][ctus] REC_DTYPE, recon [frames][w*h*3/2] (uint8, or uint16 for bit_depth 10), stats [frames])."""
     lib = oracle_lib()
-    yuv = np.ascontiguousarray(yuv, np.uint8)
+    yuv = np.ascontiguousarray(yuv, np.uint8 if bit_depth == 8 else np.uint16)
     labels = np.ascontiguousarray(labels, np.uint8)
     n_frames, nctu = labels.shape[0], labels.shape[1]
     recs = np.zeros((n_frames, nctu), REC_DTYPE)
     recon = np.zeros_like(yuv)
     stats = np.zeros(n_frames, STATS_DTYPE)
     lib.hm_oracle_set_trace(trace_path.encode() if trace_path else None)
-    lib.hm_oracle_encode_frames_tiles.restype = ctypes.c_int
-    lib.hm_oracle_encode_frames_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    rc = lib.hm_oracle_encode_frames_tiles(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
-                                           recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tiles[0], tiles[1])
+    lib.hm_oracle_encode_frames_ex.restype = ctypes.c_int
+    lib.hm_oracle_encode_frames_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rc = lib.hm_oracle_encode_frames_ex(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
+                                        recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tiles[0], tiles[1], bit_depth)
     lib.hm_oracle_set_trace(None)
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
@@ -246,7 +252,7 @@ def ctu_recon_from_frame(recon_frame, width, height, addr):
     V = recon_frame[width * height * 5 // 4:].reshape(height // 2, width // 2)
     out = []
     for P, n, xx, yy in ((Y, 64, x0, y0), (U, 32, x0 // 2, y0 // 2), (V, 32, x0 // 2, y0 // 2)):
-        b = np.zeros((n, n), np.uint8)
+        b = np.zeros((n, n), recon_frame.dtype)
         sub = P[yy:yy + n, xx:xx + n]
         b[:sub.shape[0], :sub.shape[1]] = sub
         out.append(b.ravel())

@@ -17,7 +17,8 @@ def test_rd_oracle_matches_reference_records(oracle_built, path):
     f = np.load(path)
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     tiles = tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)     # rd_t*: the reference run with tiles enabled
-    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles)
+    bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
+    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles, bit_depth=bd)
     for k in FIELDS:
         assert np.array_equal(recs[k], f["records"][k]), k
     for fr in range(f["yuv"].shape[0]):
