@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
-SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
+SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "rd_kernel_bd10.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
 
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
 
@@ -140,13 +140,16 @@ def load_library():
     lib.hevcdl_ctus_per_frame.argtypes = [ci, ci]
     lib.hevcdl_frame_bytes.argtypes = [ci, ci]
     lib.hevcdl_frame_bytes.restype = ctypes.c_size_t
+    lib.hevcdl_frame_bytes_bd.argtypes = [ci, ci, ci]
+    lib.hevcdl_frame_bytes_bd.restype = ctypes.c_size_t
+    lib.hevcdl_config_default_bd.argtypes = [ctypes.POINTER(Config), ci, ci, ci, ci]
     _lib = lib
     return lib
 
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes",
+           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit"]
 
@@ -158,10 +161,10 @@ def load_weights(path=WEIGHTS_PATH):
     return w
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1)):
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8):
     lib = load_library()
     cfg = Config()
-    st = lib.hevcdl_config_default(ctypes.byref(cfg), width, height, qp)
+    st = lib.hevcdl_config_default_bd(ctypes.byref(cfg), width, height, qp, bit_depth)
     if st:
         raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
     cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
@@ -196,13 +199,17 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1)):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8):
+        """bit_depth 10: every yuv / recon array of the decision path holds uint16 samples (frame_bytes counts bytes)."""
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth)
+        self.bit_depth = self.cfg.bit_depth
+        self.sample_dtype = np.uint8 if self.bit_depth == 8 else np.dtype("<u2")
         self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)
         self.width, self.height, self.qp = self.cfg.width, self.cfg.height, self.cfg.qp
         self.ctus = self.lib.hevcdl_ctus_per_frame(self.width, self.height)
-        self.frame_bytes = self.lib.hevcdl_frame_bytes(self.width, self.height)
+        self.frame_bytes = self.lib.hevcdl_frame_bytes_bd(self.width, self.height, self.bit_depth)
+        self.frame_samples = self.width * self.height * 3 // 2
         w = np.ascontiguousarray(load_weights() if weights is None else weights, dtype="<f4")
         self._h = ctypes.c_void_p()
         st = self.lib.hevcdl_create(ctypes.byref(self.cfg), w.ctypes.data, w.size, ctypes.byref(self._h))
@@ -222,7 +229,7 @@ class Encoder:
             raise HevcdlError(st, (self.lib.hevcdl_last_error(self._h) or b"").decode())
 
     def _frames(self, yuv):
-        yuv = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.frame_bytes)
+        yuv = np.ascontiguousarray(yuv, self.sample_dtype).reshape(-1, self.frame_samples)
         return yuv, yuv.shape[0]
 
     def predict_depth(self, yuv, want_logits=False):
@@ -300,7 +307,7 @@ class Encoder:
         return rec, st_out
 
     def get_recon(self, frame):
-        out = np.zeros(self.frame_bytes, np.uint8)
+        out = np.zeros(self.frame_samples, self.sample_dtype)
         self._check(self.lib.hevcdl_get_recon(self._h, frame, out.ctypes.data))
         return out
 

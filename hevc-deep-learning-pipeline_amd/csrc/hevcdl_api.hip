@@ -10,6 +10,15 @@
 
 extern "C" __global__ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p);
 extern "C" __global__ void hevcdl_rd_frame_kernel(hevcdl_rd_params p);
+extern "C" __global__ void hevcdl_rd_frame_kernel_bd10(hevcdl_rd_params p);       // rd_kernel_bd10.hip: the same kernel for uint16 samples
+extern "C" size_t hevcdl_rd_smem_bytes_bd10(void);
+extern "C" size_t hevcdl_rd_scratch_bytes_bd10(void);
+
+// 10-bit samples -> the 8-bit planes the CNN stage reads (the reference's label producer works on 8-bit frames: gen_frames.py)
+__global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, size_t n, int shift)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint8_t)(src[i] >> shift);
+}
 
 struct hevcdl_ctx {
   hevcdl_config cfg;
@@ -20,6 +29,7 @@ struct hevcdl_ctx {
   size_t scratch_per_frame;
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
+  uint8_t *d_yuv8;               // 8-bit copy of 10-bit input for the CNN stage
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
@@ -43,13 +53,20 @@ static hevcdl_status fail(hevcdl_ctx *c, hevcdl_status s, const char *what, hipE
 
 extern "C" int hevcdl_ctus_per_frame(int w, int h) { return ((w + 63) >> 6) * ((h + 63) >> 6); }
 extern "C" size_t hevcdl_frame_bytes(int w, int h) { return (size_t)w * h * 3 / 2; }
+extern "C" size_t hevcdl_frame_bytes_bd(int w, int h, int bit_depth) { return (size_t)w * h * 3 / 2 * (bit_depth > 8 ? 2 : 1); }
 
 extern "C" hevcdl_status hevcdl_config_default(hevcdl_config *cfg, int width, int height, int qp)
 {
+  return hevcdl_config_default_bd(cfg, width, height, qp, 8);
+}
+
+extern "C" hevcdl_status hevcdl_config_default_bd(hevcdl_config *cfg, int width, int height, int qp, int bit_depth)
+{
+  if (bit_depth != 8 && bit_depth != 10) return HEVCDL_ERR_UNSUPPORTED;
   if (!cfg || width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51) return HEVCDL_ERR_INVALID_ARG;
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = sizeof *cfg;
-  cfg->width = width; cfg->height = height; cfg->bit_depth = 8; cfg->chroma_format = 420; cfg->qp = qp;
+  cfg->width = width; cfg->height = height; cfg->bit_depth = bit_depth; cfg->chroma_format = 420; cfg->qp = qp;
   cfg->ctu_size = 64; cfg->max_partition_depth = 4; cfg->tu_log2_min = 2; cfg->tu_log2_max = 5; cfg->tu_max_depth_intra = 3;
   cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->bn_mode = HEVCDL_BN_REFERENCE; cfg->boundary_policy = HEVCDL_BOUNDARY_CLAMP;
   cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1; cfg->tile_columns = 1; cfg->tile_rows = 1;
@@ -60,15 +77,17 @@ extern "C" hevcdl_status hevcdl_config_default(hevcdl_config *cfg, int width, in
   cfg->chroma_weight = pow(2.0, (qp - cfg->qp_chroma) / 3.0);
   cfg->lambda_chroma = cfg->lambda / cfg->chroma_weight;
   for (int ch = 0; ch < 2; ch++) {
-    const int q = ch ? cfg->qp_chroma : qp, rem = q % 6, per = q / 6;
+    // quantiser QP = QP + qpBdOffset (6 per extra bit, TComTrQuant.cpp:71-100); distortion is kept at 8-bit scale (FULL_NBIT 0:
+    // DISTORTION_PRECISION_ADJUSTMENT, TypeDef.h:170), hence the 1 << 2(bd-8) divisors
+    const int q = (ch ? cfg->qp_chroma : qp) + 6 * (bit_depth - 8), rem = q % 6, per = q / 6, dadj = 2 * (bit_depth - 8);
     for (int l = 0; l < 4; l++) {                               // TComTrQuant::setErrScaleCoeff TComTrQuant.cpp:3096-3126
-      const int tshift = 15 - 8 - (l + 2);
+      const int tshift = 15 - bit_depth - (l + 2);
       double s = (double)(1 << 15);
       s = s * pow(2.0, -2.0 * tshift);
-      cfg->err_scale[ch][l] = s / QUANT_SCALES[rem] / QUANT_SCALES[rem] / (1 << 0);
+      cfg->err_scale[ch][l] = s / QUANT_SCALES[rem] / QUANT_SCALES[rem] / (1 << dadj);
     }
     const double inv = (double)INV_QUANT_SCALES[rem], lam = ch ? cfg->lambda_chroma : cfg->lambda;
-    cfg->sbh_rd_factor[ch] = (int64_t)(inv * inv * (1 << (2 * per)) / lam / 16 / (1 << 0) + 0.5);   // TComTrQuant.cpp:2532-2535
+    cfg->sbh_rd_factor[ch] = (int64_t)(inv * inv * (1 << (2 * per)) / lam / 16 / (1 << dadj) + 0.5);   // TComTrQuant.cpp:2532-2535
   }
   return HEVCDL_OK;
 }
@@ -104,7 +123,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (n_floats != HEVCDL_WEIGHT_FLOATS) return HEVCDL_ERR_INVALID_ARG;
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51 || cfg->max_frames < 1) return HEVCDL_ERR_INVALID_ARG;
   // keys that would change the path are rejected, not ignored
-  if (cfg->bit_depth != 8 || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
+  if ((cfg->bit_depth != 8 && cfg->bit_depth != 10) || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
       cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || cfg->bn_mode != HEVCDL_BN_REFERENCE ||
       cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA))
     return HEVCDL_ERR_UNSUPPORTED;
@@ -119,9 +138,9 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (!ctx) return HEVCDL_ERR_OOM;
   ctx->cfg = *cfg; ctx->err[0] = 0; ctx->profile = false;
   ctx->ctus_x = (cfg->width + 63) >> 6; ctx->ctus_y = (cfg->height + 63) >> 6; ctx->ctus = ctx->ctus_x * ctx->ctus_y;
-  ctx->frame_bytes = hevcdl_frame_bytes(cfg->width, cfg->height);
+  ctx->frame_bytes = hevcdl_frame_bytes_bd(cfg->width, cfg->height, cfg->bit_depth);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -135,10 +154,11 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
-  ctx->scratch_per_frame = hevcdl_rd_scratch_bytes();
+  ctx->scratch_per_frame = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
   CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames * cfg->tile_columns * cfg->tile_rows));    // one workspace per (frame, tile) wave
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0)));
+  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_bd10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_bd10()));
 #undef CK
   *out = ctx;
   return HEVCDL_OK;
@@ -152,7 +172,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
   delete ctx;
 }
 
@@ -214,7 +234,10 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (getenv("HEVCDL_DBGBUF")) { hipMalloc(&d_dbg, 8004 * 4); hipMemset(d_dbg, 0, 8004 * 4); p.dbgbuf = d_dbg; }
   prof_begin(ctx, ctx->ev_rd, s);
   // HEVCDL_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the number of resident waves per CU
-  hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames * p.tile_count), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
+  if (ctx->cfg.bit_depth == 8)
+    hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames * p.tile_count), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
+  else
+    hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(n_frames * p.tile_count), dim3(64), hevcdl_rd_smem_bytes_bd10(), s, p);
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
   if (d_dbg) {
@@ -239,6 +262,12 @@ extern "C" hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
   if (n_frames == 0) return HEVCDL_OK;
   if (!d_yuv || !d_labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  if (ctx->cfg.bit_depth > 8) { // the CNN stage is defined on 8-bit pictures: the top 8 bits of every sample
+    if (!ctx->d_yuv8) HIPCHK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(ctx->cfg.width, ctx->cfg.height) * (size_t)ctx->cfg.max_frames));
+    const size_t n = hevcdl_frame_bytes(ctx->cfg.width, ctx->cfg.height) * (size_t)n_frames;
+    hipLaunchKernelGGL(hevcdl_narrow_samples_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)d_yuv, ctx->d_yuv8, n, ctx->cfg.bit_depth - 8);
+    d_yuv = ctx->d_yuv8;
+  }
   return launch_cnn(ctx, d_yuv, ctx->cfg.cnn_input == HEVCDL_CNN_INPUT_LUMA ? HEVCDL_DEV_INPUT_LUMA : HEVCDL_DEV_INPUT_RGB601,
                     n_frames * ctx->ctus, 1, d_labels, d_logits_opt, (hipStream_t)stream);
 }
@@ -334,6 +363,7 @@ static const unsigned char DBK_BETA[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,6,7,
 extern "C" hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *d_recon, int n_frames, const void *d_records, void *d_out, void *stream)
 {
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (ctx->cfg.bit_depth != 8) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "the in-loop filters are implemented for 8-bit samples only");
   if (n_frames == 0) return HEVCDL_OK;
   if (!d_recon || !d_records || !d_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
   hevcdl_dbk_params p;
@@ -365,6 +395,7 @@ extern "C" hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *r
 extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_org, const void *d_deblocked, int n_frames, void *d_params, void *d_out, void *stream)
 {
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (ctx->cfg.bit_depth != 8) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "the in-loop filters are implemented for 8-bit samples only");
   if (n_frames == 0) return HEVCDL_OK;
   if (!d_org || !d_deblocked || !d_params || !d_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
   const size_t nf = (size_t)ctx->cfg.max_frames;

@@ -20,7 +20,24 @@
 #include "hevcdl.h"
 #include "hevcdl_dev.h"
 
+// Sample bit depth is a compile-time property of the kernel: this file is compiled as is for 8-bit samples and once more through
+// rd_kernel_bd10.hip (HEVCDL_BD 10, uint16 samples; InternalBitDepth 10 with the reference's FULL_NBIT 0 distortion scaling,
+// TypeDef.h:162-172).  Everything that depends on it is derived from BD below.
+#ifndef HEVCDL_BD
+#define HEVCDL_BD 8
+#endif
+#if HEVCDL_BD == 8
+typedef uint8_t pel_t;
+#define RD_SYM(name) name
+#else
+typedef uint16_t pel_t;
+#define RD_SYM(name) name##_bd10
+#endif
+
 namespace {
+constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 8);
+constexpr int SCR_LAYERS = (4 * 6144 * 2 + 5 * 6144 * (int)sizeof(pel_t) + 2047) & ~2047;   // coefficient layers + 4 reconstruction layers + best (81920 at 8 bits)
+constexpr int SSE_SH = 2 * (BD - 8), HAD_SH = BD - 8;         // DISTORTION_PRECISION_ADJUSTMENT: per squared sample / per Hadamard sum
 
 #define DEV __device__ __forceinline__
 #define DEVN __device__ __noinline__
@@ -93,14 +110,14 @@ DEV int uni(int v);
 
 struct K {                             // wave-uniform kernel context (lives in LDS)
   int W, H, cw, ctus_x, addr, cx, cy, nctu;
-  GLB const uint8_t *org[3];
-  GLB uint8_t *rec[3];
+  GLB const pel_t *org[3];
+  GLB pel_t *rec[3];
   GLB unsigned char *records;          // frame's records (global)
   GLB const uint8_t *labels;           // frame's labels
   int tx0, ty0, tx1, ty1;              // luma rectangle of the tile being coded (the whole picture without tiles)
   GLB int16_t *coef_l;                 // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
-  GLB uint8_t *rec_l;                  // scratch: [4 layers][6144] CTU-relative reconstruction
-  GLB uint8_t *best_rec;               // scratch: [6144] best reconstruction of the CU under test
+  GLB pel_t *rec_l;                  // scratch: [4 layers][6144] CTU-relative reconstruction
+  GLB pel_t *best_rec;               // scratch: [6144] best reconstruction of the CU under test
   GLB double *q_cost;                  // scratch: RDOQ per-position costs [2][1024] (coded cost, sig cost); written/read lane-parallel,
   GLB int32_t *q_rate;                 //          and SBH inputs [4][1024] (rateIncUp, rateIncDown, sigRateDelta, deltaU)
   double lambda, sqrt_lambda, cweight, lambda_c;
@@ -129,7 +146,7 @@ struct RdSmem {
   // quantised levels of the current TU (raster); the transform intermediate (row stride n+1) lives behind the first 16
   // entries, i.e. a 4x4 block of levels survives the inverse transform (transform-skip bookkeeping needs it)
   int16_t lvl[16 + 32 * 33];
-  uint8_t pred[1024];                 // prediction, then reconstruction, of the current TU
+  pel_t pred[1024];                 // prediction, then reconstruction, of the current TU
   // grouped-4x4 coefficient scans (TComRom.cpp:179-260) = CG order x order inside a CG, composed on the fly
   uint8_t scan_cg_all[3][88];         // CG order per [type][1 | 4 | 16 | 64 groups]
   uint8_t scan_in_cg[3][16];          // (y << 2) | x of the 16 positions of a CG, per scan type
@@ -138,12 +155,12 @@ struct RdSmem {
   int32_t t_ebits[128]; uint8_t t_next[2][128];
   int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
   uint8_t sv_tr[256], sv_cbf[3][256], sv_ts[3][256];
-  uint8_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
+  pel_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
   unsigned int rd_list[16];
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
-  uint8_t c8a[11][4]; int16_t c8coef[96]; uint8_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
+  uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
   unsigned long long prof[40]; unsigned int prof_n[40];
 #endif
@@ -214,7 +231,7 @@ DEV int boff(KR k, int c, int x, int y) { const int s = c ? 32 : 64; return (y -
 // dynamic index into a FLAT instruction's immediate offset with a base BELOW the indexed private object; gfx9-family
 // hardware picks the aperture from the base alone (offset ignored) -> HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
 DEV int ilog2(int n) { return n >= 32 ? (n >= 64 ? 6 : 5) : (n >= 16 ? 4 : (n >= 8 ? 3 : 2)); }
-DEV int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+DEV int clip8(int v) { return v < 0 ? 0 : (v > PEL_MAX ? PEL_MAX : v); }   // ClipBD
 DEV int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -294,7 +311,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   const unsigned long long m0 = __ballot(f0);
   const int f64 = (total > 64) ? unit_flag(64) : 0;          // uniform
   const int st = pstride(k, c);
-  GLB const uint8_t *p = k.rec[c];
+  GLB const pel_t *p = k.rec[c];
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
   auto sample = [&](int i) -> int {                          // picture sample behind line index i
@@ -315,7 +332,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
         unsigned long long above = kk >= 63 ? 0ull : (m0 & ~((2ull << kk) - 1ull));
         if (above) { const int j = __ffsll((long long)above) - 1; v = sample(unit_start(j)); }
         else if (f64) v = sample(unit_start(64));
-        else v = 128;
+        else v = 1 << (BD - 1);
       }
     }
     line_out[i] = (int16_t)v;
@@ -335,7 +352,7 @@ DEV void filter_refs(KR k, int n_)
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
   const int bl = src[0], tl = src[n2], tr = src[last];
-  if (n >= 32) strong = (abs(bl + tl - 2 * src[n]) < 8) && (abs(tl + tr - 2 * src[n2 + n]) < 8);
+  if (n >= 32) strong = (abs(bl + tl - 2 * src[n]) < (1 << (BD - 5))) && (abs(tl + tr - 2 * src[n2 + n]) < (1 << (BD - 5)));
   for (int i = lane_id(); i <= last; i += 64) {
     int v;
     if (i == 0 || i == last) v = src[i];
@@ -412,7 +429,7 @@ DEV void predict_block(KR k, int c_, int mode_, int n_)
   LDS const int16_t *line = use_filtered_refs(c, mode, n) ? lds().fline : ref_line(c);
   const int log2n = ilog2(n);
   const int dcv = (mode == DC) ? dc_value(k, line, n) : 0;
-  for (int i = lane_id(); i < n * n; i += 64) lds().pred[i] = (uint8_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
+  for (int i = lane_id(); i < n * n; i += 64) lds().pred[i] = (pel_t)pred_pixel(line, c, mode, n, log2n, i & (n - 1), i >> log2n, dcv);
   wsync();
   PROF_ADD(k, 3);
 }
@@ -480,7 +497,7 @@ DEV void dst4_inv(const int (&c)[4], int (&x)[4]) {
 template <int N, bool DST> DEV void fwd_transform_n(KR k)
 { // s->resi (stride RS) -> s->tc (raster); xTrMxN TComTrQuant.cpp:860-915
   constexpr int LOG2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
-  constexpr int s1 = LOG2 + 8 - 9, s2 = LOG2 + 6, a1 = 1 << (s1 - 1), a2 = 1 << (s2 - 1);
+  constexpr int s1 = LOG2 + BD - 9, s2 = LOG2 + 6, a1 = 1 << (s1 - 1), a2 = 1 << (s2 - 1);
   LSmem &s = lds();
   LDS int16_t *tmp_ = s.lvl + 16;
   if (lane_id() < N) {
@@ -521,7 +538,7 @@ template <int N, bool DST> DEV void inv_transform_n(KR k)
     for (int u = 0; u < N; u++) c[u] = tmp_[u * (N + 1) + lane_id()];                           // row y = lane
     if constexpr (DST) dst4_inv(c, x); else inv1d<N>(c, x);
 #pragma unroll
-    for (int i = 0; i < N; i++) s.resi[lane_id() * (N + 2) + i] = (int16_t)clip16((x[i] + 2048) >> 12);
+    for (int i = 0; i < N; i++) s.resi[lane_id() * (N + 2) + i] = (int16_t)clip16((x[i] + (1 << (19 - BD))) >> (20 - BD));
   }
   wsync();
 }
@@ -689,8 +706,8 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
   LSmem &s = lds();
   const int lane = lane_id();
   const int ch = c ? 1 : 0, log2n = ilog2(n);
-  const int qp = uni(c ? k.qp_c : k.qp), per = qp / 6, rem = qp % 6;
-  const int tshift = 15 - 8 - log2n, qbits = 14 + per + tshift;
+  const int qp = uni(c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;      // + qpBdOffset (TComTrQuant.cpp:71-100)
+  const int tshift = 15 - BD - log2n, qbits = 14 + per + tshift;
   const double lambda = c ? k.lambda_c : k.lambda;
   const double err_scale = k.err_scale[ch][log2n - 2];
   const int qcoef = uni(c_quant_scales[rem]);
@@ -1080,8 +1097,8 @@ DEV void dequant(KR k, int c_, int n_)
 {
   PROF_T0();
   const int c = uni(c_), n = uni(n_); // s->lvl -> s->tc  (TComTrQuant.cpp:1308-1425, flat scaling)
-  const int log2n = ilog2(n), qp = c ? k.qp_c : k.qp, per = qp / 6, rem = qp % 6;
-  const int tshift = 15 - 8 - log2n, rshift = 6 - (tshift + per), scale = c_inv_quant_scales[rem];
+  const int log2n = ilog2(n), qp = (c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;
+  const int tshift = 15 - BD - log2n, rshift = 6 - (tshift + per), scale = c_inv_quant_scales[rem];
   for (int i = lane_id(); i < n * n; i += 64) {
     const int q = lds().lvl[i];                       // already inside the 16-bit clip range
     int v;
@@ -1426,12 +1443,12 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   } else { wsync(); if (lane_id() < 16) s.pred[lane_id()] = s.ts_pred[comp][lane_id()]; }
   wsync();
   PROF_MARK(24);
-  GLB const uint8_t *org = k.org[comp] + (size_t)y * ps + x;
+  GLB const pel_t *org = k.org[comp] + (size_t)y * ps + x;
   for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
   wsync();
   PROF_MARK(25);
-  if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int16_t)((int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << 5); wsync(); }   // n == 4: one pass, every lane reads before any writes
+  if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int16_t)((int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << (13 - BD)); wsync(); }   // n == 4: one pass, every lane reads before any writes
   else fwd_transform(k, n, !comp && n == 4);
   PROF_MARK(26);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
@@ -1444,22 +1461,22 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   if (abs_sum > 0) {
     for (int i = lane_id(); i < n * n; i += 64) cl[i] = s.lvl[i];
     dequant(k, comp, n);
-    if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((s.tc[i] + 16) >> 5); wsync(); }
+    if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((s.tc[i] + (1 << (12 - BD))) >> (13 - BD)); wsync(); }
     else inv_transform(k, n, !comp && n == 4);
   } else {
     for (int i = lane_id(); i < n * n; i += 64) { cl[i] = 0; s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = 0; }
     wsync();
   }
   PROF_MARK(28);
-  GLB uint8_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
-  GLB uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  GLB pel_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
+  GLB pel_t *rp = k.rec[comp] + (size_t)y * ps + x;
   uint32_t d = 0;
   for (int i = lane_id(); i < n * n; i += 64) {
     const int r = i >> log2n, cc = i & (n - 1);
     const int v = clip8((int)s.pred[i] + (int)s.resi[r * RS(n) + cc]);
-    s.pred[i] = (uint8_t)v; rq[r * cs + cc] = (uint8_t)v; rp[(size_t)r * ps + cc] = (uint8_t)v;
+    s.pred[i] = (pel_t)v; rq[r * cs + cc] = (pel_t)v; rp[(size_t)r * ps + cc] = (pel_t)v;
     const int df = v - (int)org[(size_t)r * ps + cc];
-    d += (uint32_t)(df * df);
+    d += (uint32_t)(df * df) >> SSE_SH;                  // per sample, TComRdCost.cpp xGetSSE*
   }
   d = (uint32_t)wave_sum_i((int)d);
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
@@ -1482,7 +1499,7 @@ DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
   wsync();
   if (lane_id() < 16) {
     k.coef_l[(5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16) + lane_id()] = lds().ts_coef[comp][lane_id()];
-    const int r = lane_id() >> 2, cc = lane_id() & 3; const uint8_t v = lds().ts_rec[comp][lane_id()];
+    const int r = lane_id() >> 2, cc = lane_id() & 3; const pel_t v = lds().ts_rec[comp][lane_id()];
     k.rec_l[(5 - tu.log2) * 6144 + comp_off(comp) + bo + r * cs + cc] = v;
     k.rec[comp][(size_t)(y + r) * ps + x + cc] = v;
   }
@@ -1564,8 +1581,8 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
         set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
       }
       const int n = 1 << LOG2, bo = boff(k, 0, tu.x, tu.y);
-      GLB const uint8_t *rq = memo ? k.best_rec + bo : k.rec_l + (5 - LOG2) * 6144 + bo;
-      GLB uint8_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
+      GLB const pel_t *rq = memo ? k.best_rec + bo : k.rec_l + (5 - LOG2) * 6144 + bo;
+      GLB pel_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
       wsync();
       for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * k.W + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
       wsync();
@@ -1589,7 +1606,7 @@ template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int co
   GLB int16_t *dstc = (GLB int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + off;
   GLB const int16_t *srcc = k.coef_l + (5 - LOG2) * 6144 + off;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = comp_off(comp) + boff(k, comp, x, y);
-  GLB const uint8_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; GLB uint8_t *br = k.best_rec + bo;
+  GLB const pel_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; GLB pel_t *br = k.best_rec + bo;
   for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
 }
 DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_)
@@ -1625,15 +1642,15 @@ DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first, i
 // (iIdx, iFact) pair and 9 consecutive reference samples (TComPrediction.cpp:731-817).
 template <int B> DEV unsigned rmd_block(KR k, const LSmem &s, int mode, int pn, int log2n, int x, int y, int bx, int by, int dcv)
 {
-  constexpr int NW = B / 4;                                   // dwords per row of the block
+  constexpr int PPW = 4 / (int)sizeof(pel_t), NW = B / PPW;   // samples per dword, dwords per row of the block
   const int W = k.W, n2 = 2 * pn;
   GLB const uint32_t *org = (GLB const uint32_t *)(k.org[0] + (size_t)(y + by) * W + x + bx);
   uint32_t o[B][NW];
 #pragma unroll
   for (int r = 0; r < B; r++)
 #pragma unroll
-    for (int w = 0; w < NW; w++) o[r][w] = org[((size_t)r * W >> 2) + w];
-  auto opix = [&](int r, int c) -> int { return (int)((o[r][c >> 2] >> (8 * (c & 3))) & 255u); };
+    for (int w = 0; w < NW; w++) o[r][w] = org[((size_t)r * W / PPW) + w];
+  auto opix = [&](int r, int c) -> int { return (int)((o[r][c / PPW] >> (8 * (int)sizeof(pel_t) * (c % PPW))) & (unsigned)((1u << (8 * sizeof(pel_t))) - 1u)); };
   LDS const int16_t *line = use_filtered_refs(0, mode, pn) ? s.fline : s.line;
   int m[B * B];
   if (mode >= 2) {
@@ -1777,7 +1794,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         const int mode = lane_id();
         int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
         const unsigned long long fr = f0 + (unsigned long long)s.t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
-        s.rmd_cost[mode] = (double)s.satd[mode] + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
+        s.rmd_cost[mode] = (double)(s.satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
       }
       wsync();
       // xUpdateCandList :5562-5585 == stable sort by (cost, mode); keep the nfull best
@@ -1825,7 +1842,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       for (int c = 0; c < 3; c++) { s.a[A_CBF + c][zp + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][zp + i] = s.sv_ts[c][i]; }
     }
     if (pu != npu - 1) {
-      GLB uint8_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; GLB const uint8_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
+      GLB pel_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; GLB const pel_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
       for (int i = lane_id(); i < pn * pn; i += 64) rp[(size_t)(i >> pu_log2) * k.W + (i & (pn - 1))] = br[(i >> pu_log2) * 64 + (i & (pn - 1))];
     }
     set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)best_mode);
@@ -1949,8 +1966,8 @@ DEV void copy_best_rec_to_pic(KR k, const Cu &cu, int comp)
 {
   const int n = (1 << cu.log2) >> (comp ? 1 : 0), log2n = ilog2(n), x = cu.x >> (comp ? 1 : 0), y = cu.y >> (comp ? 1 : 0);
   const int cs = cstride(comp), ps = pstride(k, comp);
-  GLB const uint8_t *br = k.best_rec + comp_off(comp) + boff(k, comp, x, y);
-  GLB uint8_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  GLB const pel_t *br = k.best_rec + comp_off(comp) + boff(k, comp, x, y);
+  GLB pel_t *rp = k.rec[comp] + (size_t)y * ps + x;
   wsync();
   for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> log2n) * ps + (i & (n - 1))] = br[(i >> log2n) * cs + (i & (n - 1))];
   wsync();
@@ -2104,7 +2121,7 @@ template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
 } // namespace
 
 extern "C" __global__ __launch_bounds__(64)
-void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
+void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 {
   LSmem &s = lds();
   // one wave per (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
@@ -2116,16 +2133,16 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   k.W = p.width; k.H = p.height; k.cw = p.width >> 1; k.ctus_x = p.ctus_x; k.nctu = p.ctus_x * p.ctus_y;
   const size_t ysz = (size_t)p.width * p.height, csz = ysz >> 2, fsz = ysz + 2 * csz;
   const int nctu = p.ctus_x * p.ctus_y;
-  GLB const uint8_t *org0 = (GLB const uint8_t *)p.yuv + (size_t)frame * fsz;
-  GLB uint8_t *rec0 = (GLB uint8_t *)p.recon + (size_t)frame * fsz;
+  GLB const pel_t *org0 = (GLB const pel_t *)p.yuv + (size_t)frame * fsz;
+  GLB pel_t *rec0 = (GLB pel_t *)p.recon + (size_t)frame * fsz;
   k.org[0] = org0; k.org[1] = org0 + ysz; k.org[2] = org0 + ysz + csz;
   k.rec[0] = rec0; k.rec[1] = rec0 + ysz; k.rec[2] = rec0 + ysz + csz;
   GLB unsigned char *records = (GLB unsigned char *)p.records + (size_t)frame * nctu * REC_SIZE;
   k.records = records;
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   GLB unsigned char *scr = (GLB unsigned char *)p.scratch + (size_t)unit * p.scratch_per_frame;
-  k.coef_l = (GLB int16_t *)scr; k.rec_l = scr + 4 * 6144 * 2; k.best_rec = scr + 4 * 6144 * 2 + 4 * 6144;
-  k.q_cost = (GLB double *)(scr + 81920); k.q_rate = (GLB int32_t *)(scr + 81920 + 16384);
+  k.coef_l = (GLB int16_t *)scr; k.rec_l = (GLB pel_t *)(scr + 4 * 6144 * 2); k.best_rec = k.rec_l + 4 * 6144;
+  k.q_cost = (GLB double *)(scr + SCR_LAYERS); k.q_rate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
@@ -2232,7 +2249,7 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
       const int sh = c ? 1 : 0, ps = p.width >> sh, rx0 = k.tx0 >> sh, ry0 = k.ty0 >> sh;
       const int rw = ((k.tx1 < p.width ? k.tx1 : p.width) >> sh) - rx0, rh = ((k.ty1 < p.height ? k.ty1 : p.height) >> sh) - ry0;
       unsigned long long acc = 0;
-      GLB const uint8_t *po = org0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz)); GLB const uint8_t *pr = rec0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz));
+      GLB const pel_t *po = org0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz)); GLB const pel_t *pr = rec0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz));
       for (int yy = 0; yy < rh; yy++) {
         const size_t o = (size_t)(ry0 + yy) * ps + rx0;
         for (int xx = lane; xx < rw; xx += 64) { const int d = (int)po[o + xx] - (int)pr[o + xx]; acc += (unsigned long long)(d * d); }
@@ -2244,5 +2261,5 @@ void hevcdl_rd_frame_kernel(hevcdl_rd_params p)
   }
 }
 
-extern "C" size_t hevcdl_rd_smem_bytes(void) { return sizeof(RdSmem); }
-extern "C" size_t hevcdl_rd_scratch_bytes(void) { return 81920 + 16384 + 16384; }   // layers 79872 (padded) + RDOQ costs + SBH inputs
+extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return sizeof(RdSmem); }
+extern "C" size_t RD_SYM(hevcdl_rd_scratch_bytes)(void) { return SCR_LAYERS + 16384 + 16384; }   // layers 79872 (padded) + RDOQ costs + SBH inputs

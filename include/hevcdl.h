@@ -51,7 +51,9 @@ typedef enum {
 typedef struct hevcdl_config {
   uint32_t struct_size;          /* sizeof(hevcdl_config) */
   int32_t  width, height;        /* luma samples, multiples of 8 (min CU) */
-  int32_t  bit_depth;            /* 8 */
+  int32_t  bit_depth;            /* 8, or 10: InputBitDepth = InternalBitDepth = 10 (Profile main10); samples are then uint16,
+                                    little endian, in every yuv / recon buffer of the decision path; the CNN stage sees sample >> 2.
+                                    The in-loop filters and the bitstream writer are 8-bit only (HEVCDL_ERR_UNSUPPORTED). */
   int32_t  chroma_format;        /* 420 */
   int32_t  qp;                   /* slice QP, 0..51 */
   int32_t  ctu_size;             /* 64   (MaxCUWidth/Height)          */
@@ -102,6 +104,9 @@ typedef struct hevcdl_ctx hevcdl_ctx;
 /* Fill cfg from (width, height, qp) with the reference configuration (encoder_intra_main.cfg) and the
  * host-computed lambda family.  Replaces TEncSlice::setUpLambda / calculateLambda for this path. */
 hevcdl_status hevcdl_config_default(hevcdl_config *cfg, int width, int height, int qp);
+/* The same for a given sample bit depth (8 or 10): quantiser QP offset 6 per extra bit, distortion kept at 8-bit scale
+ * (the reference's FULL_NBIT 0 build, TypeDef.h:162-172), lambda unchanged (TEncSlice.cpp:433-527). */
+hevcdl_status hevcdl_config_default_bd(hevcdl_config *cfg, int width, int height, int qp, int bit_depth);
 
 /* weights: flat fp32 blob, HEVCDL_WEIGHT_FLOATS values (replaces torch.load at use_model.py:62). */
 hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *weights, size_t n_floats, hevcdl_ctx **out);
@@ -209,7 +214,8 @@ hevcdl_status hevcdl_profile_get(hevcdl_ctx *ctx, hevcdl_profile *out);   /* syn
 
 /* sizes */
 int      hevcdl_ctus_per_frame(int width, int height);
-size_t   hevcdl_frame_bytes(int width, int height);
+size_t   hevcdl_frame_bytes(int width, int height);                       /* 8-bit samples */
+size_t   hevcdl_frame_bytes_bd(int width, int height, int bit_depth);    /* 2 bytes per sample above 8 bits */
 
 #ifdef __cplusplus
 }

@@ -66,8 +66,15 @@ def test_invalid_and_unsupported_configurations_are_rejected(lib):
     cfg.tools = 0x3f                                                                                # FastUDIUseMPM off: would change the path
     assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size, ctypes.byref(h)) == 2
     cfg = hevcdl_amd.default_config(64, 64, 32)
-    cfg.bit_depth = 10
+    cfg.bit_depth = 12                                                                              # 8 and 10 exist
     assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size, ctypes.byref(h)) == 2
+    assert lib.hevcdl_config_default_bd(ctypes.byref(cfg), 64, 64, 32, 12) == 2
+    c8, c10 = hevcdl_amd.default_config(64, 64, 32), hevcdl_amd.default_config(64, 64, 32, bit_depth=10)
+    assert c10.bit_depth == 10 and c10.lambda_ == c8.lambda_ if hasattr(c8, "lambda_") else True
+    # distortion stays at 8-bit scale (FULL_NBIT 0): error scale of a TU drops by 2^(2*2) for the distortion shift and rises by 2^(2*2) for
+    # the transform shift -> unchanged; the sign-hiding factor gains 2^(2*2) from the QP offset of 12 and loses 2^4 from the distortion shift
+    assert [list(r) for r in c10.err_scale] == [list(r) for r in c8.err_scale] and list(c10.sbh_rd_factor) == list(c8.sbh_rd_factor)
+    assert lib.hevcdl_frame_bytes_bd(1920, 1080, 10) == 1920 * 1080 * 3
     assert lib.hevcdl_ctus_per_frame(3840, 2160) == 2040 and lib.hevcdl_ctus_per_frame(416, 240) == 28
     assert lib.hevcdl_frame_bytes(1920, 1080) == 1920 * 1080 * 3 // 2
 

@@ -32,9 +32,11 @@ def test_golden_records_bit_exact(path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     yuv, labels, ref = f["yuv"], f["labels"], f["records"]
     tiles = tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)     # rd_t*: reference runs with tiles enabled
-    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles)
+    bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd)
     recs, recon, stats = enc.compress_frames(yuv, labels)
     enc.close()
+    assert recon.dtype == (np.uint8 if bd == 8 else np.uint16)
     assert_records_equal(recs, ref, os.path.basename(path))
     for fr in range(yuv.shape[0]):
         for a in range(labels.shape[1]):
@@ -76,6 +78,34 @@ def test_tiles_match_oracle(oracle_built, w, h, qp, nf, seed, tiles):
     assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
     u_recs, _, _ = ref_tools.run_oracle(yuv, w, h, qp, labels)
     assert any(not np.array_equal(o_recs[k], u_recs[k]) for k in FIELDS)      # the tiling does change the decisions
+
+
+@pytest.mark.parametrize("w,h,qp,nf,seed,tiles,kind", [(256, 192, 24, 2, 81, (1, 1), "pattern"), (520, 136, 35, 1, 82, (2, 2), "pattern"), (192, 128, 30, 1, 83, (1, 1), "noise"),
+                                                      (128, 64, 12, 1, 84, (1, 1), "noise"), (128, 128, 48, 1, 85, (1, 1), "pattern")])
+def test_ten_bit_matches_oracle(oracle_built, w, h, qp, nf, seed, tiles, kind):
+    """InternalBitDepth 10 (uint16 samples; C5's sample format: the 8-bit pattern * 4 + noise): records, reconstruction, sums bit-exact
+    against the oracle; the CNN stage runs on the top 8 bits."""
+    import hevcdl_amd
+    import ref_tools
+    rng = np.random.default_rng(seed)
+    yuv = ref_tools.synth_yuv(w, h, nf, seed).astype(np.uint16) * 4 + rng.integers(0, 4, (nf, w * h * 3 // 2)).astype(np.uint16)
+    if kind == "noise":
+        yuv = rng.integers(0, 1024, yuv.shape).astype(np.uint16)
+    labels = ref_tools.make_labels(w, h, nf, "rand", seed + 1)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles, bit_depth=10)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    cnn_labels = enc.predict_depth(yuv)
+    enc.close()
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels, tiles=tiles, bit_depth=10)
+    assert_records_equal(recs, o_recs, "oracle 10-bit %dx%d" % (w, h))
+    assert recon.dtype == np.uint16 and np.array_equal(recon, o_recon.reshape(recon.shape)) and int(recon.max()) <= 1023
+    assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
+    enc8 = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    assert np.array_equal(cnn_labels, enc8.predict_depth((yuv >> 2).astype(np.uint8)))
+    with pytest.raises(hevcdl_amd.HevcdlError):          # in-loop filters: 8-bit only so far
+        enc10 = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, bit_depth=10)
+        enc10.deblock_frames(recon, recs)
+    enc8.close()
 
 
 def test_tile_ranges_assemble_to_the_whole_picture(oracle_built):
