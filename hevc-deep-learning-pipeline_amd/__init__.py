@@ -57,7 +57,7 @@ class Config(ctypes.Structure):
 class StreamConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("qp", ctypes.c_int32),
                 ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
-                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -172,7 +172,7 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1)):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -181,6 +181,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
         raise HevcdlError(st, "stream config")
     cfg.level_idc = level_idc
     cfg.tile_columns, cfg.tile_rows = int(tiles[0]), int(tiles[1])
+    cfg.bit_depth = bit_depth
     sao_ptr = None
     if sao is not None:
         sao = np.ascontiguousarray(sao, SAO_DTYPE)

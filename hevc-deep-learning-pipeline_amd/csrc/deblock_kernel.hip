@@ -24,7 +24,19 @@ namespace {
 enum { REC_SIZE = 15120, REC_TRIDX = 4 * 256 };
 
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ int clip8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int clipbd(int v, int mx) { return v < 0 ? 0 : (v > mx ? mx : v); }      // ClipBD
+
+// four neighbouring samples of a row as one access: a dword of 8-bit samples, two dwords of 16-bit samples (10-bit pictures)
+template <typename PEL> __device__ __forceinline__ void load4(const PEL GLB *p, int (&v)[4])
+{
+  if constexpr (sizeof(PEL) == 1) { const uint32_t w = *(const uint32_t GLB *)p; v[0] = w & 255; v[1] = (w >> 8) & 255; v[2] = (w >> 16) & 255; v[3] = w >> 24; }
+  else { const unsigned long long w = *(const unsigned long long GLB *)p; v[0] = (int)(w & 0xffff); v[1] = (int)((w >> 16) & 0xffff); v[2] = (int)((w >> 32) & 0xffff); v[3] = (int)(w >> 48); }
+}
+template <typename PEL> __device__ __forceinline__ void store4(PEL GLB *p, int a, int b, int c, int d)
+{
+  if constexpr (sizeof(PEL) == 1) *(uint32_t GLB *)p = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+  else *(unsigned long long GLB *)p = (unsigned long long)(uint32_t)a | ((unsigned long long)(uint32_t)b << 16) | ((unsigned long long)(uint32_t)c << 32) | ((unsigned long long)(uint32_t)d << 48);
+}
 
 // TU edge at the left (dir 0) / top (dir 1) border of the 4x4 partition at luma (x, y) of this frame?
 __device__ __forceinline__ bool edge_flag(const unsigned char GLB *recs, int ctus_x, int x, int y, int dir)
@@ -40,7 +52,7 @@ __device__ __forceinline__ bool edge_flag(const unsigned char GLB *recs, int ctu
 }
 
 // luma decision + filter of one 4-line segment; m[line][0..7] = p3 p2 p1 p0 | q0 q1 q2 q3
-__device__ __forceinline__ void filter_luma(int (&m)[4][8], int tc, int beta)
+__device__ __forceinline__ void filter_luma(int (&m)[4][8], int tc, int beta, int mx)
 {
   auto dp = [&](int i) { return abs(m[i][1] - 2 * m[i][2] + m[i][3]); };
   auto dq = [&](int i) { return abs(m[i][4] - 2 * m[i][5] + m[i][6]); };
@@ -68,21 +80,20 @@ __device__ __forceinline__ void filter_luma(int (&m)[4][8], int tc, int beta)
       if (abs(delta) < thr_cut) {
         const int tc2 = tc >> 1;
         delta = clip3i(-tc, tc, delta);
-        m[i][3] = clip8i(m3 + delta); m[i][4] = clip8i(m4 - delta);
-        if (fp) m[i][2] = clip8i(m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
-        if (fq) m[i][5] = clip8i(m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+        m[i][3] = clipbd(m3 + delta, mx); m[i][4] = clipbd(m4 - delta, mx);
+        if (fp) m[i][2] = clipbd(m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)), mx);
+        if (fq) m[i][5] = clipbd(m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)), mx);
       }
     }
   }
 }
 // chroma (Bs 2): p1 p0 | q0 q1 -> p0, q0
-__device__ __forceinline__ void filter_chroma(int m2, int &m3, int &m4, int m5, int tc)
+__device__ __forceinline__ void filter_chroma(int m2, int &m3, int &m4, int m5, int tc, int mx)
 {
   const int delta = clip3i(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-  m3 = clip8i(m3 + delta); m4 = clip8i(m4 - delta);
+  m3 = clipbd(m3 + delta, mx); m4 = clipbd(m4 - delta, mx);
 }
 
-__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); }
 
 } // namespace
 
@@ -90,7 +101,7 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return (
 // [8bx-4, 8bx+4) x 4 rows.  CHROMA == 1: the same on both chroma planes with chroma coordinates (edge grid 8 chroma =
 // 16 luma samples; a 4-row chroma block spans two luma partitions = two edge flags).  Reads `in`, writes `out`
 // (every sample of the plane exactly once; in == out is allowed).
-template <int CHROMA>
+template <int CHROMA, typename PEL>
 __global__ __launch_bounds__(256) void hevcdl_deblock_ver_kernel(hevcdl_dbk_params p)
 {
   const int frame = blockIdx.z;
@@ -109,37 +120,28 @@ __global__ __launch_bounds__(256) void hevcdl_deblock_ver_kernel(hevcdl_dbk_para
 #pragma unroll 1
   for (int c = 0; c < (CHROMA ? 2 : 1); c++) {
     const size_t plane = (size_t)frame * fsz + (CHROMA ? ysz + (size_t)c * (ysz >> 2) : 0);
-    const uint8_t GLB *src = (const uint8_t GLB *)p.in + plane; uint8_t GLB *dst = (uint8_t GLB *)p.out + plane;
-    uint32_t l[4], r[4];
+    const PEL GLB *src = (const PEL GLB *)p.in + plane; PEL GLB *dst = (PEL GLB *)p.out + plane;
+    int m[4][8];                                              // row i: p3 p2 p1 p0 | q0 q1 q2 q3
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const size_t o = (size_t)(y + i) * W + x;
-      l[i] = has_l ? *(const uint32_t GLB *)(src + o - 4) : 0u; r[i] = has_r ? *(const uint32_t GLB *)(src + o) : 0u;
+      int l[4] = { 0, 0, 0, 0 }, r[4] = { 0, 0, 0, 0 };
+      if (has_l) load4<PEL>(src + o - 4, l);
+      if (has_r) load4<PEL>(src + o, r);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { m[i][k] = l[k]; m[i][4 + k] = r[k]; }
     }
     if (!CHROMA) {
-      if (e0) {
-        int m[4][8];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int k = 0; k < 4; k++) { m[i][k] = (l[i] >> (8 * k)) & 255; m[i][4 + k] = (r[i] >> (8 * k)) & 255; }
-        filter_luma(m, p.tc, p.beta);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { l[i] = pack4(m[i][0], m[i][1], m[i][2], m[i][3]); r[i] = pack4(m[i][4], m[i][5], m[i][6], m[i][7]); }
-      }
+      if (e0) filter_luma(m, p.tc, p.beta, p.pel_max);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) if (i < 2 ? e0 : e1) {
-        int m3 = (l[i] >> 24) & 255, m4 = r[i] & 255;
-        filter_chroma((l[i] >> 16) & 255, m3, m4, (r[i] >> 8) & 255, p.tc_c);
-        l[i] = (l[i] & 0x00ffffffu) | ((uint32_t)m3 << 24); r[i] = (r[i] & 0xffffff00u) | (uint32_t)m4;
-      }
+      for (int i = 0; i < 4; i++) if (i < 2 ? e0 : e1) filter_chroma(m[i][2], m[i][3], m[i][4], m[i][5], p.tc_c, p.pel_max);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const size_t o = (size_t)(y + i) * W + x;
-      if (has_l) *(uint32_t GLB *)(dst + o - 4) = l[i];
-      if (has_r) *(uint32_t GLB *)(dst + o) = r[i];
+      if (has_l) store4<PEL>(dst + o - 4, m[i][0], m[i][1], m[i][2], m[i][3]);
+      if (has_r) store4<PEL>(dst + o, m[i][4], m[i][5], m[i][6], m[i][7]);
     }
   }
 }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void hevcdl_deblock_ver_kernel(hevcdl_dbk_para
 // Pass 2: horizontal edges, in place on `out`.  Thread = (4-sample column group xg, edge row by): samples
 // [4xg, 4xg+4) x rows [8by-4, 8by+4); the 4 columns are the 4 lines of the segment.  Only blocks with an edge are
 // touched (a block without one keeps the values of pass 1).
-template <int CHROMA>
+template <int CHROMA, typename PEL>
 __global__ __launch_bounds__(256) void hevcdl_deblock_hor_kernel(hevcdl_dbk_params p)
 {
   const int frame = blockIdx.z;
@@ -163,32 +165,30 @@ __global__ __launch_bounds__(256) void hevcdl_deblock_hor_kernel(hevcdl_dbk_para
   if (!e0 && !e1) return;
 #pragma unroll 1
   for (int c = 0; c < (CHROMA ? 2 : 1); c++) {
-    uint8_t GLB *pl = (uint8_t GLB *)p.out + (size_t)frame * fsz + (CHROMA ? ysz + (size_t)c * (ysz >> 2) : 0);
+    PEL GLB *pl = (PEL GLB *)p.out + (size_t)frame * fsz + (CHROMA ? ysz + (size_t)c * (ysz >> 2) : 0);
     if (!CHROMA) {
-      uint32_t row[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) row[k] = *(const uint32_t GLB *)(pl + (size_t)(y - 4 + k) * W + x);
       int m[4][8];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 8; k++) {
+        int row[4]; load4<PEL>(pl + (size_t)(y - 4 + k) * W + x, row);
 #pragma unroll
-        for (int k = 0; k < 8; k++) m[i][k] = (row[k] >> (8 * i)) & 255;
-      filter_luma(m, p.tc, p.beta);
+        for (int i = 0; i < 4; i++) m[i][k] = row[i];
+      }
+      filter_luma(m, p.tc, p.beta, p.pel_max);
 #pragma unroll
-      for (int k = 1; k < 7; k++) *(uint32_t GLB *)(pl + (size_t)(y - 4 + k) * W + x) = pack4(m[0][k], m[1][k], m[2][k], m[3][k]);
+      for (int k = 1; k < 7; k++) store4<PEL>(pl + (size_t)(y - 4 + k) * W + x, m[0][k], m[1][k], m[2][k], m[3][k]);
     } else {
-      uint32_t row[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) row[k] = *(const uint32_t GLB *)(pl + (size_t)(y - 2 + k) * W + x);
       int v[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 4; k++) {
+        int row[4]; load4<PEL>(pl + (size_t)(y - 2 + k) * W + x, row);
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[i][k] = (row[k] >> (8 * i)) & 255;
+        for (int i = 0; i < 4; i++) v[i][k] = row[i];
+      }
 #pragma unroll
-      for (int i = 0; i < 4; i++) if (i < 2 ? e0 : e1) filter_chroma(v[i][0], v[i][1], v[i][2], v[i][3], p.tc_c);
-      *(uint32_t GLB *)(pl + (size_t)(y - 1) * W + x) = pack4(v[0][1], v[1][1], v[2][1], v[3][1]);
-      *(uint32_t GLB *)(pl + (size_t)y * W + x) = pack4(v[0][2], v[1][2], v[2][2], v[3][2]);
+      for (int i = 0; i < 4; i++) if (i < 2 ? e0 : e1) filter_chroma(v[i][0], v[i][1], v[i][2], v[i][3], p.tc_c, p.pel_max);
+      store4<PEL>(pl + (size_t)(y - 1) * W + x, v[0][1], v[1][1], v[2][1], v[3][1]);
+      store4<PEL>(pl + (size_t)y * W + x, v[0][2], v[1][2], v[2][2], v[3][2]);
     }
   }
 }
@@ -198,8 +198,17 @@ extern "C" void hevcdl_launch_deblock(const hevcdl_dbk_params *pp, void *stream)
   const hevcdl_dbk_params p = *pp;
   hipStream_t s = (hipStream_t)stream;
   const int W = p.width, H = p.height, cw = W >> 1, chh = H >> 1;
-  hipLaunchKernelGGL(hevcdl_deblock_ver_kernel<0>, dim3((W / 8 + 1 + 63) / 64, (H / 4 + 3) / 4, p.n_frames), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(hevcdl_deblock_ver_kernel<1>, dim3((cw / 8 + 1 + 63) / 64, (chh / 4 + 3) / 4, p.n_frames), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(hevcdl_deblock_hor_kernel<0>, dim3((W / 4 + 63) / 64, (H / 8 + 1 + 3) / 4, p.n_frames), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(hevcdl_deblock_hor_kernel<1>, dim3((cw / 4 + 63) / 64, (chh / 8 + 1 + 3) / 4, p.n_frames), dim3(256), 0, s, p);
+  const dim3 gv0((W / 8 + 1 + 63) / 64, (H / 4 + 3) / 4, p.n_frames), gv1((cw / 8 + 1 + 63) / 64, (chh / 4 + 3) / 4, p.n_frames);
+  const dim3 gh0((W / 4 + 63) / 64, (H / 8 + 1 + 3) / 4, p.n_frames), gh1((cw / 4 + 63) / 64, (chh / 8 + 1 + 3) / 4, p.n_frames);
+  if (p.pel_max == 255) {
+    hipLaunchKernelGGL((hevcdl_deblock_ver_kernel<0, uint8_t>), gv0, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((hevcdl_deblock_ver_kernel<1, uint8_t>), gv1, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((hevcdl_deblock_hor_kernel<0, uint8_t>), gh0, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((hevcdl_deblock_hor_kernel<1, uint8_t>), gh1, dim3(256), 0, s, p);
+  } else { // 16-bit sample planes (10-bit pictures)
+    hipLaunchKernelGGL((hevcdl_deblock_ver_kernel<0, uint16_t>), gv0, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((hevcdl_deblock_ver_kernel<1, uint16_t>), gv1, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((hevcdl_deblock_hor_kernel<0, uint16_t>), gh0, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((hevcdl_deblock_hor_kernel<1, uint16_t>), gh1, dim3(256), 0, s, p);
+  }
 }

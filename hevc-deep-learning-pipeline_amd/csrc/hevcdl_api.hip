@@ -363,14 +363,15 @@ static const unsigned char DBK_BETA[52] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,6,7,
 extern "C" hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *d_recon, int n_frames, const void *d_records, void *d_out, void *stream)
 {
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
-  if (ctx->cfg.bit_depth != 8) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "the in-loop filters are implemented for 8-bit samples only");
   if (n_frames == 0) return HEVCDL_OK;
   if (!d_recon || !d_records || !d_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
   hevcdl_dbk_params p;
   p.in = (const uint8_t *)d_recon; p.out = (uint8_t *)d_out; p.records = (const unsigned char *)d_records;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames;
   const int qp = ctx->cfg.qp, qpc = CHROMA_SCALE_420[qp < 0 ? 0 : (qp > 57 ? 57 : qp)];      // TComLoopFilter.cpp:782-797, cQpOffset 0
-  p.tc = DBK_TC[qp + 2 > 53 ? 53 : qp + 2]; p.beta = DBK_BETA[qp]; p.tc_c = DBK_TC[qpc + 2 > 53 ? 53 : qpc + 2];
+  const int bd_scale = 1 << (ctx->cfg.bit_depth - 8);                                       // iBitdepthScale, TComLoopFilter.cpp:596, 770
+  p.tc = DBK_TC[qp + 2 > 53 ? 53 : qp + 2] * bd_scale; p.beta = DBK_BETA[qp] * bd_scale; p.tc_c = DBK_TC[qpc + 2 > 53 ? 53 : qpc + 2] * bd_scale;
+  p.pel_max = (1 << ctx->cfg.bit_depth) - 1;
   hevcdl_launch_deblock(&p, stream);
   HIPCHK(hipGetLastError());
   return HEVCDL_OK;

@@ -94,10 +94,10 @@ uint32_t count_emulations(const std::vector<uint8_t> &b)
   return cnt;
 }
 
-void profile_tier_level(BitOut &w, int level_idc)
-{ // codePTL / codeProfileTier, Main profile (TAppEncCfg: Profile main => compatibility flags 1 and 2)
-  w.write(0, 2); w.flag(0); w.write(1, 5);
-  w.write(0x60000000u, 32);
+void profile_tier_level(BitOut &w, int level_idc, int bit_depth)
+{ // codePTL / codeProfileTier: Profile main => idc 1, compatibility flags 1 and 2; main10 at 10 bits => idc 2, flag 2 only (TAppEncTop.cpp:120-135)
+  w.write(0, 2); w.flag(0); w.write(bit_depth > 8 ? 2 : 1, 5);
+  w.write(bit_depth > 8 ? 0x20000000u : 0x60000000u, 32);
   w.flag(0); w.flag(0); w.flag(0); w.flag(0);                       // progressive / interlaced / non-packed / frame-only
   w.write(0, 16); w.write(0, 16); w.write(0, 11); w.flag(0);        // reserved_zero_43bits, inbld_flag
   w.write((uint32_t)level_idc, 8);
@@ -405,7 +405,7 @@ void code_transform(Cabac &c, const Cu &cu, const Tu &tu)
   }
 }
 // sao(): TEncSbac::codeSAOBlkParam / codeSAOOffsetParam TEncSbac.cpp:1543-1720, called before every CTU (TEncSlice.cpp:1075-1111)
-void code_sao_offset(Cabac &c, int comp, const hevcdl_sao_offset &p)
+void code_sao_offset(Cabac &c, int comp, const hevcdl_sao_offset &p, int max_off)
 {
   const int first = comp != 2;
   if (first) {
@@ -416,20 +416,20 @@ void code_sao_offset(Cabac &c, int comp, const hevcdl_sao_offset &p)
   int off[4], k = 0;
   const int ncls = p.type == 4 ? 4 : 5;
   for (int i = 0; i < ncls; i++) { if (p.type != 4 && i == 2) continue; off[k++] = p.offset[p.type == 4 ? (p.aux + i) % 32 : i]; }
-  for (int i = 0; i < 4; i++) { // codeSaoMaxUvlc, maximum 7
+  for (int i = 0; i < 4; i++) { // codeSaoMaxUvlc, maximum (1 << (min(bitDepth, 10) - 5)) - 1: 7 at 8 bits, 31 at 10
     const int a = abs(off[i]);
     if (a == 0) c.ep(0);
-    else { c.ep(1); for (int j = 0; j < a - 1; j++) c.ep(1); if (a < 7) c.ep(0); }
+    else { c.ep(1); for (int j = 0; j < a - 1; j++) c.ep(1); if (a < max_off) c.ep(0); }
   }
   if (p.type == 4) { for (int i = 0; i < 4; i++) if (off[i]) c.ep(off[i] < 0); c.eps((uint32_t)p.aux, 5); }
   else if (first) c.eps((uint32_t)p.type, 2);
 }
-void code_sao_blk(Cabac &c, const hevcdl_sao_blk &b, bool left_avail, bool above_avail)
+void code_sao_blk(Cabac &c, const hevcdl_sao_blk &b, bool left_avail, bool above_avail, int max_off)
 {
   bool is_left = false, is_above = false;
   if (left_avail) { is_left = b.c[0].mode == 2 && b.c[0].type == 0; c.bin(CTX_SAO_MERGE, is_left); }
   if (above_avail && !is_left) { is_above = b.c[0].mode == 2 && b.c[0].type == 1; c.bin(CTX_SAO_MERGE, is_above); }
-  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_sao_offset(c, comp, b.c[comp]);
+  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_sao_offset(c, comp, b.c[comp], max_off);
 }
 
 void code_cu_tree(Cabac &c, const Pic &p, int x, int y, int depth)
@@ -466,7 +466,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
-  cfg->tile_columns = 1; cfg->tile_rows = 1;
+  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8;
   return HEVCDL_OK;
 }
 
@@ -482,6 +482,8 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51) return HEVCDL_ERR_INVALID_ARG;
   if (cfg->loop_filter_disable) return HEVCDL_ERR_UNSUPPORTED;                          // the PPS below signals deblocking on
   if ((cfg->sao_enabled != 0) != (sao != nullptr)) return HEVCDL_ERR_INVALID_ARG;         // SAO parameters go with sample_adaptive_offset_enabled_flag
+  const int bd = cfg->bit_depth;
+  if (bd != 8 && bd != 10) return HEVCDL_ERR_UNSUPPORTED;
   const int tcols = cfg->tile_columns, trows = cfg->tile_rows, tiled = tcols * trows > 1;
   if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22 || trows > ((cfg->height + 63) >> 6)) return HEVCDL_ERR_INVALID_ARG;
   if (tiled) for (int c = 0; c < tcols; c++) if (((c + 1) * ((cfg->width + 63) >> 6)) / tcols - (c * ((cfg->width + 63) >> 6)) / tcols < 4) return HEVCDL_ERR_INVALID_ARG;   // TComPicSym.cpp:388
@@ -489,7 +491,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   { // VPS  TEncCavlc.cpp:677-753
     BitOut w;
     w.write(0, 4); w.flag(1); w.flag(1); w.write(0, 6); w.write(0, 3); w.flag(1); w.write(0xffff, 16);
-    profile_tier_level(w, cfg->level_idc);
+    profile_tier_level(w, cfg->level_idc, bd);
     w.flag(1); w.ue(0); w.ue(0); w.ue(0);            // sub_layer_ordering_info_present, max_dec_pic_buffering_minus1, num_reorder, max_latency_plus1
     w.write(0, 6); w.ue(0); w.flag(0); w.flag(0);    // vps_max_layer_id, num_layer_sets_minus1, timing_info_present, extension
     w.trailing();
@@ -498,10 +500,10 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   { // SPS  TEncCavlc.cpp:500-675
     BitOut w;
     w.write(0, 4); w.write(0, 3); w.flag(1);
-    profile_tier_level(w, cfg->level_idc);
+    profile_tier_level(w, cfg->level_idc, bd);
     w.ue(0); w.ue(1); w.ue((uint32_t)cfg->width); w.ue((uint32_t)cfg->height);
     w.flag(1); w.ue(0); w.ue(0); w.ue(0); w.ue(0);   // conformance window present with zero offsets (as the reference writes it)
-    w.ue(0); w.ue(0); w.ue(4);                       // bit depths - 8, log2_max_pic_order_cnt_lsb_minus4 (8 bits)
+    w.ue((uint32_t)bd - 8); w.ue((uint32_t)bd - 8); w.ue(4);     // bit depths - 8, log2_max_pic_order_cnt_lsb_minus4 (8 bits)
     w.flag(1); w.ue(0); w.ue(0); w.ue(0);
     w.ue(0); w.ue(3); w.ue(0); w.ue(3); w.ue(2); w.ue(2);    // CB 8..64, TB 4..32, TU depth inter/intra 3
     w.flag(0); w.flag(1); w.flag(cfg->sao_enabled); w.flag(0); // scaling list, AMP, SAO, PCM
@@ -545,7 +547,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
       pic.tx0 = cx0 * 64; pic.ty0 = cy0 * 64;
       for (int cy = cy0; cy < cy1; cy++) for (int cx = cx0; cx < cx1; cx++) {
         const int a = cy * pic.ctus_x + cx;
-        if (sao) code_sao_blk(c, sao[a], cx > cx0, cy > cy0);      // merge candidates stay inside the tile (TComPic::getSAOMergeAvailability)
+        if (sao) code_sao_blk(c, sao[a], cx > cx0, cy > cy0, (1 << ((bd < 10 ? bd : 10) - 5)) - 1);      // merge candidates stay inside the tile (TComPic::getSAOMergeAvailability)
         code_cu_tree(c, pic, cx * 64, cy * 64, 0);
         if (a != ctus - 1) c.terminate(0);           // end_of_slice_segment_flag 0 (finishCU TEncCu.cpp:1112-1128)
       }

@@ -59,7 +59,8 @@ struct hevcdl_dbk_params {
   uint8_t *out;                    // [frame] deblocked picture (may alias in)
   const unsigned char *records;    // [frame][ctu] hevcdl_ctu_record (depth, trIdx give the TU grid)
   int width, height, ctus_x, ctus_per_frame, n_frames;
-  int tc, beta, tc_c;
+  int tc, beta, tc_c;              // already scaled by 1 << (bit depth - 8) (TComLoopFilter.cpp:596, 770)
+  int pel_max;                     // (1 << bit depth) - 1; 255: planes of uint8, otherwise planes of uint16
 };
 
 // sample adaptive offset (sao_kernel.hip)

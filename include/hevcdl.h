@@ -163,7 +163,7 @@ typedef struct hevcdl_stream_config {
   int32_t  loop_filter_disable;  /* must be 0 (LoopFilterDisable 0: deblocking on, zero offsets, no PPS control fields) */
   int32_t  tile_columns, tile_rows; /* as in hevcdl_config: PPS tile syntax (loop_filter_across_tiles_enabled_flag 1), CTUs in tile scan,
                                        one sub-stream per tile with entry points in the slice header */
-  int32_t  reserved;
+  int32_t  bit_depth;            /* 8 (Profile main) or 10 (Profile main10): profile_tier_level, SPS bit depths, SAO offset range */
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
 size_t        hevcdl_access_unit_bound(int width, int height);

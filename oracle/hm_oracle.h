@@ -48,6 +48,7 @@ int hm_oracle_encode_frames_ex(const void *yuv, int width, int height, int n_fra
 
 /* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
 int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);
+int hm_oracle_deblock_frame16(uint16_t *frame, int width, int height, int qp, const hm_ctu_record *recs, int bit_depth);   /* uint16 samples, bit_depth 8 or 10 */
 
 /* Sample adaptive offset (oracle/hm_sao.c).  mode 0 off / 1 new / 2 merge; type: new -> 0..3 edge offset 0/90/135/45 degrees,
  * 4 band offset; merge -> 0 left, 1 above; aux = band position; offset[class] (edge classes 0..4, bands 0..31). */

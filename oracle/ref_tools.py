@@ -209,9 +209,18 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     return recs, recon, stats
 
 
-def run_deblock(recon, width, height, qp, recs):
+def run_deblock(recon, width, height, qp, recs, bit_depth=8):
     """Oracle deblocking of pre-filter reconstructions [frames][w*h*3/2] given the records [frames][ctus] -> filtered copy."""
     lib = oracle_lib()
+    if bit_depth != 8:
+        lib.hm_oracle_deblock_frame16.restype = ctypes.c_int
+        lib.hm_oracle_deblock_frame16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        out = np.ascontiguousarray(recon, np.uint16).copy().reshape(recs.shape[0], -1)
+        recs = np.ascontiguousarray(recs)
+        for f in range(out.shape[0]):
+            if lib.hm_oracle_deblock_frame16(out[f].ctypes.data, width, height, qp, recs[f].ctypes.data, bit_depth) != 0:
+                raise RuntimeError("oracle deblock failed")
+        return out
     lib.hm_oracle_deblock_frame.restype = ctypes.c_int
     lib.hm_oracle_deblock_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     out = np.ascontiguousarray(recon, np.uint8).copy().reshape(recs.shape[0], -1)

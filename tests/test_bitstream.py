@@ -10,7 +10,7 @@ import pytest
 from conftest import GOLD
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "rd_*.npz")) if not os.path.basename(p).startswith("rd_x"))      # rd_x*: 10-bit runs (decision path only so far)
+CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
 REF_DEC = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder_ref")
 
 
@@ -22,7 +22,8 @@ def stream_of(f):
     import hevcdl_amd
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
-    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f)) for poc in range(recs.shape[0]))
+    bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8        # rd_x*: reference runs at InternalBitDepth 10, Profile main10
+    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd) for poc in range(recs.shape[0]))
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
@@ -34,7 +35,7 @@ def test_stream_is_byte_exact_with_the_reference(path):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_DEC), reason="reference decoder build (oracle/_ref) only exists in the survey container")
-@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r", "t520_q37_2x2", "t576_q27_2x3"))],
+@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r", "t520_q37_2x2", "t576_q27_2x3", "x200_q27_r", "x576_q30_2x3"))],
                          ids=lambda p: os.path.basename(p)[3:-4])
 def test_reference_decoder_reconstructs_the_deblocked_picture(path, tmp_path):
     f = np.load(path)

@@ -7,7 +7,15 @@ import pytest
 
 from conftest import GOLD
 
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "rd_*.npz")) if not os.path.basename(p).startswith("rd_x"))      # rd_x*: 10-bit runs (decision path only so far)
+CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
+
+
+def bit_depth_of(f):
+    return int(f["bit_depth"]) if "bit_depth" in f.files else 8         # rd_x*: reference runs at InternalBitDepth 10 (uint16 samples)
+
+
+def deblocked_of(f, shape):
+    return np.frombuffer(f["recon_deblocked"].tobytes(), np.uint8 if bit_depth_of(f) == 8 else "<u2").reshape(shape)
 
 
 def prefilter_frames(f):
@@ -15,9 +23,10 @@ def prefilter_frames(f):
     w, h = int(f["width"]), int(f["height"])
     nf, nctu = f["records"].shape[0], f["records"].shape[1]
     cx = (w + 63) // 64
-    frames = np.zeros((nf, w * h * 3 // 2), np.uint8)
+    dt = f["rec_y"].dtype
+    frames = np.zeros((nf, w * h * 3 // 2), dt)
     for fr in range(nf):
-        Y = np.zeros((h + 64, w + 64), np.uint8); U = np.zeros((h // 2 + 32, w // 2 + 32), np.uint8); V = U.copy()
+        Y = np.zeros((h + 64, w + 64), dt); U = np.zeros((h // 2 + 32, w // 2 + 32), dt); V = U.copy()
         for a in range(nctu):
             x0, y0 = (a % cx) * 64, (a // cx) * 64
             Y[y0:y0 + 64, x0:x0 + 64] = f["rec_y"][fr, a].reshape(64, 64)
@@ -34,8 +43,8 @@ def test_oracle_deblock_matches_reference(oracle_built, path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     recs = np.frombuffer(f["records"].tobytes(), dtype=ref_tools.REC_DTYPE).reshape(f["records"].shape[0], -1)
     pre = prefilter_frames(f)
-    out = ref_tools.run_deblock(pre, w, h, qp, recs)
-    ref = f["recon_deblocked"].reshape(out.shape)
+    out = ref_tools.run_deblock(pre, w, h, qp, recs, bit_depth=bit_depth_of(f))
+    ref = deblocked_of(f, out.shape)
     assert (pre != ref).sum() > 1000                       # the filter does something on every fixture
     assert np.array_equal(out, ref)
 
@@ -60,10 +69,10 @@ def test_gpu_deblock_matches_reference(path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     nf = f["records"].shape[0]
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, bit_depth=bit_depth_of(f))
     out = e.deblock_frames(prefilter_frames(f), recs)
     e.close()
-    assert np.array_equal(out, f["recon_deblocked"].reshape(out.shape))
+    assert np.array_equal(out, deblocked_of(f, out.shape))
 
 
 @pytest.mark.gpu
