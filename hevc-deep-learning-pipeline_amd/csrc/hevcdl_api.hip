@@ -396,7 +396,6 @@ extern "C" hevcdl_status hevcdl_deblock_frames(hevcdl_ctx *ctx, const uint8_t *r
 extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_org, const void *d_deblocked, int n_frames, void *d_params, void *d_out, void *stream)
 {
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
-  if (ctx->cfg.bit_depth != 8) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "the in-loop filters are implemented for 8-bit samples only");
   if (n_frames == 0) return HEVCDL_OK;
   if (!d_org || !d_deblocked || !d_params || !d_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
   const size_t nf = (size_t)ctx->cfg.max_frames;
@@ -407,7 +406,7 @@ extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_or
   p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames; p.qp = ctx->cfg.qp;
   p.lambda = ctx->cfg.lambda; p.lambda_chroma = ctx->cfg.lambda_chroma;          // slice lambdas per component, TEncSlice.cpp:112-140
-  p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
+  p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows; p.bit_depth = ctx->cfg.bit_depth;
   hevcdl_launch_sao(&p, stream);
   HIPCHK(hipGetLastError());
   return HEVCDL_OK;

@@ -37,7 +37,7 @@ const Key KEYS[] = {
   { "LabelDir", 0, USED, 0 }, { "BatchFrames", 0, USED, 0 }, { "Device", 0, USED, 0 }, { "Weights", 0, USED, 0 }, { "RecordFile", 0, USED, 0 },
   { "CnnInput", 0, USED, 0 }, { "PrintConfig", 0, USED, 0 }, { "LoopFilterDisable", 0, USED, 0 },
   // keys that define the path: only the implemented value is accepted
-  { "InputBitDepth", 0, PATH, "8" }, { "InternalBitDepth", 0, PATH, "8" }, { "InputChromaFormat", 0, PATH, "420" }, { "Profile", 0, PATH, "main" },
+  { "InputBitDepth", 0, USED, 0 }, { "InternalBitDepth", 0, USED, 0 }, { "InputChromaFormat", 0, PATH, "420" }, { "Profile", 0, USED, 0 },
   { "MaxCUWidth", 0, PATH, "64" }, { "MaxCUHeight", 0, PATH, "64" }, { "MaxPartitionDepth", 0, PATH, "4" },
   { "QuadtreeTULog2MaxSize", 0, PATH, "5" }, { "QuadtreeTULog2MinSize", 0, PATH, "2" }, { "QuadtreeTUMaxDepthIntra", 0, PATH, "3" },
   { "IntraPeriod", 0, PATH, "1" }, { "GOPSize", 0, PATH, "1" }, { "MaxDeltaQP", 0, PATH, "0" }, { "DeltaQpRD", 0, PATH, "0" },
@@ -121,7 +121,7 @@ std::string native_path(std::string p)
   return p;
 }
 
-double psnr_of(unsigned long long sse, double n) { return sse == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 * n / (double)sse); }   // TEncGOP.cpp:2391-2393
+double psnr_of(unsigned long long sse, double n, double maxval = 255.0) { return sse == 0 ? 999.99 : 10.0 * log10(maxval * maxval * n / (double)sse); }   // TEncGOP.cpp:2391-2393, maxval = 255 << (bitDepth - 8)
 
 std::string json_escape(const std::string &s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o; }
 
@@ -148,6 +148,13 @@ int main(int argc, char **argv)
   const int level_idc = (int)(atof(opt.get("Level", "6.2").c_str()) * 30.0 + 0.5);      // general_level_idc
   const bool deblock = opt.geti("LoopFilterDisable", 0) == 0;
   const bool sao = opt.geti("SAO", 1) != 0;                                    // TAppEncCfg.cpp: SAO defaults to on
+  // sample bit depth (TAppEncCfg.cpp:770-780): 8 (Profile main) or 10 (Profile main10; the file then holds 16-bit little-endian samples).
+  // InternalBitDepth 0 = the input's; bit-depth conversion between file and codec is not implemented.
+  const int in_bd = (int)opt.geti("InputBitDepth", 8), bit_depth = opt.geti("InternalBitDepth", 0) == 0 ? in_bd : (int)opt.geti("InternalBitDepth", 0);
+  if (bit_depth != in_bd) opt.errors.push_back("InternalBitDepth must equal InputBitDepth on this path (no bit-depth conversion)");
+  if (bit_depth != 8 && bit_depth != 10) opt.errors.push_back("InternalBitDepth = " + std::to_string(bit_depth) + " is not implemented by this path (only 8 and 10)");
+  { const std::string prof = opt.get("Profile", bit_depth == 8 ? "main" : "main10");
+    if (prof != (bit_depth == 8 ? "main" : "main10")) opt.errors.push_back("Profile = " + prof + " is not implemented by this path (main at 8 bits, main10 at 10 bits)"); }
   // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows; the in-loop filters cross tile borders (LFCrossTileBoundaryFlag 1, the default)
   const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
   if (tile_cols * tile_rows > 1) {
@@ -156,8 +163,8 @@ int main(int argc, char **argv)
   }
   if (opt.v.count("PrintConfig")) {
     printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
-           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"BitstreamFile\": \"%s\", \"level_idc\": %d, \"tiles\": [%d, %d], \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
-           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str(), json_escape(bitstream_path).c_str(), level_idc, tile_cols, tile_rows);
+           "\"FrameRate\": %g, \"LabelDir\": \"%s\", \"CnnInput\": \"%s\", \"BitstreamFile\": \"%s\", \"level_idc\": %d, \"tiles\": [%d, %d], \"bit_depth\": %d, \"stage_keys\": [", json_escape(input).c_str(), json_escape(recon_path).c_str(), width, height, qp,
+           frame_skip, n_frames, fps, json_escape(label_dir).c_str(), cnn_input.c_str(), json_escape(bitstream_path).c_str(), level_idc, tile_cols, tile_rows, bit_depth);
     for (size_t i = 0; i < stage_keys.size(); i++) printf("%s\"%s\"", i ? ", " : "", stage_keys[i].c_str());
     printf("], \"errors\": [");
     for (size_t i = 0; i < opt.errors.size(); i++) printf("%s\"%s\"", i ? ", " : "", json_escape(opt.errors[i]).c_str());
@@ -169,7 +176,7 @@ int main(int argc, char **argv)
   if (cnn_input != "rgb601" && cnn_input != "luma") opt.errors.push_back("CnnInput must be rgb601 or luma");
   if (!opt.errors.empty()) { for (const auto &e : opt.errors) fprintf(stderr, "Error: %s\n", e.c_str()); return 2; }
 
-  const size_t frame_bytes = hevcdl_frame_bytes(width, height);
+  const size_t frame_bytes = hevcdl_frame_bytes_bd(width, height, bit_depth);
   FILE *fin = fopen(input.c_str(), "rb");
   if (!fin) { fprintf(stderr, "Error: cannot open input file '%s'\n", input.c_str()); return 2; }
   fseek(fin, 0, SEEK_END); const long long fsize = ftell(fin);
@@ -179,7 +186,7 @@ int main(int argc, char **argv)
   const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", 64)));
 
   hevcdl_config cfg;
-  hevcdl_status st = hevcdl_config_default(&cfg, width, height, qp);
+  hevcdl_status st = hevcdl_config_default_bd(&cfg, width, height, qp, bit_depth);
   if (st != HEVCDL_OK) { fprintf(stderr, "Error: unsupported picture size / QP (status %d)\n", (int)st); return 2; }
   cfg.max_frames = batch; cfg.device = (int)opt.geti("Device", 0);
   cfg.tile_columns = tile_cols; cfg.tile_rows = tile_rows;
@@ -217,7 +224,7 @@ int main(int argc, char **argv)
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
   if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
-  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows;
+  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
   std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
   std::vector<uint8_t> au(hevcdl_access_unit_bound(width, height));
   const double ny = (double)width * height, nc = ny / 4;
@@ -248,12 +255,18 @@ int main(int argc, char **argv)
         const uint8_t *o = yuv.data() + frame_bytes * i, *r = recon.data() + frame_bytes * i;
         const size_t n[3] = { (size_t)width * height, (size_t)width * height / 4, (size_t)width * height / 4 };
         size_t off = 0;
-        for (int c = 0; c < 3; c++) { unsigned long long sse = 0; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o[off + k] - (int)r[off + k]; sse += (unsigned long long)(d * d); } stats[i].sse[c] = sse; off += n[c]; }
+        for (int c = 0; c < 3; c++) {
+          unsigned long long sse = 0;
+          if (bit_depth == 8) for (size_t k = 0; k < n[c]; k++) { const int d = (int)o[off + k] - (int)r[off + k]; sse += (unsigned long long)(d * d); }
+          else { const uint16_t *o16 = (const uint16_t *)o, *r16 = (const uint16_t *)r; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o16[off + k] - (int)r16[off + k]; sse += (unsigned long long)(d * d); } }
+          stats[i].sse[c] = sse; off += n[c];
+        }
       }
     }
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
     for (int i = 0; i < nb; i++) {
-      const double p[3] = { psnr_of(stats[i].sse[0], ny), psnr_of(stats[i].sse[1], nc), psnr_of(stats[i].sse[2], nc) };
+      const double maxval = (double)(255 << (bit_depth - 8));
+      const double p[3] = { psnr_of(stats[i].sse[0], ny, maxval), psnr_of(stats[i].sse[1], nc, maxval), psnr_of(stats[i].sse[2], nc, maxval) };
       // the access unit: VPS+SPS+PPS+slice, written to -b; its size is the picture's bit count (TEncGOP.cpp:2420-2447)
       size_t au_len = 0;
       st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, sao ? sao_params.data() + (size_t)ctus * i : nullptr, au.data(), au.size(), &au_len);
@@ -273,7 +286,7 @@ int main(int argc, char **argv)
     printf("\n\nSUMMARY --------------------------------------------------------\n");
     printf("\tTotal Frames |   Bitrate     Y-PSNR    U-PSNR    V-PSNR    YUV-PSNR  \n");
     printf("\t %8ld    %c %12.4lf  %8.4lf  %8.4lf  %8.4lf  %8.4lf  \n", done, 'a', sum_bits * (fps / 1000.0 / done), sum_psnr[0] / done, sum_psnr[1] / done,
-           sum_psnr[2] / done, mse_yuv == 0 ? 999.99 : 10.0 * log10(255.0 * 255.0 / mse_yuv));
+           sum_psnr[2] / done, mse_yuv == 0 ? 999.99 : 10.0 * log10((double)(255 << (bit_depth - 8)) * (double)(255 << (bit_depth - 8)) / mse_yuv));
   }
   if (frec) fclose(frec);
   if (frecords) fclose(frecords);

@@ -72,6 +72,7 @@ struct hevcdl_sao_params {
   unsigned char *recon_params;     // [frame][ctu] hevcdl_sao_blk: merge candidates resolved
   int width, height, ctus_x, ctus_per_frame, n_frames, qp;
   int tile_cols, tile_rows;        // merge candidates stay inside a tile
+  int bit_depth;                   // 8: planes of uint8; 10: planes of uint16 (offset range 31, band = sample >> 5, distortion >> 4)
   double lambda, lambda_chroma;
 };
 

@@ -45,10 +45,10 @@ struct Stat { int32_t diff[32], count[32]; };                   // one (type) of
 struct Sbac { uint8_t merge_ctx, type_ctx; unsigned long long frac; };
 
 __device__ __forceinline__ int sgn(int v) { return (v > 0) - (v < 0); }
-__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int clipbd(int v, int mx) { return v < 0 ? 0 : (v > mx ? mx : v); }      // ClipBD
 
 // edge / band class of sample p for SAO type t
-__device__ __forceinline__ int sao_class(int t, const uint8_t GLB *p, int stride)
+template <typename PEL> __device__ __forceinline__ int sao_class(int t, const PEL GLB *p, int stride, int band_shift)
 {
   const int c = p[0];
   switch (t) {
@@ -56,7 +56,7 @@ __device__ __forceinline__ int sao_class(int t, const uint8_t GLB *p, int stride
     case EO_90:  return 2 + sgn(c - p[-stride]) + sgn(c - p[stride]);
     case EO_135: return 2 + sgn(c - p[-stride - 1]) + sgn(c - p[stride + 1]);
     case EO_45:  return 2 + sgn(c - p[-stride + 1]) + sgn(c - p[stride - 1]);
-    default:     return c >> 3;
+    default:     return c >> band_shift;          // bitDepth - 5
   }
 }
 
@@ -71,7 +71,10 @@ __device__ void sb_ep(Sbac &c, int n) { c.frac += 32768ull * (unsigned long long
 __device__ uint32_t sb_bits(const Sbac &c) { return (uint32_t)(c.frac >> 15); }
 __device__ void sb_reset(Sbac &c) { c.frac &= 32767ull; }
 
-__device__ void code_offset_param(Sbac &c, int comp, const hevcdl_sao_offset &p)
+// bit-depth dependent constants of the decision: offset range (getMaxOffsetQVal: 7 / 31), distortion shift 2 (bitDepth - 8), rounding
+struct Bd { int max_off, dist_shift, bits_above_8; };
+
+__device__ void code_offset_param(Sbac &c, int comp, const hevcdl_sao_offset &p, const Bd &bd)
 { // codeSAOOffsetParam TEncSbac.cpp:1605-1681
   const int first = comp != 2;
   if (first) {
@@ -82,58 +85,60 @@ __device__ void code_offset_param(Sbac &c, int comp, const hevcdl_sao_offset &p)
     int off[4], k = 0;
     const int ncls = p.type == BO ? 4 : 5;
     for (int i = 0; i < ncls; i++) { if (p.type != BO && i == 2) continue; off[k++] = p.offset[p.type == BO ? (p.aux + i) % 32 : i]; }
-    for (int i = 0; i < 4; i++) { const int a = abs(off[i]); sb_ep(c, a == 0 ? 1 : (a < 7 ? a + 1 : a)); }
+    for (int i = 0; i < 4; i++) { const int a = abs(off[i]); sb_ep(c, a == 0 ? 1 : (a < bd.max_off ? a + 1 : a)); }
     if (p.type == BO) { for (int i = 0; i < 4; i++) if (off[i]) sb_ep(c, 1); sb_ep(c, 5); }
     else if (first) sb_ep(c, 2);
   }
 }
-__device__ void code_blk_param(Sbac &c, const hevcdl_sao_blk &b, int left_avail, int above_avail, int only_merge)
+__device__ void code_blk_param(Sbac &c, const hevcdl_sao_blk &b, int left_avail, int above_avail, int only_merge, const Bd &bd)
 { // codeSAOBlkParam TEncSbac.cpp:1683-1720
   int is_left = 0, is_above = 0;
   if (left_avail) { is_left = b.c[0].mode == MODE_MERGE && b.c[0].type == MERGE_LEFT; sb_bin(c, c.merge_ctx, is_left); }
   if (above_avail && !is_left) { is_above = b.c[0].mode == MODE_MERGE && b.c[0].type == MERGE_ABOVE; sb_bin(c, c.merge_ctx, is_above); }
   if (only_merge) return;
-  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_offset_param(c, comp, b.c[comp]);
+  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_offset_param(c, comp, b.c[comp], bd);
 }
-__device__ long long est_dist(long long count, long long offset, long long diff) { return count * offset * offset - diff * offset * 2; }
-__device__ int est_iter_offset(int type, double lambda, int offset_in, long long count, long long diff, long long &best_dist, double &best_cost)
+__device__ long long est_dist(long long count, long long offset, long long diff, const Bd &bd) { return (count * offset * offset - diff * offset * 2) >> bd.dist_shift; }   // estSaoDist :459
+__device__ int est_iter_offset(int type, double lambda, int offset_in, long long count, long long diff, long long &best_dist, double &best_cost, const Bd &bd)
 { // estIterOffset :465-496
   int it = offset_in, out = 0;
   double min_cost = lambda;
   while (it != 0) {
     long long rate = type == BO ? abs(it) + 2 : abs(it) + 1;
-    if (abs(it) == 7) rate--;
-    const long long dist = est_dist(count, it, diff);
+    if (abs(it) == bd.max_off) rate--;
+    const long long dist = est_dist(count, it, diff, bd);
     const double cost = (double)dist + lambda * (double)rate;
     if (cost < min_cost) { min_cost = cost; out = it; best_dist = dist; best_cost = cost; }
     it = it > 0 ? it - 1 : it + 1;
   }
   return out;
 }
-__device__ void derive_offsets(int type, double lambda, const Stat GLB &st, int32_t *q, int32_t &aux)
+__device__ void derive_offsets(int type, double lambda, const Stat GLB &st, int32_t *q, int32_t &aux, const Bd &bd)
 { // deriveOffsets :498-615
   const int ncls = type == BO ? 32 : 5;
   for (int i = 0; i < 32; i++) q[i] = 0;
   for (int cls = 0; cls < ncls; cls++) {
     if (type != BO && cls == 2) continue;
     if (st.count[cls] == 0) continue;
-    const double x = (double)st.diff[cls] / (double)st.count[cls];
-    int v = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);
-    q[cls] = v < -7 ? -7 : (v > 7 ? 7 : v);
+    const double x = (double)((long long)st.diff[cls] << bd.bits_above_8) / (double)st.count[cls];     // :520-523, offset step log2 0
+    int v;
+    if (bd.bits_above_8) { const int r = 1 << bd.bits_above_8; v = x > 0 ? ((int)x + (r >> 1)) / r : ((int)x - (r >> 1)) / r; }   // xRoundIbdi2 :49-52
+    else v = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);                                                     // xRoundIbdi :54-57
+    q[cls] = v < -bd.max_off ? -bd.max_off : (v > bd.max_off ? bd.max_off : v);
   }
   if (type != BO) {
     for (int cls = 0; cls < 5; cls++) {
       long long d; double c;
       if ((cls == 0 || cls == 1) && q[cls] < 0) q[cls] = 0;
       if ((cls == 3 || cls == 4) && q[cls] > 0) q[cls] = 0;
-      if (q[cls] != 0) q[cls] = est_iter_offset(type, lambda, q[cls], st.count[cls], st.diff[cls], d, c);
+      if (q[cls] != 0) q[cls] = est_iter_offset(type, lambda, q[cls], st.count[cls], st.diff[cls], d, c, bd);
     }
     aux = 0;
   } else {
     double cost[32], min_cost = MAX_DOUBLE;
     for (int cls = 0; cls < 32; cls++) {
       long long d; cost[cls] = lambda;
-      if (q[cls] != 0) q[cls] = est_iter_offset(type, lambda, q[cls], st.count[cls], st.diff[cls], d, cost[cls]);
+      if (q[cls] != 0) q[cls] = est_iter_offset(type, lambda, q[cls], st.count[cls], st.diff[cls], d, cost[cls], bd);
     }
     for (int band = 0; band < 29; band++) {
       double c = cost[band]; c += cost[band + 1]; c += cost[band + 2]; c += cost[band + 3];
@@ -142,11 +147,11 @@ __device__ void derive_offsets(int type, double lambda, const Stat GLB &st, int3
     for (int i = 0; i < 32; i++) { const int r = (i - aux) & 31; if (r >= 4) q[i] = 0; }
   }
 }
-__device__ long long get_dist(int type, int aux, const int32_t *off, const Stat GLB &st)
+__device__ long long get_dist(int type, int aux, const int32_t *off, const Stat GLB &st, const Bd &bd)
 { // getDistortion :421-457
   long long d = 0;
-  if (type != BO) for (int i = 0; i < 5; i++) d += est_dist(st.count[i], off[i], st.diff[i]);
-  else for (int i = aux; i < aux + 4; i++) d += est_dist(st.count[i % 32], off[i % 32], st.diff[i % 32]);
+  if (type != BO) for (int i = 0; i < 5; i++) d += est_dist(st.count[i], off[i], st.diff[i], bd);
+  else for (int i = aux; i < aux + 4; i++) d += est_dist(st.count[i % 32], off[i % 32], st.diff[i % 32], bd);
   return d;
 }
 
@@ -231,6 +236,72 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params
   for (int i = tid; i < NTYPES * 64; i += 256) { const int t = i >> 6, r = i & 63; if (r < 32) dst[t].diff[r] = acc[t][0][r]; else dst[t].count[r - 32] = acc[t][1][r - 32]; }
 }
 
+// The same statistics for pictures of 16-bit samples (10-bit): the CTU (+1 sample halo) staged in LDS as samples, one sample per
+// thread and step; band class = sample >> (bitDepth - 5).
+__global__ __launch_bounds__(256) void hevcdl_sao_stats16_kernel(hevcdl_sao_params p)
+{
+  __shared__ int acc[NTYPES][2][32];
+  __shared__ uint16_t tile[66][68];                                 // sample (y, x) of the CTU component at tile[y + 1][x + 1]
+  const int tid = threadIdx.x, a = blockIdx.x, comp = blockIdx.y, frame = blockIdx.z;
+  for (int i = tid; i < NTYPES * 64; i += 256) (&acc[0][0][0])[i] = 0;
+  const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
+  const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
+  const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh, ph = p.height >> sh;
+  const int left = x0 > 0, above = y0 > 0, right = x0 + 64 < p.width, below = y0 + 64 < p.height;
+  const int skip_r = comp ? 3 : 5, skip_b = comp ? 2 : 4, band_shift = p.bit_depth - 5;
+  const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
+  const size_t plane = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2)));
+  const int bx = x0 >> sh, by = y0 >> sh;
+  const uint16_t GLB *src = (const uint16_t GLB *)p.deblocked + plane, *org = (const uint16_t GLB *)p.org + plane;
+  for (int i = tid; i < (h + 2) * (w + 2); i += 256) {              // rows -1..h, columns -1..w (clamped inside the picture: unused there)
+    const int r = i / (w + 2), c = i - r * (w + 2);
+    int yy = by + r - 1, xx = bx + c - 1;
+    yy = yy < 0 ? 0 : (yy >= ph ? ph - 1 : yy); xx = xx < 0 ? 0 : (xx >= stride ? stride - 1 : xx);
+    tile[r][c] = src[(size_t)yy * stride + xx];
+  }
+  __syncthreads();
+  int eo_d[4][5], eo_c[4][5];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) { eo_d[t][k] = 0; eo_c[t][k] = 0; }
+  for (int i = tid; i < h * w; i += 256) {
+    const int y = i / w, x = i - y * w;
+    auto px = [&](int dy, int dx) -> int { return (int)tile[y + 1 + dy][x + 1 + dx]; };
+    const int c0 = px(0, 0), d = (int)org[(size_t)(by + y) * stride + bx + x] - c0;
+#pragma unroll
+    for (int t = 0; t < NTYPES; t++) {
+      const bool need_lr = (t == EO_0 || t == EO_135 || t == EO_45), need_ab = (t == EO_90 || t == EO_135 || t == EO_45);
+      const int sx = need_lr ? (left ? 0 : 1) : 0, ex = right ? w - skip_r : (need_lr ? w - 1 : w);
+      const int sy = need_ab ? (above ? 0 : 1) : 0, ey = below ? h - skip_b : (need_ab ? h - 1 : h);
+      if (x >= sx && x < ex && y >= sy && y < ey) {
+        if (t == BO) { atomicAdd(&acc[BO][0][c0 >> band_shift], d); atomicAdd(&acc[BO][1][c0 >> band_shift], 1); }
+        else {
+          const int n0 = t == EO_0 ? px(0, -1) : (t == EO_90 ? px(-1, 0) : (t == EO_135 ? px(-1, -1) : px(-1, 1)));
+          const int n1 = t == EO_0 ? px(0, 1) : (t == EO_90 ? px(1, 0) : (t == EO_135 ? px(1, 1) : px(1, -1)));
+          const int cls = 2 + sgn(c0 - n0) + sgn(c0 - n1);
+#pragma unroll
+          for (int q = 0; q < 5; q++) { eo_c[t < 4 ? t : 0][q] += (cls == q); eo_d[t < 4 ? t : 0][q] += (cls == q) ? d : 0; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      int vd = eo_d[t][k], vc = eo_c[t][k];
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0xB1, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0xB1, 0xf, 0xf, false);
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0x4E, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x4E, 0xf, 0xf, false);
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0x141, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x141, 0xf, 0xf, false);
+      vd += __builtin_amdgcn_update_dpp(0, vd, 0x140, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x140, 0xf, 0xf, false);
+      if ((tid & 15) == 0) { atomicAdd(&acc[t][0][k], vd); atomicAdd(&acc[t][1][k], vc); }
+    }
+  __syncthreads();
+  Stat GLB *dst = (Stat GLB *)p.stats + ((size_t)(frame * p.ctus_per_frame + a) * 3 + comp) * NTYPES;
+  for (int i = tid; i < NTYPES * 64; i += 256) { const int t = i >> 6, r = i & 63; if (r < 32) dst[t].diff[r] = acc[t][0][r]; else dst[t].count[r - 32] = acc[t][1][r - 32]; }
+}
+
 // one lane per picture: the CTU chain of decideBlkParams
 __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params p)
 {
@@ -238,6 +309,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
   if (frame >= p.n_frames) return;
   const int cx = p.ctus_x, nctu = p.ctus_per_frame;
   const double lambda[3] = { p.lambda, p.lambda_chroma, p.lambda_chroma };
+  const Bd bd = { (1 << ((p.bit_depth < 10 ? p.bit_depth : 10) - 5)) - 1, 2 * (p.bit_depth - 8), p.bit_depth - 8 };
   const Stat GLB *stats = (const Stat GLB *)p.stats + (size_t)frame * nctu * 3 * NTYPES;
   hevcdl_sao_blk GLB *params = (hevcdl_sao_blk GLB *)p.params + (size_t)frame * nctu;      // coded parameters
   hevcdl_sao_blk GLB *recon = (hevcdl_sao_blk GLB *)p.recon_params + (size_t)frame * nctu; // reconstructed (merge resolved)
@@ -266,30 +338,30 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
       hevcdl_sao_offset test[3];
       long long dist[3], mode_dist[3] = { 0, 0, 0 };
       for (int c = 0; c < 3; c++) { mode.c[c].mode = MODE_OFF; mode.c[c].type = 0; mode.c[c].aux = 0; for (int i = 0; i < 32; i++) mode.c[c].offset[i] = 0; }
-      go = cur; code_blk_param(go, mode, left_av, above_av, 1); mid = go;
-      sb_reset(go); code_offset_param(go, 0, mode.c[0]);
+      go = cur; code_blk_param(go, mode, left_av, above_av, 1, bd); mid = go;
+      sb_reset(go); code_offset_param(go, 0, mode.c[0], bd);
       double mc = lambda[0] * (double)sb_bits(go), cost;
       temp = go;
       for (int type = 0; type < NTYPES; type++) {
         test[0].mode = MODE_NEW; test[0].type = type;
-        derive_offsets(type, lambda[0], st[0 * NTYPES + type], test[0].offset, test[0].aux);
-        dist[0] = get_dist(type, test[0].aux, test[0].offset, st[0 * NTYPES + type]);
-        go = mid; sb_reset(go); code_offset_param(go, 0, test[0]);
+        derive_offsets(type, lambda[0], st[0 * NTYPES + type], test[0].offset, test[0].aux, bd);
+        dist[0] = get_dist(type, test[0].aux, test[0].offset, st[0 * NTYPES + type], bd);
+        go = mid; sb_reset(go); code_offset_param(go, 0, test[0], bd);
         cost = (double)dist[0] + lambda[0] * (double)(int)sb_bits(go);
         if (cost < mc) { mc = cost; mode_dist[0] = dist[0]; mode.c[0] = test[0]; temp = go; }
       }
       go = temp; mid = go;
       cost = 0; sb_reset(go);
-      { uint32_t prev = 0; for (int c = 1; c < 3; c++) { code_offset_param(go, c, mode.c[c]); const uint32_t b = sb_bits(go); cost += lambda[c] * (double)(b - prev); prev = b; } }
+      { uint32_t prev = 0; for (int c = 1; c < 3; c++) { code_offset_param(go, c, mode.c[c], bd); const uint32_t b = sb_bits(go); cost += lambda[c] * (double)(b - prev); prev = b; } }
       mc = cost;
       for (int type = 0; type < NTYPES; type++) {
         uint32_t prev = 0;
         go = mid; sb_reset(go); cost = 0;
         for (int c = 1; c < 3; c++) {
           test[c].mode = MODE_NEW; test[c].type = type;
-          derive_offsets(type, lambda[c], st[c * NTYPES + type], test[c].offset, test[c].aux);
-          dist[c] = get_dist(type, test[c].aux, test[c].offset, st[c * NTYPES + type]);
-          code_offset_param(go, c, test[c]);
+          derive_offsets(type, lambda[c], st[c * NTYPES + type], test[c].offset, test[c].aux, bd);
+          dist[c] = get_dist(type, test[c].aux, test[c].offset, st[c * NTYPES + type], bd);
+          code_offset_param(go, c, test[c], bd);
           const uint32_t b = sb_bits(go);
           cost += (double)dist[c] + (lambda[c] * (double)(b - prev));
           prev = b;
@@ -298,7 +370,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
       }
       double norm = 0;
       for (int c = 0; c < 3; c++) norm += (double)mode_dist[c] / lambda[c];
-      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0);
+      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0, bd);
       norm += (double)sb_bits(go);
       if (norm < min_cost) { min_cost = norm; best = mode; next = go; }
     }
@@ -309,10 +381,10 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
       double nd = 0;
       for (int c = 0; c < 3; c++) {
         load_off(mode.c[c], m.c[c]);
-        if (m.c[c].mode != MODE_OFF) nd += ((double)get_dist(m.c[c].type, m.c[c].aux, mode.c[c].offset, st[c * NTYPES + m.c[c].type])) / lambda[c];
+        if (m.c[c].mode != MODE_OFF) nd += ((double)get_dist(m.c[c].type, m.c[c].aux, mode.c[c].offset, st[c * NTYPES + m.c[c].type], bd)) / lambda[c];
         mode.c[c].mode = MODE_MERGE; mode.c[c].type = mt;
       }
-      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0);
+      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0, bd);
       const double cost = nd + (double)(int)sb_bits(go);
       if (cost < min_cost) { min_cost = cost; best = mode; next = go; }
     }
@@ -325,6 +397,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
   }
 }
 
+template <typename PEL>
 __global__ __launch_bounds__(256) void hevcdl_sao_apply_kernel(hevcdl_sao_params p)
 {
   const int tid = threadIdx.x, a = blockIdx.x, comp = blockIdx.y, frame = blockIdx.z;
@@ -334,7 +407,8 @@ __global__ __launch_bounds__(256) void hevcdl_sao_apply_kernel(hevcdl_sao_params
   const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh;
   const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
   const size_t off = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2))) + (size_t)(y0 >> sh) * stride + (x0 >> sh);
-  const uint8_t GLB *src = (const uint8_t GLB *)p.deblocked + off; uint8_t GLB *res = (uint8_t GLB *)p.out + off;
+  const PEL GLB *src = (const PEL GLB *)p.deblocked + off; PEL GLB *res = (PEL GLB *)p.out + off;
+  const int pel_max = (1 << p.bit_depth) - 1, band_shift = p.bit_depth - 5;
   const int mode = prm.mode, type = prm.type;
   __shared__ int offs[32];
   if (tid < 32) offs[tid] = (mode != MODE_OFF && (type == BO || tid < 5)) ? prm.offset[tid] : 0;
@@ -344,10 +418,10 @@ __global__ __launch_bounds__(256) void hevcdl_sao_apply_kernel(hevcdl_sao_params
   const int sy = (need_ab && y0 == 0) ? 1 : 0, ey = (need_ab && y0 + 64 >= p.height) ? h - 1 : h;
   for (int i = tid; i < w * h; i += 256) {
     const int y = i / w, x = i - y * w;
-    const uint8_t GLB *s = src + (size_t)y * stride + x;
+    const PEL GLB *s = src + (size_t)y * stride + x;
     int v = s[0];
-    if (mode != MODE_OFF && x >= sx && x < ex && y >= sy && y < ey) v = clip8(v + offs[sao_class(type, s, stride)]);
-    res[(size_t)y * stride + x] = (uint8_t)v;
+    if (mode != MODE_OFF && x >= sx && x < ex && y >= sy && y < ey) v = clipbd(v + offs[sao_class<PEL>(type, s, stride, band_shift)], pel_max);
+    res[(size_t)y * stride + x] = (PEL)v;
   }
 }
 
@@ -355,7 +429,10 @@ extern "C" void hevcdl_launch_sao(const hevcdl_sao_params *pp, void *stream)
 {
   const hevcdl_sao_params p = *pp;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(hevcdl_sao_stats_kernel, dim3(p.ctus_per_frame, 3, p.n_frames), dim3(256), 0, s, p);
+  const dim3 per_ctu(p.ctus_per_frame, 3, p.n_frames);
+  if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_stats_kernel, per_ctu, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(hevcdl_sao_stats16_kernel, per_ctu, dim3(256), 0, s, p);
   hipLaunchKernelGGL(hevcdl_sao_decide_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
-  hipLaunchKernelGGL(hevcdl_sao_apply_kernel, dim3(p.ctus_per_frame, 3, p.n_frames), dim3(256), 0, s, p);
+  if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint8_t>, per_ctu, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint16_t>, per_ctu, dim3(256), 0, s, p);
 }

@@ -52,8 +52,8 @@ typedef struct hevcdl_config {
   uint32_t struct_size;          /* sizeof(hevcdl_config) */
   int32_t  width, height;        /* luma samples, multiples of 8 (min CU) */
   int32_t  bit_depth;            /* 8, or 10: InputBitDepth = InternalBitDepth = 10 (Profile main10); samples are then uint16,
-                                    little endian, in every yuv / recon buffer of the decision path; the CNN stage sees sample >> 2.
-                                    The in-loop filters and the bitstream writer are 8-bit only (HEVCDL_ERR_UNSUPPORTED). */
+                                    little endian, in every yuv / recon / picture buffer (decision path and in-loop filters); the CNN
+                                    stage sees sample >> 2 */
   int32_t  chroma_format;        /* 420 */
   int32_t  qp;                   /* slice QP, 0..51 */
   int32_t  ctu_size;             /* 64   (MaxCUWidth/Height)          */

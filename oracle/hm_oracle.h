@@ -56,6 +56,8 @@ typedef struct { int32_t mode, type, aux; int32_t offset[32]; } hm_sao_offset;
 typedef struct { hm_sao_offset c[3]; } hm_sao_blk;
 /* org, deblocked, out: planar 4:2:0 frames; params: [ctus] coded parameters (as written to the bitstream). */
 int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out);
+/* uint16 sample planes, bit_depth 8 or 10 (offset range 7 / 31, band shift bit_depth - 5, distortion at 8-bit scale) */
+int hm_oracle_sao_frame16(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, int bit_depth);
 int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out, int tile_cols, int tile_rows);
 
 /* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */

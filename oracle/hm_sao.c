@@ -26,10 +26,14 @@ typedef struct { int64_t diff[32], count[32]; } stat_t;
 typedef struct { uint8_t merge_ctx, type_ctx; uint64_t frac; } sbac_t;
 
 static int sgn(int v) { return (v > 0) - (v < 0); }
-static int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+typedef uint16_t spx;                 /* 16-bit sample planes inside; the 8-bit entries widen and narrow */
+static int g_bd = 8;                  /* sample bit depth of the run (8 or 10); one run at a time per process */
+#define MAX_OFF ((1 << ((g_bd < 10 ? g_bd : 10) - 5)) - 1)      /* getMaxOffsetQVal, TComSampleAdaptiveOffset.h:73: 7 / 31 */
+#define DIST_SHIFT (2 * (g_bd - 8))                            /* 2 * DISTORTION_PRECISION_ADJUSTMENT(bitDepth - 8), :501 */
+static int clip8(int v) { const int mx = (1 << g_bd) - 1; return v < 0 ? 0 : (v > mx ? mx : v); }
 
 /* ---- statistics: every sample of the CTU whose neighbours exist and that lies outside the not-yet-deblocked margin ---- */
-static void blk_stats(stat_t st[NTYPES], const uint8_t *src, const uint8_t *org, int stride, int width, int height,
+static void blk_stats(stat_t st[NTYPES], const spx *src, const spx *org, int stride, int width, int height,
                       int left, int right, int above, int below, int skip_r, int skip_b)
 {
   int t, x, y;
@@ -40,14 +44,14 @@ static void blk_stats(stat_t st[NTYPES], const uint8_t *src, const uint8_t *org,
     const int sy = need_ab ? (above ? 0 : 1) : 0, ey = below ? height - skip_b : (need_ab ? height - 1 : height);
     for (y = sy; y < ey; y++)
       for (x = sx; x < ex; x++) {
-        const uint8_t *p = src + (size_t)y * stride + x;
+        const spx *p = src + (size_t)y * stride + x;
         int cls;
         switch (t) {
           case EO_0:   cls = 2 + sgn(p[0] - p[-1]) + sgn(p[0] - p[1]); break;
           case EO_90:  cls = 2 + sgn(p[0] - p[-stride]) + sgn(p[0] - p[stride]); break;
           case EO_135: cls = 2 + sgn(p[0] - p[-stride - 1]) + sgn(p[0] - p[stride + 1]); break;
           case EO_45:  cls = 2 + sgn(p[0] - p[-stride + 1]) + sgn(p[0] - p[stride - 1]); break;
-          default:     cls = p[0] >> 3; break;
+          default:     cls = p[0] >> (g_bd - 5); break;
         }
         st[t].diff[cls] += (int)org[(size_t)y * stride + x] - (int)p[0];
         st[t].count[cls]++;
@@ -78,7 +82,7 @@ static void code_offset_param(sbac_t *c, int comp, const hm_sao_offset *p)
     int off[4], k = 0;
     const int ncls = p->type == BO ? 4 : 5;
     for (i = 0; i < ncls; i++) { if (p->type != BO && i == 2) continue; off[k++] = p->offset[p->type == BO ? (p->aux + i) % 32 : i]; }
-    for (i = 0; i < 4; i++) { const int a = abs(off[i]); sb_ep(c, a == 0 ? 1 : (a < 7 ? a + 1 : a)); }       /* codeSaoMaxUvlc, max 7 */
+    for (i = 0; i < 4; i++) { const int a = abs(off[i]); sb_ep(c, a == 0 ? 1 : (a < MAX_OFF ? a + 1 : a)); }       /* codeSaoMaxUvlc */
     if (p->type == BO) { for (i = 0; i < 4; i++) if (off[i]) sb_ep(c, 1); sb_ep(c, 5); }
     else if (first) sb_ep(c, 2);
   }
@@ -93,7 +97,7 @@ static void code_blk_param(sbac_t *c, const hm_sao_blk *b, int left_avail, int a
 }
 
 /* ---- offsets ---- */
-static int64_t est_dist(int64_t count, int64_t offset, int64_t diff) { return count * offset * offset - diff * offset * 2; }
+static int64_t est_dist(int64_t count, int64_t offset, int64_t diff) { return (count * offset * offset - diff * offset * 2) >> DIST_SHIFT; }   /* estSaoDist :459 */
 static int est_iter_offset(int type, double lambda, int offset_in, int64_t count, int64_t diff, int64_t *best_dist, double *best_cost)
 { /* estIterOffset :465-496, offsetTh 7, bitIncrease 0 */
   int it = offset_in, out = 0;
@@ -101,7 +105,7 @@ static int est_iter_offset(int type, double lambda, int offset_in, int64_t count
   while (it != 0) {
     int64_t rate = type == BO ? abs(it) + 2 : abs(it) + 1, dist;
     double cost;
-    if (abs(it) == 7) rate--;
+    if (abs(it) == MAX_OFF) rate--;
     dist = est_dist(count, it, diff);
     cost = (double)dist + lambda * (double)rate;
     if (cost < min_cost) { min_cost = cost; out = it; *best_dist = dist; *best_cost = cost; }
@@ -118,9 +122,10 @@ static void derive_offsets(int type, double lambda, const stat_t *st, int *q, in
     double x;
     if (type != BO && cls == 2) continue;
     if (st->count[cls] == 0) continue;
-    x = (double)st->diff[cls] / (double)st->count[cls];
-    q[cls] = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);                  /* xRoundIbdi, 8 bit */
-    q[cls] = q[cls] < -7 ? -7 : (q[cls] > 7 ? 7 : q[cls]);
+    x = (double)(st->diff[cls] * (1 << (g_bd - 8))) / (double)st->count[cls];          /* :520-523, offset step log2 0 */
+    if (g_bd > 8) { const int r = 1 << (g_bd - 8); q[cls] = x > 0 ? ((int)x + (r >> 1)) / r : ((int)x - (r >> 1)) / r; }   /* xRoundIbdi2 :49-52 */
+    else q[cls] = x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);                  /* xRoundIbdi :54-57 */
+    q[cls] = q[cls] < -MAX_OFF ? -MAX_OFF : (q[cls] > MAX_OFF ? MAX_OFF : q[cls]);
   }
   if (type != BO) {
     for (cls = 0; cls < 5; cls++) {
@@ -234,7 +239,7 @@ static void mode_merge(const stat_t st[3][NTYPES], const double lambda[3], const
 }
 
 /* ---- reconstruction of one CTU component: samples whose neighbours lie outside the picture are left alone ---- */
-static void offset_block(int type, const int *offset, const uint8_t *src, uint8_t *res, int stride, int width, int height,
+static void offset_block(int type, const int *offset, const spx *src, spx *res, int stride, int width, int height,
                          int left, int right, int above, int below)
 {
   int x, y;
@@ -243,16 +248,16 @@ static void offset_block(int type, const int *offset, const uint8_t *src, uint8_
   const int sy = (need_ab && !above) ? 1 : 0, ey = (need_ab && !below) ? height - 1 : height;
   for (y = sy; y < ey; y++)
     for (x = sx; x < ex; x++) {
-      const uint8_t *p = src + (size_t)y * stride + x;
+      const spx *p = src + (size_t)y * stride + x;
       int cls;
       switch (type) {
         case EO_0:   cls = 2 + sgn(p[0] - p[-1]) + sgn(p[0] - p[1]); break;
         case EO_90:  cls = 2 + sgn(p[0] - p[-stride]) + sgn(p[0] - p[stride]); break;
         case EO_135: cls = 2 + sgn(p[0] - p[-stride - 1]) + sgn(p[0] - p[stride + 1]); break;
         case EO_45:  cls = 2 + sgn(p[0] - p[-stride + 1]) + sgn(p[0] - p[stride - 1]); break;
-        default:     cls = p[0] >> 3; break;
+        default:     cls = p[0] >> (g_bd - 5); break;
       }
-      res[(size_t)y * stride + x] = (uint8_t)clip8(p[0] + offset[cls]);
+      res[(size_t)y * stride + x] = (spx)clip8(p[0] + offset[cls]);
     }
 }
 
@@ -271,6 +276,21 @@ static int tile_start(int pos, int n_ctus, int n_tiles)
 
 int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out, int tile_cols, int tile_rows)
 {
+  const size_t n = (size_t)width * height * 3 / 2;
+  size_t i; int rc;
+  uint16_t *t;
+  if (!org || !deblocked || !out || width <= 0 || height <= 0) return -1;
+  t = (uint16_t *)malloc(3 * n * sizeof *t);
+  if (!t) return -2;
+  for (i = 0; i < n; i++) { t[i] = org[i]; t[n + i] = deblocked[i]; }
+  rc = hm_oracle_sao_frame16(t, t + n, width, height, qp, params, t + 2 * n, tile_cols, tile_rows, 8);
+  if (rc == 0) for (i = 0; i < n; i++) out[i] = (uint8_t)t[2 * n + i];
+  free(t);
+  return rc;
+}
+
+int hm_oracle_sao_frame16(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, int bit_depth)
+{
   const int cx = (width + 63) >> 6, cy = (height + 63) >> 6, nctu = cx * cy, cw = width >> 1, ch = height >> 1;
   const size_t ysz = (size_t)width * height, csz = (size_t)cw * ch;
   double lambda[3];
@@ -278,7 +298,8 @@ int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int 
   hm_sao_blk *recon;
   sbac_t go, cur, next;
   int a, comp, i;
-  if (!org || !deblocked || !params || !out || width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51) return -1;
+  if (!org || !deblocked || !params || !out || width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51 || (bit_depth != 8 && bit_depth != 10)) return -1;
+  g_bd = bit_depth;
   { /* slice lambdas, TEncSlice.cpp:112-140 */
     const int qpc = g_chroma_scale_420[qp];
     lambda[0] = 0.57 * 1.0 * pow(2.0, (qp - 12) / 3.0);
@@ -296,7 +317,7 @@ int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int 
       blk_stats(st[a][comp], deblocked + off, org + off, stride, w >> sh, h >> sh, left, right, above, below, comp ? 3 : 5, comp ? 2 : 4);
     }
   }
-  memcpy(out, deblocked, ysz + 2 * csz);
+  memcpy(out, deblocked, (ysz + 2 * csz) * sizeof(spx));
   { /* initRDOCabacCoder: I-slice contexts (ContextTables.h:445-458: merge 153, type 200) at the slice QP */
     const int init[2] = { 153, 200 };
     uint8_t *dst[2] = { &go.merge_ctx, &go.type_ctx };

@@ -235,9 +235,21 @@ def run_deblock(recon, width, height, qp, recs, bit_depth=8):
 SAO_DTYPE = np.dtype([("mode", "<i4"), ("type", "<i4"), ("aux", "<i4"), ("offset", "<i4", 32)])      # hm_sao_offset
 
 
-def run_sao(org, deblocked, width, height, qp, tiles=(1, 1)):
+def run_sao(org, deblocked, width, height, qp, tiles=(1, 1), bit_depth=8):
     """Oracle SAO of frames [n][w*h*3/2] -> (params [n][ctus][3] SAO_DTYPE, final reconstruction)."""
     lib = oracle_lib()
+    if bit_depth != 8:
+        lib.hm_oracle_sao_frame16.restype = ctypes.c_int
+        lib.hm_oracle_sao_frame16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        org = np.ascontiguousarray(org, np.uint16).reshape(-1, width * height * 3 // 2)
+        dbk = np.ascontiguousarray(deblocked, np.uint16).reshape(org.shape)
+        nctu = ((width + 63) // 64) * ((height + 63) // 64)
+        params = np.zeros((org.shape[0], nctu, 3), SAO_DTYPE)
+        out = np.zeros_like(org)
+        for f in range(org.shape[0]):
+            if lib.hm_oracle_sao_frame16(org[f].ctypes.data, dbk[f].ctypes.data, width, height, qp, params[f].ctypes.data, out[f].ctypes.data, tiles[0], tiles[1], bit_depth) != 0:
+                raise RuntimeError("oracle sao failed")
+        return params, out
     lib.hm_oracle_sao_frame_tiles.restype = ctypes.c_int
     lib.hm_oracle_sao_frame_tiles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     org = np.ascontiguousarray(org, np.uint8).reshape(-1, width * height * 3 // 2)

@@ -134,25 +134,33 @@ def test_cli_encode_matches_the_api(app, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_with_tiles_reproduces_the_reference_run(app, tmp_path):
-    """The reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) on the fixture the
-    reference encoder produced with the same switches: reconstruction file and bitstream (its picture-hash SEI aside) byte for byte."""
+@pytest.mark.parametrize("case", ["t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2"])
+def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
+    """The reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) and for 10-bit coding
+    (InputBitDepth / InternalBitDepth 10, Profile main10; x576 is C5 of the survey in miniature: both) on the fixtures the reference
+    encoder produced with the same switches: reconstruction file and bitstream (its picture-hash SEI aside) byte for byte."""
     import sys
     from conftest import GOLD
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hevc_parse as hp
-    f = np.load(os.path.join(GOLD, "rd_t520_q37_2x2.npz"))
+    f = np.load(os.path.join(GOLD, "rd_%s.npz" % case))
     w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
-    f["yuv"].tofile(tmp_path / "in.yuv")
+    bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8
+    f["yuv"].astype(np.uint8 if bd == 8 else "<u2").tofile(tmp_path / "in.yuv")
+    bd_args = [] if bd == 8 else ["--InputBitDepth=10", "--InternalBitDepth=10", "--Profile=main10"]
     for fr in range(nf):
         os.makedirs(tmp_path / "pred" / str(fr))
         for a in range(f["labels"].shape[1]):
             (tmp_path / "pred" / str(fr) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in f["labels"][fr, a]))
     r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
-                  "--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (int(f["tiles"][0]) - 1), "--NumTileRowsMinus1=%d" % (int(f["tiles"][1]) - 1)], tmp_path)
+                  "--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (int(f["tiles"][0]) - 1), "--NumTileRowsMinus1=%d" % (int(f["tiles"][1]) - 1)] + bd_args, tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_filtered"])
     ref = b"".join((b"\x00" if sc == 4 else b"") + b"\x00\x00\x01" + n for sc, n in hp.split_annexb(f["bitstream"].tobytes()) if ((n[0] >> 1) & 63) != 40)
     assert (tmp_path / "str.bin").read_bytes() == ref
-    r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "--TileUniformSpacing=1", "--NumTileColumnsMinus1=2"], tmp_path)
-    assert r.returncode == 2 and "4 CTUs wide" in r.stderr          # 9 CTU columns cannot hold three tiles of the minimum width
+    import re
+    psnr = lambda text: re.findall(r"\[Y [0-9.]+ dB +U [0-9.]+ dB +V [0-9.]+ dB\]", text)      # PSNR of the final picture, maxval 255 << (bitDepth - 8)
+    assert psnr(r.stdout) == psnr("\n".join(str(l) for l in f["summary"])) and len(psnr(r.stdout)) == nf
+    if case == "t520_q37_2x2":
+        r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "--TileUniformSpacing=1", "--NumTileColumnsMinus1=2"], tmp_path)
+        assert r.returncode == 2 and "4 CTUs wide" in r.stderr          # 9 CTU columns cannot hold three tiles of the minimum width

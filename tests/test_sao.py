@@ -9,7 +9,7 @@ import pytest
 from conftest import GOLD
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "rd_*.npz")) if not os.path.basename(p).startswith("rd_x"))      # rd_x*: 10-bit runs (decision path only so far)
+CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
 
 
 def strip_sei(stream):
@@ -23,7 +23,13 @@ def load(path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     nf = f["records"].shape[0]
     fb = w * h * 3 // 2
-    return f, w, h, qp, nf, f["yuv"].reshape(nf, fb), f["recon_deblocked"].reshape(nf, fb), f["recon_filtered"].reshape(nf, fb)
+    dt = np.uint8 if bit_depth_of(f) == 8 else np.dtype("<u2")                 # rd_x*: reference runs at InternalBitDepth 10 (uint16 samples)
+    planes = [np.frombuffer(f[k].tobytes(), dt).reshape(nf, fb) for k in ("recon_deblocked", "recon_filtered")]
+    return f, w, h, qp, nf, f["yuv"].reshape(nf, fb), planes[0], planes[1]
+
+
+def bit_depth_of(f):
+    return int(f["bit_depth"]) if "bit_depth" in f.files else 8
 
 
 def tiles_of(f):
@@ -38,10 +44,10 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     import hevcdl_amd
     import ref_tools
     f, w, h, qp, nf, org, dbk, final = load(path)
-    params, out = ref_tools.run_sao(org, dbk, w, h, qp, tiles=tiles_of(f))
+    params, out = ref_tools.run_sao(org, dbk, w, h, qp, tiles=tiles_of(f), bit_depth=bit_depth_of(f))
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f)) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 
@@ -50,12 +56,12 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
 def test_gpu_sao_matches_reference(path):
     import hevcdl_amd
     f, w, h, qp, nf, org, dbk, final = load(path)
-    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles_of(f))
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles_of(f), bit_depth=bit_depth_of(f))
     params, out = e.sao_frames(org, dbk)
     e.close()
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f)) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 
