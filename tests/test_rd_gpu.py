@@ -235,3 +235,48 @@ def test_full_size_properties(w, h):
         assert [int(v) for v in stats["sse"][f]] == sse
         assert int(stats["ctus"][f]) == cx * cy and int(stats["est_bits"][f]) > 0
     e.close()
+
+
+def test_c5_eight_k_ten_bit_tiles():
+    """C5 of the survey: 7680x4320, 10-bit samples (8-bit pattern * 4 + noise, uint16), tiles 4 x 2 (one wave per tile; one tile per GPU in
+    the 8-GPU layout).  Size-independent properties: every CU sits at its labelled depth; tile independence -- the top-left tile is bit
+    for bit the picture obtained by coding its 1920x2176 crop on its own; the filtered picture keeps to 10 bits; the access unit carries
+    seven entry points whose sub-streams fill the slice data."""
+    import hevcdl_amd
+    import ref_tools
+    import hevc_parse as hp
+    w, h, qp, tiles = 7680, 4320, 32, (4, 2)
+    rng = np.random.default_rng(5)
+    yuv = ref_tools.synth_yuv(w, h, 1, seed=5000).astype(np.uint16) * 4 + rng.integers(0, 4, (1, w * h * 3 // 2)).astype(np.uint16)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=1, tiles=tiles, bit_depth=10)
+    labels = e.predict_depth(yuv)
+    recs, recon, stats = e.compress_frames(yuv, labels)
+    dbk = e.deblock_frames(recon, recs)
+    sao, final = e.sao_frames(yuv, dbk)
+    e.close()
+    cx, cy = 120, 68
+    assert recs.shape == (1, cx * cy) and int(stats["ctus"][0]) == 8160 and int(recon.max()) <= 1023 and int(final.max()) <= 1023
+    # depth == label inside the picture (the last CTU row is half outside: 4320 = 67.5 * 64)
+    z16 = np.arange(16); zx = (z16 & 1) | ((z16 >> 1) & 2); zy = ((z16 >> 1) & 1) | ((z16 >> 2) & 2)
+    blk_of_z = (zy * 4 + zx)[np.arange(256) >> 4]
+    full_rows = recs["depth"][0].reshape(cy, cx, 256)[:cy - 1]
+    assert np.array_equal(full_rows, labels.reshape(cy, cx, 16)[:cy - 1][:, :, blk_of_z])
+    # tile 0 = CTU columns 0..29, rows 0..33 == its crop coded as a picture of its own
+    tw, th = 30 * 64, 34 * 64
+    ysz = w * h
+    Y = yuv[0, :ysz].reshape(h, w)[:th, :tw]; U = yuv[0, ysz:ysz + ysz // 4].reshape(h // 2, w // 2)[:th // 2, :tw // 2]; V = yuv[0, ysz + ysz // 4:].reshape(h // 2, w // 2)[:th // 2, :tw // 2]
+    crop = np.concatenate([Y.ravel(), U.ravel(), V.ravel()])[None]
+    lab0 = labels.reshape(cy, cx, 16)[:34, :30].reshape(1, -1, 16)
+    e0 = hevcdl_amd.Encoder(tw, th, qp, max_frames=1, bit_depth=10)
+    recs0, recon0, _ = e0.compress_frames(crop, lab0)
+    e0.close()
+    assert recs.reshape(cy, cx)[:34, :30].tobytes() == recs0.reshape(34, 30).tobytes()
+    assert np.array_equal(recon[0, :ysz].reshape(h, w)[:th, :tw].ravel(), recon0[0, :tw * th])
+    # the access unit: main10, 8 tiles, 7 entry points
+    au = hevcdl_amd.write_access_unit(w, h, qp, 0, recs[0], sao=sao[0], tiles=tiles, bit_depth=10)
+    nals = hp.split_annexb(au)
+    sps, pps = hp.parse_sps(nals[1][1]), hp.parse_pps(nals[2][1])
+    assert (sps["width"], sps["height"], sps["bd_luma_m8"], sps["bd_chroma_m8"], sps["sao"]) == (7680, 4320, 2, 2, 1)
+    assert (pps["tile_columns"], pps["tile_rows"]) == (4, 2)
+    hdr, _ = hp.parse_slice_header(nals[3][1], sps, pps)
+    assert len(hdr["entry_points"]) == 7 and sum(hdr["entry_points"]) < len(nals[3][1]) - hdr["data_byte_pos"]
