@@ -151,7 +151,26 @@ EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_l
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
-           "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit"]
+           "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5"]
+
+
+def picture_hash_sei(width, height, picture, bit_depth=8):
+    """Suffix SEI NAL with the MD5 of the three planes of `picture` (the final reconstruction) -> bytes."""
+    lib = load_library()
+    cfg = StreamConfig()
+    if lib.hevcdl_stream_config_default(ctypes.byref(cfg), width, height, 32) != 0:
+        raise HevcdlError(1, "stream config")
+    cfg.bit_depth = bit_depth
+    pic = np.ascontiguousarray(picture, np.uint8 if bit_depth == 8 else np.dtype("<u2")).reshape(-1)
+    if pic.size != width * height * 3 // 2:
+        raise ValueError("picture must hold width * height * 3 / 2 samples")
+    buf = np.zeros(128, np.uint8)
+    n = ctypes.c_size_t(0)
+    lib.hevcdl_write_picture_hash_sei.argtypes = [ctypes.POINTER(StreamConfig), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    st = lib.hevcdl_write_picture_hash_sei(ctypes.byref(cfg), pic.ctypes.data, buf.ctypes.data, 128, ctypes.byref(n))
+    if st != 0:
+        raise HevcdlError(st, "write_picture_hash_sei")
+    return buf[:n.value].tobytes()
 
 
 def load_weights(path=WEIGHTS_PATH):

@@ -49,7 +49,7 @@ const Key KEYS[] = {
   { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, PATH, "1" }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
   { "LoopFilterBetaOffset_div2", 0, PATH, "0" }, { "LoopFilterTcOffset_div2", 0, PATH, "0" },
   { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, USED, 0 }, { "SAOLcuBoundary", 0, PATH, "0" }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
-  { "LFCrossTileBoundaryFlag", 0, USED, 0 }, { "SEIDecodedPictureHash", 0, PATH, "0" },
+  { "LFCrossTileBoundaryFlag", 0, USED, 0 }, { "SEIDecodedPictureHash", 0, USED, 0 },
   // no effect on an all-intra slice with the settings above
   { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
   { "FEN", 0, NOEFFECT, 0 }, { "FDM", 0, NOEFFECT, 0 }, { "AMP", 0, NOEFFECT, 0 }, { "MaxCuDQPDepth", 0, NOEFFECT, 0 }, { "SliceArgument", 0, NOEFFECT, 0 },
@@ -155,6 +155,9 @@ int main(int argc, char **argv)
   if (bit_depth != 8 && bit_depth != 10) opt.errors.push_back("InternalBitDepth = " + std::to_string(bit_depth) + " is not implemented by this path (only 8 and 10)");
   { const std::string prof = opt.get("Profile", bit_depth == 8 ? "main" : "main10");
     if (prof != (bit_depth == 8 ? "main" : "main10")) opt.errors.push_back("Profile = " + prof + " is not implemented by this path (main at 8 bits, main10 at 10 bits)"); }
+  // decoded picture hash SEI (TAppEncCfg.cpp:1093): 0 none, 1 MD5 of the output picture behind every access unit
+  const int hash_sei = (int)opt.geti("SEIDecodedPictureHash", 0);
+  if (hash_sei != 0 && hash_sei != 1) opt.errors.push_back("SEIDecodedPictureHash = " + std::to_string(hash_sei) + " is not implemented by this path (only 0 and 1 = MD5)");
   // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows; the in-loop filters cross tile borders (LFCrossTileBoundaryFlag 1, the default)
   const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
   if (tile_cols * tile_rows > 1) {
@@ -272,8 +275,19 @@ int main(int argc, char **argv)
       st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, sao ? sao_params.data() + (size_t)ctus * i : nullptr, au.data(), au.size(), &au_len);
       if (st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)st); rc = 3; break; }
       if (fbits) fwrite(au.data(), 1, au_len, fbits);
-      printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]\n", f0 + i, 0, 'I', qp,
-             (unsigned long long)au_len * 8, p[0], p[1], p[2], et);
+      char md5_text[128] = "";
+      if (hash_sei) { // suffix SEI after the slice; not part of the picture's bit count (as in the reference)
+        uint8_t sei[128], dg[48]; size_t sei_len = 0;
+        st = hevcdl_write_picture_hash_sei(&scfg, recon.data() + frame_bytes * i, sei, sizeof sei, &sei_len);
+        if (st == HEVCDL_OK) st = hevcdl_picture_md5(&scfg, recon.data() + frame_bytes * i, dg);
+        if (st != HEVCDL_OK) { fprintf(stderr, "Error: picture hash failed (status %d)\n", (int)st); rc = 3; break; }
+        if (fbits) fwrite(sei, 1, sei_len, fbits);
+        char *q = md5_text + sprintf(md5_text, " [MD5:");
+        for (int c = 0; c < 3; c++) { for (int k = 0; k < 16; k++) q += sprintf(q, "%02x", dg[16 * c + k]); *q++ = c < 2 ? ',' : ']'; }
+        *q = 0;
+      }
+      printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]%s\n", f0 + i, 0, 'I', qp,
+             (unsigned long long)au_len * 8, p[0], p[1], p[2], et, md5_text);
       sum_bits += (double)au_len * 8;
       for (int c = 0; c < 3; c++) { sum_psnr[c] += p[c]; sum_mse[c] += (double)stats[i].sse[c] / (c ? nc : ny); }
       done++;

@@ -11,6 +11,8 @@
 //   CU / TU / residual syntax                TEncSbac.cpp:613-1541, TEncEntropy.cpp:200-398
 //   arithmetic coder                         TEncBinCoderCABAC.cpp:70-446, TComCABACTables.cpp:43-121, ContextModel.cpp:56-101
 // Pinned byte for byte by tests/golden/rd_*.npz:bitstream_nosao (the reference run with --SAO=0) and :bitstream (default run).
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +95,43 @@ uint32_t count_emulations(const std::vector<uint8_t> &b)
   for (uint8_t v : b) { if (zeros >= 2 && v <= 3) { cnt++; zeros = 0; } zeros = v == 0 ? zeros + 1 : 0; }
   return cnt;
 }
+
+// MD5 (RFC 1321) of a byte string: the decoded picture hash of the reference (libmd5 + TComPicYuvMD5.cpp:88-130) is the plain
+// MD5 of each colour plane, rows packed, samples as 1 byte (8-bit) or 2 bytes little endian.
+struct Md5 {
+  uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u }; uint64_t len = 0; uint8_t buf[64]; int fill = 0;
+  static uint32_t rol(uint32_t v, int s) { return (v << s) | (v >> (32 - s)); }
+  void block(const uint8_t *p)
+  {
+    static const int S[64] = { 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                               4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21 };
+    uint32_t m[16], a = h[0], b = h[1], c = h[2], d = h[3];
+    for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+    for (int i = 0; i < 64; i++) {
+      uint32_t f; int g;
+      if (i < 16) { f = (b & c) | (~b & d); g = i; }
+      else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+      else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+      else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+      const uint32_t k = (uint32_t)(int64_t)floor(fabs(sin((double)(i + 1))) * 4294967296.0);
+      const uint32_t t = d; d = c; c = b; b = b + rol(a + f + k + m[g], S[i]); a = t;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+  }
+  void update(const uint8_t *p, size_t n)
+  {
+    len += n;
+    while (n) { const size_t take = std::min<size_t>(n, 64 - fill); memcpy(buf + fill, p, take); fill += (int)take; p += take; n -= take; if (fill == 64) { block(buf); fill = 0; } }
+  }
+  void final(uint8_t out[16])
+  {
+    const uint64_t bits = len * 8; const uint8_t pad = 0x80, zero = 0;
+    update(&pad, 1); while (fill != 56) update(&zero, 1);
+    uint8_t l[8]; for (int i = 0; i < 8; i++) l[i] = (uint8_t)(bits >> (8 * i));
+    update(l, 8);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[4 * i + j] = (uint8_t)(h[i] >> (8 * j));
+  }
+};
 
 void profile_tier_level(BitOut &w, int level_idc, int bit_depth)
 { // codePTL / codeProfileTier: Profile main => idc 1, compatibility flags 1 and 2; main10 at 10 bits => idc 2, flag 2 only (TAppEncTop.cpp:120-135)
@@ -467,6 +506,36 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
   cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8;
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_picture_md5(const hevcdl_stream_config *cfg, const void *picture, uint8_t digest[48])
+{ // calcMD5 TComPicYuvMD5.cpp:88-130: one digest per colour plane
+  if (!cfg || cfg->struct_size != sizeof *cfg || !picture || !digest) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7)) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return HEVCDL_ERR_UNSUPPORTED;
+  const size_t bps = cfg->bit_depth > 8 ? 2 : 1, ysz = (size_t)cfg->width * cfg->height * bps, csz = ysz / 4;
+  const uint8_t *p = (const uint8_t *)picture;
+  for (int c = 0; c < 3; c++) { Md5 m; m.update(p + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz)), c ? csz : ysz); m.final(digest + 16 * c); }
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, const void *picture, uint8_t *out, size_t capacity, size_t *out_len)
+{ // SEIDecodedPictureHash 1 (MD5): suffix SEI NAL after the slice (TEncGOP.cpp:1938-1960, SEIwrite.cpp xWriteSEIDecodedPictureHash)
+  if (!cfg || cfg->struct_size != sizeof *cfg || !picture || !out || !out_len) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7)) return HEVCDL_ERR_INVALID_ARG;
+  uint8_t d[48];
+  const hevcdl_status st = hevcdl_picture_md5(cfg, picture, d);
+  if (st != HEVCDL_OK) return st;
+  BitOut w;
+  w.write(132, 8); w.write(49, 8); w.write(0, 8);          // payload type decoded_picture_hash, size 1 + 3 * 16, hash_type 0 = MD5
+  for (int i = 0; i < 48; i++) w.write(d[i], 8);
+  w.trailing();
+  std::vector<uint8_t> nal;
+  put_nal(nal, 40, w.b, false);                           // SUFFIX_SEI_NUT
+  *out_len = nal.size();
+  if (nal.size() > capacity) return HEVCDL_ERR_INVALID_ARG;
+  memcpy(out, nal.data(), nal.size());
   return HEVCDL_OK;
 }
 

@@ -172,6 +172,13 @@ size_t        hevcdl_access_unit_bound(int width, int height);
 hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc, const hevcdl_ctu_record *records, const hevcdl_sao_blk *sao,
                                        uint8_t *out, size_t capacity, size_t *out_len);
 
+/* Decoded picture hash (cfg key SEIDecodedPictureHash 1 = MD5): the suffix SEI NAL the reference appends to the access unit
+ * (TEncGOP.cpp:1938-1960), computed from `picture` = the final reconstruction (planar 4:2:0; uint16 samples at 10 bits).  At most
+ * 128 bytes.  A decoder uses it to verify its output bit for bit. */
+hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, const void *picture, uint8_t *out, size_t capacity, size_t *out_len);
+/* The three 16-byte MD5 digests (Y, Cb, Cr) themselves, as the reference prints them behind a picture's line (TEncGOP.cpp:2529-2540). */
+hevcdl_status hevcdl_picture_md5(const hevcdl_stream_config *cfg, const void *picture, uint8_t digest[48]);
+
 /* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------
  *   TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)   TEncCu.h:120, called at TEncSlice.cpp:879
  *   TEncCu::encodeCtu(TComDataCU* pCtu)                   TEncCu.h:123, called at TEncSlice.cpp:893

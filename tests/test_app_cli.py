@@ -153,11 +153,13 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
         for a in range(f["labels"].shape[1]):
             (tmp_path / "pred" / str(fr) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in f["labels"][fr, a]))
     r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
+                  "--SEIDecodedPictureHash=1",
                   "--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (int(f["tiles"][0]) - 1), "--NumTileRowsMinus1=%d" % (int(f["tiles"][1]) - 1)] + bd_args, tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_filtered"])
-    ref = b"".join((b"\x00" if sc == 4 else b"") + b"\x00\x00\x01" + n for sc, n in hp.split_annexb(f["bitstream"].tobytes()) if ((n[0] >> 1) & 63) != 40)
-    assert (tmp_path / "str.bin").read_bytes() == ref
+    assert (tmp_path / "str.bin").read_bytes() == f["bitstream"].tobytes()           # the reference's stream, picture-hash SEI included
+    md5 = lambda text: [l[l.index("[MD5:"):].strip() for l in text.splitlines() if "[MD5:" in l]
+    assert md5(r.stdout) == md5("\n".join(str(l) for l in f["summary"])) and len(md5(r.stdout)) == nf
     import re
     psnr = lambda text: re.findall(r"\[Y [0-9.]+ dB +U [0-9.]+ dB +V [0-9.]+ dB\]", text)      # PSNR of the final picture, maxval 255 << (bitDepth - 8)
     assert psnr(r.stdout) == psnr("\n".join(str(l) for l in f["summary"])) and len(psnr(r.stdout)) == nf

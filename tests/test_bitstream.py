@@ -45,6 +45,39 @@ def test_reference_decoder_reconstructs_the_deblocked_picture(path, tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "dec.yuv", np.uint8), f["recon_deblocked"])
 
 
+@pytest.mark.skipif(not os.path.exists(REF_DEC), reason="reference decoder build (oracle/_ref) only exists in the survey container")
+@pytest.mark.parametrize("name", ["c192_q32_r2", "t576_q27_2x3", "x576_q30_2x3"])
+def test_reference_decoder_verifies_the_picture_hash(name, tmp_path):
+    """Full default-configuration stream (SAO on) + our MD5 SEI of the fixture's final picture: the reference decoder reconstructs the
+    picture and finds its own MD5 equal to the one in the stream for every picture."""
+    import hevcdl_amd
+    sys_path = os.path.join(ROOT, "oracle")
+    import sys
+    sys.path.insert(0, sys_path)
+    import ref_tools
+    f = np.load(os.path.join(GOLD, "rd_%s.npz" % name))
+    w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["records"].shape[0]
+    bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8
+    dt = np.uint8 if bd == 8 else np.dtype("<u2")
+    fb = w * h * 3 // 2
+    final = np.frombuffer(f["recon_filtered"].tobytes(), dt).reshape(nf, fb)
+    dbk = np.frombuffer(f["recon_deblocked"].tobytes(), dt).reshape(nf, fb)
+    __import__("__graft_entry__").build_oracle()
+    params, out = ref_tools.run_sao(f["yuv"].reshape(nf, fb), dbk, w, h, qp, tiles=tiles_of(f), bit_depth=bd)
+    recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
+    stream = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bd)
+                      + hevcdl_amd.picture_hash_sei(w, h, final[poc], bd) for poc in range(nf))
+    (tmp_path / "s.bin").write_bytes(stream)
+    r = subprocess.run([REF_DEC, "-b", "s.bin", "-o", "dec.yuv"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ERROR" not in r.stdout and r.stdout.count("(OK)") == nf, r.stdout[-800:]
+    assert np.array_equal(np.fromfile(tmp_path / "dec.yuv", dt), final.reshape(-1))
+    # a wrong hash is caught
+    bad = bytearray(stream); bad[-10] ^= 0xff
+    (tmp_path / "bad.bin").write_bytes(bytes(bad))
+    r = subprocess.run([REF_DEC, "-b", "bad.bin", "-o", "dec2.yuv"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert "ERROR" in r.stdout or r.returncode != 0
+
+
 def test_parameter_sets_and_headers_parse_back():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

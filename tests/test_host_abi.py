@@ -20,7 +20,7 @@ def lib():
 def test_every_declared_symbol_is_exported(lib):
     import hevcdl_amd
     hdr = open(os.path.join(ROOT, "include", "hevcdl.h")).read()
-    declared = set(re.findall(r"\b(hevcdl_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(hevcdl_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"hevcdl_ctx"}
     assert declared, "no declarations parsed"
     raw = ctypes.CDLL(hevcdl_amd.LIB_PATH)

@@ -47,8 +47,10 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     params, out = ref_tools.run_sao(org, dbk, w, h, qp, tiles=tiles_of(f), bit_depth=bit_depth_of(f))
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f)) for poc in range(nf))
-    assert ours == strip_sei(f["bitstream"].tobytes())
+    aus = [hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f)) for poc in range(nf)]
+    assert b"".join(aus) == strip_sei(f["bitstream"].tobytes())
+    # with the decoded-picture-hash SEI (MD5 of the final picture) behind every access unit: the reference's stream, every byte
+    assert b"".join(au + hevcdl_amd.picture_hash_sei(w, h, out[poc], bit_depth_of(f)) for poc, au in enumerate(aus)) == f["bitstream"].tobytes()
 
 
 @pytest.mark.gpu
