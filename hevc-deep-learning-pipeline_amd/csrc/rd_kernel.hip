@@ -1421,7 +1421,9 @@ DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved)
+// TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved, 3 predict and leave the
+// reconstruction in s->pred only: a first-pass candidate of a PU coded as one TU -- nothing reads its picture / layer samples, and
+// if it becomes the best candidate set_result takes them from LDS)
 // ---------------------------------------------------------------------------------------------------
 DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
 {
@@ -1474,7 +1476,8 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   for (int i = lane_id(); i < n * n; i += 64) {
     const int r = i >> log2n, cc = i & (n - 1);
     const int v = clip8((int)s.pred[i] + (int)s.resi[r * RS(n) + cc]);
-    s.pred[i] = (pel_t)v; rq[r * cs + cc] = (pel_t)v; rp[(size_t)r * ps + cc] = (pel_t)v;
+    s.pred[i] = (pel_t)v;
+    if (mode012 != 3) { rq[r * cs + cc] = (pel_t)v; rp[(size_t)r * ps + cc] = (pel_t)v; }
     const int df = v - (int)org[(size_t)r * ps + cc];
     d += (uint32_t)(df * df) >> SSE_SH;                  // per sample, TComRdCost.cpp xGetSSE*
   }
@@ -1549,7 +1552,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
     } else {
       if (check_split) cabac_copy(k, &s.root[full_depth], &s.go);
       set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, 0); wsync();
-      single_dist = code_tu_block(k, cu, tu, 0, 0);
+      single_dist = code_tu_block(k, cu, tu, 0, (check_first == 2 && !check_split) ? 3 : 0);
       if (check_split) single_cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
       const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
       single_cost = calc_rd_cost(k, bits, single_dist);
@@ -1593,10 +1596,10 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
 }
 
 // xSetIntraResultLumaQT / xSetIntraResultChromaQT TEncSearch.cpp:1741-1781, 2150-2198
-template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp)
+template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp, int rec_in_lds)
 {
   if (uni(lds().a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
-    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp);
+    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp, 0);
     return;
   }
   if (comp && !tu_has_chroma_first(tu)) return;
@@ -1607,19 +1610,19 @@ template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int co
   GLB const int16_t *srcc = k.coef_l + (5 - LOG2) * 6144 + off;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = comp_off(comp) + boff(k, comp, x, y);
   GLB const pel_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; GLB pel_t *br = k.best_rec + bo;
-  for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
+  for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rec_in_lds ? lds().pred[i] : rq[o]; }
 }
-DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_)
+DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_, int rec_in_lds_ = 0)
 {
   PROF_T0();
-  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_);
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), rec_in_lds = uni(rec_in_lds_);
   wsync();
   switch (tu.log2) {
-    case 6: set_result<6>(k, cu, tu, comp); break;
-    case 5: set_result<5>(k, cu, tu, comp); break;
-    case 4: set_result<4>(k, cu, tu, comp); break;
-    case 3: set_result<3>(k, cu, tu, comp); break;
-    default: set_result<2>(k, cu, tu, comp); break;
+    case 6: set_result<6>(k, cu, tu, comp, rec_in_lds); break;
+    case 5: set_result<5>(k, cu, tu, comp, rec_in_lds); break;
+    case 4: set_result<4>(k, cu, tu, comp, rec_in_lds); break;
+    case 3: set_result<3>(k, cu, tu, comp, rec_in_lds); break;
+    default: set_result<2>(k, cu, tu, comp, rec_in_lds); break;
   }
   wsync();
   PROF_ADD(k, 15);
@@ -1823,11 +1826,13 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       // coding is a bit-exact repeat of the first pass (same mode, same references, same coder state): reuse it.
       const int memo = second && pu_log2 <= 5;
       if (memo && !(pu_log2 > min_tu_log2(cu))) continue;          // no split possible: the pass cannot change anything
-      const DistCost dc = recur_luma_any(k, cu, ptu, !second, memo, best_dist, best_cost);
+      // a first-pass candidate of a PU that is one TU keeps its reconstruction in LDS (code_tu_block mode 3)
+      const int lds_rec = !second && pu_log2 >= 3 && pu_log2 <= 5;
+      const DistCost dc = recur_luma_any(k, cu, ptu, second ? 0 : (lds_rec ? 2 : 1), memo, best_dist, best_cost);
       const uint32_t d = dc.dist; const double cost = dc.cost;
       if (ub(cost < best_cost)) {
         best_mode = org_mode; best_dist = d; best_cost = cost;
-        set_result_cu(k, cu, ptu, 0);
+        set_result_cu(k, cu, ptu, 0, lds_rec && uni(s.a[A_TRIDX][zp]) == init_trd);
         for (int i = lane_id(); i < pu_parts; i += 64) {
           s.sv_tr[i] = s.a[A_TRIDX][zp + i];
           for (int c = 0; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][zp + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][zp + i]; }
