@@ -690,8 +690,8 @@ DEV double rl_d(double v, int l)
 }
 
 // RDOQ, whole wave.  s->tc -> s->lvl ; returns uiAbsSum.
-//   phase A (lane-parallel over scan positions): |coef|*scale, the clipped rounding level (-> s->lvl) and the
-//     zero-level cost err^2*errScale (-> cost_coeff[sp]); wave-max gives the last nonzero scan position; everything
+//   phase A (lane-parallel over scan positions): |coef|*scale and the clipped rounding level (-> s->lvl); the zero-level cost
+//     err^2*errScale of a position is recomputed wherever it is needed; wave-max gives the last nonzero scan position; everything
 //     above it only adds its zero-level cost to the running totals, in the reference's order;
 //   phase B, per 4x4 coefficient group (CG) in reverse scan order: lanes 0..15 own the 16 positions and compute
 //     everything that does not depend on the c1/c2/Rice state machine (level, significance context and its two
@@ -737,9 +737,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
     uint32_t ma = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
     if (ma > 32767u) ma = 32767u;
     dst[blk] = (int16_t)ma;
-    const double de = (double)ld;
-    cost_coeff[sp] = de * de * err_scale;
-    if (ma > 0) my_last = sp;
+    if (ma > 0) my_last = sp;                          // (the zero-level cost of a position is recomputed where it is needed: cost0_of)
   }
   const int last_pos = wave_max_i(my_last);
   cost_cg_sig[lane] = 0; cgf[lane] = 0;
