@@ -5,8 +5,9 @@ Mirrors, for the outputs of the GPU path (`hevcdl_frame_stats`: SSE per plane, b
   * the per-picture log line  TEncGOP.cpp:2500-2541
   * the summary table         TEncAnalyze.h:163-196 (combined YUV PSNR), :198-370 (layout of the 4:2:0 table)
   * BD-PSNR / BD-rate         calc_BDBR/Bjontegaard-python3 (cubic fit over ln(rate), integrals over the common interval)
-The bits of `hevcdl_frame_stats` are the CABAC estimator's (row f-1, the byte-producing coder, is not built) and the
-reconstruction is the one `compressCtu` leaves, i.e. before the in-loop filters (row f-2): the numbers are labelled so.
+Feed it the size of the written access unit (the reference's bit count of a picture) and the SSE of the final picture
+(after the in-loop filters) to reproduce the reference's log; `hevcdl_frame_stats` itself carries the CABAC estimator's
+bits and the SSE before the in-loop filters.  maxval = 255 << (bit depth - 8) (TEncGOP.cpp:2380).
 """
 import math
 
@@ -20,10 +21,10 @@ def psnr_from_sse(sse, n_samples, maxval=MAXVAL_8BIT):
     return 999.99 if sse == 0 else 10.0 * math.log10(float(maxval) * maxval * n_samples / float(sse))
 
 
-def frame_psnr(sse_yuv, width, height):
+def frame_psnr(sse_yuv, width, height, maxval=MAXVAL_8BIT):
     """(Y, U, V) PSNR in dB of one 4:2:0 picture from its three SSE sums."""
     ny, nc = width * height, (width // 2) * (height // 2)
-    return tuple(psnr_from_sse(int(s), n) for s, n in zip(sse_yuv, (ny, nc, nc)))
+    return tuple(psnr_from_sse(int(s), n, maxval) for s, n in zip(sse_yuv, (ny, nc, nc)))
 
 
 def frame_line(poc, qp, bits, psnr, enc_time_s=0.0):
@@ -35,8 +36,9 @@ def frame_line(poc, qp, bits, psnr, enc_time_s=0.0):
 class Summary:
     """Running totals of TEncAnalyze (addResult) and its 4:2:0 printOut."""
 
-    def __init__(self, width, height, frame_rate=30.0):
+    def __init__(self, width, height, frame_rate=30.0, bit_depth=8):
         self.w, self.h, self.fps = width, height, float(frame_rate)
+        self.maxval = 255 << (bit_depth - 8)
         self.n = 0
         self.bits = 0.0
         self.psnr = [0.0, 0.0, 0.0]
@@ -44,7 +46,7 @@ class Summary:
 
     def add(self, bits, sse_yuv):
         ny, nc = self.w * self.h, (self.w // 2) * (self.h // 2)
-        p = frame_psnr(sse_yuv, self.w, self.h)
+        p = frame_psnr(sse_yuv, self.w, self.h, self.maxval)
         for c, n in enumerate((ny, nc, nc)):
             self.psnr[c] += p[c]
             self.mse[c] += float(int(sse_yuv[c])) / n
@@ -58,7 +60,7 @@ class Summary:
     def yuv_psnr(self):
         """calculateCombinedValues, TEncAnalyze.h:163-196 (4:2:0: weights 4,1,1 over 6)."""
         mse = (4 * self.mse[0] + self.mse[1] + self.mse[2]) / self.n / 6.0
-        return 999.99 if mse == 0 else 10.0 * math.log10(MAXVAL_8BIT * MAXVAL_8BIT / mse)
+        return 999.99 if mse == 0 else 10.0 * math.log10(float(self.maxval) * self.maxval / mse)
 
     def averages(self):
         return [p / self.n for p in self.psnr]

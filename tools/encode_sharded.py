@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Encode a YUV sequence on 1..N GPUs (frames shard across ranks):
+    python tools/encode_sharded.py -i in.yuv -wdt 3840 -hgt 2160 -q 32 -f 600 -b out.bin -o rec.yuv
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 tools/encode_sharded.py ...
+Output (bitstream, reconstruction, log) is identical to the single-GPU run of hevc-deep-learning-pipeline_amd/bin/TAppEncoderHevcdl."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-i", required=True); ap.add_argument("-wdt", type=int, required=True); ap.add_argument("-hgt", type=int, required=True)
+    ap.add_argument("-q", type=int, default=32); ap.add_argument("-f", type=int, required=True); ap.add_argument("-fs", type=int, default=0)
+    ap.add_argument("-b", default=None); ap.add_argument("-o", default=None); ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--tiles", default="1x1"); ap.add_argument("--bit-depth", type=int, default=8); ap.add_argument("--level", type=float, default=6.2)
+    ap.add_argument("--hash", action="store_true", help="SEIDecodedPictureHash 1 (MD5)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the summary gather (gloo when ranks share a GPU)")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    import hevcdl_amd
+    import hevcdl_amd.pipeline as pipeline
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    if world > 1:
+        dist.init_process_group(a.backend)
+    rank = dist.get_rank() if world > 1 else 0
+    tiles = tuple(int(v) for v in a.tiles.split("x"))
+    pipeline.encode_sequence(a.i, a.wdt, a.hgt, a.q, a.f, a.b, a.o, frame_skip=a.fs, batch=a.batch, tiles=tiles, bit_depth=a.bit_depth,
+                             level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=(print if rank == 0 else (lambda *x: None)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
