@@ -100,3 +100,103 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
     log("\n\nSUMMARY --------------------------------------------------------")
     log(summ.text())
     return summ, allrows
+
+
+def encode_sequence_tile_sharded(input_path, width, height, qp, n_frames, tiles, bitstream_path=None, recon_path=None, frame_skip=0, batch=None,
+                                 bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, device=None, log=print):
+    """The within-picture partition: every rank decides its share of the TILES of every picture of a batch
+    (`hevcdl_compress_tiles_dev`), one all-to-all moves the tile payloads to the picture's owner (`sharding.exchange_tiles_to_owners`:
+    picture i of the batch -> rank i mod world), the owner runs the in-loop filters on the assembled picture and writes its access unit.
+    Needs torch.distributed initialised; batch (default: world size) is a multiple of the world size.  Output == encode_sequence()."""
+    import torch
+    import torch.distributed as dist
+    from . import REC_DTYPE, SAO_DTYPE
+    rank, world = dist.get_rank(), dist.get_world_size()
+    via_host = dist.get_backend() != "nccl"                         # gloo moves host tensors
+    batch = batch or world
+    if batch % world:
+        raise ValueError("batch must be a multiple of the world size")
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", device)
+    n_tiles = tiles[0] * tiles[1]
+    t_begin, t_count = sharding.shard_tiles(n_tiles, world, rank)
+    enc = Encoder(width, height, qp, max_frames=batch, device=device, tiles=tiles, bit_depth=bit_depth)
+    ctus, fsamp, ysz = enc.ctus, width * height * 3 // 2, width * height
+    bps = 1 if bit_depth == 8 else 2
+    part_bits = (bitstream_path + ".part%d" % rank) if bitstream_path else None
+    part_rec = (recon_path + ".part%d" % rank) if recon_path else None
+    fb, fr = open(part_bits, "wb") if part_bits else None, open(part_rec, "wb") if part_rec else None
+    rows = []
+    for b0 in range(0, n_frames, batch):
+        nb = min(batch, n_frames - b0)
+        yuv = read_frames(input_path, width, height, frame_skip + b0, nb, bit_depth)
+        if nb < batch:                                              # last batch: repeat the last picture, the copies are dropped below
+            yuv = np.concatenate([yuv, np.repeat(yuv[-1:], batch - nb, axis=0)])
+        d_yuv = torch.from_numpy(yuv.view(np.uint8).reshape(batch, fsamp * bps)).to(dev)
+        d_lab = torch.zeros((batch, ctus, 16), dtype=torch.uint8, device=dev)
+        d_recs = torch.zeros((batch, ctus * REC_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d_recon = torch.zeros_like(d_yuv)
+        enc._check(enc.lib.hevcdl_predict_depth_dev(enc._h, d_yuv.data_ptr(), batch, d_lab.data_ptr(), None, None))
+        enc.compress_tiles_dev(d_yuv.data_ptr(), batch, d_lab.data_ptr(), d_recs.data_ptr(), d_recon.data_ptr(), None, t_begin, t_count)
+        torch.cuda.synchronize(dev)
+        if via_host:
+            owned, o_recon, o_recs = sharding.exchange_tiles_to_owners(d_recon.cpu(), d_recs.cpu(), width, height, tiles, bps=bps)
+            o_recon, o_recs = o_recon.to(dev), o_recs.to(dev)
+        else:
+            owned, o_recon, o_recs = sharding.exchange_tiles_to_owners(d_recon, d_recs, width, height, tiles, bps=bps)
+        no = len(owned)
+        o_org = d_yuv[torch.tensor(owned, device=dev)].contiguous()
+        o_dbk = torch.zeros_like(o_recon)
+        o_fin = torch.zeros_like(o_recon)
+        o_sao = torch.zeros((no, ctus * 3 * SAO_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        enc.deblock_frames_dev(o_recon.data_ptr(), no, o_recs.data_ptr(), o_dbk.data_ptr())
+        enc.sao_frames_dev(o_org.data_ptr(), o_dbk.data_ptr(), no, o_sao.data_ptr(), o_fin.data_ptr())
+        torch.cuda.synchronize(dev)
+        recs = np.frombuffer(o_recs.cpu().numpy().tobytes(), REC_DTYPE).reshape(no, ctus)
+        sao = np.frombuffer(o_sao.cpu().numpy().tobytes(), SAO_DTYPE).reshape(no, ctus, 3)
+        final = np.frombuffer(o_fin.cpu().numpy().tobytes(), np.uint8 if bit_depth == 8 else "<u2").reshape(no, fsamp)
+        for j, i in enumerate(owned):
+            poc = b0 + i
+            if i >= nb:
+                continue
+            au = write_access_unit(width, height, qp, poc, recs[j], level_idc=level_idc, sao=sao[j], tiles=tiles, bit_depth=bit_depth)
+            blob = au + (picture_hash_sei(width, height, final[j], bit_depth) if hash_sei else b"")
+            if fb:
+                fb.write(blob)
+            if fr:
+                final[j].tofile(fr)
+            d = (yuv[i].astype(np.int64) - final[j].astype(np.int64)) ** 2
+            rows.append([poc, len(au) * 8, int(d[:ysz].sum()), int(d[ysz:ysz + ysz // 4].sum()), int(d[ysz + ysz // 4:].sum()), len(blob)])
+        log("pictures %d..%d: tiles [%d, %d) of %d decided on rank %d" % (b0, b0 + nb - 1, t_begin, t_begin + t_count, n_tiles, rank))
+    enc.close()
+    for f in (fb, fr):
+        if f:
+            f.close()
+    cap = (n_frames + world - 1) // world + batch
+    t = torch.full((cap, 6), -1, dtype=torch.int64)
+    if rows:
+        t[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+    allrows = sharding.gather_frame_summaries(t.to(dev) if not via_host else t)
+    dist.barrier()
+    if rank != 0:
+        return None, None
+    # merge the per-rank parts in POC order: every part holds its pictures in increasing POC
+    owner_of = {int(r[0]): ((int(r[0]) % batch) % world) for r in allrows}
+    size_of = {int(r[0]): int(r[5]) for r in allrows}
+    for path, sizes in ((bitstream_path, size_of), (recon_path, None)):
+        if not path:
+            continue
+        parts = [open(path + ".part%d" % r, "rb") for r in range(world)]
+        with open(path, "wb") as out:
+            for poc in range(n_frames):
+                out.write(parts[owner_of[poc]].read(sizes[poc] if sizes else fsamp * bps))
+        for r, fpart in enumerate(parts):
+            fpart.close(); os.remove(path + ".part%d" % r)
+    summ = metrics.Summary(width, height, frame_rate, bit_depth)
+    for poc, bits, sy, su, sv, _ in allrows:
+        p = summ.add(int(bits), (int(sy), int(su), int(sv)))
+        log(metrics.frame_line(int(poc), qp, int(bits), p))
+    log("\n\nSUMMARY --------------------------------------------------------")
+    log(summ.text())
+    return summ, allrows

@@ -46,28 +46,29 @@ def tile_grid(width, height, tiles):
     return out
 
 
-def _planes(frames, width, height):
-    """[F, w*h*3/2] uint8 -> (Y [F,h,w], U [F,h/2,w/2], V [F,h/2,w/2]) views."""
+def _planes(frames, width, height, bps=1):
+    """[F, w*h*3/2*bps] uint8 -> byte views (Y [F,h,w*bps], U [F,h/2,w/2*bps], V [F,h/2,w/2*bps]); bps = bytes per sample."""
     f = frames.shape[0]
-    ysz, csz = width * height, width * height // 4
-    return (frames[:, :ysz].view(f, height, width), frames[:, ysz:ysz + csz].view(f, height // 2, width // 2),
-            frames[:, ysz + csz:].view(f, height // 2, width // 2))
+    ysz, csz = width * height * bps, width * height // 4 * bps
+    return (frames[:, :ysz].view(f, height, width * bps), frames[:, ysz:ysz + csz].view(f, height // 2, width // 2 * bps),
+            frames[:, ysz + csz:].view(f, height // 2, width // 2 * bps))
 
 
-def tile_payload_bytes(width, height, rect):
+def tile_payload_bytes(width, height, rect, bps=1):
     cx0, cy0, cx1, cy1 = rect
     w, h = min(cx1 * 64, width) - cx0 * 64, min(cy1 * 64, height) - cy0 * 64
-    return w * h * 3 // 2 + (cx1 - cx0) * (cy1 - cy0) * REC_BYTES
+    return w * h * 3 // 2 * bps + (cx1 - cx0) * (cy1 - cy0) * REC_BYTES
 
 
-def pack_tile(recon, records, width, height, rect, out):
-    """Reconstruction rectangle (Y, U, V) + CTU records of one tile of every frame -> out [F, >= payload] uint8."""
+def pack_tile(recon, records, width, height, rect, out, bps=1):
+    """Reconstruction rectangle (Y, U, V) + CTU records of one tile of every frame -> out [F, >= payload] uint8.  recon is the byte
+    view of the pictures (bps bytes per sample: 2 for 10-bit)."""
     cx0, cy0, cx1, cy1 = rect
     ctus_x = (width + 63) // 64
     x0, y0, x1, y1 = cx0 * 64, cy0 * 64, min(cx1 * 64, width), min(cy1 * 64, height)
     f, o = recon.shape[0], 0
-    for p, sh in zip(_planes(recon, width, height), (0, 1, 1)):
-        blk = p[:, y0 >> sh:y1 >> sh, x0 >> sh:x1 >> sh].reshape(f, -1)
+    for p, sh in zip(_planes(recon, width, height, bps), (0, 1, 1)):
+        blk = p[:, y0 >> sh:y1 >> sh, (x0 >> sh) * bps:(x1 >> sh) * bps].reshape(f, -1)
         out[:, o:o + blk.shape[1]] = blk
         o += blk.shape[1]
     recs = records.view(f, -1, REC_BYTES).view(f, (height + 63) // 64, ctus_x, REC_BYTES)[:, cy0:cy1, cx0:cx1].reshape(f, -1)
@@ -75,26 +76,26 @@ def pack_tile(recon, records, width, height, rect, out):
     return o + recs.shape[1]
 
 
-def unpack_tile(buf, recon, records, width, height, rect):
+def unpack_tile(buf, recon, records, width, height, rect, bps=1):
     """Inverse of pack_tile: buf [F, >= payload] -> the tile's rectangle of recon [F, w*h*3/2] and records [F, ctus*REC_BYTES]."""
     cx0, cy0, cx1, cy1 = rect
     ctus_x = (width + 63) // 64
     x0, y0, x1, y1 = cx0 * 64, cy0 * 64, min(cx1 * 64, width), min(cy1 * 64, height)
     f, o = recon.shape[0], 0
-    for p, sh in zip(_planes(recon, width, height), (0, 1, 1)):
-        hh, ww = (y1 - y0) >> sh, (x1 - x0) >> sh
-        p[:, y0 >> sh:y1 >> sh, x0 >> sh:x1 >> sh] = buf[:, o:o + hh * ww].view(f, hh, ww)
+    for p, sh in zip(_planes(recon, width, height, bps), (0, 1, 1)):
+        hh, ww = (y1 - y0) >> sh, ((x1 - x0) >> sh) * bps
+        p[:, y0 >> sh:y1 >> sh, (x0 >> sh) * bps:(x1 >> sh) * bps] = buf[:, o:o + hh * ww].view(f, hh, ww)
         o += hh * ww
     n = (cx1 - cx0) * (cy1 - cy0) * REC_BYTES
     records.view(f, (height + 63) // 64, ctus_x, REC_BYTES)[:, cy0:cy1, cx0:cx1] = buf[:, o:o + n].view(f, cy1 - cy0, cx1 - cx0, REC_BYTES)
     return o + n
 
 
-def exchange_tiles_to_owners(recon, records, width, height, tiles, group=None):
+def exchange_tiles_to_owners(recon, records, width, height, tiles, group=None, bps=1):
     """Tile-sharded decisions -> whole pictures at their owners.
 
-    recon [F, w*h*3/2] / records [F, ctus*REC_BYTES] (uint8, this rank's tiles filled in, same F on every rank, F a multiple of the
-    world size).  Frame f is owned by rank f % world.  Returns (owned frame indices, recon [F/world, ...], records [F/world, ...])
+    recon [F, w*h*3/2*bps] / records [F, ctus*REC_BYTES] (uint8 byte views, this rank's tiles filled in, same F on every rank, F a
+    multiple of the world size; bps = bytes per sample).  Frame f is owned by rank f % world.  Returns (owned frame indices, recon [F/world, ...], records [F/world, ...])
     with every tile of the owned pictures in place.  One all_to_all_single of equal padded splits."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     f = recon.shape[0]
@@ -103,7 +104,7 @@ def exchange_tiles_to_owners(recon, records, width, height, tiles, group=None):
     grid = tile_grid(width, height, tiles)
     mine = shard_tiles(len(grid), world, rank)
     # split s of the send buffer = this rank's tiles of the pictures owned by rank s, padded to the largest per-rank payload
-    per_rank = [sum(tile_payload_bytes(width, height, grid[t]) for t in range(*_span(shard_tiles(len(grid), world, r)))) for r in range(world)]
+    per_rank = [sum(tile_payload_bytes(width, height, grid[t], bps) for t in range(*_span(shard_tiles(len(grid), world, r)))) for r in range(world)]
     pad, fo = max(per_rank), f // world
     send = torch.zeros((world, fo, pad), dtype=torch.uint8, device=recon.device)
     for s in range(world):
@@ -111,7 +112,7 @@ def exchange_tiles_to_owners(recon, records, width, height, tiles, group=None):
         rsub, csub = recon[idx], records[idx]
         o = 0
         for t in range(*_span(mine)):
-            o += pack_tile(rsub, csub, width, height, grid[t], send[s, :, o:])
+            o += pack_tile(rsub, csub, width, height, grid[t], send[s, :, o:], bps)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
     owned = list(range(rank, f, world))
@@ -120,7 +121,7 @@ def exchange_tiles_to_owners(recon, records, width, height, tiles, group=None):
     for r in range(world):
         o = 0
         for t in range(*_span(shard_tiles(len(grid), world, r))):
-            o += unpack_tile(recv[r, :, o:], out_recon, out_records, width, height, grid[t])
+            o += unpack_tile(recv[r, :, o:], out_recon, out_records, width, height, grid[t], bps)
     return owned, out_recon, out_records
 
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("-b", default=None); ap.add_argument("-o", default=None); ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tiles", default="1x1"); ap.add_argument("--bit-depth", type=int, default=8); ap.add_argument("--level", type=float, default=6.2)
     ap.add_argument("--hash", action="store_true", help="SEIDecodedPictureHash 1 (MD5)")
+    ap.add_argument("--shard", default="frames", choices=["frames", "tiles"], help="frames: rank r codes a frame range; tiles: rank r decides its tiles of every picture")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the summary gather (gloo when ranks share a GPU)")
     a = ap.parse_args()
     import torch
@@ -30,8 +31,15 @@ def main():
         dist.init_process_group(a.backend)
     rank = dist.get_rank() if world > 1 else 0
     tiles = tuple(int(v) for v in a.tiles.split("x"))
-    pipeline.encode_sequence(a.i, a.wdt, a.hgt, a.q, a.f, a.b, a.o, frame_skip=a.fs, batch=a.batch, tiles=tiles, bit_depth=a.bit_depth,
-                             level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=(print if rank == 0 else (lambda *x: None)))
+    say = print if rank == 0 else (lambda *x: None)
+    if a.shard == "tiles":
+        if world < 2:
+            raise SystemExit("--shard tiles needs more than one rank (torch.distributed.run)")
+        pipeline.encode_sequence_tile_sharded(a.i, a.wdt, a.hgt, a.q, a.f, tiles, a.b, a.o, frame_skip=a.fs, batch=world * max(1, a.batch // world),
+                                              bit_depth=a.bit_depth, level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=say)
+    else:
+        pipeline.encode_sequence(a.i, a.wdt, a.hgt, a.q, a.f, a.b, a.o, frame_skip=a.fs, batch=a.batch, tiles=tiles, bit_depth=a.bit_depth,
+                                 level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=say)
     if world > 1:
         dist.destroy_process_group()
 
