@@ -94,7 +94,7 @@ def build_app(force=False):
     os.makedirs(os.path.dirname(APP_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     subprocess.run([hipcc, "-O2", "-std=c++17", "-x", "c++", src, "-x", "none", "-I" + os.path.join(ROOT, "include"), "-L" + os.path.dirname(lib), "-lhevcdl_hip",
-                    "-Wl,-rpath,$ORIGIN/../lib", "-o", APP_PATH], check=True)
+                    "-Wl,-rpath,$ORIGIN/../lib", "-pthread", "-o", APP_PATH], check=True)
     return APP_PATH
 
 

@@ -20,6 +20,8 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "hevcdl.h"
 
@@ -229,7 +231,6 @@ int main(int argc, char **argv)
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
   std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
-  std::vector<uint8_t> au(hevcdl_access_unit_bound(width, height));
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;
   int rc = 0;
@@ -248,47 +249,68 @@ int main(int argc, char **argv)
       lab = labels.data();
     }
     if (rc) break;
+    bool filtered = false;
     const auto t0 = std::chrono::steady_clock::now();
     st = hevcdl_compress_frames(ctx, yuv.data(), nb, lab, recs.data(), recon.data(), stats.data());
     const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / nb;
     if (st == HEVCDL_OK && deblock) { // TComLoopFilter::loopFilterPic (TEncGOP.cpp:1742); the picture statistics follow the filtered picture
       st = hevcdl_deblock_frames(ctx, recon.data(), nb, recs.data(), recon.data());
       if (st == HEVCDL_OK && sao) st = hevcdl_sao_frames(ctx, yuv.data(), recon.data(), nb, sao_params.data(), recon.data());   // TEncGOP.cpp:1797
-      for (int i = 0; i < nb && st == HEVCDL_OK; i++) {
-        const uint8_t *o = yuv.data() + frame_bytes * i, *r = recon.data() + frame_bytes * i;
-        const size_t n[3] = { (size_t)width * height, (size_t)width * height / 4, (size_t)width * height / 4 };
-        size_t off = 0;
-        for (int c = 0; c < 3; c++) {
-          unsigned long long sse = 0;
-          if (bit_depth == 8) for (size_t k = 0; k < n[c]; k++) { const int d = (int)o[off + k] - (int)r[off + k]; sse += (unsigned long long)(d * d); }
-          else { const uint16_t *o16 = (const uint16_t *)o, *r16 = (const uint16_t *)r; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o16[off + k] - (int)r16[off + k]; sse += (unsigned long long)(d * d); } }
-          stats[i].sse[c] = sse; off += n[c];
-        }
-      }
+      filtered = true;                      // the picture statistics follow the filtered picture: recomputed per picture below
     }
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
+    // per picture on the host: SSE of the output picture, the access unit (the arithmetic coder: ~35 ms for a 2160p picture), the
+    // picture hash.  Pictures are independent: a pool of threads fills per-picture results, the output stays in POC order.
+    struct PicOut { std::vector<uint8_t> bytes; size_t au_len = 0; char md5_text[128]; hevcdl_status st = HEVCDL_OK; };
+    std::vector<PicOut> pics(nb);
+    {
+      std::atomic<int> next(0);
+      auto work = [&]() {
+        std::vector<uint8_t> buf(hevcdl_access_unit_bound(width, height));
+        for (int i = next++; i < nb; i = next++) {
+          PicOut &po = pics[i]; po.md5_text[0] = 0;
+          if (filtered) {
+            const uint8_t *o = yuv.data() + frame_bytes * i, *r = recon.data() + frame_bytes * i;
+            const size_t n[3] = { (size_t)width * height, (size_t)width * height / 4, (size_t)width * height / 4 };
+            size_t off = 0;
+            for (int c = 0; c < 3; c++) {
+              unsigned long long sse = 0;
+              if (bit_depth == 8) for (size_t k = 0; k < n[c]; k++) { const int d = (int)o[off + k] - (int)r[off + k]; sse += (unsigned long long)(d * d); }
+              else { const uint16_t *o16 = (const uint16_t *)o, *r16 = (const uint16_t *)r; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o16[off + k] - (int)r16[off + k]; sse += (unsigned long long)(d * d); } }
+              stats[i].sse[c] = sse; off += n[c];
+            }
+          }
+          // the access unit: VPS+SPS+PPS+slice, written to -b; its size is the picture's bit count (TEncGOP.cpp:2420-2447)
+          po.st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, sao ? sao_params.data() + (size_t)ctus * i : nullptr, buf.data(), buf.size(), &po.au_len);
+          if (po.st != HEVCDL_OK) continue;
+          po.bytes.assign(buf.begin(), buf.begin() + po.au_len);
+          if (hash_sei) { // suffix SEI after the slice; not part of the picture's bit count (as in the reference)
+            uint8_t sei[128], dg[48]; size_t sei_len = 0;
+            po.st = hevcdl_write_picture_hash_sei(&scfg, recon.data() + frame_bytes * i, sei, sizeof sei, &sei_len);
+            if (po.st == HEVCDL_OK) po.st = hevcdl_picture_md5(&scfg, recon.data() + frame_bytes * i, dg);
+            if (po.st != HEVCDL_OK) continue;
+            po.bytes.insert(po.bytes.end(), sei, sei + sei_len);
+            char *q = po.md5_text + sprintf(po.md5_text, " [MD5:");
+            for (int c = 0; c < 3; c++) { for (int k = 0; k < 16; k++) q += sprintf(q, "%02x", dg[16 * c + k]); *q++ = c < 2 ? ',' : ']'; }
+            *q = 0;
+          }
+        }
+      };
+      const int nthreads = (int)std::max(1u, std::min<unsigned>({ (unsigned)nb, std::thread::hardware_concurrency(), 32u }));
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+      work();
+      for (auto &t : pool) t.join();
+    }
     for (int i = 0; i < nb; i++) {
+      const PicOut &po = pics[i];
+      if (po.st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)po.st); rc = 3; break; }
       const double maxval = (double)(255 << (bit_depth - 8));
       const double p[3] = { psnr_of(stats[i].sse[0], ny, maxval), psnr_of(stats[i].sse[1], nc, maxval), psnr_of(stats[i].sse[2], nc, maxval) };
-      // the access unit: VPS+SPS+PPS+slice, written to -b; its size is the picture's bit count (TEncGOP.cpp:2420-2447)
-      size_t au_len = 0;
-      st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, sao ? sao_params.data() + (size_t)ctus * i : nullptr, au.data(), au.size(), &au_len);
-      if (st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)st); rc = 3; break; }
-      if (fbits) fwrite(au.data(), 1, au_len, fbits);
-      char md5_text[128] = "";
-      if (hash_sei) { // suffix SEI after the slice; not part of the picture's bit count (as in the reference)
-        uint8_t sei[128], dg[48]; size_t sei_len = 0;
-        st = hevcdl_write_picture_hash_sei(&scfg, recon.data() + frame_bytes * i, sei, sizeof sei, &sei_len);
-        if (st == HEVCDL_OK) st = hevcdl_picture_md5(&scfg, recon.data() + frame_bytes * i, dg);
-        if (st != HEVCDL_OK) { fprintf(stderr, "Error: picture hash failed (status %d)\n", (int)st); rc = 3; break; }
-        if (fbits) fwrite(sei, 1, sei_len, fbits);
-        char *q = md5_text + sprintf(md5_text, " [MD5:");
-        for (int c = 0; c < 3; c++) { for (int k = 0; k < 16; k++) q += sprintf(q, "%02x", dg[16 * c + k]); *q++ = c < 2 ? ',' : ']'; }
-        *q = 0;
-      }
+      if (fbits) fwrite(po.bytes.data(), 1, po.bytes.size(), fbits);
       printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]%s\n", f0 + i, 0, 'I', qp,
-             (unsigned long long)au_len * 8, p[0], p[1], p[2], et, md5_text);
-      sum_bits += (double)au_len * 8;
+             (unsigned long long)po.au_len * 8, p[0], p[1], p[2], et, po.md5_text);
+      sum_bits += (double)po.au_len * 8;
       for (int c = 0; c < 3; c++) { sum_psnr[c] += p[c]; sum_mse[c] += (double)stats[i].sse[c] / (c ? nc : ny); }
       done++;
     }

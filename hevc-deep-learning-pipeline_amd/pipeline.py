@@ -16,6 +16,17 @@ from . import Encoder, write_access_unit, picture_hash_sei
 from . import metrics, sharding
 
 
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1))
+    return _POOL
+
+
 def read_frames(path, width, height, first, count, bit_depth=8):
     """Planar 4:2:0 frames [count, w*h*3/2] (uint8, or uint16 little endian for bit_depth 10) starting at frame `first`."""
     dt = np.uint8 if bit_depth == 8 else np.dtype("<u2")
@@ -58,15 +69,16 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
             dbk = enc.deblock_frames(recon, recs)
             sao, final = enc.sao_frames(yuv, dbk)
             et = (time.time() - t0) / nb
-            for i in range(nb):
-                poc = b0 + i
-                au = write_access_unit(width, height, qp, poc, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth)
-                if fb:
-                    fb.write(au)
-                    if hash_sei:
-                        fb.write(picture_hash_sei(width, height, final[i], bit_depth))
+            def one_picture(i):          # host work of a picture (arithmetic coder, hash, SSE): independent -> thread pool (ctypes drops the GIL)
+                au = write_access_unit(width, height, qp, b0 + i, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth)
+                sei = picture_hash_sei(width, height, final[i], bit_depth) if hash_sei else b""
                 d = (yuv[i].astype(np.int64) - final[i].astype(np.int64)) ** 2
-                rows[poc - mine.start] = [poc, len(au) * 8, int(d[:ysz].sum()), int(d[ysz:ysz + ysz // 4].sum()), int(d[ysz + ysz // 4:].sum())]
+                return au, sei, [int(d[:ysz].sum()), int(d[ysz:ysz + ysz // 4].sum()), int(d[ysz + ysz // 4:].sum())]
+            for i, (au, sei, sse) in enumerate(_pool().map(one_picture, range(nb))):
+                poc = b0 + i
+                if fb:
+                    fb.write(au + sei)
+                rows[poc - mine.start] = [poc, len(au) * 8] + sse
             if fr:
                 final.tofile(fr)
             log("rank %d: pictures %d..%d encoded (%.2f s per picture)" % (rank, b0, b0 + nb - 1, et))
