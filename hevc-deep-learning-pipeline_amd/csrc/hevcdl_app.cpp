@@ -188,7 +188,11 @@ int main(int argc, char **argv)
   const long avail = (long)(fsize / (long long)frame_bytes) - frame_skip;
   if (avail <= 0) { fprintf(stderr, "Error: input holds no frame after FrameSkip\n"); return 2; }
   if (n_frames <= 0 || n_frames > avail) n_frames = avail;                    // TAppEncTop: stops at end of file
-  const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", 64)));
+  // pictures per device call: the decision kernel runs one wavefront per (picture, tile) and the GPU holds 2048 of them, so the default
+  // is as many pictures as fill it, bounded by 16 GiB of host staging (originals, reconstruction, CTU records)
+  const long per_frame_host = (long)(2 * frame_bytes + (size_t)hevcdl_ctus_per_frame(width, height) * sizeof(hevcdl_ctu_record));
+  const long auto_batch = std::max<long>(1, std::min<long>(2048 / (tile_cols * tile_rows), (16L << 30) / per_frame_host));
+  const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", auto_batch)));
 
   hevcdl_config cfg;
   hevcdl_status st = hevcdl_config_default_bd(&cfg, width, height, qp, bit_depth);
