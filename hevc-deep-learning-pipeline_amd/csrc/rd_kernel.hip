@@ -314,29 +314,38 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   GLB const pel_t *p = k.rec[c];
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
-  auto sample = [&](int i) -> int {                          // picture sample behind line index i
-    if (i < 2 * n) return p[(size_t)(y + 2 * n - 1 - i) * st + x - 1];
-    if (i == 2 * n) return p[(size_t)(y - 1) * st + x - 1];
-    return p[(size_t)(y - 1) * st + x + (i - 2 * n - 1)];
+  auto sample_addr = [&](int i) -> size_t {                  // picture sample behind line index i
+    if (i < 2 * n) return (size_t)(y + 2 * n - 1 - i) * st + x - 1;
+    if (i == 2 * n) return (size_t)(y - 1) * st + x - 1;
+    return (size_t)(y - 1) * st + x + (i - 2 * n - 1);
   };
-  for (int i = lane_id(); i <= 4 * n; i += 64) {
-    int kk = i < 2 * n ? i / u : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / u);
-    int v;
-    const int fl = kk < 64 ? (int)((m0 >> kk) & 1) : f64;
-    if (fl) v = sample(i);
-    else {
-      // nearest available unit below (its last sample), else the first available unit above (its first sample)
-      unsigned long long below = kk >= 64 ? m0 : (m0 & ((1ull << kk) - 1ull));
-      if (below) { const int j = 63 - __clzll(below); v = sample(unit_start(j) + unit_len(j) - 1); }
-      else {
-        unsigned long long above = kk >= 63 ? 0ull : (m0 & ~((2ull << kk) - 1ull));
-        if (above) { const int j = __ffsll((long long)above) - 1; v = sample(unit_start(j)); }
-        else if (f64) v = sample(unit_start(64));
-        else v = 1 << (BD - 1);
+  // Every line element is ONE picture sample: its own when its unit is available, otherwise the last sample of the nearest
+  // available unit below, else the first sample of the first available unit above (TComPattern.cpp:350-543).  The source index
+  // is pure bit arithmetic on the availability mask, so the (up to 5) loads of a lane are issued back to back -- one memory
+  // round trip for the whole line instead of one per 64 elements.
+  constexpr int MAX_IT = 5;                                 // 4 * 64 + 1 elements
+  int val[MAX_IT]; bool have[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; it++) {
+    const int i = lane_id() + 64 * it;
+    have[it] = false; val[it] = 1 << (BD - 1);
+    if (i <= 4 * n) {
+      const int kk = i < 2 * n ? i / u : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / u);
+      const int fl = kk < 64 ? (int)((m0 >> kk) & 1) : f64;
+      int si = i;
+      if (!fl) {
+        const unsigned long long below = kk >= 64 ? m0 : (m0 & ((1ull << kk) - 1ull));
+        const unsigned long long above = kk >= 63 ? 0ull : (m0 & ~((2ull << kk) - 1ull));
+        if (below) { const int j = 63 - __clzll(below); si = unit_start(j) + unit_len(j) - 1; }
+        else if (above) { const int j = __ffsll((long long)above) - 1; si = unit_start(j); }
+        else if (f64) si = unit_start(64);
+        else si = -1;                                       // nothing available: the default value
       }
+      if (si >= 0) { have[it] = true; val[it] = (int)p[sample_addr(si)]; }
     }
-    line_out[i] = (int16_t)v;
   }
+#pragma unroll
+  for (int it = 0; it < MAX_IT; it++) { const int i = lane_id() + 64 * it; if (i <= 4 * n) line_out[i] = (int16_t)val[it]; }
   wsync();
   PROF_ADD(k, 0);
 }
