@@ -108,11 +108,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    backend = os.environ.get("HEVCDL_BENCH_BACKEND", "nccl")      # "gloo": functional test of the N > 1 path with ranks sharing one GPU
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")       # where the (tiny) collective tensors live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H, qp, F = a.width, a.height, a.qp, a.frames
     enc = hevcdl_amd.Encoder(W, H, qp, max_frames=F, device=local)
@@ -145,9 +152,9 @@ def main():
     enc.profile_enable(False)
 
     # per-frame summaries (bits, SSE) gathered to rank 0: the only collective of the path
-    st = torch.from_numpy(np.frombuffer(stats.cpu().numpy().tobytes(), dtype=hevcdl_amd.STATS_DTYPE)["est_bits"].astype(np.int64)).to(dev)
+    st = torch.from_numpy(np.frombuffer(stats.cpu().numpy().tobytes(), dtype=hevcdl_amd.STATS_DTYPE)["est_bits"].astype(np.int64)).to(cdev)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         gathered = [torch.zeros_like(st) for _ in range(world)] if rank == 0 else None
