@@ -29,7 +29,25 @@ WDIR = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "weights")
 REF = "/root/reference"
 
 
-def gen_rd(tiled=False, ten_bit=False):
+EXTREME = {  # name: (W, H, qp, content, bit depth) -- smallest pictures, one-CU-wide strips, QP 0 / 51, constant pictures
+    "e8x8_q32": (8, 8, 32, "pattern", 8), "e64x8_q20": (64, 8, 20, "noise", 8), "e8x72_q40": (8, 72, 40, "noise", 8),
+    "e136_q0": (136, 72, 0, "noise", 8), "e136_q51": (136, 72, 51, "pattern", 8), "e72_q0_b10": (72, 136, 0, "noise", 10),
+    "e200_q51_b10": (200, 72, 51, "noise", 10), "e64_white_b10": (64, 64, 30, "white", 10)}
+
+
+def extreme_yuv(w, h, qp, kind, bd):
+    rng = np.random.default_rng(w * 1000 + h + qp)
+    mx = (1 << bd) - 1
+    if kind == "noise":
+        yuv = rng.integers(0, mx + 1, (1, w * h * 3 // 2))
+    elif kind == "white":
+        yuv = np.full((1, w * h * 3 // 2), mx, np.int64)
+    else:
+        yuv = rt.synth_yuv(w, h, 1, w + h).astype(np.int64) * (4 if bd == 10 else 1)
+    return yuv.astype(np.uint8 if bd == 8 else np.uint16)
+
+
+def gen_rd(tiled=False, ten_bit=False, extreme=False):
     cases = []
     #        name            W    H   frames qp  labels seed
     spec = [("c128_q32_d0", 128, 128, 1, 32, 0, 11), ("c128_q32_d1", 128, 128, 1, 32, 1, 12),
@@ -53,12 +71,18 @@ def gen_rd(tiled=False, ten_bit=False):
         spec = [("x128_q32_r", 128, 128, 1, 32, "rand", 71, (1, 1)), ("x200_q27_r", 200, 136, 1, 27, "rand", 72, (1, 1)),
                 ("x128_q22_d3", 128, 128, 1, 22, 3, 73, (1, 1)), ("x192_q37_r2", 192, 128, 2, 37, "rand", 74, (1, 1)),
                 ("x576_q30_2x3", 576, 192, 1, 30, "rand", 75, (2, 3))]
+    if extreme:
+        spec = [(name, v[0], v[1], 1, v[2], "rand", v[2] + 7 - 100, (1, 1)) for name, v in EXTREME.items()]
     for name, w, h, nf, qp, kind, seed, tiles in spec:
         targs = rt.tile_args(tiles) if tiles != (1, 1) else []
-        yuv = rt.synth_yuv(w, h, nf, seed)
+        if extreme:
+            bd = EXTREME[name][4]
+        yuv = rt.synth_yuv(w, h, nf, seed) if not extreme else None
         if name.startswith("c128_q22"):            # one noisy case: transform skip, escapes, sign hiding
             rng = np.random.default_rng(seed)
             yuv = rng.integers(0, 256, yuv.shape).astype(np.uint8)
+        if extreme:
+            yuv = extreme_yuv(*EXTREME[name])
         if ten_bit:
             rng = np.random.default_rng(seed)
             yuv = yuv.astype(np.uint16) * 4 + rng.integers(0, 4, yuv.shape).astype(np.uint16)
@@ -187,13 +211,15 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "cnn", "weights", "bd"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd"]
     if "rd" in what:
         gen_rd()
     if "rdtiles" in what:
         gen_rd(tiled=True)
     if "rd10" in what:
         gen_rd(ten_bit=True)
+    if "rdx" in what:
+        gen_rd(extreme=True)
     if "cnn" in what or "weights" in what:
         model, sd, src = load_ref_model()
         if "weights" in what:

@@ -45,7 +45,8 @@ def test_oracle_deblock_matches_reference(oracle_built, path):
     pre = prefilter_frames(f)
     out = ref_tools.run_deblock(pre, w, h, qp, recs, bit_depth=bit_depth_of(f))
     ref = deblocked_of(f, out.shape)
-    assert (pre != ref).sum() > 1000                       # the filter does something on every fixture
+    if qp >= 22 and w * h >= 128 * 128:
+        assert (pre != ref).sum() > 1000                   # the filter does something on every ordinary fixture (tc = beta = 0 at QP 0)
     assert np.array_equal(out, ref)
 
 

@@ -280,3 +280,39 @@ def test_c5_eight_k_ten_bit_tiles():
     assert (pps["tile_columns"], pps["tile_rows"]) == (4, 2)
     hdr, _ = hp.parse_slice_header(nals[3][1], sps, pps)
     assert len(hdr["entry_points"]) == 7 and sum(hdr["entry_points"]) < len(nals[3][1]) - hdr["data_byte_pos"]
+
+
+@pytest.mark.parametrize("w,h,qp,kind,bd", [(8, 8, 32, "pattern", 8), (64, 8, 20, "noise", 8), (8, 72, 40, "noise", 8), (136, 72, 0, "noise", 8), (136, 72, 51, "pattern", 8),
+                                            (72, 136, 0, "noise", 10), (200, 72, 51, "noise", 10), (64, 64, 30, "black", 8), (64, 64, 30, "white", 10)])
+def test_extreme_sizes_and_qps_match_oracle(oracle_built, w, h, qp, kind, bd):
+    """Smallest pictures (a single 8x8 CU inside one CTU), one-CU-wide strips, QP 0 (largest levels: escape codes, 16-bit level clipping)
+    and QP 51, constant pictures at both ends of the sample range: records, reconstruction, filters bit-exact against the oracle."""
+    import hevcdl_amd
+    import ref_tools
+    rng = np.random.default_rng(w * 1000 + h + qp)
+    mx = (1 << bd) - 1
+    if kind == "noise":
+        yuv = rng.integers(0, mx + 1, (1, w * h * 3 // 2))
+    elif kind == "black":
+        yuv = np.zeros((1, w * h * 3 // 2), np.int64)
+    elif kind == "white":
+        yuv = np.full((1, w * h * 3 // 2), mx, np.int64)
+    else:
+        yuv = ref_tools.synth_yuv(w, h, 1, w + h).astype(np.int64) * (4 if bd == 10 else 1)
+    yuv = yuv.astype(np.uint8 if bd == 8 else np.uint16)
+    labels = ref_tools.make_labels(w, h, 1, "rand", qp + 7)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1, bit_depth=bd)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    dbk = enc.deblock_frames(recon, recs)
+    sao, final = enc.sao_frames(yuv, dbk)
+    enc.close()
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels, bit_depth=bd)
+    assert_records_equal(recs, o_recs, "oracle %dx%d qp %d" % (w, h, qp))
+    assert np.array_equal(recon, o_recon.reshape(recon.shape))
+    assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
+    o_dbk = ref_tools.run_deblock(o_recon.reshape(1, -1), w, h, qp, np.frombuffer(o_recs.tobytes(), dtype=ref_tools.REC_DTYPE).reshape(1, -1), bit_depth=bd)
+    assert np.array_equal(dbk, o_dbk.reshape(dbk.shape))
+    o_sao, o_final = ref_tools.run_sao(yuv, o_dbk, w, h, qp, bit_depth=bd)
+    assert sao.tobytes() == o_sao.tobytes() and np.array_equal(final, o_final.reshape(final.shape))
+    au = hevcdl_amd.write_access_unit(w, h, qp, 0, recs[0], sao=sao[0], bit_depth=bd)
+    assert len(au) > 60
