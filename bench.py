@@ -185,7 +185,7 @@ def main():
                          "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU},
             "est_bits_per_frame": total_bits / max(1, world * F),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
             nb = min(F, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
         print(json.dumps(out), flush=True)
