@@ -1,8 +1,7 @@
-// deblock_kernel.hip -- HEVC deblocking filter for gfx950 (MI355X), row f-2 of SURVEY.md section 8 (first half: the
-// deblocking stage; SAO is not built).
+// deblock_kernel.hip -- HEVC deblocking filter for gfx950 (MI355X), row f-2 of SURVEY.md section 8 (first half; SAO: sao_kernel.hip).
 //
 // Replaces, for the configuration of the hot path (all-intra => boundary strength 2 on every TU/CU edge, one slice,
-// constant QP, beta/tc offsets 0, no PCM / lossless, 8-bit 4:2:0):
+// constant QP, beta/tc offsets 0, no PCM / lossless, 8- or 10-bit 4:2:0; with tiles the filter crosses tile borders):
 //   TComLoopFilter::loopFilterPic        HM_dl/source/Lib/TLibCommon/TComLoopFilter.cpp:130-156
 //   xDeblockCU / xSetEdgefilterTU / PU   :170-360   (left/top edge of every TU, on the 8x8 grid, not at the picture border)
 //   xEdgeFilterLuma / xEdgeFilterChroma  :557-826

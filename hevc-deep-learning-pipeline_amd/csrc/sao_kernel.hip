@@ -1,7 +1,7 @@
 // sao_kernel.hip -- sample adaptive offset for gfx950 (MI355X): second half of row f-2 of SURVEY.md section 8.
 //
 // Replaces TEncSampleAdaptiveOffset::SAOProcess (HM_dl/source/Lib/TLibEncoder/TEncSampleAdaptiveOffset.cpp:244-273, called at
-// TEncGOP.cpp:1797) for the configuration of the hot path (8-bit 4:2:0, one slice, all-intra => SAO on at picture
+// TEncGOP.cpp:1797) for the configuration of the hot path (8- or 10-bit 4:2:0, one slice, all-intra => SAO on at picture
 // level, SAOLcuBoundary 0, offset step 1):
 //   1. hevcdl_sao_stats_kernel   getStatistics / getBlkStats :295-341, 943-1335     one workgroup per (CTU, component); HBM bound
 //   2. hevcdl_sao_decide_kernel  decideBlkParams / deriveModeNewRDO / deriveModeMergeRDO / deriveOffsets :421-941 with the

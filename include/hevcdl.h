@@ -114,7 +114,7 @@ void          hevcdl_destroy(hevcdl_ctx *ctx);
 const char   *hevcdl_last_error(const hevcdl_ctx *ctx);
 
 /* ---- host-buffer entry points (copy in, run, copy out) ------------------------------------- */
-/* Replaces gen_frames.py + use_model.py: planar 8-bit 4:2:0 frames -> labels[n_frames][ctus][16]
+/* Replaces gen_frames.py + use_model.py: planar 4:2:0 frames (uint8, or uint16 at bit_depth 10) -> labels[n_frames][ctus][16]
  * (clamped to the picture); logits_opt[n_frames][ctus][4][16] may be NULL. */
 hevcdl_status hevcdl_predict_depth(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, uint8_t *labels, float *logits_opt);
 /* Fixture entry: n_ctus RGB CTUs [n][64][64][3] (the tensor the reference feeds ConvNet2) -> raw labels

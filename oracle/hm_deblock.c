@@ -1,7 +1,7 @@
 /* oracle/hm_deblock.c -- TEST INFRASTRUCTURE (CPU oracle), not product code.
  *
  * Plain-C restatement of the reference's deblocking filter for the configuration of the hot path
- * (all-intra, one slice, constant QP, no PCM / lossless, beta/tc offsets 0, 8-bit 4:2:0):
+ * (all-intra, one slice, constant QP, no PCM / lossless, beta/tc offsets 0, 8- or 10-bit 4:2:0):
  *   TComLoopFilter::loopFilterPic            TLibCommon/TComLoopFilter.cpp:130-156  (all vertical edges, then all horizontal)
  *   xDeblockCU                               :170-239  (edges on the 8x8 grid; chroma on its own 8x8 grid)
  *   xSetEdgefilterTU / xSetEdgefilterPU      :274-360  (left/top edge of every TU and CU, not at the picture border)

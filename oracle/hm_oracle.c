@@ -6,7 +6,7 @@
  * (paths relative to /root/reference/HM_dl/source/Lib).  Build: gcc -O2 -ffp-contract=off.
  * Fixed configuration = /root/reference/encoder_intra_main.cfg (CTU 64, 4 depths, TU 4..32,
  * intra TU depth 3, RDOQ, RDOQTS, TransformSkip + Fast, SignHide, StrongIntraSmoothing,
- * FastUDIUseMPM, 8-bit 4:2:0, one slice, no tiles/WPP).
+ * FastUDIUseMPM, 8- or 10-bit 4:2:0, one slice, optionally uniformly spaced tiles, no WPP).
  */
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,7 +1,7 @@
 /* oracle/hm_sao.c -- TEST INFRASTRUCTURE (CPU oracle), not product code.
  *
  * Plain-C restatement of the reference's sample adaptive offset encoder for the configuration of the hot path
- * (8-bit 4:2:0, one slice, all-intra => temporal layer 0 => SAO always enabled at picture level, SAOLcuBoundary 0,
+ * (8- or 10-bit 4:2:0, one slice, all-intra => temporal layer 0 => SAO always enabled at picture level, SAOLcuBoundary 0,
  * TestSAODisableAtPictureLevel 0, offset step log2 0):
  *   statistics          TEncSampleAdaptiveOffset::getStatistics / getBlkStats   TEncSampleAdaptiveOffset.cpp:295-341, 943-1335
  *   offsets             deriveOffsets / estIterOffset / getDistortion           :421-615
