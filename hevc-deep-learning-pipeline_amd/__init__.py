@@ -51,13 +51,39 @@ class Config(ctypes.Structure):
                 ("lambda_", ctypes.c_double), ("sqrt_lambda", ctypes.c_double), ("chroma_weight", ctypes.c_double),
                 ("lambda_chroma", ctypes.c_double), ("err_scale", (ctypes.c_double * 4) * 2),
                 ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32),
-                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
+                ("reserved2", ctypes.c_int32)]
+
+
+def tile_layout(tiles, width, height):
+    """tiles = (columns, rows): uniformly spaced; or ([w0, w1, ...], [h0, h1, ...]): explicit sizes in CTUs of EVERY tile column / row
+    (TileUniformSpacing 0; the last one must take exactly the rest).  -> (columns, rows, uniform, column boundaries, row boundaries)."""
+    cx, cy = (width + 63) // 64, (height + 63) // 64
+    if isinstance(tiles[0], (int, np.integer)):
+        c, r = int(tiles[0]), int(tiles[1])
+        return c, r, 1, [(i * cx) // c for i in range(c + 1)], [(i * cy) // r for i in range(r + 1)]
+    cw, rh = [int(v) for v in tiles[0]], [int(v) for v in tiles[1]]
+    if sum(cw) != cx or sum(rh) != cy:
+        raise ValueError("explicit tile sizes must add up to the picture: %d CTU columns, %d CTU rows" % (cx, cy))
+    return len(cw), len(rh), 0, [sum(cw[:i]) for i in range(len(cw) + 1)], [sum(rh[:i]) for i in range(len(rh) + 1)]
+
+
+def _set_tiles(cfg, tiles, width, height):
+    c, r, uniform, cb, rb = tile_layout(tiles, width, height)
+    cfg.tile_columns, cfg.tile_rows, cfg.tile_uniform_spacing = c, r, uniform
+    for i in range(min(c - 1, 19)):
+        cfg.tile_column_width[i] = cb[i + 1] - cb[i]
+    for i in range(min(r - 1, 21)):
+        cfg.tile_row_height[i] = rb[i + 1] - rb[i]
 
 
 class StreamConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("qp", ctypes.c_int32),
                 ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
-                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32)]
+                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32),
+                ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
+                ("reserved2", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -187,7 +213,7 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
     if st:
         raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
     cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
-    cfg.tile_columns, cfg.tile_rows = int(tiles[0]), int(tiles[1])        # uniformly spaced (columns, rows)
+    _set_tiles(cfg, tiles, width, height)        # (columns, rows) uniformly spaced, or explicit sizes: see tile_layout
     return cfg
 
 
@@ -199,7 +225,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
     if st != 0:
         raise HevcdlError(st, "stream config")
     cfg.level_idc = level_idc
-    cfg.tile_columns, cfg.tile_rows = int(tiles[0]), int(tiles[1])
+    _set_tiles(cfg, tiles, width, height)
     cfg.bit_depth = bit_depth
     sao_ptr = None
     if sao is not None:

@@ -23,6 +23,7 @@ __global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, 
 struct hevcdl_ctx {
   hevcdl_config cfg;
   int ctus_x, ctus_y, ctus;
+  int col_bd[21], row_bd[23];    // tile boundaries in CTUs
   size_t frame_bytes;
   float *d_weights;
   unsigned char *d_scratch;      // RD per-frame workspace
@@ -69,7 +70,7 @@ extern "C" hevcdl_status hevcdl_config_default_bd(hevcdl_config *cfg, int width,
   cfg->width = width; cfg->height = height; cfg->bit_depth = bit_depth; cfg->chroma_format = 420; cfg->qp = qp;
   cfg->ctu_size = 64; cfg->max_partition_depth = 4; cfg->tu_log2_min = 2; cfg->tu_log2_max = 5; cfg->tu_max_depth_intra = 3;
   cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->bn_mode = HEVCDL_BN_REFERENCE; cfg->boundary_policy = HEVCDL_BOUNDARY_CLAMP;
-  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1; cfg->tile_columns = 1; cfg->tile_rows = 1;
+  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1; cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->tile_uniform_spacing = 1;
   // TEncSlice::calculateLambda (TEncSlice.cpp:433-527) for an all-intra GOP of 1, then setUpLambda (:112-140)
   cfg->lambda = 0.57 * 1.0 * pow(2.0, (qp - 12) / 3.0);
   cfg->sqrt_lambda = sqrt(cfg->lambda);                         // TComRdCost::setLambda TComRdCost.cpp:109-122
@@ -129,8 +130,11 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
     return HEVCDL_ERR_UNSUPPORTED;
   { // tiles: uniform spacing, every column at least 4 CTUs wide and every row 1 CTU high (TComPicSym.cpp:380-392), at most 20 x 22 (level 6.2)
     const int cx = (cfg->width + 63) >> 6, cy = (cfg->height + 63) >> 6;
-    if (cfg->tile_columns < 1 || cfg->tile_rows < 1 || cfg->tile_columns > 20 || cfg->tile_rows > 22 || cfg->tile_rows > cy) return HEVCDL_ERR_INVALID_ARG;
-    if (cfg->tile_columns > 1 || cfg->tile_rows > 1) for (int c = 0; c < cfg->tile_columns; c++) if (((c + 1) * cx) / cfg->tile_columns - (c * cx) / cfg->tile_columns < 4) return HEVCDL_ERR_INVALID_ARG;
+    int cb[21], rb[23];
+    if (cfg->tile_columns < 1 || cfg->tile_rows < 1 || cfg->tile_columns > 20 || cfg->tile_rows > 22) return HEVCDL_ERR_INVALID_ARG;
+    const int tiled = cfg->tile_columns > 1 || cfg->tile_rows > 1;
+    if (hevcdl_tile_bounds(cx, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, tiled ? 4 : 1, cb) ||
+        hevcdl_tile_bounds(cy, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, rb)) return HEVCDL_ERR_INVALID_ARG;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return HEVCDL_ERR_NO_DEVICE;
@@ -139,6 +143,8 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   ctx->cfg = *cfg; ctx->err[0] = 0; ctx->profile = false;
   ctx->ctus_x = (cfg->width + 63) >> 6; ctx->ctus_y = (cfg->height + 63) >> 6; ctx->ctus = ctx->ctus_x * ctx->ctus_y;
   ctx->frame_bytes = hevcdl_frame_bytes_bd(cfg->width, cfg->height, cfg->bit_depth);
+  hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
+  hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
   ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
   hipError_t e;
@@ -223,6 +229,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   p.stats = (unsigned char *)d_stats; p.scratch = d_scratch ? (unsigned char *)d_scratch : ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_y = ctx->ctus_y; p.n_frames = n_frames;
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
+  memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);
   p.tile_begin = tile_begin; p.tile_count = tile_count < 0 ? p.tile_cols * p.tile_rows : tile_count;
   if (d_stats) HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(hevcdl_frame_stats) * (size_t)n_frames, s));     // the tile waves of a frame add into its entry
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
@@ -407,6 +414,7 @@ extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_or
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames; p.qp = ctx->cfg.qp;
   p.lambda = ctx->cfg.lambda; p.lambda_chroma = ctx->cfg.lambda_chroma;          // slice lambdas per component, TEncSlice.cpp:112-140
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows; p.bit_depth = ctx->cfg.bit_depth;
+  memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);
   hevcdl_launch_sao(&p, stream);
   HIPCHK(hipGetLastError());
   return HEVCDL_OK;

@@ -56,8 +56,8 @@ const Key KEYS[] = {
   { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
   { "FEN", 0, NOEFFECT, 0 }, { "FDM", 0, NOEFFECT, 0 }, { "AMP", 0, NOEFFECT, 0 }, { "MaxCuDQPDepth", 0, NOEFFECT, 0 }, { "SliceArgument", 0, NOEFFECT, 0 },
   { "PCMLog2MaxSize", 0, NOEFFECT, 0 }, { "PCMLog2MinSize", 0, NOEFFECT, 0 }, { "PCMInputBitDepthFlag", 0, NOEFFECT, 0 },
-  { "PCMFilterDisableFlag", 0, NOEFFECT, 0 }, { "TileUniformSpacing", 0, USED, 0 }, { "TileColumnWidthArray", 0, NOEFFECT, 0 },
-  { "TileRowHeightArray", 0, NOEFFECT, 0 }, { "ScalingListFile", 0, NOEFFECT, 0 },
+  { "PCMFilterDisableFlag", 0, NOEFFECT, 0 }, { "TileUniformSpacing", 0, USED, 0 }, { "TileColumnWidthArray", 0, USED, 0 },
+  { "TileRowHeightArray", 0, USED, 0 }, { "ScalingListFile", 0, NOEFFECT, 0 },
 };
 
 const Key *find_key(const std::string &name, bool shortform)
@@ -162,8 +162,15 @@ int main(int argc, char **argv)
   if (hash_sei != 0 && hash_sei != 1) opt.errors.push_back("SEIDecodedPictureHash = " + std::to_string(hash_sei) + " is not implemented by this path (only 0 and 1 = MD5)");
   // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows; the in-loop filters cross tile borders (LFCrossTileBoundaryFlag 1, the default)
   const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
+  const int tile_uniform = (int)opt.geti("TileUniformSpacing", 0) != 0;
+  std::vector<int> tile_cw, tile_rh;               // TileColumnWidthArray / TileRowHeightArray: sizes in CTUs of all but the last column / row
+  auto parse_ints = [](const std::string &text, std::vector<int> &out) { std::string t = text; for (char &ch : t) if (ch == ',') ch = ' '; std::istringstream is(t); int v; while (is >> v) out.push_back(v); };
   if (tile_cols * tile_rows > 1) {
-    if (opt.geti("TileUniformSpacing", 0) != 1) opt.errors.push_back("tiles are implemented with TileUniformSpacing = 1 only");
+    if (!tile_uniform) {
+      parse_ints(opt.get("TileColumnWidthArray"), tile_cw); parse_ints(opt.get("TileRowHeightArray"), tile_rh);
+      if ((int)tile_cw.size() < tile_cols - 1 || (int)tile_rh.size() < tile_rows - 1 || tile_cols > 20 || tile_rows > 22)
+        opt.errors.push_back("TileUniformSpacing = 0 needs TileColumnWidthArray / TileRowHeightArray with a size for every tile column / row but the last");
+    }
     if (opt.geti("LFCrossTileBoundaryFlag", 1) != 1) opt.errors.push_back("tiles are implemented with LFCrossTileBoundaryFlag = 1 only");
   }
   if (opt.v.count("PrintConfig")) {
@@ -199,6 +206,10 @@ int main(int argc, char **argv)
   if (st != HEVCDL_OK) { fprintf(stderr, "Error: unsupported picture size / QP (status %d)\n", (int)st); return 2; }
   cfg.max_frames = batch; cfg.device = (int)opt.geti("Device", 0);
   cfg.tile_columns = tile_cols; cfg.tile_rows = tile_rows;
+  if (tile_cols * tile_rows > 1) {
+    cfg.tile_uniform_spacing = tile_uniform;
+    if (!tile_uniform) { for (int i = 0; i < tile_cols - 1; i++) cfg.tile_column_width[i] = tile_cw[i]; for (int i = 0; i < tile_rows - 1; i++) cfg.tile_row_height[i] = tile_rh[i]; }
+  }
   cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
   std::string wpath = opt.get("Weights");
   if (wpath.empty()) { // next to the library: <pkg>/weights/hevc_encoder_model.f32, this binary lives in <pkg>/bin
@@ -234,6 +245,7 @@ int main(int argc, char **argv)
   if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
+  scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
   std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <vector>
 #include "hevcdl.h"
+#include "hevcdl_dev.h"
 
 namespace {
 
@@ -505,7 +506,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
-  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8;
+  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1;
   return HEVCDL_OK;
 }
 
@@ -554,8 +555,11 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   const int bd = cfg->bit_depth;
   if (bd != 8 && bd != 10) return HEVCDL_ERR_UNSUPPORTED;
   const int tcols = cfg->tile_columns, trows = cfg->tile_rows, tiled = tcols * trows > 1;
-  if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22 || trows > ((cfg->height + 63) >> 6)) return HEVCDL_ERR_INVALID_ARG;
-  if (tiled) for (int c = 0; c < tcols; c++) if (((c + 1) * ((cfg->width + 63) >> 6)) / tcols - (c * ((cfg->width + 63) >> 6)) / tcols < 4) return HEVCDL_ERR_INVALID_ARG;   // TComPicSym.cpp:388
+  if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22) return HEVCDL_ERR_INVALID_ARG;
+  int col_bd[21], row_bd[23];
+  const int uniform = cfg->tile_uniform_spacing != 0;
+  if (hevcdl_tile_bounds((cfg->width + 63) >> 6, tcols, uniform, cfg->tile_column_width, tiled ? 4 : 1, col_bd) ||      // TComPicSym.cpp:380-392
+      hevcdl_tile_bounds((cfg->height + 63) >> 6, trows, uniform, cfg->tile_row_height, 1, row_bd)) return HEVCDL_ERR_INVALID_ARG;
   std::vector<uint8_t> au;
   { // VPS  TEncCavlc.cpp:677-753
     BitOut w;
@@ -589,7 +593,14 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     w.se(0); w.flag(0); w.flag(1); w.flag(0);        // init_qp_minus26 0, constrained intra, transform skip, cu_qp_delta
     w.se(0); w.se(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0);      // chroma qp offsets, slice chroma offsets present, weighted (bi)pred, transquant bypass
     w.flag(tiled); w.flag(0);                        // tiles_enabled_flag, entropy_coding_sync_enabled_flag
-    if (tiled) { w.ue((uint32_t)tcols - 1); w.ue((uint32_t)trows - 1); w.flag(1); w.flag(1); }   // uniform_spacing_flag, loop_filter_across_tiles_enabled_flag (:228-246)
+    if (tiled) { // :228-246
+      w.ue((uint32_t)tcols - 1); w.ue((uint32_t)trows - 1); w.flag(uniform);
+      if (!uniform) {
+        for (int i = 0; i < tcols - 1; i++) w.ue((uint32_t)(col_bd[i + 1] - col_bd[i]) - 1);    // column_width_minus1
+        for (int i = 0; i < trows - 1; i++) w.ue((uint32_t)(row_bd[i + 1] - row_bd[i]) - 1);    // row_height_minus1
+      }
+      w.flag(1);                                     // loop_filter_across_tiles_enabled_flag
+    }
     w.flag(1); w.flag(0);                            // loop filter across slices, deblocking_filter_control_present
     w.flag(0); w.flag(0); w.ue(0); w.flag(0); w.flag(0);
     w.trailing();
@@ -610,7 +621,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     const int ctus_y = (cfg->height + 63) >> 6, ctus = pic.ctus_x * ctus_y;
     std::vector<BitOut> sub((size_t)tcols * trows);
     for (int tr = 0; tr < trows; tr++) for (int tc = 0; tc < tcols; tc++) {
-      const int cx0 = (tc * pic.ctus_x) / tcols, cx1 = ((tc + 1) * pic.ctus_x) / tcols, cy0 = (tr * ctus_y) / trows, cy1 = ((tr + 1) * ctus_y) / trows;
+      const int cx0 = col_bd[tc], cx1 = col_bd[tc + 1], cy0 = row_bd[tr], cy1 = row_bd[tr + 1];
       BitOut &sw = sub[(size_t)tr * tcols + tc];
       Cabac c(sw, cfg->qp);
       pic.tx0 = cx0 * 64; pic.ty0 = cy0 * 64;

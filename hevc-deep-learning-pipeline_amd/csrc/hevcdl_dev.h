@@ -48,7 +48,8 @@ struct hevcdl_rd_params {
   unsigned char *cabac_out;        // [frame] coder state after the last CTU processed, or NULL
   int ctu_begin, ctu_end;          // CTU address range [begin, end) in coding order
   int width, height, ctus_x, ctus_y, n_frames, debug;
-  int tile_cols, tile_rows;        // uniformly spaced tiles (1 x 1: none); one wave per (frame, tile)
+  int tile_cols, tile_rows;        // tiles (1 x 1: none); one wave per (frame, tile)
+  int col_bd[21], row_bd[23];      // tile boundaries in CTUs (hevcdl_tile_bounds)
   int tile_begin, tile_count;      // tiles of every frame this launch covers (raster order of tiles)
   hevcdl_rd_consts k;
 };
@@ -72,9 +73,25 @@ struct hevcdl_sao_params {
   unsigned char *recon_params;     // [frame][ctu] hevcdl_sao_blk: merge candidates resolved
   int width, height, ctus_x, ctus_per_frame, n_frames, qp;
   int tile_cols, tile_rows;        // merge candidates stay inside a tile
+  int col_bd[21], row_bd[23];      // tile boundaries in CTUs
   int bit_depth;                   // 8: planes of uint8; 10: planes of uint16 (offset range 31, band = sample >> 5, distortion >> 4)
   double lambda, lambda_chroma;
 };
+
+// Tile boundaries in CTUs: bd[0] = 0 < bd[1] < ... < bd[n_tiles] = n_ctus.  Uniform spacing as TComPicSym.cpp xInitTiles; explicit sizes
+// name every tile but the last (which takes the rest).  min_size: smallest tile the reference accepts (4 CTU columns, 1 CTU row,
+// TComPicSym.cpp:380-392) when there is more than one tile in that direction.  Returns 0 when the layout is valid.
+static inline int hevcdl_tile_bounds(int n_ctus, int n_tiles, int uniform, const int32_t *sizes, int min_size, int *bd)
+{
+  if (n_tiles < 1 || n_tiles > n_ctus) return -1;
+  bd[0] = 0;
+  for (int t = 0; t < n_tiles; t++) {
+    if (uniform) bd[t + 1] = ((t + 1) * n_ctus) / n_tiles;
+    else bd[t + 1] = (t == n_tiles - 1) ? n_ctus : bd[t] + sizes[t];
+    if (bd[t + 1] - bd[t] < 1 || (n_tiles > 1 && bd[t + 1] - bd[t] < min_size)) return -1;
+  }
+  return bd[n_tiles] == n_ctus ? 0 : -1;
+}
 
 #ifdef __cplusplus
 extern "C" {

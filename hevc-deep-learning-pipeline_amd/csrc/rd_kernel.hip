@@ -2204,10 +2204,10 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   }
   wsync();
 
-  // uniform tile spacing (TComPicSym.cpp xInitTiles); CTUs of the tile in raster order.  Without tiles the caller may give a CTU range.
+  // tile rectangle from the host's boundary tables (TComPicSym.cpp xInitTiles); CTUs of the tile in raster order.  Without tiles the
+  // caller may give a CTU range.
   const int tcx = tile % p.tile_cols, tcy = tile / p.tile_cols;
-  const int cx0 = (tcx * p.ctus_x) / p.tile_cols, cx1 = ((tcx + 1) * p.ctus_x) / p.tile_cols;
-  const int cy0 = (tcy * p.ctus_y) / p.tile_rows, cy1 = ((tcy + 1) * p.ctus_y) / p.tile_rows;
+  const int cx0 = p.col_bd[tcx], cx1 = p.col_bd[tcx + 1], cy0 = p.row_bd[tcy], cy1 = p.row_bd[tcy + 1];
   const int tw = cx1 - cx0;
   k.tx0 = cx0 * 64; k.ty0 = cy0 * 64; k.tx1 = cx1 * 64; k.ty1 = cy1 * 64;
   const int i_begin = ntiles == 1 ? p.ctu_begin : 0, i_end = ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0);

@@ -327,10 +327,10 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
   next = go;
   for (int a = 0; a < nctu; a++) {
     const Stat GLB *st = stats + (size_t)a * 3 * NTYPES;
-    // merge candidates come from the same tile only (TComPic::getSAOMergeAvailability); uniform tile spacing
+    // merge candidates come from the same tile only (TComPic::getSAOMergeAvailability)
     bool left_av = true, above_av = true;
-    for (int t = 0; t < p.tile_cols; t++) if ((t * cx) / p.tile_cols == a % cx) left_av = false;
-    for (int t = 0; t < p.tile_rows; t++) if ((t * (nctu / cx)) / p.tile_rows == a / cx) above_av = false;
+    for (int t = 0; t < p.tile_cols; t++) if (p.col_bd[t] == a % cx) left_av = false;
+    for (int t = 0; t < p.tile_rows; t++) if (p.row_bd[t] == a / cx) above_av = false;
     hevcdl_sao_blk best, mode;
     double min_cost = MAX_DOUBLE;
     cur = go;

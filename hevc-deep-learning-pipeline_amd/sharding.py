@@ -37,13 +37,11 @@ def shard_tiles(n_tiles, world, rank):
 
 
 def tile_grid(width, height, tiles):
-    """Uniformly spaced tiles (TComPicSym.cpp xInitTiles) -> list of (cx0, cy0, cx1, cy1) in CTUs, raster order of tiles."""
-    cx, cy = (width + 63) // 64, (height + 63) // 64
-    out = []
-    for tr in range(tiles[1]):
-        for tc in range(tiles[0]):
-            out.append(((tc * cx) // tiles[0], (tr * cy) // tiles[1], ((tc + 1) * cx) // tiles[0], ((tr + 1) * cy) // tiles[1]))
-    return out
+    """Tiles ((columns, rows) uniformly spaced, or explicit sizes: hevcdl_amd.tile_layout) -> list of (cx0, cy0, cx1, cy1) in CTUs,
+    raster order of tiles."""
+    from . import tile_layout
+    c, r, _, cb, rb = tile_layout(tiles, width, height)
+    return [(cb[tc], rb[tr], cb[tc + 1], rb[tr + 1]) for tr in range(r) for tc in range(c)]
 
 
 def _planes(frames, width, height, bps=1):

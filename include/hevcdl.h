@@ -74,6 +74,11 @@ typedef struct hevcdl_config {
    * units of the decision path: one wavefront per (frame, tile). */
   int32_t  tile_columns, tile_rows;
   int32_t  reserved;
+  /* TileUniformSpacing 0: explicit sizes in CTUs of every tile column / row but the last (TileColumnWidthArray, TileRowHeightArray,
+   * TAppEncCfg.cpp:1026-1028); ignored when tile_uniform_spacing != 0 (the default) */
+  int32_t  tile_uniform_spacing;
+  int32_t  tile_column_width[19], tile_row_height[21];
+  int32_t  reserved2;
 } hevcdl_config;
 
 /* One CTU of decisions: what compressCtu leaves in the picture's CTU record (TEncCu.cpp:1091 copyToPic).
@@ -164,6 +169,9 @@ typedef struct hevcdl_stream_config {
   int32_t  tile_columns, tile_rows; /* as in hevcdl_config: PPS tile syntax (loop_filter_across_tiles_enabled_flag 1), CTUs in tile scan,
                                        one sub-stream per tile with entry points in the slice header */
   int32_t  bit_depth;            /* 8 (Profile main) or 10 (Profile main10): profile_tier_level, SPS bit depths, SAO offset range */
+  int32_t  tile_uniform_spacing; /* as in the hevcdl_config field, default 1; 0: column_width_minus1 / row_height_minus1 are written */
+  int32_t  tile_column_width[19], tile_row_height[21];
+  int32_t  reserved2;
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
 size_t        hevcdl_access_unit_bound(int width, int height);

@@ -62,7 +62,9 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
         # tiles (columns, rows), uniformly spaced; the reference needs tiles at least 4 CTUs wide.  520x136 has a ragged right/bottom
         # edge and uneven columns (4 + 5 CTUs)
         spec = [("t512_q32_2x2", 512, 128, 1, 32, "rand", 31, (2, 2)), ("t576_q27_2x3", 576, 192, 1, 27, "rand", 32, (2, 3)),
-                ("t520_q37_2x2", 520, 136, 2, 37, "rand", 33, (2, 2)), ("t832_q32_3x1", 832, 128, 1, 32, "rand", 34, (3, 1))]
+                ("t520_q37_2x2", 520, 136, 2, 37, "rand", 33, (2, 2)), ("t832_q32_3x1", 832, 128, 1, 32, "rand", 34, (3, 1)),
+                # TileUniformSpacing 0 with explicit sizes (all columns / rows listed; the reference is given all but the last)
+                ("n832_q32_544x12", 832, 192, 1, 32, "rand", 91, ([5, 4, 4], [1, 2])), ("n712_q27_b10", 712, 136, 1, 27, "rand", 92, ([7, 5], [2, 1]))]
     bd = 8
     if ten_bit:
         # InputBitDepth = InternalBitDepth = 10, Profile main10; samples = the 8-bit pattern * 4 + 2 bits of noise;
@@ -75,6 +77,8 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
         spec = [(name, v[0], v[1], 1, v[2], "rand", v[2] + 7 - 100, (1, 1)) for name, v in EXTREME.items()]
     for name, w, h, nf, qp, kind, seed, tiles in spec:
         targs = rt.tile_args(tiles) if tiles != (1, 1) else []
+        if name == "n712_q27_b10":
+            bd, ten_bit = 10, True
         if extreme:
             bd = EXTREME[name][4]
         yuv = rt.synth_yuv(w, h, nf, seed) if not extreme else None
@@ -98,7 +102,8 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
         nctu = lab.shape[1]
         assert len(dump) == nf * nctu
         summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
-        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, tiles=np.array(tiles), bit_depth=bd,
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd,
+                            **({"tiles": np.array(tiles)} if isinstance(tiles[0], int) else {"tiles": np.array([len(tiles[0]), len(tiles[1])]), "tile_col_sizes": np.array(tiles[0]), "tile_row_sizes": np.array(tiles[1])}),
                             records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
                             rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
                             bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),

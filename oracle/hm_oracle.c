@@ -1556,6 +1556,18 @@ int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int
 int hm_oracle_encode_frames_ex(const void *yuv_, int width, int height, int n_frames, int qp,
                                const uint8_t *labels, hm_ctu_record *out_recs, void *recon_,
                                hm_frame_stats *stats, int tile_cols, int tile_rows, int bit_depth)
+{ /* uniform spacing, TComPicSym.cpp:220-260 */
+  int col_bd[64], row_bd[64], t;
+  const int cx = (width + 63) >> 6, cy = (height + 63) >> 6;
+  if (tile_cols < 1 || tile_rows < 1 || tile_cols > 20 || tile_rows > 22) return -1;
+  for (t = 0; t <= tile_cols; t++) col_bd[t] = (t * cx) / tile_cols;
+  for (t = 0; t <= tile_rows; t++) row_bd[t] = (t * cy) / tile_rows;
+  return hm_oracle_encode_frames_tb(yuv_, width, height, n_frames, qp, labels, out_recs, recon_, stats, tile_cols, tile_rows, col_bd, row_bd, bit_depth);
+}
+
+int hm_oracle_encode_frames_tb(const void *yuv_, int width, int height, int n_frames, int qp,
+                               const uint8_t *labels, hm_ctu_record *out_recs, void *recon_,
+                               hm_frame_stats *stats, int tile_cols, int tile_rows, const int *col_bd, const int *row_bd, int bit_depth)
 {
   const uint8_t *yuv = (const uint8_t *)yuv_; uint8_t *recon = (uint8_t *)recon_;
   const int wide = bit_depth > 8;                /* samples are uint16 (little endian) */
@@ -1595,11 +1607,10 @@ int hm_oracle_encode_frames_ex(const void *yuv_, int width, int height, int n_fr
     for (int c = 0; c < 3; c++) memset(e->rec[c], 0, sizeof(pel) * (c ? csz : ysz));
     e->labels = labels + (size_t)f * nctu * 16;
     e->est_bits = 0;
-    /* CTUs in tile scan (tiles in raster order, CTUs in raster order inside a tile; uniform spacing TComPicSym.cpp:220-260);
+    /* CTUs in tile scan (tiles in raster order, CTUs in raster order inside a tile; boundaries from the caller);
        the coder is re-initialised at the first CTU of every tile (TEncSlice.cpp:719-720, 804-807) */
     for (int tr = 0; tr < tile_rows; tr++) for (int tc = 0; tc < tile_cols; tc++) {
-      const int cx0 = (tc * e->ctus_x) / tile_cols, cx1 = ((tc + 1) * e->ctus_x) / tile_cols;
-      const int cy0 = (tr * e->ctus_y) / tile_rows, cy1 = ((tr + 1) * e->ctus_y) / tile_rows;
+      const int cx0 = col_bd[tc], cx1 = col_bd[tc + 1], cy0 = row_bd[tr], cy1 = row_bd[tr + 1];
       e->tx0 = cx0 * 64; e->ty0 = cy0 * 64; e->tx1 = cx1 * 64; e->ty1 = cy1 * 64;
       cabac_t truec; cabac_init(&truec, qp);
       for (int cy = cy0; cy < cy1; cy++) for (int cx = cx0; cx < cx1; cx++) {

@@ -45,6 +45,10 @@ int hm_oracle_encode_frames_tiles(const uint8_t *yuv, int width, int height, int
 int hm_oracle_encode_frames_ex(const void *yuv, int width, int height, int n_frames, int qp,
                                const uint8_t *labels, hm_ctu_record *out_recs, void *recon,
                                hm_frame_stats *stats, int tile_cols, int tile_rows, int bit_depth);
+/* explicit tile boundaries in CTUs: col_bd[0] = 0 < ... < col_bd[tile_cols] = CTU columns (TileUniformSpacing 0 with width / height arrays) */
+int hm_oracle_encode_frames_tb(const void *yuv, int width, int height, int n_frames, int qp,
+                               const uint8_t *labels, hm_ctu_record *out_recs, void *recon,
+                               hm_frame_stats *stats, int tile_cols, int tile_rows, const int *col_bd, const int *row_bd, int bit_depth);
 
 /* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
 int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);
@@ -58,6 +62,7 @@ typedef struct { hm_sao_offset c[3]; } hm_sao_blk;
 int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out);
 /* uint16 sample planes, bit_depth 8 or 10 (offset range 7 / 31, band shift bit_depth - 5, distortion at 8-bit scale) */
 int hm_oracle_sao_frame16(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, int bit_depth);
+int hm_oracle_sao_frame16_tb(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, const int *col_bd, const int *row_bd, int bit_depth);
 int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out, int tile_cols, int tile_rows);
 
 /* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */

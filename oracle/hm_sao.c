@@ -266,11 +266,11 @@ int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width,
   return hm_oracle_sao_frame_tiles(org, deblocked, width, height, qp, params, out, 1, 1);
 }
 
-/* first CTU column / row of a uniformly spaced tile (TComPicSym.cpp xInitTiles) */
-static int tile_start(int pos, int n_ctus, int n_tiles)
+/* first CTU column / row of a tile */
+static int tile_start(int pos, const int *bd, int n_tiles)
 {
   int t;
-  for (t = 0; t < n_tiles; t++) if ((t * n_ctus) / n_tiles == pos) return 1;
+  for (t = 0; t < n_tiles; t++) if (bd[t] == pos) return 1;
   return 0;
 }
 
@@ -290,6 +290,15 @@ int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int 
 }
 
 int hm_oracle_sao_frame16(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, int bit_depth)
+{ /* uniform spacing */
+  int col_bd[64], row_bd[64], t;
+  if (tile_cols < 1 || tile_rows < 1 || tile_cols > 20 || tile_rows > 22) return -1;
+  for (t = 0; t <= tile_cols; t++) col_bd[t] = (t * ((width + 63) >> 6)) / tile_cols;
+  for (t = 0; t <= tile_rows; t++) row_bd[t] = (t * ((height + 63) >> 6)) / tile_rows;
+  return hm_oracle_sao_frame16_tb(org, deblocked, width, height, qp, params, out, tile_cols, tile_rows, col_bd, row_bd, bit_depth);
+}
+
+int hm_oracle_sao_frame16_tb(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, const int *col_bd, const int *row_bd, int bit_depth)
 {
   const int cx = (width + 63) >> 6, cy = (height + 63) >> 6, nctu = cx * cy, cw = width >> 1, ch = height >> 1;
   const size_t ysz = (size_t)width * height, csz = (size_t)cw * ch;
@@ -336,8 +345,8 @@ int hm_oracle_sao_frame16(const uint16_t *org, const uint16_t *deblocked, int wi
     cur = go;
     /* merge candidates come from the same tile only (TComPic::getSAOMergeAvailability; statistics and offsets do cross tiles:
        LFCrossTileBoundaryFlag 1) */
-    if (!tile_start(a % cx, cx, tile_cols)) ml[MERGE_LEFT] = &recon[a - 1];
-    if (!tile_start(a / cx, cy, tile_rows)) ml[MERGE_ABOVE] = &recon[a - cx];
+    if (!tile_start(a % cx, col_bd, tile_cols)) ml[MERGE_LEFT] = &recon[a - 1];
+    if (!tile_start(a / cx, row_bd, tile_rows)) ml[MERGE_ABOVE] = &recon[a - cx];
     mode_new((const stat_t (*)[NTYPES])st[a], lambda, ml, &mode, &cost, &cur, &go);
     if (cost < min_cost) { min_cost = cost; params[a] = mode; next = go; }
     mode_merge((const stat_t (*)[NTYPES])st[a], lambda, ml, &mode, &cost, &cur, &go);

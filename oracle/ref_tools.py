@@ -184,8 +184,23 @@ def oracle_lib():
 
 
 def tile_args(tiles):
-    """Reference command-line switches for tiles = (columns, rows), uniformly spaced."""
-    return ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (tiles[0] - 1), "--NumTileRowsMinus1=%d" % (tiles[1] - 1)]
+    """Reference command-line switches for tiles = (columns, rows) uniformly spaced, or ([widths], [heights]) in CTUs (all of them)."""
+    if isinstance(tiles[0], (int, np.integer)):
+        return ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (tiles[0] - 1), "--NumTileRowsMinus1=%d" % (tiles[1] - 1)]
+    return ["--TileUniformSpacing=0", "--NumTileColumnsMinus1=%d" % (len(tiles[0]) - 1), "--NumTileRowsMinus1=%d" % (len(tiles[1]) - 1),
+            "--TileColumnWidthArray=" + " ".join(str(int(v)) for v in tiles[0][:-1]), "--TileRowHeightArray=" + " ".join(str(int(v)) for v in tiles[1][:-1])]
+
+
+def tile_bounds(tiles, width, height):
+    """(columns, rows, int32 column boundaries, int32 row boundaries) in CTUs for either form of `tiles`."""
+    cx, cy = (width + 63) // 64, (height + 63) // 64
+    if isinstance(tiles[0], (int, np.integer)):
+        c, r = int(tiles[0]), int(tiles[1])
+        cb, rb = [(i * cx) // c for i in range(c + 1)], [(i * cy) // r for i in range(r + 1)]
+    else:
+        c, r = len(tiles[0]), len(tiles[1])
+        cb, rb = [int(sum(tiles[0][:i])) for i in range(c + 1)], [int(sum(tiles[1][:i])) for i in range(r + 1)]
+    return c, r, np.array(cb, np.int32), np.array(rb, np.int32)
 
 
 def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bit_depth=8):
@@ -198,11 +213,12 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     recon = np.zeros_like(yuv)
     stats = np.zeros(n_frames, STATS_DTYPE)
     lib.hm_oracle_set_trace(trace_path.encode() if trace_path else None)
-    lib.hm_oracle_encode_frames_ex.restype = ctypes.c_int
-    lib.hm_oracle_encode_frames_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-    rc = lib.hm_oracle_encode_frames_ex(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
-                                        recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tiles[0], tiles[1], bit_depth)
+    lib.hm_oracle_encode_frames_tb.restype = ctypes.c_int
+    lib.hm_oracle_encode_frames_tb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    tc, tr, cb, rb = tile_bounds(tiles, width, height)
+    rc = lib.hm_oracle_encode_frames_tb(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
+                                        recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tc, tr, cb.ctypes.data, rb.ctypes.data, bit_depth)
     lib.hm_oracle_set_trace(None)
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
@@ -238,30 +254,22 @@ SAO_DTYPE = np.dtype([("mode", "<i4"), ("type", "<i4"), ("aux", "<i4"), ("offset
 def run_sao(org, deblocked, width, height, qp, tiles=(1, 1), bit_depth=8):
     """Oracle SAO of frames [n][w*h*3/2] -> (params [n][ctus][3] SAO_DTYPE, final reconstruction)."""
     lib = oracle_lib()
-    if bit_depth != 8:
-        lib.hm_oracle_sao_frame16.restype = ctypes.c_int
-        lib.hm_oracle_sao_frame16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        org = np.ascontiguousarray(org, np.uint16).reshape(-1, width * height * 3 // 2)
-        dbk = np.ascontiguousarray(deblocked, np.uint16).reshape(org.shape)
-        nctu = ((width + 63) // 64) * ((height + 63) // 64)
-        params = np.zeros((org.shape[0], nctu, 3), SAO_DTYPE)
-        out = np.zeros_like(org)
-        for f in range(org.shape[0]):
-            if lib.hm_oracle_sao_frame16(org[f].ctypes.data, dbk[f].ctypes.data, width, height, qp, params[f].ctypes.data, out[f].ctypes.data, tiles[0], tiles[1], bit_depth) != 0:
-                raise RuntimeError("oracle sao failed")
-        return params, out
-    lib.hm_oracle_sao_frame_tiles.restype = ctypes.c_int
-    lib.hm_oracle_sao_frame_tiles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    org = np.ascontiguousarray(org, np.uint8).reshape(-1, width * height * 3 // 2)
-    dbk = np.ascontiguousarray(deblocked, np.uint8).reshape(org.shape)
+    lib.hm_oracle_sao_frame16_tb.restype = ctypes.c_int
+    lib.hm_oracle_sao_frame16_tb.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    dt = np.uint8 if bit_depth == 8 else np.uint16
+    org16 = np.ascontiguousarray(np.asarray(org, dt).reshape(-1, width * height * 3 // 2), np.uint16)
+    dbk16 = np.ascontiguousarray(np.asarray(deblocked, dt).reshape(org16.shape), np.uint16)
     nctu = ((width + 63) // 64) * ((height + 63) // 64)
-    params = np.zeros((org.shape[0], nctu, 3), SAO_DTYPE)
-    out = np.zeros_like(org)
-    for f in range(org.shape[0]):
-        rc = lib.hm_oracle_sao_frame_tiles(org[f].ctypes.data, dbk[f].ctypes.data, width, height, qp, params[f].ctypes.data, out[f].ctypes.data, tiles[0], tiles[1])
+    params = np.zeros((org16.shape[0], nctu, 3), SAO_DTYPE)
+    out = np.zeros_like(org16)
+    tc, tr, cb, rb = tile_bounds(tiles, width, height)
+    for f in range(org16.shape[0]):
+        rc = lib.hm_oracle_sao_frame16_tb(org16[f].ctypes.data, dbk16[f].ctypes.data, width, height, qp, params[f].ctypes.data, out[f].ctypes.data,
+                                          tc, tr, cb.ctypes.data, rb.ctypes.data, bit_depth)
         if rc != 0:
             raise RuntimeError("oracle sao failed rc=%d" % rc)
-    return params, out
+    return params, out.astype(dt)
 
 
 def ctu_recon_from_frame(recon_frame, width, height, addr):

@@ -21,6 +21,14 @@ def pytest_configure(config):
         pass
 
 
+def fixture_tiles(f):
+    """Tile layout of a golden fixture: (1, 1) for the untiled runs, (columns, rows) for the uniformly spaced ones (rd_t*), explicit CTU
+    sizes ([widths], [heights]) for the runs with TileUniformSpacing 0 (rd_n*)."""
+    if "tile_col_sizes" in f.files:
+        return [int(v) for v in f["tile_col_sizes"]], [int(v) for v in f["tile_row_sizes"]]
+    return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)
+
+
 @pytest.fixture(scope="session")
 def oracle_built():
     """Compile the plain-C oracle (test infrastructure) once per session."""

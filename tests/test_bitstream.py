@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD
+from conftest import GOLD, fixture_tiles
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -15,7 +15,7 @@ REF_DEC = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder_ref")
 
 
 def tiles_of(f):
-    return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)      # rd_t*: reference runs with tiles enabled
+    return fixture_tiles(f)
 
 
 def stream_of(f):

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD
+from conftest import GOLD, fixture_tiles
 
 FIELDS = ["depth", "part_size", "luma_dir", "chroma_dir", "tr_idx", "cbf", "tskip", "bits", "dist", "cost", "coeff_y", "coeff_cb", "coeff_cr"]
 
@@ -16,7 +16,7 @@ def test_rd_oracle_matches_reference_records(oracle_built, path):
     import ref_tools
     f = np.load(path)
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
-    tiles = tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)     # rd_t*: the reference run with tiles enabled
+    tiles = fixture_tiles(f)                                                        # rd_t* / rd_n*: reference runs with tiles enabled
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
     recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles, bit_depth=bd)
     for k in FIELDS:

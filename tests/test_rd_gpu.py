@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD
+from conftest import GOLD, fixture_tiles
 
 pytestmark = pytest.mark.gpu
 FIELDS = ["depth", "part_size", "luma_dir", "chroma_dir", "tr_idx", "cbf", "tskip", "bits", "dist", "cost", "coeff_y", "coeff_cb", "coeff_cr"]
@@ -31,7 +31,7 @@ def test_golden_records_bit_exact(path):
     f = np.load(path)
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     yuv, labels, ref = f["yuv"], f["labels"], f["records"]
-    tiles = tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)     # rd_t*: reference runs with tiles enabled
+    tiles = fixture_tiles(f)                                                        # rd_t* / rd_n*: reference runs with tiles enabled
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
     enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd)
     recs, recon, stats = enc.compress_frames(yuv, labels)
@@ -59,7 +59,8 @@ def test_matches_oracle_on_seeded_inputs(oracle_built, w, h, qp, nf, seed):
     assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
 
 
-@pytest.mark.parametrize("w,h,qp,nf,seed,tiles", [(768, 192, 32, 2, 44, (3, 2)), (520, 200, 25, 1, 45, (2, 4)), (1280, 64, 36, 1, 46, (5, 1))])
+@pytest.mark.parametrize("w,h,qp,nf,seed,tiles", [(768, 192, 32, 2, 44, (3, 2)), (520, 200, 25, 1, 45, (2, 4)), (1280, 64, 36, 1, 46, (5, 1)),
+                                                  (1280, 200, 29, 1, 47, ([4, 6, 10], [1, 3]))])        # last: TileUniformSpacing 0, explicit CTU sizes
 def test_tiles_match_oracle(oracle_built, w, h, qp, nf, seed, tiles):
     """Tiles (uniform spacing): one wave per (frame, tile); records, reconstruction and the per-frame sums equal the oracle's tile run."""
     import hevcdl_amd
@@ -75,6 +76,10 @@ def test_tiles_match_oracle(oracle_built, w, h, qp, nf, seed, tiles):
     o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels, tiles=tiles)
     assert_records_equal(recs, o_recs, "oracle tiles %dx%d" % (w, h))
     assert np.array_equal(recon, o_recon)
+    dbk = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles)
+    d = dbk.deblock_frames(recon, recs); sao, fin = dbk.sao_frames(yuv, d); dbk.close()
+    o_sao, o_fin = ref_tools.run_sao(yuv, d, w, h, qp, tiles=tiles)
+    assert sao.tobytes() == o_sao.tobytes() and np.array_equal(fin, o_fin)      # SAO merge candidates follow the same tile layout
     assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"])
     u_recs, _, _ = ref_tools.run_oracle(yuv, w, h, qp, labels)
     assert any(not np.array_equal(o_recs[k], u_recs[k]) for k in FIELDS)      # the tiling does change the decisions

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLD
+from conftest import GOLD, fixture_tiles
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -33,7 +33,7 @@ def bit_depth_of(f):
 
 
 def tiles_of(f):
-    return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)      # rd_t*: reference runs with tiles enabled
+    return fixture_tiles(f)
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
