@@ -59,6 +59,68 @@ def _cpu_worker(args):
     return time.time() - t
 
 
+REF_ENC = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_ref")
+
+
+def _prepare_ref_run(args):
+    """Working directory of one reference-encoder process: input band, the label files it polls for (TEncCu.cpp:244-253), output dir."""
+    idx, yuv, w, h, qp, labels, base = args
+    d = os.path.join(base, "p%d" % idx)
+    os.makedirs(os.path.join(d, "rec"))
+    yuv.astype(np.uint8).tofile(os.path.join(d, "in.yuv"))
+    os.makedirs(os.path.join(d, "pred", "0"))
+    for a in range(labels.shape[1]):
+        with open(os.path.join(d, "pred", "0", "ctu%d.txt" % a), "w") as fh:
+            fh.write(" ".join(str(int(v)) for v in labels[0, a]) + " ")
+    return d
+
+
+def _run_ref(args):
+    import subprocess
+    d, cmd = args
+    t = time.time()
+    r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("reference encoder failed: " + r.stdout[-500:] + r.stderr[-500:])
+    return time.time() - t
+
+
+def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=6):
+    """The reference itself (oracle/_ref/TAppEncoder_ref, built from /root/reference by oracle/build_ref.sh; configuration = the
+    reference's cfg as switches, oracle/ref_args.py) on the host cores: P processes, each encoding the top `band_rows` CTU rows of a
+    distinct frame with its labels already on disk, wall clock from first start to last exit.  Encoder only (in-loop filters and bitstream
+    included, as the reference runs them); the label CNN is excluded."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_args
+    cores = os.cpu_count() or 1
+    p = min(cores, yuv_host.shape[0], max_procs or cores)
+    full_h = height
+    height = min(height, 64 * band_rows)
+    cx = (width + 63) // 64
+    ysz, csz = width * full_h, (width // 2) * (full_h // 2)
+
+    def band(fr):
+        return np.concatenate([fr[:width * height], fr[ysz:ysz + (width // 2) * (height // 2)], fr[ysz + csz:ysz + csz + (width // 2) * (height // 2)]])
+    labels_host = np.ascontiguousarray(labels_host[:p, :cx * ((height + 63) // 64)])
+    base = tempfile.mkdtemp(prefix="hevcdl_cpu_")
+    try:
+        dirs = [_prepare_ref_run((i, band(yuv_host[i]), width, height, qp, labels_host[i:i + 1], base)) for i in range(p)]
+        cmd = [REF_ENC, "-i", "in.yuv", "-b", "rec/str.bin", "-o", "rec/rec.yuv"] + ref_args.reference_args(width, height, 1, qp)
+        t = time.time()
+        with ThreadPoolExecutor(max_workers=p) as pool:
+            per = list(pool.map(_run_ref, [(d, cmd) for d in dirs]))
+        wall = time.time() - t
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    ctus = p * labels_host.shape[1]
+    return {"value": ctus / wall, "unit": "CTUs/s", "cores": p, "kind": "reference",
+            "sample": "top %dx%d band of %d frames of the workload, QP%d (1 reference-encoder process per band, label files from the GPU CNN, CNN excluded; deblocking, SAO and bitstream included), %.1f s wall, %.1f CTUs/s per core"
+                      % (width, height, p, qp, wall, ctus / sum(per) if sum(per) > 0 else 0.0)}
+
+
 def cpu_baseline(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=3):
     """Oracle (CPU port, bit-identical to the reference on the golden vectors) timed on the host cores of this node:
     P processes, each encoding the top `band_rows` CTU rows of a distinct frame of the same workload (bounded sample:
@@ -98,6 +160,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="frames per GPU per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0)
+    ap.add_argument("--cpu-baseline", default="reference", choices=["reference", "port"], help="reference: oracle/_ref/TAppEncoder_ref when present; port: the plain-C oracle")
     a = ap.parse_args()
 
     import torch
@@ -187,7 +250,9 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
             nb = min(F, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
+            # the reference build travels with the repository (oracle/_ref); without it the plain-C port stands in
+            base_fn = cpu_baseline_reference if os.path.exists(REF_ENC) and a.cpu_baseline != "port" else cpu_baseline
+            out["cpu_baseline"] = base_fn(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
         print(json.dumps(out), flush=True)
     enc.close()
     if world > 1:
