@@ -53,7 +53,7 @@ class Config(ctypes.Structure):
                 ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("reserved2", ctypes.c_int32)]
+                ("lf_across_tiles", ctypes.c_int32)]
 
 
 def tile_layout(tiles, width, height):
@@ -83,7 +83,7 @@ class StreamConfig(ctypes.Structure):
                 ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("reserved2", ctypes.c_int32)]
+                ("lf_across_tiles", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -206,7 +206,7 @@ def load_weights(path=WEIGHTS_PATH):
     return w
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8):
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
     lib = load_library()
     cfg = Config()
     st = lib.hevcdl_config_default_bd(ctypes.byref(cfg), width, height, qp, bit_depth)
@@ -214,10 +214,11 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
         raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
     cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
     _set_tiles(cfg, tiles, width, height)        # (columns, rows) uniformly spaced, or explicit sizes: see tile_layout
+    cfg.lf_across_tiles = 1 if lf_across_tiles else 0                   # LFCrossTileBoundaryFlag
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -226,6 +227,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
         raise HevcdlError(st, "stream config")
     cfg.level_idc = level_idc
     _set_tiles(cfg, tiles, width, height)
+    cfg.lf_across_tiles = 1 if lf_across_tiles else 0
     cfg.bit_depth = bit_depth
     sao_ptr = None
     if sao is not None:
@@ -245,10 +247,10 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
         """bit_depth 10: every yuv / recon array of the decision path holds uint16 samples (frame_bytes counts bytes)."""
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles)
         self.bit_depth = self.cfg.bit_depth
         self.sample_dtype = np.uint8 if self.bit_depth == 8 else np.dtype("<u2")
         self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)

@@ -38,8 +38,12 @@ template <typename PEL> __device__ __forceinline__ void store4(PEL GLB *p, int a
 }
 
 // TU edge at the left (dir 0) / top (dir 1) border of the 4x4 partition at luma (x, y) of this frame?
-__device__ __forceinline__ bool edge_flag(const unsigned char GLB *recs, int ctus_x, int x, int y, int dir)
+__device__ __forceinline__ bool edge_flag(const hevcdl_dbk_params &p, const unsigned char GLB *recs, int ctus_x, int x, int y, int dir)
 {
+  if (!p.lf_across_tiles) { // xSetLoopfilterParam TComLoopFilter.cpp:362-400: the neighbouring CU of another tile does not exist for the filter
+    const int pos = (dir ? y : x) >> 6, n = dir ? p.tile_rows : p.tile_cols;
+    if ((((dir ? y : x)) & 63) == 0) for (int t = 1; t < n; t++) if ((dir ? p.row_bd[t] : p.col_bd[t]) == pos) return false;
+  }
   const unsigned char GLB *r = recs + (size_t)((y >> 6) * ctus_x + (x >> 6)) * REC_SIZE;
   const int x4 = (x & 63) >> 2, y4 = (y & 63) >> 2;
   int z = 0;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256) void hevcdl_deblock_ver_kernel(hevcdl_dbk_para
   const bool has_l = x > 0, has_r = x < W;
   bool e0 = false, e1 = false;
   if (has_l && has_r) {
-    if (CHROMA) { e0 = edge_flag(recs, p.ctus_x, 2 * x, 2 * y, 0); e1 = edge_flag(recs, p.ctus_x, 2 * x, 2 * y + 4, 0); }
-    else e0 = edge_flag(recs, p.ctus_x, x, y, 0);
+    if (CHROMA) { e0 = edge_flag(p, recs, p.ctus_x, 2 * x, 2 * y, 0); e1 = edge_flag(p, recs, p.ctus_x, 2 * x, 2 * y + 4, 0); }
+    else e0 = edge_flag(p, recs, p.ctus_x, x, y, 0);
   }
 #pragma unroll 1
   for (int c = 0; c < (CHROMA ? 2 : 1); c++) {
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(256) void hevcdl_deblock_hor_kernel(hevcdl_dbk_para
   const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
   const unsigned char GLB *recs = (const unsigned char GLB *)p.records + (size_t)frame * p.ctus_per_frame * REC_SIZE;
   bool e0, e1 = false;
-  if (CHROMA) { e0 = edge_flag(recs, p.ctus_x, 2 * x, 2 * y, 1); e1 = edge_flag(recs, p.ctus_x, 2 * x + 4, 2 * y, 1); }
-  else e0 = edge_flag(recs, p.ctus_x, x, y, 1);
+  if (CHROMA) { e0 = edge_flag(p, recs, p.ctus_x, 2 * x, 2 * y, 1); e1 = edge_flag(p, recs, p.ctus_x, 2 * x + 4, 2 * y, 1); }
+  else e0 = edge_flag(p, recs, p.ctus_x, x, y, 1);
   if (!e0 && !e1) return;
 #pragma unroll 1
   for (int c = 0; c < (CHROMA ? 2 : 1); c++) {

@@ -70,7 +70,7 @@ extern "C" hevcdl_status hevcdl_config_default_bd(hevcdl_config *cfg, int width,
   cfg->width = width; cfg->height = height; cfg->bit_depth = bit_depth; cfg->chroma_format = 420; cfg->qp = qp;
   cfg->ctu_size = 64; cfg->max_partition_depth = 4; cfg->tu_log2_min = 2; cfg->tu_log2_max = 5; cfg->tu_max_depth_intra = 3;
   cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->bn_mode = HEVCDL_BN_REFERENCE; cfg->boundary_policy = HEVCDL_BOUNDARY_CLAMP;
-  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1; cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->tile_uniform_spacing = 1;
+  cfg->cnn_input = HEVCDL_CNN_INPUT_RGB601; cfg->device = 0; cfg->max_frames = 1; cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->tile_uniform_spacing = 1; cfg->lf_across_tiles = 1;
   // TEncSlice::calculateLambda (TEncSlice.cpp:433-527) for an all-intra GOP of 1, then setUpLambda (:112-140)
   cfg->lambda = 0.57 * 1.0 * pow(2.0, (qp - 12) / 3.0);
   cfg->sqrt_lambda = sqrt(cfg->lambda);                         // TComRdCost::setLambda TComRdCost.cpp:109-122
@@ -379,6 +379,8 @@ extern "C" hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *
   const int bd_scale = 1 << (ctx->cfg.bit_depth - 8);                                       // iBitdepthScale, TComLoopFilter.cpp:596, 770
   p.tc = DBK_TC[qp + 2 > 53 ? 53 : qp + 2] * bd_scale; p.beta = DBK_BETA[qp] * bd_scale; p.tc_c = DBK_TC[qpc + 2 > 53 ? 53 : qpc + 2] * bd_scale;
   p.pel_max = (1 << ctx->cfg.bit_depth) - 1;
+  p.lf_across_tiles = ctx->cfg.lf_across_tiles != 0; p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
+  memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);
   hevcdl_launch_deblock(&p, stream);
   HIPCHK(hipGetLastError());
   return HEVCDL_OK;
@@ -413,7 +415,7 @@ extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_or
   p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames; p.qp = ctx->cfg.qp;
   p.lambda = ctx->cfg.lambda; p.lambda_chroma = ctx->cfg.lambda_chroma;          // slice lambdas per component, TEncSlice.cpp:112-140
-  p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows; p.bit_depth = ctx->cfg.bit_depth;
+  p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows; p.bit_depth = ctx->cfg.bit_depth; p.lf_across_tiles = ctx->cfg.lf_across_tiles != 0;
   memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);
   hevcdl_launch_sao(&p, stream);
   HIPCHK(hipGetLastError());

@@ -160,7 +160,7 @@ int main(int argc, char **argv)
   // decoded picture hash SEI (TAppEncCfg.cpp:1093): 0 none, 1 MD5 of the output picture behind every access unit
   const int hash_sei = (int)opt.geti("SEIDecodedPictureHash", 0);
   if (hash_sei != 0 && hash_sei != 1) opt.errors.push_back("SEIDecodedPictureHash = " + std::to_string(hash_sei) + " is not implemented by this path (only 0 and 1 = MD5)");
-  // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows; the in-loop filters cross tile borders (LFCrossTileBoundaryFlag 1, the default)
+  // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows or explicit sizes; LFCrossTileBoundaryFlag (default 1) lets the in-loop filters cross tile borders
   const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
   const int tile_uniform = (int)opt.geti("TileUniformSpacing", 0) != 0;
   std::vector<int> tile_cw, tile_rh;               // TileColumnWidthArray / TileRowHeightArray: sizes in CTUs of all but the last column / row
@@ -171,7 +171,6 @@ int main(int argc, char **argv)
       if ((int)tile_cw.size() < tile_cols - 1 || (int)tile_rh.size() < tile_rows - 1 || tile_cols > 20 || tile_rows > 22)
         opt.errors.push_back("TileUniformSpacing = 0 needs TileColumnWidthArray / TileRowHeightArray with a size for every tile column / row but the last");
     }
-    if (opt.geti("LFCrossTileBoundaryFlag", 1) != 1) opt.errors.push_back("tiles are implemented with LFCrossTileBoundaryFlag = 1 only");
   }
   if (opt.v.count("PrintConfig")) {
     printf("{\"InputFile\": \"%s\", \"ReconFile\": \"%s\", \"SourceWidth\": %d, \"SourceHeight\": %d, \"QP\": %d, \"FrameSkip\": %ld, \"FramesToBeEncoded\": %ld, "
@@ -207,7 +206,7 @@ int main(int argc, char **argv)
   cfg.max_frames = batch; cfg.device = (int)opt.geti("Device", 0);
   cfg.tile_columns = tile_cols; cfg.tile_rows = tile_rows;
   if (tile_cols * tile_rows > 1) {
-    cfg.tile_uniform_spacing = tile_uniform;
+    cfg.tile_uniform_spacing = tile_uniform; cfg.lf_across_tiles = opt.geti("LFCrossTileBoundaryFlag", 1) != 0;
     if (!tile_uniform) { for (int i = 0; i < tile_cols - 1; i++) cfg.tile_column_width[i] = tile_cw[i]; for (int i = 0; i < tile_rows - 1; i++) cfg.tile_row_height[i] = tile_rh[i]; }
   }
   cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
@@ -245,7 +244,7 @@ int main(int argc, char **argv)
   if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
-  scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
+  scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
   std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;

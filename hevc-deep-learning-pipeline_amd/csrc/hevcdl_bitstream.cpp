@@ -506,7 +506,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
-  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1;
+  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1; cfg->lf_across_tiles = 1;
   return HEVCDL_OK;
 }
 
@@ -599,7 +599,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
         for (int i = 0; i < tcols - 1; i++) w.ue((uint32_t)(col_bd[i + 1] - col_bd[i]) - 1);    // column_width_minus1
         for (int i = 0; i < trows - 1; i++) w.ue((uint32_t)(row_bd[i + 1] - row_bd[i]) - 1);    // row_height_minus1
       }
-      w.flag(1);                                     // loop_filter_across_tiles_enabled_flag
+      w.flag(cfg->lf_across_tiles != 0);             // loop_filter_across_tiles_enabled_flag
     }
     w.flag(1); w.flag(0);                            // loop filter across slices, deblocking_filter_control_present
     w.flag(0); w.flag(0); w.ue(0); w.flag(0); w.flag(0);

@@ -62,6 +62,7 @@ struct hevcdl_dbk_params {
   int width, height, ctus_x, ctus_per_frame, n_frames;
   int tc, beta, tc_c;              // already scaled by 1 << (bit depth - 8) (TComLoopFilter.cpp:596, 770)
   int pel_max;                     // (1 << bit depth) - 1; 255: planes of uint8, otherwise planes of uint16
+  int lf_across_tiles, tile_cols, tile_rows, col_bd[21], row_bd[23];   // LFCrossTileBoundaryFlag 0: no edge on a tile border is filtered
 };
 
 // sample adaptive offset (sao_kernel.hip)
@@ -75,6 +76,7 @@ struct hevcdl_sao_params {
   int tile_cols, tile_rows;        // merge candidates stay inside a tile
   int col_bd[21], row_bd[23];      // tile boundaries in CTUs
   int bit_depth;                   // 8: planes of uint8; 10: planes of uint16 (offset range 31, band = sample >> 5, distortion >> 4)
+  int lf_across_tiles;             // 0: a neighbouring CTU of another tile counts as missing (like the picture border)
   double lambda, lambda_chroma;
 };
 

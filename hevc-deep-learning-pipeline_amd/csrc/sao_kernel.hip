@@ -47,6 +47,20 @@ struct Sbac { uint8_t merge_ctx, type_ctx; unsigned long long frac; };
 __device__ __forceinline__ int sgn(int v) { return (v > 0) - (v < 0); }
 __device__ __forceinline__ int clipbd(int v, int mx) { return v < 0 ? 0 : (v > mx ? mx : v); }      // ClipBD
 
+// Which neighbouring CTUs of CTU a exist for SAO.  Offsets (for_stats 0): inside the picture and, with LFCrossTileBoundaryFlag 0, inside the
+// same tile (TComPicSym::deriveLoopFilterBoundaryAvailibility; tiles are rectangles, so a tile border acts exactly like the picture
+// border).  Statistics (for_stats 1): left / above likewise, but right / below only look at the picture
+// (TEncSampleAdaptiveOffset::getStatistics :322-330 overrides them).
+__device__ __forceinline__ void sao_neighbours(const hevcdl_sao_params &p, int a, int for_stats, int &left, int &right, int &above, int &below)
+{
+  const int cx = p.ctus_x, x = a % cx, y = a / cx, x0 = x * 64, y0 = y * 64;
+  left = x0 > 0; above = y0 > 0; right = x0 + 64 < p.width; below = y0 + 64 < p.height;
+  if (!p.lf_across_tiles) {
+    for (int t = 1; t < p.tile_cols; t++) { if (p.col_bd[t] == x) left = 0; if (!for_stats && p.col_bd[t] == x + 1) right = 0; }
+    for (int t = 1; t < p.tile_rows; t++) { if (p.row_bd[t] == y) above = 0; if (!for_stats && p.row_bd[t] == y + 1) below = 0; }
+  }
+}
+
 // edge / band class of sample p for SAO type t
 template <typename PEL> __device__ __forceinline__ int sao_class(int t, const PEL GLB *p, int stride, int band_shift)
 {
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params
   const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
   const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
   const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh, ph = p.height >> sh;
-  const int left = x0 > 0, above = y0 > 0, right = x0 + 64 < p.width, below = y0 + 64 < p.height;
+  int left, right, above, below; sao_neighbours(p, a, 1, left, right, above, below);
   const int skip_r = comp ? 3 : 5, skip_b = comp ? 2 : 4;
   const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
   const size_t plane = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2)));
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats16_kernel(hevcdl_sao_para
   const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
   const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
   const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh, ph = p.height >> sh;
-  const int left = x0 > 0, above = y0 > 0, right = x0 + 64 < p.width, below = y0 + 64 < p.height;
+  int left, right, above, below; sao_neighbours(p, a, 1, left, right, above, below);
   const int skip_r = comp ? 3 : 5, skip_b = comp ? 2 : 4, band_shift = p.bit_depth - 5;
   const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
   const size_t plane = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2)));
@@ -414,8 +428,9 @@ __global__ __launch_bounds__(256) void hevcdl_sao_apply_kernel(hevcdl_sao_params
   if (tid < 32) offs[tid] = (mode != MODE_OFF && (type == BO || tid < 5)) ? prm.offset[tid] : 0;
   __syncthreads();
   const bool need_lr = (type == EO_0 || type == EO_135 || type == EO_45), need_ab = (type == EO_90 || type == EO_135 || type == EO_45);
-  const int sx = (need_lr && x0 == 0) ? 1 : 0, ex = (need_lr && x0 + 64 >= p.width) ? w - 1 : w;
-  const int sy = (need_ab && y0 == 0) ? 1 : 0, ey = (need_ab && y0 + 64 >= p.height) ? h - 1 : h;
+  int left, right, above, below; sao_neighbours(p, a, 0, left, right, above, below);
+  const int sx = (need_lr && !left) ? 1 : 0, ex = (need_lr && !right) ? w - 1 : w;
+  const int sy = (need_ab && !above) ? 1 : 0, ey = (need_ab && !below) ? h - 1 : h;
   for (int i = tid; i < w * h; i += 256) {
     const int y = i / w, x = i - y * w;
     const PEL GLB *s = src + (size_t)y * stride + x;

@@ -78,7 +78,7 @@ typedef struct hevcdl_config {
    * TAppEncCfg.cpp:1026-1028); ignored when tile_uniform_spacing != 0 (the default) */
   int32_t  tile_uniform_spacing;
   int32_t  tile_column_width[19], tile_row_height[21];
-  int32_t  reserved2;
+  int32_t  lf_across_tiles;      /* LFCrossTileBoundaryFlag (default 1): 0 = deblocking and SAO stop at tile borders */
 } hevcdl_config;
 
 /* One CTU of decisions: what compressCtu leaves in the picture's CTU record (TEncCu.cpp:1091 copyToPic).
@@ -171,7 +171,7 @@ typedef struct hevcdl_stream_config {
   int32_t  bit_depth;            /* 8 (Profile main) or 10 (Profile main10): profile_tier_level, SPS bit depths, SAO offset range */
   int32_t  tile_uniform_spacing; /* as in the hevcdl_config field, default 1; 0: column_width_minus1 / row_height_minus1 are written */
   int32_t  tile_column_width[19], tile_row_height[21];
-  int32_t  reserved2;
+  int32_t  lf_across_tiles;      /* loop_filter_across_tiles_enabled_flag of the PPS (default 1) */
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
 size_t        hevcdl_access_unit_bound(int width, int height);

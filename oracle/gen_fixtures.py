@@ -64,7 +64,9 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
         spec = [("t512_q32_2x2", 512, 128, 1, 32, "rand", 31, (2, 2)), ("t576_q27_2x3", 576, 192, 1, 27, "rand", 32, (2, 3)),
                 ("t520_q37_2x2", 520, 136, 2, 37, "rand", 33, (2, 2)), ("t832_q32_3x1", 832, 128, 1, 32, "rand", 34, (3, 1)),
                 # TileUniformSpacing 0 with explicit sizes (all columns / rows listed; the reference is given all but the last)
-                ("n832_q32_544x12", 832, 192, 1, 32, "rand", 91, ([5, 4, 4], [1, 2])), ("n712_q27_b10", 712, 136, 1, 27, "rand", 92, ([7, 5], [2, 1]))]
+                ("n832_q32_544x12", 832, 192, 1, 32, "rand", 91, ([5, 4, 4], [1, 2])), ("n712_q27_b10", 712, 136, 1, 27, "rand", 92, ([7, 5], [2, 1])),
+                # LFCrossTileBoundaryFlag 0: deblocking and SAO stop at the tile borders
+                ("l576_q32_lf0", 576, 192, 1, 32, "rand", 93, (2, 3)), ("l520_q27_lf0_b10", 520, 200, 1, 27, "rand", 94, (2, 2))]
     bd = 8
     if ten_bit:
         # InputBitDepth = InternalBitDepth = 10, Profile main10; samples = the 8-bit pattern * 4 + 2 bits of noise;
@@ -77,8 +79,12 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
         spec = [(name, v[0], v[1], 1, v[2], "rand", v[2] + 7 - 100, (1, 1)) for name, v in EXTREME.items()]
     for name, w, h, nf, qp, kind, seed, tiles in spec:
         targs = rt.tile_args(tiles) if tiles != (1, 1) else []
-        if name == "n712_q27_b10":
+        if name in ("n712_q27_b10", "l520_q27_lf0_b10"):
             bd, ten_bit = 10, True
+        else:
+            bd, ten_bit = (8, False) if tiled else (bd, ten_bit)
+        if name.startswith("l"):
+            targs = targs + ["--LFCrossTileBoundaryFlag=0"]
         if extreme:
             bd = EXTREME[name][4]
         yuv = rt.synth_yuv(w, h, nf, seed) if not extreme else None
@@ -102,7 +108,7 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
         nctu = lab.shape[1]
         assert len(dump) == nf * nctu
         summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
-        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd,
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd, lf_across_tiles=0 if name.startswith("l") else 1,
                             **({"tiles": np.array(tiles)} if isinstance(tiles[0], int) else {"tiles": np.array([len(tiles[0]), len(tiles[1])]), "tile_col_sizes": np.array(tiles[0]), "tile_row_sizes": np.array(tiles[1])}),
                             records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
                             rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),

@@ -93,6 +93,22 @@ int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const
 
 int hm_oracle_deblock_frame16(uint16_t *frame, int width, int height, int qp, const hm_ctu_record *recs, int bit_depth)
 {
+  return hm_oracle_deblock_frame16_tb(frame, width, height, qp, recs, bit_depth, 1, 1, NULL, NULL);
+}
+
+/* col_bd / row_bd != NULL: LFCrossTileBoundaryFlag 0 -- edges on the tile borders (CTU units) are left alone (xSetLoopfilterParam
+   TComLoopFilter.cpp:362-400: the neighbouring CU of another tile does not exist for the filter) */
+static int on_tile_border(int pos, int n_tiles, const int *bd)
+{
+  int t;
+  if (!bd || (pos & 63)) return 0;
+  for (t = 1; t < n_tiles; t++) if (bd[t] == (pos >> 6)) return 1;
+  return 0;
+}
+
+int hm_oracle_deblock_frame16_tb(uint16_t *frame, int width, int height, int qp, const hm_ctu_record *recs, int bit_depth,
+                                 int tile_cols, int tile_rows, const int *col_bd, const int *row_bd)
+{
   const int ctus_x = (width + 63) >> 6, cw = width >> 1, ch = height >> 1;
   spx *Y = frame, *C[2] = { frame + (size_t)width * height, frame + (size_t)width * height + (size_t)cw * ch };
   int dir, x, y, i, c;
@@ -109,7 +125,7 @@ int hm_oracle_deblock_frame16(uint16_t *frame, int width, int height, int qp, co
       for (y = 0; y < height; y += dir ? 8 : 4)
         for (x = 0; x < width; x += dir ? 4 : 8) {
           spx *src; int off, step, dp0, dq0, dp3, dq3, d0, d3, d;
-          if (!edge_flag(recs, ctus_x, x, y, dir)) continue;
+          if (!edge_flag(recs, ctus_x, x, y, dir) || on_tile_border(dir ? y : x, dir ? tile_rows : tile_cols, dir ? row_bd : col_bd)) continue;
           src = Y + (size_t)y * width + x; off = dir ? width : 1; step = dir ? 1 : width;
           dp0 = calc_dp(src, off); dq0 = calc_dq(src, off); dp3 = calc_dp(src + 3 * step, off); dq3 = calc_dq(src + 3 * step, off);
           d0 = dp0 + dq0; d3 = dp3 + dq3; d = d0 + d3;
@@ -122,7 +138,7 @@ int hm_oracle_deblock_frame16(uint16_t *frame, int width, int height, int qp, co
       /* chroma: edges on the chroma 8x8 grid (luma 16), 2 chroma lines per luma partition, Bs 2 everywhere (:746) */
       for (y = 0; y < height; y += dir ? 16 : 4)
         for (x = 0; x < width; x += dir ? 4 : 16) {
-          if (!edge_flag(recs, ctus_x, x, y, dir)) continue;
+          if (!edge_flag(recs, ctus_x, x, y, dir) || on_tile_border(dir ? y : x, dir ? tile_rows : tile_cols, dir ? row_bd : col_bd)) continue;
           for (c = 0; c < 2; c++) {
             spx *src = C[c] + (size_t)(y >> 1) * cw + (x >> 1);
             const int off = dir ? cw : 1, step = dir ? 1 : cw;

@@ -53,6 +53,9 @@ int hm_oracle_encode_frames_tb(const void *yuv, int width, int height, int n_fra
 /* Deblocking (oracle/hm_deblock.c): filters one planar 4:2:0 frame in place, given the frame's CTU records. */
 int hm_oracle_deblock_frame(uint8_t *frame, int width, int height, int qp, const hm_ctu_record *recs);
 int hm_oracle_deblock_frame16(uint16_t *frame, int width, int height, int qp, const hm_ctu_record *recs, int bit_depth);   /* uint16 samples, bit_depth 8 or 10 */
+/* col_bd / row_bd (tile boundaries in CTUs) non-NULL = LFCrossTileBoundaryFlag 0: no filtering across tile borders */
+int hm_oracle_deblock_frame16_tb(uint16_t *frame, int width, int height, int qp, const hm_ctu_record *recs, int bit_depth,
+                                 int tile_cols, int tile_rows, const int *col_bd, const int *row_bd);
 
 /* Sample adaptive offset (oracle/hm_sao.c).  mode 0 off / 1 new / 2 merge; type: new -> 0..3 edge offset 0/90/135/45 degrees,
  * 4 band offset; merge -> 0 left, 1 above; aux = band position; offset[class] (edge classes 0..4, bands 0..31). */
@@ -63,6 +66,7 @@ int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width,
 /* uint16 sample planes, bit_depth 8 or 10 (offset range 7 / 31, band shift bit_depth - 5, distortion at 8-bit scale) */
 int hm_oracle_sao_frame16(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, int bit_depth);
 int hm_oracle_sao_frame16_tb(const uint16_t *org, const uint16_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint16_t *out, int tile_cols, int tile_rows, const int *col_bd, const int *row_bd, int bit_depth);
+void hm_oracle_sao_set_lf_across_tiles(int flag);   /* LFCrossTileBoundaryFlag for the next hm_oracle_sao_* calls (default 1) */
 int hm_oracle_sao_frame_tiles(const uint8_t *org, const uint8_t *deblocked, int width, int height, int qp, hm_sao_blk *params, uint8_t *out, int tile_cols, int tile_rows);
 
 /* Debug: if non-NULL, every RD cost evaluation appends (bits, dist) to this FILE (text). */

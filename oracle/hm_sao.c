@@ -266,6 +266,9 @@ int hm_oracle_sao_frame(const uint8_t *org, const uint8_t *deblocked, int width,
   return hm_oracle_sao_frame_tiles(org, deblocked, width, height, qp, params, out, 1, 1);
 }
 
+static int g_lf_across_tiles = 1;
+void hm_oracle_sao_set_lf_across_tiles(int flag) { g_lf_across_tiles = flag != 0; }
+
 /* first CTU column / row of a tile */
 static int tile_start(int pos, const int *bd, int n_tiles)
 {
@@ -319,7 +322,12 @@ int hm_oracle_sao_frame16_tb(const uint16_t *org, const uint16_t *deblocked, int
   for (a = 0; a < nctu; a++) { /* getStatistics :295-341: only picture borders count; 5/4 (luma) and 3/2 (chroma) columns/rows next to a right/lower CTU are skipped */
     const int x0 = (a % cx) * 64, y0 = (a / cx) * 64;
     const int w = x0 + 64 > width ? width - x0 : 64, h = y0 + 64 > height ? height - y0 : 64;
-    const int left = x0 > 0, above = y0 > 0, right = x0 + 64 < width, below = y0 + 64 < height;
+    int left = x0 > 0, above = y0 > 0;
+    const int right = x0 + 64 < width, below = y0 + 64 < height;    /* :322-330: for the statistics right / below only look at the picture */
+    if (!g_lf_across_tiles) { /* deriveLoopFilterBoundaryAvailibility: a CTU of another tile is missing, like the picture border */
+      if (tile_start(a % cx, col_bd, tile_cols)) left = 0;
+      if (tile_start(a / cx, row_bd, tile_rows)) above = 0;
+    }
     for (comp = 0; comp < 3; comp++) {
       const int sh = comp ? 1 : 0, stride = comp ? cw : width;
       const size_t off = (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + csz)) + (size_t)(y0 >> sh) * stride + (x0 >> sh);
@@ -364,7 +372,14 @@ int hm_oracle_sao_frame16_tb(const uint16_t *org, const uint16_t *deblocked, int
       int o[32];
       if (p->mode == MODE_OFF) continue;
       if (p->type == BO) memcpy(o, p->offset, sizeof o); else { memset(o, 0, sizeof o); memcpy(o, p->offset, sizeof(int) * 5); }
-      offset_block(p->type, o, deblocked + off, out + off, stride, w >> sh, h >> sh, x0 > 0, x0 + 64 < width, y0 > 0, y0 + 64 < height);
+      { int left = x0 > 0, above = y0 > 0, right = x0 + 64 < width, below = y0 + 64 < height;
+        if (!g_lf_across_tiles) { /* offsetCTU: all neighbours tile-aware */
+          if (tile_start(a % cx, col_bd, tile_cols)) left = 0;
+          if (tile_start(a / cx, row_bd, tile_rows)) above = 0;
+          if (a % cx + 1 < cx && tile_start(a % cx + 1, col_bd, tile_cols)) right = 0;
+          if (a / cx + 1 < cy && tile_start(a / cx + 1, row_bd, tile_rows)) below = 0;
+        }
+        offset_block(p->type, o, deblocked + off, out + off, stride, w >> sh, h >> sh, left, right, above, below); }
     }
   }
   free(st); free(recon);

@@ -225,9 +225,22 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     return recs, recon, stats
 
 
-def run_deblock(recon, width, height, qp, recs, bit_depth=8):
-    """Oracle deblocking of pre-filter reconstructions [frames][w*h*3/2] given the records [frames][ctus] -> filtered copy."""
+def run_deblock(recon, width, height, qp, recs, bit_depth=8, tiles=(1, 1), lf_across_tiles=True):
+    """Oracle deblocking of pre-filter reconstructions [frames][w*h*3/2] given the records [frames][ctus] -> filtered copy.
+    lf_across_tiles False = LFCrossTileBoundaryFlag 0: edges on the borders of `tiles` are left alone."""
     lib = oracle_lib()
+    if not lf_across_tiles:
+        lib.hm_oracle_deblock_frame16_tb.restype = ctypes.c_int
+        lib.hm_oracle_deblock_frame16_tb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        tc, tr, cb, rb = tile_bounds(tiles, width, height)
+        dt = np.uint8 if bit_depth == 8 else np.uint16
+        out = np.ascontiguousarray(np.asarray(recon, dt), np.uint16).copy().reshape(recs.shape[0], -1)
+        recs = np.ascontiguousarray(recs)
+        for f in range(out.shape[0]):
+            if lib.hm_oracle_deblock_frame16_tb(out[f].ctypes.data, width, height, qp, recs[f].ctypes.data, bit_depth, tc, tr, cb.ctypes.data, rb.ctypes.data) != 0:
+                raise RuntimeError("oracle deblock failed")
+        return out.astype(dt)
     if bit_depth != 8:
         lib.hm_oracle_deblock_frame16.restype = ctypes.c_int
         lib.hm_oracle_deblock_frame16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
@@ -251,9 +264,10 @@ def run_deblock(recon, width, height, qp, recs, bit_depth=8):
 SAO_DTYPE = np.dtype([("mode", "<i4"), ("type", "<i4"), ("aux", "<i4"), ("offset", "<i4", 32)])      # hm_sao_offset
 
 
-def run_sao(org, deblocked, width, height, qp, tiles=(1, 1), bit_depth=8):
+def run_sao(org, deblocked, width, height, qp, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
     """Oracle SAO of frames [n][w*h*3/2] -> (params [n][ctus][3] SAO_DTYPE, final reconstruction)."""
     lib = oracle_lib()
+    lib.hm_oracle_sao_set_lf_across_tiles(1 if lf_across_tiles else 0)
     lib.hm_oracle_sao_frame16_tb.restype = ctypes.c_int
     lib.hm_oracle_sao_frame16_tb.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -269,6 +283,7 @@ def run_sao(org, deblocked, width, height, qp, tiles=(1, 1), bit_depth=8):
                                           tc, tr, cb.ctypes.data, rb.ctypes.data, bit_depth)
         if rc != 0:
             raise RuntimeError("oracle sao failed rc=%d" % rc)
+    lib.hm_oracle_sao_set_lf_across_tiles(1)
     return params, out.astype(dt)
 
 

@@ -29,6 +29,11 @@ def fixture_tiles(f):
     return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)
 
 
+def fixture_lf(f):
+    """LFCrossTileBoundaryFlag of a golden fixture (rd_l*: 0)."""
+    return bool(int(f["lf_across_tiles"])) if "lf_across_tiles" in f.files else True
+
+
 @pytest.fixture(scope="session")
 def oracle_built():
     """Compile the plain-C oracle (test infrastructure) once per session."""

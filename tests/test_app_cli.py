@@ -69,7 +69,7 @@ def test_keys_that_change_the_path_are_rejected(app, tmp_path):
     write_cfgs(tmp_path)
     for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
                           (["--WaveFrontSynchro=1"], "WaveFrontSynchro"), (["--NumTileColumnsMinus1=1", "--TileColumnWidthArray="], "TileColumnWidthArray"),
-                          (["--NumTileRowsMinus1=1", "--TileUniformSpacing=1", "--LFCrossTileBoundaryFlag=0"], "LFCrossTileBoundaryFlag")):
+                          (["--SEIDecodedPictureHash=2"], "SEIDecodedPictureHash")):
         r = run(app, ["-c", "main.cfg", "-c", "seq.cfg"] + extra + ["--PrintConfig"], tmp_path)
         assert r.returncode == 2 and needle in " ".join(json.loads(r.stdout)["errors"])
     r = run(app, ["-c", "missing.cfg"], tmp_path)
@@ -134,7 +134,7 @@ def test_cli_encode_matches_the_api(app, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10"])
+@pytest.mark.parametrize("case", ["t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
     """The reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) and for 10-bit coding
     (InputBitDepth / InternalBitDepth 10, Profile main10; x576 is C5 of the survey in miniature: both) on the fixtures the reference
@@ -144,7 +144,7 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hevc_parse as hp
     import ref_tools
-    from conftest import fixture_tiles
+    from conftest import fixture_tiles, fixture_lf
     f = np.load(os.path.join(GOLD, "rd_%s.npz" % case))
     w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8
@@ -156,7 +156,7 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
             (tmp_path / "pred" / str(fr) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in f["labels"][fr, a]))
     r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
                   "--SEIDecodedPictureHash=1",
-                  ] + ref_tools.tile_args(fixture_tiles(f)) + bd_args, tmp_path)
+                  ] + ref_tools.tile_args(fixture_tiles(f)) + bd_args + ([] if fixture_lf(f) else ["--LFCrossTileBoundaryFlag=0"]), tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_filtered"])
     assert (tmp_path / "str.bin").read_bytes() == f["bitstream"].tobytes()           # the reference's stream, picture-hash SEI included

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles
+from conftest import GOLD, fixture_tiles, fixture_lf
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -23,7 +23,7 @@ def stream_of(f):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8        # rd_x*: reference runs at InternalBitDepth 10, Profile main10
-    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd) for poc in range(recs.shape[0]))
+    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd, lf_across_tiles=fixture_lf(f)) for poc in range(recs.shape[0]))
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])

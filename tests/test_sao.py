@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles
+from conftest import GOLD, fixture_tiles, fixture_lf
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -44,10 +44,11 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     import hevcdl_amd
     import ref_tools
     f, w, h, qp, nf, org, dbk, final = load(path)
-    params, out = ref_tools.run_sao(org, dbk, w, h, qp, tiles=tiles_of(f), bit_depth=bit_depth_of(f))
+    params, out = ref_tools.run_sao(org, dbk, w, h, qp, tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f))
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    aus = [hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f)) for poc in range(nf)]
+    aus = [hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f),
+                                        lf_across_tiles=fixture_lf(f)) for poc in range(nf)]
     assert b"".join(aus) == strip_sei(f["bitstream"].tobytes())
     # with the decoded-picture-hash SEI (MD5 of the final picture) behind every access unit: the reference's stream, every byte
     assert b"".join(au + hevcdl_amd.picture_hash_sei(w, h, out[poc], bit_depth_of(f)) for poc, au in enumerate(aus)) == f["bitstream"].tobytes()
@@ -58,12 +59,12 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
 def test_gpu_sao_matches_reference(path):
     import hevcdl_amd
     f, w, h, qp, nf, org, dbk, final = load(path)
-    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles_of(f), bit_depth=bit_depth_of(f))
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f))
     params, out = e.sao_frames(org, dbk)
     e.close()
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f)) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 
