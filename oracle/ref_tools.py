@@ -187,8 +187,12 @@ def tile_args(tiles):
     """Reference command-line switches for tiles = (columns, rows) uniformly spaced, or ([widths], [heights]) in CTUs (all of them)."""
     if isinstance(tiles[0], (int, np.integer)):
         return ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (tiles[0] - 1), "--NumTileRowsMinus1=%d" % (tiles[1] - 1)]
-    return ["--TileUniformSpacing=0", "--NumTileColumnsMinus1=%d" % (len(tiles[0]) - 1), "--NumTileRowsMinus1=%d" % (len(tiles[1]) - 1),
-            "--TileColumnWidthArray=" + " ".join(str(int(v)) for v in tiles[0][:-1]), "--TileRowHeightArray=" + " ".join(str(int(v)) for v in tiles[1][:-1])]
+    args = ["--TileUniformSpacing=0", "--NumTileColumnsMinus1=%d" % (len(tiles[0]) - 1), "--NumTileRowsMinus1=%d" % (len(tiles[1]) - 1)]
+    if len(tiles[0]) > 1:
+        args.append("--TileColumnWidthArray=" + " ".join(str(int(v)) for v in tiles[0][:-1]))
+    if len(tiles[1]) > 1:
+        args.append("--TileRowHeightArray=" + " ".join(str(int(v)) for v in tiles[1][:-1]))
+    return args
 
 
 def tile_bounds(tiles, width, height):

@@ -321,3 +321,30 @@ def test_extreme_sizes_and_qps_match_oracle(oracle_built, w, h, qp, kind, bd):
     assert sao.tobytes() == o_sao.tobytes() and np.array_equal(final, o_final.reshape(final.shape))
     au = hevcdl_amd.write_access_unit(w, h, qp, 0, recs[0], sao=sao[0], bit_depth=bd)
     assert len(au) > 60
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_configurations_match_oracle(oracle_built, seed):
+    """Seeded sweep over picture size (multiples of 8, ragged CTU edges), QP 0..51, bit depth, content, label policy and -- when the picture is
+    wide enough -- tile layout (uniform or explicit) with either LFCrossTileBoundaryFlag: decisions, reconstruction, deblocking and SAO
+    against the oracle."""
+    import hevcdl_amd
+    import ref_tools
+    from test_oracle_vs_reference_sweep import sweep_case      # the same cases are run against the reference encoder in the container
+    w, h, qp, bd, tiles, lf, yuv, labels = sweep_case(seed)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1, tiles=tiles, bit_depth=bd, lf_across_tiles=lf)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    dbk = enc.deblock_frames(recon, recs)
+    sao, final = enc.sao_frames(yuv, dbk)
+    enc.close()
+    what = "%dx%d qp %d bd %d tiles %s lf %d" % (w, h, qp, bd, tiles, lf)
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels, tiles=tiles, bit_depth=bd)
+    assert_records_equal(recs, o_recs, what)
+    assert np.array_equal(recon, o_recon.reshape(recon.shape)), what
+    assert np.array_equal(stats["sse"], o_stats["sse"]) and np.array_equal(stats["est_bits"], o_stats["est_bits"]), what
+    o_dbk = ref_tools.run_deblock(o_recon.reshape(1, -1), w, h, qp, np.frombuffer(o_recs.tobytes(), dtype=ref_tools.REC_DTYPE).reshape(1, -1), bit_depth=bd, tiles=tiles, lf_across_tiles=lf)
+    assert np.array_equal(dbk, o_dbk.reshape(dbk.shape)), what
+    o_sao, o_final = ref_tools.run_sao(yuv, o_dbk, w, h, qp, tiles=tiles, bit_depth=bd, lf_across_tiles=lf)
+    assert sao.tobytes() == o_sao.tobytes() and np.array_equal(final, o_final.reshape(final.shape)), what
+    au = hevcdl_amd.write_access_unit(w, h, qp, 0, recs[0], sao=sao[0], tiles=tiles, bit_depth=bd, lf_across_tiles=lf)
+    assert len(au) > 60
