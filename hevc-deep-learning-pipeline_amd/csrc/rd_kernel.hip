@@ -154,7 +154,7 @@ struct RdSmem {
   // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
   int32_t t_ebits[128]; uint8_t t_next[2][128];
   int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
-  uint8_t sv_tr[256], sv_cbf[3][256], sv_ts[3][256];
+  uint8_t sv[4][256];                 // saved best candidate: luma search trIdx / cbf / tskip in [0..2]; chroma search (later, disjoint in time) cbf Cb, Cr, tskip Cb, Cr
   pel_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
   unsigned int rd_list[16];
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
@@ -1583,7 +1583,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost }; return r; }
       if (memo) { // the saved best candidate of the first pass IS the unsplit coding (sv_* / best_rec, est_intra_luma)
         wsync();
-        for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = s.sv_tr[i]; s.a[A_CBF][zabs + i] = s.sv_cbf[0][i]; s.a[A_TSKIP][zabs + i] = s.sv_ts[0][i]; }
+        for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = s.sv[0][i]; s.a[A_CBF][zabs + i] = s.sv[1][i]; s.a[A_TSKIP][zabs + i] = s.sv[2][i]; }
       } else {
         cabac_copy(k, &s.go, &s.test[full_depth]);
         set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
@@ -1841,8 +1841,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         best_mode = org_mode; best_dist = d; best_cost = cost;
         set_result_cu(k, cu, ptu, 0, lds_rec && uni(s.a[A_TRIDX][zp]) == init_trd);
         for (int i = lane_id(); i < pu_parts; i += 64) {
-          s.sv_tr[i] = s.a[A_TRIDX][zp + i];
-          for (int c = 0; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][zp + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][zp + i]; }
+          s.sv[0][i] = s.a[A_TRIDX][zp + i]; s.sv[1][i] = s.a[A_CBF][zp + i]; s.sv[2][i] = s.a[A_TSKIP][zp + i];   // the luma search leaves chroma entries alone
         }
         wsync();
       }
@@ -1850,8 +1849,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     overall += best_dist;
     wsync();
     for (int i = lane_id(); i < pu_parts; i += 64) {
-      s.a[A_TRIDX][zp + i] = s.sv_tr[i];
-      for (int c = 0; c < 3; c++) { s.a[A_CBF + c][zp + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][zp + i] = s.sv_ts[c][i]; }
+      s.a[A_TRIDX][zp + i] = s.sv[0][i]; s.a[A_CBF][zp + i] = s.sv[1][i]; s.a[A_TSKIP][zp + i] = s.sv[2][i];
     }
     if (pu != npu - 1) {
       GLB pel_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; GLB const pel_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
@@ -1963,11 +1961,11 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     if (ub(cost < best_cost)) {
       best_cost = cost; best_dist = d; best_mode = mode_list[m];
       set_result_cu(k, cu, root, 1); set_result_cu(k, cu, root, 2);
-      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv_cbf[c][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv_ts[c][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
+      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv[c - 1][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv[c + 1][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
       wsync();
     }
   }
-  for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv_cbf[c][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv_ts[c][i]; }
+  for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv[c - 1][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv[c + 1][i]; }
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
   PROF_ADD(k, 17);
