@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
-SOURCES = ["cnn_kernel.hip", "rd_kernel.hip", "rd_kernel_bd10.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
+SOURCES = ["cnn_kernel.hip", "fc_kernel.hip", "rd_kernel.hip", "rd_kernel_bd10.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
 
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
 

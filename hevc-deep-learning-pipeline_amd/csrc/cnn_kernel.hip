@@ -41,12 +41,10 @@ struct CnnSmem {
     float t64[3 * T64_CH];                 // conv64 input tile (only live before the quadrant loop)
     struct {
       union { float t32[3 * T32_CH]; float a2[64 * A2_CH]; };   // conv1 input tile | conv2 output
-      float a3[2048][4];                   // conv3 outputs, [flatten index][quadrant]
     } q;
   };
   double red[2][4][16];                    // per-wave partial sums / sums of squares
   float alpha[16], beta[16];               // BN folded to y = x*alpha + beta (conv1 / conv64)
-  float h1[4][256], h2[4][64], lg[4][16];
 };
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m)
@@ -162,10 +160,11 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
   CnnSmem LDS &sm = *(CnnSmem LDS *)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gctu = blockIdx.x;                       // global CTU index over all frames
+  const int gctu = p.ctu_base + blockIdx.x;          // global CTU index over all frames (a launch covers a chunk of CTUs)
   const int frame = gctu / p.ctus_per_frame, addr = gctu - frame * p.ctus_per_frame;
   const int x0 = (addr % p.ctus_x) * 64, y0 = (addr / p.ctus_x) * 64;
   const float GLB *W = (const float GLB *)p.weights;
+  float GLB *a3_out = (float GLB *)p.a3 + (size_t)blockIdx.x * (4 * 2048);      // this CTU's 4 rows of the fully connected head's input (fc_kernel.hip)
 #ifdef HEVCDL_CNN_PROF
   unsigned long long pt_[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_readcyclecounter();
 #define CNN_MARK(i) do { __syncthreads(); const unsigned long long n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pl_; pl_ = n_; } while (0)
@@ -371,7 +370,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[n][t];
           const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-          sm.q.a3[ch * 16 + t * 4 + g4][q] = fmaxf(v, 0.f);      // flatten order (C,H,W), use_model.py:53
+          a3_out[(size_t)q * 2048 + ch * 16 + t * 4 + g4] = fmaxf(v, 0.f);      // flatten order (C,H,W), use_model.py:53; row 4 * ctu + q of the head's input
         }
       }
       __syncthreads();
@@ -379,110 +378,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     CNN_MARK(5);
   }
 
-  // ---- fc1 (2048 -> 256) for the 4 quadrants at once; weights pre-transposed [k][j] ---------------------
-  {
-    // fc1 as 16 independent 4x4 outer products per instruction: v_mfma_f32_4x4x1_16b_f32, block b of lane group
-    // l >> 2: D[quadrant i][channel 4b + j] += x[k][i] * W[k][4b + j]; A = lane (l & 3)'s quadrant activation, B = the
-    // lane's own output channel (weights row k is one coalesced 256-byte read per wave), result register i = quadrant i
-    // of channel 64*wave + lane.  Four accumulator sets (k mod 4) keep dependent MFMAs apart.
-    const float GLB *f1 = W + HEVCDL_W_FC1 + tid;
-    const float LDS *xa = &sm.q.a3[0][lane & 3];
-    v4f acc[4] = { {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0} };
-    // the 2 MB of weights stream from L2 with one wave per SIMD: 64 loads of the next chunk are in flight while the
-    // current chunk's 64 MFMAs run (two register sets of 64)
-    float wa[64], wb[64];
-#pragma unroll
-    for (int u = 0; u < 64; u++) wa[u] = f1[(size_t)u * 256];
-#pragma unroll 1
-    for (int k0 = 0; k0 < 2048; k0 += 128) {
-#pragma unroll
-      for (int u = 0; u < 64; u++) wb[u] = f1[(size_t)(k0 + 64 + u) * 256];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 64; u++) acc[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[(k0 + u) * 4], wa[u], acc[u & 3], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      const int kn = k0 + 128 < 2048 ? k0 + 128 : 0;
-#pragma unroll
-      for (int u = 0; u < 64; u++) wa[u] = f1[(size_t)(kn + u) * 256];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 64; u++) acc[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[(k0 + 64 + u) * 4], wb[u], acc[u & 3], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const v4f r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    const float b = W[HEVCDL_W_FC1 + 2048 * 256 + tid];
-    sm.h1[0][tid] = fmaxf(r.x + b, 0.f); sm.h1[1][tid] = fmaxf(r.y + b, 0.f);
-    sm.h1[2][tid] = fmaxf(r.z + b, 0.f); sm.h1[3][tid] = fmaxf(r.w + b, 0.f);
-  }
-  __syncthreads();
-  CNN_MARK(6);
-  {
-    const float GLB *f2 = W + HEVCDL_W_FC2; const int q = tid >> 6, j = tid & 63;
-    float a = 0;
-#pragma unroll 1
-    for (int k0 = 0; k0 < 256; k0 += 32) {
-      float w[32];
-#pragma unroll
-      for (int u = 0; u < 32; u++) w[u] = f2[(k0 + u) * 64 + j];
-#pragma unroll
-      for (int u = 0; u < 32; u++) a = fmaf(sm.h1[q][k0 + u], w[u], a);
-    }
-    sm.h2[q][j] = fmaxf(a + f2[256 * 64 + j], 0.f);
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const float GLB *f3 = W + HEVCDL_W_FC3; const int q = tid >> 4, j = tid & 15;
-    float a = 0, w[64];
-#pragma unroll
-    for (int u = 0; u < 64; u++) w[u] = f3[u * 16 + j];
-#pragma unroll
-    for (int u = 0; u < 64; u++) a = fmaf(sm.h2[q][u], w[u], a);
-    a += f3[64 * 16 + j];
-    sm.lg[q][j] = a;
-    if (p.logits) ((float GLB *)p.logits)[(size_t)gctu * 64 + q * 16 + j] = a;
-  }
-  __syncthreads();
-
-  // ---- labels: 4x argmax + fix-ups (use_model.py:101-119), then the boundary clamp ---------------------
-  if (tid == 0) {
-    uint8_t lab[16];
-    const int quads[4][4] = { {0, 1, 4, 5}, {2, 3, 6, 7}, {8, 9, 12, 13}, {10, 11, 14, 15} };
-    for (int q = 0; q < 4; q++) {
-      int d[4]; bool any0 = false, all0 = true, any1 = false, all1 = true;
-      for (int k = 0; k < 4; k++) {
-        int best = 0; float bv = sm.lg[q][4 * k];
-        for (int j = 1; j < 4; j++) if (sm.lg[q][4 * k + j] > bv) { bv = sm.lg[q][4 * k + j]; best = j; }   // first maximum wins
-        d[k] = best;
-      }
-      for (int k = 0; k < 4; k++) { any0 |= d[k] == 0; all0 &= d[k] == 0; }
-      if (any0 && !all0) for (int k = 0; k < 4; k++) if (d[k] == 0) d[k] = 1;
-      for (int k = 0; k < 4; k++) { any1 |= d[k] == 1; all1 &= d[k] == 1; }
-      if (any1 && !all1) for (int k = 0; k < 4; k++) if (d[k] == 1) d[k] = 2;
-      bool zero = (d[0] | d[1] | d[2] | d[3]) == 0;
-      if (q == 1 && zero && lab[0] != 0) d[0] = d[1] = d[2] = d[3] = 1;
-      if (q == 2 && zero && lab[2] != 0) d[0] = d[1] = d[2] = d[3] = 1;
-      if (q == 3 && zero && lab[8] != 0) d[0] = d[1] = d[2] = d[3] = 1;
-      for (int k = 0; k < 4; k++) lab[quads[q][k]] = (uint8_t)d[k];
-    }
-    if (p.clamp) {
-      int mxl = 0;
-      for (int c = 0; c < 16; c++) {
-        const int px = x0 + (c & 3) * 16, py = y0 + (c >> 2) * 16;
-        int md = 0;
-        if (px < p.width && py < p.height) {
-          while (md < 3) { const int s = 64 >> md; if ((px / s) * s + s <= p.width && (py / s) * s + s <= p.height) break; md++; }
-        }
-        if (lab[c] < md) lab[c] = (uint8_t)md;
-        if (lab[c] > mxl) mxl = lab[c];
-      }
-      if (mxl > 0) for (int c = 0; c < 16; c++) if (lab[c] < 1) lab[c] = 1;
-      for (int q = 0; q < 4; q++) {
-        int m = 0; for (int k = 0; k < 4; k++) if (lab[quads[q][k]] > m) m = lab[quads[q][k]];
-        if (m >= 2) for (int k = 0; k < 4; k++) if (lab[quads[q][k]] < 2) lab[quads[q][k]] = 2;
-      }
-    }
-    for (int c = 0; c < 16; c++) ((uint8_t GLB *)p.labels)[(size_t)gctu * 16 + c] = lab[c];
-  }
+  // the fully connected head (fc1..fc3) and the label logic run batched over CTUs in fc_kernel.hip
 #ifdef HEVCDL_CNN_PROF
   CNN_MARK(7);
   if (tid == 0 && gctu == 0 && p.logits) for (int i = 0; i < 8; i++) ((float GLB *)p.logits)[i] = (float)pt_[i];

@@ -4,11 +4,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "hevcdl.h"
 #include "hevcdl_dev.h"
 
 extern "C" __global__ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p);
+extern "C" __global__ void hevcdl_fc_kernel(hevcdl_fc_params p);          // fc_kernel.hip: fully connected head + labels, 16 CTUs per workgroup
 extern "C" __global__ void hevcdl_rd_frame_kernel(hevcdl_rd_params p);
 extern "C" __global__ void hevcdl_rd_frame_kernel_bd10(hevcdl_rd_params p);       // rd_kernel_bd10.hip: the same kernel for uint16 samples
 extern "C" size_t hevcdl_rd_smem_bytes_bd10(void);
@@ -31,6 +33,7 @@ struct hevcdl_ctx {
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
   uint8_t *d_yuv8;               // 8-bit copy of 10-bit input for the CNN stage
+  float *d_a3; size_t a3_ctus;   // conv3 outputs of one chunk of CTUs (32 KB per CTU): the hand-over from the conv kernel to the head kernel
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
@@ -146,7 +149,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -163,6 +166,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   ctx->scratch_per_frame = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
   CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames * cfg->tile_columns * cfg->tile_rows));    // one workspace per (frame, tile) wave
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
+  CK(hipFuncSetAttribute((const void *)hevcdl_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_fc_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0)));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_bd10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_bd10()));
 #undef CK
@@ -178,7 +182,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
   delete ctx;
 }
 
@@ -211,8 +215,25 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   p.input = (const uint8_t *)d_in; p.weights = ctx->d_weights; p.labels = (uint8_t *)d_labels; p.logits = (float *)d_logits;
   p.input_mode = mode; p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.clamp = clamp;
   if (mode == HEVCDL_DEV_INPUT_RGB_CTU) { p.ctus_per_frame = n_ctus > 0 ? n_ctus : 1; p.ctus_x = p.ctus_per_frame; }
+  // convolutions per CTU (one workgroup each) -> 32 KB of conv3 output per CTU in HBM -> the fully connected head batched over 16 CTUs
+  // per workgroup.  The hand-over buffer holds one chunk of CTUs (<= 4 GiB); larger batches go through it chunk by chunk.
+  const size_t chunk = (size_t)std::min<long long>(n_ctus, 131072);
+  if (ctx->a3_ctus < chunk) { hipFree(ctx->d_a3); ctx->d_a3 = nullptr; ctx->a3_ctus = 0; HIPCHK(hipMalloc(&ctx->d_a3, chunk * 4 * 2048 * sizeof(float))); ctx->a3_ctus = chunk; }
+  p.a3 = ctx->d_a3;
+  hevcdl_fc_params f;
+  f.a3 = ctx->d_a3; f.weights = ctx->d_weights; f.width = p.width; f.height = p.height; f.ctus_x = p.ctus_x; f.ctus_per_frame = p.ctus_per_frame; f.clamp = clamp;
   prof_begin(ctx, ctx->ev_cnn, s);
-  hipLaunchKernelGGL(hevcdl_cnn_ctu_kernel, dim3(n_ctus), dim3(256), hevcdl_cnn_smem_bytes(), s, p);
+  for (size_t base = 0; base < (size_t)n_ctus; base += chunk) {
+    const int n = (int)std::min<size_t>(chunk, (size_t)n_ctus - base);
+    p.ctu_base = (int)base;
+    hipLaunchKernelGGL(hevcdl_cnn_ctu_kernel, dim3(n), dim3(256), hevcdl_cnn_smem_bytes(), s, p);
+    f.n_ctus = n; f.ctu_base = (int)base; f.labels = (uint8_t *)d_labels + base * 16;
+    f.logits = d_logits ? (float *)d_logits + base * 64 : nullptr;
+#ifdef HEVCDL_CNN_PROF
+    f.logits = nullptr;              // the profiling build returns the conv kernel's phase timers through the logits buffer
+#endif
+    hipLaunchKernelGGL(hevcdl_fc_kernel, dim3((n + 15) / 16), dim3(256), hevcdl_fc_smem_bytes(), s, f);
+  }
   prof_end(ctx, ctx->ev_cnn, s);
   HIPCHK(hipGetLastError());
   return HEVCDL_OK;

@@ -25,6 +25,17 @@ struct hevcdl_cnn_params {
   uint8_t *labels;                 // [ctu][16]
   float *logits;                   // [ctu][4][16] or NULL
   int input_mode, width, height, ctus_x, ctus_per_frame, clamp;
+  float *a3;                       // [ctu of the launch][4 quadrants][2048]: flattened conv3 output = input rows of the fully connected head
+  int ctu_base;                    // global index of the launch's first CTU
+};
+
+// fully connected head + labels (fc_kernel.hip), 16 CTUs per workgroup
+struct hevcdl_fc_params {
+  const float *a3;                 // [n_ctus * 4][2048]
+  const float *weights;
+  uint8_t *labels;                 // [n_ctus][16] of this launch
+  float *logits;                   // [n_ctus][4][16] of this launch, or NULL
+  int n_ctus, ctu_base, width, height, ctus_x, ctus_per_frame, clamp;
 };
 
 // decision constants (bit patterns computed on the host, see include/hevcdl.h)
@@ -101,6 +112,7 @@ extern "C" {
 void hevcdl_launch_sao(const struct hevcdl_sao_params *p, void *stream);
 void hevcdl_launch_deblock(const struct hevcdl_dbk_params *p, void *stream);
 size_t hevcdl_cnn_smem_bytes(void);
+size_t hevcdl_fc_smem_bytes(void);
 size_t hevcdl_rd_smem_bytes(void);
 size_t hevcdl_rd_scratch_bytes(void);
 #ifdef __cplusplus
