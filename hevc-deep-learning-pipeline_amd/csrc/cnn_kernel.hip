@@ -22,6 +22,9 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifndef HEVCDL_CNN_SKEW
+#define HEVCDL_CNN_SKEW 40            // start offset of the second workgroup of a CU, in units of 8128 cycles (see the kernel)
+#endif
 #define LDS __attribute__((address_space(3)))
 #define GLB __attribute__((address_space(1)))
 
@@ -29,16 +32,15 @@ constexpr int A_CH = 328;                  // 18x18 halo'd 16x16 map, channel st
 constexpr int A_ROW = 18;
 constexpr int A2_CH = 104;                 // 10x10 halo'd 8x8 map
 constexpr int A2_ROW = 10;
-constexpr int T64_ROW = 72, T64_CH = 68 * 72;   // fp32 input tile of the CTU, halo 2, row pitch == 8 (mod 32)
+constexpr int T64_ROW = 72, T64_CH = 36 * 72;   // fp32 input tile of HALF the CTU (32 rows + halo 2; conv64 runs in two halves), row pitch == 8 (mod 32)
 constexpr int T32_ROW = 40, T32_CH = 36 * 40;   // fp32 input tile of one quadrant, halo 2
 
 struct CnnSmem {
-  uint8_t in[3][64][64];                   // RGB planes of the CTU (zero past the picture edge)
   float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95)
   int koff64[76], koff32[76];              // im2col offset of tap k = (c*5+ky)*5+kx inside the input tiles
   float act12[32 * A_CH];                  // conv1 output (channels 0..15) ++ conv64 output (16..31): cat of use_model.py:50
   union {
-    float t64[3 * T64_CH];                 // conv64 input tile (only live before the quadrant loop)
+    float t64[3 * T64_CH];                 // conv64 input tile of one half of the CTU (only live before the quadrant loop)
     struct {
       union { float t32[3 * T32_CH]; float a2[64 * A2_CH]; };   // conv1 input tile | conv2 output
     } q;
@@ -73,11 +75,14 @@ __device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin
 // M-tile = 4 horizontally adjacent 2x2 windows, lane group g = lane >> 4 ends up with window g in its 4 registers.
 // The pooled extreme (max for gamma >= 0, min otherwise) is written straight into the halo'd destination map and
 // rescaled in place once the statistics of the whole map are known.
+// phase 0: the whole map in one call (conv1 on a quadrant).  phase 1 / 2: upper / lower half of the CTU for conv64 (tile rows are then
+// relative to the half); the statistics of the halves meet in sm.red and the map is normalised after the second.
 template <int POOL>
-__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *out, int tid)
+__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *out, int tid, int phase)
 {
   constexpr int ROW = (POOL == 4) ? T64_ROW : T32_ROW;
-  constexpr int TILES = (POOL == 4) ? 64 : 16;      // per wave
+  constexpr int TILES = (POOL == 4) ? 32 : 16;      // per wave and call
+  const int tile0 = (phase == 2) ? 128 : 0, yoff = (phase == 2) ? 32 : 0;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
   float bw[19];
 #pragma unroll
@@ -92,9 +97,9 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     v4f acc[4]; int base[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int t = wave * TILES + t0 + u;
+      const int t = tile0 + wave * TILES + t0 + u;
       int y, x;
-      if (POOL == 4) { y = 4 * (t >> 4) + (i >> 2); x = 4 * (t & 15) + (i & 3); }
+      if (POOL == 4) { y = 4 * (t >> 4) + (i >> 2) - yoff; x = 4 * (t & 15) + (i & 3); }
       else { y = 2 * (t >> 2) + ((i >> 1) & 1); x = 2 * (4 * (t & 3) + (i >> 2)) + (i & 1); }
       base[u] = y * ROW + x;
       acc[u] = (v4f){ bias, bias, bias, bias };
@@ -118,7 +123,7 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int t = wave * TILES + t0 + u;
+      const int t = tile0 + wave * TILES + t0 + u;
       const v4f a = acc[u];
       s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
       ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
@@ -132,8 +137,9 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
   }
   // per-channel statistics over the whole map: lane groups, then waves
   s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
-  if (lane < 16) { sm.red[0][wave][lane] = s; sm.red[1][wave][lane] = ss; }
+  if (lane < 16) { if (phase == 2) { sm.red[0][wave][lane] += s; sm.red[1][wave][lane] += ss; } else { sm.red[0][wave][lane] = s; sm.red[1][wave][lane] = ss; } }
   __syncthreads();
+  if (phase == 1) return;                 // the lower half follows (the barrier above also frees the tile for it)
   if (tid < 16) {
     double a = 0, b = 0;
     for (int k = 0; k < 4; k++) { a += sm.red[0][k][tid]; b += sm.red[1][k][tid]; }
@@ -153,7 +159,9 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
 
 } // namespace
 
-extern "C" __global__ __launch_bounds__(256)
+// 75.9 KB of LDS and at most 256 registers per lane: two workgroups (8 waves) share a CU, so the MFMA phases of one overlap the
+// tile fills, statistics and weight fetches of the other
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -164,6 +172,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
   const int frame = gctu / p.ctus_per_frame, addr = gctu - frame * p.ctus_per_frame;
   const int x0 = (addr % p.ctus_x) * 64, y0 = (addr / p.ctus_x) * 64;
   const float GLB *W = (const float GLB *)p.weights;
+  // Two workgroups share a CU, and every CTU takes the same time: started together they would stay in lockstep -- both in their MFMA phases,
+  // then both in their fill / statistics phases.  The workgroup that landed in the second wave slot of its SIMDs (HW_ID.wave_id, measured
+  // with tools/hwid_probe.hip: blocks 0..255 take slot 0, blocks 256..511 slot 1 of the same CUs) starts about half a CTU time late; the
+  // offset then carries through the whole launch because slots are refilled as they drain.  (-17 % kernel time.)
+  if ((int)blockIdx.x < 2 * p.n_cus && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1))      // HW_REG_HW_ID[3:0] = wave slot
+    for (int it = 0; it < HEVCDL_CNN_SKEW; it++) __builtin_amdgcn_s_sleep(127);                         // x 8128 cycles
   float GLB *a3_out = (float GLB *)p.a3 + (size_t)blockIdx.x * (4 * 2048);      // this CTU's 4 rows of the fully connected head's input (fc_kernel.hip)
 #ifdef HEVCDL_CNN_PROF
   unsigned long long pt_[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_readcyclecounter();
@@ -178,50 +192,44 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     const int k = tid < 75 ? tid : 0, c = k / 25, r = k - c * 25, ky = r / 5, kx = r - ky * 5;   // tap 75 is padding (zero weight)
     sm.koff64[tid] = c * T64_CH + ky * T64_ROW + kx; sm.koff32[tid] = c * T32_CH + ky * T32_ROW + kx;
   }
-  if (p.input_mode == HEVCDL_DEV_INPUT_RGB_CTU) {
-    const uint8_t GLB *src = (const uint8_t GLB *)p.input + (size_t)gctu * (64 * 64 * 3);
-    for (int i = tid; i < 64 * 64 * 3; i += 256) { int pix = i / 3, c = i - pix * 3; sm.in[c][pix >> 6][pix & 63] = src[i]; }
-  } else {
-    const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
-    const uint8_t GLB *Y = (const uint8_t GLB *)p.input + (size_t)frame * fsz, *U = Y + ysz, *V = U + (ysz >> 2);
-    const int cw = p.width >> 1;
-    for (int i = tid; i < 64 * 64; i += 256) {
-      const int y = i >> 6, x = i & 63, gx = x0 + x, gy = y0 + y;
-      int r = 0, g = 0, b = 0;
-      if (gx < p.width && gy < p.height) {
-        const int yv = Y[(size_t)gy * p.width + gx];
-        if (p.input_mode == HEVCDL_DEV_INPUT_LUMA) { r = g = b = yv; }
-        else {
-          const int d = (int)U[(size_t)(gy >> 1) * cw + (gx >> 1)] - 128, e = (int)V[(size_t)(gy >> 1) * cw + (gx >> 1)] - 128, c = yv - 16;
-          r = (298 * c + 409 * e + 128) >> 8; g = (298 * c - 100 * d - 208 * e + 128) >> 8; b = (298 * c + 516 * d + 128) >> 8;
-          r = r < 0 ? 0 : (r > 255 ? 255 : r); g = g < 0 ? 0 : (g > 255 ? 255 : g); b = b < 0 ? 0 : (b > 255 ? 255 : b);
-        }
+  // The CTU's RGB samples are read from HBM where a tile is filled (twice per sample: conv64's half tile and conv1's quadrant tile);
+  // YUV input is converted on the fly (BT.601 limited range, nearest chroma), samples past the picture edge are 0.
+  const size_t ysz_ = (size_t)p.width * p.height, fsz_ = ysz_ + (ysz_ >> 1);
+  const uint8_t GLB *srcRGB = (const uint8_t GLB *)p.input + (size_t)gctu * (64 * 64 * 3);
+  const uint8_t GLB *Yp = (const uint8_t GLB *)p.input + (size_t)frame * fsz_, *Up = Yp + ysz_, *Vp = Up + (ysz_ >> 2);
+  auto pixel = [&](int x, int y, int &r, int &g, int &b) {
+    if (p.input_mode == HEVCDL_DEV_INPUT_RGB_CTU) { const uint8_t GLB *q = srcRGB + (y * 64 + x) * 3; r = q[0]; g = q[1]; b = q[2]; return; }
+    const int gx = x0 + x, gy = y0 + y, cw = p.width >> 1;
+    r = g = b = 0;
+    if (gx < p.width && gy < p.height) {
+      const int yv = Yp[(size_t)gy * p.width + gx];
+      if (p.input_mode == HEVCDL_DEV_INPUT_LUMA) { r = g = b = yv; }
+      else {
+        const int d = (int)Up[(size_t)(gy >> 1) * cw + (gx >> 1)] - 128, e = (int)Vp[(size_t)(gy >> 1) * cw + (gx >> 1)] - 128, c = yv - 16;
+        r = (298 * c + 409 * e + 128) >> 8; g = (298 * c - 100 * d - 208 * e + 128) >> 8; b = (298 * c + 516 * d + 128) >> 8;
+        r = r < 0 ? 0 : (r > 255 ? 255 : r); g = g < 0 ? 0 : (g > 255 ? 255 : g); b = b < 0 ? 0 : (b > 255 ? 255 : b);
       }
-      sm.in[0][y][x] = (uint8_t)r; sm.in[1][y][x] = (uint8_t)g; sm.in[2][y][x] = (uint8_t)b;
     }
-  }
+  };
   // zero halos only: the interiors of the maps / tiles are rewritten before they are read
   for (int i = tid; i < 32 * 72; i += 256) {                       // 18x18 map + 4 pad words: 68 border words + 4 = 72 per channel
     const int c = i / 72, r = i - c * 72;
     const int o = r < 18 ? r : (r < 36 ? 17 * 18 + (r - 18) : (r < 52 ? (r - 35) * 18 : (r < 68 ? (r - 51) * 18 + 17 : 324 + (r - 68))));
     sm.act12[c * A_CH + o] = 0.f;
   }
-  for (int i = tid; i < 3 * (4 * T64_ROW + 64 * 8); i += 256) {       // 2 rows top + 2 bottom (full pitch), 64 rows x (2 left + 2+4 right incl. pitch padding)
-    const int c = i / (4 * T64_ROW + 512), r = i - c * (4 * T64_ROW + 512);
-    int o;
-    if (r < 2 * T64_ROW) o = r; else if (r < 4 * T64_ROW) o = 66 * T64_ROW + (r - 2 * T64_ROW);
-    else { const int q = r - 4 * T64_ROW, y = q >> 3, k = q & 7; o = (y + 2) * T64_ROW + (k < 2 ? k : 64 + k); }
-    sm.t64[c * T64_CH + o] = 0.f;
-  }
-  for (int i = tid; i < 3 * 64 * 64; i += 256) {
-    const int c = i >> 12, y = (i >> 6) & 63, x = i & 63;
-    sm.t64[c * T64_CH + (y + 2) * T64_ROW + x + 2] = sm.lut[sm.in[c][y][x]];
-  }
   __syncthreads();
-
   CNN_MARK(0);
-  // ---- conv64 branch, once per CTU (use_model.py:38-43) --------------------------------------------
-  conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12 + 16 * A_CH, tid);
+  // ---- conv64 branch, once per CTU (use_model.py:38-43), in two halves of 32 rows: the tile holds input rows 32h - 2 .. 32h + 33 ----
+  for (int h = 0; h < 2; h++) {
+    for (int i = tid; i < 36 * T64_ROW; i += 256) {
+      const int r = i / T64_ROW, cc = i - r * T64_ROW, x = cc - 2, y = 32 * h - 2 + r;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (x >= 0 && x < 64 && y >= 0 && y < 64) { int rr, gg, bb; pixel(x, y, rr, gg, bb); v0 = sm.lut[rr]; v1 = sm.lut[gg]; v2 = sm.lut[bb]; }
+      sm.t64[i] = v0; sm.t64[T64_CH + i] = v1; sm.t64[2 * T64_CH + i] = v2;
+    }
+    __syncthreads();
+    conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12 + 16 * A_CH, tid, h + 1);
+  }
 
   CNN_MARK(1);
   const int i16 = lane & 15, g4 = lane >> 4;
@@ -235,13 +243,15 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       else { const int q2 = r - 4 * T32_ROW, y = q2 >> 3, k = q2 & 7; o = (y + 2) * T32_ROW + (k < 2 ? k : 32 + k); }
       sm.q.t32[c * T32_CH + o] = 0.f;
     }
-    for (int i = tid; i < 3 * 32 * 32; i += 256) {
-      const int c = i >> 10, y = (i >> 5) & 31, x = i & 31;
-      sm.q.t32[c * T32_CH + (y + 2) * T32_ROW + x + 2] = sm.lut[sm.in[c][(q >> 1) * 32 + y][(q & 1) * 32 + x]];
+    for (int i = tid; i < 32 * 32; i += 256) {
+      const int y = i >> 5, x = i & 31;
+      int rr, gg, bb; pixel((q & 1) * 32 + x, (q >> 1) * 32 + y, rr, gg, bb);
+      float LDS *d = sm.q.t32 + (y + 2) * T32_ROW + x + 2;
+      d[0] = sm.lut[rr]; d[T32_CH] = sm.lut[gg]; d[2 * T32_CH] = sm.lut[bb];
     }
     __syncthreads();
     CNN_MARK(2);
-    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, tid);
+    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, tid, 0);
     CNN_MARK(3);
     for (int i = tid; i < 64 * 40; i += 256) {                        // the input tile is dead: zero the halo of conv2's output (36 border words + 4 pad per channel)
       const int c = i / 40, r = i - c * 40;

@@ -24,7 +24,7 @@ __global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, 
 
 struct hevcdl_ctx {
   hevcdl_config cfg;
-  int ctus_x, ctus_y, ctus;
+  int ctus_x, ctus_y, ctus, n_cus;
   int col_bd[21], row_bd[23];    // tile boundaries in CTUs
   size_t frame_bytes;
   float *d_weights;
@@ -153,6 +153,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
+  { hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, cfg->device)); ctx->n_cus = prop.multiProcessorCount; }
   std::vector<float> pk(HEVCDL_W_TOTAL);
   pack_conv5(weights + B_C1W, weights + B_C1B, weights + B_C1G, weights + B_C1BE, pk.data() + HEVCDL_W_C1);
   pack_conv5(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, pk.data() + HEVCDL_W_C64);
@@ -219,7 +220,7 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   // per workgroup.  The hand-over buffer holds one chunk of CTUs (<= 4 GiB); larger batches go through it chunk by chunk.
   const size_t chunk = (size_t)std::min<long long>(n_ctus, 131072);
   if (ctx->a3_ctus < chunk) { hipFree(ctx->d_a3); ctx->d_a3 = nullptr; ctx->a3_ctus = 0; HIPCHK(hipMalloc(&ctx->d_a3, chunk * 4 * 2048 * sizeof(float))); ctx->a3_ctus = chunk; }
-  p.a3 = ctx->d_a3;
+  p.a3 = ctx->d_a3; p.n_cus = ctx->n_cus;
   hevcdl_fc_params f;
   f.a3 = ctx->d_a3; f.weights = ctx->d_weights; f.width = p.width; f.height = p.height; f.ctus_x = p.ctus_x; f.ctus_per_frame = p.ctus_per_frame; f.clamp = clamp;
   prof_begin(ctx, ctx->ev_cnn, s);

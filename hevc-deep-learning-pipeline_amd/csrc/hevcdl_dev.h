@@ -27,6 +27,7 @@ struct hevcdl_cnn_params {
   int input_mode, width, height, ctus_x, ctus_per_frame, clamp;
   float *a3;                       // [ctu of the launch][4 quadrants][2048]: flattened conv3 output = input rows of the fully connected head
   int ctu_base;                    // global index of the launch's first CTU
+  int n_cus;                       // compute units of the device (first-generation workgroups = 2 per CU)
 };
 
 // fully connected head + labels (fc_kernel.hip), 16 CTUs per workgroup
