@@ -232,7 +232,7 @@ def main():
         rd_avg_s = (prof["rd_ms"] / max(1, prof["rd_launches"])) / 1e3
         achieved = (ALGO_BYTES_PER_CTU * F * ctus / rd_avg_s) / 1e9 if rd_avg_s > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01i_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01k_traffic.json")
         if os.path.exists(tpath):   # PMC counters cannot be collected from inside the process: per-CTU bytes of the committed rocprofv3 passes
             tj = json.load(open(tpath))
             traffic = (tj["fetch_bytes_per_ctu"] + tj["write_bytes_per_ctu"]) * F * ctus
