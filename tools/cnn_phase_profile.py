@@ -7,7 +7,7 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
 import numpy as np, hevcdl_amd, ref_tools
 yuv=ref_tools.synth_yuv(1920,1080,4,seed=1)
 enc=hevcdl_amd.Encoder(1920,1080,32,max_frames=4); lab,lg=enc.predict_depth(yuv,want_logits=True)
-names=['input+tiles','conv64','conv1 tile x4','conv1 x4','conv2 x4','conv3 x4','fc1','fc2+fc3+labels']
+names=['prologue','conv64 (2 halves, tiles incl.)','conv1 tile x4','conv1 x4','conv2 x4','conv3 x4','-','epilogue']   # the fully connected head is fc_kernel.hip
 v=lg.reshape(-1)[:8]; tot=v.sum()
 for n,c in zip(names,v): print('%-18s %10.0f cycles %5.1f%%'%(n,c,100*c/tot))
 print('total %.0f cycles (all CUs busy: 2040 CTUs per frame)'%tot)
