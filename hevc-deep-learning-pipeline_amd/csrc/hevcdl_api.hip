@@ -168,6 +168,10 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames * cfg->tile_columns * cfg->tile_rows));    // one workspace per (frame, tile) wave
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_fc_smem_bytes()));
+  { // conv -> head hand-over buffer for one chunk of CTUs, allocated up front so that no step pays for it
+    const size_t chunk = (size_t)std::min<long long>((long long)cfg->max_frames * ctx->ctus, 131072);
+    CK(hipMalloc(&ctx->d_a3, chunk * 4 * 2048 * sizeof(float))); ctx->a3_ctus = chunk;
+  }
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0)));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_bd10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_bd10()));
 #undef CK
