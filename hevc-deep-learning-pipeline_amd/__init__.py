@@ -161,6 +161,7 @@ def load_library():
     lib.hevcdl_compress_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_encode_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_compress_tiles_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, ci, vp]
+    lib.hevcdl_encode_pictures.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, vp]
     lib.hevcdl_profile_enable.argtypes = [vp, ci]
     lib.hevcdl_profile_get.argtypes = [vp, ctypes.POINTER(Profile)]
     lib.hevcdl_ctus_per_frame.argtypes = [ci, ci]
@@ -175,7 +176,7 @@ def load_library():
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
+           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_encode_pictures", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5"]
 
@@ -307,6 +308,22 @@ class Encoder:
             lab_ptr = labels.ctypes.data
         self._check(self.lib.hevcdl_compress_frames(self._h, yuv.ctypes.data, n, lab_ptr, recs.ctypes.data, recon.ctypes.data, stats.ctypes.data))
         return recs, recon, stats
+
+    def encode_pictures(self, yuv, labels=None, deblock=True, sao=True):
+        """Whole picture pipeline in one call (the pictures stay in HBM between the stages) -> (records [n, ctus], output pictures [n, samples],
+        SAO parameters [n, ctus, 3] or None, stats [n])."""
+        yuv, n = self._frames(yuv)
+        recs = np.zeros((n, self.ctus), REC_DTYPE)
+        out = np.zeros_like(yuv)
+        stats = np.zeros(n, STATS_DTYPE)
+        params = np.zeros((n, self.ctus, 3), SAO_DTYPE) if sao else None
+        lab_ptr = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, np.uint8).reshape(n, self.ctus, 16)
+            lab_ptr = labels.ctypes.data
+        self._check(self.lib.hevcdl_encode_pictures(self._h, yuv.ctypes.data, n, lab_ptr, int(bool(deblock)), recs.ctypes.data, out.ctypes.data,
+                                                    params.ctypes.data if sao else None, stats.ctypes.data))
+        return recs, out, params, stats
 
     # ---- deblocking filter (TComLoopFilter::loopFilterPic) ----
     def deblock_frames(self, recon, records):

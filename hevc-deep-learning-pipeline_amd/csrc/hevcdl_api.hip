@@ -33,6 +33,7 @@ struct hevcdl_ctx {
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
   uint8_t *d_yuv8;               // 8-bit copy of 10-bit input for the CNN stage
+  uint8_t *d_picture;            // final pictures of hevcdl_encode_pictures (SAO output)
   float *d_a3; size_t a3_ctus;   // conv3 outputs of one chunk of CTUs (32 KB per CTU): the hand-over from the conv kernel to the head kernel
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
@@ -149,7 +150,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -187,7 +188,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
   delete ctx;
 }
 
@@ -463,6 +464,34 @@ extern "C" hevcdl_status hevcdl_sao_frames(hevcdl_ctx *ctx, const uint8_t *org, 
   if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "sao kernels", e);
   HIPCHK(hipMemcpy(params, ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * n_frames, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(out, ctx->d_records, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
+// ---- whole picture pipeline for host buffers: the stages of TEncGOP::compressGOP between reading a picture and writing its NAL units, with
+// the picture staying in HBM in between (one upload of the originals, one download of records / final picture / SAO parameters) ----------
+extern "C" hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, hevcdl_ctu_record *records,
+                                                void *picture_out, hevcdl_sao_blk *sao_opt, hevcdl_frame_stats *stats_opt)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!yuv || !records || !picture_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  if (sao_opt && !deblock) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "SAO runs on the deblocked picture only");
+  st = ensure_staging(ctx); if (st) return st;
+  if (sao_opt && !ctx->d_sao_params) HIPCHK(hipMalloc(&ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * ctx->cfg.max_frames));
+  if (sao_opt && !ctx->d_picture) HIPCHK(hipMalloc(&ctx->d_picture, ctx->frame_bytes * (size_t)ctx->cfg.max_frames));
+  HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice));
+  else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
+  st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;
+  uint8_t *d_final = ctx->d_recon;
+  if (deblock) { st = hevcdl_deblock_frames_dev(ctx, ctx->d_recon, n_frames, ctx->d_records, ctx->d_recon, nullptr); if (st) return st; }      // in place
+  if (sao_opt) { st = hevcdl_sao_frames_dev(ctx, ctx->d_yuv, ctx->d_recon, n_frames, ctx->d_sao_params, ctx->d_picture, nullptr); if (st) return st; d_final = ctx->d_picture; }
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "picture pipeline", e);
+  HIPCHK(hipMemcpy(records, ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(picture_out, d_final, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
+  if (sao_opt) HIPCHK(hipMemcpy(sao_opt, ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * n_frames, hipMemcpyDeviceToHost));
+  if (stats_opt) HIPCHK(hipMemcpy(stats_opt, ctx->d_stats, sizeof(hevcdl_frame_stats) * n_frames, hipMemcpyDeviceToHost));
   return HEVCDL_OK;
 }
 

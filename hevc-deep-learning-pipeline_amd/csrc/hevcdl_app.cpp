@@ -266,13 +266,10 @@ int main(int argc, char **argv)
     if (rc) break;
     bool filtered = false;
     const auto t0 = std::chrono::steady_clock::now();
-    st = hevcdl_compress_frames(ctx, yuv.data(), nb, lab, recs.data(), recon.data(), stats.data());
+    // CNN -> decisions -> deblocking (TEncGOP.cpp:1742) -> SAO (:1797) in one call: the pictures stay in HBM between the stages
+    st = hevcdl_encode_pictures(ctx, yuv.data(), nb, lab, deblock ? 1 : 0, recs.data(), recon.data(), sao ? sao_params.data() : nullptr, stats.data());
     const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / nb;
-    if (st == HEVCDL_OK && deblock) { // TComLoopFilter::loopFilterPic (TEncGOP.cpp:1742); the picture statistics follow the filtered picture
-      st = hevcdl_deblock_frames(ctx, recon.data(), nb, recs.data(), recon.data());
-      if (st == HEVCDL_OK && sao) st = hevcdl_sao_frames(ctx, yuv.data(), recon.data(), nb, sao_params.data(), recon.data());   // TEncGOP.cpp:1797
-      filtered = true;                      // the picture statistics follow the filtered picture: recomputed per picture below
-    }
+    filtered = deblock;                       // the picture statistics follow the filtered picture: recomputed per picture below
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
     // per picture on the host: SSE of the output picture, the access unit (the arithmetic coder: ~35 ms for a 2160p picture), the
     // picture hash.  Pictures are independent: a pool of threads fills per-picture results, the output stays in POC order.

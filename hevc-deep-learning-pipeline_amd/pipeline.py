@@ -65,9 +65,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
             yuv = read_frames(input_path, width, height, frame_skip + b0, nb, bit_depth)
             t0 = time.time()
             labels = labels_fn(b0, nb) if labels_fn else None
-            recs, recon, _ = enc.compress_frames(yuv, labels)
-            dbk = enc.deblock_frames(recon, recs)
-            sao, final = enc.sao_frames(yuv, dbk)
+            recs, final, sao, _ = enc.encode_pictures(yuv, labels)          # CNN -> decisions -> deblocking -> SAO, pictures stay in HBM
             et = (time.time() - t0) / nb
             def one_picture(i):          # host work of a picture (arithmetic coder, hash, SSE): independent -> thread pool (ctypes drops the GIL)
                 au = write_access_unit(width, height, qp, b0 + i, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth)
