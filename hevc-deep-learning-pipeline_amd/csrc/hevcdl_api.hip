@@ -15,6 +15,7 @@ extern "C" __global__ void hevcdl_rd_frame_kernel(hevcdl_rd_params p);
 extern "C" __global__ void hevcdl_rd_frame_kernel_bd10(hevcdl_rd_params p);       // rd_kernel_bd10.hip: the same kernel for uint16 samples
 extern "C" size_t hevcdl_rd_smem_bytes_bd10(void);
 extern "C" size_t hevcdl_rd_scratch_bytes_bd10(void);
+extern "C" int hevcdl_rd_waves_per_group(void);
 
 // 10-bit samples -> the 8-bit planes the CNN stage reads (the reference's label producer works on 8-bit frames: gen_frames.py)
 __global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, size_t n, int shift)
@@ -28,8 +29,8 @@ struct hevcdl_ctx {
   int col_bd[21], row_bd[23];    // tile boundaries in CTUs
   size_t frame_bytes;
   float *d_weights;
-  unsigned char *d_scratch;      // RD per-frame workspace
-  size_t scratch_per_frame;
+  unsigned char *d_scratch;      // decision kernel workspace: one block per wave of every workgroup a launch can have
+  size_t scratch_per_wave; int rd_groups;   // workgroups of a launch: one per CU, fewer when the context cannot hold that many units
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
   uint8_t *d_yuv8;               // 8-bit copy of 10-bit input for the CNN stage
@@ -165,15 +166,16 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
-  ctx->scratch_per_frame = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
-  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_frame * (size_t)cfg->max_frames * cfg->tile_columns * cfg->tile_rows));    // one workspace per (frame, tile) wave
+  ctx->scratch_per_wave = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
+  ctx->rd_groups = (int)std::min<long long>(ctx->n_cus, (long long)cfg->max_frames * cfg->tile_columns * cfg->tile_rows);
+  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_wave * (size_t)ctx->rd_groups * hevcdl_rd_waves_per_group()));
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_fc_smem_bytes()));
   { // conv -> head hand-over buffer for one chunk of CTUs, allocated up front so that no step pays for it
     const size_t chunk = (size_t)std::min<long long>((long long)cfg->max_frames * ctx->ctus, 131072);
     CK(hipMalloc(&ctx->d_a3, chunk * 4 * 2048 * sizeof(float))); ctx->a3_ctus = chunk;
   }
-  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0)));
+  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_bd10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_bd10()));
 #undef CK
   *out = ctx;
@@ -246,14 +248,14 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
 }
 
 static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s,
-                               int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr, void *d_scratch = nullptr,
+                               int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr,
                                int tile_begin = 0, int tile_count = -1)
 {
   hevcdl_rd_params p;
   memset(&p, 0, sizeof p);
   p.ctu_begin = ctu_begin; p.ctu_end = ctu_end < 0 ? ctx->ctus : ctu_end; p.cabac_in = (const unsigned char *)d_cabac_in; p.cabac_out = (unsigned char *)d_cabac_out;
   p.yuv = (const uint8_t *)d_yuv; p.labels = (const uint8_t *)d_labels; p.records = (unsigned char *)d_records; p.recon = (uint8_t *)d_recon;
-  p.stats = (unsigned char *)d_stats; p.scratch = d_scratch ? (unsigned char *)d_scratch : ctx->d_scratch; p.scratch_per_frame = ctx->scratch_per_frame;
+  p.stats = (unsigned char *)d_stats; p.scratch = ctx->d_scratch; p.scratch_per_wave = ctx->scratch_per_wave;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_y = ctx->ctus_y; p.n_frames = n_frames;
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
   memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);
@@ -263,22 +265,27 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
   p.k.sbh_rd_factor[0] = ctx->cfg.sbh_rd_factor[0]; p.k.sbh_rd_factor[1] = ctx->cfg.sbh_rd_factor[1];
   p.k.qp = ctx->cfg.qp; p.k.qp_chroma = ctx->cfg.qp_chroma;
-  p.debug = getenv("HEVCDL_DEBUG") ? atoi(getenv("HEVCDL_DEBUG")) : 0;
-  unsigned int *d_dbg = nullptr;
-  if (getenv("HEVCDL_DBGBUF")) { hipMalloc(&d_dbg, 8004 * 4); hipMemset(d_dbg, 0, 8004 * 4); p.dbgbuf = d_dbg; }
+#if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)
+  unsigned int *d_dbg = nullptr;               // instrumented builds only (tools/phase_profile.py): in-kernel timers / traces come back through this buffer
+  HIPCHK(hipMalloc(&d_dbg, 8004 * 4)); HIPCHK(hipMemset(d_dbg, 0, 8004 * 4)); p.dbgbuf = d_dbg;
+#endif
+  // One workgroup (hevcdl_rd_waves_per_group() wavefronts, the whole LDS) per CU; the units (frame x tile) are dealt round-robin to the
+  // workgroups, a wave per unit; waves left without a unit help the others (rd_kernel.hip).
+  const int n_units = n_frames * p.tile_count, groups = std::min(n_units, ctx->rd_groups), threads = 64 * hevcdl_rd_waves_per_group();
   prof_begin(ctx, ctx->ev_rd, s);
-  // HEVCDL_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the number of resident waves per CU
   if (ctx->cfg.bit_depth == 8)
-    hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(n_frames * p.tile_count), dim3(64), hevcdl_rd_smem_bytes() + (getenv("HEVCDL_LDS_PAD") ? atoi(getenv("HEVCDL_LDS_PAD")) : 0), s, p);
+    hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), hevcdl_rd_smem_bytes(), s, p);
   else
-    hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(n_frames * p.tile_count), dim3(64), hevcdl_rd_smem_bytes_bd10(), s, p);
+    hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), hevcdl_rd_smem_bytes_bd10(), s, p);
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
-  if (d_dbg) {
+#if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)
+  {
     std::vector<unsigned int> hb(8004); hipDeviceSynchronize(); hipMemcpy(hb.data(), d_dbg, 8004 * 4, hipMemcpyDeviceToHost);
     for (unsigned i = 0; i < hb[0] && i < 4000; i++) printf("DBGV %u %u\n", hb[1 + 2 * i], hb[2 + 2 * i]);
     fflush(stdout); hipFree(d_dbg);
   }
+#endif
   return HEVCDL_OK;
 }
 
@@ -322,7 +329,7 @@ extern "C" hevcdl_status hevcdl_compress_tiles_dev(hevcdl_ctx *ctx, const void *
   if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > ctx->cfg.tile_columns * ctx->cfg.tile_rows) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "tile range outside the tile grid");
   if (n_frames == 0 || tile_count == 0) return HEVCDL_OK;
   if (!d_yuv || !d_labels || !d_records || !d_recon) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
-  return launch_rd(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, (hipStream_t)stream, 0, -1, nullptr, nullptr, nullptr, tile_begin, tile_count);
+  return launch_rd(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, (hipStream_t)stream, 0, -1, nullptr, nullptr, tile_begin, tile_count);
 }
 
 extern "C" hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels,
@@ -529,7 +536,7 @@ extern "C" hevcdl_status hevcdl_compress_ctu(hevcdl_ctx *ctx, int frame, int ctu
   const void *cab_in = (state_in_opt || ctu_addr > 0) ? cab : nullptr;      // NULL: slice-start contexts from the QP
   hevcdl_status st = launch_rd(ctx, ctx->d_yuv + ctx->frame_bytes * frame, 1, ctx->d_labels + (size_t)ctx->ctus * 16 * frame,
                                ctx->d_records + (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * frame, ctx->d_recon + ctx->frame_bytes * frame, nullptr, nullptr,
-                               ctu_addr, ctu_addr + 1, cab_in, cab, ctx->d_scratch + ctx->scratch_per_frame * frame);
+                               ctu_addr, ctu_addr + 1, cab_in, cab);
   if (st) return st;
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "rd kernel", e);

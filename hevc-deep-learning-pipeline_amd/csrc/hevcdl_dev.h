@@ -53,8 +53,8 @@ struct hevcdl_rd_params {
   unsigned char *records;          // [frame][ctu] hevcdl_ctu_record
   uint8_t *recon;                  // [frame] planar 4:2:0 reconstruction (also the neighbour source)
   unsigned char *stats;            // [frame] hevcdl_frame_stats or NULL
-  unsigned char *scratch;          // [frame] per-frame workspace
-  size_t scratch_per_frame;
+  unsigned char *scratch;          // [workgroup][wave] workspace
+  size_t scratch_per_wave;
   unsigned int *dbgbuf;
   const unsigned char *cabac_in;   // [frame] 168-byte coder state to start from, or NULL: slice-start state (only with ctu_begin == 0)
   unsigned char *cabac_out;        // [frame] coder state after the last CTU processed, or NULL
@@ -115,7 +115,8 @@ void hevcdl_launch_deblock(const struct hevcdl_dbk_params *p, void *stream);
 size_t hevcdl_cnn_smem_bytes(void);
 size_t hevcdl_fc_smem_bytes(void);
 size_t hevcdl_rd_smem_bytes(void);
-size_t hevcdl_rd_scratch_bytes(void);
+size_t hevcdl_rd_scratch_bytes(void);      // per wave
+int hevcdl_rd_waves_per_group(void);
 #ifdef __cplusplus
 }
 #endif

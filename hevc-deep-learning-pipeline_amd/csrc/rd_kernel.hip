@@ -8,8 +8,18 @@
 //  TComRdCost.cpp, DCT/DST/RDOQ/dequant TComTrQuant.cpp, CABAC-as-rate-estimator TEncSbac.cpp / ContextModel.cpp).
 //
 // Execution model: the CTUs of one slice are a strict serial chain (reconstructed neighbours + the adaptive CABAC
-// state advanced by the final encode of every previous CTU), all-intra frames are independent.  One wavefront
-// (64 lanes) therefore walks one frame; the grid is the batch of frames.  Inside the wave
+// state advanced by the final encode of every previous CTU), all-intra frames (and tiles) are independent units.
+// A workgroup is NW wavefronts on one CU, each with a private LDS block (RdSmem) and private global scratch.  The
+// units of a launch are dealt round-robin to the workgroups; inside a workgroup the first waves are MASTERS (one unit
+// each, walking its CTUs in coding order), the others HELPERS.  Where the reference's search evaluates alternatives
+// that all start from the same saved state -- the luma candidates of the first RD pass (TEncSearch.cpp:2378-2400,
+// each reloads CI_CURR_BEST), the five chroma modes (:2640-2660) -- the master opens a REGION in shared LDS: the
+// alternatives become tasks that any wave of the workgroup (the master included) claims with an LDS atomic, runs
+// on a private copy of the master's state, and answers with (cost, distortion) + its arrays / levels /
+// reconstruction in a result slot; the master then picks the winner exactly as the serial loop would (smallest cost,
+// first in list order on ties: the loop's strict <).  With 2048 units in flight every wave is a master and the
+// kernel is the one-wave-per-unit design; with fewer units the spare waves shorten each unit's critical path.
+// Inside a wave
 //   * pixel work is lane-parallel: reference gather, the 35-mode rough mode decision (one lane per
 //     (mode, 8x8 block) task: predict + Hadamard), prediction, residual, DCT/DST, dequant, reconstruction, SSE;
 //   * the inherently sequential parts (RDOQ reverse scan, CABAC bin counting) run on lane 0 out of LDS.
@@ -36,7 +46,19 @@ typedef uint16_t pel_t;
 
 namespace {
 constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 8);
-constexpr int SCR_LAYERS = (4 * 6144 * 2 + 5 * 6144 * (int)sizeof(pel_t) + 2047) & ~2047;   // coefficient layers + 4 reconstruction layers + best (81920 at 8 bits)
+#ifndef HEVCDL_NW
+#define HEVCDL_NW 8
+#endif
+constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
+constexpr int NSLOT = 10;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
+// per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
+// followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
+// per-position arrays, then NSLOT result slots (a layer set + 1 KB of attribute arrays each)
+constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
+constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + 2047) & ~2047;
+constexpr int SCR_RDOQ = 16384 + 16384;
+constexpr int SLOT_BYTES = (LAYER_SET + 1024 + 2047) & ~2047;
+constexpr int SCR_WAVE = SCR_LAYERS + SCR_RDOQ + NSLOT * SLOT_BYTES;
 constexpr int SSE_SH = 2 * (BD - 8), HAD_SH = BD - 8;         // DISTORTION_PRECISION_ADJUSTMENT: per squared sample / per Hadamard sum
 
 #define DEV __device__ __forceinline__
@@ -115,11 +137,16 @@ struct K {                             // wave-uniform kernel context (lives in 
   GLB unsigned char *records;          // frame's records (global)
   GLB const uint8_t *labels;           // frame's labels
   int tx0, ty0, tx1, ty1;              // luma rectangle of the tile being coded (the whole picture without tiles)
-  GLB int16_t *coef_l;                 // scratch: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
-  GLB pel_t *rec_l;                  // scratch: [4 layers][6144] CTU-relative reconstruction
-  GLB pel_t *best_rec;               // scratch: [6144] best reconstruction of the CU under test
+  GLB int16_t *coef_l;                 // ACTIVE layer set: [4 layers][6144] levels (Y 4096, Cb 1024, Cr 1024), z-order TU layout
+  GLB pel_t *rec_l;                  //                   [4 layers][6144] CTU-relative reconstruction
+  GLB pel_t *best_rec;               // scratch: [6144] best reconstruction of the CU under test (the master's)
   GLB double *q_cost;                  // scratch: RDOQ per-position costs [2][1024] (coded cost, sig cost); written/read lane-parallel,
-  GLB int32_t *q_rate;                 //          and SBH inputs [4][1024] (rateIncUp, rateIncDown, sigRateDelta, deltaU)
+  GLB int32_t *q_rate;                 //          and SBH inputs [4][1024] (rateIncUp, rateIncDown, sigRateDelta, deltaU)   (the executing wave's)
+  GLB pel_t *ovl;                    // task overlay [6144], CTU-relative: trial reconstruction of the task being run (the executing wave's)
+  GLB unsigned char *slots;            // the master's NSLOT result slots
+  // While a task runs (in_task) its trial reconstruction goes to the overlay instead of the picture, and reference samples inside
+  // the task rectangle (luma coordinates) come from there: the picture only ever holds what the master has committed.
+  int in_task, trx0, try0, trx1, try1;
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
   long long sbh[2];
@@ -129,8 +156,10 @@ struct K {                             // wave-uniform kernel context (lives in 
 };
 typedef const LDS K &KR;
 
-struct RdSmem {
+struct __attribute__((aligned(16))) RdSmem {
   K k;
+  // the executing wave's own scratch (K is copied from the master when a helper runs one of its tasks; these are not)
+  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate;
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
   uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
@@ -175,10 +204,13 @@ struct RdSmem {
 };
 typedef LDS RdSmem LSmem;
 
-// the workgroup's RdSmem sits at dynamic-LDS offset 0 (single-wave workgroups): every function reaches it directly
-DEV LSmem &lds() { extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[]; return *(LSmem *)smem_raw_; }
+// Dynamic LDS = NW private blocks (one per wave) followed by the workgroup's shared part; every function reaches its wave's block directly
+DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_workitem_id_x() >> 6)); }
+DEV LDS unsigned char *lds_base() { extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[]; return (LDS unsigned char *)smem_raw_; }
+DEV LSmem &lds_of(int w) { return *(LSmem *)(lds_base() + (size_t)w * sizeof(RdSmem)); }
+DEV LSmem &lds() { return lds_of(wave_id()); }
 DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-// Single-wave workgroup: "barrier" = ordering of this wave's own memory operations as seen by its other lanes.
+// Inside a wave: "barrier" = ordering of this wave's own memory operations as seen by its other lanes.
 // The hardware keeps a wave's LDS operations, and its vector-memory operations to one address, in program order, so
 // a wavefront-scope fence (a compiler-only constraint: no s_waitcnt vmcnt(0), no cache action) is sufficient.
 DEV void wsync()
@@ -199,6 +231,40 @@ DEV void wsync()
 #define PROF_ADD(k, id) do { } while (0)
 #endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// -DHEVCDL_DBG_EXEC: trap (s99 = site) when a function that needs the whole wave is entered with lanes masked off; run under rocgdb
+#ifdef HEVCDL_DBG_EXEC
+#define CHECK_EXEC(id) do { if (__builtin_amdgcn_read_exec() != ~0ull) { asm volatile("s_mov_b32 s99, %0\n s_trap 2" :: "i"(id) : "s99"); } } while (0)
+#else
+#define CHECK_EXEC(id) do { } while (0)
+#endif
+// ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
+enum { T_LUMA_P1 = 1, T_CHROMA = 2 };
+struct __attribute__((aligned(8))) Region {
+  // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
+  // the count can only come from the region that is open, whose parameters were written before the ticket was
+  int ticket, done, kind, owner;            // done: completion counter; owner: wave index of the master
+  int cu[7], tu[6], pad_;                   // the CU under test (struct Cu), the PU (luma) or the CU's root TU (chroma) (struct Tu)
+  int modes[12];                            // the alternatives: intra directions
+  uint32_t dist[12]; double cost[12];       // the answers
+};
+typedef LDS Region LRegion;
+struct __attribute__((aligned(16))) WgShared { Region reg[NW]; int masters_active, pad_[3]; };
+DEV LDS WgShared &wg_shared() { return *(LDS WgShared *)(lds_base() + (size_t)NW * sizeof(RdSmem)); }
+DEV LRegion &my_region() { return wg_shared().reg[wave_id()]; }
+DEV int lds_load(LDS int *p) { return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+DEVN int lds_add(LDS int *p, int v)
+{ // one atomic per wave (lane 0), result to every lane.  NOT inlined: inlined into a loop whose exit depends on the result, the lane-0
+  // branch was merged with the loop's back edge and the loop went on with lane 0 alone (observed with ROCm 7.2's clang)
+  int r = 0;
+  if (lane_id() == 0) r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return uni(r);
+}
+// hand-over points between waves of the workgroup (same CU: LDS and the vector L1 are shared, workgroup scope is enough)
+DEV void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+DEV GLB int16_t *slot_coef(GLB unsigned char *slots, int i) { return (GLB int16_t *)(slots + (size_t)i * SLOT_BYTES); }
+DEV GLB pel_t *slot_rec(GLB unsigned char *slots, int i) { return (GLB pel_t *)(slots + (size_t)i * SLOT_BYTES + 4 * 6144 * 2); }
+DEV GLB uint8_t *slot_attr(GLB unsigned char *slots, int i) { return (GLB uint8_t *)(slots + (size_t)i * SLOT_BYTES + LAYER_SET); }
 // Every lane of the wave follows the same control path by construction; the values that steer it are copied to
 // SGPRs (readfirstlane) so that branches enclosing barriers / calls are scalar branches, not EXEC-masked regions.
 DEV bool ub(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
@@ -227,6 +293,13 @@ DEV int comp_off(int c) { return c == 0 ? 0 : (c == 1 ? 4096 : 5120); }
 DEV int cstride(int c) { return c ? 32 : 64; }
 DEV int pstride(KR k, int c) { return c ? k.cw : k.W; }
 DEV int boff(KR k, int c, int x, int y) { const int s = c ? 32 : 64; return (y - k.cy * s) * s + (x - k.cx * s); }
+// where the reconstruction of the block at (x, y) of component c goes (and where the same task reads it back): the picture, or the
+// executing wave's overlay while a task runs
+DEV GLB pel_t *rec_target(KR k, int c, int x, int y, int &stride)
+{
+  if (uni(k.in_task)) { stride = cstride(c); return k.ovl + comp_off(c) + boff(k, c, x, y); }
+  stride = pstride(k, c); return k.rec[c] + (size_t)y * stride + x;
+}
 // log2 of a block size in {4,8,16,32,64}.  NOT 31-clz(n): that form let the compiler fold the constant part of a
 // dynamic index into a FLAT instruction's immediate offset with a base BELOW the indexed private object; gfx9-family
 // hardware picks the aperture from the base alone (offset ignored) -> HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
@@ -312,12 +385,20 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   const int f64 = (total > 64) ? unit_flag(64) : 0;          // uniform
   const int st = pstride(k, c);
   GLB const pel_t *p = k.rec[c];
+  // samples inside the rectangle of the running task come from its overlay, everything else from the picture
+  const int csh = c ? 1 : 0, cs_ = c ? 32 : 64, task = uni(k.in_task);
+  const int rx0 = k.trx0 >> csh, ry0 = k.try0 >> csh, rx1 = k.trx1 >> csh, ry1 = k.try1 >> csh;
+  GLB const pel_t *po = k.ovl + comp_off(c);
+  const int ox = k.cx * cs_, oy = k.cy * cs_;
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
-  auto sample_addr = [&](int i) -> size_t {                  // picture sample behind line index i
-    if (i < 2 * n) return (size_t)(y + 2 * n - 1 - i) * st + x - 1;
-    if (i == 2 * n) return (size_t)(y - 1) * st + x - 1;
-    return (size_t)(y - 1) * st + x + (i - 2 * n - 1);
+  auto sample_ptr = [&](int i) -> GLB const pel_t * {        // the sample behind line index i
+    int sx, sy;
+    if (i < 2 * n) { sy = y + 2 * n - 1 - i; sx = x - 1; }
+    else if (i == 2 * n) { sy = y - 1; sx = x - 1; }
+    else { sy = y - 1; sx = x + (i - 2 * n - 1); }
+    if (task && sx >= rx0 && sx < rx1 && sy >= ry0 && sy < ry1) return po + (sy - oy) * cs_ + (sx - ox);
+    return p + (size_t)sy * st + sx;
   };
   // Every line element is ONE picture sample: its own when its unit is available, otherwise the last sample of the nearest
   // available unit below, else the first sample of the first available unit above (TComPattern.cpp:350-543).  The source index
@@ -341,7 +422,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
         else if (f64) si = unit_start(64);
         else si = -1;                                       // nothing available: the default value
       }
-      if (si >= 0) { have[it] = true; val[it] = (int)p[sample_addr(si)]; }
+      if (si >= 0) { have[it] = true; val[it] = (int)*sample_ptr(si); }
     }
   }
 #pragma unroll
@@ -1374,6 +1455,7 @@ DEV void enc_intra_header(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma,
 }
 template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_, int luma_, int chroma_)
 {
+  CHECK_EXEC(11);
   PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int luma = uni(luma_), chroma = uni(chroma_); // xGetIntraBitsQT TEncSearch.cpp:1093-1117
   LCabac *c = &lds().go;
@@ -1428,12 +1510,12 @@ DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved, 3 predict and leave the
-// reconstruction in s->pred only: a first-pass candidate of a PU coded as one TU -- nothing reads its picture / layer samples, and
-// if it becomes the best candidate set_result takes them from LDS)
+// TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved, 3 predict and write the
+// reconstruction to the layer only: a first-pass candidate of a PU coded as one TU -- nothing reads its picture samples)
 // ---------------------------------------------------------------------------------------------------
 DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
 {
+  CHECK_EXEC(1);
   PROF_T0();
   PROF_MARK0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_);
@@ -1478,13 +1560,14 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   }
   PROF_MARK(28);
   GLB pel_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
-  GLB pel_t *rp = k.rec[comp] + (size_t)y * ps + x;
+  int rps; GLB pel_t *rp = rec_target(k, comp, x, y, rps);
   uint32_t d = 0;
   for (int i = lane_id(); i < n * n; i += 64) {
     const int r = i >> log2n, cc = i & (n - 1);
     const int v = clip8((int)s.pred[i] + (int)s.resi[r * RS(n) + cc]);
     s.pred[i] = (pel_t)v;
-    if (mode012 != 3) { rq[r * cs + cc] = (pel_t)v; rp[(size_t)r * ps + cc] = (pel_t)v; }
+    rq[r * cs + cc] = (pel_t)v;
+    if (mode012 != 3) rp[(size_t)r * rps + cc] = (pel_t)v;
     const int df = v - (int)org[(size_t)r * ps + cc];
     d += (uint32_t)(df * df) >> SSE_SH;                  // per sample, TComRdCost.cpp xGetSSE*
   }
@@ -1505,13 +1588,14 @@ DEV void store_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
 DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
 { // xLoadIntraResultQT TEncSearch.cpp:1819-1870
   const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
-  const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
+  const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = boff(k, comp, x, y);
+  int rps; GLB pel_t *rp = rec_target(k, comp, x, y, rps);
   wsync();
   if (lane_id() < 16) {
     k.coef_l[(5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16) + lane_id()] = lds().ts_coef[comp][lane_id()];
     const int r = lane_id() >> 2, cc = lane_id() & 3; const pel_t v = lds().ts_rec[comp][lane_id()];
     k.rec_l[(5 - tu.log2) * 6144 + comp_off(comp) + bo + r * cs + cc] = v;
-    k.rec[comp][(size_t)(y + r) * ps + x + cc] = v;
+    rp[(size_t)r * rps + cc] = v;
   }
   wsync();
 }
@@ -1522,6 +1606,7 @@ DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
 // split alternative is evaluated; if the unsplit TU wins, its arrays / reconstruction come back from the saved best.
 template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, int check_first_, int memo_ = 0, uint32_t memo_dist = 0, double memo_cost = 0.0)
 {
+  CHECK_EXEC(2);
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int check_first = uni(check_first_), memo = uni(memo_);
   LSmem &s = lds();
   const int full_depth = cu.depth + tu.trd, zabs = cu.zbase + tu.zrel;
@@ -1592,9 +1677,9 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       }
       const int n = 1 << LOG2, bo = boff(k, 0, tu.x, tu.y);
       GLB const pel_t *rq = memo ? k.best_rec + bo : k.rec_l + (5 - LOG2) * 6144 + bo;
-      GLB pel_t *rp = k.rec[0] + (size_t)tu.y * k.W + tu.x;
+      int rps; GLB pel_t *rp = rec_target(k, 0, tu.x, tu.y, rps);
       wsync();
-      for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * k.W + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
+      for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * rps + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
       wsync();
     }
   }
@@ -1603,10 +1688,10 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
 }
 
 // xSetIntraResultLumaQT / xSetIntraResultChromaQT TEncSearch.cpp:1741-1781, 2150-2198
-template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp, int rec_in_lds)
-{
+template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp, GLB const int16_t *src_coef, GLB const pel_t *src_rec)
+{ // source: a layer set (the wave's own, or the result slot of the winning task)
   if (uni(lds().a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
-    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp, 0);
+    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp, src_coef, src_rec);
     return;
   }
   if (comp && !tu_has_chroma_first(tu)) return;
@@ -1614,22 +1699,23 @@ template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int co
   const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
   const int off = comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
   GLB int16_t *dstc = (GLB int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + off;
-  GLB const int16_t *srcc = k.coef_l + (5 - LOG2) * 6144 + off;
+  GLB const int16_t *srcc = src_coef + (5 - LOG2) * 6144 + off;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = comp_off(comp) + boff(k, comp, x, y);
-  GLB const pel_t *rq = k.rec_l + (5 - LOG2) * 6144 + bo; GLB pel_t *br = k.best_rec + bo;
-  for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rec_in_lds ? lds().pred[i] : rq[o]; }
+  GLB const pel_t *rq = src_rec + (5 - LOG2) * 6144 + bo; GLB pel_t *br = k.best_rec + bo;
+  for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
 }
-DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_, int rec_in_lds_ = 0)
+DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_, GLB const int16_t *src_coef, GLB const pel_t *src_rec)
 {
+  CHECK_EXEC(10);
   PROF_T0();
-  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), rec_in_lds = uni(rec_in_lds_);
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_);
   wsync();
   switch (tu.log2) {
-    case 6: set_result<6>(k, cu, tu, comp, rec_in_lds); break;
-    case 5: set_result<5>(k, cu, tu, comp, rec_in_lds); break;
-    case 4: set_result<4>(k, cu, tu, comp, rec_in_lds); break;
-    case 3: set_result<3>(k, cu, tu, comp, rec_in_lds); break;
-    default: set_result<2>(k, cu, tu, comp, rec_in_lds); break;
+    case 6: set_result<6>(k, cu, tu, comp, src_coef, src_rec); break;
+    case 5: set_result<5>(k, cu, tu, comp, src_coef, src_rec); break;
+    case 4: set_result<4>(k, cu, tu, comp, src_coef, src_rec); break;
+    case 3: set_result<3>(k, cu, tu, comp, src_coef, src_rec); break;
+    default: set_result<2>(k, cu, tu, comp, src_coef, src_rec); break;
   }
   wsync();
   PROF_ADD(k, 15);
@@ -1779,9 +1865,14 @@ DEVN void rmd_satd(KR k, int x_, int y_, int pn_)
   PROF_ADD(k, 2);
 }
 
+DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_);
+DEVN void region_run(KR k, LRegion &r);
+DEV void region_close(LRegion &r) { }
+
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
 DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 {
+  CHECK_EXEC(5);
   PROF_T0();
   const Cu cu = ucu(cu_);
   LSmem &s = lds();
@@ -1822,30 +1913,50 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       wsync();
       nfull = uni((int)s.bc_u32[1]);
     }
-    // ---- RD pass 1 (:2355-2443) and pass 2 (:2445-2512) ----
+    // ---- RD pass 1 (:2355-2443): the candidates are independent (each starts from the [depth][CI_CURR_BEST] snapshot) -> a region ----
     uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
-    for (int m = 0; m <= nfull; m++) {
-      const int second = (m == nfull);
-      const uint32_t org_mode = second ? best_mode : (uint32_t)uni((int)s.rd_list[m]);
-      set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)org_mode);
+    {
+      LRegion &r = my_region();
+      wsync();
+      if (lane_id() < nfull) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
+      region_open(r, T_LUMA_P1, nfull, cu, ptu);
+      region_run(k, r);
+      // the serial loop keeps a candidate when its cost is strictly smaller: the winner is the smallest cost, first in list order
+      int win = -1;
+      for (int m = 0; m < nfull; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
+      if (win >= 0) { // xSetIntraResultLumaQT + the saved arrays, from the winner's result slot
+        best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
+        GLB const uint8_t *at = slot_attr(k.slots, win);
+        wsync();
+        for (int i = lane_id(); i < pu_parts; i += 64) {
+          const uint8_t t0 = at[i], t1 = at[256 + i], t2 = at[512 + i];
+          s.sv[0][i] = t0; s.sv[1][i] = t1; s.sv[2][i] = t2;
+          s.a[A_TRIDX][zp + i] = t0; s.a[A_CBF][zp + i] = t1; s.a[A_TSKIP][zp + i] = t2;
+        }
+        wsync();
+        set_result_cu(k, cu, ptu, 0, slot_coef(k.slots, win), slot_rec(k.slots, win));
+      }
+      region_close(r);
+    }
+    // ---- RD pass 2 (:2445-2512) = the best first-pass mode again, now with TU splitting allowed.  Its unsplit coding is a bit-exact
+    // repeat of the first pass (same mode, same references, same coder state): reuse it (memo) ----
+    do {
+      set_parts(k, s.a[A_LDIR], zp, pu_parts, (int)best_mode);
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
-      // second pass = the best first-pass mode again, now with TU splitting allowed (TEncSearch.cpp:2445-2512).  Its unsplit
-      // coding is a bit-exact repeat of the first pass (same mode, same references, same coder state): reuse it.
-      const int memo = second && pu_log2 <= 5;
-      if (memo && !(pu_log2 > min_tu_log2(cu))) continue;          // no split possible: the pass cannot change anything
-      // a first-pass candidate of a PU that is one TU keeps its reconstruction in LDS (code_tu_block mode 3)
-      const int lds_rec = !second && pu_log2 >= 3 && pu_log2 <= 5;
-      const DistCost dc = recur_luma_any(k, cu, ptu, second ? 0 : (lds_rec ? 2 : 1), memo, best_dist, best_cost);
-      const uint32_t d = dc.dist; const double cost = dc.cost;
-      if (ub(cost < best_cost)) {
-        best_mode = org_mode; best_dist = d; best_cost = cost;
-        set_result_cu(k, cu, ptu, 0, lds_rec && uni(s.a[A_TRIDX][zp]) == init_trd);
+      const int memo = pu_log2 <= 5;
+      if (memo && !(pu_log2 > min_tu_log2(cu))) break;              // no split possible: the pass cannot change anything
+      PROF_MARK0();
+      const DistCost dc = recur_luma_any(k, cu, ptu, 0, memo, best_dist, best_cost);
+      PROF_MARK(37);
+      if (ub(dc.cost < best_cost)) {
+        best_dist = dc.dist; best_cost = dc.cost;
+        set_result_cu(k, cu, ptu, 0, k.coef_l, k.rec_l);
         for (int i = lane_id(); i < pu_parts; i += 64) {
           s.sv[0][i] = s.a[A_TRIDX][zp + i]; s.sv[1][i] = s.a[A_CBF][zp + i]; s.sv[2][i] = s.a[A_TSKIP][zp + i];   // the luma search leaves chroma entries alone
         }
         wsync();
       }
-    }
+    } while (0);
     overall += best_dist;
     wsync();
     for (int i = lane_id(); i < pu_parts; i += 64) {
@@ -1873,6 +1984,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 // xRecurIntraChromaCodingQT TEncSearch.cpp:1941-2145
 template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
 {
+  CHECK_EXEC(7);
   uint32_t dist_sum = 0;
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
@@ -1932,9 +2044,137 @@ template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
   return dist_sum;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// regions: open / claim / run / answer
+// ---------------------------------------------------------------------------------------------------
+DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_)
+{ CHECK_EXEC(12); // r.modes[] already written by the caller
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int kind = uni(kind_), n = uni(n_);
+  wsync();
+  if (lane_id() == 0) {
+    r.kind = kind; r.owner = wave_id(); r.done = 0;
+    r.cu[0] = cu.x; r.cu[1] = cu.y; r.cu[2] = cu.log2; r.cu[3] = cu.depth; r.cu[4] = cu.zbase; r.cu[5] = cu.nparts; r.cu[6] = cu.part;
+    r.tu[0] = tu.x; r.tu[1] = tu.y; r.tu[2] = tu.log2; r.tu[3] = tu.trd; r.tu[4] = tu.zrel; r.tu[5] = tu.nparts;
+  }
+  wsync();
+  wg_release();                                              // the master's arrays, snapshots and picture writes before the ticket
+  if (lane_id() == 0) __hip_atomic_store(&r.ticket, n << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// a helper takes over the master's view of the CTU: kernel context + attribute arrays (the coder snapshot a task starts from is
+// read straight from the master's block)
+DEV void import_owner(int owner)
+{
+  LSmem &s = lds(); LSmem &ow = lds_of(owner);
+  static_assert(sizeof(K) % 8 == 0 && offsetof(RdSmem, a) % 8 == 0 && offsetof(RdSmem, k) == 0, "8-byte copies");
+  wsync();
+  { LDS unsigned long long *d = (LDS unsigned long long *)&s.k; LDS const unsigned long long *q = (LDS const unsigned long long *)&ow.k;
+    for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = q[i]; }
+  { LDS unsigned long long *d = (LDS unsigned long long *)&s.a[0][0]; LDS const unsigned long long *q = (LDS const unsigned long long *)&ow.a[0][0];
+    for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[i] = q[i]; }
+  wsync();
+  s.k.q_cost = s.my_qcost; s.k.q_rate = s.my_qrate; s.k.ovl = s.my_ovl;      // every lane stores the same values
+  if (lane_id() < 3) s.ref_key[lane_id()] = -1;
+  if (lane_id() == 0) s.fline_key = -1;
+  wsync();
+}
+
+// one alternative, on the executing wave's private state; levels / reconstruction go to the result slot, trial samples to the overlay
+DEVN void run_task(LRegion &r, int idx_)
+{
+  CHECK_EXEC(3);
+  const int idx = uni(idx_);
+  LSmem &s = lds(); LDS K &kk = s.k; KR k = s.k;
+  LSmem &ow = lds_of(uni(r.owner));
+  const Cu cu = { uni(r.cu[0]), uni(r.cu[1]), uni(r.cu[2]), uni(r.cu[3]), uni(r.cu[4]), uni(r.cu[5]), uni(r.cu[6]) };
+  const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
+  const int kind = uni(r.kind), mode = uni(r.modes[idx]);
+  wsync();
+  kk.coef_l = slot_coef(kk.slots, idx); kk.rec_l = slot_rec(kk.slots, idx); kk.in_task = 1;
+  kk.trx0 = tu.x; kk.try0 = tu.y; kk.trx1 = tu.x + (1 << tu.log2); kk.try1 = tu.y + (1 << tu.log2);
+  wsync();
+  LCabac *start = &ow.curr[cu.depth];
+  GLB uint8_t *at = slot_attr(kk.slots, idx);
+  uint32_t dist; double cost;
+  if (kind == T_LUMA_P1) { // one candidate of the first RD pass (TEncSearch.cpp:2378-2443)
+    const int zp = cu.zbase + tu.zrel;
+    set_parts(k, s.a[A_LDIR], zp, tu.nparts, mode);
+    cabac_copy(k, &s.go, start);
+    // a candidate of a PU that is one TU writes its reconstruction to the layer only (code_tu_block mode 3)
+    const int one_tu = tu.log2 >= 3 && tu.log2 <= 5;
+    PROF_MARK0();
+    const DistCost dc = recur_luma_any(k, cu, tu, one_tu ? 2 : 1);
+    PROF_MARK(36);
+    dist = dc.dist; cost = dc.cost;
+    wsync();
+    for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
+  } else { // one chroma mode (TEncSearch.cpp:2640-2700)
+    cabac_copy(k, &s.go, start);
+    set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, mode); wsync();
+    uint32_t bits;
+    switch (cu.log2) {
+      case 6: dist = recur_chroma<6>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<6>(k, cu, tu, 0, 1); break;
+      case 5: dist = recur_chroma<5>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<5>(k, cu, tu, 0, 1); break;
+      case 4: dist = recur_chroma<4>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<4>(k, cu, tu, 0, 1); break;
+      default: dist = recur_chroma<3>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<3>(k, cu, tu, 0, 1); break;
+    }
+    cost = calc_rd_cost(k, bits, dist);
+    wsync();
+    for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { at[(c - 1) * 256 + i] = s.a[A_CBF + c][cu.zbase + i]; at[(c + 1) * 256 + i] = s.a[A_TSKIP + c][cu.zbase + i]; }
+  }
+  if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
+  wsync();
+  kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
+  wsync();
+}
+
+// claim a task of region r: its index, or -1
+DEV int region_claim(LRegion &r)
+{
+  const int t = lds_add(&r.ticket, 1), idx = t & 0xffff, n = (int)((unsigned)t >> 16);
+  return idx < n ? idx : -1;
+}
+DEVN void region_run(KR k, LRegion &r)
+{ CHECK_EXEC(4); // the master works on its own region, then waits for the helpers' last tasks
+  const int n = (int)((unsigned)lds_load(&r.ticket) >> 16);
+  for (;;) {
+    const int idx = region_claim(r);
+    if (idx < 0) break;
+    run_task(r, idx);
+    wg_release();
+    lds_add(&r.done, 1);
+  }
+  while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2);
+  wg_acquire();
+}
+// waves without a unit (or done with theirs) serve the regions of the workgroup's masters until the last master has finished
+DEV void helper_loop()
+{
+  LDS WgShared &sh = wg_shared();
+  const int me = wave_id();
+  while (lds_load(&sh.masters_active) > 0) {
+    int did = 0;
+    for (int j = 1; j <= NW && !did; j++) {
+      LRegion &r = sh.reg[(me + j) % NW];
+      const int t = lds_load(&r.ticket);
+      if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
+      const int idx = region_claim(r);
+      if (idx < 0) continue;
+      wg_acquire();
+      import_owner(uni(r.owner));
+      run_task(r, idx);
+      wg_release();
+      lds_add(&r.done, 1);
+      did = 1;
+    }
+    if (!did) __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 // estIntraPredChromaQT TEncSearch.cpp:2588-2737 (4:2:0: one chroma PU per CU)
 DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
 {
+  CHECK_EXEC(6);
   PROF_T0();
   const Cu cu = ucu(cu_);
   LSmem &s = lds();
@@ -1946,25 +2186,25 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   const int luma_mode = uni(s.a[A_LDIR][cu.zbase]);
   for (int i = 0; i < 4; i++) if ((int)mode_list[i] == luma_mode) { mode_list[i] = 34; break; }   // getAllowedChromaDir TComDataCU.cpp:1334-1353
   uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
-  for (int m = 0; m < 5; m++) {
-    cabac_copy(k, &s.go, &s.curr[cu.depth]);
-    uint32_t d;
-    set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)mode_list[m]); wsync();
-    uint32_t bits;
-    switch (cu.log2) {
-      case 6: d = recur_chroma<6>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<6>(k, cu, root, 0, 1); break;
-      case 5: d = recur_chroma<5>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<5>(k, cu, root, 0, 1); break;
-      case 4: d = recur_chroma<4>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<4>(k, cu, root, 0, 1); break;
-      default: d = recur_chroma<3>(k, cu, root); cabac_copy(k, &s.go, &s.curr[cu.depth]); bits = intra_bits_qt<3>(k, cu, root, 0, 1); break;
-    }
-    const double cost = calc_rd_cost(k, bits, d);
-    if (ub(cost < best_cost)) {
-      best_cost = cost; best_dist = d; best_mode = mode_list[m];
-      set_result_cu(k, cu, root, 1); set_result_cu(k, cu, root, 2);
-      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.sv[c - 1][i] = s.a[A_CBF + c][cu.zbase + i]; s.sv[c + 1][i] = s.a[A_TSKIP + c][cu.zbase + i]; }
+  { // the five modes are independent (each starts from the [depth][CI_CURR_BEST] snapshot, TEncSearch.cpp:2640-2660) -> a region
+    LRegion &r = my_region();
+    wsync();
+    if (lane_id() == 0) for (int m = 0; m < 5; m++) r.modes[m] = (int)mode_list[m];
+    region_open(r, T_CHROMA, 5, cu, root);
+    region_run(k, r);
+    int win = -1;
+    for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
+    if (win >= 0) {
+      best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
+      GLB const uint8_t *at = slot_attr(k.slots, win);
       wsync();
+      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 4; c++) s.sv[c][i] = at[c * 256 + i];
+      wsync();
+      set_result_cu(k, cu, root, 1, slot_coef(k.slots, win), slot_rec(k.slots, win)); set_result_cu(k, cu, root, 2, slot_coef(k.slots, win), slot_rec(k.slots, win));
     }
+    region_close(r);
   }
+  wsync();
   for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv[c - 1][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv[c + 1][i]; }
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
@@ -1986,6 +2226,7 @@ DEV void copy_best_rec_to_pic(KR k, const Cu &cu, int comp)
 // xCheckRDCostIntra TEncCu.cpp:1600-1665; the end state of the CU syntax is left in s->temp[depth]
 DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
 {
+  CHECK_EXEC(8);
   LSmem &s = lds();
   const int part = uni(part_);
   Cu cu = ucu(cu_); cu.part = part;
@@ -2040,6 +2281,7 @@ DEV void load_cand8(KR k, const Cu &cu)
 // xCompressCU TEncCu.cpp:470-1104 with the reference's label-pruning edits (:496-520, 815-834, 947-965)
 template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
 {
+  CHECK_EXEC(9);
   const int x = uni(x_), y = uni(y_);
   LSmem &s = lds();
   const int log2 = 6 - DEPTH, size = 1 << log2;
@@ -2128,16 +2370,12 @@ template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
   enc_cu_syntax(k, c, cu);
 }
 
-} // namespace
-
-extern "C" __global__ __launch_bounds__(64)
-void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
+// one unit = one (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
+// (a launch may cover only tiles [tile_begin, tile_begin + tile_count) of every frame: tile sharding across GPUs)
+DEV void process_unit(const hevcdl_rd_params &p, int unit)
 {
   LSmem &s = lds();
-  // one wave per (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
-  // (a launch may cover only tiles [tile_begin, tile_begin + tile_count) of every frame: tile sharding across GPUs)
-  const int ntiles = p.tile_cols * p.tile_rows, unit = blockIdx.x, frame = unit / p.tile_count, tile = p.tile_begin + (unit - frame * p.tile_count);
-  if (frame >= p.n_frames) return;
+  const int ntiles = p.tile_cols * p.tile_rows, frame = unit / p.tile_count, tile = p.tile_begin + (unit - frame * p.tile_count);
   LDS K &k = s.k;                       // every lane stores the same values
   const int lane = lane_id();
   k.W = p.width; k.H = p.height; k.cw = p.width >> 1; k.ctus_x = p.ctus_x; k.nctu = p.ctus_x * p.ctus_y;
@@ -2150,35 +2388,12 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   GLB unsigned char *records = (GLB unsigned char *)p.records + (size_t)frame * nctu * REC_SIZE;
   k.records = records;
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
-  GLB unsigned char *scr = (GLB unsigned char *)p.scratch + (size_t)unit * p.scratch_per_frame;
-  k.coef_l = (GLB int16_t *)scr; k.rec_l = (GLB pel_t *)(scr + 4 * 6144 * 2); k.best_rec = k.rec_l + 4 * 6144;
-  k.q_cost = (GLB double *)(scr + SCR_LAYERS); k.q_rate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
+  k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
+  k.q_cost = s.my_qcost; k.q_rate = s.my_qrate;
+  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
-
-  // tables into LDS: z-scan map, CABAC tables, scans
-  for (int r = lane; r < 256; r += 64) {
-    const int x = r & 15, y = r >> 4; int z = 0;
-    for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
-    s.r2z[r] = (uint8_t)z;
-  }
-  for (int i = lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
-  if (lane < 9) { s.t_ang[lane] = c_ang_table[lane]; s.t_inv_ang[lane] = c_inv_ang_table[lane]; }
-  if (lane < 16) s.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
-  if (lane < 32) s.t_group_idx[lane] = c_group_idx[lane];
-  if (lane < 5) s.t_filter_thr[lane] = c_intra_filter_thr[lane];
-  if (lane < 12) { // CG order of every (scan type, block size)
-    const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
-    LDS uint8_t *cg = s.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
-    int ln = 0, c = 0;
-    for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
-  }
-  wsync();
-  if (lane < 3) { // order inside a CG, per scan type
-    int l2 = 0, c2 = 0;
-    for (int q = 0; q < 16; q++) { s.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
-  }
   if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
 #ifdef HEVCDL_KERNEL_PROF
   if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
@@ -2247,7 +2462,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   }
 #ifdef HEVCDL_KERNEL_PROF
   wsync();
-  if (frame == 0 && p.dbgbuf && lane < 40) {
+  if (unit == 0 && p.dbgbuf && lane < 40) {
     if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
     p.dbgbuf[1 + 2 * lane] = (unsigned int)(s.prof[lane] >> 10); p.dbgbuf[2 + 2 * lane] = s.prof_n[lane];
     if (lane == 0) p.dbgbuf[0] = 40;
@@ -2271,5 +2486,58 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   }
 }
 
-extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return sizeof(RdSmem); }
-extern "C" size_t RD_SYM(hevcdl_rd_scratch_bytes)(void) { return SCR_LAYERS + 16384 + 16384; }   // layers 79872 (padded) + RDOQ costs + SBH inputs
+} // namespace
+
+extern "C" __global__ __launch_bounds__(NW * 64)
+void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
+{
+  LSmem &s = lds();
+  const int lane = lane_id(), wave = wave_id();
+  // this wave's global scratch
+  {
+    GLB unsigned char *scr = (GLB unsigned char *)p.scratch + ((size_t)blockIdx.x * NW + wave) * p.scratch_per_wave;
+    s.my_coef = (GLB int16_t *)scr; s.my_rec = (GLB pel_t *)(scr + 4 * 6144 * 2); s.my_ovl = s.my_rec + 5 * 6144;
+    s.my_qcost = (GLB double *)(scr + SCR_LAYERS); s.my_qrate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
+    s.k.slots = scr + SCR_LAYERS + SCR_RDOQ;
+  }
+  // tables into this wave's LDS block: z-scan map, CABAC tables, scans
+  for (int r = lane; r < 256; r += 64) {
+    const int x = r & 15, y = r >> 4; int z = 0;
+    for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+    s.r2z[r] = (uint8_t)z;
+  }
+  for (int i = lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
+  if (lane < 9) { s.t_ang[lane] = c_ang_table[lane]; s.t_inv_ang[lane] = c_inv_ang_table[lane]; }
+  if (lane < 16) s.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
+  if (lane < 32) s.t_group_idx[lane] = c_group_idx[lane];
+  if (lane < 5) s.t_filter_thr[lane] = c_intra_filter_thr[lane];
+  if (lane < 12) { // CG order of every (scan type, block size)
+    const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
+    LDS uint8_t *cg = s.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
+    int ln = 0, c = 0;
+    for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
+  }
+  wsync();
+  if (lane < 3) { // order inside a CG, per scan type
+    int l2 = 0, c2 = 0;
+    for (int q = 0; q < 16; q++) { s.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
+  }
+  // units are dealt round-robin: unit u belongs to workgroup u mod G, wave (u div G) mod NW
+  const int n_units = p.n_frames * p.tile_count, G = (int)gridDim.x, first = (int)blockIdx.x + G * wave;
+  LDS WgShared &sh = wg_shared();
+  if (lane == 0) {
+    sh.reg[wave].ticket = 0; sh.reg[wave].done = 0; sh.reg[wave].owner = wave;
+    if (wave == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; }
+  }
+  __syncthreads();
+  if (first < n_units) {
+    for (int u = first; u < n_units; u += G * NW) process_unit(p, u);
+    wg_release();
+    lds_add(&sh.masters_active, -1);
+  }
+  helper_loop();
+}
+
+extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return (size_t)NW * sizeof(RdSmem) + sizeof(WgShared); }
+extern "C" size_t RD_SYM(hevcdl_rd_scratch_bytes)(void) { return SCR_WAVE; }        // per wave
+extern "C" int RD_SYM(hevcdl_rd_waves_per_group)(void) { return NW; }

@@ -1,0 +1,33 @@
+"""Decision-kernel timing at 2160p (or WxH): tools/time_rd.py frames [frames ...] [--size WxH]; labels from the on-device CNN."""
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
+import numpy as np, torch
+import hevcdl_amd, ref_tools
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+W, H = 3840, 2160
+for a in sys.argv[1:]:
+    if a.startswith('--size='):
+        W, H = [int(v) for v in a[7:].split('x')]
+counts = [int(a) for a in args] or [1, 75, 600]
+nmax = max(counts)
+base = ref_tools.synth_yuv(W, H, 4, seed=4000)
+enc = hevcdl_amd.Encoder(W, H, 32, max_frames=nmax)
+fb = hevcdl_amd.frame_bytes(W, H) if hasattr(hevcdl_amd, 'frame_bytes') else W * H * 3 // 2
+yuv = torch.empty((nmax, fb), dtype=torch.uint8, device='cuda')
+hb = torch.from_numpy(np.ascontiguousarray(base.reshape(4, -1))).cuda()
+for f in range(nmax):
+    yuv[f] = hb[f % 4]
+ctus = ((W + 63) // 64) * ((H + 63) // 64)
+labels = torch.empty((nmax, ctus, 16), dtype=torch.uint8, device='cuda')
+recs = torch.empty((nmax, ctus, 15120), dtype=torch.uint8, device='cuda')
+recon = torch.empty_like(yuv)
+stats = torch.zeros((nmax, 40), dtype=torch.uint8, device='cuda')
+enc.predict_depth_dev(yuv.data_ptr(), nmax, labels.data_ptr())
+torch.cuda.synchronize()
+for n in counts:
+    t0 = time.time()
+    enc.compress_frames_dev(yuv.data_ptr(), n, labels.data_ptr(), recs.data_ptr(), recon.data_ptr(), stats.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print("frames %5d  rd %.3f s  %.1f CTU/s" % (n, dt, n * ctus / dt), flush=True)
+enc.close()
