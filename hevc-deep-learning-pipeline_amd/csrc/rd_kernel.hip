@@ -53,11 +53,11 @@ constexpr int NW = HEVCDL_NW;                                 // wavefronts per 
 constexpr int NSLOT = 10;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
-// per-position arrays, then NSLOT result slots (a layer set + 1 KB of attribute arrays each)
+// per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
-constexpr int SLOT_BYTES = (LAYER_SET + 1024 + 2047) & ~2047;
+constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
 constexpr int SCR_WAVE = SCR_LAYERS + SCR_RDOQ + NSLOT * SLOT_BYTES;
 constexpr int SSE_SH = 2 * (BD - 8), HAD_SH = BD - 8;         // DISTORTION_PRECISION_ADJUSTMENT: per squared sample / per Hadamard sum
 
@@ -162,7 +162,6 @@ struct __attribute__((aligned(16))) RdSmem {
   GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate;
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
-  uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
   int16_t line[264], fline[264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
   int16_t cline[2][132];              // chroma reference samples (n <= 32, never filtered in 4:2:0)
   // the reference lines are kept across consecutive TU codings of the same block (candidate modes of one PU share
@@ -176,13 +175,6 @@ struct __attribute__((aligned(16))) RdSmem {
   // entries, i.e. a 4x4 block of levels survives the inverse transform (transform-skip bookkeeping needs it)
   int16_t lvl[16 + 32 * 33];
   pel_t pred[1024];                 // prediction, then reconstruction, of the current TU
-  // grouped-4x4 coefficient scans (TComRom.cpp:179-260) = CG order x order inside a CG, composed on the fly
-  uint8_t scan_cg_all[3][88];         // CG order per [type][1 | 4 | 16 | 64 groups]
-  uint8_t scan_in_cg[3][16];          // (y << 2) | x of the 16 positions of a CG, per scan type
-  // small constant tables copied to LDS once per kernel: the serial RDOQ / bin-counting code reads them with
-  // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
-  int32_t t_ebits[128]; uint8_t t_next[2][128];
-  int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
   uint8_t sv[4][256];                 // saved best candidate: luma search trIdx / cbf / tskip in [0..2]; chroma search (later, disjoint in time) cbf Cb, Cr, tskip Cb, Cr
   pel_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
   unsigned int rd_list[16];
@@ -238,7 +230,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3 };
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
   // the count can only come from the region that is open, whose parameters were written before the ticket was
@@ -248,9 +240,24 @@ struct __attribute__((aligned(8))) Region {
   uint32_t dist[12]; double cost[12];       // the answers
 };
 typedef LDS Region LRegion;
-struct __attribute__((aligned(16))) WgShared { Region reg[NW]; int masters_active, pad_[3]; };
+struct Tables {                        // read-only after kernel start, one copy per workgroup
+  uint8_t r2z[256];                   // raster -> z-scan of the 16x16 partition grid (TComRom.cpp:284-352)
+  // grouped-4x4 coefficient scans (TComRom.cpp:179-260) = CG order x order inside a CG, composed on the fly
+  uint8_t scan_cg_all[3][88];         // CG order per [type][1 | 4 | 16 | 64 groups]
+  uint8_t scan_in_cg[3][16];          // (y << 2) | x of the 16 positions of a CG, per scan type
+  // small constant tables copied to LDS once per kernel: the serial RDOQ / bin-counting code reads them with
+  // data-dependent indices, and an LDS read (~64 cycles) is several times cheaper than a constant-memory miss
+  int32_t t_ebits[128]; uint8_t t_next[2][128];
+  int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
+};
+struct __attribute__((aligned(16))) WgShared {
+  Region reg[NW][2];                  // two regions per master: [1] serves the speculative second pass
+  int masters_active, has_helpers, pad_[2];     // has_helpers: the workgroup started with waves that have no unit
+  Tables tab;
+};
 DEV LDS WgShared &wg_shared() { return *(LDS WgShared *)(lds_base() + (size_t)NW * sizeof(RdSmem)); }
-DEV LRegion &my_region() { return wg_shared().reg[wave_id()]; }
+DEV LRegion &my_region(int which = 0) { return wg_shared().reg[wave_id()][which]; }
+DEV LDS Tables &tb() { return wg_shared().tab; }
 DEV int lds_load(LDS int *p) { return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 DEVN int lds_add(LDS int *p, int v)
 { // one atomic per wave (lane 0), result to every lane.  NOT inlined: inlined into a loop whose exit depends on the result, the lane-0
@@ -265,6 +272,7 @@ DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 DEV GLB int16_t *slot_coef(GLB unsigned char *slots, int i) { return (GLB int16_t *)(slots + (size_t)i * SLOT_BYTES); }
 DEV GLB pel_t *slot_rec(GLB unsigned char *slots, int i) { return (GLB pel_t *)(slots + (size_t)i * SLOT_BYTES + 4 * 6144 * 2); }
 DEV GLB uint8_t *slot_attr(GLB unsigned char *slots, int i) { return (GLB uint8_t *)(slots + (size_t)i * SLOT_BYTES + LAYER_SET); }
+DEV GLB unsigned long long *slot_state(GLB unsigned char *slots, int i, int out) { return (GLB unsigned long long *)(slots + (size_t)i * SLOT_BYTES + LAYER_SET + 1024 + 256 * out); }
 // Every lane of the wave follows the same control path by construction; the values that steer it are copied to
 // SGPRs (readfirstlane) so that branches enclosing barriers / calls are scalar branches, not EXEC-masked regions.
 DEV bool ub(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
@@ -312,15 +320,14 @@ DEV int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 // ---------------------------------------------------------------------------------------------------
 DEV void enc_bin(LCabac *c, int ctx, int bin)
 {
-  LSmem &t = lds();
   const uint8_t st = c->ctx[ctx];
-  c->frac += (unsigned long long)t.t_ebits[st ^ bin];
-  c->ctx[ctx] = t.t_next[(st & 1) == bin][st];
+  c->frac += (unsigned long long)tb().t_ebits[st ^ bin];
+  c->ctx[ctx] = tb().t_next[(st & 1) == bin][st];
 }
 DEV void enc_ep(LCabac *c, int n) { c->frac += 32768ull * (unsigned long long)n; }
 DEV void reset_bits(LCabac *c) { c->frac &= 32767ull; }
 DEV uint32_t get_bits(const LCabac *c) { return (uint32_t)(c->frac >> 15); }
-DEV int ctx_bits(const LCabac *c, int ctx, int bin) { return lds().t_ebits[c->ctx[ctx] ^ bin]; }
+DEV int ctx_bits(const LCabac *c, int ctx, int bin) { return tb().t_ebits[c->ctx[ctx] ^ bin]; }
 DEV void cabac_copy(KR k, LCabac *dst, const LCabac *src)
 { // wave-parallel 168-byte snapshot copy (TEncSbac::load/store, TEncSbac.cpp:396-425)
   PROF_T0();
@@ -345,7 +352,7 @@ DEV void set_parts(KR k, LDS uint8_t *a, int z0, int n, int v)
 // attribute of the 4x4 partition (x4,y4) of the picture: current CTU from LDS, earlier CTUs from their records
 DEV int part_attr(KR k, int field, int x4, int y4)
 {
-  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), z = lds().r2z[((y4 & 15) << 4) | (x4 & 15)];
+  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), z = tb().r2z[((y4 & 15) << 4) | (x4 & 15)];
   if (a == k.addr) return lds().a[field][z];
   return k.records[(size_t)a * REC_SIZE + field * 256 + z];
 }
@@ -359,7 +366,7 @@ DEV int unit_avail(KR k, int x4, int y4, int cur_x4, int cur_y4)
   if (x4 * 4 < k.tx0 || y4 * 4 < k.ty0 || x4 * 4 >= k.tx1 || y4 * 4 >= k.ty1) return 0;   // another tile is never available (bEnforceTileRestriction)
   const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4);
   if (a != k.addr) return a < k.addr;                   // CTUs of one tile are coded in raster order
-  return lds().r2z[((y4 & 15) << 4) | (x4 & 15)] < lds().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
+  return tb().r2z[((y4 & 15) << 4) | (x4 & 15)] < tb().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
 }
 
 DEV LDS int16_t *ref_line(int c) { return c ? lds().cline[c - 1] : lds().line; }
@@ -462,7 +469,7 @@ DEV int use_filtered_refs(int c, int mode, int n)
 { // TComPattern.cpp:545-570; chroma never in 4:2:0
   if (c || mode == DC) return 0;
   const int d1 = abs(mode - HOR), d2 = abs(mode - VER), diff = d1 < d2 ? d1 : d2;
-  return diff > lds().t_filter_thr[ilog2(n) - 2];
+  return diff > tb().t_filter_thr[ilog2(n) - 2];
 }
 
 // closed-form intra prediction of one sample (TComPrediction.cpp:183-473, 731-817); dcval only for DC
@@ -484,8 +491,8 @@ DEV int pred_pixel(LDS const int16_t *line, int c, int mode, int n, int log2n, i
   const int is_ver = mode >= 18;
   const int ang_mode = is_ver ? mode - VER : -(mode - HOR);
   const int abs_ang = abs(ang_mode);
-  const int angle = (ang_mode < 0 ? -1 : 1) * lds().t_ang[abs_ang];
-  const int inv_angle = lds().t_inv_ang[abs_ang];
+  const int angle = (ang_mode < 0 ? -1 : 1) * tb().t_ang[abs_ang];
+  const int inv_angle = tb().t_inv_ang[abs_ang];
   const int x = is_ver ? px : py, y = is_ver ? py : px;
   auto ref = [&](int i) -> int {
     if (i >= 0) return is_ver ? line[n2 + i] : line[n2 - i];
@@ -703,7 +710,7 @@ DEV int sig_ctx_inc(const CParam &cp, const ScanFn &scan, int pat, int scan_pos)
   const int raster = scan[scan_pos], py = raster >> cp.log2, px = raster - (py << cp.log2);
   if (px + py == 0) return 0;
   int offset;
-  if (cp.log2 == 2) offset = lds().t_ctx_map4[4 * py + px];
+  if (cp.log2 == 2) offset = tb().t_ctx_map4[4 * py + px];
   else {
     int cnt; const int xs = px & 3, ys = py & 3;
     if (pat == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
@@ -717,10 +724,10 @@ DEV int sig_ctx_inc(const CParam &cp, const ScanFn &scan, int pat, int scan_pos)
 }
 DEV ScanFn scan_of(const LSmem &s, int type, int log2n)
 {
-  ScanFn f; f.cg = s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); f.in = s.scan_in_cg[type]; f.log2n = log2n; f.l = log2n - 2;
+  ScanFn f; f.cg = tb().scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); f.in = tb().scan_in_cg[type]; f.log2n = log2n; f.l = log2n - 2;
   return f;
 }
-DEV LDS const uint8_t *scan_cg_of(const LSmem &s, int type, int log2n) { return s.scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); }
+DEV LDS const uint8_t *scan_cg_of(const LSmem &s, int type, int log2n) { return tb().scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); }
 DEV int ctx_set_index(int ch, int subset, int found_gt1) { return (ch ? 4 : 0) + ((!ch && subset > 0) ? 2 : 0) + (found_gt1 ? 1 : 0); }   // TComChromaFormat.h:243-251
 DEV void last_ctx_params(int ch, int n, int &off, int &shift)
 { // TComChromaFormat.h:211-226
@@ -1053,7 +1060,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
     { // TEncSbac.cpp:1910-1930 (prefix sums are integers: any evaluation order)
       int off, shift; last_ctx_params(ch, n, off, shift);
       const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
-      const int ng = s.t_group_idx[n - 1];
+      const int ng = tb().t_group_idx[n - 1];
       { // lanes 0..15: X, lanes 16..31: Y; entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar
         const int kk = lane & 15, isy = (lane >> 4) & 1;
         const int cx_ = (isy ? by : bx) + off + (kk >> shift);
@@ -1077,7 +1084,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
       const double cc_j = cost_coeff[sp_j], cs_j = cost_sig[sp_j], c0_j = cost0_of(blk_j);
       int py = blk_j >> log2n, px = blk_j - (py << log2n);
       if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-      const int gx2 = s.t_group_idx[px], gy2 = s.t_group_idx[py];
+      const int gx2 = tb().t_group_idx[px], gy2 = tb().t_group_idx[py];
       double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
       if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
       if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
@@ -1224,8 +1231,8 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
   if (scan_last < 0) return;                                    // never called for an empty TU (cbf checked by the caller)
   wsync();
   int cx0 = c->ctx[lane], cx1 = c->ctx[64 + lane], cx2 = c->ctx[128 + (lane & 31)];
-  const int eb0 = s.t_ebits[lane], eb1 = s.t_ebits[64 + lane];
-  const int nx = (int)((unsigned)s.t_next[0][lane] | ((unsigned)s.t_next[0][64 + lane] << 8) | ((unsigned)s.t_next[1][lane] << 16) | ((unsigned)s.t_next[1][64 + lane] << 24));
+  const int eb0 = tb().t_ebits[lane], eb1 = tb().t_ebits[64 + lane];
+  const int nx = (int)((unsigned)tb().t_next[0][lane] | ((unsigned)tb().t_next[0][64 + lane] << 8) | ((unsigned)tb().t_next[1][lane] << 16) | ((unsigned)tb().t_next[1][64 + lane] << 24));
   unsigned long long frac;
   { const unsigned long long f = c->frac; frac = ((unsigned long long)(unsigned)uni((int)(f >> 32)) << 32) | (unsigned)uni((int)f); }
   auto bin = [&](int ctx, int b) { // TEncBinCABACCounter::encodeBin TEncBinCoderCABACCounter.cpp:90-105
@@ -1242,7 +1249,7 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
     const int pos_last = uni(scan[scan_last]);
     int py = pos_last >> log2n, px = pos_last - (py << log2n);
     if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-    const int gx = uni(s.t_group_idx[px]), gy = uni(s.t_group_idx[py]), gmax = uni(s.t_group_idx[n - 1]); int off, shift, kk;
+    const int gx = uni(tb().t_group_idx[px]), gy = uni(tb().t_group_idx[py]), gmax = uni(tb().t_group_idx[n - 1]); int off, shift, kk;
     last_ctx_params(ch, n, off, shift);
     const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
     for (kk = 0; kk < gx; kk++) bin(bx + (kk >> shift), 1);
@@ -1600,6 +1607,16 @@ DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
   wsync();
 }
 
+DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_);
+DEVN void region_run(KR k, LRegion &r);
+DEV void region_close(LRegion &r) { }
+DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
+DEV void region_wait(LRegion &r, int n) { while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2); wg_acquire(); }
+DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()]; wsync(); }
+DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
+struct DistCbf { uint32_t dist, cbf; };
+template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_);
+
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
 // memo != 0 (second RD pass, TU == PU): the unsplit coding of this TU with this mode was evaluated in the first pass from
 // the same coder state -- (memo_dist, memo_cost) are its results, bit for bit what a re-run would give -- so only the
@@ -1656,7 +1673,11 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       else if (check_full) { cabac_copy(k, &s.test[full_depth], &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
       else cabac_copy(k, &s.root[full_depth], &s.go);
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
-      for (int i = 0; i < 4; i++) {
+      bool spec = false;
+      if constexpr (LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && lds_load(&wg_shared().has_helpers) && (LOG2 - 1 > min_tu_log2(cu));
+      if (spec) { // second pass of a PU, spare waves in the workgroup: the children's two alternatives run concurrently (spec_children)
+        if constexpr (LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; }
+      } else for (int i = 0; i < 4; i++) {
         const Tu ch = tu_child(tu, i);
         { const DistCost r = recur_luma<LOG2 - 1>(k, cu, ch, check_first); split_dist += r.dist; split_cost += r.cost; }
         split_cbf |= (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
@@ -1731,6 +1752,67 @@ DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first, i
   }
 }
 
+// The four children of a TU in the second RD pass, when the workgroup has spare waves.  The reference decides child by child
+// (xRecurIntraCodingLumaQT :1598-1710): unsplit coding, then the four grandchildren, keep the cheaper, and the next child starts from
+// the winner's reconstruction and coder state.  The unsplit coding wins most of the time, so this wave codes the CHAIN of unsplit
+// children (picture, own layers and coder state advance exactly as if each had won) while the split alternative of every child runs as a
+// task on another wave from the state the chain had when it reached that child.  Then the children are judged in order: as long as the
+// unsplit coding wins, the chain WAS the reference's path; the first child whose split wins takes the task's result, and the chain
+// restarts behind it.  Every comparison is the reference's (strict <), every coding starts from the state the reference would have.
+template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
+{
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
+  LSmem &s = lds();
+  LRegion &r = my_region(1);
+  uint32_t split_dist = 0, split_cbf = 0;
+  int j = 0;
+  while (j < 4) {
+    wsync();
+    if (lane_id() < 4) r.modes[lane_id()] = j + lane_id();          // task i: the split alternative of child j + i
+    if (lane_id() == 0) s.ref_key[0] = -1;                          // a restarted chain meets the same block again with new neighbours
+    region_open(r, T_LUMA_SPLIT, 0, cu, tu);
+    for (int c = j; c < 4; c++) {
+      const Tu ch = tu_child(tu, c);
+      state_to_global(slot_state(k.slots, c, 0), &s.go);
+      region_publish(r);
+      // the unsplit alternative (the single-TU branch of recur_luma)
+      set_parts(k, s.a[A_TSKIP + 0], cu.zbase + ch.zrel, ch.nparts, 0); wsync();
+      const uint32_t d = code_tu_block(k, cu, ch, 0, 0);
+      const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
+      const uint32_t bits = intra_bits_qt<LOG2 - 1>(k, cu, ch, 1, 0);
+      const double cost = calc_rd_cost(k, bits, d);
+      if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; }
+    }
+    region_wait(r, 4 - j);
+    wsync();
+    int brk = -1;
+    for (int c = j; c < 4 && brk < 0; c++) if (ub(r.cost[c - j] < r.cost[4 + c])) brk = c;
+    const int last = brk < 0 ? 4 : brk;
+    for (int c = j; c < last; c++) { split_dist += (uint32_t)uni((int)r.dist[4 + c]); split_cbf |= (uint32_t)uni(r.modes[4 + c]); }
+    if (brk >= 0) { // the split of child brk wins: its arrays, levels, reconstruction and end state replace the chain's
+      const Tu ch = tu_child(tu, brk);
+      const int zc = cu.zbase + ch.zrel, n = 1 << (LOG2 - 1), lay = (5 - (LOG2 - 2)) * 6144, bo = boff(k, 0, ch.x, ch.y);
+      GLB const uint8_t *at = slot_attr(k.slots, brk);
+      GLB const int16_t *sc = slot_coef(k.slots, brk) + lay + zc * 16; GLB int16_t *dc = k.coef_l + lay + zc * 16;
+      GLB const pel_t *sr = slot_rec(k.slots, brk) + lay + bo; GLB pel_t *dr = k.rec_l + lay + bo;
+      GLB pel_t *rp = k.rec[0] + (size_t)ch.y * k.W + ch.x;
+      wsync();
+      for (int i = lane_id(); i < ch.nparts; i += 64) { s.a[A_TRIDX][zc + i] = at[i]; s.a[A_CBF][zc + i] = at[256 + i]; s.a[A_TSKIP][zc + i] = at[512 + i]; }
+      for (int i = lane_id(); i < n * n; i += 64) {
+        dc[i] = sc[i];
+        const int o = (i >> (LOG2 - 1)) * 64 + (i & (n - 1)); const pel_t v = sr[o];
+        dr[o] = v; rp[(size_t)(i >> (LOG2 - 1)) * k.W + (i & (n - 1))] = v;
+      }
+      state_from_global(&s.go, slot_state(k.slots, brk, 1));
+      split_dist += (uint32_t)uni((int)r.dist[brk - j]);
+      split_cbf |= (uint32_t)(uni(s.a[A_CBF][zc]) >> ch.trd) & 1;
+    }
+    j = brk < 0 ? 4 : brk + 1;
+  }
+  const DistCbf res = { split_dist, split_cbf };
+  return res;
+}
+
 // rough mode decision for one PU: 35 predictions + SATD (TEncSearch.cpp:2266-2346).  One lane per
 // (mode, 8x8 block) task (4x4 blocks for a 4x4 PU): predict the block in registers, Hadamard, add into satd[mode].
 // Angular modes are evaluated row by row in the mode's own orientation (the horizontal family on the transposed
@@ -1753,7 +1835,7 @@ template <int B> DEV unsigned rmd_block(KR k, const LSmem &s, int mode, int pn, 
     const int is_ver = mode >= 18, sgn = is_ver ? 1 : -1;
     const int ang_mode = is_ver ? mode - VER : -(mode - HOR);
     const int abs_ang = abs(ang_mode);
-    const int angle = (ang_mode < 0 ? -1 : 1) * s.t_ang[abs_ang], inv_angle = s.t_inv_ang[abs_ang];
+    const int angle = (ang_mode < 0 ? -1 : 1) * tb().t_ang[abs_ang], inv_angle = tb().t_inv_ang[abs_ang];
     const int x0 = is_ver ? bx : by, y0 = is_ver ? by : bx;   // block origin in the mode's orientation
     const int edge = (angle == 0) && (pn <= 16) && (x0 == 0);
     const int s0 = line[n2];
@@ -1865,10 +1947,6 @@ DEVN void rmd_satd(KR k, int x_, int y_, int pn_)
   PROF_ADD(k, 2);
 }
 
-DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_);
-DEVN void region_run(KR k, LRegion &r);
-DEV void region_close(LRegion &r) { }
-
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
 DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 {
@@ -1894,7 +1972,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       if (lane_id() < 35) {
         const int mode = lane_id();
         int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
-        const unsigned long long fr = f0 + (unsigned long long)s.t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
+        const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
         s.rmd_cost[mode] = (double)(s.satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
       }
       wsync();
@@ -2090,13 +2168,22 @@ DEVN void run_task(LRegion &r, int idx_)
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
   const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
-  kk.coef_l = slot_coef(kk.slots, idx); kk.rec_l = slot_rec(kk.slots, idx); kk.in_task = 1;
-  kk.trx0 = tu.x; kk.try0 = tu.y; kk.trx1 = tu.x + (1 << tu.log2); kk.try1 = tu.y + (1 << tu.log2);
+  const int slot = kind == T_LUMA_SPLIT ? mode : idx;       // the split alternative of child `mode` of r.tu
+  const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
+  kk.coef_l = slot_coef(kk.slots, slot); kk.rec_l = slot_rec(kk.slots, slot); kk.in_task = 1;
+  kk.trx0 = ttu.x; kk.try0 = ttu.y; kk.trx1 = ttu.x + (1 << ttu.log2); kk.try1 = ttu.y + (1 << ttu.log2);
   wsync();
   LCabac *start = &ow.curr[cu.depth];
-  GLB uint8_t *at = slot_attr(kk.slots, idx);
+  GLB uint8_t *at = slot_attr(kk.slots, slot);
   uint32_t dist; double cost;
-  if (kind == T_LUMA_P1) { // one candidate of the first RD pass (TEncSearch.cpp:2378-2443)
+  if (kind == T_LUMA_SPLIT) { // second RD pass: the four grandchildren of one child, from the state the chain of unsplit children had there
+    const int zc = cu.zbase + ttu.zrel;
+    state_from_global(&s.go, slot_state(kk.slots, slot, 0));
+    const DistCost dc = recur_luma_any(k, cu, ttu, 0, 1, 0, MAX_DOUBLE);     // memo form with an unlimited unsplit cost: the split is evaluated and taken
+    dist = dc.dist; cost = dc.cost;
+    state_to_global(slot_state(kk.slots, slot, 1), &s.go);
+    for (int i = lane_id(); i < ttu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zc + i]; at[256 + i] = s.a[A_CBF][zc + i]; at[512 + i] = s.a[A_TSKIP][zc + i]; }
+  } else if (kind == T_LUMA_P1) { // one candidate of the first RD pass (TEncSearch.cpp:2378-2443)
     const int zp = cu.zbase + tu.zrel;
     set_parts(k, s.a[A_LDIR], zp, tu.nparts, mode);
     cabac_copy(k, &s.go, start);
@@ -2128,11 +2215,18 @@ DEVN void run_task(LRegion &r, int idx_)
   wsync();
 }
 
-// claim a task of region r: its index, or -1
-DEV int region_claim(LRegion &r)
+// claim a task of region r: its index, or -1.  Compare-and-swap, not a blind add: the count grows while a region is open (region_publish),
+// and an index taken by a failed claim would be skipped when it becomes valid later.
+DEVN int region_claim(LRegion &r)
 {
-  const int t = lds_add(&r.ticket, 1), idx = t & 0xffff, n = (int)((unsigned)t >> 16);
-  return idx < n ? idx : -1;
+  int res = -1;
+  if (lane_id() == 0) {
+    int t = __hip_atomic_load(&r.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((t & 0xffff) < (int)((unsigned)t >> 16)) {
+      if (__hip_atomic_compare_exchange_strong(&r.ticket, &t, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { res = t & 0xffff; break; }
+    }
+  }
+  return uni(res);
 }
 DEVN void region_run(KR k, LRegion &r)
 { CHECK_EXEC(4); // the master works on its own region, then waits for the helpers' last tasks
@@ -2154,8 +2248,8 @@ DEV void helper_loop()
   const int me = wave_id();
   while (lds_load(&sh.masters_active) > 0) {
     int did = 0;
-    for (int j = 1; j <= NW && !did; j++) {
-      LRegion &r = sh.reg[(me + j) % NW];
+    for (int j = 2; j < 2 * NW + 2 && !did; j++) {
+      LRegion &r = sh.reg[(me + (j >> 1)) % NW][j & 1];
       const int t = lds_load(&r.ticket);
       if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
       const int idx = region_claim(r);
@@ -2285,7 +2379,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
   const int x = uni(x_), y = uni(y_);
   LSmem &s = lds();
   const int log2 = 6 - DEPTH, size = 1 << log2;
-  Cu cu = { x, y, log2, DEPTH, (int)s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)], 256 >> (2 * DEPTH), SIZE_2Nx2N };
+  Cu cu = { x, y, log2, DEPTH, (int)tb().r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)], 256 >> (2 * DEPTH), SIZE_2Nx2N };
   const int boundary = uni(!(x + size <= k.W && y + size <= k.H));
   const int pred_depth = uni(k.labels[k.addr * 16 + 4 * ((y & 63) / 16) + (x & 63) / 16]);
   const int check_cur = pred_depth == DEPTH, check_next = pred_depth > DEPTH;
@@ -2353,7 +2447,7 @@ template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
   const int x = uni(x_), y = uni(y_);
   LSmem &s = lds();
   const int size = 64 >> DEPTH;
-  const int z = s.r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)];
+  const int z = tb().r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)];
   int boundary = 0;
   const int dz = uni(s.a[A_DEPTH][z]);
   if (ub(x + size <= k.W && y + size <= k.H)) {
@@ -2445,7 +2539,7 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
     if (lane == 0) reset_bits(truec);
     encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
     wsync();
-    if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)s.t_ebits[126]; s.est_bits += truec->frac >> 15; }
+    if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)tb().t_ebits[126]; s.est_bits += truec->frac >> 15; }
     // flush the CTU record
     GLB unsigned char *rec = records + (size_t)a * REC_SIZE;
     for (int i = lane; i < 11 * 256 / 4; i += 64) ((GLB uint32_t *)rec)[i] = ((LDS const uint32_t *)&s.a[0][0])[i];
@@ -2500,34 +2594,33 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     s.my_qcost = (GLB double *)(scr + SCR_LAYERS); s.my_qrate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
     s.k.slots = scr + SCR_LAYERS + SCR_RDOQ;
   }
-  // tables into this wave's LDS block: z-scan map, CABAC tables, scans
-  for (int r = lane; r < 256; r += 64) {
-    const int x = r & 15, y = r >> 4; int z = 0;
-    for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
-    s.r2z[r] = (uint8_t)z;
-  }
-  for (int i = lane; i < 128; i += 64) { s.t_ebits[i] = c_entropy_bits[i]; s.t_next[1][i] = c_next_mps[i]; s.t_next[0][i] = c_next_lps[i]; }
-  if (lane < 9) { s.t_ang[lane] = c_ang_table[lane]; s.t_inv_ang[lane] = c_inv_ang_table[lane]; }
-  if (lane < 16) s.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
-  if (lane < 32) s.t_group_idx[lane] = c_group_idx[lane];
-  if (lane < 5) s.t_filter_thr[lane] = c_intra_filter_thr[lane];
-  if (lane < 12) { // CG order of every (scan type, block size)
-    const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
-    LDS uint8_t *cg = s.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
-    int ln = 0, c = 0;
-    for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
-  }
-  wsync();
-  if (lane < 3) { // order inside a CG, per scan type
-    int l2 = 0, c2 = 0;
-    for (int q = 0; q < 16; q++) { s.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
-  }
   // units are dealt round-robin: unit u belongs to workgroup u mod G, wave (u div G) mod NW
   const int n_units = p.n_frames * p.tile_count, G = (int)gridDim.x, first = (int)blockIdx.x + G * wave;
   LDS WgShared &sh = wg_shared();
-  if (lane == 0) {
-    sh.reg[wave].ticket = 0; sh.reg[wave].done = 0; sh.reg[wave].owner = wave;
-    if (wave == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; }
+  if (lane == 0) for (int q = 0; q < 2; q++) { sh.reg[wave][q].ticket = 0; sh.reg[wave][q].done = 0; sh.reg[wave][q].owner = wave; }
+  if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
+    LDS Tables &t = sh.tab;
+    for (int r = lane; r < 256; r += 64) {
+      const int x = r & 15, y = r >> 4; int z = 0;
+      for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+      t.r2z[r] = (uint8_t)z;
+    }
+    for (int i = lane; i < 128; i += 64) { t.t_ebits[i] = c_entropy_bits[i]; t.t_next[1][i] = c_next_mps[i]; t.t_next[0][i] = c_next_lps[i]; }
+    if (lane < 9) { t.t_ang[lane] = c_ang_table[lane]; t.t_inv_ang[lane] = c_inv_ang_table[lane]; }
+    if (lane < 16) t.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
+    if (lane < 32) t.t_group_idx[lane] = c_group_idx[lane];
+    if (lane < 5) t.t_filter_thr[lane] = c_intra_filter_thr[lane];
+    if (lane < 12) { // CG order of every (scan type, block size)
+      const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
+      LDS uint8_t *cg = t.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
+      int ln = 0, c = 0;
+      for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
+    }
+    if (lane < 3) { // order inside a CG, per scan type
+      int l2 = 0, c2 = 0;
+      for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
+    }
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m <= NW; }
   }
   __syncthreads();
   if (first < n_units) {
