@@ -2,12 +2,18 @@
 """bench.py -- all-intra CTUs/s of the hot path (on-device CNN depth predictor + depth-pruned CTU decision kernel).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run, one rank per GPU.
-A step = one pass of the whole hot path (hevcdl_encode_frames_dev: CNN + RD search) over one batch of synthetic frames
-that is already resident in HBM.  Frames are independent, so ranks shard by frame with no data-path collective; RCCL
-only gathers the per-frame rate/SSE records (weak scaling: per-GPU work is fixed).
-Prints ONE JSON line on rank 0 (metric of BASELINE.json + roofline + cpu_baseline).
+
+Workload of the headline line = C4 of BASELINE.json as written: 600 frames of 3840x2160, QP32.  The 600 frames are the job: with N ranks
+every rank takes a contiguous block of 600/N frames (sharding.shard_frames), i.e. STRONG scaling -- the total work is fixed.  A step = one
+pass of the whole hot path (hevcdl_encode_frames_dev: CNN + RD search) over the rank's frames, which are already resident in HBM.  Frames
+are independent, so there is no data-path collective; RCCL only gathers the per-frame rate records.
+Prints ONE JSON line on rank 0 (metric of BASELINE.json + roofline + cpu_baseline); on the single-GPU run it additionally carries
+  "saturated"    the same step over 2048 frames per GPU (every wave of the chip owns a frame: the throughput ceiling of the kernel),
+  "c2"           C2 of BASELINE.json (10 frames of 1920x1080) next to the reference encoder on 10 host cores in the same run,
+  "parity_check" the reference encoder's own CTU records / reconstruction for the top band of the timed frames against the GPU's.
 """
 import argparse
+import hashlib
 import json
 import multiprocessing as mp
 import os
@@ -20,33 +26,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_CTU = 27408        # orig 6144 + recon 6144 + levels 12288 + record 2816 + labels 16
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+RD_KERNEL_SRC = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "csrc", "rd_kernel.hip")
 
 
-def synth_frames_torch(torch, dev, width, height, n_frames, seed):
-    """Synthetic planar 4:2:0 frames generated on the device (generator of SURVEY.md section 8d)."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    y = torch.arange(height, device=dev, dtype=torch.float32).view(1, height, 1)
-    x = torch.arange(width, device=dev, dtype=torch.float32).view(1, 1, width)
-    f = torch.arange(n_frames, device=dev, dtype=torch.float32).view(n_frames, 1, 1)
+def synth_frames_torch(torch, dev, width, height, frame_ids, seed):
+    """Synthetic planar 4:2:0 frames generated on the device (generator of SURVEY.md section 8d).  A frame depends only on its index
+    (noise seeded per frame), so a frame's content does not depend on how the job is sharded."""
+    n_frames = len(frame_ids)
+    y = torch.arange(height, device=dev, dtype=torch.float32).view(height, 1)
+    x = torch.arange(width, device=dev, dtype=torch.float32).view(1, width)
     out = torch.empty((n_frames, width * height * 3 // 2), dtype=torch.uint8, device=dev)
-    chunk = 8
-    for s in range(0, n_frames, chunk):
-        e = min(n_frames, s + chunk)
-        ff = f[s:e]
-        Y = 128 + 50 * torch.sin(x / 57) * torch.cos(y / 43) + 30 * torch.sin((x + y + 3 * ff) / 19)
-        Y = Y + torch.randn((e - s, height, width), device=dev, generator=g) * 5
-        bw, bh = min(1200, width // 3), min(600, height // 3)
-        for k in range(s, e):
-            bx = (width // 5 + 4 * k) % max(1, width - bw)
-            by = height // 4
-            blk = Y[k - s, by:by + bh, bx:bx + bw]
-            Y[k - s, by:by + bh, bx:bx + bw] = torch.floor(blk / 24) * 24
-        Y = Y.clamp(0, 255).to(torch.uint8)
-        xc, yc = x[:, :, ::2], y[:, ::2, :]
-        U = (128 + 25 * torch.sin(xc / 61)).expand(e - s, height // 2, width // 2).clamp(0, 255).to(torch.uint8)
-        V = (128 + 25 * torch.cos(yc / 47)).expand(e - s, height // 2, width // 2).clamp(0, 255).to(torch.uint8)
-        out[s:e] = torch.cat([Y.reshape(e - s, -1), U.reshape(e - s, -1), V.reshape(e - s, -1)], dim=1)
+    base = 128 + 50 * torch.sin(x / 57) * torch.cos(y / 43)
+    xc, yc = x[:, ::2], y[::2, :]
+    U = (128 + 25 * torch.sin(xc / 61)).expand(height // 2, width // 2).clamp(0, 255).to(torch.uint8).reshape(-1)
+    V = (128 + 25 * torch.cos(yc / 47)).expand(height // 2, width // 2).clamp(0, 255).to(torch.uint8).reshape(-1)
+    g = torch.Generator(device=dev)
+    bw, bh = min(1200, width // 3), min(600, height // 3)
+    for i, k in enumerate(frame_ids):
+        g.manual_seed(seed + int(k))
+        Y = base + 30 * torch.sin((x + y + 3 * float(k)) / 19) + torch.randn((height, width), device=dev, generator=g) * 5
+        bx = (width // 5 + 4 * int(k)) % max(1, width - bw)
+        by = height // 4
+        Y[by:by + bh, bx:bx + bw] = torch.floor(Y[by:by + bh, bx:bx + bw] / 24) * 24
+        out[i, :width * height] = Y.clamp(0, 255).to(torch.uint8).reshape(-1)
+        out[i, width * height:width * height * 5 // 4] = U
+        out[i, width * height * 5 // 4:] = V
     return out
 
 
@@ -60,10 +64,22 @@ def _cpu_worker(args):
 
 
 REF_ENC = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_ref")
+REF_STAGES = "CTU decisions (label files preloaded) + final entropy coding + deblocking + SAO + bitstream / reconstruction files, process start-up and file I/O included; label CNN excluded"
+GPU_STAGES = "on-device label CNN + CTU decisions (records, levels, reconstruction before the in-loop filters), frames resident in HBM; final entropy coding, deblocking, SAO and file I/O excluded"
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _prepare_ref_run(args):
-    """Working directory of one reference-encoder process: input band, the label files it polls for (TEncCu.cpp:244-253), output dir."""
+    """Working directory of one reference-encoder process: input picture, the label files it polls for (TEncCu.cpp:244-253), output dir."""
     idx, yuv, w, h, qp, labels, base = args
     d = os.path.join(base, "p%d" % idx)
     os.makedirs(os.path.join(d, "rec"))
@@ -77,87 +93,183 @@ def _prepare_ref_run(args):
 
 def _run_ref(args):
     import subprocess
-    d, cmd = args
+    d, cmd, dump = args
+    env = dict(os.environ)
+    if dump:
+        env["HEVCDL_DUMP"] = os.path.join(d, "dump.bin")        # oracle/ref_hook.cpp: CTU record + reconstruction after every compressCtu
     t = time.time()
-    r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+    r = subprocess.run(cmd, cwd=d, env=env, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("reference encoder failed: " + r.stdout[-500:] + r.stderr[-500:])
     return time.time() - t
 
 
-def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=6):
-    """The reference itself (oracle/_ref/TAppEncoder_ref, built from /root/reference by oracle/build_ref.sh; configuration = the
-    reference's cfg as switches, oracle/ref_args.py) on the host cores: P processes, each encoding the top `band_rows` CTU rows of a
-    distinct frame with its labels already on disk, wall clock from first start to last exit.  Encoder only (in-loop filters and bitstream
-    included, as the reference runs them); the label CNN is excluded."""
+def _band(fr, width, full_h, height):
+    ysz, csz = width * full_h, (width // 2) * (full_h // 2)
+    return np.concatenate([fr[:width * height], fr[ysz:ysz + (width // 2) * (height // 2)], fr[ysz + csz:ysz + csz + (width // 2) * (height // 2)]])
+
+
+def run_reference_pictures(pictures, labels, width, height, qp, procs, dump=False, workers=None):
+    """P reference-encoder processes (oracle/_ref/TAppEncoder_ref; configuration = the reference's cfg as switches, oracle/ref_args.py), one
+    picture each, started together; -> (wall seconds, per-process seconds, list of dump arrays or None)."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_args
-    cores = os.cpu_count() or 1
-    p = min(cores, yuv_host.shape[0], max_procs or cores)
-    full_h = height
-    height = min(height, 64 * band_rows)
-    cx = (width + 63) // 64
-    ysz, csz = width * full_h, (width // 2) * (full_h // 2)
-
-    def band(fr):
-        return np.concatenate([fr[:width * height], fr[ysz:ysz + (width // 2) * (height // 2)], fr[ysz + csz:ysz + csz + (width // 2) * (height // 2)]])
-    labels_host = np.ascontiguousarray(labels_host[:p, :cx * ((height + 63) // 64)])
     base = tempfile.mkdtemp(prefix="hevcdl_cpu_")
+    dumps = None
     try:
-        dirs = [_prepare_ref_run((i, band(yuv_host[i]), width, height, qp, labels_host[i:i + 1], base)) for i in range(p)]
+        dirs = [_prepare_ref_run((i, pictures[i], width, height, qp, labels[i:i + 1], base)) for i in range(procs)]
         cmd = [REF_ENC, "-i", "in.yuv", "-b", "rec/str.bin", "-o", "rec/rec.yuv"] + ref_args.reference_args(width, height, 1, qp)
         t = time.time()
-        with ThreadPoolExecutor(max_workers=p) as pool:
-            per = list(pool.map(_run_ref, [(d, cmd) for d in dirs]))
+        with ThreadPoolExecutor(max_workers=workers or procs) as pool:
+            per = list(pool.map(_run_ref, [(d, cmd, dump) for d in dirs]))
         wall = time.time() - t
+        if dump:
+            import ref_tools
+            dumps = [np.fromfile(os.path.join(d, "dump.bin"), dtype=ref_tools.DUMP_DTYPE) for d in dirs]
     finally:
         shutil.rmtree(base, ignore_errors=True)
-    ctus = p * labels_host.shape[1]
-    return {"value": ctus / wall, "unit": "CTUs/s", "cores": p, "kind": "reference",
-            "sample": "top %dx%d band of %d frames of the workload, QP%d (1 reference-encoder process per band, label files from the GPU CNN, CNN excluded; deblocking, SAO and bitstream included), %.1f s wall, %.1f CTUs/s per core"
-                      % (width, height, p, qp, wall, ctus / sum(per) if sum(per) > 0 else 0.0)}
+    return wall, per, dumps
 
 
-def cpu_baseline(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=3):
-    """Oracle (CPU port, bit-identical to the reference on the golden vectors) timed on the host cores of this node:
-    P processes, each encoding the top `band_rows` CTU rows of a distinct frame of the same workload (bounded sample:
-    a full 2160p frame per process would take minutes), wall clock from first start to last exit."""
+def parity_against_dumps(dumps, gpu_records, gpu_recon_bands, width, height):
+    """Reference CTU records + reconstruction (oracle/ref_hook.cpp dumps) against the GPU's for the same pictures: every field of the record
+    and the three reconstruction blocks of every CTU, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_tools
+    ctus = mism = 0
+    first = None
+    for i, dump in enumerate(dumps):
+        for e in dump:
+            a = int(e["addr"])
+            r = gpu_records[i, a]
+            ok = all(np.array_equal(e["rec"][k], r[k]) for k in ref_tools.FIELDS)
+            if ok:
+                ry, ru, rv = ref_tools.ctu_recon_from_frame(gpu_recon_bands[i], width, height, a)
+                ok = np.array_equal(e["rec_y"], ry) and np.array_equal(e["rec_cb"], ru) and np.array_equal(e["rec_cr"], rv)
+            ctus += 1
+            if not ok:
+                mism += 1
+                first = first or [i, a]
+    return {"ctus": ctus, "mismatches": mism, "first_mismatch": first,
+            "checked": "every field of hevcdl_ctu_record (depth, partition, intra modes, TU tree, cbf, transform skip, bits / distortion / cost, levels) and the "
+                       "reconstruction of every CTU, reference encoder (TEncCu::compressCtu through oracle/ref_hook.cpp) vs GPU"}
+
+
+def effective_cores():
+    """Host cores this process may use: the hardware threads, capped by the cgroup CPU quota (the GPU boxes run the job in a container
+    whose cpu.max is far below the node's thread count; more processes than that only time-slice)."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=6, gpu_records=None, gpu_recon=None):
+    """The reference itself on the host cores.  (1) P = usable cores: P processes, a whole frame of the workload each,
+    wall clock from first start to last exit -> value.  (2) one such process alone -> one_process.  (3) parity: the top `band_rows` CTU
+    rows of every sampled frame (the decisions of those rows do not depend on the rows below) are encoded with the CTU-record dump of
+    oracle/ref_hook.cpp switched on and compared with the GPU's records / reconstruction of the same frames."""
+    cores = effective_cores()
+    p = min(cores, yuv_host.shape[0], max_procs or cores)
+    nct = labels_host.shape[1]
+    ww, perw, _ = run_reference_pictures([yuv_host[i] for i in range(p)], np.ascontiguousarray(labels_host[:p]), width, height, qp, p)
+    out = {"value": p * nct / ww, "unit": "CTUs/s", "cores": p, "kind": "reference", "cpu_model": cpu_model(),
+           "sample": "%d whole %dx%d frames of the workload, QP%d, one reference-encoder process per usable core (%d hardware threads on the node, cgroup CPU quota %d), "
+                     "%.1f s wall, %.1f CTUs/s per process" % (p, width, height, qp, os.cpu_count() or 1, cores, ww, p * nct / sum(perw)),
+           "stages_cpu": REF_STAGES, "stages_gpu": GPU_STAGES}
+    w1, _, _ = run_reference_pictures([yuv_host[0]], np.ascontiguousarray(labels_host[:1]), width, height, qp, 1)
+    out["one_process"] = {"value": nct / w1, "unit": "CTUs/s", "cores": 1, "sample": "one whole frame, one process alone on the node, %.1f s" % w1}
+    parity = None
+    if gpu_records is not None:
+        n = gpu_records.shape[0]
+        bh = min(height, 64 * band_rows)
+        nb = ((width + 63) // 64) * ((bh + 63) // 64)
+        bands = [_band(yuv_host[i], width, height, bh) for i in range(n)]
+        t = time.time()
+        _, _, dumps = run_reference_pictures(bands, np.ascontiguousarray(labels_host[:n, :nb]), width, bh, qp, n, dump=True, workers=cores)
+        parity = parity_against_dumps(dumps, gpu_records, [_band(gpu_recon[i], width, height, bh) for i in range(n)], width, bh)
+        parity["sample"] = "top %dx%d band (%d CTU rows) of %d frames of the timed job, %.1f s" % (width, bh, band_rows, n, time.time() - t)
+    return out, parity
+
+
+def cpu_baseline_port(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=3):
+    """Oracle (CPU port, bit-identical to the reference on the golden vectors) timed on the host cores of this node: stands in where the
+    reference build (oracle/_ref) is absent.  P processes, each encoding the top `band_rows` CTU rows of a distinct frame."""
     import __graft_entry__ as g
     g.build_oracle()
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     p = min(cores, yuv_host.shape[0], max_procs or cores)
-    full_h = height
-    height = min(height, 64 * band_rows)
+    bh = min(height, 64 * band_rows)
     cx = (width + 63) // 64
-    ysz, csz = width * full_h, (width // 2) * (full_h // 2)
-
-    def band(fr):
-        return np.concatenate([fr[:width * height], fr[ysz:ysz + (width // 2) * (height // 2)], fr[ysz + csz:ysz + csz + (width // 2) * (height // 2)]])
-    yuv_host = np.stack([band(yuv_host[i]) for i in range(p)])
-    labels_host = np.ascontiguousarray(labels_host[:p, :cx * ((height + 63) // 64)])
-    jobs = [(yuv_host[i:i + 1], width, height, qp, labels_host[i:i + 1]) for i in range(p)]
+    bands = np.stack([_band(yuv_host[i], width, height, bh) for i in range(p)])
+    lab = np.ascontiguousarray(labels_host[:p, :cx * ((bh + 63) // 64)])
+    jobs = [(bands[i:i + 1], width, bh, qp, lab[i:i + 1]) for i in range(p)]
     t = time.time()
     with mp.get_context("spawn").Pool(p) as pool:
         per = pool.map(_cpu_worker, jobs)
     wall = time.time() - t
-    ctus = p * labels_host.shape[1]
-    return {"value": ctus / wall, "unit": "CTUs/s", "cores": p, "kind": "port",
+    ctus = p * lab.shape[1]
+    return {"value": ctus / wall, "unit": "CTUs/s", "cores": p, "kind": "port", "cpu_model": cpu_model(),
             "sample": "top %dx%d band of %d frames of the workload, QP%d (1 band per process, labels from the GPU CNN, CNN excluded), %.1f s wall, %.1f CTUs/s per core"
-                      % (width, height, p, qp, wall, ctus / sum(per) if sum(per) > 0 else 0.0)}
+                      % (width, bh, p, qp, wall, ctus / sum(per) if sum(per) > 0 else 0.0)}, None
+
+
+def measured_traffic(n_ctus):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS kernel source (profiles/r02_traffic.json names the sha of
+    rd_kernel.hip it was collected on); None when the source has changed since (the counters cannot be read from inside the process)."""
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no counter pass committed for this build"
+    tj = json.load(open(tpath))
+    sha = hashlib.sha256(open(RD_KERNEL_SRC, "rb").read()).hexdigest()[:16]
+    if tj.get("rd_kernel_sha16") != sha:
+        return None, "profiles/r02_traffic.json was collected on another build of rd_kernel.hip (%s, now %s): not reported" % (tj.get("rd_kernel_sha16"), sha)
+    return (tj["fetch_bytes_per_ctu"] + tj["write_bytes_per_ctu"]) * n_ctus, tj["source"] + "; " + tj["note"]
+
+
+def timed_steps(torch, enc, tensors, n_frames, steps, warmup, barrier):
+    yuv, labels, records, recon, stats = tensors
+    stream = torch.cuda.current_stream()
+
+    def step():
+        enc.encode_frames_dev(yuv.data_ptr(), n_frames, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream.cuda_stream)
+    for _ in range(warmup):
+        step()
+    barrier()
+    enc.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = enc.profile_get()
+    enc.profile_enable(False)
+    return elapsed, prof
+
+
+def alloc(torch, hevcdl_amd, dev, n, frame_bytes, ctus):
+    return (torch.zeros((n, ctus, 16), dtype=torch.uint8, device=dev), torch.zeros((n, ctus, hevcdl_amd.REC_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+            torch.zeros((n, frame_bytes), dtype=torch.uint8, device=dev), torch.zeros((n, hevcdl_amd.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=2048, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--frames", type=int, default=600, help="frames of the job (C4: 600), split over the ranks")
+    ap.add_argument("--saturated-frames", type=int, default=2048, help="extra single-GPU measurement with this many frames in flight (0: skip)")
+    ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0)
     ap.add_argument("--cpu-baseline", default="reference", choices=["reference", "port"], help="reference: oracle/_ref/TAppEncoder_ref when present; port: the plain-C oracle")
@@ -165,6 +277,7 @@ def main():
 
     import torch
     import hevcdl_amd
+    import hevcdl_amd.sharding as sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,77 +297,103 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W, H, qp, F = a.width, a.height, a.qp, a.frames
-    enc = hevcdl_amd.Encoder(W, H, qp, max_frames=F, device=local)
-    ctus = enc.ctus
-    yuv = synth_frames_torch(torch, dev, W, H, F, seed=1000 + rank)
-    labels = torch.zeros((F, ctus, 16), dtype=torch.uint8, device=dev)
-    records = torch.zeros((F, ctus, hevcdl_amd.REC_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    recon = torch.zeros_like(yuv)
-    stats = torch.zeros((F, hevcdl_amd.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        enc.encode_frames_dev(yuv.data_ptr(), F, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream.cuda_stream)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    enc.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = enc.profile_get()
-    enc.profile_enable(False)
+    W, H, qp, F = a.width, a.height, a.qp, a.frames
+    mine = sharding.shard_frames(F, world, rank)                   # contiguous block of the job's frames
+    Fr = len(mine)
+    per_rank = len(sharding.shard_frames(F, world, 0))
+    enc = hevcdl_amd.Encoder(W, H, qp, max_frames=max(1, per_rank), device=local)
+    ctus = enc.ctus
+    yuv = synth_frames_torch(torch, dev, W, H, list(mine), seed=1000)
+    labels, records, recon, stats = alloc(torch, hevcdl_amd, dev, max(1, Fr), enc.frame_bytes, ctus)
+    elapsed, prof = timed_steps(torch, enc, (yuv, labels, records, recon, stats), Fr, a.steps, a.warmup, barrier)
 
-    # per-frame summaries (bits, SSE) gathered to rank 0: the only collective of the path
-    st = torch.from_numpy(np.frombuffer(stats.cpu().numpy().tobytes(), dtype=hevcdl_amd.STATS_DTYPE)["est_bits"].astype(np.int64)).to(cdev)
+    # per-frame summaries (estimated bits) gathered to rank 0: the only collective of the path
+    st = np.frombuffer(stats.cpu().numpy().tobytes(), dtype=hevcdl_amd.STATS_DTYPE)["est_bits"].astype(np.int64)[:Fr]
+    stt = torch.zeros(per_rank, dtype=torch.int64)
+    stt[:Fr] = torch.from_numpy(st.copy())
+    stt = stt.to(cdev)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        gathered = [torch.zeros_like(st) for _ in range(world)] if rank == 0 else None
-        dist.gather(st, gathered, dst=0)
+        gathered = [torch.zeros_like(stt) for _ in range(world)] if rank == 0 else None
+        dist.gather(stt, gathered, dst=0)
         total_bits = int(sum(int(g.sum().item()) for g in gathered)) if rank == 0 else 0
     else:
-        total_bits = int(st.sum().item())
+        total_bits = int(stt.sum().item())
 
     if rank == 0:
-        total_ctus = world * F * ctus * a.steps
+        total_ctus = F * ctus * a.steps
         value = total_ctus / elapsed
         rd_avg_s = (prof["rd_ms"] / max(1, prof["rd_launches"])) / 1e3
-        achieved = (ALGO_BYTES_PER_CTU * F * ctus / rd_avg_s) / 1e9 if rd_avg_s > 0 else 0.0
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01k_traffic.json")
-        if os.path.exists(tpath):   # PMC counters cannot be collected from inside the process: per-CTU bytes of the committed rocprofv3 passes
-            tj = json.load(open(tpath))
-            traffic = (tj["fetch_bytes_per_ctu"] + tj["write_bytes_per_ctu"]) * F * ctus
-            traffic_src = tj["source"] + "; " + tj["note"]
+        achieved = (ALGO_BYTES_PER_CTU * Fr * ctus / rd_avg_s) / 1e9 if rd_avg_s > 0 else 0.0
+        traffic, traffic_src = measured_traffic(Fr * ctus)
+        is_c4 = (W, H, qp, F) == (3840, 2160, 32, 600)
         out = {
             "metric": "all-intra CTUs/s at 2160p QP32", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8/int32/f64", "data": "synthetic",
-            "config": {"workload": "%dx%d 8-bit 4:2:0 all-intra QP%d, %d frames per GPU per step (frame-sharded; C4 of BASELINE.json is 75/GPU at 8 GPUs), on-device CNN labels + depth-pruned CTU decisions" % (W, H, qp, F),
-                       "frames_per_gpu": F, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
+            "config": {"workload": "%dx%d 8-bit 4:2:0 all-intra QP%d, %d frames%s, frame-sharded (contiguous blocks of %d frames per GPU), on-device CNN labels + depth-pruned CTU decisions"
+                                   % (W, H, qp, F, " (C4 of BASELINE.json)" if is_c4 else "", per_rank),
+                       "frames": F, "frames_per_gpu": per_rank, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
-                         "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU},
-            "est_bits_per_frame": total_bits / max(1, world * F),
+                         "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
+                         "units_per_launch": "%d frames x %d CTUs (rank 0)" % (Fr, ctus)},
+            "est_bits_per_frame": total_bits / max(1, F),
         }
-        if not a.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 of the single-GPU run only
-            nb = min(F, os.cpu_count() or 1)
-            # the reference build travels with the repository (oracle/_ref); without it the plain-C port stands in
-            base_fn = cpu_baseline_reference if os.path.exists(REF_ENC) and a.cpu_baseline != "port" else cpu_baseline
-            out["cpu_baseline"] = base_fn(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
+        if world == 1:
+            if not a.no_cpu_baseline:       # the CPU baseline is timed on rank 0 of the single-GPU run only
+                nb = min(Fr, 256)                      # frames sampled for the parity check
+                cx = (W + 63) // 64
+                rows = 6
+                if os.path.exists(REF_ENC) and a.cpu_baseline != "port":
+                    rec_h = np.frombuffer(records[:nb, :cx * rows].contiguous().cpu().numpy().tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nb, cx * rows)
+                    cb, parity = cpu_baseline_reference(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None, rows,
+                                                        gpu_records=rec_h, gpu_recon=recon[:nb].cpu().numpy())
+                else:     # the reference build travels with the repository (oracle/_ref); without it the plain-C port stands in
+                    cb, parity = cpu_baseline_port(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
+                out["cpu_baseline"] = cb
+                if parity is not None:
+                    out["parity_check"] = parity
+            del yuv, labels, records, recon, stats
+            enc.close()
+            torch.cuda.empty_cache()
+            if a.saturated_frames > 0:      # every wave of the chip owns a frame: what the kernel does when the job is large enough
+                S = a.saturated_frames
+                e2 = hevcdl_amd.Encoder(W, H, qp, max_frames=S, device=local)
+                y2 = synth_frames_torch(torch, dev, W, H, list(range(min(S, 64))), seed=1000)
+                y2 = y2.repeat((S + y2.shape[0] - 1) // y2.shape[0], 1)[:S].contiguous()
+                t2 = alloc(torch, hevcdl_amd, dev, S, e2.frame_bytes, ctus)
+                el2, pr2 = timed_steps(torch, e2, (y2,) + t2, S, 1, 0, barrier)
+                out["saturated"] = {"frames_per_gpu": S, "value": S * ctus / el2, "unit": "CTUs/s", "ms_per_step": 1e3 * el2, "kernel_ms": pr2["rd_ms"], "cnn_kernel_ms": pr2["cnn_ms"],
+                                    "note": "one step, %d distinct frames repeated; not the headline: the job of BASELINE.json has 600 frames" % min(S, 64)}
+                del y2, t2
+                e2.close()
+                torch.cuda.empty_cache()
+            if not a.no_c2:                 # C2 of BASELINE.json: 10 frames of 1080p on one GPU, the reference on 10 host cores beside it
+                w2, h2, n2 = 1920, 1080, 10
+                e3 = hevcdl_amd.Encoder(w2, h2, qp, max_frames=n2, device=local)
+                y3 = synth_frames_torch(torch, dev, w2, h2, list(range(n2)), seed=2000)
+                t3 = alloc(torch, hevcdl_amd, dev, n2, e3.frame_bytes, e3.ctus)
+                el3, pr3 = timed_steps(torch, e3, (y3,) + t3, n2, 3, 1, barrier)
+                c2 = {"workload": "1920x1080 8-bit 4:2:0 all-intra QP%d, 10 frames (C2 of BASELINE.json)" % qp, "value": 3 * n2 * e3.ctus / el3, "unit": "CTUs/s",
+                      "ms_per_step": 1e3 * el3 / 3, "kernel_ms": pr3["rd_ms"] / 3, "cnn_kernel_ms": pr3["cnn_ms"] / 3}
+                if not a.no_cpu_baseline and os.path.exists(REF_ENC) and a.cpu_baseline != "port":
+                    ww, perw, _ = run_reference_pictures(list(y3.cpu().numpy()), t3[0].cpu().numpy(), w2, h2, qp, n2)
+                    c2["cpu_reference"] = {"value": n2 * e3.ctus / ww, "unit": "CTUs/s", "cores": n2, "sample": "the same 10 frames, one reference-encoder process per frame, %.1f s wall" % ww,
+                                           "stages_cpu": REF_STAGES, "stages_gpu": GPU_STAGES}
+                    c2["gpu_over_cpu"] = c2["value"] / c2["cpu_reference"]["value"]
+                out["c2"] = c2
+                e3.close()
         print(json.dumps(out), flush=True)
-    enc.close()
+    if world > 1 or rank != 0:
+        enc.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

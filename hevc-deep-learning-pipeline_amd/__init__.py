@@ -158,6 +158,7 @@ def load_library():
     lib.hevcdl_compress_ctu.argtypes = [vp, ci, ci, vp, vp, vp]
     lib.hevcdl_get_recon.argtypes = [vp, ci, vp]
     lib.hevcdl_predict_depth_dev.argtypes = [vp, vp, ci, vp, vp, vp]
+    lib.hevcdl_clamp_labels_dev.argtypes = [vp, vp, ci, vp]
     lib.hevcdl_compress_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_encode_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_compress_tiles_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, ci, vp]
@@ -176,7 +177,7 @@ def load_library():
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_encode_pictures", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
+           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_encode_pictures", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5"]
 
@@ -379,6 +380,10 @@ class Encoder:
     # ---- device-resident entry points: arguments are raw device pointers (ints), e.g. torch.Tensor.data_ptr() ----
     def predict_depth_dev(self, d_yuv, n, d_labels, d_logits=None, stream=None):
         self._check(self.lib.hevcdl_predict_depth_dev(self._h, d_yuv, n, d_labels, d_logits, stream))
+
+    def clamp_labels_dev(self, d_labels, n, stream=None):
+        """Caller-made labels on the device: boundary clamp + quadtree consistency in place (hevcdl_clamp_labels_dev)."""
+        self._check(self.lib.hevcdl_clamp_labels_dev(self._h, d_labels, n, stream))
 
     def compress_frames_dev(self, d_yuv, n, d_labels, d_records, d_recon, d_stats=None, stream=None):
         self._check(self.lib.hevcdl_compress_frames_dev(self._h, d_yuv, n, d_labels, d_records, d_recon, d_stats, stream))

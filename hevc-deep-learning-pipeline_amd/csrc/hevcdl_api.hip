@@ -23,6 +23,35 @@ __global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (uint8_t)(src[i] >> shift);
 }
 
+// Boundary policy HEVCDL_BOUNDARY_CLAMP applied to caller-supplied labels (the label files of the reference's use_model.py are unclamped):
+// every cell is raised to the smallest depth whose CU lies inside the picture, then the quadtree is made consistent again (a split CTU has
+// no depth-0 cell, a split 32x32 quadrant no depth-1 cell) -- the same rule the label stage of fc_kernel.hip applies to its own output.
+// Labels above 3 are a caller error: *bad is set.  One thread per CTU.
+__global__ void hevcdl_clamp_labels_kernel(uint8_t *labels, int n_ctus, int ctus_per_frame, int ctus_x, int width, int height, int *bad)
+{
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_ctus) return;
+  const int addr = g % ctus_per_frame, x0 = (addr % ctus_x) * 64, y0 = (addr / ctus_x) * 64;
+  uint8_t *lab = labels + (size_t)g * 16;
+  const int quads[4][4] = { {0, 1, 4, 5}, {2, 3, 6, 7}, {8, 9, 12, 13}, {10, 11, 14, 15} };
+  int l[16], mxl = 0;
+  for (int c = 0; c < 16; c++) {
+    l[c] = lab[c];
+    if (l[c] > 3) { *bad = 1; l[c] = 3; }
+    const int px = x0 + (c & 3) * 16, py = y0 + (c >> 2) * 16;
+    int md = 0;
+    if (px < width && py < height) while (md < 3) { const int s = 64 >> md; if ((px / s) * s + s <= width && (py / s) * s + s <= height) break; md++; }
+    if (l[c] < md) l[c] = md;
+    if (l[c] > mxl) mxl = l[c];
+  }
+  if (mxl > 0) for (int c = 0; c < 16; c++) if (l[c] < 1) l[c] = 1;
+  for (int q = 0; q < 4; q++) {
+    int m = 0; for (int k = 0; k < 4; k++) if (l[quads[q][k]] > m) m = l[quads[q][k]];
+    if (m >= 2) for (int k = 0; k < 4; k++) if (l[quads[q][k]] < 2) l[quads[q][k]] = 2;
+  }
+  for (int c = 0; c < 16; c++) lab[c] = (uint8_t)l[c];
+}
+
 struct hevcdl_ctx {
   hevcdl_config cfg;
   int ctus_x, ctus_y, ctus, n_cus;
@@ -40,6 +69,7 @@ struct hevcdl_ctx {
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
   unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params;   // SAO workspace
+  int *d_flag;                   // device-side error flag of the label check
   bool profile;
   std::vector<hipEvent_t> ev_cnn, ev_rd;       // start/stop pairs
   char err[256];
@@ -151,7 +181,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr; ctx->d_flag = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -164,6 +194,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_fc(weights + B_F1W, weights + B_F1B, 256, 2048, pk.data() + HEVCDL_W_FC1);
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
+  CK(hipMalloc(&ctx->d_flag, sizeof(int)));
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
   ctx->scratch_per_wave = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
@@ -190,7 +221,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_flag);
   delete ctx;
 }
 
@@ -298,6 +329,22 @@ static hevcdl_status check_frames(hevcdl_ctx *ctx, int n_frames)
   return HEVCDL_OK;
 }
 
+// caller-supplied labels (device copy): boundary clamp + quadtree consistency in place; labels above 3 -> HEVCDL_ERR_INVALID_ARG
+extern "C" hevcdl_status hevcdl_clamp_labels_dev(hevcdl_ctx *ctx, void *d_labels, int n_frames, void *stream)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!d_labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null device pointer");
+  const int n = n_frames * ctx->ctus;
+  HIPCHK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), (hipStream_t)stream));
+  hipLaunchKernelGGL(hevcdl_clamp_labels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint8_t *)d_labels, n, ctx->ctus, ctx->ctus_x, ctx->cfg.width, ctx->cfg.height, ctx->d_flag);
+  int bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  if (bad) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "labels: depth above 3");
+  return HEVCDL_OK;
+}
+
 extern "C" hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream)
 {
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
@@ -386,7 +433,7 @@ extern "C" hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *
   if (!yuv || !records) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
   st = ensure_staging(ctx); if (st) return st;
   HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
-  if (labels_opt) HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) { HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice)); st = hevcdl_clamp_labels_dev(ctx, ctx->d_labels, n_frames, nullptr); if (st) return st; }
   else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
   st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;
   hipError_t e = hipDeviceSynchronize();
@@ -487,7 +534,7 @@ extern "C" hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv
   if (sao_opt && !ctx->d_sao_params) HIPCHK(hipMalloc(&ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * ctx->cfg.max_frames));
   if (sao_opt && !ctx->d_picture) HIPCHK(hipMalloc(&ctx->d_picture, ctx->frame_bytes * (size_t)ctx->cfg.max_frames));
   HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
-  if (labels_opt) HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) { HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice)); st = hevcdl_clamp_labels_dev(ctx, ctx->d_labels, n_frames, nullptr); if (st) return st; }
   else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
   st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;
   uint8_t *d_final = ctx->d_recon;
@@ -510,7 +557,7 @@ extern "C" hevcdl_status hevcdl_begin_frames(hevcdl_ctx *ctx, const uint8_t *yuv
   st = ensure_staging(ctx); if (st) return st;
   if (!ctx->d_cabac) HIPCHK(hipMalloc(&ctx->d_cabac, (size_t)168 * ctx->cfg.max_frames));
   HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
-  if (labels_opt) HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) { HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice)); st = hevcdl_clamp_labels_dev(ctx, ctx->d_labels, n_frames, nullptr); if (st) return st; }
   else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
   HIPCHK(hipMemset(ctx->d_recon, 0, ctx->frame_bytes * n_frames));
   HIPCHK(hipMemset(ctx->d_records, 0, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames));

@@ -1783,7 +1783,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       const double cost = calc_rd_cost(k, bits, d);
       if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; }
     }
-    region_wait(r, 4 - j);
+    { PROF_MARK0(); region_wait(r, 4 - j); PROF_MARK(38); }
     wsync();
     int brk = -1;
     for (int c = j; c < 4 && brk < 0; c++) if (ub(r.cost[c - j] < r.cost[4 + c])) brk = c;
@@ -1997,8 +1997,10 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       LRegion &r = my_region();
       wsync();
       if (lane_id() < nfull) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
+      PROF_MARK0();
       region_open(r, T_LUMA_P1, nfull, cu, ptu);
       region_run(k, r);
+      PROF_MARK(36);
       // the serial loop keeps a candidate when its cost is strictly smaller: the winner is the smallest cost, first in list order
       int win = -1;
       for (int m = 0; m < nfull; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
@@ -2189,9 +2191,7 @@ DEVN void run_task(LRegion &r, int idx_)
     cabac_copy(k, &s.go, start);
     // a candidate of a PU that is one TU writes its reconstruction to the layer only (code_tu_block mode 3)
     const int one_tu = tu.log2 >= 3 && tu.log2 <= 5;
-    PROF_MARK0();
     const DistCost dc = recur_luma_any(k, cu, tu, one_tu ? 2 : 1);
-    PROF_MARK(36);
     dist = dc.dist; cost = dc.cost;
     wsync();
     for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
@@ -2284,8 +2284,10 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     LRegion &r = my_region();
     wsync();
     if (lane_id() == 0) for (int m = 0; m < 5; m++) r.modes[m] = (int)mode_list[m];
+    PROF_MARK0();
     region_open(r, T_CHROMA, 5, cu, root);
     region_run(k, r);
+    PROF_MARK(39);
     int win = -1;
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
     if (win >= 0) {

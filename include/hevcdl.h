@@ -218,6 +218,13 @@ hevcdl_status hevcdl_get_recon(hevcdl_ctx *ctx, int frame, uint8_t *recon);
 /* ---- device-buffer entry points (inputs/outputs already resident in HBM, asynchronous on `stream`) ---- */
 /* All pointers are device pointers; stream is a hipStream_t (NULL = default stream). */
 hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream);
+/* Labels that do NOT come from hevcdl_predict_depth* (e.g. the unclamped label files of the reference's use_model.py, TEncCu.cpp:244-287):
+ * boundary policy HEVCDL_BOUNDARY_CLAMP + quadtree consistency, in place; a depth above 3 is HEVCDL_ERR_INVALID_ARG.  The host-pointer
+ * entry points (labels_opt of hevcdl_compress_frames / hevcdl_encode_pictures / hevcdl_begin_frames) do this themselves; the device
+ * entry points below take d_labels as they are and require them to satisfy the policy.  Synchronises `stream`.
+ * One context = one launch in flight: the context owns the kernels' workspace, so calls on different streams of the same context must
+ * not overlap (use one context per concurrent stream). */
+hevcdl_status hevcdl_clamp_labels_dev(hevcdl_ctx *ctx, void *d_labels, int n_frames, void *stream);
 hevcdl_status hevcdl_compress_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels,
                                          void *d_records, void *d_recon, void *d_stats, void *stream);
 /* The same for tiles [tile_begin, tile_begin + tile_count) of every frame only (raster order of the cfg's tile grid): the unit of

@@ -152,7 +152,7 @@ def gen_weights(sd):
 def gen_cnn(model, src):
     import torch
     rng = np.random.default_rng(1234)
-    n = 64
+    n = 256                                        # >= 256 CTUs
     ctus = np.zeros((n, 64, 64, 3), np.uint8)
     yy, xx = np.mgrid[0:64, 0:64]
     for i in range(n):
@@ -203,7 +203,7 @@ def gen_cnn(model, src):
 
     labels = np.array([ref_labels(logits[i]) for i in range(n)], np.uint8)
     np.savez_compressed(os.path.join(GOLD, "cnn_f1.npz"), ctu_rgb=ctus, logits=logits, labels=labels)
-    m = 4000
+    m = 10000                                      # F-cnn-2: >= 10 000 tuples
     digits = rng.integers(0, 4, (m, 4, 4))
     fake = np.zeros((m, 4, 16), np.float32)
     for k in range(4):
@@ -211,6 +211,26 @@ def gen_cnn(model, src):
     lab2 = np.array([ref_labels(fake[i]) for i in range(m)], np.uint8)
     np.savez_compressed(os.path.join(GOLD, "cnn_f2.npz"), digits=digits.astype(np.uint8), labels=lab2)
     print("cnn fixtures:", n, "CTUs,", m, "label tuples; label histogram", np.bincount(labels.ravel(), minlength=4))
+
+
+def gen_full():
+    """One whole 1920x1080 frame through the reference (510 CTUs, labels = what the label CNN gives on this frame, computed by the numpy
+    restatement of the CNN): the full-size pin of the decision path ("cross-check on large frames").  The input is
+    regenerated from its seed (ref_tools.synth_yuv); stored are the labels, the reference's CTU records and checksums of its reconstruction."""
+    import zlib
+    import cnn_oracle
+    w, h, qp, seed = 1920, 1080, 32, 77
+    yuv = rt.synth_yuv(w, h, 1, seed)
+    wts = cnn_oracle.load_weights(os.path.join(WDIR, "hevc_encoder_model.f32"))
+    lab, _ = cnn_oracle.predict_labels(wts, yuv, w, h)
+    dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab)
+    dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+    nctu = lab.shape[1]
+    assert len(dump) == nctu
+    crc = np.array([[zlib.crc32(e[k].tobytes()) for k in ("rec_y", "rec_cb", "rec_cr")] for e in dump], np.uint32)
+    np.savez_compressed(os.path.join(GOLD, "full_f1080_q32.npz"), width=w, height=h, qp=qp, seed=seed, labels=lab, records=dump["rec"].reshape(1, nctu), recon_crc32=crc,
+                        summary=np.array([ln for ln in out.splitlines() if ln.startswith("POC")]))
+    print("full-frame fixture: %d CTUs, label histogram %s" % (nctu, np.bincount(lab.ravel(), minlength=4)))
 
 
 def gen_bd():
@@ -222,7 +242,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full"]
     if "rd" in what:
         gen_rd()
     if "rdtiles" in what:
@@ -239,3 +259,5 @@ if __name__ == "__main__":
             gen_cnn(model, src)
     if "bd" in what:
         gen_bd()
+    if "full" in what:
+        gen_full()

@@ -30,6 +30,25 @@ def test_rd_oracle_matches_reference_records(oracle_built, path):
     assert int(stats["sse"].sum()) == int(((yuv - recon.astype(np.int64)) ** 2).sum())
 
 
+def full_frame_crc(recon_frame, w, h, nctu):
+    import zlib
+    import ref_tools
+    return np.array([[zlib.crc32(b.tobytes()) for b in ref_tools.ctu_recon_from_frame(recon_frame, w, h, a)] for a in range(nctu)], np.uint32)
+
+
+def test_rd_oracle_matches_reference_on_a_whole_1080p_frame(oracle_built):
+    """The full-size pin: 510 CTUs of 1920x1080 coded by the reference itself (tests/golden/full_f1080_q32.npz,
+    oracle/gen_fixtures.py gen_full) -- records bit for bit, reconstruction by per-CTU checksums."""
+    import ref_tools
+    f = np.load(os.path.join(GOLD, "full_f1080_q32.npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    yuv = ref_tools.synth_yuv(w, h, 1, int(f["seed"]))
+    recs, recon, stats = ref_tools.run_oracle(yuv, w, h, qp, f["labels"])
+    for k in FIELDS:
+        assert np.array_equal(recs[k], f["records"][k]), k
+    assert np.array_equal(full_frame_crc(recon[0], w, h, recs.shape[1]), f["recon_crc32"])
+
+
 def test_fixtures_cover_the_decision_space():
     """depths 0..3, both partition sizes, transform skip, split transforms and boundary CTUs all occur in the golden set."""
     seen_depth, seen_part, ts, tr, outside = set(), set(), 0, 0, 0

@@ -44,6 +44,75 @@ def test_golden_records_bit_exact(path):
             assert np.array_equal(y, f["rec_y"][fr, a]) and np.array_equal(u, f["rec_cb"][fr, a]) and np.array_equal(v, f["rec_cr"][fr, a]), (fr, a)
 
 
+def test_whole_1080p_frame_matches_the_reference_golden():
+    """Full-size parity against the reference itself: one 1920x1080 frame (510 CTUs), records bit for bit and the reconstruction of every CTU
+    by checksum (tests/golden/full_f1080_q32.npz: a run of the reference encoder, oracle/gen_fixtures.py gen_full)."""
+    import hevcdl_amd
+    import ref_tools
+    from test_oracle_golden import full_frame_crc
+    f = np.load(os.path.join(GOLD, "full_f1080_q32.npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    yuv = ref_tools.synth_yuv(w, h, 1, int(f["seed"]))
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1)
+    recs, recon, stats = enc.compress_frames(yuv, f["labels"])
+    gpu_labels = enc.predict_depth(yuv)
+    enc.close()
+    assert_records_equal(recs, f["records"], "full_f1080_q32")
+    assert np.array_equal(full_frame_crc(recon[0], w, h, recs.shape[1]), f["recon_crc32"])
+    # the fixture's labels are the numpy CNN's; the device CNN agrees on (nearly) every CTU of this frame
+    assert (gpu_labels == f["labels"]).mean() > 0.99
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
+def test_whole_1080p_frame_matches_a_live_reference_run():
+    """The reference encoder itself, run now on this machine with the labels the device CNN gives (oracle/_ref travels with the repository):
+    a fresh seed per run of the suite would be nondeterministic, so the seed is fixed but differs from the golden's."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp = 1920, 1080, 27
+    yuv = ref_tools.synth_yuv(w, h, 1, 1234)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1)
+    labels = enc.predict_depth(yuv)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    sys_path_bench = os.path.join(os.path.dirname(GOLD), "..")
+    import sys
+    sys.path.insert(0, sys_path_bench)
+    import bench
+    wall, per, dumps = bench.run_reference_pictures([yuv[0]], labels, w, h, qp, 1, dump=True)
+    res = bench.parity_against_dumps(dumps, recs, [recon[0]], w, h)
+    assert res["ctus"] == recs.shape[1] and res["mismatches"] == 0, res
+
+
+def test_unclamped_caller_labels_get_the_boundary_policy(oracle_built):
+    """Label files of the reference's own label producer are not clamped at the picture border.  Caller-supplied
+    labels therefore go through the boundary policy before the search: raw random labels on 200x136 give exactly the result of their clamped
+    form (no CU left undecided, SIZE_NONE only outside the picture), and a depth above 3 is rejected."""
+    import hevcdl_amd
+    import ref_tools
+    import cnn_oracle
+    w, h, qp = 200, 136, 30
+    yuv = ref_tools.synth_yuv(w, h, 1, 91)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1)
+    raw = np.random.default_rng(5).integers(0, 4, (1, enc.ctus, 16)).astype(np.uint8)
+    clamped = cnn_oracle.clamp_labels(raw.copy(), w, h)
+    assert not np.array_equal(raw, clamped)
+    r1, rec1, s1 = enc.compress_frames(yuv, raw)
+    r2, rec2, s2 = enc.compress_frames(yuv, clamped)
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, clamped)
+    assert_records_equal(r1, r2, "raw vs clamped labels")
+    assert_records_equal(r1, o_recs, "clamped labels vs oracle")
+    assert np.array_equal(rec1, rec2) and np.array_equal(rec1, o_recon)
+    for k in ("encode_pictures", "begin_frames"):
+        a = getattr(enc, k)(yuv, raw)
+        b = getattr(enc, k)(yuv, clamped)
+        assert np.array_equal(a[0] if isinstance(a, tuple) else a, b[0] if isinstance(b, tuple) else b), k
+    bad = raw.copy(); bad[0, 3, 7] = 4
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        enc.compress_frames(yuv, bad)
+    enc.close()
+
+
 @pytest.mark.parametrize("w,h,qp,nf,seed", [(256, 128, 30, 3, 41), (136, 72, 24, 2, 42), (320, 192, 40, 1, 43)])
 def test_matches_oracle_on_seeded_inputs(oracle_built, w, h, qp, nf, seed):
     import hevcdl_amd

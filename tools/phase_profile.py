@@ -1,5 +1,5 @@
 import sys, os, subprocess
-names=["build_refs","filter_refs","rmd_satd","predict_block","rdoq:cg-prologue","rdoq:cg-walk","rdoq","dequant","rdoq:cg-epilogue","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh","-","tu:refs+pred","tu:org+residual","tu:fwd","tu:rdoq(mark)","tu:store+dequant+inv","tu:recon+sse","load_tu_coef","n:CGs","n:allzeroCGs","n:allzero-after-allzero","rdoq:lookahead","rdoq:zero-run batch"]
+names=["build_refs","filter_refs","rmd_satd","predict_block","rdoq:cg-prologue","rdoq:cg-walk","rdoq","dequant","rdoq:cg-epilogue","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh","-","tu:refs+pred","tu:org+residual","tu:fwd","tu:rdoq(mark)","tu:store+dequant+inv","tu:recon+sse","load_tu_coef","n:CGs","n:allzeroCGs","n:allzero-after-allzero","rdoq:lookahead","rdoq:zero-run batch","luma:pass1 region (wall)","luma:pass2 (wall)","luma:pass2 wait for splits","chroma region (wall)"]
 code="""
 import sys
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
@@ -8,7 +8,7 @@ W,H=%s,%s
 yuv=ref_tools.synth_yuv(W,H,1,seed=1)
 enc=hevcdl_amd.Encoder(W,H,32,max_frames=1); lab=enc.predict_depth(yuv); enc.compress_frames(yuv,lab); enc.close()
 """%(sys.argv[1],sys.argv[2])
-out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_DBGBUF='1',HEVCDL_LIB='/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so'),capture_output=True,text=True)
+out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_LIB='/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so'),capture_output=True,text=True)
 rows=[l.split()[1:] for l in out.stdout.splitlines() if l.startswith('DBGV')]
 tot=int(rows[14][0]) if len(rows)>14 else 1
 for i,r in enumerate(rows[:len(names)]):
