@@ -81,7 +81,7 @@ def cpu_model():
 def _prepare_ref_run(args):
     """Working directory of one reference-encoder process: input picture, the label files it polls for (TEncCu.cpp:244-253), output dir."""
     idx, yuv, w, h, qp, labels, base = args
-    d = os.path.join(base, "p%d" % idx)
+    d = os.path.join(base, "p%s" % idx)
     os.makedirs(os.path.join(d, "rec"))
     yuv.astype(np.uint8).tofile(os.path.join(d, "in.yuv"))
     os.makedirs(os.path.join(d, "pred", "0"))

@@ -48,4 +48,16 @@ if [ "$1" = "--decoder" ]; then
     COMMON="$COMMON $OUT/obj/$(basename ${f%.*}).o"; done
   g++ -o $OUT/TAppDecoder_ref $OUT/objd/*.o $COMMON -lpthread
 fi
+# The ANCHOR of the BD-rate comparison: the same encoder with the label pruning switched off, i.e. the
+# behaviour of unmodified HM 16.20 (the reference ships it only as TAppEncoder_original.exe).  Same pipe technique on the same single
+# translation unit: one statement, `check_current = check_next = true;`, is inserted in the stream in front of TEncCu.cpp:522
+# (`Int iBaseQP = xComputeQP(`), after the label lookup has set the two flags.  It is an anchor for rate / PSNR, not a parity pin.
+SRC=$REF/Lib/TLibEncoder/TEncCu.cpp
+if [ ! $OUT/obj_anchor_TEncCu.o -nt $SRC ]; then
+  sed -e '/#include *<io.h>/d' -e '/#include *<Windows.h>/d' \
+      -e 's/^\( *\)Int iBaseQP = xComputeQP( rpcBestCU, uiDepth );/\1check_current = check_next = true; Int iBaseQP = xComputeQP( rpcBestCU, uiDepth );/' "$SRC" | \
+    $CXX -x c++ -include unistd.h -D_access=access '-DSleep(ms)=usleep(1000*(ms))' -I"$(dirname "$SRC")" -c - -o $OUT/obj_anchor_TEncCu.o
+fi
+g++ -o $OUT/TAppEncoder_anchor $(ls $OUT/obj/*.o | grep -v '/TEncCu.o$') $OUT/obj_anchor_TEncCu.o -lpthread \
+    -Wl,--wrap=_ZN6TEncCu11compressCtuEiP10TComDataCU
 echo "built: $(ls $OUT | grep -v obj | tr '\n' ' ')"

@@ -233,6 +233,34 @@ def gen_full():
     print("full-frame fixture: %d CTUs, label histogram %s" % (nctu, np.bincount(lab.ravel(), minlength=4)))
 
 
+def gen_bd_anchor():
+    """F-rd-4: rate / PSNR points of the unpruned anchor (oracle/_ref/TAppEncoder_anchor) and of the reference as shipped (label files) on a
+    small input at QP 22 / 27 / 32 / 37, with the BD figures of the reference's formulas: pins metrics.py and, on the GPU, the device path's
+    rate / PSNR against the reference's own log lines."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import bd_anchor
+    import cnn_oracle
+    import hevcdl_amd.metrics as metrics
+    w, h, nf, seed = 384, 192, 2, 3000
+    yuv = rt.synth_yuv(w, h, nf, seed)
+    wts = cnn_oracle.load_weights(os.path.join(WDIR, "hevc_encoder_model.f32"))
+    lab, _ = cnn_oracle.predict_labels(wts, yuv, w, h)
+    base = tempfile.mkdtemp(prefix="bdfix_")
+    pts = {}
+    for name, binary in (("label_path", bd_anchor.REF), ("anchor", bd_anchor.ANCHOR)):
+        pts[name] = [bd_anchor.curve_from_runs([bd_anchor.run_encoder(binary, yuv[i], lab[i], w, h, qp, base, "%s%d_%d" % (name, qp, i)) for i in range(nf)]) for qp in bd_anchor.QPS]
+    an, lp = pts["anchor"], pts["label_path"]
+    rate = lambda c: [p["kbps"] for p in c]
+    psnr = lambda c: [p["psnr_y"] for p in c]
+    np.savez_compressed(os.path.join(GOLD, "bd_anchor_small.npz"), width=w, height=h, frames=nf, seed=seed, qps=np.array(bd_anchor.QPS), labels=lab,
+                        anchor_kbps=np.array(rate(an)), anchor_psnr_y=np.array(psnr(an)), label_kbps=np.array(rate(lp)), label_psnr_y=np.array(psnr(lp)),
+                        label_bits=np.array([p["bits_per_frame"] for p in lp]), label_psnr_yuv=np.array([[p["psnr_y"], p["psnr_u"], p["psnr_v"]] for p in lp]),
+                        bd_rate_percent=metrics.bd_rate(rate(an), psnr(an), rate(lp), psnr(lp)), bd_psnr_db=metrics.bd_psnr(rate(an), psnr(an), rate(lp), psnr(lp)))
+    print("bd anchor fixture: BD-rate %.3f %%, BD-PSNR %.4f dB" % (metrics.bd_rate(rate(an), psnr(an), rate(lp), psnr(lp)), metrics.bd_psnr(rate(an), psnr(an), rate(lp), psnr(lp))))
+
+
 def gen_bd():
     """Known-answer for a BD-rate script: values computed from the reference's
     calc_BDBR sample with its own bundled formula."""
@@ -242,7 +270,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor"]
     if "rd" in what:
         gen_rd()
     if "rdtiles" in what:
@@ -261,3 +289,5 @@ if __name__ == "__main__":
         gen_bd()
     if "full" in what:
         gen_full()
+    if "bdanchor" in what:
+        gen_bd_anchor()

@@ -57,3 +57,41 @@ def test_summary_table_and_picture_line(metrics):
     assert txt.splitlines()[1].startswith("\t        2    a    2550.0000  ")
     line = metrics.frame_line(3, 32, 80000, (33.5678, 40.1, 41.25), 1.4)
     assert line == "POC    3 TId: 0 ( I-SLICE, QP 32 )      80000 bits [Y 33.5678 dB    U 40.1000 dB    V 41.2500 dB] [ET     1 ]"
+
+
+def test_bd_against_the_unpruned_anchor_fixture(metrics):
+    """F-rd-4: four rate / PSNR points of unpruned HM (the anchor) and of the label-pruned reference, taken from the two encoders' own log
+    lines (oracle/gen_fixtures.py gen_bd_anchor); the BD figures are those of the reference's formulas."""
+    f = np.load(os.path.join(GOLD, "bd_anchor_small.npz"))
+    assert metrics.bd_rate(f["anchor_kbps"], f["anchor_psnr_y"], f["label_kbps"], f["label_psnr_y"]) == pytest.approx(float(f["bd_rate_percent"]), abs=1e-9)
+    assert metrics.bd_psnr(f["anchor_kbps"], f["anchor_psnr_y"], f["label_kbps"], f["label_psnr_y"]) == pytest.approx(float(f["bd_psnr_db"]), abs=1e-9)
+    # pruning never searches more than the anchor does: at equal QP the anchor's RD cost is at least as good, so the pruned curve is not better overall
+    assert float(f["bd_rate_percent"]) > 0
+
+
+@pytest.mark.gpu
+def test_device_path_reproduces_the_label_path_points_of_the_anchor_fixture(metrics):
+    """The device path (decisions, deblocking, SAO, bitstream) on the fixture's input and labels gives, QP by QP, exactly the bits and the
+    PSNR the reference printed for the same labels -- hence the same BD-rate against the anchor."""
+    import hevcdl_amd
+    import ref_tools
+    f = np.load(os.path.join(GOLD, "bd_anchor_small.npz"))
+    w, h, nf = int(f["width"]), int(f["height"]), int(f["frames"])
+    yuv = ref_tools.synth_yuv(w, h, nf, int(f["seed"]))
+    kbps, psnr = [], []
+    for qi, qp in enumerate(f["qps"]):
+        enc = hevcdl_amd.Encoder(w, h, int(qp), max_frames=nf)
+        recs, final, sao, _ = enc.encode_pictures(yuv, f["labels"])
+        enc.close()
+        summ = metrics.Summary(w, h, 30.0)
+        ysz = w * h
+        for i in range(nf):
+            au = hevcdl_amd.write_access_unit(w, h, int(qp), 0, recs[i], sao=sao[i])      # POC 0: the fixture's runs code one picture per process
+            assert len(au) * 8 == int(f["label_bits"][qi][i]), (qp, i)
+            d = (yuv[i].astype(np.int64) - final[i].astype(np.int64)) ** 2
+            summ.add(len(au) * 8, (int(d[:ysz].sum()), int(d[ysz:ysz + ysz // 4].sum()), int(d[ysz + ysz // 4:].sum())))
+        av = summ.averages()
+        assert av[0] == pytest.approx(float(f["label_psnr_yuv"][qi][0]), abs=1e-4)
+        kbps.append(summ.bitrate_kbps()); psnr.append(av[0])
+    # the reference prints PSNR with four decimals; the cubic fit over these nearly flat points turns that rounding into a few hundredths of a percent
+    assert metrics.bd_rate(f["anchor_kbps"], f["anchor_psnr_y"], kbps, psnr) == pytest.approx(float(f["bd_rate_percent"]), abs=0.1)
