@@ -160,6 +160,7 @@ struct __attribute__((aligned(16))) RdSmem {
   K k;
   // the executing wave's own scratch (K is copied from the master when a helper runs one of its tasks; these are not)
   GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate;
+  int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task; joined in check_rd_cost_intra
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
   int16_t line[264], fline[264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
@@ -230,7 +231,8 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4 };
+enum { SLOT_P2 = 4, SLOT_CHROMA = 5 };          // result slots: 0..3 the split tasks of the second pass (by child), 4 its verdict, 5..9 the chroma modes; the first pass uses 0..9 before any of them
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
   // the count can only come from the region that is open, whose parameters were written before the ticket was
@@ -2025,6 +2027,15 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
       const int memo = pu_log2 <= 5;
       if (memo && !(pu_log2 > min_tu_log2(cu))) break;              // no split possible: the pass cannot change anything
+      if (memo && npu == 1 && lds_load(&wg_shared().has_helpers)) {
+        // Spare waves: the pass is handed to one of them and joined in check_rd_cost_intra, after the chroma search and the CU's syntax have
+        // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time).  If the split wins, those two are redone.
+        LRegion &r2 = my_region(1);
+        wsync();
+        if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = 1; }
+        region_open(r2, T_LUMA_P2, 1, cu, ptu);
+        break;
+      }
       PROF_MARK0();
       const DistCost dc = recur_luma_any(k, cu, ptu, 0, memo, best_dist, best_cost);
       PROF_MARK(37);
@@ -2170,15 +2181,31 @@ DEVN void run_task(LRegion &r, int idx_)
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
   const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
-  const int slot = kind == T_LUMA_SPLIT ? mode : idx;       // the split alternative of child `mode` of r.tu
+  const int slot = kind == T_LUMA_SPLIT ? mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
-  kk.coef_l = slot_coef(kk.slots, slot); kk.rec_l = slot_rec(kk.slots, slot); kk.in_task = 1;
-  kk.trx0 = ttu.x; kk.try0 = ttu.y; kk.trx1 = ttu.x + (1 << ttu.log2); kk.try1 = ttu.y + (1 << ttu.log2);
+  if (kind == T_LUMA_P2) { // the whole second pass: trial samples go to the picture (the master keeps off the CU's luma until the join), levels to this wave's layers
+    kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
+  } else {
+    kk.coef_l = slot_coef(kk.slots, slot); kk.rec_l = slot_rec(kk.slots, slot); kk.in_task = 1;
+    kk.trx0 = ttu.x; kk.try0 = ttu.y; kk.trx1 = ttu.x + (1 << ttu.log2); kk.try1 = ttu.y + (1 << ttu.log2);
+  }
   wsync();
   LCabac *start = &ow.curr[cu.depth];
   GLB uint8_t *at = slot_attr(kk.slots, slot);
   uint32_t dist; double cost;
-  if (kind == T_LUMA_SPLIT) { // second RD pass: the four grandchildren of one child, from the state the chain of unsplit children had there
+  if (kind == T_LUMA_P2) { // second RD pass of the PU (TEncSearch.cpp:2445-2512) with the first pass's result as the unsplit alternative
+    const int zp = cu.zbase + tu.zrel;
+    const double memo_cost = r.cost[4]; const uint32_t memo_dist = (uint32_t)uni((int)r.dist[4]);
+    cabac_copy(k, &s.go, start);
+    const DistCost dc = recur_luma_any(k, cu, tu, 0, 1, memo_dist, memo_cost);
+    dist = memo_dist; cost = memo_cost;
+    if (ub(dc.cost < memo_cost)) { // the split wins: levels -> record, reconstruction -> the master's best, arrays -> the verdict slot
+      dist = dc.dist; cost = dc.cost;
+      set_result_cu(k, cu, tu, 0, k.coef_l, k.rec_l);
+      wsync();
+      for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
+    }
+  } else if (kind == T_LUMA_SPLIT) { // second RD pass: the four grandchildren of one child, from the state the chain of unsplit children had there
     const int zc = cu.zbase + ttu.zrel;
     state_from_global(&s.go, slot_state(kk.slots, slot, 0));
     const DistCost dc = recur_luma_any(k, cu, ttu, 0, 1, 0, MAX_DOUBLE);     // memo form with an unlimited unsplit cost: the split is evaluated and taken
@@ -2248,8 +2275,8 @@ DEV void helper_loop()
   const int me = wave_id();
   while (lds_load(&sh.masters_active) > 0) {
     int did = 0;
-    for (int j = 2; j < 2 * NW + 2 && !did; j++) {
-      LRegion &r = sh.reg[(me + (j >> 1)) % NW][j & 1];
+    for (int j = 0; j < 2 * NW && !did; j++) { // the second-pass regions first: they sit on the masters' critical paths
+      LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][j < NW ? 1 : 0];
       const int t = lds_load(&r.ticket);
       if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
       const int idx = region_claim(r);
@@ -2292,11 +2319,11 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
     if (win >= 0) {
       best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
-      GLB const uint8_t *at = slot_attr(k.slots, win);
+      GLB const uint8_t *at = slot_attr(k.slots, SLOT_CHROMA + win);
       wsync();
       for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 4; c++) s.sv[c][i] = at[c * 256 + i];
       wsync();
-      set_result_cu(k, cu, root, 1, slot_coef(k.slots, win), slot_rec(k.slots, win)); set_result_cu(k, cu, root, 2, slot_coef(k.slots, win), slot_rec(k.slots, win));
+      set_result_cu(k, cu, root, 1, slot_coef(k.slots, SLOT_CHROMA + win), slot_rec(k.slots, SLOT_CHROMA + win)); set_result_cu(k, cu, root, 2, slot_coef(k.slots, SLOT_CHROMA + win), slot_rec(k.slots, SLOT_CHROMA + win));
     }
     region_close(r);
   }
@@ -2334,14 +2361,35 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
   }
   wsync();
-  uint32_t dist = est_intra_luma(k, cu);
-  copy_best_rec_to_pic(k, cu, 0);
-  dist += est_intra_chroma(k, cu);
+  if (lane_id() == 0) s.p2_pending = 0;
   wsync();
-  if (lane_id() == 0) reset_bits(&s.go);
-  enc_cu_syntax(k, &s.go, cu);
-  cabac_copy(k, &s.temp[cu.depth], &s.go);
-  Rd r; r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
+  uint32_t dist_l = est_intra_luma(k, cu);
+  int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma)
+  Rd r;
+  for (;;) {
+    if (!pending) copy_best_rec_to_pic(k, cu, 0);
+    const uint32_t dist = dist_l + est_intra_chroma(k, cu);
+    wsync();
+    if (lane_id() == 0) reset_bits(&s.go);
+    enc_cu_syntax(k, &s.go, cu);
+    cabac_copy(k, &s.temp[cu.depth], &s.go);
+    r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
+    if (!pending) break;
+    // join: the second pass's verdict
+    LRegion &r2 = my_region(1);
+    region_wait(r2, 1);
+    pending = 0;
+    wsync();
+    if (lane_id() == 0) s.p2_pending = 0;
+    if (!ub(r2.cost[0] < r2.cost[4])) { copy_best_rec_to_pic(k, cu, 0); break; }      // nothing changed: chroma and syntax stand
+    // the split won: take its distortion and arrays (its levels and reconstruction are in the record / best reconstruction already) and
+    // repeat the chroma search and the syntax, which depend on the TU tree
+    dist_l = (uint32_t)uni((int)r2.dist[0]);
+    GLB const uint8_t *at = slot_attr(k.slots, SLOT_P2);
+    for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_TRIDX][cu.zbase + i] = at[i]; s.a[A_CBF][cu.zbase + i] = at[256 + i]; s.a[A_TSKIP][cu.zbase + i] = at[512 + i]; }
+    cabac_copy(k, &s.go, &s.curr[cu.depth]);
+    wsync();
+  }
   return r;
 }
 
@@ -2622,7 +2670,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       int l2 = 0, c2 = 0;
       for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
     }
-    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m <= NW; }
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m < NW; }     // more helpers than masters: a wave is always free for the innermost tasks
   }
   __syncthreads();
   if (first < n_units) {
