@@ -1,12 +1,17 @@
+# Round profile: bench line, rocprofv3 kernel trace and the two HBM counter passes of the same command (C4: 600 frames of 2160p).
+# usage (on the GPU box, through gpurun): bash tools/profile_round.sh r02a
 set -x
+TAG=${1:-r02}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof
 cd $R
-python bench.py > gpurun_out/prof/r01k_bench.json 2> gpurun_out/prof/r01k_bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof/r01k_trace -o r01k -- python bench.py --no-cpu-baseline > gpurun_out/prof/r01k_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof/r01k_fetch -o r01k -- python bench.py --frames 512 --no-cpu-baseline > gpurun_out/prof/r01k_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof/r01k_write -o r01k -- python bench.py --frames 512 --no-cpu-baseline > gpurun_out/prof/r01k_write.log 2>&1
-python tools/rocpd_summary.py gpurun_out/prof/r01k_trace gpurun_out/prof/r01k_fetch gpurun_out/prof/r01k_write > gpurun_out/prof/r01k_summary.txt 2>&1
-tail -1 gpurun_out/prof/r01k_bench.json | cut -c1-400
-cat gpurun_out/prof/r01k_summary.txt
+python bench.py --steps 3 --warmup 1 > gpurun_out/prof/${TAG}_bench.json 2> gpurun_out/prof/${TAG}_bench.err
+Q="--steps 1 --warmup 0 --no-cpu-baseline --no-c2 --saturated-frames 0"
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof/${TAG}_trace -o ${TAG} -- python bench.py $Q > gpurun_out/prof/${TAG}_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof/${TAG}_fetch -o ${TAG} -- python bench.py $Q > gpurun_out/prof/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof/${TAG}_write -o ${TAG} -- python bench.py $Q > gpurun_out/prof/${TAG}_write.log 2>&1
+python tools/rocpd_summary.py gpurun_out/prof/${TAG}_trace gpurun_out/prof/${TAG}_fetch gpurun_out/prof/${TAG}_write > gpurun_out/prof/${TAG}_summary.txt 2>&1
+sha256sum hevc-deep-learning-pipeline_amd/csrc/rd_kernel.hip | cut -c1-16 > gpurun_out/prof/${TAG}_rd_kernel_sha16.txt
+tail -1 gpurun_out/prof/${TAG}_bench.json | cut -c1-300
+cat gpurun_out/prof/${TAG}_summary.txt
