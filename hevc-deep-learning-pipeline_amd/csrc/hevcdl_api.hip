@@ -195,6 +195,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_flag, sizeof(int)));
+  if (cfg->bit_depth > 8) CK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(cfg->width, cfg->height) * (size_t)cfg->max_frames));    // the CNN stage's 8-bit copy
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
   ctx->scratch_per_wave = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
@@ -231,12 +232,18 @@ static hevcdl_status ensure_staging(hevcdl_ctx *ctx)
 {
   if (ctx->d_yuv) return HEVCDL_OK;
   const size_t nf = (size_t)ctx->cfg.max_frames;
-  HIPCHK(hipMalloc(&ctx->d_yuv, ctx->frame_bytes * nf));
-  HIPCHK(hipMalloc(&ctx->d_recon, ctx->frame_bytes * nf));
-  HIPCHK(hipMalloc(&ctx->d_labels, (size_t)ctx->ctus * 16 * nf));
-  HIPCHK(hipMalloc(&ctx->d_logits, (size_t)ctx->ctus * 64 * sizeof(float) * nf));
-  HIPCHK(hipMalloc(&ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * nf));
-  HIPCHK(hipMalloc(&ctx->d_stats, sizeof(hevcdl_frame_stats) * nf));
+  // all or nothing: a partial set would let later calls run on null buffers (records alone are 63 GB at 2048 frames of 2160p)
+  void **bufs[6] = { (void **)&ctx->d_recon, (void **)&ctx->d_labels, (void **)&ctx->d_logits, (void **)&ctx->d_records, (void **)&ctx->d_stats, (void **)&ctx->d_yuv };
+  const size_t sizes[6] = { ctx->frame_bytes * nf, (size_t)ctx->ctus * 16 * nf, (size_t)ctx->ctus * 64 * sizeof(float) * nf, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * nf,
+                            sizeof(hevcdl_frame_stats) * nf, ctx->frame_bytes * nf };
+  for (int i = 0; i < 6; i++) {
+    const hipError_t e = hipMalloc(bufs[i], sizes[i]);
+    if (e != hipSuccess) {
+      for (int j = 0; j <= i; j++) { hipFree(*bufs[j]); *bufs[j] = nullptr; }
+      (void)hipGetLastError();
+      return fail(ctx, e == hipErrorOutOfMemory ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP, "staging buffers (cfg.max_frames)", e);
+    }
+  }
   return HEVCDL_OK;
 }
 
@@ -408,10 +415,11 @@ extern "C" hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t
   if (!ctu_rgb || !labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
   HIPCHK(hipSetDevice(ctx->cfg.device));
   uint8_t *d_in = nullptr, *d_lab = nullptr; float *d_lg = nullptr;
-  HIPCHK(hipMalloc(&d_in, (size_t)n_ctus * 12288));
-  HIPCHK(hipMalloc(&d_lab, (size_t)n_ctus * 16));
-  HIPCHK(hipMalloc(&d_lg, (size_t)n_ctus * 64 * sizeof(float)));
-  HIPCHK(hipMemcpy(d_in, ctu_rgb, (size_t)n_ctus * 12288, hipMemcpyHostToDevice));
+  hipError_t e0 = hipMalloc(&d_in, (size_t)n_ctus * 12288);
+  if (e0 == hipSuccess) e0 = hipMalloc(&d_lab, (size_t)n_ctus * 16);
+  if (e0 == hipSuccess) e0 = hipMalloc(&d_lg, (size_t)n_ctus * 64 * sizeof(float));
+  if (e0 == hipSuccess) e0 = hipMemcpy(d_in, ctu_rgb, (size_t)n_ctus * 12288, hipMemcpyHostToDevice);
+  if (e0 != hipSuccess) { hipFree(d_in); hipFree(d_lab); hipFree(d_lg); return fail(ctx, e0 == hipErrorOutOfMemory ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP, "predict_depth_rgb buffers", e0); }
   hevcdl_status st = launch_cnn(ctx, d_in, HEVCDL_DEV_INPUT_RGB_CTU, n_ctus, 0, d_lab, d_lg, nullptr);
   if (st == HEVCDL_OK) {
     hipError_t e = hipDeviceSynchronize();

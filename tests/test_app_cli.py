@@ -134,9 +134,11 @@ def test_cli_encode_matches_the_api(app, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10"])
+@pytest.mark.parametrize("case", ["b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
-    """The reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) and for 10-bit coding
+    """b416_q32_r is C1 of BASELINE.json (416x240, one frame, QP32, untiled 8-bit, the reference's default configuration); c192 / b200 are
+    further untiled 8-bit runs (two frames; a picture that is not a multiple of 64).  The rest:
+    the reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) and for 10-bit coding
     (InputBitDepth / InternalBitDepth 10, Profile main10; x576 is C5 of the survey in miniature: both) on the fixtures the reference
     encoder produced with the same switches: reconstruction file and bitstream (its picture-hash SEI aside) byte for byte."""
     import sys
