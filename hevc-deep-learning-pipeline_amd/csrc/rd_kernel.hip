@@ -50,6 +50,9 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #define HEVCDL_NW 8
 #endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
+#ifndef HEVCDL_SPEC_MARGIN
+#define HEVCDL_SPEC_MARGIN 0
+#endif
 constexpr int NSLOT = 10;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
@@ -125,7 +128,7 @@ __constant__ int8_t c_dct_mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80
 struct __attribute__((aligned(8))) Cabac { uint8_t ctx[160]; unsigned long long frac; };   // 168 bytes
 typedef LDS Cabac LCabac;
 struct Rd { double cost; uint32_t bits, dist; };
-struct DistCost { uint32_t dist; double cost; };
+struct DistCost { uint32_t dist; double cost; unsigned long long cfrac; };   // cfrac: fractional bits (<< 15) of the TU tree's coefficient bins
 struct Cu { int x, y, log2, depth, zbase, nparts, part; };
 struct Tu { int x, y, log2, trd, zrel, nparts; };
 DEV int uni(int v);
@@ -182,6 +185,8 @@ struct __attribute__((aligned(16))) RdSmem {
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
+  unsigned long long cfrac_last;      // coefficient part of the last intra_bits_qt count (fractional bits)
+  Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
   unsigned long long prof[40]; unsigned int prof_n[40];
@@ -240,6 +245,7 @@ struct __attribute__((aligned(8))) Region {
   int cu[7], tu[6], pad_;                   // the CU under test (struct Cu), the PU (luma) or the CU's root TU (chroma) (struct Tu)
   int modes[12];                            // the alternatives: intra directions
   uint32_t dist[12]; double cost[12];       // the answers
+  unsigned long long cfrac[8];              // second pass: coefficient fractional bits of a child's alternative ([0..3] split tasks, [4..7] the chain's unsplit codings)
 };
 typedef LDS Region LRegion;
 struct Tables {                        // read-only after kernel start, one copy per workgroup
@@ -1472,8 +1478,38 @@ template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_
   if (lane_id() == 0) reset_bits(c);
   enc_intra_header(k, c, cu, tu, luma, chroma);
   enc_subdiv_cbf<LOG2>(k, c, cu, tu, luma, chroma);
+  wsync();
+  const unsigned long long f0_ = c->frac;
   if (luma) enc_coeff_qt<LOG2>(k, c, cu, tu, 0, 0);
+  wsync();
+  if (luma && lane_id() == 0) lds().cfrac_last = c->frac - f0_;
   if (chroma) { enc_coeff_qt<LOG2>(k, c, cu, tu, 1, 0); enc_coeff_qt<LOG2>(k, c, cu, tu, 2, 0); }
+  wsync();
+  PROF_ADD(k, 10);
+  return uni((int)get_bits(c));
+}
+DEV unsigned long long uni64(unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); }
+// Bits of a split TU (xGetIntraBitsQT of the parent after its four children, TEncSearch.cpp:1679-1700) WITHOUT coding the children's
+// coefficients a second time.  The count is: mode header + subdivision / cbf flags of the whole tree, then every TU's coefficients in
+// coding order, all from the state the parent started with (root).  Coefficient bins only touch the coefficient contexts (significance,
+// last position, greater-1/2, transform skip: indices >= CTX_SIG_CG) and the flags only the others, and the children were counted one
+// after the other from the same starting state -- so the coefficient bins of the recount are, bin for bin, the ones the children's own
+// counts coded: their fractional bits (cfrac, summed by the caller) and their final contexts (the coder `go` now holds them) are taken
+// over, and only the flags are coded here.  Leaves `go` exactly as the full recount would.
+template <int LOG2> DEVN uint32_t split_bits(KR k, const Cu cu_, const Tu tu_, LCabac *root, unsigned long long cfrac)
+{
+  PROF_T0();
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
+  LSmem &s = lds();
+  LCabac *c = &s.go;
+  cabac_copy(k, &s.spl, c);                     // the children's end state: coefficient contexts
+  cabac_copy(k, c, root);
+  if (lane_id() == 0) reset_bits(c);
+  enc_intra_header(k, c, cu, tu, 1, 0);
+  enc_subdiv_cbf<LOG2>(k, c, cu, tu, 1, 0);
+  wsync();
+  for (int i = CTX_SIG_CG + lane_id(); i < NUM_CTX; i += 64) c->ctx[i] = s.spl.ctx[i];
+  if (lane_id() == 0) c->frac += cfrac;
   wsync();
   PROF_ADD(k, 10);
   return uni((int)get_bits(c));
@@ -1616,7 +1652,7 @@ DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16);
 DEV void region_wait(LRegion &r, int n) { while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2); wg_acquire(); }
 DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()]; wsync(); }
 DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
-struct DistCbf { uint32_t dist, cbf; };
+struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
 template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_);
 
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
@@ -1633,6 +1669,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
   int check_split = LOG2 > min_tu_log2(cu);
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
+  unsigned long long single_cfrac = 0;
   const int check_ts = (LOG2 == 2) && (cu.part == SIZE_NxN);
   if (memo) { single_cost = memo_cost; single_dist = memo_dist; cabac_copy(k, &s.root[full_depth], &s.go); }
   else if (check_full) {
@@ -1649,7 +1686,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
           const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0); cost = calc_rd_cost(k, bits, d);
         }
         if (ub(cost < single_cost)) {
-          single_cost = cost; single_dist = d; single_cbf = cbf; best_ts = m;
+          single_cost = cost; single_dist = d; single_cbf = cbf; best_ts = m; single_cfrac = uni64(s.cfrac_last);
           if (m == 0) cabac_copy(k, &s.tbest, &s.go);
         }
         if (m == 0) cabac_copy(k, &s.go, &s.root[full_depth]);
@@ -1667,6 +1704,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       if (check_split) single_cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
       const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
       single_cost = calc_rd_cost(k, bits, single_dist);
+      single_cfrac = uni64(s.cfrac_last);
     }
   }
   if constexpr (LOG2 > 2) {
@@ -1675,20 +1713,20 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       else if (check_full) { cabac_copy(k, &s.test[full_depth], &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
       else cabac_copy(k, &s.root[full_depth], &s.go);
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
+      unsigned long long split_cfrac = 0;
       bool spec = false;
       if constexpr (LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && lds_load(&wg_shared().has_helpers) && (LOG2 - 1 > min_tu_log2(cu));
       if (spec) { // second pass of a PU, spare waves in the workgroup: the children's two alternatives run concurrently (spec_children)
-        if constexpr (LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; }
+        if constexpr (LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; split_cfrac = dc.cfrac; }
       } else for (int i = 0; i < 4; i++) {
         const Tu ch = tu_child(tu, i);
-        { const DistCost r = recur_luma<LOG2 - 1>(k, cu, ch, check_first); split_dist += r.dist; split_cost += r.cost; }
+        { const DistCost r = recur_luma<LOG2 - 1>(k, cu, ch, check_first); split_dist += r.dist; split_cost += r.cost; split_cfrac += r.cfrac; }
         split_cbf |= (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
       }
       if (split_cbf) { for (int i = lane_id(); i < tu.nparts; i += 64) s.a[A_CBF][zabs + i] |= (uint8_t)(1 << tu.trd); }
-      cabac_copy(k, &s.go, &s.root[full_depth]);
-      const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
+      const uint32_t bits = split_bits<LOG2>(k, cu, tu, &s.root[full_depth], split_cfrac);
       split_cost = calc_rd_cost(k, bits, split_dist);
-      if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost }; return r; }
+      if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost, split_cfrac }; return r; }
       if (memo) { // the saved best candidate of the first pass IS the unsplit coding (sv_* / best_rec, est_intra_luma)
         wsync();
         for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = s.sv[0][i]; s.a[A_CBF][zabs + i] = s.sv[1][i]; s.a[A_TSKIP][zabs + i] = s.sv[2][i]; }
@@ -1706,7 +1744,7 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       wsync();
     }
   }
-  const DistCost r = { single_dist, single_cost };
+  const DistCost r = { single_dist, single_cost, single_cfrac };
   return r;
 }
 
@@ -1767,6 +1805,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
   LSmem &s = lds();
   LRegion &r = my_region(1);
   uint32_t split_dist = 0, split_cbf = 0;
+  unsigned long long split_cfrac = 0;
   int j = 0;
   while (j < 4) {
     wsync();
@@ -1783,14 +1822,14 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
       const uint32_t bits = intra_bits_qt<LOG2 - 1>(k, cu, ch, 1, 0);
       const double cost = calc_rd_cost(k, bits, d);
-      if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; }
+      if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; r.cfrac[4 + c] = s.cfrac_last; }
     }
     { PROF_MARK0(); region_wait(r, 4 - j); PROF_MARK(38); }
     wsync();
     int brk = -1;
     for (int c = j; c < 4 && brk < 0; c++) if (ub(r.cost[c - j] < r.cost[4 + c])) brk = c;
     const int last = brk < 0 ? 4 : brk;
-    for (int c = j; c < last; c++) { split_dist += (uint32_t)uni((int)r.dist[4 + c]); split_cbf |= (uint32_t)uni(r.modes[4 + c]); }
+    for (int c = j; c < last; c++) { split_dist += (uint32_t)uni((int)r.dist[4 + c]); split_cbf |= (uint32_t)uni(r.modes[4 + c]); split_cfrac += uni64(r.cfrac[4 + c]); }
     if (brk >= 0) { // the split of child brk wins: its arrays, levels, reconstruction and end state replace the chain's
       const Tu ch = tu_child(tu, brk);
       const int zc = cu.zbase + ch.zrel, n = 1 << (LOG2 - 1), lay = (5 - (LOG2 - 2)) * 6144, bo = boff(k, 0, ch.x, ch.y);
@@ -1807,11 +1846,12 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       }
       state_from_global(&s.go, slot_state(k.slots, brk, 1));
       split_dist += (uint32_t)uni((int)r.dist[brk - j]);
+      split_cfrac += uni64(r.cfrac[brk - j]);
       split_cbf |= (uint32_t)(uni(s.a[A_CBF][zc]) >> ch.trd) & 1;
     }
     j = brk < 0 ? 4 : brk + 1;
   }
-  const DistCbf res = { split_dist, split_cbf };
+  const DistCbf res = { split_dist, split_cbf, split_cfrac };
   return res;
 }
 
@@ -2158,6 +2198,7 @@ DEV void import_owner(int owner)
 {
   LSmem &s = lds(); LSmem &ow = lds_of(owner);
   static_assert(sizeof(K) % 8 == 0 && offsetof(RdSmem, a) % 8 == 0 && offsetof(RdSmem, k) == 0, "8-byte copies");
+  static_assert(offsetof(RdSmem, line) % 8 == 0 && offsetof(RdSmem, fline) % 8 == 0 && offsetof(RdSmem, cline) % 8 == 0, "8-byte copies of the reference lines");
   wsync();
   { LDS unsigned long long *d = (LDS unsigned long long *)&s.k; LDS const unsigned long long *q = (LDS const unsigned long long *)&ow.k;
     for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = q[i]; }
@@ -2210,6 +2251,7 @@ DEVN void run_task(LRegion &r, int idx_)
     state_from_global(&s.go, slot_state(kk.slots, slot, 0));
     const DistCost dc = recur_luma_any(k, cu, ttu, 0, 1, 0, MAX_DOUBLE);     // memo form with an unlimited unsplit cost: the split is evaluated and taken
     dist = dc.dist; cost = dc.cost;
+    if (lane_id() == 0) r.cfrac[idx] = dc.cfrac;
     state_to_global(slot_state(kk.slots, slot, 1), &s.go);
     for (int i = lane_id(); i < ttu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zc + i]; at[256 + i] = s.a[A_CBF][zc + i]; at[512 + i] = s.a[A_TSKIP][zc + i]; }
   } else if (kind == T_LUMA_P1) { // one candidate of the first RD pass (TEncSearch.cpp:2378-2443)
@@ -2218,11 +2260,25 @@ DEVN void run_task(LRegion &r, int idx_)
     cabac_copy(k, &s.go, start);
     // a candidate of a PU that is one TU writes its reconstruction to the layer only (code_tu_block mode 3)
     const int one_tu = tu.log2 >= 3 && tu.log2 <= 5;
+    if (&s != &ow && tu.log2 <= 5) {
+      // the master gathered (and smoothed) the PU's reference samples for the rough mode decision and never rebuilds them while this region
+      // is open (a PU of one TU: every candidate meets the same block): take its lines instead of gathering them from the picture again
+      wsync();
+      for (int i = lane_id(); i < 66; i += 64) { ((LDS unsigned long long *)s.line)[i] = ((LDS const unsigned long long *)ow.line)[i]; ((LDS unsigned long long *)s.fline)[i] = ((LDS const unsigned long long *)ow.fline)[i]; }
+      if (lane_id() == 0) { s.ref_key[0] = ow.ref_key[0]; s.fline_key = ow.fline_key; }
+      wsync();
+    }
     const DistCost dc = recur_luma_any(k, cu, tu, one_tu ? 2 : 1);
     dist = dc.dist; cost = dc.cost;
     wsync();
     for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
   } else { // one chroma mode (TEncSearch.cpp:2640-2700)
+    if (&s != &ow && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0) { // one chroma TU per component: the master gathered both lines before it opened the region
+      wsync();
+      for (int i = lane_id(); i < 66; i += 64) ((LDS unsigned long long *)s.cline)[i] = ((LDS const unsigned long long *)ow.cline)[i];
+      if (lane_id() < 2) s.ref_key[1 + lane_id()] = ow.ref_key[1 + lane_id()];
+      wsync();
+    }
     cabac_copy(k, &s.go, start);
     set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, mode); wsync();
     uint32_t bits;
@@ -2311,6 +2367,10 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     LRegion &r = my_region();
     wsync();
     if (lane_id() == 0) for (int m = 0; m < 5; m++) r.modes[m] = (int)mode_list[m];
+    if (cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0) { // the five modes of an unsplit CU share their reference samples: gather them once, the tasks copy them
+      const int nc = (1 << cu.log2) >> 1;
+      build_refs(k, 1, cu.x >> 1, cu.y >> 1, nc, 1); build_refs(k, 2, cu.x >> 1, cu.y >> 1, nc, 1);
+    }
     PROF_MARK0();
     region_open(r, T_CHROMA, 5, cu, root);
     region_run(k, r);
@@ -2539,10 +2599,6 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
   if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
-#ifdef HEVCDL_KERNEL_PROF
-  if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
-  const unsigned long long prof_start_ = __builtin_readcyclecounter();
-#endif
   wsync();
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719.
   // A per-CTU call (hevcdl_compress_ctu) resumes from the state the previous call left instead.
@@ -2604,14 +2660,6 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
     GLB unsigned long long *dstc = (GLB unsigned long long *)p.cabac_out + (size_t)frame * 21;
     if (lane < 21) dstc[lane] = ((LDS const unsigned long long *)truec)[lane];
   }
-#ifdef HEVCDL_KERNEL_PROF
-  wsync();
-  if (unit == 0 && p.dbgbuf && lane < 40) {
-    if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
-    p.dbgbuf[1 + 2 * lane] = (unsigned int)(s.prof[lane] >> 10); p.dbgbuf[2 + 2 * lane] = s.prof_n[lane];
-    if (lane == 0) p.dbgbuf[0] = 40;
-  }
-#endif
   if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits; every tile adds its rectangle (the host zeroed the entry)
     GLB hevcdl_frame_stats *st = (GLB hevcdl_frame_stats *)p.stats + frame;
     for (int c = 0; c < 3; c++) {
@@ -2670,8 +2718,12 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       int l2 = 0, c2 = 0;
       for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
     }
-    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m < NW; }     // more helpers than masters: a wave is always free for the innermost tasks
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m < NW - HEVCDL_SPEC_MARGIN; }     // more helpers than masters: a wave is always free for the innermost tasks
   }
+#ifdef HEVCDL_KERNEL_PROF
+  if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
+  const unsigned long long prof_start_ = __builtin_readcyclecounter();
+#endif
   __syncthreads();
   if (first < n_units) {
     for (int u = first; u < n_units; u += G * NW) process_unit(p, u);
@@ -2679,6 +2731,15 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     lds_add(&sh.masters_active, -1);
   }
   helper_loop();
+#ifdef HEVCDL_KERNEL_PROF
+  // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)
+  wsync();
+  if (blockIdx.x == 0 && p.dbgbuf && lane < 40) {
+    if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
+    atomicAdd(&p.dbgbuf[1 + 2 * lane], (unsigned int)(s.prof[lane] >> 10)); atomicAdd(&p.dbgbuf[2 + 2 * lane], s.prof_n[lane]);
+    if (lane == 0) p.dbgbuf[0] = 40;
+  }
+#endif
 }
 
 extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return (size_t)NW * sizeof(RdSmem) + sizeof(WgShared); }

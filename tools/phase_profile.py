@@ -6,8 +6,11 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
 import numpy as np, hevcdl_amd, ref_tools
 W,H=%s,%s
 yuv=ref_tools.synth_yuv(W,H,1,seed=1)
-enc=hevcdl_amd.Encoder(W,H,32,max_frames=1); lab=enc.predict_depth(yuv); enc.compress_frames(yuv,lab); enc.close()
+F=int(sys.argv[3]) if len(sys.argv)>3 else 1
+yuv=np.concatenate([ref_tools.synth_yuv(W,H,min(F,4),seed=1)]*((F+3)//4))[:F]
+enc=hevcdl_amd.Encoder(W,H,32,max_frames=F); lab=enc.predict_depth(yuv); enc.compress_frames(yuv,lab); enc.close()
 """%(sys.argv[1],sys.argv[2])
+code=code.replace("sys.argv[3]", repr(sys.argv[3]) if len(sys.argv)>3 else "'1'").replace("len(sys.argv)>3","True")
 out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_LIB='/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so'),capture_output=True,text=True)
 rows=[l.split()[1:] for l in out.stdout.splitlines() if l.startswith('DBGV')]
 tot=int(rows[14][0]) if len(rows)>14 else 1
