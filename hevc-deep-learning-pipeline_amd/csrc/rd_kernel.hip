@@ -58,7 +58,8 @@ constexpr int NSLOT = 10;                                     // result slots of
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
 // per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
-constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + 2047) & ~2047;
+constexpr int SAVE_BYTES = 8192;                              // the chain owner's state while it runs one of its own split tasks (spec_children)
+constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + SAVE_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
 constexpr int SCR_WAVE = SCR_LAYERS + SCR_RDOQ + NSLOT * SLOT_BYTES;
@@ -162,7 +163,7 @@ typedef const LDS K &KR;
 struct __attribute__((aligned(16))) RdSmem {
   K k;
   // the executing wave's own scratch (K is copied from the master when a helper runs one of its tasks; these are not)
-  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate;
+  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save;
   int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task; joined in check_rd_cost_intra
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
@@ -1654,12 +1655,14 @@ DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync
 DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
 struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
 template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_);
+DEVN int region_claim(LRegion &r);
+template <bool LEAF> DEVN void run_task(LRegion &r, int idx_);
 
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
 // memo != 0 (second RD pass, TU == PU): the unsplit coding of this TU with this mode was evaluated in the first pass from
 // the same coder state -- (memo_dist, memo_cost) are its results, bit for bit what a re-run would give -- so only the
 // split alternative is evaluated; if the unsplit TU wins, its arrays / reconstruction come back from the saved best.
-template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, int check_first_, int memo_ = 0, uint32_t memo_dist = 0, double memo_cost = 0.0)
+template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, int check_first_, int memo_ = 0, uint32_t memo_dist = 0, double memo_cost = 0.0)
 {
   CHECK_EXEC(2);
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int check_first = uni(check_first_), memo = uni(memo_);
@@ -1715,9 +1718,9 @@ template <int LOG2> DEVN DistCost recur_luma(KR k, const Cu cu_, const Tu tu_, i
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       unsigned long long split_cfrac = 0;
       bool spec = false;
-      if constexpr (LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && lds_load(&wg_shared().has_helpers) && (LOG2 - 1 > min_tu_log2(cu));
+      if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && lds_load(&wg_shared().has_helpers) && (LOG2 - 1 > min_tu_log2(cu));
       if (spec) { // second pass of a PU, spare waves in the workgroup: the children's two alternatives run concurrently (spec_children)
-        if constexpr (LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; split_cfrac = dc.cfrac; }
+        if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; split_cfrac = dc.cfrac; }
       } else for (int i = 0; i < 4; i++) {
         const Tu ch = tu_child(tu, i);
         { const DistCost r = recur_luma<LOG2 - 1>(k, cu, ch, check_first); split_dist += r.dist; split_cost += r.cost; split_cfrac += r.cfrac; }
@@ -1781,12 +1784,13 @@ DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_, GLB const i
   wsync();
   PROF_ADD(k, 15);
 }
-DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first, int memo = 0, uint32_t md = 0, double mc = 0.0)
+// SPEC: only the second pass run as a task of its own (T_LUMA_P2) hands its children's split alternatives to other waves (spec_children)
+template <bool SPEC = false> DEV DistCost recur_luma_any(KR k, const Cu &cu, const Tu &tu, int check_first, int memo = 0, uint32_t md = 0, double mc = 0.0)
 {
   switch (tu.log2) {
     case 6: return recur_luma<6>(k, cu, tu, check_first, memo, md, mc);
-    case 5: return recur_luma<5>(k, cu, tu, check_first, memo, md, mc);
-    case 4: return recur_luma<4>(k, cu, tu, check_first, memo, md, mc);
+    case 5: return recur_luma<5, SPEC>(k, cu, tu, check_first, memo, md, mc);
+    case 4: return recur_luma<4, SPEC>(k, cu, tu, check_first, memo, md, mc);
     case 3: return recur_luma<3>(k, cu, tu, check_first, memo, md, mc);
     default: return recur_luma<2>(k, cu, tu, check_first, memo, md, mc);
   }
@@ -1824,7 +1828,28 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       const double cost = calc_rd_cost(k, bits, d);
       if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; r.cfrac[4 + c] = s.cfrac_last; }
     }
-    { PROF_MARK0(); region_wait(r, 4 - j); PROF_MARK(38); }
+    { // wait for the split tasks; those nobody has claimed yet this wave runs itself: its own state (everything a task overwrites: kernel context,
+      // coder snapshots, attribute arrays) goes to its global scratch and comes back afterwards, the cached reference lines are dropped
+      PROF_MARK0();
+      constexpr int SAVE_WORDS = (int)(offsetof(RdSmem, line) / 8);
+      static_assert(offsetof(RdSmem, line) % 8 == 0 && offsetof(RdSmem, line) <= SAVE_BYTES, "state save area");
+      while (lds_load(&r.done) < 4 - j) {
+        const int idx = region_claim(r);
+        if (idx < 0) { __builtin_amdgcn_s_sleep(2); continue; }
+        wsync();
+        for (int i = lane_id(); i < SAVE_WORDS; i += 64) s.my_save[i] = ((LDS const unsigned long long *)&s)[i];
+        run_task<true>(r, idx);
+        wsync();
+        for (int i = lane_id(); i < SAVE_WORDS; i += 64) ((LDS unsigned long long *)&s)[i] = s.my_save[i];
+        wsync();
+        if (lane_id() < 3) s.ref_key[lane_id()] = -1;
+        if (lane_id() == 0) s.fline_key = -1;
+        wg_release();
+        lds_add(&r.done, 1);
+      }
+      wg_acquire();
+      PROF_MARK(38);
+    }
     wsync();
     int brk = -1;
     for (int c = j; c < 4 && brk < 0; c++) if (ub(r.cost[c - j] < r.cost[4 + c])) brk = c;
@@ -2212,8 +2237,8 @@ DEV void import_owner(int owner)
 }
 
 // one alternative, on the executing wave's private state; levels / reconstruction go to the result slot, trial samples to the overlay
-DEVN void run_task(LRegion &r, int idx_)
-{
+template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
+{ // LEAF: the instance a chain owner uses for its own split tasks (spec_children): every kind but the second-pass task, no nested regions
   CHECK_EXEC(3);
   const int idx = uni(idx_);
   LSmem &s = lds(); LDS K &kk = s.k; KR k = s.k;
@@ -2234,11 +2259,12 @@ DEVN void run_task(LRegion &r, int idx_)
   LCabac *start = &ow.curr[cu.depth];
   GLB uint8_t *at = slot_attr(kk.slots, slot);
   uint32_t dist; double cost;
-  if (kind == T_LUMA_P2) { // second RD pass of the PU (TEncSearch.cpp:2445-2512) with the first pass's result as the unsplit alternative
+  if (!LEAF && kind == T_LUMA_P2) { // second RD pass of the PU (TEncSearch.cpp:2445-2512) with the first pass's result as the unsplit alternative
     const int zp = cu.zbase + tu.zrel;
     const double memo_cost = r.cost[4]; const uint32_t memo_dist = (uint32_t)uni((int)r.dist[4]);
     cabac_copy(k, &s.go, start);
-    const DistCost dc = recur_luma_any(k, cu, tu, 0, 1, memo_dist, memo_cost);
+    DistCost dc = { 0, 0.0, 0 };
+    if constexpr (!LEAF) dc = recur_luma_any<true>(k, cu, tu, 0, 1, memo_dist, memo_cost);
     dist = memo_dist; cost = memo_cost;
     if (ub(dc.cost < memo_cost)) { // the split wins: levels -> record, reconstruction -> the master's best, arrays -> the verdict slot
       dist = dc.dist; cost = dc.cost;
@@ -2317,7 +2343,7 @@ DEVN void region_run(KR k, LRegion &r)
   for (;;) {
     const int idx = region_claim(r);
     if (idx < 0) break;
-    run_task(r, idx);
+    run_task<false>(r, idx);
     wg_release();
     lds_add(&r.done, 1);
   }
@@ -2339,7 +2365,7 @@ DEV void helper_loop()
       if (idx < 0) continue;
       wg_acquire();
       import_owner(uni(r.owner));
-      run_task(r, idx);
+      run_task<false>(r, idx);
       wg_release();
       lds_add(&r.done, 1);
       did = 1;
@@ -2688,7 +2714,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   // this wave's global scratch
   {
     GLB unsigned char *scr = (GLB unsigned char *)p.scratch + ((size_t)blockIdx.x * NW + wave) * p.scratch_per_wave;
-    s.my_coef = (GLB int16_t *)scr; s.my_rec = (GLB pel_t *)(scr + 4 * 6144 * 2); s.my_ovl = s.my_rec + 5 * 6144;
+    s.my_coef = (GLB int16_t *)scr; s.my_rec = (GLB pel_t *)(scr + 4 * 6144 * 2); s.my_ovl = s.my_rec + 5 * 6144; s.my_save = (GLB unsigned long long *)(s.my_ovl + 6144);
     s.my_qcost = (GLB double *)(scr + SCR_LAYERS); s.my_qrate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
     s.k.slots = scr + SCR_LAYERS + SCR_RDOQ;
   }
