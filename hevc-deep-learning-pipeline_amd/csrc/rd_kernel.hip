@@ -2744,7 +2744,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       int l2 = 0, c2 = 0;
       for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
     }
-    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m < NW - HEVCDL_SPEC_MARGIN; }     // more helpers than masters: a wave is always free for the innermost tasks
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m <= NW - HEVCDL_SPEC_MARGIN; }     // spare waves for the second-pass tasks (chain owners serve their own split tasks, so no wave ever waits on an unserved region)
   }
 #ifdef HEVCDL_KERNEL_PROF
   if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
