@@ -151,6 +151,10 @@ struct K {                             // wave-uniform kernel context (lives in 
   // While a task runs (in_task) its trial reconstruction goes to the overlay instead of the picture, and reference samples inside
   // the task rectangle (luma coordinates) come from there: the picture only ever holds what the master has committed.
   int in_task, trx0, try0, trx1, try1;
+  // Origin of the active layer set: levels / reconstruction of a TU are stored relative to the block the set currently serves (the PU of
+  // the luma search, the CU of a chroma task, the child of a split task), so that every PU reuses the same few KB of a set and the sets
+  // of all waves stay cache resident (laid out CTU-wide they did not: profiles/r02_traffic.json).  lz: z-scan offset in luma samples.
+  int lz, lx, ly;
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
   long long sbh[2];
@@ -312,6 +316,10 @@ DEV int pstride(KR k, int c) { return c ? k.cw : k.W; }
 DEV int boff(KR k, int c, int x, int y) { const int s = c ? 32 : 64; return (y - k.cy * s) * s + (x - k.cx * s); }
 // where the reconstruction of the block at (x, y) of component c goes (and where the same task reads it back): the picture, or the
 // executing wave's overlay while a task runs
+DEV int lay_coef_o(int lz, int log2, int c, int zabs) { const int o = zabs * 16 - lz; return (5 - log2) * 6144 + comp_off(c) + (c ? o >> 2 : o); }
+DEV int lay_rec_o(int lx, int ly, int log2, int c, int x, int y) { const int sh = c ? 1 : 0; return (5 - log2) * 6144 + comp_off(c) + (y - (ly >> sh)) * cstride(c) + (x - (lx >> sh)); }
+DEV int lay_coef(KR k, int log2, int c, int zabs) { return lay_coef_o(k.lz, log2, c, zabs); }                 // offset of a TU's levels in the active layer set
+DEV int lay_rec(KR k, int log2, int c, int x, int y) { return lay_rec_o(k.lx, k.ly, log2, c, x, y); }          // ... of its reconstruction (row stride 64 / 32)
 DEV GLB pel_t *rec_target(KR k, int c, int x, int y, int &stride)
 {
   if (uni(k.in_task)) { stride = cstride(c); return k.ovl + comp_off(c) + boff(k, c, x, y); }
@@ -1418,7 +1426,7 @@ DEV void load_tu_coef(KR k, int real, int comp, int log2_luma, int zabs_comp, in
 {
   const int off = comp ? (zabs_comp * 16) >> 2 : zabs_comp * 16;
   GLB const int16_t *src = real ? (GLB const int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + comp_off(comp) + off
-                            : k.coef_l + (5 - log2_luma) * 6144 + comp_off(comp) + off;
+                            : k.coef_l + lay_coef(k, log2_luma, comp, zabs_comp);
   PROF_T0();
   wsync();
   for (int i = lane_id(); i < n * n; i += 64) lds().lvl[i] = src[i];
@@ -1594,7 +1602,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
   set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
-  GLB int16_t *cl = k.coef_l + (5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
+  GLB int16_t *cl = k.coef_l + lay_coef(k, tu.log2, comp, zabs);
   if (abs_sum > 0) {
     for (int i = lane_id(); i < n * n; i += 64) cl[i] = s.lvl[i];
     dequant(k, comp, n);
@@ -1605,7 +1613,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
     wsync();
   }
   PROF_MARK(28);
-  GLB pel_t *rq = k.rec_l + (5 - tu.log2) * 6144 + comp_off(comp) + bo;
+  GLB pel_t *rq = k.rec_l + lay_rec(k, tu.log2, comp, x, y);
   int rps; GLB pel_t *rp = rec_target(k, comp, x, y, rps);
   uint32_t d = 0;
   for (int i = lane_id(); i < n * n; i += 64) {
@@ -1638,9 +1646,9 @@ DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
   int rps; GLB pel_t *rp = rec_target(k, comp, x, y, rps);
   wsync();
   if (lane_id() < 16) {
-    k.coef_l[(5 - tu.log2) * 6144 + comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16) + lane_id()] = lds().ts_coef[comp][lane_id()];
+    k.coef_l[lay_coef(k, tu.log2, comp, zabs) + lane_id()] = lds().ts_coef[comp][lane_id()];
     const int r = lane_id() >> 2, cc = lane_id() & 3; const pel_t v = lds().ts_rec[comp][lane_id()];
-    k.rec_l[(5 - tu.log2) * 6144 + comp_off(comp) + bo + r * cs + cc] = v;
+    k.rec_l[lay_rec(k, tu.log2, comp, x, y) + r * cs + cc] = v;
     rp[(size_t)r * rps + cc] = v;
   }
   wsync();
@@ -1740,7 +1748,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
         set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
       }
       const int n = 1 << LOG2, bo = boff(k, 0, tu.x, tu.y);
-      GLB const pel_t *rq = memo ? k.best_rec + bo : k.rec_l + (5 - LOG2) * 6144 + bo;
+      GLB const pel_t *rq = memo ? k.best_rec + bo : k.rec_l + lay_rec(k, LOG2, 0, tu.x, tu.y);
       int rps; GLB pel_t *rp = rec_target(k, 0, tu.x, tu.y, rps);
       wsync();
       for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * rps + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
@@ -1752,10 +1760,10 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
 }
 
 // xSetIntraResultLumaQT / xSetIntraResultChromaQT TEncSearch.cpp:1741-1781, 2150-2198
-template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp, GLB const int16_t *src_coef, GLB const pel_t *src_rec)
-{ // source: a layer set (the wave's own, or the result slot of the winning task)
+template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int comp, GLB const int16_t *src_coef, GLB const pel_t *src_rec, int slz, int slx, int sly)
+{ // source: a layer set (the wave's own, or the result slot of the winning task) and its origin
   if (uni(lds().a[A_TRIDX][cu.zbase + tu.zrel]) > tu.trd) {
-    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp, src_coef, src_rec);
+    if constexpr (LOG2 > 2) for (int i = 0; i < 4; i++) set_result<LOG2 - 1>(k, cu, tu_child(tu, i), comp, src_coef, src_rec, slz, slx, sly);
     return;
   }
   if (comp && !tu_has_chroma_first(tu)) return;
@@ -1763,23 +1771,24 @@ template <int LOG2> DEV void set_result(KR k, const Cu &cu, const Tu &tu, int co
   const int zabs = cu.zbase + (comp ? tu_czrel(tu) : tu.zrel);
   const int off = comp_off(comp) + (comp ? (zabs * 16) >> 2 : zabs * 16);
   GLB int16_t *dstc = (GLB int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF) + off;
-  GLB const int16_t *srcc = src_coef + (5 - LOG2) * 6144 + off;
+  GLB const int16_t *srcc = src_coef + lay_coef_o(slz, LOG2, comp, zabs);
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y, cs = cstride(comp), bo = comp_off(comp) + boff(k, comp, x, y);
-  GLB const pel_t *rq = src_rec + (5 - LOG2) * 6144 + bo; GLB pel_t *br = k.best_rec + bo;
+  GLB const pel_t *rq = src_rec + lay_rec_o(slx, sly, LOG2, comp, x, y); GLB pel_t *br = k.best_rec + bo;
   for (int i = lane_id(); i < n * n; i += 64) { dstc[i] = srcc[i]; const int o = (i >> log2n) * cs + (i & (n - 1)); br[o] = rq[o]; }
 }
-DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_, GLB const int16_t *src_coef, GLB const pel_t *src_rec)
+DEVN void set_result_cu(KR k, const Cu cu_, const Tu tu_, int comp_, GLB const int16_t *src_coef, GLB const pel_t *src_rec, int slz_, int slx_, int sly_)
 {
+  const int slz = uni(slz_), slx = uni(slx_), sly = uni(sly_);
   CHECK_EXEC(10);
   PROF_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_);
   wsync();
   switch (tu.log2) {
-    case 6: set_result<6>(k, cu, tu, comp, src_coef, src_rec); break;
-    case 5: set_result<5>(k, cu, tu, comp, src_coef, src_rec); break;
-    case 4: set_result<4>(k, cu, tu, comp, src_coef, src_rec); break;
-    case 3: set_result<3>(k, cu, tu, comp, src_coef, src_rec); break;
-    default: set_result<2>(k, cu, tu, comp, src_coef, src_rec); break;
+    case 6: set_result<6>(k, cu, tu, comp, src_coef, src_rec, slz, slx, sly); break;
+    case 5: set_result<5>(k, cu, tu, comp, src_coef, src_rec, slz, slx, sly); break;
+    case 4: set_result<4>(k, cu, tu, comp, src_coef, src_rec, slz, slx, sly); break;
+    case 3: set_result<3>(k, cu, tu, comp, src_coef, src_rec, slz, slx, sly); break;
+    default: set_result<2>(k, cu, tu, comp, src_coef, src_rec, slz, slx, sly); break;
   }
   wsync();
   PROF_ADD(k, 15);
@@ -1857,10 +1866,11 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
     for (int c = j; c < last; c++) { split_dist += (uint32_t)uni((int)r.dist[4 + c]); split_cbf |= (uint32_t)uni(r.modes[4 + c]); split_cfrac += uni64(r.cfrac[4 + c]); }
     if (brk >= 0) { // the split of child brk wins: its arrays, levels, reconstruction and end state replace the chain's
       const Tu ch = tu_child(tu, brk);
-      const int zc = cu.zbase + ch.zrel, n = 1 << (LOG2 - 1), lay = (5 - (LOG2 - 2)) * 6144, bo = boff(k, 0, ch.x, ch.y);
+      const int zc = cu.zbase + ch.zrel, n = 1 << (LOG2 - 1);
       GLB const uint8_t *at = slot_attr(k.slots, brk);
-      GLB const int16_t *sc = slot_coef(k.slots, brk) + lay + zc * 16; GLB int16_t *dc = k.coef_l + lay + zc * 16;
-      GLB const pel_t *sr = slot_rec(k.slots, brk) + lay + bo; GLB pel_t *dr = k.rec_l + lay + bo;
+      // the split task's slot has the child as its origin; this wave's own set the PU
+      GLB const int16_t *sc = slot_coef(k.slots, brk) + lay_coef_o(zc * 16, LOG2 - 2, 0, zc); GLB int16_t *dc = k.coef_l + lay_coef(k, LOG2 - 2, 0, zc);
+      GLB const pel_t *sr = slot_rec(k.slots, brk) + lay_rec_o(ch.x, ch.y, LOG2 - 2, 0, ch.x, ch.y); GLB pel_t *dr = k.rec_l + lay_rec(k, LOG2 - 2, 0, ch.x, ch.y);
       GLB pel_t *rp = k.rec[0] + (size_t)ch.y * k.W + ch.x;
       wsync();
       for (int i = lane_id(); i < ch.nparts; i += 64) { s.a[A_TRIDX][zc + i] = at[i]; s.a[A_CBF][zc + i] = at[256 + i]; s.a[A_TSKIP][zc + i] = at[512 + i]; }
@@ -2027,6 +2037,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
   for (int pu = 0; pu < npu; pu++) {
     const int poff = pu * pu_parts, zp = cu.zbase + poff;
     const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
+    { LDS K &kk = s.k; wsync(); kk.lz = zp * 16; kk.lx = ptu.x; kk.ly = ptu.y; wsync(); }       // this wave's own layer set serves the PU (second pass)
     // ---- rough mode decision ----
     build_refs(k, 0, ptu.x, ptu.y, pn, 1);
     if (pn >= 8 && pn <= 32) filter_refs(k, pn);
@@ -2081,7 +2092,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           s.a[A_TRIDX][zp + i] = t0; s.a[A_CBF][zp + i] = t1; s.a[A_TSKIP][zp + i] = t2;
         }
         wsync();
-        set_result_cu(k, cu, ptu, 0, slot_coef(k.slots, win), slot_rec(k.slots, win));
+        set_result_cu(k, cu, ptu, 0, slot_coef(k.slots, win), slot_rec(k.slots, win), zp * 16, ptu.x, ptu.y);        // a first-pass slot's origin is the PU
       }
       region_close(r);
     }
@@ -2106,7 +2117,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       PROF_MARK(37);
       if (ub(dc.cost < best_cost)) {
         best_dist = dc.dist; best_cost = dc.cost;
-        set_result_cu(k, cu, ptu, 0, k.coef_l, k.rec_l);
+        set_result_cu(k, cu, ptu, 0, k.coef_l, k.rec_l, k.lz, k.lx, k.ly);
         for (int i = lane_id(); i < pu_parts; i += 64) {
           s.sv[0][i] = s.a[A_TRIDX][zp + i]; s.sv[1][i] = s.a[A_CBF][zp + i]; s.sv[2][i] = s.a[A_TSKIP][zp + i];   // the luma search leaves chroma entries alone
         }
@@ -2249,6 +2260,8 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   wsync();
   const int slot = kind == T_LUMA_SPLIT ? mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
+  const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
+  kk.lz = (cu.zbase + (kind == T_CHROMA ? 0 : ttu.zrel)) * 16; kk.lx = kind == T_CHROMA ? cu.x : ttu.x; kk.ly = kind == T_CHROMA ? cu.y : ttu.y;
   if (kind == T_LUMA_P2) { // the whole second pass: trial samples go to the picture (the master keeps off the CU's luma until the join), levels to this wave's layers
     kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   } else {
@@ -2268,7 +2281,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
     dist = memo_dist; cost = memo_cost;
     if (ub(dc.cost < memo_cost)) { // the split wins: levels -> record, reconstruction -> the master's best, arrays -> the verdict slot
       dist = dc.dist; cost = dc.cost;
-      set_result_cu(k, cu, tu, 0, k.coef_l, k.rec_l);
+      set_result_cu(k, cu, tu, 0, k.coef_l, k.rec_l, k.lz, k.lx, k.ly);
       wsync();
       for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
     }
@@ -2321,6 +2334,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
+  kk.lz = olz; kk.lx = olx; kk.ly = oly;
   wsync();
 }
 
@@ -2409,7 +2423,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
       wsync();
       for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 4; c++) s.sv[c][i] = at[c * 256 + i];
       wsync();
-      set_result_cu(k, cu, root, 1, slot_coef(k.slots, SLOT_CHROMA + win), slot_rec(k.slots, SLOT_CHROMA + win)); set_result_cu(k, cu, root, 2, slot_coef(k.slots, SLOT_CHROMA + win), slot_rec(k.slots, SLOT_CHROMA + win));
+      for (int c = 1; c < 3; c++) set_result_cu(k, cu, root, c, slot_coef(k.slots, SLOT_CHROMA + win), slot_rec(k.slots, SLOT_CHROMA + win), cu.zbase * 16, cu.x, cu.y);   // a chroma slot's origin is the CU
     }
     region_close(r);
   }
@@ -2620,7 +2634,7 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
   k.q_cost = s.my_qcost; k.q_rate = s.my_qrate;
-  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0;
+  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
