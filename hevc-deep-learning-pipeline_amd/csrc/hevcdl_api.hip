@@ -228,6 +228,10 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
 
 extern "C" const char *hevcdl_last_error(const hevcdl_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
 
+// page-locked host memory for the buffers of the host-pointer entry points (optional: any host memory works, pinned memory copies faster)
+extern "C" void *hevcdl_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+extern "C" void hevcdl_host_free(void *p) { if (p) hipHostFree(p); }
+
 static hevcdl_status ensure_staging(hevcdl_ctx *ctx)
 {
   if (ctx->d_yuv) return HEVCDL_OK;

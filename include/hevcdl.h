@@ -215,6 +215,11 @@ hevcdl_status hevcdl_compress_ctu(hevcdl_ctx *ctx, int frame, int ctu_addr, cons
                                   hevcdl_ctu_record *record, hevcdl_cabac_state *state_out_opt);
 hevcdl_status hevcdl_get_recon(hevcdl_ctx *ctx, int frame, uint8_t *recon);
 
+/* Page-locked host memory for the yuv / records / picture buffers handed to the host-pointer entry points (optional; ordinary memory works,
+ * page-locked memory is copied at the DMA rate).  NULL when no GPU runtime is available. */
+void *hevcdl_host_alloc(size_t bytes);
+void hevcdl_host_free(void *p);
+
 /* ---- device-buffer entry points (inputs/outputs already resident in HBM, asynchronous on `stream`) ---- */
 /* All pointers are device pointers; stream is a hipStream_t (NULL = default stream). */
 hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream);
