@@ -70,6 +70,7 @@ struct hevcdl_ctx {
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
   unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params;   // SAO workspace
   int *d_flag;                   // device-side error flag of the label check
+  unsigned char *d_sched;        // decision kernel: hand-over of units between workgroups (finished counter, per-workgroup unit counts, mailboxes)
   bool profile;
   std::vector<hipEvent_t> ev_cnn, ev_rd;       // start/stop pairs
   char err[256];
@@ -181,7 +182,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr; ctx->d_flag = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -195,6 +196,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_flag, sizeof(int)));
+  CK(hipMalloc(&ctx->d_sched, 8192 + 1024 * 192));
   if (cfg->bit_depth > 8) CK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(cfg->width, cfg->height) * (size_t)cfg->max_frames));    // the CNN stage's 8-bit copy
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
@@ -222,7 +224,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_flag);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
   delete ctx;
 }
 
@@ -314,6 +316,19 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // One workgroup (hevcdl_rd_waves_per_group() wavefronts, the whole LDS) per CU; the units (frame x tile) are dealt round-robin to the
   // workgroups, a wave per unit; waves left without a unit help the others (rd_kernel.hip).
   const int n_units = n_frames * p.tile_count, groups = std::min(n_units, ctx->rd_groups), threads = 64 * hevcdl_rd_waves_per_group();
+  // Uneven dealing (e.g. 600 frames on 256 workgroups): the surplus units travel round the ring of workgroups so that every workgroup --
+  // and every frame -- is crowded for the same share of the time (rd_kernel.hip, process_unit).  Only for whole-unit launches of a few units
+  // per workgroup.
+  p.sched = ctx->d_sched;
+  p.migrate = (n_units > groups && n_units % groups != 0 && n_units / groups <= 3 && groups <= 1024 && groups >= 8 && !d_cabac_in && !d_cabac_out &&
+               ctu_begin == 0 && p.ctu_end == ctx->ctus) ? 1 : 0;
+  if (p.migrate) {
+    std::vector<int> init(16 + groups, 0);
+    const int base = n_units / groups, extra = n_units % groups;
+    for (int g = 0; g < groups; g++) { const int e = (g * extra + groups - 1) / groups; init[16 + g] = base + ((e < extra && (e * groups) / extra == g) ? 1 : 0); }    // the kernel's dealing
+    HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 8192 + (size_t)groups * 192, s));
+    HIPCHK(hipMemcpyAsync(ctx->d_sched, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));      // pageable source: the copy is staged before the call returns
+  }
   prof_begin(ctx, ctx->ev_rd, s);
   if (ctx->cfg.bit_depth == 8)
     hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), hevcdl_rd_smem_bytes(), s, p);

@@ -56,6 +56,8 @@ struct hevcdl_rd_params {
   unsigned char *scratch;          // [workgroup][wave] workspace
   size_t scratch_per_wave;
   unsigned int *dbgbuf;
+  unsigned char *sched;            // hand-over of units between workgroups: [0] finished units, [16 + g] units walked by workgroup g, +8192: one mailbox per workgroup
+  int migrate;                     // 1: units travel round the ring of workgroups (uneven dealing)
   const unsigned char *cabac_in;   // [frame] 168-byte coder state to start from, or NULL: slice-start state (only with ctu_begin == 0)
   unsigned char *cabac_out;        // [frame] coder state after the last CTU processed, or NULL
   int ctu_begin, ctu_end;          // CTU address range [begin, end) in coding order

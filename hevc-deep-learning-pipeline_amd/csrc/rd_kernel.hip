@@ -50,9 +50,6 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #define HEVCDL_NW 8
 #endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
-#ifndef HEVCDL_SPEC_MARGIN
-#define HEVCDL_SPEC_MARGIN 0
-#endif
 constexpr int NSLOT = 10;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
@@ -167,7 +164,7 @@ typedef const LDS K &KR;
 struct __attribute__((aligned(16))) RdSmem {
   K k;
   // the executing wave's own scratch (K is copied from the master when a helper runs one of its tasks; these are not)
-  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save;
+  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save; GLB unsigned char *my_slots;
   int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task; joined in check_rd_cost_intra
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
@@ -265,12 +262,19 @@ struct Tables {                        // read-only after kernel start, one copy
 };
 struct __attribute__((aligned(16))) WgShared {
   Region reg[NW][2];                  // two regions per master: [1] serves the speculative second pass
-  int masters_active, has_helpers, pad_[2];     // has_helpers: the workgroup started with waves that have no unit
+  int masters_active, pad_[3];                  // waves that currently walk a unit
   Tables tab;
 };
 DEV LDS WgShared &wg_shared() { return *(LDS WgShared *)(lds_base() + (size_t)NW * sizeof(RdSmem)); }
 DEV LRegion &my_region(int which = 0) { return wg_shared().reg[wave_id()][which]; }
 DEV LDS Tables &tb() { return wg_shared().tab; }
+#ifndef HEVCDL_SPEC_MARGIN
+#define HEVCDL_SPEC_MARGIN 0
+#endif
+DEV int lds_load(LDS int *p);
+// spare waves for the second-pass tasks: at least as many waves without a unit as with one (chain owners serve their own split tasks, so no
+// wave ever waits on an unserved region)
+DEV int spare_waves() { return 2 * lds_load(&wg_shared().masters_active) <= NW - HEVCDL_SPEC_MARGIN; }
 DEV int lds_load(LDS int *p) { return uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 DEVN int lds_add(LDS int *p, int v)
 { // one atomic per wave (lane 0), result to every lane.  NOT inlined: inlined into a loop whose exit depends on the result, the lane-0
@@ -1726,7 +1730,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       unsigned long long split_cfrac = 0;
       bool spec = false;
-      if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && lds_load(&wg_shared().has_helpers) && (LOG2 - 1 > min_tu_log2(cu));
+      if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && spare_waves() && (LOG2 - 1 > min_tu_log2(cu));
       if (spec) { // second pass of a PU, spare waves in the workgroup: the children's two alternatives run concurrently (spec_children)
         if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; split_cfrac = dc.cfrac; }
       } else for (int i = 0; i < 4; i++) {
@@ -2103,7 +2107,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
       const int memo = pu_log2 <= 5;
       if (memo && !(pu_log2 > min_tu_log2(cu))) break;              // no split possible: the pass cannot change anything
-      if (memo && npu == 1 && lds_load(&wg_shared().has_helpers)) {
+      if (memo && npu == 1 && spare_waves()) {
         // Spare waves: the pass is handed to one of them and joined in check_rd_cost_intra, after the chroma search and the CU's syntax have
         // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time).  If the split wins, those two are redone.
         LRegion &r2 = my_region(1);
@@ -2365,11 +2369,11 @@ DEVN void region_run(KR k, LRegion &r)
   wg_acquire();
 }
 // waves without a unit (or done with theirs) serve the regions of the workgroup's masters until the last master has finished
-DEV void helper_loop()
-{
+DEV int helper_step()
+{ // one scan of the workgroup's regions: 1 when a task was run
   LDS WgShared &sh = wg_shared();
   const int me = wave_id();
-  while (lds_load(&sh.masters_active) > 0) {
+  {
     int did = 0;
     for (int j = 0; j < 2 * NW && !did; j++) { // the second-pass regions first: they sit on the masters' critical paths
       LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][j < NW ? 1 : 0];
@@ -2384,7 +2388,7 @@ DEV void helper_loop()
       lds_add(&r.done, 1);
       did = 1;
     }
-    if (!did) __builtin_amdgcn_s_sleep(32);
+    return did;
   }
 }
 
@@ -2616,7 +2620,30 @@ template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
 
 // one unit = one (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
 // (a launch may cover only tiles [tile_begin, tile_begin + tile_count) of every frame: tile sharding across GPUs)
-DEV void process_unit(const hevcdl_rd_params &p, int unit)
+// Hand-over of a unit between workgroups (p.migrate): when the units do not divide evenly over the workgroups (600 frames on 256 CUs: 88
+// workgroups walk three frames, 168 two), every frame is a serial chain and the launch lasts as long as the most crowded workgroup.  A
+// master therefore offers its unit to the next workgroup of the ring at a CTU boundary whenever that one currently walks fewer units: the
+// whole state of a unit between two CTUs is its position and the coder state (168 B) -- records and reconstruction are in HBM.  The surplus
+// units keep travelling round the ring, every workgroup is crowded for the same share of the time, and so is every frame.
+#ifndef HEVCDL_HOP
+#define HEVCDL_HOP 16
+#endif
+struct Mbox { int state, unit, next_i, pad_; unsigned long long cabac[21]; };     // state: 0 empty, 2 being filled, 1 full, 3 being taken
+DEV GLB int *sched_finished(const hevcdl_rd_params &p) { return (GLB int *)p.sched; }
+DEV GLB int *sched_count(const hevcdl_rd_params &p, int g) { return (GLB int *)p.sched + 16 + g; }
+DEV GLB Mbox *sched_mbox(const hevcdl_rd_params &p, int g) { return (GLB Mbox *)((GLB unsigned char *)p.sched + 8192) + g; }
+DEV int glb_load_lane0(GLB int *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV int glb_load(GLB int *q) { int v = 0; if (lane_id() == 0) v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return uni(v); }
+DEVN int glb_add(GLB int *q, int d) { int v = 0; if (lane_id() == 0) v = __hip_atomic_fetch_add(q, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return uni(v); }
+DEVN int glb_cas(GLB int *q, int expect, int desired)
+{ // 1 when the swap happened
+  int ok = 0;
+  if (lane_id() == 0) { int e = expect; ok = __hip_atomic_compare_exchange_strong(q, &e, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
+  return uni(ok);
+}
+
+// -> 0: the unit is finished, 1: handed over to the next workgroup.  i_resume >= 0: continue a unit taken from this workgroup's mailbox.
+DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
 {
   LSmem &s = lds();
   const int ntiles = p.tile_cols * p.tile_rows, frame = unit / p.tile_count, tile = p.tile_begin + (unit - frame * p.tile_count);
@@ -2633,7 +2660,7 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
   k.records = records;
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
-  k.q_cost = s.my_qcost; k.q_rate = s.my_qrate;
+  k.q_cost = s.my_qcost; k.q_rate = s.my_qrate; k.slots = s.my_slots;        // (a wave that served other masters' tasks holds their context)
   k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
@@ -2643,7 +2670,13 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719.
   // A per-CTU call (hevcdl_compress_ctu) resumes from the state the previous call left instead.
   LCabac *truec = &s.truec;
-  if (p.cabac_in) {
+  if (i_resume >= 0) { // the coder state travels with the unit; taking it frees the mailbox
+    GLB Mbox *mb = sched_mbox(p, (int)blockIdx.x);
+    if (lane < 21) ((LDS unsigned long long *)truec)[lane] = mb->cabac[lane];
+    wsync();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&mb->state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (p.cabac_in) {
     GLB const unsigned long long *src = (GLB const unsigned long long *)p.cabac_in + (size_t)frame * 21;
     if (lane < 21) ((LDS unsigned long long *)truec)[lane] = src[lane];
   } else {
@@ -2663,8 +2696,23 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
   const int cx0 = p.col_bd[tcx], cx1 = p.col_bd[tcx + 1], cy0 = p.row_bd[tcy], cy1 = p.row_bd[tcy + 1];
   const int tw = cx1 - cx0;
   k.tx0 = cx0 * 64; k.ty0 = cy0 * 64; k.tx1 = cx1 * 64; k.ty1 = cy1 * 64;
-  const int i_begin = ntiles == 1 ? p.ctu_begin : 0, i_end = ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0);
+  const int i_begin = i_resume >= 0 ? i_resume : (ntiles == 1 ? p.ctu_begin : 0), i_end = ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0);
   for (int i = i_begin; i < i_end; i++) {
+    if (p.migrate && i > i_begin && ((i - i_begin) & (HEVCDL_HOP - 1)) == 0) { // every HEVCDL_HOP CTUs: does the next workgroup of the ring walk fewer units than this one?
+      const int g = (int)blockIdx.x, ng = (g + 1) % (int)gridDim.x;
+      if (lds_load(&wg_shared().masters_active) > glb_load(sched_count(p, ng)) && glb_cas(&sched_mbox(p, ng)->state, 0, 2)) {
+        GLB Mbox *mb = sched_mbox(p, ng);
+        wsync();
+        if (lane < 21) mb->cabac[lane] = ((LDS const unsigned long long *)truec)[lane];
+        if (lane == 0) { mb->unit = unit; mb->next_i = i; }
+        if (p.stats && lane == 0) __hip_atomic_fetch_add(&((GLB hevcdl_frame_stats *)p.stats + frame)->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // records, reconstruction and the mailbox before the flag: the taker runs on another XCD
+        glb_add(sched_count(p, ng), 1); glb_add(sched_count(p, g), -1);
+        if (lane == 0) __hip_atomic_store(&mb->state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 1;
+      }
+    }
     const int cx = cx0 + i % tw, cy = cy0 + i / tw, a = cy * p.ctus_x + cx;
     wsync();
     k.addr = a; k.cx = cx; k.cy = cy;
@@ -2716,6 +2764,7 @@ DEV void process_unit(const hevcdl_rd_params &p, int unit)
     }
     if (lane == 0) { __hip_atomic_fetch_add(&st->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tile == p.tile_begin) { st->ctus = (uint32_t)nctu; st->pad = 0; } }
   }
+  return 0;
 }
 
 } // namespace
@@ -2730,10 +2779,16 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     GLB unsigned char *scr = (GLB unsigned char *)p.scratch + ((size_t)blockIdx.x * NW + wave) * p.scratch_per_wave;
     s.my_coef = (GLB int16_t *)scr; s.my_rec = (GLB pel_t *)(scr + 4 * 6144 * 2); s.my_ovl = s.my_rec + 5 * 6144; s.my_save = (GLB unsigned long long *)(s.my_ovl + 6144);
     s.my_qcost = (GLB double *)(scr + SCR_LAYERS); s.my_qrate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
-    s.k.slots = scr + SCR_LAYERS + SCR_RDOQ;
+    s.my_slots = scr + SCR_LAYERS + SCR_RDOQ;
   }
   // units are dealt round-robin: unit u belongs to workgroup u mod G, wave (u div G) mod NW
-  const int n_units = p.n_frames * p.tile_count, G = (int)gridDim.x, first = (int)blockIdx.x + G * wave;
+  const int n_units = p.n_frames * p.tile_count, G = (int)gridDim.x;
+  int first = (int)blockIdx.x + G * wave;
+  if (p.migrate) { // the surplus units (beyond `base` per workgroup) start evenly spaced round the ring, not bunched in the first workgroups
+    const int base = n_units / G, extra = n_units - base * G, g = (int)blockIdx.x;
+    if (wave == base) { const int e = (g * extra + G - 1) / G; first = (e < extra && (e * G) / extra == g) ? base * G + e : n_units; }
+    else if (wave > base) first = n_units;
+  }
   LDS WgShared &sh = wg_shared();
   if (lane == 0) for (int q = 0; q < 2; q++) { sh.reg[wave][q].ticket = 0; sh.reg[wave][q].done = 0; sh.reg[wave][q].owner = wave; }
   if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
@@ -2758,19 +2813,39 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       int l2 = 0, c2 = 0;
       for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
     }
-    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; sh.masters_active = m; sh.has_helpers = 2 * m <= NW - HEVCDL_SPEC_MARGIN; }     // spare waves for the second-pass tasks (chain owners serve their own split tasks, so no wave ever waits on an unserved region)
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m; }
   }
 #ifdef HEVCDL_KERNEL_PROF
   if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
-  if (first < n_units) {
-    for (int u = first; u < n_units; u += G * NW) process_unit(p, u);
-    wg_release();
-    lds_add(&sh.masters_active, -1);
+  // a wave walks a unit (master) or serves the workgroup's regions (helper); with p.migrate units arrive and leave through the mailboxes
+  int unit = first < n_units ? first : -1, i_resume = -1;
+  for (;;) {
+    if (unit >= 0) {
+      const int moved = process_unit(p, unit, i_resume);
+      int next = -1;
+      if (!moved) {
+        if (p.migrate) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); glb_add(sched_count(p, (int)blockIdx.x), -1); glb_add(sched_finished(p), 1); }
+        else if (unit + G * NW < n_units) next = unit + G * NW;        // more units than wave slots: the next one of this wave's list
+      }
+      unit = next; i_resume = -1;
+      if (unit < 0) { wg_release(); lds_add(&sh.masters_active, -1); }
+      continue;
+    }
+    if (p.migrate) {
+      if (glb_load(sched_finished(p)) >= n_units) break;
+      GLB Mbox *mb = sched_mbox(p, (int)blockIdx.x);
+      if (glb_load(&mb->state) == 1 && glb_cas(&mb->state, 1, 3)) { // a unit handed over by the previous workgroup of the ring
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        unit = uni(mb->unit); i_resume = uni(mb->next_i);
+        lds_add(&sh.masters_active, 1);
+        continue;
+      }
+    } else if (lds_load(&sh.masters_active) <= 0) break;
+    if (!helper_step()) __builtin_amdgcn_s_sleep(32);
   }
-  helper_loop();
 #ifdef HEVCDL_KERNEL_PROF
   // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)
   wsync();

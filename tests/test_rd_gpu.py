@@ -113,6 +113,32 @@ def test_unclamped_caller_labels_get_the_boundary_policy(oracle_built):
     enc.close()
 
 
+def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built):
+    """600 frames on 256 workgroups do not divide evenly: the surplus frames travel round the ring of workgroups (a frame is handed over at a CTU
+    boundary: position + coder state).  The launch that migrates must give, frame by frame, what launches without migration give (<= one frame
+    per workgroup), and a sample of frames must equal the oracle."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf = 512, 256, 33, 600                       # 32 CTUs per frame: two hand-over points per frame
+    base = ref_tools.synth_yuv(w, h, 8, 77)
+    rng = np.random.default_rng(3)
+    yuv = np.stack([np.clip(base[i % 8].astype(np.int16) + rng.integers(-2, 3, base.shape[1]) * (1 + i % 3), 0, 255).astype(np.uint8) for i in range(nf)])
+    labels = ref_tools.make_labels(w, h, nf, "rand", 5)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    recs, recon, stats = enc.compress_frames(yuv, labels)               # 600 units on min(600, CUs) workgroups: migrates
+    parts = [enc.compress_frames(yuv[a:a + 200], labels[a:a + 200]) for a in range(0, nf, 200)]      # 200 units: one per workgroup
+    enc.close()
+    recs2 = np.concatenate([p[0] for p in parts]); recon2 = np.concatenate([p[1] for p in parts]); stats2 = np.concatenate([p[2] for p in parts])
+    assert_records_equal(recs, recs2, "migrating launch vs plain launches")
+    assert np.array_equal(recon, recon2)
+    for k in ("sse", "est_bits", "ctus"):
+        assert np.array_equal(stats[k], stats2[k]), k
+    pick = [0, 255, 256, 511, 512, 599]
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv[pick], w, h, qp, labels[pick])
+    assert_records_equal(recs[pick], o_recs, "migrating launch vs oracle")
+    assert np.array_equal(recon[pick], o_recon) and np.array_equal(stats["est_bits"][pick], o_stats["est_bits"])
+
+
 @pytest.mark.parametrize("w,h,qp,nf,seed", [(256, 128, 30, 3, 41), (136, 72, 24, 2, 42), (320, 192, 40, 1, 43)])
 def test_matches_oracle_on_seeded_inputs(oracle_built, w, h, qp, nf, seed):
     import hevcdl_amd
