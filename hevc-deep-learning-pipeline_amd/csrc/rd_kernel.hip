@@ -2626,7 +2626,7 @@ template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
 // whole state of a unit between two CTUs is its position and the coder state (168 B) -- records and reconstruction are in HBM.  The surplus
 // units keep travelling round the ring, every workgroup is crowded for the same share of the time, and so is every frame.
 #ifndef HEVCDL_HOP
-#define HEVCDL_HOP 16
+#define HEVCDL_HOP 4
 #endif
 struct Mbox { int state, unit, next_i, pad_; unsigned long long cabac[21]; };     // state: 0 empty, 2 being filled, 1 full, 3 being taken
 DEV GLB int *sched_finished(const hevcdl_rd_params &p) { return (GLB int *)p.sched; }
