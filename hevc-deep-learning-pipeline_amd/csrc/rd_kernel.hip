@@ -50,13 +50,14 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #define HEVCDL_NW 8
 #endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
-constexpr int NSLOT = 10;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
+constexpr int NSLOT = 15;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
 // per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
-constexpr int SAVE_BYTES = 8192;                              // the chain owner's state while it runs one of its own split tasks (spec_children)
-constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + SAVE_BYTES + 2047) & ~2047;
+constexpr int SAVE_BYTES = 8192, N_SAVE = 2;   // two areas: consecutive children can each leave a pass pending (compress_cu)
+//                            // the chain owner's state while it runs one of its own split tasks (spec_children)
+constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
 constexpr int SCR_WAVE = SCR_LAYERS + SCR_RDOQ + NSLOT * SLOT_BYTES;
@@ -152,6 +153,9 @@ struct K {                             // wave-uniform kernel context (lives in 
   // the luma search, the CU of a chroma task, the child of a split task), so that every PU reuses the same few KB of a set and the sets
   // of all waves stay cache resident (laid out CTU-wide they did not: profiles/r02_traffic.json).  lz: z-scan offset in luma samples.
   int lz, lx, ly;
+  // The second luma pass of the PREVIOUS sibling CU may still be running (its trial samples are in the picture): luma reference samples inside
+  // that CU's rectangle then come from best_rec, which holds the reconstruction the search continued with (the first pass's winner).
+  int sx0, sy0, sx1, sy1;
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
   long long sbh[2];
@@ -188,6 +192,7 @@ struct __attribute__((aligned(16))) RdSmem {
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
   unsigned long long cfrac_last;      // coefficient part of the last intra_bits_qt count (fractional bits)
+  int carry_ok, carry, restart, pad_carry;   // second pass pending across the CU boundary: allowed for the CU being coded / pending from the previous sibling / it won: redo
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
@@ -239,7 +244,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
 enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4 };
-enum { SLOT_P2 = 4, SLOT_CHROMA = 5 };          // result slots: 0..3 the split tasks of the second pass (by child), 4 its verdict, 5..9 the chroma modes; the first pass uses 0..9 before any of them
+enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it), 10..13 the split tasks of the second pass (by child), 14 its verdict + start state: a second pass may still run while the next CU's first pass does
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
   // the count can only come from the region that is open, whose parameters were written before the ticket was
@@ -270,6 +275,9 @@ DEV LRegion &my_region(int which = 0) { return wg_shared().reg[wave_id()][which]
 DEV LDS Tables &tb() { return wg_shared().tab; }
 #ifndef HEVCDL_SPEC_MARGIN
 #define HEVCDL_SPEC_MARGIN 0
+#endif
+#ifndef HEVCDL_CARRY_MAX
+#define HEVCDL_CARRY_MAX 1      // a second pass stays pending across the CU boundary only in workgroups with this many masters at most (it costs throughput when waves are scarce)
 #endif
 DEV int lds_load(LDS int *p);
 // spare waves for the second-pass tasks: at least as many waves without a unit as with one (chain owners serve their own split tasks, so no
@@ -418,6 +426,8 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   const int rx0 = k.trx0 >> csh, ry0 = k.try0 >> csh, rx1 = k.trx1 >> csh, ry1 = k.try1 >> csh;
   GLB const pel_t *po = k.ovl + comp_off(c);
   const int ox = k.cx * cs_, oy = k.cy * cs_;
+  const int spx0 = k.sx0, spy0 = k.sy0, spx1 = k.sx1, spy1 = k.sy1;
+  GLB const pel_t *pbest = k.best_rec;
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
   auto sample_ptr = [&](int i) -> GLB const pel_t * {        // the sample behind line index i
@@ -426,6 +436,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
     else if (i == 2 * n) { sy = y - 1; sx = x - 1; }
     else { sy = y - 1; sx = x + (i - 2 * n - 1); }
     if (task && sx >= rx0 && sx < rx1 && sy >= ry0 && sy < ry1) return po + (sy - oy) * cs_ + (sx - ox);
+    if (!c && sx >= spx0 && sx < spx1 && sy >= spy0 && sy < spy1) return pbest + (sy - oy) * 64 + (sx - ox);     // previous sibling, second pass pending
     return p + (size_t)sy * st + sx;
   };
   // Every line element is ONE picture sample: its own when its unit is available, otherwise the last sample of the nearest
@@ -1831,7 +1842,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
     region_open(r, T_LUMA_SPLIT, 0, cu, tu);
     for (int c = j; c < 4; c++) {
       const Tu ch = tu_child(tu, c);
-      state_to_global(slot_state(k.slots, c, 0), &s.go);
+      state_to_global(slot_state(k.slots, SLOT_SPLIT + c, 0), &s.go);
       region_publish(r);
       // the unsplit alternative (the single-TU branch of recur_luma)
       set_parts(k, s.a[A_TSKIP + 0], cu.zbase + ch.zrel, ch.nparts, 0); wsync();
@@ -1871,10 +1882,10 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
     if (brk >= 0) { // the split of child brk wins: its arrays, levels, reconstruction and end state replace the chain's
       const Tu ch = tu_child(tu, brk);
       const int zc = cu.zbase + ch.zrel, n = 1 << (LOG2 - 1);
-      GLB const uint8_t *at = slot_attr(k.slots, brk);
+      GLB const uint8_t *at = slot_attr(k.slots, SLOT_SPLIT + brk);
       // the split task's slot has the child as its origin; this wave's own set the PU
-      GLB const int16_t *sc = slot_coef(k.slots, brk) + lay_coef_o(zc * 16, LOG2 - 2, 0, zc); GLB int16_t *dc = k.coef_l + lay_coef(k, LOG2 - 2, 0, zc);
-      GLB const pel_t *sr = slot_rec(k.slots, brk) + lay_rec_o(ch.x, ch.y, LOG2 - 2, 0, ch.x, ch.y); GLB pel_t *dr = k.rec_l + lay_rec(k, LOG2 - 2, 0, ch.x, ch.y);
+      GLB const int16_t *sc = slot_coef(k.slots, SLOT_SPLIT + brk) + lay_coef_o(zc * 16, LOG2 - 2, 0, zc); GLB int16_t *dc = k.coef_l + lay_coef(k, LOG2 - 2, 0, zc);
+      GLB const pel_t *sr = slot_rec(k.slots, SLOT_SPLIT + brk) + lay_rec_o(ch.x, ch.y, LOG2 - 2, 0, ch.x, ch.y); GLB pel_t *dr = k.rec_l + lay_rec(k, LOG2 - 2, 0, ch.x, ch.y);
       GLB pel_t *rp = k.rec[0] + (size_t)ch.y * k.W + ch.x;
       wsync();
       for (int i = lane_id(); i < ch.nparts; i += 64) { s.a[A_TRIDX][zc + i] = at[i]; s.a[A_CBF][zc + i] = at[256 + i]; s.a[A_TSKIP][zc + i] = at[512 + i]; }
@@ -1883,7 +1894,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
         const int o = (i >> (LOG2 - 1)) * 64 + (i & (n - 1)); const pel_t v = sr[o];
         dr[o] = v; rp[(size_t)(i >> (LOG2 - 1)) * k.W + (i & (n - 1))] = v;
       }
-      state_from_global(&s.go, slot_state(k.slots, brk, 1));
+      state_from_global(&s.go, slot_state(k.slots, SLOT_SPLIT + brk, 1));
       split_dist += (uint32_t)uni((int)r.dist[brk - j]);
       split_cfrac += uni64(r.cfrac[brk - j]);
       split_cbf |= (uint32_t)(uni(s.a[A_CBF][zc]) >> ch.trd) & 1;
@@ -2083,6 +2094,20 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       region_open(r, T_LUMA_P1, nfull, cu, ptu);
       region_run(k, r);
       PROF_MARK(36);
+      if (uni(s.carry)) { // the previous sibling's second pass was left running: its verdict is needed before this CU's own pass goes out
+        LRegion &rp = my_region(1);
+        region_wait(rp, 1);
+        wsync();
+        LDS K &kk = s.k;
+        kk.sx0 = kk.sy0 = kk.sx1 = kk.sy1 = 0;
+        if (lane_id() == 0) s.carry = 0;
+        wsync();
+        if (ub(rp.cost[0] < rp.cost[4])) { // its split won: everything since was built on the wrong reconstruction -> the parent redoes both CUs (compress_cu)
+          if (lane_id() == 0) s.restart = 1;
+          wsync();
+          return 0;
+        }
+      }
       // the serial loop keeps a candidate when its cost is strictly smaller: the winner is the smallest cost, first in list order
       int win = -1;
       for (int m = 0; m < nfull; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
@@ -2113,6 +2138,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         LRegion &r2 = my_region(1);
         wsync();
         if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = 1; }
+        state_to_global(slot_state(k.slots, SLOT_P2, 0), &s.curr[cu.depth]);
         region_open(r2, T_LUMA_P2, 1, cu, ptu);
         break;
       }
@@ -2262,7 +2288,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
   const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
-  const int slot = kind == T_LUMA_SPLIT ? mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
+  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
   kk.lz = (cu.zbase + (kind == T_CHROMA ? 0 : ttu.zrel)) * 16; kk.lx = kind == T_CHROMA ? cu.x : ttu.x; kk.ly = kind == T_CHROMA ? cu.y : ttu.y;
@@ -2279,7 +2305,10 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   if (!LEAF && kind == T_LUMA_P2) { // second RD pass of the PU (TEncSearch.cpp:2445-2512) with the first pass's result as the unsplit alternative
     const int zp = cu.zbase + tu.zrel;
     const double memo_cost = r.cost[4]; const uint32_t memo_dist = (uint32_t)uni((int)r.dist[4]);
-    cabac_copy(k, &s.go, start);
+    wsync();
+    kk.sx0 = kk.sy0 = kk.sx1 = kk.sy1 = 0;                     // this pass IS the pending one: its own CU's samples are the picture's (the master may be in the next CU by now)
+    wsync();
+    state_from_global(&s.go, slot_state(kk.slots, SLOT_P2, 0)); // the master's [depth][CI_CURR_BEST] snapshot as it was when the pass was handed over
     DistCost dc = { 0, 0.0, 0 };
     if constexpr (!LEAF) dc = recur_luma_any<true>(k, cu, tu, 0, 1, memo_dist, memo_cost);
     dist = memo_dist; cost = memo_cost;
@@ -2469,7 +2498,8 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
   wsync();
   uint32_t dist_l = est_intra_luma(k, cu);
   int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma)
-  Rd r;
+  Rd r = { 0.0, 0, 0 };
+  if (uni(s.restart)) return r;                      // the previous sibling's pending pass won: the parent starts over
   for (;;) {
     if (!pending) copy_best_rec_to_pic(k, cu, 0);
     const uint32_t dist = dist_l + est_intra_chroma(k, cu);
@@ -2479,6 +2509,15 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     cabac_copy(k, &s.temp[cu.depth], &s.go);
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
     if (!pending) break;
+    if (uni(s.carry_ok)) { // the next sibling is a plain CU of the same size: it starts while this pass is still running and joins it after its own
+      // first pass (est_intra_luma); until then this CU's luma in the picture belongs to the pass, the search reads best_rec instead
+      LDS K &kk = s.k;
+      wsync();
+      kk.sx0 = cu.x; kk.sy0 = cu.y; kk.sx1 = cu.x + (1 << cu.log2); kk.sy1 = cu.y + (1 << cu.log2);
+      if (lane_id() == 0) { s.carry = 1; s.p2_pending = 0; }
+      wsync();
+      break;
+    }
     // join: the second pass's verdict
     LRegion &r2 = my_region(1);
     region_wait(r2, 1);
@@ -2542,6 +2581,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
   if (!boundary) {
     if (check_cur) {
       Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N);
+      if (uni(s.restart)) return t;
       if (ub(t.cost < best.cost)) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
       if (DEPTH == 3) {
         save_cand8(k, cu);
@@ -2559,17 +2599,51 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
     best.cost = calc_rd_cost(k, best.bits, best.dist);
     cabac_copy(k, &s.next[DEPTH], &s.go);
   }
-  if (best_is_real) for (int c = 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093
+  if (best_is_real) for (int c = uni(s.carry) ? 1 : 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093 (luma stays with a pass that is still running)
   if constexpr (DEPTH < 3) {
     Rd temp = { 0, 0, 0 };
     const int h = size >> 1, qn = cu.nparts >> 2;
+    // A child that is a plain CU (label == its depth, inside the picture) followed by another such child may leave its second luma pass
+    // running while the next one starts (check_rd_cost_intra / est_intra_luma).  Should that pass then decide for the split (~5 % of CUs),
+    // both children are coded again from the state saved before the first of them, this time joining the pass inside the CU.
+    auto plain_leaf = [&](int j) -> int {
+      const int jx = x + (j & 1) * h, jy = y + (j >> 1) * h;
+      return jx + h <= k.W && jy + h <= k.H && uni(k.labels[k.addr * 16 + 4 * ((jy & 63) / 16) + (jx & 63) / 16]) == DEPTH + 1;
+    };
+    Rd temp_saved[2] = { temp, temp }; int no_carry = 0;
+    constexpr int SAVE_WORDS = (int)(offsetof(RdSmem, line) / 8);
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
       if (ub(sx < k.W && sy < k.H)) {
+        int carry_ok = 0;
+        if constexpr (DEPTH + 1 < 3) carry_ok = check_next && !no_carry && i < 3 && plain_leaf(i) && plain_leaf(i + 1) && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
+        no_carry = 0;
+        if (carry_ok) { // state to come back to (a pass still pending from child i - 1 will have been joined by then); two areas by parity of i
+          GLB unsigned long long *sv = s.my_save + (i & 1) * (SAVE_BYTES / 8);
+          wsync();
+          for (int q = lane_id(); q < SAVE_WORDS; q += 64) sv[q] = ((LDS const unsigned long long *)&s)[q];
+          if (i & 1) temp_saved[1] = temp; else temp_saved[0] = temp;
+        }
+        wsync();
+        if (lane_id() == 0) s.carry_ok = carry_ok;
+        wsync();
         cabac_copy(k, &s.curr[DEPTH + 1], (i == 0) ? &s.curr[DEPTH] : &s.next[DEPTH + 1]);
         Rd sub;
         if (check_next) sub = compress_cu<DEPTH + 1>(k, sx, sy);
         else { sub.cost = MAX_DOUBLE / 16; sub.dist = 0xffffffffu >> 3; sub.bits = 0xffffffffu >> 3; }
+        if (uni(s.restart)) { // raised inside child i: the pass left pending by child i - 1 chose the split
+          wsync();
+          { GLB const unsigned long long *sv = s.my_save + ((i - 1) & 1) * (SAVE_BYTES / 8);
+            for (int q = lane_id(); q < SAVE_WORDS; q += 64) ((LDS unsigned long long *)&s)[q] = sv[q]; }
+          wsync();
+          LDS K &kk = s.k;
+          kk.sx0 = kk.sy0 = kk.sx1 = kk.sy1 = 0;
+          if (lane_id() < 3) s.ref_key[lane_id()] = -1;
+          if (lane_id() == 0) { s.fline_key = -1; s.restart = 0; s.carry = 0; s.carry_ok = 0; s.p2_pending = 0; }
+          wsync();
+          temp = ((i - 1) & 1) ? temp_saved[1] : temp_saved[0]; no_carry = 1; i -= 2;         // child i - 1 again, without leaving its pass pending
+          continue;
+        }
         temp.cost += sub.cost; temp.dist += sub.dist; temp.bits += sub.bits;
       } else if (check_next || boundary) { // initSubCU defaults copied to the picture (:989)
         const int z0 = cu.zbase + i * qn;
@@ -2661,11 +2735,11 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
   k.q_cost = s.my_qcost; k.q_rate = s.my_qrate; k.slots = s.my_slots;        // (a wave that served other masters' tasks holds their context)
-  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0;
+  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.sx0 = k.sy0 = k.sx1 = k.sy1 = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
-  if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; }
+  if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; s.carry_ok = 0; s.carry = 0; s.restart = 0; }
   wsync();
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719.
   // A per-CTU call (hevcdl_compress_ctu) resumes from the state the previous call left instead.
