@@ -1044,11 +1044,13 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
     const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
     if (lane < 16 && j <= start_pin) {
       dst[blk_j] = (int16_t)lvl_j;
+#ifndef HEVCDL_EXP_NOQ
       cost_coeff[sp_j] = cc_j; cost_sig[sp_j] = cs_j;
       sig_rate_delta[blk_j] = b1_j - b0_j;                         // 0 at the last position
       delta_u[blk_j] = (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8));
       rate_inc_up[blk_j] = (c1_j >= 0) ? ru0_j : ru_j;
       rate_inc_down[blk_j] = rd_j;
+#endif
     }
     if (cg_nonzero) cgf[cgblk] = 1;
     wsync();

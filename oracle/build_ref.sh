@@ -60,4 +60,16 @@ if [ ! $OUT/obj_anchor_TEncCu.o -nt $SRC ]; then
 fi
 g++ -o $OUT/TAppEncoder_anchor $(ls $OUT/obj/*.o | grep -v '/TEncCu.o$') $OUT/obj_anchor_TEncCu.o -lpthread \
     -Wl,--wrap=_ZN6TEncCu11compressCtuEiP10TComDataCU
+# STAGE TRACES: the encoder with HM's own two trace switches on -- DEBUG_INTRA_SEARCH_COSTS (TypeDef.h:59: cost lines of the
+# mode search, TEncSearch.cpp:2315,2395) and DEBUG_TRANSFORM_AND_QUANTISE (TypeDef.h:60: every TU block on its way through transform, quantiser,
+# dequantiser and inverse transform, TComTrQuant.cpp:1496-1658).  TypeDef.h sets both to 0 unconditionally, so the two translation units that test
+# them are piped to the compiler with an #undef/#define pair inserted behind their last #include; nothing else differs from TAppEncoder_ref.
+tr_unit() { # src macro anchor-include obj
+  [ "$4" -nt "$1" ] && return 0
+  sed -e "s|^\(#include $3\)\$|\1\n#undef $2\n#define $2 1|" "$1" | $CXX -x c++ -I"$(dirname "$1")" -c - -o "$4"
+}
+tr_unit $REF/Lib/TLibEncoder/TEncSearch.cpp DEBUG_INTRA_SEARCH_COSTS '<limits>' $OUT/obj_trace_TEncSearch.o
+tr_unit $REF/Lib/TLibCommon/TComTrQuant.cpp DEBUG_TRANSFORM_AND_QUANTISE '"Debug.h"' $OUT/obj_trace_TComTrQuant.o
+g++ -o $OUT/TAppEncoder_trace $(ls $OUT/obj/*.o | grep -v -e '/TEncSearch.o$' -e '/TComTrQuant.o$') $OUT/obj_trace_TEncSearch.o $OUT/obj_trace_TComTrQuant.o -lpthread \
+    -Wl,--wrap=_ZN6TEncCu11compressCtuEiP10TComDataCU
 echo "built: $(ls $OUT | grep -v obj | tr '\n' ' ')"

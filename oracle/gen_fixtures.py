@@ -233,6 +233,27 @@ def gen_full():
     print("full-frame fixture: %d CTUs, label histogram %s" % (nctu, np.bincount(lab.ravel(), minlength=4)))
 
 
+def gen_stage_traces():
+    """F-rd-3: HM's own stage traces (TAppEncoder_trace of oracle/build_ref.sh = the reference with DEBUG_INTRA_SEARCH_COSTS and
+    DEBUG_TRANSFORM_AND_QUANTISE on): every line of the mode search and every TU block on its way through transform / quantiser / dequantiser /
+    inverse transform, in search order.  Inputs are regenerated from their seeds; stored are the labels and the parsed events
+    (ref_tools.parse_reference_stage_trace)."""
+    cases = [("stage_a64_q32", 64, 64, 32, 11, [[1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2]]),
+             ("stage_b128_q27", 128, 64, 27, 12, [[2, 2, 3, 3, 2, 2, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0], [3, 3, 1, 1, 3, 3, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3]])]
+    saved = rt.REF_ENC
+    rt.REF_ENC = rt.STAGE_REF
+    try:
+        for name, w, h, qp, seed, labels in cases:
+            yuv = rt.synth_yuv(w, h, 1, seed)
+            lab = np.array([[rt.fixup_labels(l) for l in labels]], np.uint8)
+            dump, out, _, _ = rt.run_reference(yuv, w, h, qp, lab)
+            ev = rt.parse_reference_stage_trace(out)
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), width=w, height=h, qp=qp, seed=seed, labels=lab, **ev)
+            print(name, "events", len(ev["kind"]), "by kind", np.bincount(ev["kind"], minlength=4), "block values", ev["blk"].size)
+    finally:
+        rt.REF_ENC = saved
+
+
 def gen_bd_anchor():
     """F-rd-4: rate / PSNR points of the unpruned anchor (oracle/_ref/TAppEncoder_anchor) and of the reference as shipped (label files) on a
     small input at QP 22 / 27 / 32 / 37, with the BD figures of the reference's formulas: pins metrics.py and, on the GPU, the device path's
@@ -270,7 +291,9 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor", "stage"]
+    if "stage" in what:
+        gen_stage_traces()
     if "rd" in what:
         gen_rd()
     if "rdtiles" in what:

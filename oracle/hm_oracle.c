@@ -41,6 +41,15 @@ static uint8_t  g_scan_cg[3][4][64];                 /* ungrouped scan of the CG
 static int16_t  g_dct[4][32][32];                    /* T_N[k][n], N = 4<<i */
 static uint8_t  g_next_state[128][2];                /* ContextModel.cpp:114-127 */
 static FILE    *g_trace = NULL;
+static FILE    *g_stage = NULL;                      /* stage trace (F-rd-3): the events HM prints under DEBUG_INTRA_SEARCH_COSTS / DEBUG_TRANSFORM_AND_QUANTISE */
+
+void hm_oracle_set_stage_trace(const char *path)
+{
+  if (g_stage) { fclose(g_stage); g_stage = NULL; }
+  if (path) g_stage = fopen(path, "w");
+}
+
+static void stage_block32(const int32_t *v, int n) { for (int i = 0; i < n * n; i++) fprintf(g_stage, "%d ", v[i]); fputc('\n', g_stage); }
 
 void hm_oracle_set_trace(const char *path)
 {
@@ -1060,6 +1069,12 @@ static void enc_cu_syntax(enc_t *e, cabac_t *c, const cu_t *cu)
  * TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424
  * mode012: 0 = predict, 1 = predict and save prediction, 2 = reuse saved prediction
  * ===================================================================================== */
+static void stage_block_pel(const pel *v, int stride, int n)
+{
+  for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) fprintf(g_stage, "%d ", (int)v[j * stride + i]);
+  fputc('\n', g_stage);
+}
+
 static void code_tu_block(enc_t *e, const cu_t *cu, const tu_t *tu, int comp, int mode012, uint32_t *dist)
 {
   const int n = comp ? tu_csize(tu) : (1 << tu->log2);
@@ -1087,12 +1102,17 @@ static void code_tu_block(enc_t *e, const cu_t *cu, const tu_t *tu, int comp, in
   if (tskip) { for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) tc[j * n + i] = (int32_t)resi[j * s + i] << (13 - g_bd); }   /* transform shift 15 - bitDepth - 2 */
   else fwd_transform(resi, s, tc, n, !comp && n == 4);
   const int cbf_ctx = comp ? tu->trd : (tu->trd == 0 ? 1 : 0);
+  if (g_stage) { fprintf(g_stage, "F %d %d\n", n, comp); stage_block_pel(resi, s, n); stage_block32(tc, n); }      /* TComTrQuant.cpp:1496-1516 */
   uint32_t abs_sum = rdoq(e, &e->go, comp, n, mode, tskip, cbf_ctx, tc, coef);
+  if (g_stage) stage_block32(coef, n);                                                                               /* :1525-1528 */
   set_parts(e->r->a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu->nparts, (abs_sum > 0 ? 1 : 0) << tu->trd);
   if (abs_sum > 0) {
+    if (g_stage) { fprintf(g_stage, "I %d %d\n", n, comp); stage_block32(coef, n); }                                 /* :1603-1606 */
     dequant(e, comp, n, coef, tc);
+    if (g_stage) stage_block32(tc, n);                                                                               /* :1610-1613 */
     if (tskip) { for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) resi[j * s + i] = (pel)((tc[j * n + i] + (1 << (12 - g_bd))) >> (13 - g_bd)); }
     else inv_transform(tc, resi, s, n, !comp && n == 4);
+    if (g_stage) stage_block_pel(resi, s, n);                                                                        /* :1658-1662 */
   } else {
     memset(coef, 0, sizeof(int32_t) * n * n);
     for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) resi[j * s + i] = 0;
@@ -1247,6 +1267,7 @@ static void est_intra_luma(enc_t *e, const cu_t *cu, uint32_t *cu_dist)
       uint32_t sad = satd(org, e->W, pred, 64, pn);
       uint32_t mb = mode_bits_intra(e, cu, pu, mode);
       double cost = (double)sad + (double)mb * e->sqrt_lambda;
+      if (g_stage) fprintf(g_stage, "R %d %u %u %.17g\n", mode, sad, mb, cost);                                      /* TEncSearch.cpp:2315-2317 */
       /* xUpdateCandList :5562-5585 */
       int shift = 0;
       while (shift < nfull && cost < cost_list[nfull - 1 - shift]) shift++;
@@ -1275,6 +1296,7 @@ static void est_intra_luma(enc_t *e, const cu_t *cu, uint32_t *cu_dist)
       e->go = e->curr[cu->depth];
       uint32_t d = 0; double cost = 0.0;
       recur_luma(e, cu, &ptu, !second, &d, &cost);
+      if (g_stage && !second) fprintf(g_stage, "P %u %.17g\n", org_mode, cost);                                      /* TEncSearch.cpp:2395-2397 (printed for the first loop only) */
       if (cost < best_cost) {
         best_mode = org_mode; best_dist = d; best_cost = cost;
         set_result(e, cu, &ptu, 0);

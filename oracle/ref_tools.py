@@ -6,6 +6,7 @@ Nothing here is imported by the product package.
 """
 import ctypes
 import os
+import re
 import shutil
 import subprocess
 import tempfile
@@ -335,3 +336,86 @@ def compare(dump, recs, recon, width, height, verbose=True):
                     idx = np.argwhere(e[k] != ours)[:4].ravel().tolist()
                     print("MISMATCH frame %d ctu %d %s at %s" % (f, a, k, idx))
     return bad
+
+
+# ---- stage traces ---------------------------------------------------------------------------------------------
+# One event per line HM prints under DEBUG_INTRA_SEARCH_COSTS / DEBUG_TRANSFORM_AND_QUANTISE (oracle/build_ref.sh: TAppEncoder_trace), in the
+# order of the search.  kind 0: "1st pass" line (a = mode, b = SATD, c = mode bits, cost); 1: "2nd pass" line = one candidate of the first RD loop
+# (a = luma mode, cost); 2: a TU through transformNxN (a = size, b = component; blocks: residual, coefficients, levels); 3: a TU through
+# invTransformNxN (blocks: levels, dequantised coefficients, residual).  Costs are the 6 significant digits std::cout prints.
+STAGE_REF = os.path.join(os.path.dirname(REF_ENC), "TAppEncoder_trace")
+_RE_P1 = re.compile(r"^1st pass mode (\d+) SAD = (\d+), mode bits = (\d+), cost = (\S+)$")
+_RE_P2 = re.compile(r"^2nd pass \[luma,chroma\] mode \[(\d+),(\d+)\] cost = (\S+)$")
+_RE_TU = re.compile(r"^(\d+): (\d+)x(\d+) channel (\d+) TU (at input to transform|between transform and quantiser|at output of quantiser|"
+                    r"at input to dequantiser|between dequantiser and inverse-transform|at output of inverse-transform)$")
+_TU_STEP = {"at input to transform": (2, 0), "between transform and quantiser": (2, 1), "at output of quantiser": (2, 2),
+            "at input to dequantiser": (3, 0), "between dequantiser and inverse-transform": (3, 1), "at output of inverse-transform": (3, 2)}
+
+
+def _pack_events(ev, blocks):
+    off = np.zeros(len(ev) + 1, np.int64)
+    for i, b in enumerate(blocks):
+        off[i + 1] = off[i] + (0 if b is None else b.size)
+    return {"kind": np.array([e[0] for e in ev], np.uint8), "a": np.array([e[1] for e in ev], np.int32), "b": np.array([e[2] for e in ev], np.int64),
+            "c": np.array([e[3] for e in ev], np.int32), "cost": np.array([e[4] for e in ev], np.float64), "blk_off": off,
+            "blk": np.concatenate([b for b in blocks if b is not None] or [np.zeros(0, np.int32)]).astype(np.int32)}
+
+
+def parse_reference_stage_trace(text):
+    lines = text.splitlines()
+    ev, blocks, i = [], [], 0
+    while i < len(lines):
+        ln = lines[i]
+        m = _RE_P1.match(ln)
+        if m:
+            ev.append((0, int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)))); blocks.append(None); i += 1; continue
+        m = _RE_P2.match(ln)
+        if m:
+            ev.append((1, int(m.group(1)), int(m.group(2)), 0, float(m.group(3)))); blocks.append(None); i += 1; continue
+        m = _RE_TU.match(ln)
+        if m:
+            n, comp = int(m.group(2)), int(m.group(4))
+            kind, step = _TU_STEP[m.group(5)]
+            vals = np.array([int(v) for r in lines[i + 1:i + 1 + n] for v in r.split()], np.int32)
+            assert vals.size == n * n, (ln, vals.size)
+            if step == 0:
+                ev.append((kind, n, comp, 0, 0.0)); blocks.append(vals)
+            else:
+                assert ev[-1][:3] == (kind, n, comp), (ln, ev[-1])
+                blocks[-1] = np.concatenate([blocks[-1], vals])
+            i += 1 + n; continue
+        i += 1
+    return _pack_events(ev, blocks)
+
+
+def parse_oracle_stage_trace(path):
+    ev, blocks = [], []
+    with open(path) as fh:
+        lines = fh.read().splitlines()
+    i = 0
+    while i < len(lines):
+        t = lines[i].split()
+        if t[0] == "R":
+            ev.append((0, int(t[1]), int(t[2]), int(t[3]), float("%g" % float(t[4])))); blocks.append(None); i += 1
+        elif t[0] == "P":
+            ev.append((1, int(t[1]), 0, 0, float("%g" % float(t[2])))); blocks.append(None); i += 1
+        else:
+            ev.append((2 if t[0] == "F" else 3, int(t[1]), int(t[2]), 0, 0.0))
+            blocks.append(np.array(" ".join(lines[i + 1:i + 4]).split(), np.int64).astype(np.int32)); i += 4
+    return _pack_events(ev, blocks)
+
+
+def run_oracle_stage_trace(yuv, width, height, qp, labels):
+    """The oracle's own events for the same input (records / reconstruction are returned as by run_oracle)."""
+    lib = oracle_lib()
+    lib.hm_oracle_set_stage_trace.argtypes = [ctypes.c_char_p]
+    fd, path = tempfile.mkstemp(prefix="hm_stage_", suffix=".txt")
+    os.close(fd)
+    try:
+        lib.hm_oracle_set_stage_trace(path.encode())
+        out = run_oracle(yuv, width, height, qp, labels)
+        lib.hm_oracle_set_stage_trace(None)
+        return parse_oracle_stage_trace(path), out
+    finally:
+        lib.hm_oracle_set_stage_trace(None)
+        os.remove(path)

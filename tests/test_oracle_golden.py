@@ -49,6 +49,29 @@ def test_rd_oracle_matches_reference_on_a_whole_1080p_frame(oracle_built):
     assert np.array_equal(full_frame_crc(recon[0], w, h, recs.shape[1]), f["recon_crc32"])
 
 
+@pytest.mark.parametrize("name", ["stage_a64_q32", "stage_b128_q27"])
+def test_rd_oracle_stages_match_reference_traces(oracle_built, name):
+    """F-rd-3: HM's own stage traces -- the reference built with DEBUG_INTRA_SEARCH_COSTS and DEBUG_TRANSFORM_AND_QUANTISE
+    (TypeDef.h:59-60; oracle/build_ref.sh TAppEncoder_trace, oracle/gen_fixtures.py gen_stage_traces).  The oracle walks the search in the same
+    order, so every event has to agree in sequence: the 35 rough-mode lines per PU (SATD, mode bits, cost), the cost of every candidate of the
+    first RD loop, and every TU block at the six points of transformNxN / invTransformNxN (residual, coefficients, levels after RDOQ; levels,
+    dequantised coefficients, reconstructed residual).  Costs carry the 6 significant digits the reference prints."""
+    import ref_tools
+    f = np.load(os.path.join(GOLD, name + ".npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    yuv = ref_tools.synth_yuv(w, h, 1, int(f["seed"]))
+    ev, _ = ref_tools.run_oracle_stage_trace(yuv, w, h, qp, f["labels"])
+    kind = f["kind"]
+    assert np.bincount(kind, minlength=4).min() > 500                      # all four kinds of event are there in numbers
+    assert np.array_equal(ev["kind"], kind)
+    assert np.array_equal(ev["a"], f["a"]) and np.array_equal(ev["c"], f["c"])
+    assert np.array_equal(ev["b"][kind != 1], f["b"][kind != 1])           # (the chroma mode printed with a candidate line is not an output of the search)
+    assert np.array_equal(ev["cost"], f["cost"])
+    assert np.array_equal(ev["blk_off"], f["blk_off"]) and np.array_equal(ev["blk"], f["blk"])
+    sizes = set(f["a"][kind == 2].tolist())
+    assert {4, 8, 16}.issubset(sizes) and set(f["b"][kind == 2].tolist()) == {0, 1, 2}
+
+
 def test_fixtures_cover_the_decision_space():
     """depths 0..3, both partition sizes, transform skip, split transforms and boundary CTUs all occur in the golden set."""
     seen_depth, seen_part, ts, tr, outside = set(), set(), 0, 0, 0
