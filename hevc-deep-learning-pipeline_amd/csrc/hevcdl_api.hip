@@ -291,6 +291,22 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   return HEVCDL_OK;
 }
 
+#ifdef HEVCDL_STAGE_TRACE
+static unsigned int *g_stage_log = nullptr;
+static const size_t STAGE_LOG_WORDS = (12u << 20) + 8;       // rd_kernel.hip STAGE_CAP + header
+// words of the log of the last launch (header excluded), copied to dst up to cap_words; returns the number of words the kernel wanted to write
+extern "C" size_t hevcdl_stage_trace_fetch(unsigned int *dst, size_t cap_words)
+{
+  if (!g_stage_log) return 0;
+  unsigned int used = 0;
+  hipDeviceSynchronize();
+  hipMemcpy(&used, g_stage_log, 4, hipMemcpyDeviceToHost);
+  size_t n = used; if (n > (size_t)(12u << 20)) n = (size_t)(12u << 20); if (n > cap_words) n = cap_words;
+  if (n) hipMemcpy(dst, g_stage_log + 2, n * 4, hipMemcpyDeviceToHost);
+  return used;
+}
+#endif
+
 static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s,
                                int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr,
                                int tile_begin = 0, int tile_count = -1)
@@ -309,6 +325,11 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
   p.k.sbh_rd_factor[0] = ctx->cfg.sbh_rd_factor[0]; p.k.sbh_rd_factor[1] = ctx->cfg.sbh_rd_factor[1];
   p.k.qp = ctx->cfg.qp; p.k.qp_chroma = ctx->cfg.qp_chroma;
+#ifdef HEVCDL_STAGE_TRACE
+  // stage-trace build (tests/test_rd_gpu.py, lib/libhevcdl_hip_trace.so): the kernel logs its search events here; hevcdl_stage_trace_fetch reads them
+  if (!g_stage_log) HIPCHK(hipMalloc(&g_stage_log, STAGE_LOG_WORDS * 4));
+  HIPCHK(hipMemsetAsync(g_stage_log, 0, 8, s)); p.dbgbuf = g_stage_log;
+#endif
 #if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)
   unsigned int *d_dbg = nullptr;               // instrumented builds only (tools/phase_profile.py): in-kernel timers / traces come back through this buffer
   HIPCHK(hipMalloc(&d_dbg, 8004 * 4)); HIPCHK(hipMemset(d_dbg, 0, 8004 * 4)); p.dbgbuf = d_dbg;

@@ -365,6 +365,30 @@ DEV void cabac_copy(KR k, LCabac *dst, const LCabac *src)
   wsync();
   PROF_ADD(k, 12);
 }
+#ifdef HEVCDL_STAGE_TRACE
+// Stage-trace build (tests only, lib/libhevcdl_hip_trace.so): the events HM prints under DEBUG_INTRA_SEARCH_COSTS / DEBUG_TRANSFORM_AND_QUANTISE
+// (TypeDef.h:59-60) go to a log in HBM, a record per event: 6 header words {kind, a, b, c, cost lo, cost hi} and, for TU events, three blocks of
+// a * a values.  dbgbuf[0] = words used, the log starts at dbgbuf[2].  Waves log concurrently: the order of the records means nothing.
+constexpr unsigned STAGE_CAP = 12u << 20;
+DEVN GLB unsigned *stage_alloc(KR k, int words_)
+{
+  const int words = uni(words_);
+  unsigned off = 0;
+  if (lane_id() == 0) off = __hip_atomic_fetch_add(k.dbgbuf, (unsigned)words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  off = (unsigned)uni((int)off);
+  return off + (unsigned)words <= STAGE_CAP ? k.dbgbuf + 2 + off : nullptr;
+}
+DEV void stage_line(KR k, int kind, int a, unsigned b, unsigned c, double cost, bool on)
+{ // one record per enabled lane
+  if (on) {
+    const unsigned off = __hip_atomic_fetch_add(k.dbgbuf, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (off + 6u <= STAGE_CAP) {
+      GLB unsigned *t = k.dbgbuf + 2 + off; const unsigned long long cb = (unsigned long long)__double_as_longlong(cost);
+      t[0] = (unsigned)kind; t[1] = (unsigned)a; t[2] = b; t[3] = c; t[4] = (unsigned)cb; t[5] = (unsigned)(cb >> 32);
+    }
+  }
+}
+#endif
 DEV double calc_rd_cost(KR k, uint32_t bits, uint32_t dist)
 { // TComRdCost.cpp:62-107
 #ifdef HEVCDL_KERNEL_DEBUG
@@ -1044,13 +1068,11 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
     const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
     if (lane < 16 && j <= start_pin) {
       dst[blk_j] = (int16_t)lvl_j;
-#ifndef HEVCDL_EXP_NOQ
       cost_coeff[sp_j] = cc_j; cost_sig[sp_j] = cs_j;
       sig_rate_delta[blk_j] = b1_j - b0_j;                         // 0 at the last position
       delta_u[blk_j] = (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8));
       rate_inc_up[blk_j] = (c1_j >= 0) ? ru0_j : ru_j;
       rate_inc_down[blk_j] = rd_j;
-#endif
     }
     if (cg_nonzero) cgf[cgblk] = 1;
     wsync();
@@ -1610,21 +1632,49 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
   wsync();
   PROF_MARK(25);
+#ifdef HEVCDL_STAGE_TRACE
+  GLB unsigned *tr = stage_alloc(k, 6 + 3 * n * n);                 // transformNxN: residual, coefficients (TComTrQuant.cpp:1496-1516)
+  if (tr) {
+    if (lane_id() < 6) tr[lane_id()] = lane_id() == 0 ? 2u : (lane_id() == 1 ? (unsigned)n : (lane_id() == 2 ? (unsigned)comp : 0u));
+    for (int i = lane_id(); i < n * n; i += 64) tr[6 + i] = (unsigned)(int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))];
+  }
+  wsync();
+#endif
   if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.tc[i] = (int16_t)((int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] << (13 - BD)); wsync(); }   // n == 4: one pass, every lane reads before any writes
   else fwd_transform(k, n, !comp && n == 4);
   PROF_MARK(26);
   const int cbf_ctx = comp ? tu.trd : (tu.trd == 0 ? 1 : 0);
+#ifdef HEVCDL_STAGE_TRACE
+  if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + n * n + i] = (unsigned)(int)s.tc[i];
+#endif
   { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
   wsync();
   PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
+#ifdef HEVCDL_STAGE_TRACE
+  if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + 2 * n * n + i] = abs_sum > 0 ? (unsigned)(int)s.lvl[i] : 0u;      // levels behind the quantiser (:1525-1528)
+  GLB unsigned *ti = abs_sum > 0 ? stage_alloc(k, 6 + 3 * n * n) : nullptr;                                                    // invTransformNxN (:1603-1662)
+  if (ti) {
+    if (lane_id() < 6) ti[lane_id()] = lane_id() == 0 ? 3u : (lane_id() == 1 ? (unsigned)n : (lane_id() == 2 ? (unsigned)comp : 0u));
+    for (int i = lane_id(); i < n * n; i += 64) ti[6 + i] = (unsigned)(int)s.lvl[i];
+  }
+#endif
   set_parts(k, s.a[A_CBF + comp], zabs, comp ? tu_cnparts(tu) : tu.nparts, (abs_sum > 0 ? 1 : 0) << tu.trd);
   GLB int16_t *cl = k.coef_l + lay_coef(k, tu.log2, comp, zabs);
   if (abs_sum > 0) {
     for (int i = lane_id(); i < n * n; i += 64) cl[i] = s.lvl[i];
     dequant(k, comp, n);
+#ifdef HEVCDL_STAGE_TRACE
+    wsync();
+    if (ti) for (int i = lane_id(); i < n * n; i += 64) ti[6 + n * n + i] = (unsigned)(int)s.tc[i];
+    wsync();
+#endif
     if (tskip) { for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((s.tc[i] + (1 << (12 - BD))) >> (13 - BD)); wsync(); }
     else inv_transform(k, n, !comp && n == 4);
+#ifdef HEVCDL_STAGE_TRACE
+    wsync();
+    if (ti) for (int i = lane_id(); i < n * n; i += 64) ti[6 + 2 * n * n + i] = (unsigned)(int)s.resi[(i >> log2n) * RS(n) + (i & (n - 1))];
+#endif
   } else {
     for (int i = lane_id(); i < n * n; i += 64) { cl[i] = 0; s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = 0; }
     wsync();
@@ -2070,6 +2120,13 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
         s.rmd_cost[mode] = (double)(s.satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
       }
+#ifdef HEVCDL_STAGE_TRACE
+      {  // "1st pass mode" lines, TEncSearch.cpp:2315-2317
+        const bool on = lane_id() < 35; const int mode = on ? lane_id() : 0; int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
+        const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
+        stage_line(k, 0, mode, s.satd[mode] >> HAD_SH, (unsigned)(fr >> 15), (double)(s.satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda, on);
+      }
+#endif
       wsync();
       // xUpdateCandList :5562-5585 == stable sort by (cost, mode); keep the nfull best
       if (lane_id() < 35) {
@@ -2110,6 +2167,9 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           return 0;
         }
       }
+#ifdef HEVCDL_STAGE_TRACE
+      { const bool on = lane_id() < nfull; stage_line(k, 1, on ? r.modes[lane_id()] : 0, 0u, 0u, on ? r.cost[lane_id()] : 0.0, on); }   // "2nd pass" lines, :2395-2397
+#endif
       // the serial loop keeps a candidate when its cost is strictly smaller: the winner is the smallest cost, first in list order
       int win = -1;
       for (int m = 0; m < nfull; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
