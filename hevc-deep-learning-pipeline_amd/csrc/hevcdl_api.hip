@@ -68,7 +68,7 @@ struct hevcdl_ctx {
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
-  unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params;   // SAO workspace
+  unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params, *d_sao_cand;   // SAO workspace
   int *d_flag;                   // device-side error flag of the label check
   unsigned char *d_sched;        // decision kernel: hand-over of units between workgroups (finished counter, per-workgroup unit counts, mailboxes)
   bool profile;
@@ -182,7 +182,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = ctx->d_sao_cand = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -224,7 +224,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_sao_cand); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
   delete ctx;
 }
 
@@ -539,9 +539,10 @@ extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_or
   const size_t nf = (size_t)ctx->cfg.max_frames;
   if (!ctx->d_sao_stats) HIPCHK(hipMalloc(&ctx->d_sao_stats, (size_t)ctx->ctus * 3 * 5 * 256 * nf));
   if (!ctx->d_sao_recon) HIPCHK(hipMalloc(&ctx->d_sao_recon, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * nf));
+  if (!ctx->d_sao_cand) HIPCHK(hipMalloc(&ctx->d_sao_cand, (size_t)ctx->ctus * 3 * 5 * 48 * nf));
   hevcdl_sao_params p;
   p.org = (const uint8_t *)d_org; p.deblocked = (const uint8_t *)d_deblocked; p.out = (uint8_t *)d_out;
-  p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon;
+  p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon; p.cand = ctx->d_sao_cand;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames; p.qp = ctx->cfg.qp;
   p.lambda = ctx->cfg.lambda; p.lambda_chroma = ctx->cfg.lambda_chroma;          // slice lambdas per component, TEncSlice.cpp:112-140
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows; p.bit_depth = ctx->cfg.bit_depth; p.lf_across_tiles = ctx->cfg.lf_across_tiles != 0;

@@ -993,9 +993,6 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
     // Only positions whose rounded level is nonzero touch the c1/c2/Rice state (TComTrQuant.cpp:2300-2380): walk those,
     // highest scan position first.  c1 is 1 at the start of every group; zero positions below a visited one see its c1.
     unsigned nzmask = (unsigned)(__ballot(valid_j && ma_j > 0) & 0xffffull);
-#ifdef HEVCDL_KERNEL_PROF
-    if (lane == 0) { s.prof_n[31]++; if (!nzmask) { s.prof_n[32]++; if (s.prof[33]) s.prof_n[33]++; } s.prof[33] = !nzmask && cgpos != cg_last; }
-#endif
     while (nzmask) {
       const int pin = 31 - __clz((int)nzmask);
       nzmask &= ~(1u << pin);
@@ -1725,7 +1722,7 @@ DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_)
 DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
 DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
-DEV void region_wait(LRegion &r, int n) { while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2); wg_acquire(); }
+DEV void region_wait(LRegion &r, int n) { PROF_T0(); while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2); wg_acquire(); PROF_ADD(0, 33); }
 DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()]; wsync(); }
 DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
 struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
@@ -2456,7 +2453,7 @@ DEVN void region_run(KR k, LRegion &r)
     wg_release();
     lds_add(&r.done, 1);
   }
-  while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2);
+  { PROF_T0(); while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2); PROF_ADD(k, 32); }
   wg_acquire();
 }
 // waves without a unit (or done with theirs) serve the regions of the workgroup's masters until the last master has finished
@@ -2960,7 +2957,9 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   int unit = first < n_units ? first : -1, i_resume = -1;
   for (;;) {
     if (unit >= 0) {
+      PROF_T0();
       const int moved = process_unit(p, unit, i_resume);
+      PROF_ADD(0, 31);
       int next = -1;
       if (!moved) {
         if (p.migrate) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); glb_add(sched_count(p, (int)blockIdx.x), -1); glb_add(sched_finished(p), 1); }
@@ -2980,7 +2979,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
         continue;
       }
     } else if (lds_load(&sh.masters_active) <= 0) break;
-    if (!helper_step()) __builtin_amdgcn_s_sleep(32);
+    { PROF_T0(); if (!helper_step()) { __builtin_amdgcn_s_sleep(32); PROF_ADD(0, 23); } }
   }
 #ifdef HEVCDL_KERNEL_PROF
   // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)

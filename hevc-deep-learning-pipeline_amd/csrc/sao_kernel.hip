@@ -316,6 +316,23 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats16_kernel(hevcdl_sao_para
   for (int i = tid; i < NTYPES * 64; i += 256) { const int t = i >> 6, r = i & 63; if (r < 32) dst[t].diff[r] = acc[t][0][r]; else dst[t].count[r - 32] = acc[t][1][r - 32]; }
 }
 
+// Candidate offsets of every (picture, CTU, component, type): deriveOffsets + getDistortion depend on the statistics and lambda only -- not on the
+// coder state or the neighbours' decisions that chain the CTUs of a picture -- so they run ahead of the chain, one thread each.
+struct Cand { int8_t off[32]; int32_t aux, pad; long long dist; };      // 48 bytes, same order as the statistics
+__global__ __launch_bounds__(256) void hevcdl_sao_offsets_kernel(hevcdl_sao_params p)
+{
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)p.n_frames * p.ctus_per_frame * 3 * NTYPES;
+  if (idx >= total) return;
+  const int type = (int)(idx % NTYPES), comp = (int)((idx / NTYPES) % 3);
+  const Bd bd = { (1 << ((p.bit_depth < 10 ? p.bit_depth : 10) - 5)) - 1, 2 * (p.bit_depth - 8), p.bit_depth - 8 };
+  const Stat GLB &st = ((const Stat GLB *)p.stats)[idx];
+  int32_t q[32], aux;
+  derive_offsets(type, comp ? p.lambda_chroma : p.lambda, st, q, aux, bd);
+  Cand GLB &c = ((Cand GLB *)p.cand)[idx];
+  for (int i = 0; i < 32; i++) c.off[i] = (int8_t)q[i];
+  c.aux = aux; c.pad = 0; c.dist = get_dist(type, aux, q, st, bd);
+}
+
 // one lane per picture: the CTU chain of decideBlkParams
 __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params p)
 {
@@ -341,6 +358,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
   next = go;
   for (int a = 0; a < nctu; a++) {
     const Stat GLB *st = stats + (size_t)a * 3 * NTYPES;
+    const Cand GLB *cand = (const Cand GLB *)p.cand + ((size_t)frame * nctu + a) * 3 * NTYPES;      // hevcdl_sao_offsets_kernel
     // merge candidates come from the same tile only (TComPic::getSAOMergeAvailability)
     bool left_av = true, above_av = true;
     for (int t = 0; t < p.tile_cols; t++) if (p.col_bd[t] == a % cx) left_av = false;
@@ -358,8 +376,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
       temp = go;
       for (int type = 0; type < NTYPES; type++) {
         test[0].mode = MODE_NEW; test[0].type = type;
-        derive_offsets(type, lambda[0], st[0 * NTYPES + type], test[0].offset, test[0].aux, bd);
-        dist[0] = get_dist(type, test[0].aux, test[0].offset, st[0 * NTYPES + type], bd);
+        { const Cand GLB &cd = cand[0 * NTYPES + type]; for (int i = 0; i < 32; i++) test[0].offset[i] = cd.off[i]; test[0].aux = cd.aux; dist[0] = cd.dist; }
         go = mid; sb_reset(go); code_offset_param(go, 0, test[0], bd);
         cost = (double)dist[0] + lambda[0] * (double)(int)sb_bits(go);
         if (cost < mc) { mc = cost; mode_dist[0] = dist[0]; mode.c[0] = test[0]; temp = go; }
@@ -373,8 +390,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
         go = mid; sb_reset(go); cost = 0;
         for (int c = 1; c < 3; c++) {
           test[c].mode = MODE_NEW; test[c].type = type;
-          derive_offsets(type, lambda[c], st[c * NTYPES + type], test[c].offset, test[c].aux, bd);
-          dist[c] = get_dist(type, test[c].aux, test[c].offset, st[c * NTYPES + type], bd);
+          { const Cand GLB &cd = cand[c * NTYPES + type]; for (int i = 0; i < 32; i++) test[c].offset[i] = cd.off[i]; test[c].aux = cd.aux; dist[c] = cd.dist; }
           code_offset_param(go, c, test[c], bd);
           const uint32_t b = sb_bits(go);
           cost += (double)dist[c] + (lambda[c] * (double)(b - prev));
@@ -447,6 +463,8 @@ extern "C" void hevcdl_launch_sao(const hevcdl_sao_params *pp, void *stream)
   const dim3 per_ctu(p.ctus_per_frame, 3, p.n_frames);
   if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_stats_kernel, per_ctu, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(hevcdl_sao_stats16_kernel, per_ctu, dim3(256), 0, s, p);
+  const size_t n_cand = (size_t)p.n_frames * p.ctus_per_frame * 3 * NTYPES;
+  hipLaunchKernelGGL(hevcdl_sao_offsets_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(hevcdl_sao_decide_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
   if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint8_t>, per_ctu, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint16_t>, per_ctu, dim3(256), 0, s, p);

@@ -19,7 +19,7 @@ def main():
     nf = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     w, h = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "3840x2160").split("x"))
     d = tempfile.mkdtemp(prefix="hevcdl_e2e_")
-    yuv = bench.synth_frames_torch(torch, torch.device("cuda", 0), w, h, nf, seed=4000).cpu().numpy()
+    yuv = bench.synth_frames_torch(torch, torch.device("cuda", 0), w, h, list(range(nf)), seed=4000).cpu().numpy()
     yuv.tofile(os.path.join(d, "in.yuv"))
     del yuv
     for tiles in ((1, 1), (4, 2)):
