@@ -180,7 +180,8 @@ struct __attribute__((aligned(16))) RdSmem {
   // residual (row stride n+2: conflict-free column access) and transform / dequantised coefficients (raster) share
   // storage: the residual is dead once the forward transform has consumed it and is rebuilt by the inverse transform.
   // Every value fits 16 bits (HEVC transform dynamic range; the reference clips the inverse stages explicitly).
-  union { int16_t resi[32 * 34]; int16_t tc[1024]; };
+  // For TUs up to 8x8 (95 % of all codings) the part behind the coefficients also holds RDOQ's per-position outputs (rdoq_lane0).
+  union __attribute__((aligned(16))) { int16_t resi[32 * 34]; int16_t tc[1024]; };
   // quantised levels of the current TU (raster); the transform intermediate (row stride n+1) lives behind the first 16
   // entries, i.e. a 4x4 block of levels survives the inverse transform (transform-skip bookkeeping needs it)
   int16_t lvl[16 + 32 * 33];
@@ -868,8 +869,18 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
   CParam cp; get_cparam(cp, c, n, dir_mode);
   const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   LDS const int16_t *src = s.tc; LDS int16_t *dst = s.lvl;
-  GLB double *cost_coeff = k.q_cost, *cost_sig = k.q_cost + 1024;
-  GLB int32_t *rate_inc_up = k.q_rate, *rate_inc_down = k.q_rate + 1024, *sig_rate_delta = k.q_rate + 2048, *delta_u = k.q_rate + 3072;
+  // Per-position outputs read again by the last-position search and by sign hiding: coded cost and significance cost by scan position, the
+  // four rate / error terms of sign hiding by raster position -- 32 bytes per position.  Up to 8x8 they fit behind the coefficients in LDS
+  // (the residual that shares that storage is dead until the inverse transform): 128 + 64 * 32 = 2176 bytes; larger TUs use the wave's HBM
+  // workspace.
+  const bool qlds = n <= 8;
+  GLB double *gq_cost = k.q_cost; GLB int32_t *gq_rate = k.q_rate;
+  LDS double *lq_cost = (LDS double *)((LDS char *)s.tc + 2 * ncoef); LDS int32_t *lq_rate = (LDS int32_t *)(lq_cost + 2 * ncoef);
+  enum { Q_COEFF = 0, Q_SIG = 1, Q_UP = 0, Q_DOWN = 1, Q_SIGDELTA = 2, Q_DELTAU = 3 };
+  auto q_cost_st = [&](int a, int i, double v) { if (qlds) lq_cost[a * ncoef + i] = v; else gq_cost[a * 1024 + i] = v; };
+  auto q_cost_ld = [&](int a, int i) -> double { double v; if (qlds) v = lq_cost[a * ncoef + i]; else v = gq_cost[a * 1024 + i]; return v; };
+  auto q_rate_st = [&](int a, int i, int32_t v) { if (qlds) lq_rate[a * ncoef + i] = v; else gq_rate[a * 1024 + i] = v; };
+  auto q_rate_ld = [&](int a, int i) -> int32_t { int32_t v; if (qlds) v = lq_rate[a * ncoef + i]; else v = gq_rate[a * 1024 + i]; return v; };
   LDS double *cost_cg_sig = s.cg_cost; LDS uint8_t *cgf = s.cgf;
   auto level_double = [&](int blk) -> int32_t {
     const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
@@ -1065,11 +1076,11 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
     const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
     if (lane < 16 && j <= start_pin) {
       dst[blk_j] = (int16_t)lvl_j;
-      cost_coeff[sp_j] = cc_j; cost_sig[sp_j] = cs_j;
-      sig_rate_delta[blk_j] = b1_j - b0_j;                         // 0 at the last position
-      delta_u[blk_j] = (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8));
-      rate_inc_up[blk_j] = (c1_j >= 0) ? ru0_j : ru_j;
-      rate_inc_down[blk_j] = rd_j;
+      q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j);
+      q_rate_st(Q_SIGDELTA, blk_j, b1_j - b0_j);                   // 0 at the last position
+      q_rate_st(Q_DELTAU, blk_j, (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8)));
+      q_rate_st(Q_UP, blk_j, (c1_j >= 0) ? ru0_j : ru_j);
+      q_rate_st(Q_DOWN, blk_j, rd_j);
     }
     if (cg_nonzero) cgf[cgblk] = 1;
     wsync();
@@ -1089,7 +1100,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
         zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
         if (zero_cost < base_cost) {
           base_cost = zero_cost; cgc = r0;
-          if (lane < 16 && lvl_j) { dst[blk_j] = 0; cost_coeff[sp_j] = c0_j; cost_sig[sp_j] = 0; }
+          if (lane < 16 && lvl_j) { dst[blk_j] = 0; q_cost_st(Q_COEFF, sp_j, c0_j); q_cost_st(Q_SIG, sp_j, 0.0); }
           if (lane == 0) cgf[cgblk] = 0;
         }
         if (lane == 0) cost_cg_sig[cgpos] = cgc;
@@ -1134,7 +1145,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
       if (!uni(cgf[cgblk])) continue;
       const int j = lane & 15, sp_j = cgpos * 16 + j, blk_j = scan[sp_j];
       const int lv_j = dst[blk_j];
-      const double cc_j = cost_coeff[sp_j], cs_j = cost_sig[sp_j], c0_j = cost0_of(blk_j);
+      const double cc_j = q_cost_ld(Q_COEFF, sp_j), cs_j = q_cost_ld(Q_SIG, sp_j), c0_j = cost0_of(blk_j);
       int py = blk_j >> log2n, px = blk_j - (py << log2n);
       if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
       const int gx2 = tb().t_group_idx[px], gy2 = tb().t_group_idx[py];
@@ -1205,14 +1216,15 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
           long long cur_cost = I64MAX; int cur_change = 0;
           const int nmax = (last_cg == 1) ? last_nz : 15;
           if (j <= nmax) {
+            const int32_t du_j = q_rate_ld(Q_DELTAU, blk_j), riu_j = q_rate_ld(Q_UP, blk_j), rid_j = q_rate_ld(Q_DOWN, blk_j), srd_j = q_rate_ld(Q_SIGDELTA, blk_j);
             if (lv_j != 0) {
-              const long long up = rd_factor * (-(long long)delta_u[blk_j]) + rate_inc_up[blk_j];
-              long long down = rd_factor * ((long long)delta_u[blk_j]) + rate_inc_down[blk_j] - ((abs(lv_j) == 1) ? sig_rate_delta[blk_j] : 0);
+              const long long up = rd_factor * (-(long long)du_j) + riu_j;
+              long long down = rd_factor * ((long long)du_j) + rid_j - ((abs(lv_j) == 1) ? srd_j : 0);
               if (last_cg == 1 && last_nz == j && abs(lv_j) == 1) down -= (4 << 15);
               if (up < down) { cur_cost = up; cur_change = 1; }
               else { cur_change = -1; cur_cost = (j == first_nz && abs(lv_j) == 1) ? I64MAX : down; }
             } else {
-              cur_cost = rd_factor * (-(long long)abs(delta_u[blk_j])) + (1 << 15) + rate_inc_up[blk_j] + sig_rate_delta[blk_j];
+              cur_cost = rd_factor * (-(long long)abs(du_j)) + (1 << 15) + riu_j + srd_j;
               cur_change = 1;
               if (j < first_nz) { const uint32_t ts = src[blk_j] >= 0 ? 0 : 1; if (ts != signbit) cur_cost = I64MAX; }
             }
