@@ -91,7 +91,7 @@ class Profile(ctypes.Structure):
     _fields_ = [("cnn_ms", ctypes.c_double), ("rd_ms", ctypes.c_double), ("cnn_launches", ctypes.c_uint32), ("rd_launches", ctypes.c_uint32)]
 
 
-def build_ext(force=False, verbose=False, defines=(), out=None):
+def build_ext(force=False, verbose=False, defines=(), out=None, extra_flags=()):
     """Compile every HIP source for gfx950 into lib/libhevcdl_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(PKG_DIR, "csrc", s) for s in SOURCES]
     deps = srcs + [os.path.join(PKG_DIR, "csrc", "hevcdl_dev.h"), os.path.join(ROOT, "include", "hevcdl.h")]
@@ -102,7 +102,7 @@ def build_ext(force=False, verbose=False, defines=(), out=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-unused-value",
            "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + ["-D" + d for d in defines] + srcs + ["-o", out]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + ["-D" + d for d in defines] + list(extra_flags) + srcs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -197,7 +197,7 @@ struct __attribute__((aligned(16))) RdSmem {
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
-  unsigned long long prof[40]; unsigned int prof_n[40];
+  unsigned long long prof[HEVCDL_BD == 8 ? 56 : 40]; unsigned int prof_n[HEVCDL_BD == 8 ? 56 : 40]; int prof_task, prof_pad;     // (the 10-bit build has no LDS to spare: its profiling build keeps the first 40 timers)
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   union {
@@ -230,11 +230,15 @@ DEV void wsync()
 #define PROF_MARK0() unsigned long long prof_m_ = __builtin_readcyclecounter()
 #define PROF_MARK(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); lds().prof[id] += n_ - prof_m_; lds().prof_n[id]++; prof_m_ = n_; } else prof_m_ = 0; } while (0)
 #define PROF_ADD(k, id) do { if (lane_id() == 0) { lds().prof[id] += __builtin_readcyclecounter() - prof_t0_; lds().prof_n[id]++; } } while (0)
+#define PROF_ADD_T(k, id, tid) do { if (lane_id() == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - prof_t0_; lds().prof[id] += d_; lds().prof_n[id]++; if (HEVCDL_BD == 8 && lds().prof_task) { lds().prof[tid] += d_; lds().prof_n[tid]++; } } } while (0)
+#define PROF_TASK(v) do { if (lane_id() == 0) lds().prof_task = (v); } while (0)
 #else
 #define PROF_T0() do { } while (0)
 #define PROF_MARK0() do { } while (0)
 #define PROF_MARK(id) do { } while (0)
 #define PROF_ADD(k, id) do { } while (0)
+#define PROF_ADD_T(k, id, tid) do { } while (0)
+#define PROF_TASK(v) do { } while (0)
 #endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // -DHEVCDL_DBG_EXEC: trap (s99 = site) when a function that needs the whole wave is entered with lanes masked off; run under rocgdb
@@ -1542,7 +1546,7 @@ template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_
   if (luma && lane_id() == 0) lds().cfrac_last = c->frac - f0_;
   if (chroma) { enc_coeff_qt<LOG2>(k, c, cu, tu, 1, 0); enc_coeff_qt<LOG2>(k, c, cu, tu, 2, 0); }
   wsync();
-  PROF_ADD(k, 10);
+  PROF_ADD_T(k, 10, 49);
   return uni((int)get_bits(c));
 }
 DEV unsigned long long uni64(unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); }
@@ -1568,7 +1572,7 @@ template <int LOG2> DEVN uint32_t split_bits(KR k, const Cu cu_, const Tu tu_, L
   for (int i = CTX_SIG_CG + lane_id(); i < NUM_CTX; i += 64) c->ctx[i] = s.spl.ctx[i];
   if (lane_id() == 0) c->frac += cfrac;
   wsync();
-  PROF_ADD(k, 10);
+  PROF_ADD_T(k, 10, 49);
   return uni((int)get_bits(c));
 }
 template <int LOG2> DEV void enc_transform(KR k, LCabac *c, const Cu &cu, const Tu &tu)
@@ -1705,7 +1709,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   if (comp) d = (uint32_t)(k.cweight * (double)d);            // getDistPart TComRdCost.cpp:350-353
   wsync();
   PROF_MARK(29);
-  PROF_ADD(k, 9);
+  PROF_ADD_T(k, 9, 48);
   return d;
 }
 
@@ -2353,12 +2357,14 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
 { // LEAF: the instance a chain owner uses for its own split tasks (spec_children): every kind but the second-pass task, no nested regions
   CHECK_EXEC(3);
   const int idx = uni(idx_);
+  PROF_T0();
   LSmem &s = lds(); LDS K &kk = s.k; KR k = s.k;
   LSmem &ow = lds_of(uni(r.owner));
   const Cu cu = { uni(r.cu[0]), uni(r.cu[1]), uni(r.cu[2]), uni(r.cu[3]), uni(r.cu[4]), uni(r.cu[5]), uni(r.cu[6]) };
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
   const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
+  PROF_TASK(kind != T_LUMA_P2);
   const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
@@ -2440,6 +2446,10 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   kk.lz = olz; kk.lx = olx; kk.ly = oly;
   wsync();
+  PROF_TASK(0);
+#ifdef HEVCDL_KERNEL_PROF
+  if (HEVCDL_BD == 8) { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
+#endif
 }
 
 // claim a task of region r: its index, or -1.  Compare-and-swap, not a blind add: the count grows while a region is open (region_publish),
@@ -2860,6 +2870,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     const int cx = cx0 + i % tw, cy = cy0 + i / tw, a = cy * p.ctus_x + cx;
     wsync();
+    PROF_MARK0();
     k.addr = a; k.cx = cx; k.cy = cy;
     // initCtu TComDataCU.cpp:420-500
     for (int i = lane; i < 256; i += 64) {
@@ -2872,13 +2883,16 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
+    PROF_MARK(HEVCDL_BD == 8 ? 47 : 39);
     const Rd best = compress_cu<0>(k, cx * 64, cy * 64);
+    PROF_MARK(HEVCDL_BD == 8 ? 45 : 39);
     // the state-advancing encode (TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
     wsync();
     if (lane == 0) reset_bits(truec);
     encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
     wsync();
     if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)tb().t_ebits[126]; s.est_bits += truec->frac >> 15; }
+    PROF_MARK(HEVCDL_BD == 8 ? 46 : 39);
     // flush the CTU record
     GLB unsigned char *rec = records + (size_t)a * REC_SIZE;
     for (int i = lane; i < 11 * 256 / 4; i += 64) ((GLB uint32_t *)rec)[i] = ((LDS const uint32_t *)&s.a[0][0])[i];
@@ -2887,6 +2901,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       *(GLB double *)(rec + REC_COST) = best.cost;
     }
     wsync();
+    PROF_MARK(HEVCDL_BD == 8 ? 47 : 39);
   }
   if (p.cabac_out) {
     wsync();
@@ -2961,7 +2976,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m; }
   }
 #ifdef HEVCDL_KERNEL_PROF
-  if (lane < 40) { s.prof[lane] = 0; s.prof_n[lane] = 0; }
+  if (lane < (HEVCDL_BD == 8 ? 56 : 40)) { s.prof[lane] = 0; s.prof_n[lane] = 0; } if (lane == 0) s.prof_task = 0;
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
@@ -2996,10 +3011,10 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 #ifdef HEVCDL_KERNEL_PROF
   // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)
   wsync();
-  if (blockIdx.x == 0 && p.dbgbuf && lane < 40) {
+  if (blockIdx.x == 0 && p.dbgbuf && lane < (HEVCDL_BD == 8 ? 56 : 40)) {
     if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
     atomicAdd(&p.dbgbuf[1 + 2 * lane], (unsigned int)(s.prof[lane] >> 10)); atomicAdd(&p.dbgbuf[2 + 2 * lane], s.prof_n[lane]);
-    if (lane == 0) p.dbgbuf[0] = 40;
+    if (lane == 0) p.dbgbuf[0] = 56;
   }
 #endif
 }
