@@ -18,6 +18,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <atomic>
@@ -198,7 +199,9 @@ int main(int argc, char **argv)
   // is as many pictures as fill it, bounded by 16 GiB of host staging (originals, reconstruction, CTU records)
   const long per_frame_host = (long)(2 * frame_bytes + (size_t)hevcdl_ctus_per_frame(width, height) * sizeof(hevcdl_ctu_record));
   const long auto_batch = std::max<long>(1, std::min<long>(2048 / (tile_cols * tile_rows), (16L << 30) / per_frame_host));
-  const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", auto_batch)));
+  // (several device calls: equal shares -- a call costs about the same from 1 to ~250 pictures, so a short last call would be wasted time)
+  const long even_batch = (n_frames + ((n_frames + auto_batch - 1) / auto_batch) - 1) / ((n_frames + auto_batch - 1) / auto_batch);
+  const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", even_batch)));
 
   hevcdl_config cfg;
   hevcdl_status st = hevcdl_config_default_bd(&cfg, width, height, qp, bit_depth);
@@ -235,11 +238,22 @@ int main(int argc, char **argv)
   // The batch buffers the library copies from / to are page-locked (hevcdl_host_alloc): the copies then run at the PCIe DMA rate instead
   // of through the runtime's pageable staging path (a batch of 2160p pictures moves 12 MB in and 43 MB out per picture).
   struct Pinned { void *p = nullptr; Pinned(size_t n) { p = hevcdl_host_alloc(n); } ~Pinned() { hevcdl_host_free(p); } uint8_t *data() const { return (uint8_t *)p; } };
-  Pinned yuv(frame_bytes * batch), recon(frame_bytes * batch), recs_mem((size_t)ctus * batch * sizeof(hevcdl_ctu_record));
-  if (!yuv.p || !recon.p || !recs_mem.p) { fprintf(stderr, "Error: cannot allocate the host staging buffers of %d pictures\n", batch); return 3; }
-  struct { hevcdl_ctu_record *p; hevcdl_ctu_record *data() const { return p; } } recs = { (hevcdl_ctu_record *)recs_mem.p };
-  std::vector<uint8_t> labels((size_t)ctus * 16 * batch);
-  std::vector<hevcdl_frame_stats> stats(batch);
+  // Two sets of batch buffers when the sequence takes more than one device call: while the host codes the access units of batch k (the
+  // arithmetic coder, hashes, file writes), a second thread reads batch k + 1 and runs it on the device (the context has one call in flight).
+  struct Stage {
+    Pinned yuv, recon, recs_mem; std::vector<uint8_t> labels; std::vector<hevcdl_frame_stats> stats; std::vector<hevcdl_sao_blk> sao_params;
+    int nb = 0, rc = 0; long f0 = 0; double t_read = 0, t_dev = 0, et = 0;
+    Stage(size_t fb, int ctus_, int batch_, bool sao_) : yuv(fb * batch_), recon(fb * batch_), recs_mem((size_t)ctus_ * batch_ * sizeof(hevcdl_ctu_record)),
+      labels((size_t)ctus_ * 16 * batch_), stats(batch_), sao_params(sao_ ? (size_t)ctus_ * batch_ : 0) { }
+    hevcdl_ctu_record *recs() const { return (hevcdl_ctu_record *)recs_mem.p; }
+  };
+  const long n_batches = (n_frames + batch - 1) / batch;
+  const int n_stages = n_batches > 1 ? 2 : 1;
+  std::unique_ptr<Stage> stages[2];
+  for (int i = 0; i < n_stages; i++) {
+    stages[i].reset(new Stage(frame_bytes, ctus, batch, sao != 0));
+    if (!stages[i]->yuv.p || !stages[i]->recon.p || !stages[i]->recs_mem.p) { fprintf(stderr, "Error: cannot allocate the host staging buffers of %d pictures\n", batch); return 3; }
+  }
   FILE *frec = recon_path.empty() ? nullptr : fopen(recon_path.c_str(), "wb");
   if (!recon_path.empty() && !frec) { fprintf(stderr, "Error: cannot open reconstruction file '%s'\n", recon_path.c_str()); return 2; }
   const std::string record_path = native_path(opt.get("RecordFile"));
@@ -250,39 +264,50 @@ int main(int argc, char **argv)
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
   scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
-  std::vector<hevcdl_sao_blk> sao_params(sao ? (size_t)ctus * batch : 0);
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;
   int rc = 0;
   double t_read = 0, t_dev = 0, t_host = 0, t_write = 0;          // where the wall clock goes (printed to stderr at the end)
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-  for (long f0 = 0; f0 < n_frames && rc == 0; f0 += batch) {
-    const int nb = (int)std::min<long>(batch, n_frames - f0);
+  // producer: file -> labels -> device (CNN -> decisions -> deblocking (TEncGOP.cpp:1742) -> SAO (:1797) in one call: the pictures stay in HBM
+  // between the stages)
+  auto produce = [&](Stage *bp, long f0) {
+    Stage &B = *bp;
+    B.f0 = f0; B.nb = (int)std::min<long>(batch, n_frames - f0); B.rc = 0;
     const auto tr0 = now();
     fseek(fin, (long)((frame_skip + f0) * (long long)frame_bytes), SEEK_SET);
-    if (fread(yuv.data(), frame_bytes, nb, fin) != (size_t)nb) { fprintf(stderr, "Error: short read of '%s'\n", input.c_str()); rc = 2; break; }
+    if (fread(B.yuv.data(), frame_bytes, B.nb, fin) != (size_t)B.nb) { fprintf(stderr, "Error: short read of '%s'\n", input.c_str()); B.rc = 2; return; }
     const uint8_t *lab = nullptr;
     if (!label_dir.empty()) {
-      for (int i = 0; i < nb && rc == 0; i++) for (int a = 0; a < ctus; a++) {
+      for (int i = 0; i < B.nb && B.rc == 0; i++) for (int a = 0; a < ctus; a++) {
         const std::string p = label_dir + "/" + std::to_string(f0 + i) + "/ctu" + std::to_string(a) + ".txt";
         std::ifstream lf(p); int v;
-        for (int j = 0; j < 16; j++) { if (!(lf >> v) || v < 0 || v > 3) { fprintf(stderr, "Error: label file '%s' must hold 16 depths 0..3\n", p.c_str()); rc = 2; break; } labels[((size_t)i * ctus + a) * 16 + j] = (uint8_t)v; }
-        if (rc) break;
+        for (int j = 0; j < 16; j++) { if (!(lf >> v) || v < 0 || v > 3) { fprintf(stderr, "Error: label file '%s' must hold 16 depths 0..3\n", p.c_str()); B.rc = 2; break; } B.labels[((size_t)i * ctus + a) * 16 + j] = (uint8_t)v; }
+        if (B.rc) break;
       }
-      lab = labels.data();
+      lab = B.labels.data();
     }
-    if (rc) break;
-    bool filtered = false;
-    const auto t0 = std::chrono::steady_clock::now();
-    t_read += secs(tr0, t0);
-    // CNN -> decisions -> deblocking (TEncGOP.cpp:1742) -> SAO (:1797) in one call: the pictures stay in HBM between the stages
-    st = hevcdl_encode_pictures(ctx, yuv.data(), nb, lab, deblock ? 1 : 0, recs.data(), recon.data(), sao ? sao_params.data() : nullptr, stats.data());
-    const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / nb;
-    filtered = deblock;                       // the picture statistics follow the filtered picture: recomputed per picture below
+    if (B.rc) return;
+    const auto t0 = now();
+    B.t_read = secs(tr0, t0);
+    const hevcdl_status est = hevcdl_encode_pictures(ctx, B.yuv.data(), B.nb, lab, deblock ? 1 : 0, B.recs(), B.recon.data(), sao ? B.sao_params.data() : nullptr, B.stats.data());
+    B.t_dev = secs(t0, now()); B.et = B.t_dev / B.nb;
+    if (est != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)est); B.rc = 3; }
+  };
+  std::thread producer;
+  produce(stages[0].get(), 0);
+  for (long bi = 0; bi < n_batches && rc == 0; bi++) {
+    if (bi > 0) producer.join();
+    Stage &B = *stages[bi % n_stages];
+    if (B.rc) { rc = B.rc; break; }
+    if (bi + 1 < n_batches) producer = std::thread(produce, stages[(bi + 1) % n_stages].get(), (bi + 1) * (long)batch);
+    const int nb = B.nb; const long f0 = B.f0; const double et = B.et;
+    Pinned &yuv = B.yuv, &recon = B.recon; std::vector<hevcdl_frame_stats> &stats = B.stats; std::vector<hevcdl_sao_blk> &sao_params = B.sao_params;
+    struct { hevcdl_ctu_record *p; hevcdl_ctu_record *data() const { return p; } } recs = { B.recs() };
+    const bool filtered = deblock;            // the picture statistics follow the filtered picture: recomputed per picture below
+    t_read += B.t_read; t_dev += B.t_dev;
     const auto th0 = now();
-    t_dev += secs(t0, th0);
-    if (st != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)st); rc = 3; break; }
     // per picture on the host: SSE of the output picture, the access unit (the arithmetic coder: ~35 ms for a 2160p picture), the
     // picture hash.  Pictures are independent: a pool of threads fills per-picture results, the output stays in POC order.
     struct PicOut { std::vector<uint8_t> bytes; size_t au_len = 0; char md5_text[128]; hevcdl_status st = HEVCDL_OK; };
@@ -344,7 +369,9 @@ int main(int argc, char **argv)
     if (frecords) fwrite(recs.data(), sizeof(hevcdl_ctu_record), (size_t)ctus * nb, frecords);
     t_write += secs(tw0, now());
   }
-  fprintf(stderr, "stage seconds: read %.2f  device (copies + CNN + decisions + filters) %.2f  host (entropy coding, hashes) %.2f  write %.2f\n", t_read, t_dev, t_host, t_write);
+  if (producer.joinable()) producer.join();
+  fprintf(stderr, "stage seconds: read %.2f  device (copies + CNN + decisions + filters) %.2f  host (entropy coding, hashes) %.2f  write %.2f%s\n", t_read, t_dev, t_host, t_write,
+          n_stages > 1 ? "  (read + device of a batch overlap host + write of the batch before)" : "");
   if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
     const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
     printf("\n\nSUMMARY --------------------------------------------------------\n");

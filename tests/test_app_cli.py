@@ -33,7 +33,7 @@ FrameRate : 30
 FrameSkip : 0
 SourceWidth : 192
 SourceHeight : 128
-FramesToBeEncoded : 2
+FramesToBeEncoded : 3
 Level : 3.1
 BitstreamFile : .\\rec\\str.bin
 ReconFile : .\\rec\\rec.yuv
@@ -94,7 +94,7 @@ def test_cli_encode_matches_the_api(app, tmp_path):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import ref_tools
     write_cfgs(tmp_path)
-    w, h, nf, skip, qp = 192, 128, 2, 1, 32
+    w, h, nf, skip, qp = 192, 128, 3, 1, 32       # --BatchFrames=1 below: three device calls, the two sets of batch buffers are both reused
     yuv = ref_tools.synth_yuv(w, h, nf + skip, seed=31)
     yuv.tofile(tmp_path / "in_192x128.yuv")
     labels = ref_tools.make_labels(w, h, nf, "rand", 32)

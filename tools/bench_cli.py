@@ -2,7 +2,7 @@ import sys, os, time, subprocess, tempfile
 sys.path.insert(0, "/root/repo")
 import torch; torch.cuda.init()
 import bench
-nf, w, h = 128, 3840, 2160
+nf, w, h = (int(sys.argv[1]) if len(sys.argv) > 1 else 128), 3840, 2160
 d = tempfile.mkdtemp(prefix="hevcdl_cli_")
 bench.synth_frames_torch(torch, torch.device("cuda", 0), w, h, list(range(nf)), seed=4000).cpu().numpy().tofile(os.path.join(d, "in.yuv"))
 app = "/root/repo/hevc-deep-learning-pipeline_amd/bin/TAppEncoderHevcdl"
