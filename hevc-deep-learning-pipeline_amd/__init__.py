@@ -209,13 +209,14 @@ def load_weights(path=WEIGHTS_PATH):
     return w
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0):
     lib = load_library()
     cfg = Config()
     st = lib.hevcdl_config_default_bd(ctypes.byref(cfg), width, height, qp, bit_depth)
     if st:
         raise HevcdlError(st, "hevcdl_config_default(%d,%d,%d)" % (width, height, qp))
     cfg.max_frames, cfg.device, cfg.cnn_input = max_frames, device, cnn_input
+    cfg.bn_mode = bn_mode                      # 0: training-mode BatchNorm as the reference runs it; 1 (HEVCDL_BN_EVAL): the checkpoint's running statistics
     _set_tiles(cfg, tiles, width, height)        # (columns, rows) uniformly spaced, or explicit sizes: see tile_layout
     cfg.lf_across_tiles = 1 if lf_across_tiles else 0                   # LFCrossTileBoundaryFlag
     return cfg
@@ -250,10 +251,10 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0):
         """bit_depth 10: every yuv / recon array of the decision path holds uint16 samples (frame_bytes counts bytes)."""
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode)
         self.bit_depth = self.cfg.bit_depth
         self.sample_dtype = np.uint8 if self.bit_depth == 8 else np.dtype("<u2")
         self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)

@@ -47,6 +47,7 @@ struct CnnSmem {
   };
   double red[2][4][16];                    // per-wave partial sums / sums of squares
   float alpha[16], beta[16];               // BN folded to y = x*alpha + beta (conv1 / conv64)
+  int bn_eval;                             // HEVCDL_BN_EVAL: the packed gamma / beta slots already hold the folded running statistics
 };
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m)
@@ -145,7 +146,8 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     for (int k = 0; k < 4; k++) { a += sm.red[0][k][tid]; b += sm.red[1][k][tid]; }
     constexpr int SIZE = 16 * POOL;
     float al, be;
-    bn_fold(a, b, (double)(SIZE * SIZE), w[1232 + tid], w[1248 + tid], al, be);
+    if (sm.bn_eval) { al = w[1232 + tid]; be = w[1248 + tid]; }      // eval mode: folded on the host (pack_bn)
+    else bn_fold(a, b, (double)(SIZE * SIZE), w[1232 + tid], w[1248 + tid], al, be);
     sm.alpha[tid] = al; sm.beta[tid] = be;
   }
   __syncthreads();
@@ -172,6 +174,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
   const int frame = gctu / p.ctus_per_frame, addr = gctu - frame * p.ctus_per_frame;
   const int x0 = (addr % p.ctus_x) * 64, y0 = (addr / p.ctus_x) * 64;
   const float GLB *W = (const float GLB *)p.weights;
+  if (tid == 0) sm.bn_eval = p.bn_eval;      // (read behind the first barrier of the first convolution)
   // Two workgroups share a CU, and every CTU takes the same time: started together they would stay in lockstep -- both in their MFMA phases,
   // then both in their fill / statistics phases.  The workgroup that landed in the second wave slot of its SIMDs (HW_ID.wave_id, measured
   // with tools/hwid_probe.hip: blocks 0..255 take slot 0, blocks 256..511 slot 1 of the same CUs) starts about half a CTU time late; the
@@ -311,7 +314,8 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       }
       s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
       float al, be;
-      bn_fold(s, ss, 256.0, b2[64 + ch], b2[128 + ch], al, be);
+      if (p.bn_eval) { al = b2[64 + ch]; be = b2[128 + ch]; }
+      else bn_fold(s, ss, 256.0, b2[64 + ch], b2[128 + ch], al, be);
 #pragma unroll
       for (int t = 0; t < 16; t++) {
         const v4f a = acc[t];
@@ -375,7 +379,8 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         }
         s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
         float al, be;
-        bn_fold(s, ss, 64.0, b3[128 + ch], b3[256 + ch], al, be);
+        if (p.bn_eval) { al = b3[128 + ch]; be = b3[256 + ch]; }
+        else bn_fold(s, ss, 64.0, b3[128 + ch], b3[256 + ch], al, be);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[n][t];

@@ -151,6 +151,17 @@ static void pack_conv3(const float *w, const float *b, const float *g, const flo
   float *t = dst + (size_t)9 * ic * oc;
   memcpy(t, b, oc * sizeof(float)); memcpy(t + oc, g, oc * sizeof(float)); memcpy(t + 2 * oc, be, oc * sizeof(float));
 }
+// HEVCDL_BN_EVAL: BatchNorm with the checkpoint's running statistics (model.eval()) is the fixed affine map y = x * alpha + beta' with
+// alpha = gamma / sqrt(running_var + eps), beta' = beta - running_mean * alpha; the kernels find the pair in the gamma / beta slots of the
+// packed layer (state_dict order: weight, bias, running_mean, running_var follow each other, `oc` floats each).
+static void fold_bn_eval(const float *g, const float *be, int oc, float *dst_g, float *dst_be)
+{
+  const float *rm = be + oc, *rv = be + 2 * oc;
+  for (int c = 0; c < oc; c++) {
+    const double a = (double)g[c] / sqrt((double)rv[c] + 1e-5);
+    dst_g[c] = (float)a; dst_be[c] = (float)((double)be[c] - (double)rm[c] * a);
+  }
+}
 static void pack_fc(const float *w, const float *b, int out, int in, float *dst)
 { for (int j = 0; j < out; j++) for (int k = 0; k < in; k++) dst[(size_t)k * out + j] = w[(size_t)j * in + k]; memcpy(dst + (size_t)in * out, b, out * sizeof(float)); }
 
@@ -161,7 +172,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51 || cfg->max_frames < 1) return HEVCDL_ERR_INVALID_ARG;
   // keys that would change the path are rejected, not ignored
   if ((cfg->bit_depth != 8 && cfg->bit_depth != 10) || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
-      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || cfg->bn_mode != HEVCDL_BN_REFERENCE ||
+      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
       cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA))
     return HEVCDL_ERR_UNSUPPORTED;
   { // tiles: uniform spacing, every column at least 4 CTUs wide and every row 1 CTU high (TComPicSym.cpp:380-392), at most 20 x 22 (level 6.2)
@@ -192,6 +203,12 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_conv5(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, pk.data() + HEVCDL_W_C64);
   pack_conv3(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 32, pk.data() + HEVCDL_W_C2);
   pack_conv3(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 64, pk.data() + HEVCDL_W_C3);
+  if (cfg->bn_mode == HEVCDL_BN_EVAL) {
+    fold_bn_eval(weights + B_C1G, weights + B_C1BE, 16, pk.data() + HEVCDL_W_C1 + 1232, pk.data() + HEVCDL_W_C1 + 1248);
+    fold_bn_eval(weights + B_C64G, weights + B_C64BE, 16, pk.data() + HEVCDL_W_C64 + 1232, pk.data() + HEVCDL_W_C64 + 1248);
+    fold_bn_eval(weights + B_C2G, weights + B_C2BE, 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 128);
+    fold_bn_eval(weights + B_C3G, weights + B_C3BE, 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 256);
+  }
   pack_fc(weights + B_F1W, weights + B_F1B, 256, 2048, pk.data() + HEVCDL_W_FC1);
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
@@ -271,7 +288,7 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   // per workgroup.  The hand-over buffer holds one chunk of CTUs (<= 4 GiB); larger batches go through it chunk by chunk.
   const size_t chunk = (size_t)std::min<long long>(n_ctus, 131072);
   if (ctx->a3_ctus < chunk) { hipFree(ctx->d_a3); ctx->d_a3 = nullptr; ctx->a3_ctus = 0; HIPCHK(hipMalloc(&ctx->d_a3, chunk * 4 * 2048 * sizeof(float))); ctx->a3_ctus = chunk; }
-  p.a3 = ctx->d_a3; p.n_cus = ctx->n_cus;
+  p.a3 = ctx->d_a3; p.n_cus = ctx->n_cus; p.bn_eval = ctx->cfg.bn_mode == HEVCDL_BN_EVAL;
   hevcdl_fc_params f;
   f.a3 = ctx->d_a3; f.weights = ctx->d_weights; f.width = p.width; f.height = p.height; f.ctus_x = p.ctus_x; f.ctus_per_frame = p.ctus_per_frame; f.clamp = clamp;
   prof_begin(ctx, ctx->ev_cnn, s);

@@ -28,6 +28,7 @@ struct hevcdl_cnn_params {
   float *a3;                       // [ctu of the launch][4 quadrants][2048]: flattened conv3 output = input rows of the fully connected head
   int ctu_base;                    // global index of the launch's first CTU
   int n_cus;                       // compute units of the device (first-generation workgroups = 2 per CU)
+  int bn_eval;                     // 1: BatchNorm with the checkpoint's running statistics (folded into the packed gamma / beta slots by the host)
 };
 
 // fully connected head + labels (fc_kernel.hip), 16 CTUs per workgroup

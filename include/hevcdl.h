@@ -43,7 +43,8 @@ typedef enum {
 
 #define HEVCDL_CNN_INPUT_RGB601 0   /* BT.601 limited-range YUV -> RGB, nearest chroma (defined by this project) */
 #define HEVCDL_CNN_INPUT_LUMA   1   /* R = G = B = Y */
-#define HEVCDL_BN_REFERENCE     0   /* training-mode BatchNorm, as use_model.py:61-63 runs it */
+#define HEVCDL_BN_REFERENCE     0   /* training-mode BatchNorm, as use_model.py:61-63 runs it (the reference never calls model.eval()) */
+#define HEVCDL_BN_EVAL          1   /* BatchNorm with the checkpoint's running statistics (what model.eval() would give; NOT the reference pipeline's labels) */
 #define HEVCDL_BOUNDARY_CLAMP   0   /* clamp labels to the picture */
 
 #define HEVCDL_WEIGHT_FLOATS 637712 /* state_dict order of rec/hevc_encoder_model.pt, fp32 tensors only */

@@ -52,37 +52,46 @@ def _bn_train(x, gamma, beta):
     return ((x - mean.astype(np.float32)) * inv * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)).astype(np.float32)
 
 
+def _bn_eval(x, gamma, beta, mean, var):
+    """model.eval(): the checkpoint's running statistics (HEVCDL_BN_EVAL; not what the reference pipeline runs)."""
+    inv = (1.0 / np.sqrt(var.astype(np.float64) + 1e-5)).astype(np.float32)
+    return ((x - mean.reshape(1, -1, 1, 1)) * inv.reshape(1, -1, 1, 1) * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)).astype(np.float32)
+
+
 def _pool(x, k):
     n, c, h, w = x.shape
     return x.reshape(n, c, h // k, k, w // k, k).max(axis=(3, 5))
 
 
-def _block(x, w, name, pad, pool):
+def _block(x, w, name, pad, pool, bn_eval=False):
     y = _conv2d(x, w[name + ".0.weight"], w[name + ".0.bias"], pad)
-    y = _bn_train(y, w[name + ".1.weight"], w[name + ".1.bias"])
+    if bn_eval:
+        y = _bn_eval(y, w[name + ".1.weight"], w[name + ".1.bias"], w[name + ".1.running_mean"], w[name + ".1.running_var"])
+    else:
+        y = _bn_train(y, w[name + ".1.weight"], w[name + ".1.bias"])
     return _pool(np.maximum(y, 0), pool)
 
 
-def forward(w, x32, x64):
+def forward(w, x32, x64, bn_eval=False):
     """use_model.py:48-58.  x32 [N,3,32,32], x64 [N,3,64,64] fp32 in [0,1] -> logits [N,16]."""
-    a = _block(x32, w, "conv1", 2, 2)
-    b = _block(x64, w, "conv64", 2, 4)
+    a = _block(x32, w, "conv1", 2, 2, bn_eval)
+    b = _block(x64, w, "conv64", 2, 4, bn_eval)
     out = np.concatenate([a, b], axis=1)
-    out = _block(out, w, "conv2", 1, 2)
-    out = _block(out, w, "conv3", 1, 2)
+    out = _block(out, w, "conv2", 1, 2, bn_eval)
+    out = _block(out, w, "conv3", 1, 2, bn_eval)
     out = out.reshape(out.shape[0], -1)
     out = np.maximum(out @ w["fc1.0.weight"].T + w["fc1.0.bias"], 0).astype(np.float32)
     out = np.maximum(out @ w["fc2.0.weight"].T + w["fc2.0.bias"], 0).astype(np.float32)
     return (out @ w["fc3.weight"].T + w["fc3.bias"]).astype(np.float32)
 
 
-def ctu_logits(w, ctu_rgb):
+def ctu_logits(w, ctu_rgb, bn_eval=False):
     """ctu_rgb [N,64,64,3] uint8 -> logits [N,4,16] (quadrant layer2 = 0..3, use_model.py:89-100)."""
     x = (ctu_rgb.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2)     # ToTensor
     outs = []
     for q in range(4):
         ox, oy = (q % 2) * 32, (q // 2) * 32
-        outs.append(forward(w, np.ascontiguousarray(x[:, :, oy:oy + 32, ox:ox + 32]), x))
+        outs.append(forward(w, np.ascontiguousarray(x[:, :, oy:oy + 32, ox:ox + 32]), x, bn_eval))
     return np.stack(outs, axis=1)
 
 

@@ -133,6 +133,27 @@ def load_ref_model():
     return model, sd, src
 
 
+def gen_cnn_eval():
+    """F-cnn-1, second half ("... in reference (train-BN) mode and in eval mode"): the CTUs of cnn_f1.npz through a freshly
+    loaded reference model after model.eval() -- BatchNorm then uses the checkpoint's running statistics (a model that has run in training
+    mode has already moved them, hence the fresh load).  This is the selectable HEVCDL_BN_EVAL mode, not what the reference pipeline runs."""
+    import torch
+    model, _, _ = load_ref_model()
+    model.eval()
+    ctus = np.load(os.path.join(GOLD, "cnn_f1.npz"))["ctu_rgb"]
+    logits = np.zeros((len(ctus), 4, 16), np.float32)
+    with torch.no_grad():
+        for i in range(len(ctus)):
+            x = torch.from_numpy(ctus[i].astype(np.float32) / 255.0).permute(2, 0, 1)
+            for q in range(4):
+                ox, oy = (q % 2) * 32, (q // 2) * 32
+                logits[i, q] = model(x[:, oy:oy + 32, ox:ox + 32].unsqueeze(0).contiguous(), x.unsqueeze(0))[0].numpy()
+    import cnn_oracle
+    labels = cnn_oracle.labels_from_logits(logits)          # post-processing pinned by cnn_f1 / cnn_f2
+    np.savez_compressed(os.path.join(GOLD, "cnn_f1_eval.npz"), logits=logits, labels=labels)
+    print("cnn eval fixture:", len(ctus), "CTUs; label histogram", np.bincount(labels.ravel(), minlength=4))
+
+
 def gen_weights(sd):
     os.makedirs(WDIR, exist_ok=True)
     tensors, chunks, off = [], [], 0
@@ -291,7 +312,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor", "stage"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval"]
     if "stage" in what:
         gen_stage_traces()
     if "rd" in what:
@@ -308,6 +329,8 @@ if __name__ == "__main__":
             gen_weights(sd)
         if "cnn" in what:
             gen_cnn(model, src)
+    if "cnneval" in what:
+        gen_cnn_eval()
     if "bd" in what:
         gen_bd()
     if "full" in what:

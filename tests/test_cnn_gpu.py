@@ -31,6 +31,24 @@ def test_logits_and_labels_match_reference_fixture(enc):
     assert np.array_equal(labels[safe], f["labels"][safe])
 
 
+def test_eval_mode_batchnorm_matches_the_reference_model_in_eval_mode():
+    """HEVCDL_BN_EVAL (BN mode {reference-train, eval}; F-cnn-1's eval half, tests/golden/cnn_f1_eval.npz = the reference
+    model after model.eval() on the CTUs of cnn_f1.npz): BatchNorm with the checkpoint's running statistics.  Same tolerance and label rule
+    as the reference mode; the two modes disagree on most labels, so a mix-up cannot pass."""
+    import hevcdl_amd
+    f, g = np.load(os.path.join(GOLD, "cnn_f1.npz")), np.load(os.path.join(GOLD, "cnn_f1_eval.npz"))
+    e = hevcdl_amd.Encoder(128, 128, 32, max_frames=2, bn_mode=1)
+    labels, logits = e.predict_depth_rgb(f["ctu_rgb"])
+    e.close()
+    err = np.abs(logits - g["logits"]).max()
+    assert err < LOGIT_TOL, err
+    srt = np.sort(g["logits"].reshape(-1, 4, 4, 4), axis=-1)
+    safe = ((srt[..., -1] - srt[..., -2]) > 1e-2).all(axis=(1, 2))
+    assert safe.sum() > 32
+    assert np.array_equal(labels[safe], g["labels"][safe])
+    assert (g["labels"] != f["labels"]).mean() > 0.3
+
+
 def test_yuv_path_matches_oracle(enc):
     import cnn_oracle
     import hevcdl_amd

@@ -96,6 +96,19 @@ def test_cnn_oracle_matches_reference_logits_and_labels():
     assert np.array_equal(cnn_oracle.labels_from_logits(lg), f["labels"][:n])
 
 
+def test_cnn_oracle_eval_mode_matches_reference_model_in_eval_mode():
+    """The selectable eval-mode BatchNorm (running statistics of the checkpoint; tests/golden/cnn_f1_eval.npz from the reference model after
+    model.eval(), oracle/gen_fixtures.py gen_cnn_eval)."""
+    import cnn_oracle
+    import hevcdl_amd
+    f, g = np.load(os.path.join(GOLD, "cnn_f1.npz")), np.load(os.path.join(GOLD, "cnn_f1_eval.npz"))
+    w = cnn_oracle.load_weights(hevcdl_amd.WEIGHTS_PATH)
+    n = 48
+    logits = cnn_oracle.ctu_logits(w, f["ctu_rgb"][:n], bn_eval=True)
+    assert np.abs(logits - g["logits"][:n]).max() < 1e-4
+    assert np.array_equal(cnn_oracle.labels_from_logits(g["logits"]), g["labels"])
+
+
 def test_label_postprocessing_matches_reference_lines():
     import cnn_oracle
     f = np.load(os.path.join(GOLD, "cnn_f2.npz"))
