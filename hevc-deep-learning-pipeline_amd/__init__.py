@@ -42,6 +42,11 @@ class HevcdlError(RuntimeError):
         self.status = status
 
 
+class Planes(ctypes.Structure):
+    """hevcdl_planes of include/hevcdl.h."""
+    _fields_ = [("plane", ctypes.c_void_p * 3), ("row_stride", ctypes.c_size_t * 3), ("frame_stride", ctypes.c_size_t * 3), ("sample_bytes", ctypes.c_int32)]
+
+
 class Config(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("bit_depth", ctypes.c_int32), ("chroma_format", ctypes.c_int32), ("qp", ctypes.c_int32),
@@ -147,6 +152,8 @@ def load_library():
     lib.hevcdl_predict_depth.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_predict_depth_rgb.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_compress_frames.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.hevcdl_predict_depth_planes.argtypes = [vp, vp, ci, vp, vp]
+    lib.hevcdl_compress_frames_planes.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     lib.hevcdl_stream_config_default.argtypes = [ctypes.POINTER(StreamConfig), ci, ci, ci]
     lib.hevcdl_access_unit_bound.argtypes = [ci, ci]
     lib.hevcdl_access_unit_bound.restype = ctypes.c_size_t
@@ -177,7 +184,7 @@ def load_library():
 
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
-           "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
+           "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_planes", "hevcdl_compress_frames_planes", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5"]
@@ -298,6 +305,38 @@ class Encoder:
         logits = np.zeros((n, 4, 16), np.float32)
         self._check(self.lib.hevcdl_predict_depth_rgb(self._h, ctu_rgb.ctypes.data, n, labels.ctypes.data, logits.ctypes.data))
         return labels, logits
+
+    def _planes(self, y, u, v):
+        """Three arrays [frames][rows][cols] (views with any row / frame pitch, uint8 or 16-bit samples) -> (hevcdl_planes, n_frames, keep-alive)."""
+        arrs = [np.asarray(a) for a in (y, u, v)]
+        arrs = [a[None] if a.ndim == 2 else a for a in arrs]
+        sb = arrs[0].dtype.itemsize
+        pl = Planes()
+        for c, a in enumerate(arrs):
+            if a.ndim != 3 or a.dtype.itemsize != sb or a.strides[2] != sb or a.shape[1:] != ((self.height, self.width) if c == 0 else (self.height // 2, self.width // 2)):
+                raise ValueError("plane %d: expected [frames][%d][%d] with unit column stride" % (c, self.height if c == 0 else self.height // 2, self.width if c == 0 else self.width // 2))
+            pl.plane[c], pl.row_stride[c], pl.frame_stride[c] = a.ctypes.data, a.strides[1], a.strides[0]
+        pl.sample_bytes = sb
+        return pl, arrs[0].shape[0], arrs
+
+    def predict_depth_planes(self, y, u, v):
+        pl, n, keep = self._planes(y, u, v)
+        labels = np.zeros((n, self.ctus, 16), np.uint8)
+        self._check(self.lib.hevcdl_predict_depth_planes(self._h, ctypes.byref(pl), n, labels.ctypes.data, None))
+        return labels
+
+    def compress_frames_planes(self, y, u, v, labels=None):
+        """compress_frames for pictures held as three planes with their own pitch (e.g. views into an encoder's padded picture buffers)."""
+        pl, n, keep = self._planes(y, u, v)
+        recs = np.zeros((n, self.ctus), REC_DTYPE)
+        recon = np.zeros((n, self.frame_bytes), np.uint8)
+        stats = np.zeros(n, STATS_DTYPE)
+        lab_ptr = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, np.uint8).reshape(n, self.ctus, 16)
+            lab_ptr = labels.ctypes.data
+        self._check(self.lib.hevcdl_compress_frames_planes(self._h, ctypes.byref(pl), n, lab_ptr, recs.ctypes.data, recon.ctypes.data, stats.ctypes.data))
+        return recs, (recon.view(np.uint16) if self.bit_depth > 8 else recon), stats
 
     def compress_frames(self, yuv, labels=None):
         """-> (records [n, ctus] REC_DTYPE, recon [n, frame_bytes] uint8, stats [n] STATS_DTYPE)."""

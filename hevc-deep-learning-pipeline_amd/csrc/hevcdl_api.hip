@@ -68,7 +68,8 @@ struct hevcdl_ctx {
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
   unsigned char *d_cabac; std::vector<int> next_ctu; int session_frames;
-  unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params, *d_sao_cand;   // SAO workspace
+  unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params, *d_sao_cand;
+  unsigned char *d_wide;                 // 16-bit staging of hevcdl_*_planes with sample_bytes 2 on an 8-bit context   // SAO workspace
   int *d_flag;                   // device-side error flag of the label check
   unsigned char *d_sched;        // decision kernel: hand-over of units between workgroups (finished counter, per-workgroup unit counts, mailboxes)
   bool profile;
@@ -193,7 +194,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = ctx->d_sao_cand = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = ctx->d_sao_cand = nullptr; ctx->d_wide = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -241,7 +242,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_sao_cand); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
+  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_sao_cand); hipFree(ctx->d_wide); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
   delete ctx;
 }
 
@@ -450,6 +451,32 @@ extern "C" hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d
   return hevcdl_compress_frames_dev(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, stream);
 }
 
+// hevcdl_planes -> the packed planar frames of the staging buffer (row by row: hipMemcpy2D; 8-bit samples in 16-bit containers are narrowed on the device)
+static hevcdl_status upload_planes(hevcdl_ctx *ctx, const hevcdl_planes *src, int n_frames)
+{
+  if (!src || !src->plane[0] || !src->plane[1] || !src->plane[2]) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null plane pointer");
+  const int native = ctx->cfg.bit_depth > 8 ? 2 : 1, sb = src->sample_bytes;
+  if (sb != native && !(sb == 2 && native == 1)) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "sample_bytes does not fit the context's bit depth");
+  const int w = ctx->cfg.width, h = ctx->cfg.height;
+  for (int c = 0; c < 3; c++) if (src->row_stride[c] < (size_t)(c ? w / 2 : w) * sb) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "row stride smaller than a row");
+  unsigned char *dst = (unsigned char *)ctx->d_yuv;
+  if (sb != native) {
+    if (!ctx->d_wide) HIPCHK(hipMalloc(&ctx->d_wide, 2 * ctx->frame_bytes * (size_t)ctx->cfg.max_frames));
+    dst = ctx->d_wide;
+  }
+  const size_t fb = ctx->frame_bytes / native * sb, off[3] = { 0, (size_t)w * h * sb, (size_t)w * h * sb + (size_t)(w / 2) * (h / 2) * sb };
+  for (int f = 0; f < n_frames; f++) for (int c = 0; c < 3; c++) {
+    const size_t rw = (size_t)(c ? w / 2 : w) * sb; const int rows = c ? h / 2 : h;
+    HIPCHK(hipMemcpy2D(dst + (size_t)f * fb + off[c], rw, (const unsigned char *)src->plane[c] + (size_t)f * src->frame_stride[c], src->row_stride[c], rw, rows, hipMemcpyHostToDevice));
+  }
+  if (sb != native) {
+    hipLaunchKernelGGL(hevcdl_narrow_samples_kernel, dim3(2048), dim3(256), 0, (hipStream_t)nullptr, (const uint16_t *)ctx->d_wide, (uint8_t *)ctx->d_yuv, ctx->frame_bytes * (size_t)n_frames, 0);
+    HIPCHK(hipGetLastError());
+  }
+  return HEVCDL_OK;
+}
+
+static hevcdl_status predict_depth_staged(hevcdl_ctx *ctx, int n_frames, uint8_t *labels, float *logits_opt);
 extern "C" hevcdl_status hevcdl_predict_depth(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, uint8_t *labels, float *logits_opt)
 {
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
@@ -457,6 +484,20 @@ extern "C" hevcdl_status hevcdl_predict_depth(hevcdl_ctx *ctx, const uint8_t *yu
   if (!yuv || !labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
   st = ensure_staging(ctx); if (st) return st;
   HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  return predict_depth_staged(ctx, n_frames, labels, logits_opt);
+}
+extern "C" hevcdl_status hevcdl_predict_depth_planes(hevcdl_ctx *ctx, const hevcdl_planes *src, int n_frames, uint8_t *labels, float *logits_opt)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  st = ensure_staging(ctx); if (st) return st;
+  st = upload_planes(ctx, src, n_frames); if (st) return st;
+  return predict_depth_staged(ctx, n_frames, labels, logits_opt);
+}
+static hevcdl_status predict_depth_staged(hevcdl_ctx *ctx, int n_frames, uint8_t *labels, float *logits_opt)
+{
+  hevcdl_status st;
   st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, logits_opt ? ctx->d_logits : nullptr, nullptr); if (st) return st;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(labels, ctx->d_labels, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyDeviceToHost));
@@ -490,6 +531,7 @@ extern "C" hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t
   return st;
 }
 
+static hevcdl_status compress_frames_staged(hevcdl_ctx *ctx, int n_frames, const uint8_t *labels_opt, hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt);
 extern "C" hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,
                                                 hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt)
 {
@@ -498,6 +540,21 @@ extern "C" hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *
   if (!yuv || !records) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
   st = ensure_staging(ctx); if (st) return st;
   HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  return compress_frames_staged(ctx, n_frames, labels_opt, records, recon_opt, stats_opt);
+}
+extern "C" hevcdl_status hevcdl_compress_frames_planes(hevcdl_ctx *ctx, const hevcdl_planes *src, int n_frames, const uint8_t *labels_opt,
+                                                       hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!records) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  st = ensure_staging(ctx); if (st) return st;
+  st = upload_planes(ctx, src, n_frames); if (st) return st;
+  return compress_frames_staged(ctx, n_frames, labels_opt, records, recon_opt, stats_opt);
+}
+static hevcdl_status compress_frames_staged(hevcdl_ctx *ctx, int n_frames, const uint8_t *labels_opt, hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt)
+{
+  hevcdl_status st;
   if (labels_opt) { HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice)); st = hevcdl_clamp_labels_dev(ctx, ctx->d_labels, n_frames, nullptr); if (st) return st; }
   else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
   st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;

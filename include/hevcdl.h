@@ -131,6 +131,21 @@ hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t *ctu_rgb, 
 hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,
                                      hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt);
 
+/* The same two entry points for pictures that are NOT packed: three planes with their own row pitch, as an encoder's picture buffers hold them
+ * (HM: TComPicYuv = one Pel (int16) plane per component with a margin of 80 samples round the picture, stride = width + 160,
+ * TComPicYuv.cpp:81-104; getAddr(compID) / getStride(compID) give exactly plane[] / row_stride[]).  Strides are in BYTES.  sample_bytes: 1
+ * (uint8 samples, bit_depth 8), or 2 (16-bit containers: the samples of a bit_depth 10 context, or 8-bit samples in int16 as HM keeps them --
+ * narrowed on the device).  frame_stride[c]: distance from plane c of frame i to plane c of frame i + 1 (ignored for n_frames 1). */
+typedef struct hevcdl_planes {
+  const void *plane[3];          /* first sample of Y, Cb, Cr of frame 0 */
+  size_t      row_stride[3];     /* bytes from one row to the next, >= the plane's width * sample_bytes */
+  size_t      frame_stride[3];   /* bytes from frame i to frame i + 1, per plane */
+  int32_t     sample_bytes;      /* 1 or 2 */
+} hevcdl_planes;
+hevcdl_status hevcdl_predict_depth_planes(hevcdl_ctx *ctx, const hevcdl_planes *src, int n_frames, uint8_t *labels, float *logits_opt);
+hevcdl_status hevcdl_compress_frames_planes(hevcdl_ctx *ctx, const hevcdl_planes *src, int n_frames, const uint8_t *labels_opt,
+                                            hevcdl_ctu_record *records, uint8_t *recon_opt, hevcdl_frame_stats *stats_opt);
+
 /* ---- deblocking filter (first in-loop filter of the reference) -------------------------------------
  * Replaces TComLoopFilter::loopFilterPic(TComPic*) (TLibCommon/TComLoopFilter.cpp:130, called at TEncGOP.cpp:1742) for
  * the pictures this library decides: recon = what hevcdl_compress_frames returned, records = its CTU records (the

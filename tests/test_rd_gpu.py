@@ -139,6 +139,54 @@ def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built)
     assert np.array_equal(recon[pick], o_recon) and np.array_equal(stats["est_bits"][pick], o_stats["est_bits"])
 
 
+def _padded_planes(yuv, w, h, dtype, margin, extra):
+    """Frames [n][w*h*3/2] -> three plane views [n][rows][cols] inside padded buffers (margin samples round every plane, `extra` more per row),
+    the way an encoder's picture buffers hold them (TComPicYuv: margin 80, one int16 per sample)."""
+    n = yuv.shape[0]
+    views = []
+    off = 0
+    for c in range(3):
+        pw, ph = (w, h) if c == 0 else (w // 2, h // 2)
+        buf = np.full((n, ph + 2 * margin, pw + 2 * margin + extra), 77, dtype)
+        buf[:, margin:margin + ph, margin:margin + pw] = yuv[:, off:off + pw * ph].reshape(n, ph, pw)
+        views.append(buf[:, margin:margin + ph, margin:margin + pw])
+        off += pw * ph
+    return views
+
+
+def test_planes_with_their_own_pitch_give_the_packed_result():
+    """hevcdl_compress_frames_planes / hevcdl_predict_depth_planes (planes + strides): pictures handed over as three planes
+    inside padded buffers -- uint8 with an odd pitch, and HM's own layout (8-bit samples in int16, margin 80: TComPicYuv.cpp:81-104) -- must
+    give exactly what the packed entry points give; so must 10-bit samples in uint16 planes; bad strides / sample sizes are refused."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf = 200, 136, 30, 2
+    yuv = ref_tools.synth_yuv(w, h, nf, seed=71)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    labels = e.predict_depth(yuv)
+    recs, recon, stats = e.compress_frames(yuv)
+    for dtype, margin, extra in ((np.uint8, 3, 5), (np.int16, 80, 0)):
+        y, u, v = _padded_planes(yuv, w, h, dtype, margin, extra)
+        assert np.array_equal(e.predict_depth_planes(y, u, v), labels)
+        r2, rec2, st2 = e.compress_frames_planes(y, u, v)
+        assert r2.tobytes() == recs.tobytes() and np.array_equal(rec2, recon) and st2.tobytes() == stats.tobytes()
+        r3, rec3, _ = e.compress_frames_planes(y[1], u[1], v[1], labels=labels[1:])          # one frame as 2-D views, caller's labels
+        assert r3.tobytes() == recs[1:].tobytes() and np.array_equal(rec3, recon[1:])
+    pl, n, keep = e._planes(*_padded_planes(yuv, w, h, np.uint8, 0, 0))
+    pl.row_stride[1] = w // 2 - 1
+    out = np.zeros((nf, e.ctus, 16), np.uint8)
+    assert e.lib.hevcdl_predict_depth_planes(e._h, hevcdl_amd.ctypes.byref(pl), n, out.ctypes.data, None) == 1      # HEVCDL_ERR_INVALID_ARG
+    e.close()
+    yuv10 = (ref_tools.synth_yuv(w, h, 1, seed=72).astype(np.uint16) << 2) | 1
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=1, bit_depth=10)
+    recs, recon, stats = e.compress_frames(yuv10)
+    r2, rec2, _ = e.compress_frames_planes(*_padded_planes(yuv10, w, h, np.uint16, 16, 2))
+    assert r2.tobytes() == recs.tobytes() and np.array_equal(rec2.reshape(-1), np.asarray(recon).reshape(-1))
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        e.compress_frames_planes(*_padded_planes(yuv10.astype(np.uint8), w, h, np.uint8, 0, 0))     # one byte per sample on a 10-bit context
+    e.close()
+
+
 _STAGE_CHILD = """
 import ctypes, sys
 import numpy as np
