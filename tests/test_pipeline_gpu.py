@@ -69,3 +69,42 @@ def test_tile_sharded_encode_equals_single_process(tmp_path, w, h, nf, tiles, bd
     assert (tmp_path / "one.yuv").read_bytes() == (tmp_path / "two.yuv").read_bytes()
     lines = lambda t: [l.rsplit(" [ET", 1)[0] for l in t.splitlines() if l.startswith("POC") or l.startswith("\t ")]
     assert lines(r1.stdout) == lines(r2.stdout) and len(lines(r1.stdout)) == nf + 1
+
+
+@pytest.mark.parametrize("w,h,bd,tiles", [(200, 136, 8, (1, 1)), (8, 8, 8, (1, 1)), (520, 200, 10, (2, 2)), (1928, 1080, 8, (1, 1))])
+def test_device_entry_points_stay_inside_their_buffers(w, h, bd, tiles):
+    """Bounds check of every device-pointer entry point (the image has no address sanitizer for device code): each output buffer sits between
+    two 64 KiB guard areas filled with a pattern -- inputs likewise, so an out-of-range write of a neighbouring kernel would show -- and the
+    guards must be untouched after CNN, decisions, deblocking and SAO on ragged picture sizes."""
+    import torch
+    import hevcdl_amd
+    import ref_tools
+    nf, G = 2, 65536
+    dev = torch.device("cuda", 0)
+    e = hevcdl_amd.Encoder(w, h, 30, max_frames=nf, tiles=tiles, bit_depth=bd)
+    yuv = ref_tools.synth_yuv(w, h, nf, seed=91)
+    if bd == 10:
+        yuv = (yuv.astype(np.uint16) << 2) | 2
+    sizes = {"yuv": e.frame_bytes * nf, "labels": e.ctus * 16 * nf, "records": e.ctus * 15120 * nf, "recon": e.frame_bytes * nf, "stats": 40 * nf,
+             "dbk": e.frame_bytes * nf, "sao": e.ctus * np.dtype(hevcdl_amd.SAO_DTYPE).itemsize * 3 * nf, "final": e.frame_bytes * nf}
+    bufs = {}
+    for k, n in sizes.items():
+        n = (n + 255) // 256 * 256
+        t = torch.full((n + 2 * G,), 0xA5, dtype=torch.uint8, device=dev)
+        bufs[k] = (t, n)
+    ptr = lambda k: bufs[k][0].data_ptr() + G
+    bufs["yuv"][0][G:G + sizes["yuv"]] = torch.from_numpy(np.ascontiguousarray(yuv).view(np.uint8).reshape(-1)).to(dev)
+    e.predict_depth_dev(ptr("yuv"), nf, ptr("labels"))
+    e.compress_frames_dev(ptr("yuv"), nf, ptr("labels"), ptr("records"), ptr("recon"), ptr("stats"))
+    e.deblock_frames_dev(ptr("recon"), nf, ptr("records"), ptr("dbk"))
+    e.sao_frames_dev(ptr("yuv"), ptr("dbk"), nf, ptr("sao"), ptr("final"))
+    torch.cuda.synchronize()
+    for k, (t, n) in bufs.items():
+        assert bool((t[:G] == 0xA5).all()) and bool((t[G + n:] == 0xA5).all()), "guard area of %s overwritten" % k
+        if k != "yuv":
+            assert bool((t[G:G + sizes[k]] != 0xA5).any()), "%s not written" % k
+    # and the results are the ones the host entry points give
+    recs, recon, _ = e.compress_frames(yuv)
+    assert bufs["records"][0][G:G + sizes["records"]].cpu().numpy().tobytes() == recs.tobytes()
+    assert bufs["recon"][0][G:G + sizes["recon"]].cpu().numpy().tobytes() == np.ascontiguousarray(recon).tobytes()
+    e.close()
