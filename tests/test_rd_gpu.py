@@ -84,6 +84,30 @@ def test_whole_1080p_frame_matches_a_live_reference_run():
     assert res["ctus"] == recs.shape[1] and res["mismatches"] == 0, res
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_2160p_wide_bands_match_a_live_reference_run_at_the_sweep_qps(qp):
+    """The four QPs of BASELINE.json's C3 sweep at the full 3840 width: the top 3840x384 band (6 CTU rows, 360 CTUs) of three 2160p frames,
+    coded as pictures of their own by the reference encoder (run now, labels of the device CNN) and by the decision kernel -- every field of
+    every CTU record and the reconstruction."""
+    import sys
+    import hevcdl_amd
+    import ref_tools
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), ".."))
+    import bench
+    w, h, nf = 3840, 384, 3
+    full = ref_tools.synth_yuv(3840, 2160, nf, 500 + qp)
+    ysz, csz = 3840 * 2160, 1920 * 1080
+    band = np.concatenate([full[:, :w * h], full[:, ysz:ysz + (w // 2) * (h // 2)], full[:, ysz + csz:ysz + csz + (w // 2) * (h // 2)]], axis=1)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    labels = enc.predict_depth(band)
+    recs, recon, stats = enc.compress_frames(band, labels)
+    enc.close()
+    wall, per, dumps = bench.run_reference_pictures([band[i] for i in range(nf)], labels, w, h, qp, nf, dump=True, workers=min(nf, bench.effective_cores()))
+    res = bench.parity_against_dumps(dumps, recs, [recon[i] for i in range(nf)], w, h)
+    assert res["ctus"] == nf * 360 and res["mismatches"] == 0, res
+
+
 def test_unclamped_caller_labels_get_the_boundary_policy(oracle_built):
     """Label files of the reference's own label producer are not clamped at the picture border.  Caller-supplied
     labels therefore go through the boundary policy before the search: raw random labels on 200x136 give exactly the result of their clamped
