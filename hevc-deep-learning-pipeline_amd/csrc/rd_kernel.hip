@@ -2365,6 +2365,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
   PROF_TASK(kind != T_LUMA_P2);
+  PROF_MARK0();
   const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
@@ -2417,7 +2418,9 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
       if (lane_id() == 0) { s.ref_key[0] = ow.ref_key[0]; s.fline_key = ow.fline_key; }
       wsync();
     }
+    PROF_MARK(HEVCDL_BD == 8 ? 50 : 39);
     const DistCost dc = recur_luma_any(k, cu, tu, one_tu ? 2 : 1);
+    PROF_MARK(HEVCDL_BD == 8 ? 51 : 39);
     dist = dc.dist; cost = dc.cost;
     wsync();
     for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
@@ -2443,6 +2446,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   }
   if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
+  if (kind == T_LUMA_P1) PROF_MARK(HEVCDL_BD == 8 ? 52 : 39);
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   kk.lz = olz; kk.lx = olx; kk.ly = oly;
   wsync();
@@ -2492,7 +2496,7 @@ DEV int helper_step()
       const int idx = region_claim(r);
       if (idx < 0) continue;
       wg_acquire();
-      import_owner(uni(r.owner));
+      { PROF_T0(); import_owner(uni(r.owner)); PROF_ADD(0, HEVCDL_BD == 8 ? 53 : 39); }
       run_task<false>(r, idx);
       wg_release();
       lds_add(&r.done, 1);
