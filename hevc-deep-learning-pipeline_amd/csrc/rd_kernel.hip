@@ -1142,6 +1142,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
       }
       wsync();
     }
+    RDOQ_MARK(HEVCDL_BD == 8 ? 54 : 39);
     int found_last = 0;
     for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
       const int cgblk = uni(scan_cg[cgpos]);
@@ -1157,6 +1158,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
       if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
       if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
       const double cl_j = lambda * lc;
+      RDOQ_MARK(HEVCDL_BD == 8 ? 55 : 39);
       // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
       // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
       // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
@@ -1176,6 +1178,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
         for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
       }
       const double total_j = (mine + cl_j) - cs_j;
+      RDOQ_MARK(HEVCDL_BD == 8 ? 44 : 39);
       const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
       const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
       unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
