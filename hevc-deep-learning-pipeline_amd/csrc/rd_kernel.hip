@@ -248,7 +248,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5 };
 enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it), 10..13 the split tasks of the second pass (by child), 14 its verdict + start state: a second pass may still run while the next CU's first pass does
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
@@ -278,6 +278,9 @@ struct __attribute__((aligned(16))) WgShared {
 DEV LDS WgShared &wg_shared() { return *(LDS WgShared *)(lds_base() + (size_t)NW * sizeof(RdSmem)); }
 DEV LRegion &my_region(int which = 0) { return wg_shared().reg[wave_id()][which]; }
 DEV LDS Tables &tb() { return wg_shared().tab; }
+#ifndef HEVCDL_RMD_SLICE_ROUNDS
+#define HEVCDL_RMD_SLICE_ROUNDS 3      // rough mode decisions of this many rounds of 64 (mode, block) tasks or more are dealt to the workgroup's waves
+#endif
 #ifndef HEVCDL_SPEC_MARGIN
 #define HEVCDL_SPEC_MARGIN 0
 #endif
@@ -2085,25 +2088,43 @@ template <int B> DEV unsigned rmd_block(KR k, const LSmem &s, int mode, int pn, 
     return (sum + 1) >> 1;
   }
 }
-DEVN void rmd_satd(KR k, int x_, int y_, int pn_)
+// rounds [r0, r1) of the rough mode decision's (mode, block) tasks, 64 per round, of the PU at (x, y); the SATD sums go to acc.satd (the
+// owner's: integer atomics, any order).  The reference lines are the executing wave's (a helper copies the owner's first).
+DEVN void rmd_rounds(KR k, LSmem &acc, int x_, int y_, int pn_, int dcv_, int r0_, int r1_)
 {
-  PROF_T0();
-  const int x = uni(x_), y = uni(y_), pn = uni(pn_);
+  const int x = uni(x_), y = uni(y_), pn = uni(pn_), dcv = uni(dcv_), r0 = uni(r0_), r1 = uni(r1_);
   LSmem &s = lds();
   const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
-  if (lane_id() < 36) s.satd[lane_id()] = 0;
-  const int dcv = dc_value(k, s.line, pn);
-  wsync();
 #pragma unroll 1
-  for (int t0 = 0; t0 < ntask; t0 += 64) {
+  for (int t0 = r0 * 64; t0 < r1 * 64 && t0 < ntask; t0 += 64) {
     const int t = t0 + lane_id();
     if (t < ntask) {
       const int mode = t / nblk, blk = t - mode * nblk, bx = (blk % nbx) * b, by = (blk / nbx) * b;
       const unsigned sum = (b == 8) ? rmd_block<8>(k, s, mode, pn, log2n, x, y, bx, by, dcv) : rmd_block<4>(k, s, mode, pn, log2n, x, y, bx, by, dcv);
-      __hip_atomic_fetch_add(&s.satd[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&acc.satd[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   wsync();
+}
+DEVN void rmd_satd(KR k, const Cu cu_, const Tu ptu_)
+{
+  PROF_T0();
+  const Cu cu = ucu(cu_); const Tu ptu = utu(ptu_);
+  const int x = ptu.x, y = ptu.y, pn = 1 << ptu.log2;
+  LSmem &s = lds();
+  const int b = pn >= 8 ? 8 : 4, nbx = pn / b, ntask = 35 * nbx * nbx, nrounds = (ntask + 63) >> 6;
+  if (lane_id() < 36) s.satd[lane_id()] = 0;
+  const int dcv = dc_value(k, s.line, pn);
+  wsync();
+  if (nrounds >= HEVCDL_RMD_SLICE_ROUNDS && lds_load(&wg_shared().masters_active) < NW) {
+    // 16x16 PUs and larger (3 / 9 / 35 rounds) with waves without a unit in the workgroup: the rounds are dealt to them in up to NW slices
+    LRegion &r = my_region();
+    const int ntasks = nrounds < NW ? nrounds : NW;
+    wsync();
+    if (lane_id() == 0) { r.modes[0] = dcv; r.modes[1] = nrounds; }
+    region_open(r, T_RMD, ntasks, cu, ptu);
+    region_run(k, r);
+  } else rmd_rounds(k, s, x, y, pn, dcv, 0, nrounds);
   PROF_ADD(k, 2);
 }
 
@@ -2124,7 +2145,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     // ---- rough mode decision ----
     build_refs(k, 0, ptu.x, ptu.y, pn, 1);
     if (pn >= 8 && pn <= 32) filter_refs(k, pn);
-    rmd_satd(k, ptu.x, ptu.y, pn);
+    rmd_satd(k, cu, ptu);
     int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
     int nfull = c_num_rd_cand[pu_log2 - 2];
     { // mode bits (xModeBitsIntra :5530-5557): 3 possible values, from the [depth][CI_CURR_BEST] snapshot
@@ -2367,6 +2388,16 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
   const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
+  if (kind == T_RMD) { // a slice of the rough mode decision's rounds (rmd_satd): SATD sums into the owner's array, nothing else
+    const int nrounds = uni(r.modes[1]), ntasks = nrounds < NW ? nrounds : NW, per = (nrounds + ntasks - 1) / ntasks;
+    if (&s != &ow) { // the owner's gathered / smoothed reference lines
+      wsync();
+      for (int i = lane_id(); i < 66; i += 64) { ((LDS unsigned long long *)s.line)[i] = ((LDS const unsigned long long *)ow.line)[i]; ((LDS unsigned long long *)s.fline)[i] = ((LDS const unsigned long long *)ow.fline)[i]; }
+      wsync();
+    }
+    rmd_rounds(k, ow, tu.x, tu.y, 1 << tu.log2, uni(r.modes[0]), idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
+    return;
+  }
   PROF_TASK(kind != T_LUMA_P2);
   PROF_MARK0();
   const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
