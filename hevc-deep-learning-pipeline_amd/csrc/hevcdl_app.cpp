@@ -38,7 +38,7 @@ const Key KEYS[] = {
   { "QP", "q", USED, 0 },
   // extensions of this front end
   { "LabelDir", 0, USED, 0 }, { "BatchFrames", 0, USED, 0 }, { "Device", 0, USED, 0 }, { "Weights", 0, USED, 0 }, { "RecordFile", 0, USED, 0 },
-  { "CnnInput", 0, USED, 0 }, { "PrintConfig", 0, USED, 0 }, { "LoopFilterDisable", 0, USED, 0 },
+  { "CnnInput", 0, USED, 0 }, { "BnMode", 0, USED, 0 }, { "PrintConfig", 0, USED, 0 }, { "LoopFilterDisable", 0, USED, 0 },
   // keys that define the path: only the implemented value is accepted
   { "InputBitDepth", 0, USED, 0 }, { "InternalBitDepth", 0, USED, 0 }, { "InputChromaFormat", 0, PATH, "420" }, { "Profile", 0, USED, 0 },
   { "MaxCUWidth", 0, PATH, "64" }, { "MaxCUHeight", 0, PATH, "64" }, { "MaxPartitionDepth", 0, PATH, "4" },
@@ -186,6 +186,8 @@ int main(int argc, char **argv)
   if (input.empty()) opt.errors.push_back("InputFile (-i) is required");
   if (width <= 0 || height <= 0) opt.errors.push_back("SourceWidth / SourceHeight (-wdt / -hgt) are required");
   if (cnn_input != "rgb601" && cnn_input != "luma") opt.errors.push_back("CnnInput must be rgb601 or luma");
+  const std::string bn_mode = opt.get("BnMode", "reference");        // reference: training-mode BatchNorm as use_model.py runs it; eval: running statistics
+  if (bn_mode != "reference" && bn_mode != "eval") opt.errors.push_back("BnMode must be reference or eval");
   if (!opt.errors.empty()) { for (const auto &e : opt.errors) fprintf(stderr, "Error: %s\n", e.c_str()); return 2; }
 
   const size_t frame_bytes = hevcdl_frame_bytes_bd(width, height, bit_depth);
@@ -213,6 +215,7 @@ int main(int argc, char **argv)
     if (!tile_uniform) { for (int i = 0; i < tile_cols - 1; i++) cfg.tile_column_width[i] = tile_cw[i]; for (int i = 0; i < tile_rows - 1; i++) cfg.tile_row_height[i] = tile_rh[i]; }
   }
   cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
+  cfg.bn_mode = bn_mode == "eval" ? HEVCDL_BN_EVAL : HEVCDL_BN_REFERENCE;
   std::string wpath = opt.get("Weights");
   if (wpath.empty()) { // next to the library: <pkg>/weights/hevc_encoder_model.f32, this binary lives in <pkg>/bin
     std::string self = argv[0]; const size_t s1 = self.find_last_of('/'); self = s1 == std::string::npos ? "." : self.substr(0, s1);
