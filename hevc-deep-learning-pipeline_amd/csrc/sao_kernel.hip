@@ -456,6 +456,70 @@ __global__ __launch_bounds__(256) void hevcdl_sao_apply_kernel(hevcdl_sao_params
   }
 }
 
+// The same for 8-bit pictures with four samples per thread and step: dword loads of the row and of the two neighbouring rows / columns (served
+// by the vector L1), one dword store; adjacent lanes on adjacent dwords.  A CTU without offsets (mode off, or a type whose offsets are all 0) is a copy.
+__global__ __launch_bounds__(256) void hevcdl_sao_apply8_kernel(hevcdl_sao_params p)
+{
+  const int tid = threadIdx.x, a = blockIdx.x, comp = blockIdx.y, frame = blockIdx.z;
+  const hevcdl_sao_offset GLB &prm = ((const hevcdl_sao_blk GLB *)p.recon_params)[(size_t)frame * p.ctus_per_frame + a].c[comp];
+  const int cx = p.ctus_x, x0 = (a % cx) * 64, y0 = (a / cx) * 64;
+  const int wl = x0 + 64 > p.width ? p.width - x0 : 64, hl = y0 + 64 > p.height ? p.height - y0 : 64;
+  const int sh = comp ? 1 : 0, stride = p.width >> sh, w = wl >> sh, h = hl >> sh, wd = w >> 2;
+  const size_t ysz = (size_t)p.width * p.height, fsz = ysz + (ysz >> 1);
+  const size_t plane = (size_t)frame * fsz + (comp == 0 ? 0 : (comp == 1 ? ysz : ysz + (ysz >> 2)));
+  const size_t plane_bytes = comp == 0 ? ysz : (ysz >> 2);
+  const size_t off = (size_t)(y0 >> sh) * stride + (x0 >> sh);
+  const uint8_t GLB *pl = (const uint8_t GLB *)p.deblocked + plane; uint8_t GLB *res = (uint8_t GLB *)p.out + plane;
+  const int mode = prm.mode, type = prm.type;
+  __shared__ int offs[32];
+  if (tid < 32) offs[tid] = (mode != MODE_OFF && (type == BO || tid < 5)) ? prm.offset[tid] : 0;
+  __syncthreads();
+  const bool need_lr = (type == EO_0 || type == EO_135 || type == EO_45), need_ab = (type == EO_90 || type == EO_135 || type == EO_45);
+  int left, right, above, below; sao_neighbours(p, a, 0, left, right, above, below);
+  const int sx = (need_lr && !left) ? 1 : 0, ex = (need_lr && !right) ? w - 1 : w;
+  const int sy = (need_ab && !above) ? 1 : 0, ey = (need_ab && !below) ? h - 1 : h;
+  // dword at sample offset o of the plane; o is clamped into the plane (a clamped dword only ever feeds samples outside [sx, ex) x [sy, ey))
+  auto ld = [&](long long o) -> uint32_t { o = o < 0 ? 0 : (o > (long long)plane_bytes - 4 ? (long long)plane_bytes - 4 : o); return *(const uint32_t GLB *)(pl + o); };
+  const int dx = type == EO_135 ? -1 : (type == EO_45 ? 1 : 0);      // column of the neighbour in the row above (the one below: -dx)
+  for (int i = tid; i < wd * h; i += 256) {
+    const int y = i / wd, xd = i - y * wd;
+    const long long o = (long long)off + (long long)y * stride + 4 * xd;
+    const uint32_t c4 = ld(o);
+    uint32_t out = c4;
+    if (mode != MODE_OFF && y >= sy && y < ey) {
+      int cls[4];
+      if (type == BO) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cls[k] = (int)((c4 >> (8 * k + 3)) & 31u);
+      } else {
+        // the 6 samples left neighbour .. right neighbour of the row holding the first neighbour (n0) and of the row holding the second (n1)
+        unsigned long long r0, r1;
+        if (type == EO_0) { r0 = r1 = ((unsigned long long)ld(o + 4) << 40) | ((unsigned long long)c4 << 8) | (ld(o - 4) >> 24); }
+        else {
+          const long long ou = o - stride, od = o + stride;
+          r0 = ((unsigned long long)ld(ou + 4) << 40) | ((unsigned long long)ld(ou) << 8) | (ld(ou - 4) >> 24);
+          r1 = ((unsigned long long)ld(od + 4) << 40) | ((unsigned long long)ld(od) << 8) | (ld(od - 4) >> 24);
+        }
+        // byte j of r = sample 4 xd - 1 + j of that row
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int c0 = (int)((c4 >> (8 * k)) & 255u);
+          const int n0 = (int)((r0 >> (8 * (k + 1 + (type == EO_0 ? -1 : dx)))) & 255u), n1 = (int)((r1 >> (8 * (k + 1 + (type == EO_0 ? 1 : -dx)))) & 255u);
+          cls[k] = 2 + sgn(c0 - n0) + sgn(c0 - n1);
+        }
+      }
+      out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = 4 * xd + k, c0 = (int)((c4 >> (8 * k)) & 255u);
+        const int v = (x >= sx && x < ex) ? clipbd(c0 + offs[cls[k]], 255) : c0;
+        out |= (uint32_t)v << (8 * k);
+      }
+    }
+    *(uint32_t GLB *)(res + o) = out;
+  }
+}
+
 extern "C" void hevcdl_launch_sao(const hevcdl_sao_params *pp, void *stream)
 {
   const hevcdl_sao_params p = *pp;
@@ -466,6 +530,6 @@ extern "C" void hevcdl_launch_sao(const hevcdl_sao_params *pp, void *stream)
   const size_t n_cand = (size_t)p.n_frames * p.ctus_per_frame * 3 * NTYPES;
   hipLaunchKernelGGL(hevcdl_sao_offsets_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(hevcdl_sao_decide_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
-  if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint8_t>, per_ctu, dim3(256), 0, s, p);
+  if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_apply8_kernel, per_ctu, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint16_t>, per_ctu, dim3(256), 0, s, p);
 }
