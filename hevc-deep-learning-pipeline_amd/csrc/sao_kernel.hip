@@ -199,11 +199,12 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params
     tile[r][c] = *(const uint32_t GLB *)(src + (size_t)yy * stride + xx);
   }
   __syncthreads();
-  int eo_d[4][5], eo_c[4][5];
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-#pragma unroll
-    for (int k = 0; k < 5; k++) { eo_d[t][k] = 0; eo_c[t][k] = 0; }
+  // Per-thread edge statistics in packed fields (a thread sees at most 16 samples of a 64x64 block): counts of the five classes in 6-bit
+  // fields of one word; sums of (difference + 256) of classes 0..3 in 13-bit fields of a 64-bit word (16 * 511 < 8192; a class-4 sample
+  // lands above them and can only carry upwards), class 4 in a word of its own.  One shift-and-add per sample and type instead of five
+  // compare-and-adds; unpacked once after the loop.
+  uint32_t pc[4] = { 0, 0, 0, 0 }, pd4[4] = { 0, 0, 0, 0 };
+  unsigned long long pd[4] = { 0, 0, 0, 0 };
   for (int i = tid; i < h * wd; i += 256) {
     const int y = i / wd, xd = i - y * wd;
     const uint32_t o4 = *(const uint32_t GLB *)(org + (size_t)(by + y) * stride + bx + xd * 4);
@@ -227,8 +228,10 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params
             const int n0 = t == EO_0 ? px(1, k - 1) : (t == EO_90 ? px(0, k) : (t == EO_135 ? px(0, k - 1) : px(0, k + 1)));
             const int n1 = t == EO_0 ? px(1, k + 1) : (t == EO_90 ? px(2, k) : (t == EO_135 ? px(2, k + 1) : px(2, k - 1)));
             const int cls = 2 + sgn(c0 - n0) + sgn(c0 - n1);
-#pragma unroll
-            for (int q = 0; q < 5; q++) { eo_c[t < 4 ? t : 0][q] += (cls == q); eo_d[t < 4 ? t : 0][q] += (cls == q) ? d : 0; }
+            const int tt = t < 4 ? t : 0;
+            pc[tt] += 1u << (6 * cls);
+            pd[tt] += (unsigned long long)(uint32_t)(d + 256) << (13 * cls);
+            pd4[tt] += cls == 4 ? (uint32_t)(d + 256) : 0u;
           }
         }
       }
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats_kernel(hevcdl_sao_params
   for (int t = 0; t < 4; t++)
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      int vd = eo_d[t][k], vc = eo_c[t][k];
+      int vc = (int)((pc[t] >> (6 * k)) & 63u);
+      int vd = (k < 4 ? (int)((pd[t] >> (13 * k)) & 8191ull) : (int)pd4[t]) - 256 * vc;
       vd += __builtin_amdgcn_update_dpp(0, vd, 0xB1, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0xB1, 0xf, 0xf, false);
       vd += __builtin_amdgcn_update_dpp(0, vd, 0x4E, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x4E, 0xf, 0xf, false);
       vd += __builtin_amdgcn_update_dpp(0, vd, 0x141, 0xf, 0xf, false); vc += __builtin_amdgcn_update_dpp(0, vc, 0x141, 0xf, 0xf, false);
