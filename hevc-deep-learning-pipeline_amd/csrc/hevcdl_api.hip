@@ -613,10 +613,10 @@ extern "C" hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_or
   const size_t nf = (size_t)ctx->cfg.max_frames;
   if (!ctx->d_sao_stats) HIPCHK(hipMalloc(&ctx->d_sao_stats, (size_t)ctx->ctus * 3 * 5 * 256 * nf));
   if (!ctx->d_sao_recon) HIPCHK(hipMalloc(&ctx->d_sao_recon, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * nf));
-  if (!ctx->d_sao_cand) HIPCHK(hipMalloc(&ctx->d_sao_cand, (size_t)ctx->ctus * 3 * 5 * 48 * nf));
+  if (!ctx->d_sao_cand) HIPCHK(hipMalloc(&ctx->d_sao_cand, (size_t)ctx->ctus * (3 * 5 * 16 + 32) * nf));      // candidates, then the chain's records
   hevcdl_sao_params p;
   p.org = (const uint8_t *)d_org; p.deblocked = (const uint8_t *)d_deblocked; p.out = (uint8_t *)d_out;
-  p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon; p.cand = ctx->d_sao_cand;
+  p.stats = ctx->d_sao_stats; p.params = (unsigned char *)d_params; p.recon_params = ctx->d_sao_recon; p.cand = ctx->d_sao_cand; p.crec = ctx->d_sao_cand + (size_t)ctx->ctus * 3 * 5 * 16 * nf;
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames; p.qp = ctx->cfg.qp;
   p.lambda = ctx->cfg.lambda; p.lambda_chroma = ctx->cfg.lambda_chroma;          // slice lambdas per component, TEncSlice.cpp:112-140
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows; p.bit_depth = ctx->cfg.bit_depth; p.lf_across_tiles = ctx->cfg.lf_across_tiles != 0;

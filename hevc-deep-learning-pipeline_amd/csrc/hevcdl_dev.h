@@ -87,7 +87,8 @@ struct hevcdl_sao_params {
   unsigned char *stats;            // [frame][ctu][3][5] {int32 diff[32], count[32]}  (3840 bytes per CTU)
   unsigned char *params;           // [frame][ctu] hevcdl_sao_blk: coded parameters
   unsigned char *recon_params;     // [frame][ctu] hevcdl_sao_blk: merge candidates resolved
-  unsigned char *cand;             // [frame][ctu][3][5] candidate offsets of every type {int8 offset[32], int32 aux, pad, int64 distortion} (720 bytes per CTU)
+  unsigned char *cand;             // [frame][ctu][3][5] candidate offsets of every type {int8 offset[4], int32 aux, int64 distortion} (240 bytes per CTU)
+  unsigned char *crec;             // [frame][ctu] the decision chain's compact record (32 bytes), expanded into params / recon_params afterwards
   int width, height, ctus_x, ctus_per_frame, n_frames, qp;
   int tile_cols, tile_rows;        // merge candidates stay inside a tile
   int col_bd[21], row_bd[23];      // tile boundaries in CTUs

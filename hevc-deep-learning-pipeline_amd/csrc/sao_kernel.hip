@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void hevcdl_sao_stats16_kernel(hevcdl_sao_para
 }
 
 // Candidate offsets of every (picture, CTU, component, type): deriveOffsets + getDistortion depend on the statistics and lambda only -- not on the
-// coder state or the neighbours' decisions that chain the CTUs of a picture -- so they run ahead of the chain, one thread each.
-struct Cand { int8_t off[32]; int32_t aux, pad; long long dist; };      // 48 bytes, same order as the statistics
+// coder state or the neighbours' decisions that chain the CTUs of a picture -- so they run ahead of the chain, one thread each.  A set of offsets
+// has at most four nonzero entries (edge classes 0, 1, 3, 4; the four bands from the band position on): that is how the chain carries it.
+struct Cand { int8_t off[4]; int32_t aux; long long dist; };          // 16 bytes, same order as the statistics
+struct Cmp { int mode, type, aux, off[4]; };                            // one component's parameters in the chain (registers)
+struct CRec { uint32_t hdr[3], off[3]; int32_t merge; uint32_t pad; };  // what the chain leaves per CTU: resolved parameters (mode | type << 8 | aux << 16, four int8 offsets) + merge direction or -1
 __global__ __launch_bounds__(256) void hevcdl_sao_offsets_kernel(hevcdl_sao_params p)
 {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)p.n_frames * p.ctus_per_frame * 3 * NTYPES;
@@ -333,11 +336,46 @@ __global__ __launch_bounds__(256) void hevcdl_sao_offsets_kernel(hevcdl_sao_para
   int32_t q[32], aux;
   derive_offsets(type, comp ? p.lambda_chroma : p.lambda, st, q, aux, bd);
   Cand GLB &c = ((Cand GLB *)p.cand)[idx];
-  for (int i = 0; i < 32; i++) c.off[i] = (int8_t)q[i];
-  c.aux = aux; c.pad = 0; c.dist = get_dist(type, aux, q, st, bd);
+  for (int i = 0; i < 4; i++) c.off[i] = (int8_t)(type == BO ? q[(aux + i) & 31] : q[i < 2 ? i : i + 1]);
+  c.aux = aux; c.dist = get_dist(type, aux, q, st, bd);
 }
 
-// one lane per picture: the CTU chain of decideBlkParams
+__device__ void code_offset_cmp(Sbac &c, int comp, const Cmp &p, const Bd &bd)
+{ // codeSAOOffsetParam TEncSbac.cpp:1605-1681 on the compact form
+  const int first = comp != 2;
+  if (first) {
+    const int sym = p.mode == MODE_OFF ? 0 : (p.type == BO ? 1 : 2);
+    if (sym == 0) sb_bin(c, c.type_ctx, 0); else { sb_bin(c, c.type_ctx, 1); sb_ep(c, 1); }
+  }
+  if (p.mode == MODE_NEW) {
+    for (int i = 0; i < 4; i++) { const int a = abs(p.off[i]); sb_ep(c, a == 0 ? 1 : (a < bd.max_off ? a + 1 : a)); }
+    if (p.type == BO) { for (int i = 0; i < 4; i++) if (p.off[i]) sb_ep(c, 1); sb_ep(c, 5); }
+    else if (first) sb_ep(c, 2);
+  }
+}
+__device__ void code_blk_cmp(Sbac &c, const Cmp (&b)[3], int left_avail, int above_avail, int only_merge, const Bd &bd)
+{ // codeSAOBlkParam TEncSbac.cpp:1683-1720
+  int is_left = 0, is_above = 0;
+  if (left_avail) { is_left = b[0].mode == MODE_MERGE && b[0].type == MERGE_LEFT; sb_bin(c, c.merge_ctx, is_left); }
+  if (above_avail && !is_left) { is_above = b[0].mode == MODE_MERGE && b[0].type == MERGE_ABOVE; sb_bin(c, c.merge_ctx, is_above); }
+  if (only_merge) return;
+  if (!is_left && !is_above) for (int comp = 0; comp < 3; comp++) code_offset_cmp(c, comp, b[comp], bd);
+}
+__device__ long long get_dist_cmp(int type, int aux, const int (&off)[4], const Stat GLB &st, const Bd &bd)
+{ // getDistortion :421-457 (an edge class 2 / a band outside the four has offset 0 and adds nothing)
+  long long d = 0;
+  for (int i = 0; i < 4; i++) { const int k = type == BO ? (aux + i) & 31 : (i < 2 ? i : i + 1); d += est_dist(st.count[k], off[i], st.diff[k], bd); }
+  return d;
+}
+__device__ void crec_get(const CRec GLB &r, int c, Cmp &o)
+{
+  const uint32_t h = r.hdr[c], f = r.off[c];
+  o.mode = (int)(h & 255u); o.type = (int)((h >> 8) & 255u); o.aux = (int)(h >> 16);
+  for (int i = 0; i < 4; i++) o.off[i] = (int)(int8_t)((f >> (8 * i)) & 255u);
+}
+
+// one lane per picture: the CTU chain of decideBlkParams.  Everything it carries is compact (Cmp / CRec): the 32-entry parameter blocks of
+// the interface are written afterwards by hevcdl_sao_expand_kernel, in parallel.
 __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params p)
 {
   const int frame = blockIdx.x * 64 + threadIdx.x;
@@ -346,8 +384,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
   const double lambda[3] = { p.lambda, p.lambda_chroma, p.lambda_chroma };
   const Bd bd = { (1 << ((p.bit_depth < 10 ? p.bit_depth : 10) - 5)) - 1, 2 * (p.bit_depth - 8), p.bit_depth - 8 };
   const Stat GLB *stats = (const Stat GLB *)p.stats + (size_t)frame * nctu * 3 * NTYPES;
-  hevcdl_sao_blk GLB *params = (hevcdl_sao_blk GLB *)p.params + (size_t)frame * nctu;      // coded parameters
-  hevcdl_sao_blk GLB *recon = (hevcdl_sao_blk GLB *)p.recon_params + (size_t)frame * nctu; // reconstructed (merge resolved)
+  CRec GLB *crec = (CRec GLB *)p.crec + (size_t)frame * nctu;
   Sbac go, cur, next, mid, temp;
   { // initRDOCabacCoder: I-slice contexts at the slice QP (ContextTables.h:445-458)
     const int init[2] = { 153, 200 };
@@ -360,6 +397,7 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
     go.frac = 0;
   }
   next = go;
+  const Cmp off_cmp = { MODE_OFF, 0, 0, { 0, 0, 0, 0 } };
   for (int a = 0; a < nctu; a++) {
     const Stat GLB *st = stats + (size_t)a * 3 * NTYPES;
     const Cand GLB *cand = (const Cand GLB *)p.cand + ((size_t)frame * nctu + a) * 3 * NTYPES;      // hevcdl_sao_offsets_kernel
@@ -367,66 +405,93 @@ __global__ __launch_bounds__(64) void hevcdl_sao_decide_kernel(hevcdl_sao_params
     bool left_av = true, above_av = true;
     for (int t = 0; t < p.tile_cols; t++) if (p.col_bd[t] == a % cx) left_av = false;
     for (int t = 0; t < p.tile_rows; t++) if (p.row_bd[t] == a / cx) above_av = false;
-    hevcdl_sao_blk best, mode;
+    Cmp best[3], mode[3];
+    int best_merge = -1;
     double min_cost = MAX_DOUBLE;
     cur = go;
+    auto take = [&](Cmp &d, int type, const Cand GLB &cd) { d.mode = MODE_NEW; d.type = type; d.aux = cd.aux; for (int i = 0; i < 4; i++) d.off[i] = cd.off[i]; };
     { // ---- deriveModeNewRDO :617-758 ----
-      hevcdl_sao_offset test[3];
+      Cmp test[3];
       long long dist[3], mode_dist[3] = { 0, 0, 0 };
-      for (int c = 0; c < 3; c++) { mode.c[c].mode = MODE_OFF; mode.c[c].type = 0; mode.c[c].aux = 0; for (int i = 0; i < 32; i++) mode.c[c].offset[i] = 0; }
-      go = cur; code_blk_param(go, mode, left_av, above_av, 1, bd); mid = go;
-      sb_reset(go); code_offset_param(go, 0, mode.c[0], bd);
+      for (int c = 0; c < 3; c++) mode[c] = off_cmp;
+      go = cur; code_blk_cmp(go, mode, left_av, above_av, 1, bd); mid = go;
+      sb_reset(go); code_offset_cmp(go, 0, mode[0], bd);
       double mc = lambda[0] * (double)sb_bits(go), cost;
       temp = go;
       for (int type = 0; type < NTYPES; type++) {
-        test[0].mode = MODE_NEW; test[0].type = type;
-        { const Cand GLB &cd = cand[0 * NTYPES + type]; for (int i = 0; i < 32; i++) test[0].offset[i] = cd.off[i]; test[0].aux = cd.aux; dist[0] = cd.dist; }
-        go = mid; sb_reset(go); code_offset_param(go, 0, test[0], bd);
+        take(test[0], type, cand[0 * NTYPES + type]); dist[0] = cand[0 * NTYPES + type].dist;
+        go = mid; sb_reset(go); code_offset_cmp(go, 0, test[0], bd);
         cost = (double)dist[0] + lambda[0] * (double)(int)sb_bits(go);
-        if (cost < mc) { mc = cost; mode_dist[0] = dist[0]; mode.c[0] = test[0]; temp = go; }
+        if (cost < mc) { mc = cost; mode_dist[0] = dist[0]; mode[0] = test[0]; temp = go; }
       }
       go = temp; mid = go;
       cost = 0; sb_reset(go);
-      { uint32_t prev = 0; for (int c = 1; c < 3; c++) { code_offset_param(go, c, mode.c[c], bd); const uint32_t b = sb_bits(go); cost += lambda[c] * (double)(b - prev); prev = b; } }
+      { uint32_t prev = 0; for (int c = 1; c < 3; c++) { code_offset_cmp(go, c, mode[c], bd); const uint32_t b = sb_bits(go); cost += lambda[c] * (double)(b - prev); prev = b; } }
       mc = cost;
       for (int type = 0; type < NTYPES; type++) {
         uint32_t prev = 0;
         go = mid; sb_reset(go); cost = 0;
         for (int c = 1; c < 3; c++) {
-          test[c].mode = MODE_NEW; test[c].type = type;
-          { const Cand GLB &cd = cand[c * NTYPES + type]; for (int i = 0; i < 32; i++) test[c].offset[i] = cd.off[i]; test[c].aux = cd.aux; dist[c] = cd.dist; }
-          code_offset_param(go, c, test[c], bd);
+          take(test[c], type, cand[c * NTYPES + type]); dist[c] = cand[c * NTYPES + type].dist;
+          code_offset_cmp(go, c, test[c], bd);
           const uint32_t b = sb_bits(go);
           cost += (double)dist[c] + (lambda[c] * (double)(b - prev));
           prev = b;
         }
-        if (cost < mc) { mc = cost; for (int c = 1; c < 3; c++) { mode_dist[c] = dist[c]; mode.c[c] = test[c]; } }
+        if (cost < mc) { mc = cost; for (int c = 1; c < 3; c++) { mode_dist[c] = dist[c]; mode[c] = test[c]; } }
       }
       double norm = 0;
       for (int c = 0; c < 3; c++) norm += (double)mode_dist[c] / lambda[c];
-      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0, bd);
+      go = cur; sb_reset(go); code_blk_cmp(go, mode, left_av, above_av, 0, bd);
       norm += (double)sb_bits(go);
-      if (norm < min_cost) { min_cost = norm; best = mode; next = go; }
+      if (norm < min_cost) { min_cost = norm; for (int c = 0; c < 3; c++) best[c] = mode[c]; best_merge = -1; next = go; }
     }
     // ---- deriveModeMergeRDO :760-812 ----
     for (int mt = 0; mt < 2; mt++) {
       if (!(mt == MERGE_LEFT ? left_av : above_av)) continue;
-      const hevcdl_sao_blk GLB &m = recon[mt == MERGE_LEFT ? a - 1 : a - cx];
+      const CRec GLB &m = crec[mt == MERGE_LEFT ? a - 1 : a - cx];          // the neighbour's resolved parameters
+      Cmp res[3];
       double nd = 0;
       for (int c = 0; c < 3; c++) {
-        load_off(mode.c[c], m.c[c]);
-        if (m.c[c].mode != MODE_OFF) nd += ((double)get_dist(m.c[c].type, m.c[c].aux, mode.c[c].offset, st[c * NTYPES + m.c[c].type], bd)) / lambda[c];
-        mode.c[c].mode = MODE_MERGE; mode.c[c].type = mt;
+        crec_get(m, c, res[c]);
+        if (res[c].mode != MODE_OFF) nd += ((double)get_dist_cmp(res[c].type, res[c].aux, res[c].off, st[c * NTYPES + res[c].type], bd)) / lambda[c];
+        mode[c] = res[c]; mode[c].mode = MODE_MERGE; mode[c].type = mt;
       }
-      go = cur; sb_reset(go); code_blk_param(go, mode, left_av, above_av, 0, bd);
+      go = cur; sb_reset(go); code_blk_cmp(go, mode, left_av, above_av, 0, bd);
       const double cost = nd + (double)(int)sb_bits(go);
-      if (cost < min_cost) { min_cost = cost; best = mode; next = go; }
+      if (cost < min_cost) { min_cost = cost; for (int c = 0; c < 3; c++) best[c] = res[c]; best_merge = mt; next = go; }
     }
     go = next;
-    for (int c = 0; c < 3; c++) store_off(params[a].c[c], best.c[c]);
-    for (int c = 0; c < 3; c++) { // reconstructBlkSAOParam (offset step 1)
-      if (best.c[c].mode == MODE_MERGE) { hevcdl_sao_offset t; load_off(t, recon[best.c[c].type == MERGE_LEFT ? a - 1 : a - cx].c[c]); store_off(recon[a].c[c], t); }
-      else store_off(recon[a].c[c], best.c[c]);
+    CRec out;                                                              // reconstructBlkSAOParam: a merged CTU carries the neighbour's parameters
+    for (int c = 0; c < 3; c++) {
+      out.hdr[c] = (uint32_t)best[c].mode | ((uint32_t)best[c].type << 8) | ((uint32_t)best[c].aux << 16);
+      out.off[c] = ((uint32_t)best[c].off[0] & 255u) | (((uint32_t)best[c].off[1] & 255u) << 8) | (((uint32_t)best[c].off[2] & 255u) << 16) | (((uint32_t)best[c].off[3] & 255u) << 24);
+    }
+    out.merge = best_merge; out.pad = 0;
+    { CRec GLB &dst = crec[a]; for (int c = 0; c < 3; c++) { dst.hdr[c] = out.hdr[c]; dst.off[c] = out.off[c]; } dst.merge = out.merge; dst.pad = 0; }
+  }
+}
+
+// The interface's parameter blocks from the chain's compact records, one thread per (picture, CTU): coded parameters (a merged CTU: mode
+// MERGE + direction, offsets of the candidate as the reference's SAOBlkParam holds them) and the resolved ones the reconstruction reads.
+__global__ __launch_bounds__(256) void hevcdl_sao_expand_kernel(hevcdl_sao_params p)
+{
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)p.n_frames * p.ctus_per_frame;
+  if (idx >= total) return;
+  const CRec GLB &r = ((const CRec GLB *)p.crec)[idx];
+  hevcdl_sao_blk GLB &par = ((hevcdl_sao_blk GLB *)p.params)[idx], &rec = ((hevcdl_sao_blk GLB *)p.recon_params)[idx];
+  const int merge = r.merge;
+  for (int c = 0; c < 3; c++) {
+    Cmp v; crec_get(r, c, v);
+    rec.c[c].mode = v.mode; rec.c[c].type = v.type; rec.c[c].aux = v.aux;
+    par.c[c].mode = merge >= 0 ? MODE_MERGE : v.mode; par.c[c].type = merge >= 0 ? merge : v.type; par.c[c].aux = v.aux;
+    for (int i = 0; i < 32; i++) {
+      int o = 0;
+      if (v.mode != MODE_OFF) {
+        if (v.type == BO) { const int k = (i - v.aux) & 31; if (k < 4) o = v.off[k]; }
+        else if (i < 5 && i != 2) o = v.off[i < 2 ? i : i - 1];
+      }
+      rec.c[c].offset[i] = o; par.c[c].offset[i] = o;
     }
   }
 }
@@ -534,6 +599,8 @@ extern "C" void hevcdl_launch_sao(const hevcdl_sao_params *pp, void *stream)
   const size_t n_cand = (size_t)p.n_frames * p.ctus_per_frame * 3 * NTYPES;
   hipLaunchKernelGGL(hevcdl_sao_offsets_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(hevcdl_sao_decide_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
+  const size_t n_ctu = (size_t)p.n_frames * p.ctus_per_frame;
+  hipLaunchKernelGGL(hevcdl_sao_expand_kernel, dim3((unsigned)((n_ctu + 255) / 256)), dim3(256), 0, s, p);
   if (p.bit_depth == 8) hipLaunchKernelGGL(hevcdl_sao_apply8_kernel, per_ctu, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(hevcdl_sao_apply_kernel<uint16_t>, per_ctu, dim3(256), 0, s, p);
 }
