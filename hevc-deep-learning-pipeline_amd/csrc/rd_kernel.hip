@@ -49,6 +49,11 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #ifndef HEVCDL_NW
 #define HEVCDL_NW 8
 #endif
+#ifdef HEVCDL_RDOQ_V1
+#define HEVCDL_RDOQ rdoq_lane0
+#else
+#define HEVCDL_RDOQ rdoq_wave
+#endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
 constexpr int NSLOT = 15;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
@@ -61,6 +66,7 @@ constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE *
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
 constexpr int SCR_WAVE = SCR_LAYERS + SCR_RDOQ + NSLOT * SLOT_BYTES;
+constexpr int RQ_ROWS = BD == 8 ? 4 : 2;                       // coefficient groups RDOQ decides side by side (one per row of 16 lanes; the 10-bit kernel has LDS for two)
 constexpr int SSE_SH = 2 * (BD - 8), HAD_SH = BD - 8;         // DISTORTION_PRECISION_ADJUSTMENT: per squared sample / per Hadamard sum
 
 #define DEV __device__ __forceinline__
@@ -197,11 +203,11 @@ struct __attribute__((aligned(16))) RdSmem {
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
-  unsigned long long prof[HEVCDL_BD == 8 ? 56 : 40]; unsigned int prof_n[HEVCDL_BD == 8 ? 56 : 40]; int prof_task, prof_pad;     // (the 10-bit build has no LDS to spare: its profiling build keeps the first 40 timers)
+  unsigned long long prof[HEVCDL_BD == 8 ? 64 : 40]; unsigned int prof_n[HEVCDL_BD == 8 ? 64 : 40]; int prof_task, prof_pad;     // (the 10-bit build has no LDS to spare: its profiling build keeps the first 40 timers)
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   union {
-    double chain[5][17];              // RDOQ per-position addends of the five ordered sums (rows padded)
+    double chain[5][RQ_ROWS * 16 + 1];   // RDOQ per-position addends of the five ordered sums, one batch of coefficient groups (rows padded)
     double zb[2][64];                 // RDOQ, run of all-zero groups: zero-level costs / significance costs of 4 groups
     struct { double rmd_cost[36]; unsigned int satd[36]; };   // rough mode decision (never live during RDOQ)
   };
@@ -786,6 +792,22 @@ DEV int sig_ctx_inc(const CParam &cp, const ScanFn &scan, int pat, int scan_pos)
   }
   return cp.first_sig_ctx + offset;
 }
+DEV int sig_ctx_inc_xy(const CParam &cp, int pat, int px, int py)
+{ // sig_ctx_inc from the block coordinates of the position
+  if (px + py == 0) return 0;
+  int offset;
+  if (cp.log2 == 2) offset = tb().t_ctx_map4[4 * py + px];
+  else {
+    int cnt; const int xs = px & 3, ys = py & 3;
+    if (pat == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
+    else if (pat == 1) cnt = (ys >= 2) ? 0 : ((ys >= 1) ? 1 : 2);
+    else if (pat == 2) cnt = (xs >= 2) ? 0 : ((xs >= 1) ? 1 : 2);
+    else cnt = 2;
+    const int not_first = ((px >> 2) + (py >> 2)) > 0;
+    offset = (not_first ? (cp.ch ? 0 : 3) : 0) + cnt;
+  }
+  return cp.first_sig_ctx + offset;
+}
 DEV ScanFn scan_of(const LSmem &s, int type, int log2n)
 {
   ScanFn f; f.cg = tb().scan_cg_all[type] + (log2n == 2 ? 0 : (log2n == 3 ? 1 : (log2n == 4 ? 5 : 21))); f.in = tb().scan_in_cg[type]; f.log2n = log2n; f.l = log2n - 2;
@@ -1263,6 +1285,444 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
   return (uint32_t)uni((int)abs_sum);
 }
 
+// RDOQ, whole wave, coefficient groups in batches (the version the kernel uses; rdoq_lane0 above is the group-by-group form it grew out of, kept
+// for A/B runs under HEVCDL_RDOQ_V1).  s->tc -> s->lvl ; returns uiAbsSum.  Same arithmetic, same order of every fp64 sum as the reference
+// (TComTrQuant.cpp:2119-2661); what changes is how the work inside phase B is laid out:
+//   * What a group's level decisions depend on: its own positions (the c1 / c2 / Rice state machine runs inside a group and starts afresh in
+//     each), the context set (one carried bit: did the previous group in scan order end with c1 == 0), and the significance pattern (are the
+//     groups to the right / below significant AFTER their own RDOQ).  They do NOT depend on the running cost sums.  So up to RQ_ROWS consecutive
+//     groups are decided side by side, one per row of 16 lanes, when (a) none of them has a not-yet-final neighbour inside the batch -- groups
+//     of one anti-diagonal never are neighbours, groups without a rounded level are final (insignificant) from the start -- and (b) the carried
+//     bit of every row but the first is known beforehand: a group whose largest rounded level is >= 3 keeps a level > 1 (the candidates are
+//     the rounded level and one below), one whose largest is <= 1 cannot have any; only "largest == 2" ends a batch.
+//   * Inside a row the state a position sees is a fold over the decided levels above it (counts of levels, of levels > 1, of levels == 1;
+//     the Rice parameter only moves when a level > 3 exists).  Every lane evaluates xGetCodedLevel for its own position under the state the
+//     current levels imply, starting from the rounded levels; the levels are re-derived until nothing changes.  The system is triangular (a
+//     position only depends on higher scan positions), so the fixed point is the sequential result; it is reached after one pass more than
+//     the number of decisions that differ from the guess (typically 2 passes for the whole batch instead of one serial visit per level).
+//   * The ordered sums and the group-level tests (zero-out of a group, TComTrQuant.cpp:2385-2440) then run group by group in scan order,
+//     addends transposed through LDS once per batch.
+DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
+{
+  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
+  LSmem &s = lds();
+  const int lane = lane_id();
+  const int ch = c ? 1 : 0, log2n = ilog2(n);
+  const int qp = uni(c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;      // + qpBdOffset (TComTrQuant.cpp:71-100)
+  const int tshift = 15 - BD - log2n, qbits = 14 + per + tshift;
+  const double lambda = c ? k.lambda_c : k.lambda;
+  const double err_scale = k.err_scale[ch][log2n - 2];
+  const int qcoef = uni(c_quant_scales[rem]);
+  const int ncoef = n * n;
+  CParam cp; get_cparam(cp, c, n, dir_mode);
+  const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
+  LDS const int16_t *src = s.tc; LDS int16_t *dst = s.lvl;
+  const bool qlds = n <= 8;                          // per-position outputs: behind the coefficients in LDS up to 8x8, the wave's HBM workspace above (see rdoq_lane0)
+  GLB double *gq_cost = k.q_cost; GLB int32_t *gq_rate = k.q_rate;
+  LDS double *lq_cost = (LDS double *)((LDS char *)s.tc + 2 * ncoef); LDS int32_t *lq_rate = (LDS int32_t *)(lq_cost + 2 * ncoef);
+  enum { Q_COEFF = 0, Q_SIG = 1, Q_UP = 0, Q_DOWN = 1, Q_SIGDELTA = 2, Q_DELTAU = 3 };
+  auto q_cost_st = [&](int a, int i, double v) { if (qlds) lq_cost[a * ncoef + i] = v; else gq_cost[a * 1024 + i] = v; };
+  auto q_cost_ld = [&](int a, int i) -> double { double v; if (qlds) v = lq_cost[a * ncoef + i]; else v = gq_cost[a * 1024 + i]; return v; };
+  auto q_rate_st = [&](int a, int i, int32_t v) { if (qlds) lq_rate[a * ncoef + i] = v; else gq_rate[a * 1024 + i] = v; };
+  auto q_rate_ld = [&](int a, int i) -> int32_t { int32_t v; if (qlds) v = lq_rate[a * ncoef + i]; else v = gq_rate[a * 1024 + i]; return v; };
+  LDS double *cost_cg_sig = s.cg_cost;
+  auto level_double = [&](int blk) -> int32_t {
+    const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
+    return (int32_t)(tmpl < lim ? tmpl : lim);
+  };
+  auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
+#ifdef HEVCDL_KERNEL_PROF
+  unsigned long long pt_ = __builtin_readcyclecounter();
+#endif
+  // ---- phase A: rounded levels; per group (bit = its index in scan order): any level, any level > 1, any level > 2 ----
+  unsigned long long cg_nz = 0, cg_ge2 = 0, cg_ge3 = 0;
+  int last_pos = -1;
+  for (int base = 0; base < ncoef; base += 64) {
+    const int sp = base + lane;
+    int ma = 0;
+    if (sp < ncoef) {
+      const int blk = scan[sp];
+      const int32_t ld = level_double(blk);
+      uint32_t m = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
+      if (m > 32767u) m = 32767u;
+      dst[blk] = (int16_t)m; ma = (int)m;
+    }
+    const unsigned long long b1 = __ballot(ma > 0), b2 = __ballot(ma > 1), b3 = __ballot(ma > 2);
+    if (b1) last_pos = base + 63 - __clzll((long long)b1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int g = (base >> 4) + r;
+      if ((b1 >> (16 * r)) & 0xffffull) cg_nz |= 1ull << g;
+      if ((b2 >> (16 * r)) & 0xffffull) cg_ge2 |= 1ull << g;
+      if ((b3 >> (16 * r)) & 0xffffull) cg_ge3 |= 1ull << g;
+    }
+  }
+  cost_cg_sig[lane] = 0;
+  wsync();
+  if (last_pos < 0) return 0;
+  RDOQ_MARK(18);
+  const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
+  double block_uncoded = 0;
+  // zero-level costs above the last position, summed in scan order from the top (as rdoq_lane0)
+  for (int top = ncoef - 1; top > last_pos; top -= 64) {
+    const int sp = top - lane;
+    const double c0 = (sp > last_pos) ? cost0_of(scan[sp]) : 0.0;
+    if (!__ballot(c0 != 0.0)) continue;
+    wsync();
+    s.zb[0][lane] = c0;
+    wsync();
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) v[t] = s.zb[0][h * 16 + t];
+#pragma unroll
+      for (int t = 0; t < 16; t++) block_uncoded += v[t];
+    }
+  }
+  double base_cost = block_uncoded;
+  RDOQ_MARK(19);
+  const int cg_last = last_pos >> 4, wg = cp.wg, lwg = log2n - 2;
+  // rates of the significant-group flag, by context (0 / 1) and value
+  const double cgr00 = lambda * (double)ctx_bits(cab, cg_off, 0), cgr01 = lambda * (double)ctx_bits(cab, cg_off, 1);
+  const double cgr10 = lambda * (double)ctx_bits(cab, cg_off + 1, 0), cgr11 = lambda * (double)ctx_bits(cab, cg_off + 1, 1);
+  unsigned long long cgf_mask = 0;                     // significant-group flags after RDOQ, bit = raster index of the group
+  auto cgf_at = [&](int gx, int gy) -> int { return (int)((cgf_mask >> (gy * wg + gx)) & 1ull); };
+  int carry = 0;                                       // the previous group in scan order ended with c1 == 0
+  // ---- phase B ----
+  int cgpos = cg_last;
+  while (cgpos >= 0) {
+    // --- the batch: groups cgpos, cgpos - 1, ... (row r of 16 lanes <-> group cgpos - r) ---
+    int R = 1, diag = -1;
+    if ((cg_nz >> cgpos) & 1ull) { const int b = uni(scan_cg[cgpos]); diag = (b >> lwg) + (b & (wg - 1)); }
+    while (R < RQ_ROWS && cgpos - R >= 0) {
+      const int q = cgpos - R;
+      if (((cg_ge2 >> (q + 1)) & 1ull) && !((cg_ge3 >> (q + 1)) & 1ull)) break;            // the bit carried into q is not known beforehand
+      const int qnz = (int)((cg_nz >> q) & 1ull);
+      if (diag >= 0 || qnz) {
+        const int b = uni(scan_cg[q]), dq = (b >> lwg) + (b & (wg - 1));
+        if (diag >= 0 && dq != diag) break;                                                // might be a neighbour of a row still to be decided
+        if (qnz) diag = dq;
+      }
+      R++;
+    }
+    const int any_nz = (int)(((cg_nz >> (cgpos - R + 1)) & ((1ull << R) - 1ull)) != 0ull);
+    // --- per position: everything that does not depend on the state machine ---
+    const int row = lane >> 4, j = lane & 15;
+    const bool rv = row < R;
+    const int q = rv ? cgpos - row : cgpos;
+    const int cgblk = scan_cg[q], gy = cgblk >> lwg, gx = cgblk & (wg - 1);
+    const int pin = scan.in[j], px = (gx << 2) + (pin & 3), py = (gy << 2) + (pin >> 2);
+    const int sp_j = q * 16 + j, blk_j = (py << log2n) + px;
+    const int pat = ((gx < wg - 1) ? cgf_at(gx + 1, gy) : 0) + (((gy < wg - 1) ? cgf_at(gx, gy + 1) : 0) << 1);      // TComTrQuant.cpp:2672-2705
+    const int start_pin = (q == cg_last) ? (last_pos & 15) : 15;
+    const bool valid = rv && j <= start_pin;
+    const int32_t ld_j = level_double(blk_j);
+    const int ma_j = valid ? (int)dst[blk_j] : 0;
+    const double c0_j = (double)ld_j * (double)ld_j * err_scale;
+    const bool is_last = sp_j == last_pos;
+    const int sigctx_j = is_last ? 0 : sig_off + sig_ctx_inc_xy(cp, pat, px, py);
+    const int b0_j = is_last ? 0 : ctx_bits(cab, sigctx_j, 0), b1_j = is_last ? 0 : ctx_bits(cab, sigctx_j, 1);
+    const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
+    RDOQ_MARK(4);
+    int lvl_j = 0, ru_j = 0, rd_j = 0;
+    double cc_j = c0_j + cs0_j, cs_j = cs0_j;
+    unsigned long long g1m = 0;
+    if (any_nz) {
+      // greater-1 / greater-2 rates of the row's context set (m_greaterOneBits[4 * ctxSet + c1][bin], m_levelAbsBits[ctxSet][bin])
+      const int ctx_set = ctx_set_index(ch, q, row == 0 ? carry : (int)((cg_ge3 >> (q + 1)) & 1ull));
+      int g1r0[4], g1r1[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { g1r0[t] = ctx_bits(cab, CTX_ONE + 4 * ctx_set + t, 0); g1r1[t] = ctx_bits(cab, CTX_ONE + 4 * ctx_set + t, 1); }
+      const int g2r0 = ctx_bits(cab, CTX_ABS + ctx_set, 0), g2r1 = ctx_bits(cab, CTX_ABS + ctx_set, 1);
+      const unsigned above = (0xfffeu << j) & 0xffffu;                                   // the positions of the row this one comes after
+      const bool vis = valid && ma_j > 0;
+      int c1s = 1, c1idx = 0, c2idx = 0, gr = 0, rate_a = 0, rate_b = 0;
+      // xGetICRate TComTrQuant.cpp:2881-2955 under this position's state
+      auto ic_rate = [&](int al, int r1_0, int r1_1) -> int {
+        const int base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
+        int rate = 32768;
+        if (al >= base) {
+          uint32_t symbol = (uint32_t)(al - base), length;
+          if (symbol < (3u << gr)) { length = symbol >> gr; rate += (int)(length + 1 + gr) << 15; }
+          else {
+            length = (uint32_t)gr; symbol -= (3u << gr);
+            while (symbol >= (1u << length)) symbol -= (1u << (length++));
+            rate += (int)(3 + length + 1 - gr + length) << 15;
+          }
+          if (c1idx < 8) { rate += r1_1; if (c2idx < 1) rate += g2r1; }
+        } else if (al == 1) rate += r1_0;
+        else if (al == 2) { rate += r1_1; rate += g2r0; }
+        else rate = 0;
+        return rate;
+      };
+      int r1_0 = g1r0[1], r1_1 = g1r1[1];
+      lvl_j = vis ? ma_j : 0;
+      for (;;) {
+        // the state each position sees, from the levels as they stand
+        const unsigned long long nzm = __ballot(lvl_j > 0), e1m = __ballot(lvl_j == 1);
+        g1m = __ballot(lvl_j > 1);
+        const unsigned f_nz = (unsigned)(nzm >> (16 * row)) & above, f_g1 = (unsigned)(g1m >> (16 * row)) & above, f_e1 = (unsigned)(e1m >> (16 * row)) & above;
+        c1idx = __popc(f_nz); c2idx = __popc(f_g1);
+        { const int e = 1 + __popc(f_e1); c1s = f_g1 ? 0 : (e < 3 ? e : 3); }
+        gr = 0;
+        if (__ballot(lvl_j > 3)) { // the Rice parameter moves only at a level above 3 << parameter that is coded with an escape (:2360-2366)
+          const int base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
+          const int e_j = (lvl_j >= base) ? lvl_j : 0;
+#pragma unroll
+          for (int t = 15; t >= 1; t--) {
+            const int e_t = __shfl(e_j, (lane & 48) | t);
+            if (t > j && e_t > (3 << gr)) gr = gr + 1 < 4 ? gr + 1 : 4;
+          }
+        }
+        r1_0 = c1s == 0 ? g1r0[0] : (c1s == 1 ? g1r0[1] : (c1s == 2 ? g1r0[2] : g1r0[3]));
+        r1_1 = c1s == 0 ? g1r1[0] : (c1s == 1 ? g1r1[1] : (c1s == 2 ? g1r1[2] : g1r1[3]));
+        // xGetCodedLevel TComTrQuant.cpp:2812-2879: zero (only below 3), the rounded level, one below it
+        double best = MAX_DOUBLE, cost_s = 0.0; int best_lvl = 0;
+        if (!is_last && ma_j < 3) { cost_s = cs0_j; best = c0_j + cs0_j; }
+        const double cur_sig = is_last ? 0.0 : cs1_j;
+        {
+          const double err = (double)(ld_j - (int32_t)((uint32_t)ma_j << qbits));
+          rate_a = ic_rate(ma_j, r1_0, r1_1);
+          double cur = err * err * err_scale + lambda * (double)rate_a;
+          cur += cur_sig;
+          if (cur < best) { best_lvl = ma_j; best = cur; cost_s = cur_sig; }
+        }
+        if (ma_j > 1) {
+          const int al = ma_j - 1;
+          const double err = (double)(ld_j - (int32_t)((uint32_t)al << qbits));
+          rate_b = ic_rate(al, r1_0, r1_1);
+          double cur = err * err * err_scale + lambda * (double)rate_b;
+          cur += cur_sig;
+          if (cur < best) { best_lvl = al; best = cur; cost_s = cur_sig; }
+        }
+        const int nl = vis ? best_lvl : 0;
+        if (vis) { cc_j = best; cs_j = cost_s; }
+        const unsigned long long chg = __ballot(nl != lvl_j);
+        lvl_j = nl;
+        if (!chg) break;
+      }
+      // rate deltas of level +-1 for sign hiding (:2340-2352); a zero level: the greater-1 rate it would start with
+      if (lvl_j > 0) {
+        const bool top = lvl_j == ma_j;
+        const int now = top ? rate_a : rate_b;
+        const int other = ic_rate(top ? lvl_j + 1 : lvl_j - 1, r1_0, r1_1);
+        ru_j = (top ? other : rate_a) - now;
+        rd_j = (lvl_j == 1 ? 0 : (top ? rate_b : other)) - now;
+      } else ru_j = r1_0;
+      RDOQ_MARK(5);
+      if (valid) {
+        dst[blk_j] = (int16_t)lvl_j;
+        q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j);
+        q_rate_st(Q_SIGDELTA, blk_j, b1_j - b0_j);                   // 0 at the last position
+        q_rate_st(Q_DELTAU, blk_j, (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8)));
+        q_rate_st(Q_UP, blk_j, ru_j);
+        q_rate_st(Q_DOWN, blk_j, rd_j);
+      }
+    }
+    // --- the ordered sums, group by group (each in scan order, pin = 15..0, as the reference accumulates them), on lanes 0..4:
+    //   0 block_uncoded += c0      1 base_cost += cost_c      2 sig_cost += cost_s
+    //   3 coded += cost_c - cost_s (nonzero levels)           4 uncoded += c0 (nonzero levels)
+    // A position that does not contribute adds +0.0, which leaves a sum unchanged.
+    const bool nz_j = valid && lvl_j != 0;
+    const unsigned long long nzfin = __ballot(nz_j);
+    if (rv) {
+      const int o = row * 16 + j;
+      s.chain[0][o] = valid ? c0_j : 0.0; s.chain[1][o] = valid ? cc_j : 0.0; s.chain[2][o] = valid ? cs_j : 0.0;
+      s.chain[3][o] = nz_j ? cc_j - cs_j : 0.0; s.chain[4][o] = nz_j ? c0_j : 0.0;
+    }
+    wsync();
+    for (int r = 0; r < R; r++) {
+      const int qq = cgpos - r;
+      const int cb = uni(scan_cg[qq]), ggy = cb >> lwg, ggx = cb & (wg - 1);
+      double st_sig_cost, st_sig_cost0, st_coded, st_uncoded;
+      {
+        const int crow = lane < 4 ? lane : 4;
+        double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = s.chain[crow][r * 16 + t];
+#pragma unroll
+        for (int t = 15; t >= 0; t--) acc += v[t];
+        block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1); st_sig_cost = rl_d(acc, 2); st_coded = rl_d(acc, 3); st_uncoded = rl_d(acc, 4);
+        st_sig_cost0 = rl_d(cs_j, 16 * r);
+      }
+      const unsigned nzrow = (unsigned)(nzfin >> (16 * r)) & 0xffffu;
+      const int st_nnz_before0 = __popc(nzrow & 0xfffeu), cg_nonzero = nzrow != 0;
+      int flag = cg_nonzero;
+      if (qq) {
+        const int csx = (((ggx < wg - 1) ? cgf_at(ggx + 1, ggy) : 0) + ((ggy < wg - 1) ? cgf_at(ggx, ggy + 1) : 0)) != 0;    // TComTrQuant.cpp:3023-3049
+        const double r0 = csx ? cgr10 : cgr00, r1 = csx ? cgr11 : cgr01;
+        if (!cg_nonzero) {
+          base_cost += r0 - st_sig_cost;
+          if (lane == 0) cost_cg_sig[qq] = r0;
+        } else if (qq < cg_last) {
+          if (st_nnz_before0 == 0) { base_cost -= st_sig_cost0; st_sig_cost -= st_sig_cost0; }
+          double zero_cost = base_cost;
+          base_cost += r1; zero_cost += r0;
+          double cgc = r1;
+          zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
+          if (zero_cost < base_cost) {
+            base_cost = zero_cost; cgc = r0; flag = 0;
+            if (row == r && lvl_j) { dst[blk_j] = 0; q_cost_st(Q_COEFF, sp_j, c0_j); q_cost_st(Q_SIG, sp_j, 0.0); }
+          }
+          if (lane == 0) cost_cg_sig[qq] = cgc;
+        }
+      } else flag = 1;
+      if (flag) cgf_mask |= 1ull << cb;
+    }
+    carry = (int)(((g1m >> (16 * (R - 1))) & 0xffffull) != 0ull);
+    wsync();
+    RDOQ_MARK(8);
+    cgpos -= R;
+  }
+  RDOQ_MARK(20);
+  // ---- phase C: last position, TComTrQuant.cpp:2440-2528.  Per CG the 16 positions' costs are fetched
+  // lane-parallel, the walk itself is wave-uniform (readlane) and usually ends inside the first group ----
+  int best_last_p1 = 0;
+  {
+    double best_cost;
+    {
+      const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
+      best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
+      base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
+    }
+    LDS int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
+    { // TEncSbac.cpp:1910-1930 (prefix sums are integers: any evaluation order)
+      int off, shift; last_ctx_params(ch, n, off, shift);
+      const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
+      const int ng = tb().t_group_idx[n - 1];
+      { // lanes 0..15: X, lanes 16..31: Y; entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar
+        const int kk = lane & 15, isy = (lane >> 4) & 1;
+        const int cx_ = (isy ? by : bx) + off + (kk >> shift);
+        const int b1 = (kk < ng) ? ctx_bits(cab, cx_, 1) : 0, b0 = (kk < ng) ? ctx_bits(cab, cx_, 0) : 0;
+        int inc = b1;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        if (lane < 32 && kk <= ng) s.last_bits[isy][kk] = inc - b1 + b0;
+      }
+      wsync();
+    }
+    RDOQ_MARK(HEVCDL_BD == 8 ? 54 : 39);
+    int found_last = 0;
+    for (int cgp = cg_last; cgp >= 0 && !found_last; cgp--) {
+      const int cgblk = uni(scan_cg[cgp]);
+      base_cost -= cost_cg_sig[cgp];
+      if (!((cgf_mask >> cgblk) & 1ull)) continue;
+      const int j = lane & 15, sp_j = cgp * 16 + j, blk_j = scan[sp_j];
+      const int lv_j = dst[blk_j];
+      const double cc_j = q_cost_ld(Q_COEFF, sp_j), cs_j = q_cost_ld(Q_SIG, sp_j), c0_j = cost0_of(blk_j);
+      int py = blk_j >> log2n, px = blk_j - (py << log2n);
+      if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
+      const int gx2 = tb().t_group_idx[px], gy2 = tb().t_group_idx[py];
+      double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
+      if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
+      if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
+      const double cl_j = lambda * lc;
+      RDOQ_MARK(HEVCDL_BD == 8 ? 55 : 39);
+      // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
+      // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
+      // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
+      // lane-parallel, then only the positions with a level are compared, highest scan position first.
+      const int start_pin = (cgp == cg_last) ? (last_pos & 15) : 15;
+      const bool in_j = j <= start_pin;
+      const double a1_j = in_j ? (lv_j ? -cc_j : -cs_j) : 0.0, a2_j = (in_j && lv_j) ? c0_j : 0.0;
+      wsync();
+      if (lane < 16) { s.zb[0][j] = a1_j; s.zb[1][j] = a2_j; }
+      wsync();
+      double mine = base_cost, acc = base_cost;
+      {
+        double v1[16], v2[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) { v1[t] = s.zb[0][15 - t]; v2[t] = s.zb[1][15 - t]; }
+#pragma unroll
+        for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
+      }
+      const double total_j = (mine + cl_j) - cs_j;
+      RDOQ_MARK(HEVCDL_BD == 8 ? 44 : 39);
+      const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
+      const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
+      unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
+      while (cand) {
+        const int pin = 31 - __clz((int)cand);
+        cand &= ~(1u << pin);
+        const double total = rl_d(total_j, pin);
+        if (total < best_cost) { best_last_p1 = cgp * 16 + pin + 1; best_cost = total; }
+      }
+      if (gt1) found_last = 1;
+      base_cost = acc;
+    }
+  }
+
+  RDOQ_MARK(21);
+  // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact)
+  uint32_t abs_sum = 0;
+  for (int sp = lane; sp <= last_pos; sp += 64) {
+    const int blk = scan[sp];
+    if (sp < best_last_p1) { const int lv = dst[blk]; abs_sum += (uint32_t)lv; dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv); }
+    else dst[blk] = 0;
+  }
+  abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
+  wsync();
+  if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660; lanes 0..15 own the positions of the current CG
+    const long long rd_factor = k.sbh[ch];
+    const long long I64MAX = 0x7fffffffffffffffll;
+    int last_cg = -1;
+    for (int subset = cg_last; subset >= 0; subset--) {
+      const int sub_pos = subset << 4, j = lane & 15, blk_j = scan[sub_pos + j];
+      const int lv_j = dst[blk_j];
+      const unsigned nzmask = (unsigned)(__ballot(lv_j != 0) & 0xffffull);
+      if (!nzmask) continue;                                       // lastCG stays -1 until the first CG with levels
+      const int last_nz = 31 - __clz((int)nzmask), first_nz = __ffs((int)nzmask) - 1;
+      if (last_cg == -1) last_cg = 1;
+      if (last_nz - first_nz >= 4) {
+        int sum = (j >= first_nz && j <= last_nz) ? lv_j : 0;
+        sum = row_sum_i(sum);
+        const int lv_first = __builtin_amdgcn_readlane(lv_j, first_nz);
+        const uint32_t signbit = lv_first > 0 ? 0 : 1;
+        if (signbit != ((uint32_t)sum & 1u)) {
+          long long cur_cost = I64MAX; int cur_change = 0;
+          const int nmax = (last_cg == 1) ? last_nz : 15;
+          if (j <= nmax) {
+            const int32_t du_j = q_rate_ld(Q_DELTAU, blk_j), riu_j = q_rate_ld(Q_UP, blk_j), rid_j = q_rate_ld(Q_DOWN, blk_j), srd_j = q_rate_ld(Q_SIGDELTA, blk_j);
+            if (lv_j != 0) {
+              const long long up = rd_factor * (-(long long)du_j) + riu_j;
+              long long down = rd_factor * ((long long)du_j) + rid_j - ((abs(lv_j) == 1) ? srd_j : 0);
+              if (last_cg == 1 && last_nz == j && abs(lv_j) == 1) down -= (4 << 15);
+              if (up < down) { cur_cost = up; cur_change = 1; }
+              else { cur_change = -1; cur_cost = (j == first_nz && abs(lv_j) == 1) ? I64MAX : down; }
+            } else {
+              cur_cost = rd_factor * (-(long long)abs(du_j)) + (1 << 15) + riu_j + srd_j;
+              cur_change = 1;
+              if (j < first_nz) { const uint32_t ts = src[blk_j] >= 0 ? 0 : 1; if (ts != signbit) cur_cost = I64MAX; }
+            }
+          }
+          // the reference scans n = nmax..0 and keeps the first strict minimum: smallest cost, ties -> largest n
+          long long bc = cur_cost; int bn = (j <= nmax && cur_cost != I64MAX) ? j : -1;
+          for (int m = 8; m >= 1; m >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)bc, m), hi = (unsigned)__shfl_xor((int)(unsigned)(bc >> 32), m);
+            const long long oc = (long long)(((unsigned long long)hi << 32) | lo); const int on = __shfl_xor(bn, m);
+            if (on >= 0 && (bn < 0 || oc < bc || (oc == bc && on > bn))) { bc = oc; bn = on; }
+          }
+          const int min_n = __builtin_amdgcn_readlane(bn, 0);
+          if (min_n >= 0) {
+            int final_change = __builtin_amdgcn_readlane(cur_change, min_n);
+            const int lv_min = __builtin_amdgcn_readlane(lv_j, min_n);
+            if (lv_min == 32767 || lv_min == -32768) final_change = -1;
+            if (lane == min_n) { if (src[blk_j] >= 0) dst[blk_j] = (int16_t)(lv_j + final_change); else dst[blk_j] = (int16_t)(lv_j - final_change); }
+          }
+        }
+      }
+      if (last_cg == 1) last_cg = 0;
+    }
+  }
+  wsync();
+  RDOQ_MARK(22);
+  return (uint32_t)uni((int)abs_sum);
+}
+
 DEV void dequant(KR k, int c_, int n_)
 {
   PROF_T0();
@@ -1666,7 +2126,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
 #ifdef HEVCDL_STAGE_TRACE
   if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + n * n + i] = (unsigned)(int)s.tc[i];
 #endif
-  { PROF_T0(); const uint32_t as_ = rdoq_lane0(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); }
+  { PROF_T0(); const uint32_t as_ = HEVCDL_RDOQ(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); if (HEVCDL_BD == 8) PROF_ADD(k, 60 + log2n - 2); }
   wsync();
   PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
@@ -1716,6 +2176,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   wsync();
   PROF_MARK(29);
   PROF_ADD_T(k, 9, 48);
+  if (HEVCDL_BD == 8) PROF_ADD(k, 56 + log2n - 2);
   return d;
 }
 
@@ -3014,7 +3475,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m; }
   }
 #ifdef HEVCDL_KERNEL_PROF
-  if (lane < (HEVCDL_BD == 8 ? 56 : 40)) { s.prof[lane] = 0; s.prof_n[lane] = 0; } if (lane == 0) s.prof_task = 0;
+  if (lane < (HEVCDL_BD == 8 ? 64 : 40)) { s.prof[lane] = 0; s.prof_n[lane] = 0; } if (lane == 0) s.prof_task = 0;
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
@@ -3049,10 +3510,10 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 #ifdef HEVCDL_KERNEL_PROF
   // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)
   wsync();
-  if (blockIdx.x == 0 && p.dbgbuf && lane < (HEVCDL_BD == 8 ? 56 : 40)) {
+  if (blockIdx.x == 0 && p.dbgbuf && lane < (HEVCDL_BD == 8 ? 64 : 40)) {
     if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
     atomicAdd(&p.dbgbuf[1 + 2 * lane], (unsigned int)(s.prof[lane] >> 10)); atomicAdd(&p.dbgbuf[2 + 2 * lane], s.prof_n[lane]);
-    if (lane == 0) p.dbgbuf[0] = 56;
+    if (lane == 0) p.dbgbuf[0] = 64;
   }
 #endif
 }
