@@ -207,11 +207,14 @@ struct __attribute__((aligned(16))) RdSmem {
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   union {
-    double chain[5][RQ_ROWS * 16 + 1];   // RDOQ per-position addends of the five ordered sums, one batch of coefficient groups (rows padded)
+    double chain[5][17];              // rdoq_lane0: per-position addends of the five ordered sums (rows padded)
+    double chainb[3][RQ_ROWS * 16 + 1];  // rdoq_wave: zero-level cost, coded cost, significance cost of every position of a batch of groups
     double zb[2][64];                 // RDOQ, run of all-zero groups: zero-level costs / significance costs of 4 groups
     struct { double rmd_cost[36]; unsigned int satd[36]; };   // rough mode decision (never live during RDOQ)
   };
   uint8_t cgf[64];                    // significant-CG flags (RDOQ / bit counter)
+  // RDOQ rate tables of the call (the contexts are frozen while a TU is quantised): significance [context - first][bin], greater-1 [set][c1][bin], greater-2 [set][bin]
+  int32_t rq_sig[28][2], rq_g1[4][4][2], rq_g2[4][2];
   int last_bits[2][12];
 };
 typedef LDS RdSmem LSmem;
@@ -1362,6 +1365,13 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   if (last_pos < 0) return 0;
   RDOQ_MARK(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
+  { // rate tables: one pair of dependent LDS reads here instead of one per batch and use
+    const int set0 = ch ? 4 : 0;
+    if (lane < 28) { const int st = cab->ctx[sig_off + lane]; s.rq_sig[lane][0] = tb().t_ebits[st]; s.rq_sig[lane][1] = tb().t_ebits[st ^ 1]; }
+    else if (lane < 44) { const int e = lane - 28, st = cab->ctx[CTX_ONE + 4 * set0 + e]; s.rq_g1[e >> 2][e & 3][0] = tb().t_ebits[st]; s.rq_g1[e >> 2][e & 3][1] = tb().t_ebits[st ^ 1]; }
+    else if (lane < 48) { const int e = lane - 44, st = cab->ctx[CTX_ABS + set0 + e]; s.rq_g2[e][0] = tb().t_ebits[st]; s.rq_g2[e][1] = tb().t_ebits[st ^ 1]; }
+    wsync();
+  }
   double block_uncoded = 0;
   // zero-level costs above the last position, summed in scan order from the top (as rdoq_lane0)
   for (int top = ncoef - 1; top > last_pos; top -= 64) {
@@ -1389,21 +1399,19 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   unsigned long long cgf_mask = 0;                     // significant-group flags after RDOQ, bit = raster index of the group
   auto cgf_at = [&](int gx, int gy) -> int { return (int)((cgf_mask >> (gy * wg + gx)) & 1ull); };
   int carry = 0;                                       // the previous group in scan order ended with c1 == 0
+  const unsigned long long dstart = wg == 8 ? 0xA44208101020844Bull : (wg == 4 ? 0xA44Bull : 0xBull);
   // ---- phase B ----
   int cgpos = cg_last;
   while (cgpos >= 0) {
     // --- the batch: groups cgpos, cgpos - 1, ... (row r of 16 lanes <-> group cgpos - r) ---
-    int R = 1, diag = -1;
-    if ((cg_nz >> cgpos) & 1ull) { const int b = uni(scan_cg[cgpos]); diag = (b >> lwg) + (b & (wg - 1)); }
+    // (the groups' scan order goes anti-diagonal by anti-diagonal in all three scan types: bit i of dstart = group i is the first of its diagonal)
+    int R = 1, qnz0 = ((cg_nz >> cgpos) & 1ull) ? cgpos : -1;                                // the first row with a rounded level: its diagonal binds the batch
     while (R < RQ_ROWS && cgpos - R >= 0) {
       const int q = cgpos - R;
       if (((cg_ge2 >> (q + 1)) & 1ull) && !((cg_ge3 >> (q + 1)) & 1ull)) break;            // the bit carried into q is not known beforehand
       const int qnz = (int)((cg_nz >> q) & 1ull);
-      if (diag >= 0 || qnz) {
-        const int b = uni(scan_cg[q]), dq = (b >> lwg) + (b & (wg - 1));
-        if (diag >= 0 && dq != diag) break;                                                // might be a neighbour of a row still to be decided
-        if (qnz) diag = dq;
-      }
+      if (qnz0 >= 0) { if ((dstart >> (q + 1)) & ((1ull << (qnz0 - q)) - 1ull)) break; }     // another diagonal: might be a neighbour of a row still to be decided
+      else if (qnz) qnz0 = q;
       R++;
     }
     const int any_nz = (int)(((cg_nz >> (cgpos - R + 1)) & ((1ull << R) - 1ull)) != 0ull);
@@ -1421,8 +1429,8 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     const int ma_j = valid ? (int)dst[blk_j] : 0;
     const double c0_j = (double)ld_j * (double)ld_j * err_scale;
     const bool is_last = sp_j == last_pos;
-    const int sigctx_j = is_last ? 0 : sig_off + sig_ctx_inc_xy(cp, pat, px, py);
-    const int b0_j = is_last ? 0 : ctx_bits(cab, sigctx_j, 0), b1_j = is_last ? 0 : ctx_bits(cab, sigctx_j, 1);
+    const int sc_j = is_last ? 0 : sig_ctx_inc_xy(cp, pat, px, py);
+    const int b0_j = is_last ? 0 : s.rq_sig[sc_j][0], b1_j = is_last ? 0 : s.rq_sig[sc_j][1];
     const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
     RDOQ_MARK(4);
     int lvl_j = 0, ru_j = 0, rd_j = 0;
@@ -1431,10 +1439,11 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     if (any_nz) {
       // greater-1 / greater-2 rates of the row's context set (m_greaterOneBits[4 * ctxSet + c1][bin], m_levelAbsBits[ctxSet][bin])
       const int ctx_set = ctx_set_index(ch, q, row == 0 ? carry : (int)((cg_ge3 >> (q + 1)) & 1ull));
+      const int cset = ctx_set - (ch ? 4 : 0);
       int g1r0[4], g1r1[4];
 #pragma unroll
-      for (int t = 0; t < 4; t++) { g1r0[t] = ctx_bits(cab, CTX_ONE + 4 * ctx_set + t, 0); g1r1[t] = ctx_bits(cab, CTX_ONE + 4 * ctx_set + t, 1); }
-      const int g2r0 = ctx_bits(cab, CTX_ABS + ctx_set, 0), g2r1 = ctx_bits(cab, CTX_ABS + ctx_set, 1);
+      for (int t = 0; t < 4; t++) { g1r0[t] = s.rq_g1[cset][t][0]; g1r1[t] = s.rq_g1[cset][t][1]; }
+      const int g2r0 = s.rq_g2[cset][0], g2r1 = s.rq_g2[cset][1];
       const unsigned above = (0xfffeu << j) & 0xffffu;                                   // the positions of the row this one comes after
       const bool vis = valid && ma_j > 0;
       int c1s = 1, c1idx = 0, c2idx = 0, gr = 0, rate_a = 0, rate_b = 0;
@@ -1526,28 +1535,35 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     // A position that does not contribute adds +0.0, which leaves a sum unchanged.
     const bool nz_j = valid && lvl_j != 0;
     const unsigned long long nzfin = __ballot(nz_j);
+    const double d_j = cc_j - cs_j;
     if (rv) {
       const int o = row * 16 + j;
-      s.chain[0][o] = valid ? c0_j : 0.0; s.chain[1][o] = valid ? cc_j : 0.0; s.chain[2][o] = valid ? cs_j : 0.0;
-      s.chain[3][o] = nz_j ? cc_j - cs_j : 0.0; s.chain[4][o] = nz_j ? c0_j : 0.0;
+      s.chainb[0][o] = valid ? c0_j : 0.0; s.chainb[1][o] = valid ? cc_j : 0.0; s.chainb[2][o] = valid ? cs_j : 0.0;
     }
     wsync();
+    RDOQ_MARK(HEVCDL_BD == 8 ? 37 : 39);
     for (int r = 0; r < R; r++) {
       const int qq = cgpos - r;
-      const int cb = uni(scan_cg[qq]), ggy = cb >> lwg, ggx = cb & (wg - 1);
-      double st_sig_cost, st_sig_cost0, st_coded, st_uncoded;
+      const int cb = __builtin_amdgcn_readlane(cgblk, 16 * r), ggy = cb >> lwg, ggx = cb & (wg - 1);
+      double st_sig_cost, st_sig_cost0, st_coded = 0.0, st_uncoded = 0.0;
+      const unsigned nzrow = (unsigned)(nzfin >> (16 * r)) & 0xffffu;
       {
-        const int crow = lane < 4 ? lane : 4;
+        const int arow = lane < 2 ? lane : 2;
         double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
         double v[16];
 #pragma unroll
-        for (int t = 0; t < 16; t++) v[t] = s.chain[crow][r * 16 + t];
+        for (int t = 0; t < 16; t++) v[t] = s.chainb[arow][r * 16 + t];
 #pragma unroll
         for (int t = 15; t >= 0; t--) acc += v[t];
-        block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1); st_sig_cost = rl_d(acc, 2); st_coded = rl_d(acc, 3); st_uncoded = rl_d(acc, 4);
+        block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1); st_sig_cost = rl_d(acc, 2);
         st_sig_cost0 = rl_d(cs_j, 16 * r);
+        // sums 3 and 4 run over the positions with a level only (adding +0.0 for the others would change nothing): a handful, highest position first
+        for (unsigned m = nzrow; m; ) {
+          const int t = 31 - __clz((int)m); m &= ~(1u << t);
+          st_coded += rl_d(d_j, 16 * r + t); st_uncoded += rl_d(c0_j, 16 * r + t);
+        }
       }
-      const unsigned nzrow = (unsigned)(nzfin >> (16 * r)) & 0xffffu;
+      RDOQ_MARK(34);
       const int st_nnz_before0 = __popc(nzrow & 0xfffeu), cg_nonzero = nzrow != 0;
       int flag = cg_nonzero;
       if (qq) {
@@ -1570,6 +1586,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         }
       } else flag = 1;
       if (flag) cgf_mask |= 1ull << cb;
+      RDOQ_MARK(35);
     }
     carry = (int)(((g1m >> (16 * (R - 1))) & 0xffffull) != 0ull);
     wsync();
