@@ -55,14 +55,16 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #define HEVCDL_RDOQ rdoq_wave
 #endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
-constexpr int NSLOT = 15;                                     // result slots of a region (<= 8 + 2 luma candidates, 5 chroma modes)
+constexpr int NPEND = BD == 8 ? 2 : 1;                         // second luma passes a master may leave running behind it (the 10-bit kernel has LDS for one more region only)
+constexpr int NREG = 1 + NPEND;                                // regions per wave: [0] first pass / chroma / rough-mode slices, [1..] the second passes (master: their tickets; chain owner: [1] its split tasks)
+constexpr int NSLOT = 20;                                     // result slots of a master: 0..9 first pass, 5..9 chroma, then one set of 5 per second pass that can be pending
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
 // per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
-constexpr int SAVE_BYTES = 8192, N_SAVE = 2;   // two areas: consecutive children can each leave a pass pending (compress_cu)
-//                            // the chain owner's state while it runs one of its own split tasks (spec_children)
-constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + 2047) & ~2047;
+constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while it runs one of its own split tasks (spec_children)
+constexpr int LEAF_LOG = 192, LOG_BYTES = 65 * LEAF_LOG;     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
+constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
 constexpr int SCR_WAVE = SCR_LAYERS + SCR_RDOQ + NSLOT * SLOT_BYTES;
@@ -159,9 +161,11 @@ struct K {                             // wave-uniform kernel context (lives in 
   // the luma search, the CU of a chroma task, the child of a split task), so that every PU reuses the same few KB of a set and the sets
   // of all waves stay cache resident (laid out CTU-wide they did not: profiles/r02_traffic.json).  lz: z-scan offset in luma samples.
   int lz, lx, ly;
-  // The second luma pass of the PREVIOUS sibling CU may still be running (its trial samples are in the picture): luma reference samples inside
-  // that CU's rectangle then come from best_rec, which holds the reconstruction the search continued with (the first pass's winner).
-  int sx0, sy0, sx1, sy1;
+  // The second luma passes of up to two EARLIER CUs of the CTU may still be running (their trial samples are in the picture): luma reference samples
+  // inside such a CU's rectangle come from best_rec, which holds the reconstruction the search continued with (the first pass's winner).
+  // -> srect[p]: (x0 | y0 << 16 | x1 << 32 | y1 << 48), 0 = none; ONE 8-byte word each, so that a helper copying this context never sees half a rectangle
+  unsigned long long srect[2];
+  int pset, pad_pset;                  // the slot set of the second pass this wave is running (run_task)
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
   long long sbh[2];
@@ -174,8 +178,8 @@ typedef const LDS K &KR;
 struct __attribute__((aligned(16))) RdSmem {
   K k;
   // the executing wave's own scratch (K is copied from the master when a helper runs one of its tasks; these are not)
-  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save; GLB unsigned char *my_slots;
-  int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task; joined in check_rd_cost_intra
+  GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save; GLB unsigned char *my_slots; GLB unsigned long long *my_log;
+  int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task (value: the region that holds its ticket); joined in check_rd_cost_intra or left pending
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
   int16_t line[264], fline[264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
@@ -199,11 +203,14 @@ struct __attribute__((aligned(16))) RdSmem {
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
   unsigned long long cfrac_last;      // coefficient part of the last intra_bits_qt count (fractional bits)
-  int carry_ok, carry, restart, pad_carry;   // second pass pending across the CU boundary: allowed for the CU being coded / pending from the previous sibling / it won: redo
+  // Second passes left running behind the master (compress_cu): carry_ok: the CU being coded may leave its pass pending; pend_*: the passes pending, oldest
+  // first (index of their CU among the CTU's coded CUs, region of their ticket); restart: a pending pass chose the split -> the CTU is walked again, CUs
+  // [0, replay_upto) from the log, CU nocarry_leaf without leaving its pass pending
+  int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[2], pend_reg[2], left_pending, pad_pend;
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
-  unsigned long long prof[HEVCDL_BD == 8 ? 64 : 40]; unsigned int prof_n[HEVCDL_BD == 8 ? 64 : 40]; int prof_task, prof_pad;     // (the 10-bit build has no LDS to spare: its profiling build keeps the first 40 timers)
+  unsigned long long prof[64]; int prof_task, prof_pad;     // timers of the profiling build (8-bit kernel only): cycles in the low 40 bits, calls above
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   union {
@@ -237,9 +244,10 @@ DEV void wsync()
 #ifdef HEVCDL_KERNEL_PROF
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
 #define PROF_MARK0() unsigned long long prof_m_ = __builtin_readcyclecounter()
-#define PROF_MARK(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); lds().prof[id] += n_ - prof_m_; lds().prof_n[id]++; prof_m_ = n_; } else prof_m_ = 0; } while (0)
-#define PROF_ADD(k, id) do { if (lane_id() == 0) { lds().prof[id] += __builtin_readcyclecounter() - prof_t0_; lds().prof_n[id]++; } } while (0)
-#define PROF_ADD_T(k, id, tid) do { if (lane_id() == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - prof_t0_; lds().prof[id] += d_; lds().prof_n[id]++; if (HEVCDL_BD == 8 && lds().prof_task) { lds().prof[tid] += d_; lds().prof_n[tid]++; } } } while (0)
+#define PROF_ACC_(id, d) (lds().prof[id] += ((unsigned long long)(d) & 0xffffffffffull) + (1ull << 40))
+#define PROF_MARK(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - prof_m_); prof_m_ = n_; } else prof_m_ = 0; } while (0)
+#define PROF_ADD(k, id) do { if (lane_id() == 0) { PROF_ACC_(id, __builtin_readcyclecounter() - prof_t0_); } } while (0)
+#define PROF_ADD_T(k, id, tid) do { if (lane_id() == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - prof_t0_; PROF_ACC_(id, d_); if (lds().prof_task) { PROF_ACC_(tid, d_); } } } while (0)
 #define PROF_TASK(v) do { if (lane_id() == 0) lds().prof_task = (v); } while (0)
 #else
 #define PROF_T0() do { } while (0)
@@ -258,7 +266,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
 enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5 };
-enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it), 10..13 the split tasks of the second pass (by child), 14 its verdict + start state: a second pass may still run while the next CU's first pass does
+enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14, SLOT_PSET = 5 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it); per second pass (set p = its region - 1, slots + 5 p): 10..13 its split tasks (by child), 14 its verdict + start state
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
   // the count can only come from the region that is open, whose parameters were written before the ticket was
@@ -280,7 +288,7 @@ struct Tables {                        // read-only after kernel start, one copy
   int t_ang[9], t_inv_ang[9]; uint8_t t_group_idx[32], t_ctx_map4[16], t_filter_thr[8];
 };
 struct __attribute__((aligned(16))) WgShared {
-  Region reg[NW][2];                  // two regions per master: [1] serves the speculative second pass
+  Region reg[NW][NREG];               // see NREG
   int masters_active, pad_[3];                  // waves that currently walk a unit
   Tables tab;
 };
@@ -467,7 +475,9 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   const int rx0 = k.trx0 >> csh, ry0 = k.try0 >> csh, rx1 = k.trx1 >> csh, ry1 = k.try1 >> csh;
   GLB const pel_t *po = k.ovl + comp_off(c);
   const int ox = k.cx * cs_, oy = k.cy * cs_;
-  const int spx0 = k.sx0, spy0 = k.sy0, spx1 = k.sx1, spy1 = k.sy1;
+  const unsigned long long sr0 = k.srect[0], sr1 = k.srect[1];
+  const int spx0 = (int)(sr0 & 0xffff), spy0 = (int)((sr0 >> 16) & 0xffff), spx1 = (int)((sr0 >> 32) & 0xffff), spy1 = (int)(sr0 >> 48);
+  const int sqx0 = (int)(sr1 & 0xffff), sqy0 = (int)((sr1 >> 16) & 0xffff), sqx1 = (int)((sr1 >> 32) & 0xffff), sqy1 = (int)(sr1 >> 48);
   GLB const pel_t *pbest = k.best_rec;
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
@@ -477,7 +487,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
     else if (i == 2 * n) { sy = y - 1; sx = x - 1; }
     else { sy = y - 1; sx = x + (i - 2 * n - 1); }
     if (task && sx >= rx0 && sx < rx1 && sy >= ry0 && sy < ry1) return po + (sy - oy) * cs_ + (sx - ox);
-    if (!c && sx >= spx0 && sx < spx1 && sy >= spy0 && sy < spy1) return pbest + (sy - oy) * 64 + (sx - ox);     // previous sibling, second pass pending
+    if (!c && ((sx >= spx0 && sx < spx1 && sy >= spy0 && sy < spy1) || (sx >= sqx0 && sx < sqx1 && sy >= sqy0 && sy < sqy1))) return pbest + (sy - oy) * 64 + (sx - ox);     // an earlier CU whose second pass is pending
     return p + (size_t)sy * st + sx;
   };
   // Every line element is ONE picture sample: its own when its unit is available, otherwise the last sample of the nearest
@@ -922,7 +932,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
   // ---- phase A ----
 #ifdef HEVCDL_KERNEL_PROF
   unsigned long long pt_ = __builtin_readcyclecounter();
-#define RDOQ_MARK(id) do { if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); s.prof[id] += n_ - pt_; s.prof_n[id]++; pt_ = n_; } } while (0)
+#define RDOQ_MARK(id) do { if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - pt_); pt_ = n_; } } while (0)
 #else
 #define RDOQ_MARK(id) do { } while (0)
 #endif
@@ -1170,7 +1180,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
       }
       wsync();
     }
-    RDOQ_MARK(HEVCDL_BD == 8 ? 54 : 39);
+    RDOQ_MARK(54);
     int found_last = 0;
     for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
       const int cgblk = uni(scan_cg[cgpos]);
@@ -1186,7 +1196,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
       if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
       if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
       const double cl_j = lambda * lc;
-      RDOQ_MARK(HEVCDL_BD == 8 ? 55 : 39);
+      RDOQ_MARK(55);
       // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
       // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
       // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
@@ -1206,7 +1216,7 @@ DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, 
         for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
       }
       const double total_j = (mine + cl_j) - cs_j;
-      RDOQ_MARK(HEVCDL_BD == 8 ? 44 : 39);
+      RDOQ_MARK(44);
       const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
       const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
       unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
@@ -1541,7 +1551,6 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       s.chainb[0][o] = valid ? c0_j : 0.0; s.chainb[1][o] = valid ? cc_j : 0.0; s.chainb[2][o] = valid ? cs_j : 0.0;
     }
     wsync();
-    RDOQ_MARK(HEVCDL_BD == 8 ? 37 : 39);
     for (int r = 0; r < R; r++) {
       const int qq = cgpos - r;
       const int cb = __builtin_amdgcn_readlane(cgblk, 16 * r), ggy = cb >> lwg, ggx = cb & (wg - 1);
@@ -1622,7 +1631,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       }
       wsync();
     }
-    RDOQ_MARK(HEVCDL_BD == 8 ? 54 : 39);
+    RDOQ_MARK(54);
     int found_last = 0;
     for (int cgp = cg_last; cgp >= 0 && !found_last; cgp--) {
       const int cgblk = uni(scan_cg[cgp]);
@@ -1638,7 +1647,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
       if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
       const double cl_j = lambda * lc;
-      RDOQ_MARK(HEVCDL_BD == 8 ? 55 : 39);
+      RDOQ_MARK(55);
       // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
       // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
       // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
@@ -1658,7 +1667,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
       }
       const double total_j = (mine + cl_j) - cs_j;
-      RDOQ_MARK(HEVCDL_BD == 8 ? 44 : 39);
+      RDOQ_MARK(44);
       const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
       const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
       unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
@@ -2143,7 +2152,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
 #ifdef HEVCDL_STAGE_TRACE
   if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + n * n + i] = (unsigned)(int)s.tc[i];
 #endif
-  { PROF_T0(); const uint32_t as_ = HEVCDL_RDOQ(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); if (HEVCDL_BD == 8) PROF_ADD(k, 60 + log2n - 2); }
+  { PROF_T0(); const uint32_t as_ = HEVCDL_RDOQ(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
   wsync();
   PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
@@ -2193,7 +2202,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   wsync();
   PROF_MARK(29);
   PROF_ADD_T(k, 9, 48);
-  if (HEVCDL_BD == 8) PROF_ADD(k, 56 + log2n - 2);
+  PROF_ADD(k, 56 + log2n - 2);
   return d;
 }
 
@@ -2381,6 +2390,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
   LRegion &r = my_region(1);
+  const int sbase = SLOT_SPLIT + SLOT_PSET * uni(k.pset);         // the split tasks' result slots of this pass's set
   uint32_t split_dist = 0, split_cbf = 0;
   unsigned long long split_cfrac = 0;
   int j = 0;
@@ -2391,7 +2401,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
     region_open(r, T_LUMA_SPLIT, 0, cu, tu);
     for (int c = j; c < 4; c++) {
       const Tu ch = tu_child(tu, c);
-      state_to_global(slot_state(k.slots, SLOT_SPLIT + c, 0), &s.go);
+      state_to_global(slot_state(k.slots, sbase + c, 0), &s.go);
       region_publish(r);
       // the unsplit alternative (the single-TU branch of recur_luma)
       set_parts(k, s.a[A_TSKIP + 0], cu.zbase + ch.zrel, ch.nparts, 0); wsync();
@@ -2421,7 +2431,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
         lds_add(&r.done, 1);
       }
       wg_acquire();
-      PROF_MARK(38);
+      PROF_MARK(37);
     }
     wsync();
     int brk = -1;
@@ -2431,10 +2441,10 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
     if (brk >= 0) { // the split of child brk wins: its arrays, levels, reconstruction and end state replace the chain's
       const Tu ch = tu_child(tu, brk);
       const int zc = cu.zbase + ch.zrel, n = 1 << (LOG2 - 1);
-      GLB const uint8_t *at = slot_attr(k.slots, SLOT_SPLIT + brk);
+      GLB const uint8_t *at = slot_attr(k.slots, sbase + brk);
       // the split task's slot has the child as its origin; this wave's own set the PU
-      GLB const int16_t *sc = slot_coef(k.slots, SLOT_SPLIT + brk) + lay_coef_o(zc * 16, LOG2 - 2, 0, zc); GLB int16_t *dc = k.coef_l + lay_coef(k, LOG2 - 2, 0, zc);
-      GLB const pel_t *sr = slot_rec(k.slots, SLOT_SPLIT + brk) + lay_rec_o(ch.x, ch.y, LOG2 - 2, 0, ch.x, ch.y); GLB pel_t *dr = k.rec_l + lay_rec(k, LOG2 - 2, 0, ch.x, ch.y);
+      GLB const int16_t *sc = slot_coef(k.slots, sbase + brk) + lay_coef_o(zc * 16, LOG2 - 2, 0, zc); GLB int16_t *dc = k.coef_l + lay_coef(k, LOG2 - 2, 0, zc);
+      GLB const pel_t *sr = slot_rec(k.slots, sbase + brk) + lay_rec_o(ch.x, ch.y, LOG2 - 2, 0, ch.x, ch.y); GLB pel_t *dr = k.rec_l + lay_rec(k, LOG2 - 2, 0, ch.x, ch.y);
       GLB pel_t *rp = k.rec[0] + (size_t)ch.y * k.W + ch.x;
       wsync();
       for (int i = lane_id(); i < ch.nparts; i += 64) { s.a[A_TRIDX][zc + i] = at[i]; s.a[A_CBF][zc + i] = at[256 + i]; s.a[A_TSKIP][zc + i] = at[512 + i]; }
@@ -2443,7 +2453,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
         const int o = (i >> (LOG2 - 1)) * 64 + (i & (n - 1)); const pel_t v = sr[o];
         dr[o] = v; rp[(size_t)(i >> (LOG2 - 1)) * k.W + (i & (n - 1))] = v;
       }
-      state_from_global(&s.go, slot_state(k.slots, SLOT_SPLIT + brk, 1));
+      state_from_global(&s.go, slot_state(k.slots, sbase + brk, 1));
       split_dist += (uint32_t)uni((int)r.dist[brk - j]);
       split_cfrac += uni64(r.cfrac[brk - j]);
       split_cbf |= (uint32_t)(uni(s.a[A_CBF][zc]) >> ch.trd) & 1;
@@ -2606,6 +2616,27 @@ DEVN void rmd_satd(KR k, const Cu cu_, const Tu ptu_)
   PROF_ADD(k, 2);
 }
 
+// Join the oldest second pass left pending (compress_cu).  Verdict "nothing changes": its CU is final as the walk assumed (the pass itself has put the
+// first pass's reconstruction back into the picture).  The split won: everything coded since stands on the wrong reconstruction and coder state -> the
+// other pending pass is waited for (its slots and the picture must be quiet) and the CTU is walked again from the log (process_unit).
+DEVN void pend_join_oldest(KR k)
+{
+  LSmem &s = lds(); LDS K &kk = s.k;
+  const int reg = uni(s.pend_reg[0]), leaf = uni(s.pend_leaf[0]), n = uni(s.pend_n);
+  LRegion &rp = my_region(reg);
+  region_wait(rp, 1);
+  wsync();
+  const int won = ub(rp.cost[0] < rp.cost[4]);
+  if (won && n > 1) region_wait(my_region(uni(s.pend_reg[1])), 1);
+  wsync();
+  if (lane_id() == 0) {
+    kk.srect[reg - 1] = 0;
+    if (won) { kk.srect[0] = 0; kk.srect[1] = 0; s.restart = 1; s.replay_upto = leaf; s.nocarry_leaf = leaf; s.pend_n = 0; }
+    else { s.pend_leaf[0] = s.pend_leaf[1]; s.pend_reg[0] = s.pend_reg[1]; s.pend_n = n - 1; }
+  }
+  wsync();
+}
+
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
 DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 {
@@ -2668,20 +2699,6 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       region_open(r, T_LUMA_P1, nfull, cu, ptu);
       region_run(k, r);
       PROF_MARK(36);
-      if (uni(s.carry)) { // the previous sibling's second pass was left running: its verdict is needed before this CU's own pass goes out
-        LRegion &rp = my_region(1);
-        region_wait(rp, 1);
-        wsync();
-        LDS K &kk = s.k;
-        kk.sx0 = kk.sy0 = kk.sx1 = kk.sy1 = 0;
-        if (lane_id() == 0) s.carry = 0;
-        wsync();
-        if (ub(rp.cost[0] < rp.cost[4])) { // its split won: everything since was built on the wrong reconstruction -> the parent redoes both CUs (compress_cu)
-          if (lane_id() == 0) s.restart = 1;
-          wsync();
-          return 0;
-        }
-      }
 #ifdef HEVCDL_STAGE_TRACE
       { const bool on = lane_id() < nfull; stage_line(k, 1, on ? r.modes[lane_id()] : 0, 0u, 0u, on ? r.cost[lane_id()] : 0.0, on); }   // "2nd pass" lines, :2395-2397
 #endif
@@ -2711,11 +2728,14 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       if (memo && !(pu_log2 > min_tu_log2(cu))) break;              // no split possible: the pass cannot change anything
       if (memo && npu == 1 && spare_waves()) {
         // Spare waves: the pass is handed to one of them and joined in check_rd_cost_intra, after the chroma search and the CU's syntax have
-        // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time).  If the split wins, those two are redone.
-        LRegion &r2 = my_region(1);
+        // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time) -- or later still (compress_cu).  If the split
+        // wins, what was built on the assumption is redone.
+        if (uni(s.pend_n) == NPEND) { pend_join_oldest(k); if (uni(s.restart)) return 0; }   // no ticket region free: the oldest pending pass first
+        const int reg = (uni(s.pend_n) && uni(s.pend_reg[0]) == 1) ? 2 : 1;                 // a free ticket region = slot set + 1
+        LRegion &r2 = my_region(reg);
         wsync();
-        if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = 1; }
-        state_to_global(slot_state(k.slots, SLOT_P2, 0), &s.curr[cu.depth]);
+        if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.modes[1] = reg - 1; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = reg; }
+        state_to_global(slot_state(k.slots, SLOT_P2 + SLOT_PSET * (reg - 1), 0), &s.curr[cu.depth]);
         region_open(r2, T_LUMA_P2, 1, cu, ptu);
         break;
       }
@@ -2878,7 +2898,8 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   }
   PROF_TASK(kind != T_LUMA_P2);
   PROF_MARK0();
-  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
+  const int pset = kind == T_LUMA_P2 ? uni(r.modes[1]) : uni(kk.pset);    // slot set of the second pass: given with its ticket; a split task finds it in the chain owner's context
+  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
   kk.lz = (cu.zbase + (kind == T_CHROMA ? 0 : ttu.zrel)) * 16; kk.lx = kind == T_CHROMA ? cu.x : ttu.x; kk.ly = kind == T_CHROMA ? cu.y : ttu.y;
@@ -2896,9 +2917,9 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
     const int zp = cu.zbase + tu.zrel;
     const double memo_cost = r.cost[4]; const uint32_t memo_dist = (uint32_t)uni((int)r.dist[4]);
     wsync();
-    kk.sx0 = kk.sy0 = kk.sx1 = kk.sy1 = 0;                     // this pass IS the pending one: its own CU's samples are the picture's (the master may be in the next CU by now)
+    kk.srect[pset] = 0; kk.pset = pset;                        // this pass IS the pending one of its set: its own CU's samples are the picture's (the master may be CUs ahead by now)
     wsync();
-    state_from_global(&s.go, slot_state(kk.slots, SLOT_P2, 0)); // the master's [depth][CI_CURR_BEST] snapshot as it was when the pass was handed over
+    state_from_global(&s.go, slot_state(kk.slots, slot, 0));    // the master's [depth][CI_CURR_BEST] snapshot as it was when the pass was handed over
     DistCost dc = { 0, 0.0, 0 };
     if constexpr (!LEAF) dc = recur_luma_any<true>(k, cu, tu, 0, 1, memo_dist, memo_cost);
     dist = memo_dist; cost = memo_cost;
@@ -2930,9 +2951,9 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
       if (lane_id() == 0) { s.ref_key[0] = ow.ref_key[0]; s.fline_key = ow.fline_key; }
       wsync();
     }
-    PROF_MARK(HEVCDL_BD == 8 ? 50 : 39);
+    PROF_MARK(50);
     const DistCost dc = recur_luma_any(k, cu, tu, one_tu ? 2 : 1);
-    PROF_MARK(HEVCDL_BD == 8 ? 51 : 39);
+    PROF_MARK(51);
     dist = dc.dist; cost = dc.cost;
     wsync();
     for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
@@ -2958,13 +2979,13 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   }
   if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
-  if (kind == T_LUMA_P1) PROF_MARK(HEVCDL_BD == 8 ? 52 : 39);
+  if (kind == T_LUMA_P1) PROF_MARK(52);
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   kk.lz = olz; kk.lx = olx; kk.ly = oly;
   wsync();
   PROF_TASK(0);
 #ifdef HEVCDL_KERNEL_PROF
-  if (HEVCDL_BD == 8) { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
+  { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
 #endif
 }
 
@@ -3001,14 +3022,17 @@ DEV int helper_step()
   const int me = wave_id();
   {
     int did = 0;
-    for (int j = 0; j < 2 * NW && !did; j++) { // the second-pass regions first: they sit on the masters' critical paths
-      LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][j < NW ? 1 : 0];
+    // the second-pass regions first when they sit on the masters' critical paths; behind the masters' own regions when the passes are left pending
+    // (compress_cu): then it is the first pass and the chroma search the master waits for
+    const int p2_first = lds_load(&sh.masters_active) > HEVCDL_CARRY_MAX;
+    for (int j = 0; j < NREG * NW && !did; j++) {
+      LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][p2_first ? (j < NPEND * NW ? 1 + j / NW : 0) : (j < NW ? 0 : j / NW)];
       const int t = lds_load(&r.ticket);
       if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
       const int idx = region_claim(r);
       if (idx < 0) continue;
       wg_acquire();
-      { PROF_T0(); import_owner(uni(r.owner)); PROF_ADD(0, HEVCDL_BD == 8 ? 53 : 39); }
+      { PROF_T0(); import_owner(uni(r.owner)); PROF_ADD(0, 53); }
       run_task<false>(r, idx);
       wg_release();
       lds_add(&r.done, 1);
@@ -3091,12 +3115,12 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
   }
   wsync();
-  if (lane_id() == 0) s.p2_pending = 0;
+  if (lane_id() == 0) { s.p2_pending = 0; s.left_pending = 0; }
   wsync();
   uint32_t dist_l = est_intra_luma(k, cu);
-  int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma)
+  int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma): the region of its ticket
   Rd r = { 0.0, 0, 0 };
-  if (uni(s.restart)) return r;                      // the previous sibling's pending pass won: the parent starts over
+  if (uni(s.restart)) return r;                      // a pending pass of an earlier CU chose the split: the CTU is walked again (process_unit)
   for (;;) {
     if (!pending) copy_best_rec_to_pic(k, cu, 0);
     const uint32_t dist = dist_l + est_intra_chroma(k, cu);
@@ -3106,18 +3130,21 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     cabac_copy(k, &s.temp[cu.depth], &s.go);
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
     if (!pending) break;
-    if (uni(s.carry_ok)) { // the next sibling is a plain CU of the same size: it starts while this pass is still running and joins it after its own
-      // first pass (est_intra_luma); until then this CU's luma in the picture belongs to the pass, the search reads best_rec instead
+    if (uni(s.carry_ok)) { // the walk goes on while this pass is still running (compress_cu); until it is joined this CU's luma in the picture belongs to
+      // the pass, the search reads best_rec instead
       LDS K &kk = s.k;
       wsync();
-      kk.sx0 = cu.x; kk.sy0 = cu.y; kk.sx1 = cu.x + (1 << cu.log2); kk.sy1 = cu.y + (1 << cu.log2);
-      if (lane_id() == 0) { s.carry = 1; s.p2_pending = 0; }
+      if (lane_id() == 0) {
+        kk.srect[pending - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
+        const int n = s.pend_n; s.pend_leaf[n] = s.leaf_idx - 1; s.pend_reg[n] = pending; s.pend_n = n + 1; s.p2_pending = 0; s.left_pending = 1;
+      }
       wsync();
       break;
     }
     // join: the second pass's verdict
-    LRegion &r2 = my_region(1);
+    LRegion &r2 = my_region(pending);
     region_wait(r2, 1);
+    const int pset = pending - 1;
     pending = 0;
     wsync();
     if (lane_id() == 0) s.p2_pending = 0;
@@ -3125,7 +3152,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     // the split won: take its distortion and arrays (its levels and reconstruction are in the record / best reconstruction already) and
     // repeat the chroma search and the syntax, which depend on the TU tree
     dist_l = (uint32_t)uni((int)r2.dist[0]);
-    GLB const uint8_t *at = slot_attr(k.slots, SLOT_P2);
+    GLB const uint8_t *at = slot_attr(k.slots, SLOT_P2 + SLOT_PSET * pset);
     for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_TRIDX][cu.zbase + i] = at[i]; s.a[A_CBF][cu.zbase + i] = at[256 + i]; s.a[A_TSKIP][cu.zbase + i] = at[512 + i]; }
     cabac_copy(k, &s.go, &s.curr[cu.depth]);
     wsync();
@@ -3163,6 +3190,14 @@ DEV void load_cand8(KR k, const Cu &cu)
 }
 
 // xCompressCU TEncCu.cpp:470-1104 with the reference's label-pruning edits (:496-520, 815-834, 947-965)
+//
+// Second passes left behind.  With the labels the walk over a CTU is a fixed sequence of CUs ("leaves": each is tested at exactly one depth), every one
+// starting from the coder state and the reconstruction its predecessor left.  The second luma pass of a CU (est_intra_luma) changes its result in ~5 % of
+// the cases and takes longer than everything else the master does for the CU, so the master does not wait for it: the pass stays pending (up to NPEND of
+// them, check_rd_cost_intra) while the walk goes on as if it changed nothing, and is joined when its ticket region is needed again, when it is seen to be
+// finished at the start of a later CU, or at the end of the CTU.  Every coded CU is logged (cost triple + the coder state behind it).  If a pass then does
+// choose the split, everything after its CU was built on the wrong reconstruction and coder state: the CTU is walked again (process_unit) -- the CUs before
+// that one are final (arrays, levels, picture) and only their logged results are replayed, that CU is coded again with its pass joined inside it.
 template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
 {
   CHECK_EXEC(9);
@@ -3177,14 +3212,34 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
   int best_is_real = 0;
   if (!boundary) {
     if (check_cur) {
-      Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N);
-      if (uni(s.restart)) return t;
-      if (ub(t.cost < best.cost)) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
-      if (DEPTH == 3) {
-        save_cand8(k, cu);
-        Rd t2 = check_rd_cost_intra(k, cu, SIZE_NxN);
-        if (ub(t2.cost < best.cost)) { best = t2; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
-        else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
+      const int li = uni(s.leaf_idx);
+      wsync();
+      if (lane_id() == 0) s.leaf_idx = li + 1;
+      wsync();
+      GLB unsigned long long *lg = s.my_log + (size_t)(li & 63) * (LEAF_LOG / 8);
+      if (li < uni(s.replay_upto)) { // walked before and final: its result and the coder state behind it from the log
+        const unsigned long long w0 = lg[0], w1 = lg[1];
+        best.cost = __longlong_as_double((long long)uni64(w0)); best.bits = (uint32_t)uni((int)(unsigned)w1); best.dist = (uint32_t)uni((int)(unsigned)(w1 >> 32));
+        state_from_global(&s.next[DEPTH], lg + 2);
+      } else {
+        // a pending pass that has finished meanwhile is joined right away: a restart costs the less the earlier it is seen
+        while (uni(s.pend_n) && lds_load(&my_region(uni(s.pend_reg[0])).done) >= 1) { pend_join_oldest(k); if (uni(s.restart)) return best; }
+        const int carry_ok = NPEND > 0 && DEPTH >= 1 && DEPTH <= 2 && li != uni(s.nocarry_leaf) && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
+        wsync();
+        if (lane_id() == 0) s.carry_ok = carry_ok;
+        wsync();
+        Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N);
+        if (uni(s.restart)) return t;
+        if (ub(t.cost < best.cost)) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
+        if (DEPTH == 3) {
+          save_cand8(k, cu);
+          Rd t2 = check_rd_cost_intra(k, cu, SIZE_NxN);
+          if (ub(t2.cost < best.cost)) { best = t2; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+          else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
+        }
+        wsync();
+        if (lane_id() == 0) { lg[0] = (unsigned long long)__double_as_longlong(best.cost); lg[1] = (unsigned long long)best.bits | ((unsigned long long)best.dist << 32); }
+        state_to_global(lg + 2, &s.next[DEPTH]);
       }
     } else { best.cost = MAX_DOUBLE / 16; best.dist = 0xffffffffu >> 3; best.bits = 0xffffffffu >> 3; }
     // split flag of the unsplit candidate (:858-867); for the dummy candidate the loaded state is stale and irrelevant
@@ -3196,51 +3251,18 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
     best.cost = calc_rd_cost(k, best.bits, best.dist);
     cabac_copy(k, &s.next[DEPTH], &s.go);
   }
-  if (best_is_real) for (int c = uni(s.carry) ? 1 : 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093 (luma stays with a pass that is still running)
+  if (best_is_real) for (int c = uni(s.left_pending) ? 1 : 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093 (luma stays with a pass that is still running)
   if constexpr (DEPTH < 3) {
     Rd temp = { 0, 0, 0 };
     const int h = size >> 1, qn = cu.nparts >> 2;
-    // A child that is a plain CU (label == its depth, inside the picture) followed by another such child may leave its second luma pass
-    // running while the next one starts (check_rd_cost_intra / est_intra_luma).  Should that pass then decide for the split (~5 % of CUs),
-    // both children are coded again from the state saved before the first of them, this time joining the pass inside the CU.
-    auto plain_leaf = [&](int j) -> int {
-      const int jx = x + (j & 1) * h, jy = y + (j >> 1) * h;
-      return jx + h <= k.W && jy + h <= k.H && uni(k.labels[k.addr * 16 + 4 * ((jy & 63) / 16) + (jx & 63) / 16]) == DEPTH + 1;
-    };
-    Rd temp_saved[2] = { temp, temp }; int no_carry = 0;
-    constexpr int SAVE_WORDS = (int)(offsetof(RdSmem, line) / 8);
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
       if (ub(sx < k.W && sy < k.H)) {
-        int carry_ok = 0;
-        if constexpr (DEPTH + 1 < 3) carry_ok = check_next && !no_carry && i < 3 && plain_leaf(i) && plain_leaf(i + 1) && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
-        no_carry = 0;
-        if (carry_ok) { // state to come back to (a pass still pending from child i - 1 will have been joined by then); two areas by parity of i
-          GLB unsigned long long *sv = s.my_save + (i & 1) * (SAVE_BYTES / 8);
-          wsync();
-          for (int q = lane_id(); q < SAVE_WORDS; q += 64) sv[q] = ((LDS const unsigned long long *)&s)[q];
-          if (i & 1) temp_saved[1] = temp; else temp_saved[0] = temp;
-        }
-        wsync();
-        if (lane_id() == 0) s.carry_ok = carry_ok;
-        wsync();
         cabac_copy(k, &s.curr[DEPTH + 1], (i == 0) ? &s.curr[DEPTH] : &s.next[DEPTH + 1]);
         Rd sub;
         if (check_next) sub = compress_cu<DEPTH + 1>(k, sx, sy);
         else { sub.cost = MAX_DOUBLE / 16; sub.dist = 0xffffffffu >> 3; sub.bits = 0xffffffffu >> 3; }
-        if (uni(s.restart)) { // raised inside child i: the pass left pending by child i - 1 chose the split
-          wsync();
-          { GLB const unsigned long long *sv = s.my_save + ((i - 1) & 1) * (SAVE_BYTES / 8);
-            for (int q = lane_id(); q < SAVE_WORDS; q += 64) ((LDS unsigned long long *)&s)[q] = sv[q]; }
-          wsync();
-          LDS K &kk = s.k;
-          kk.sx0 = kk.sy0 = kk.sx1 = kk.sy1 = 0;
-          if (lane_id() < 3) s.ref_key[lane_id()] = -1;
-          if (lane_id() == 0) { s.fline_key = -1; s.restart = 0; s.carry = 0; s.carry_ok = 0; s.p2_pending = 0; }
-          wsync();
-          temp = ((i - 1) & 1) ? temp_saved[1] : temp_saved[0]; no_carry = 1; i -= 2;         // child i - 1 again, without leaving its pass pending
-          continue;
-        }
+        if (uni(s.restart)) return best;
         temp.cost += sub.cost; temp.dist += sub.dist; temp.bits += sub.bits;
       } else if (check_next || boundary) { // initSubCU defaults copied to the picture (:989)
         const int z0 = cu.zbase + i * qn;
@@ -3332,11 +3354,11 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
   k.q_cost = s.my_qcost; k.q_rate = s.my_qrate; k.slots = s.my_slots;        // (a wave that served other masters' tasks holds their context)
-  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.sx0 = k.sy0 = k.sx1 = k.sy1 = 0;
+  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.srect[0] = k.srect[1] = 0; k.pset = 0; k.pad_pset = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
-  if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; s.carry_ok = 0; s.carry = 0; s.restart = 0; }
+  if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; s.carry_ok = 0; s.restart = 0; s.pend_n = 0; s.p2_pending = 0; s.left_pending = 0; }
   wsync();
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719.
   // A per-CTU call (hevcdl_compress_ctu) resumes from the state the previous call left instead.
@@ -3399,16 +3421,45 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    PROF_MARK(HEVCDL_BD == 8 ? 47 : 39);
-    const Rd best = compress_cu<0>(k, cx * 64, cy * 64);
-    PROF_MARK(HEVCDL_BD == 8 ? 45 : 39);
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.pend_n = 0; s.restart = 0; }
+    wsync();
+    PROF_MARK(47);
+    Rd best;
+    int encoded = 0;
+    for (;;) {
+      best = compress_cu<0>(k, cx * 64, cy * 64);
+      if (!uni(s.restart) && uni(s.pend_n)) { // passes still pending at the end of the CTU: the state-advancing encode below runs first, on the same assumption as
+        // the walk did (they change nothing), and they are joined behind it; the coder state it started from is kept (entry 64 of the log) in case one does
+        GLB unsigned long long *keep = s.my_log + 64 * (LEAF_LOG / 8);
+        state_to_global(keep, truec);
+        if (lane == 0) reset_bits(truec);
+        encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
+        encoded = 1;
+        while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k);
+        if (uni(s.restart)) { state_from_global(truec, keep); encoded = 0; }
+      }
+      if (!uni(s.restart)) break;
+      // a pending second pass chose the split: the walk again, replaying the CUs before its own (compress_cu)
+      wsync();
+#ifdef HEVCDL_KERNEL_PROF
+      if (lane == 0) PROF_ACC_(38, (unsigned long long)(s.leaf_idx - s.replay_upto) << 10);   // restarts, CUs thrown away
+#endif
+      if (lane < 3) s.ref_key[lane] = -1;
+      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; }
+      wsync();
+      cabac_copy(k, &s.curr[0], truec);
+      cabac_copy(k, &s.go, truec);
+    }
+    PROF_MARK(45);
     // the state-advancing encode (TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
     wsync();
-    if (lane == 0) reset_bits(truec);
-    encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
+    if (!encoded) {
+      if (lane == 0) reset_bits(truec);
+      encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
+    }
     wsync();
     if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)tb().t_ebits[126]; s.est_bits += truec->frac >> 15; }
-    PROF_MARK(HEVCDL_BD == 8 ? 46 : 39);
+    PROF_MARK(46);
     // flush the CTU record
     GLB unsigned char *rec = records + (size_t)a * REC_SIZE;
     for (int i = lane; i < 11 * 256 / 4; i += 64) ((GLB uint32_t *)rec)[i] = ((LDS const uint32_t *)&s.a[0][0])[i];
@@ -3417,7 +3468,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       *(GLB double *)(rec + REC_COST) = best.cost;
     }
     wsync();
-    PROF_MARK(HEVCDL_BD == 8 ? 47 : 39);
+    PROF_MARK(47);
   }
   if (p.cabac_out) {
     wsync();
@@ -3454,6 +3505,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   {
     GLB unsigned char *scr = (GLB unsigned char *)p.scratch + ((size_t)blockIdx.x * NW + wave) * p.scratch_per_wave;
     s.my_coef = (GLB int16_t *)scr; s.my_rec = (GLB pel_t *)(scr + 4 * 6144 * 2); s.my_ovl = s.my_rec + 5 * 6144; s.my_save = (GLB unsigned long long *)(s.my_ovl + 6144);
+    s.my_log = s.my_save + N_SAVE * (SAVE_BYTES / 8);
     s.my_qcost = (GLB double *)(scr + SCR_LAYERS); s.my_qrate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
     s.my_slots = scr + SCR_LAYERS + SCR_RDOQ;
   }
@@ -3466,7 +3518,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     else if (wave > base) first = n_units;
   }
   LDS WgShared &sh = wg_shared();
-  if (lane == 0) for (int q = 0; q < 2; q++) { sh.reg[wave][q].ticket = 0; sh.reg[wave][q].done = 0; sh.reg[wave][q].owner = wave; }
+  if (lane == 0) for (int q = 0; q < NREG; q++) { sh.reg[wave][q].ticket = 0; sh.reg[wave][q].done = 0; sh.reg[wave][q].owner = wave; }
   if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
     LDS Tables &t = sh.tab;
     for (int r = lane; r < 256; r += 64) {
@@ -3492,7 +3544,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m; }
   }
 #ifdef HEVCDL_KERNEL_PROF
-  if (lane < (HEVCDL_BD == 8 ? 64 : 40)) { s.prof[lane] = 0; s.prof_n[lane] = 0; } if (lane == 0) s.prof_task = 0;
+  s.prof[lane] = 0; if (lane == 0) s.prof_task = 0;
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
@@ -3527,9 +3579,9 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 #ifdef HEVCDL_KERNEL_PROF
   // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)
   wsync();
-  if (blockIdx.x == 0 && p.dbgbuf && lane < (HEVCDL_BD == 8 ? 64 : 40)) {
-    if (lane == 14) { s.prof[14] = __builtin_readcyclecounter() - prof_start_; s.prof_n[14] = 1; }
-    atomicAdd(&p.dbgbuf[1 + 2 * lane], (unsigned int)(s.prof[lane] >> 10)); atomicAdd(&p.dbgbuf[2 + 2 * lane], s.prof_n[lane]);
+  if (blockIdx.x == 0 && p.dbgbuf) {
+    if (lane == 14) s.prof[14] = ((__builtin_readcyclecounter() - prof_start_) & 0xffffffffffull) + (1ull << 40);
+    atomicAdd(&p.dbgbuf[1 + 2 * lane], (unsigned int)((s.prof[lane] & 0xffffffffffull) >> 10)); atomicAdd(&p.dbgbuf[2 + 2 * lane], (unsigned int)(s.prof[lane] >> 40));
     if (lane == 0) p.dbgbuf[0] = 64;
   }
 #endif

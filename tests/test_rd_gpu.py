@@ -284,7 +284,7 @@ def test_kernel_stages_cover_the_reference_traces(name, tmp_path):
     missing_lines, missing_tus = ref_lines - dev_lines, ref_tus - dev_tus
     assert not missing_lines, "%d of %d cost lines missing, e.g. %s" % (len(missing_lines), len(ref_lines), sorted(missing_lines)[:3])
     assert not missing_tus, "%d of %d TU events missing, e.g. %s" % (len(missing_tus), len(ref_tus), [t[:3] for t in sorted(missing_tus)[:5]])
-    assert dev_lines == ref_lines                                    # the mode search itself is never speculative: not one cost line more
+    assert len(dev_lines - ref_lines) <= len(ref_lines) // 20        # the mode search of a CU coded while an earlier CU's second pass is pending is thrown away when that pass chooses the split
     assert len(dev_tus - ref_tus) <= len(ref_tus) // 20              # speculative codings that were thrown away (measured: 0 and 62 of 5443)
     assert len(ref_lines) > 1000 and len(ref_tus) > 1000
 
