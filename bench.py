@@ -10,7 +10,11 @@ are independent, so there is no data-path collective; RCCL only gathers the per-
 Prints ONE JSON line on rank 0 (metric of BASELINE.json + roofline + cpu_baseline); on the single-GPU run it additionally carries
   "saturated"    the same step over 2048 frames per GPU (every wave of the chip owns a frame: the throughput ceiling of the kernel),
   "c2"           C2 of BASELINE.json (10 frames of 1920x1080) next to the reference encoder on 10 host cores in the same run,
-  "parity_check" the reference encoder's own CTU records / reconstruction for the top band of the timed frames against the GPU's.
+  "parity_check" the reference encoder's own CTU records / reconstruction against the GPU's: whole frames of the timed job (every CTU row, the ragged
+                 bottom row of 2160p included) and the top band of 256 more,
+  "e2e"          the same 600 frames through the WHOLE picture pipeline (CNN, decisions, deblocking, SAO on the device; final entropy coding on host
+                 threads) -- the stage list of the CPU baseline, for a like-for-like ratio,
+  "latency_floor_s" one frame alone on the GPU: a frame is a serial chain of CTUs, so no sharding of the job finishes sooner than this.
 """
 import argparse
 import hashlib
@@ -171,7 +175,7 @@ def effective_cores():
     return n
 
 
-def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=6, gpu_records=None, gpu_recon=None):
+def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=None, band_rows=6, gpu_records=None, gpu_recon=None, gpu_records_full=None):
     """The reference itself on the host cores.  (1) P = usable cores: P processes, a whole frame of the workload each,
     wall clock from first start to last exit -> value.  (2) one such process alone -> one_process.  (3) parity: the top `band_rows` CTU
     rows of every sampled frame (the decisions of those rows do not depend on the rows below) are encoded with the CTU-record dump of
@@ -187,6 +191,12 @@ def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=N
     w1, _, _ = run_reference_pictures([yuv_host[0]], np.ascontiguousarray(labels_host[:1]), width, height, qp, 1)
     out["one_process"] = {"value": nct / w1, "unit": "CTUs/s", "cores": 1, "sample": "one whole frame, one process alone on the node, %.1f s" % w1}
     parity = None
+    whole = None
+    if gpu_records_full is not None:      # the p whole frames once more, OUTSIDE the timed legs, with the CTU-record dump of oracle/ref_hook.cpp: every CTU of the picture
+        t = time.time()
+        _, _, dumps = run_reference_pictures([yuv_host[i] for i in range(p)], np.ascontiguousarray(labels_host[:p]), width, height, qp, p, dump=True)
+        whole = parity_against_dumps(dumps, gpu_records_full[:p], [gpu_recon[i] for i in range(p)], width, height)
+        whole["sample"] = "%d WHOLE %dx%d frames of the timed job (all %d CTU rows, the last one half outside the picture), %.1f s" % (p, width, height, (height + 63) // 64, time.time() - t)
     if gpu_records is not None:
         n = gpu_records.shape[0]
         bh = min(height, 64 * band_rows)
@@ -196,6 +206,15 @@ def cpu_baseline_reference(yuv_host, labels_host, width, height, qp, max_procs=N
         _, _, dumps = run_reference_pictures(bands, np.ascontiguousarray(labels_host[:n, :nb]), width, bh, qp, n, dump=True, workers=cores)
         parity = parity_against_dumps(dumps, gpu_records, [_band(gpu_recon[i], width, height, bh) for i in range(n)], width, bh)
         parity["sample"] = "top %dx%d band (%d CTU rows) of %d frames of the timed job, %.1f s" % (width, bh, band_rows, n, time.time() - t)
+    if whole is not None:                 # one record: whole frames first, the bands of more frames beside them
+        bands = parity
+        parity = dict(whole)
+        if bands is not None:
+            parity["ctus"] += bands["ctus"]; parity["mismatches"] += bands["mismatches"]
+            parity["first_mismatch"] = parity["first_mismatch"] or bands["first_mismatch"]
+            parity["sample"] = whole["sample"] + " + " + bands["sample"]
+            parity["whole_frames"] = {"ctus": whole["ctus"], "mismatches": whole["mismatches"]}
+            parity["bands"] = {"ctus": bands["ctus"], "mismatches": bands["mismatches"]}
     return out, parity
 
 
@@ -254,6 +273,86 @@ def timed_steps(torch, enc, tensors, n_frames, steps, warmup, barrier):
     return elapsed, prof
 
 
+E2E_STAGES = ("on-device label CNN + CTU decisions + deblocking + SAO, frames resident in HBM; CTU records, SAO parameters and final pictures copied to page-locked host "
+              "memory; final entropy coding of every access unit (hevcdl_write_access_unit: parameter sets + slice) on host threads, chunk by chunk while the next "
+              "chunk is copied; streams and pictures stay in memory (no file I/O, no process start-up)")
+
+
+def e2e_leg(torch, hevcdl_amd, dev, enc, tensors, n_frames, width, height, qp, chunk=60):
+    """The job once more through the WHOLE picture pipeline -- the stages the CPU baseline's number contains (TEncGOP.cpp:1742-1935: decisions, in-loop filters,
+    entropy coding), the label CNN on top: one like-for-like throughput.  The device side is one batch (a smaller batch is no faster: a frame is a serial
+    chain); the host codes chunk k on its threads while chunk k + 1 is copied."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    yuv, labels, records, recon, stats = tensors
+    lib, ctus = enc.lib, enc.ctus
+    rec_b, sao_b = hevcdl_amd.REC_DTYPE.itemsize * ctus, hevcdl_amd.SAO_DTYPE.itemsize * 3 * ctus
+    final = torch.empty_like(recon)
+    sao = torch.zeros((max(1, n_frames), sao_b), dtype=torch.uint8, device=dev)
+    chunk = max(1, min(chunk, n_frames))
+    hbuf = [(torch.empty((chunk, rec_b), dtype=torch.uint8).pin_memory(), torch.empty((chunk, sao_b), dtype=torch.uint8).pin_memory(),
+             torch.empty((chunk, recon.shape[1]), dtype=torch.uint8).pin_memory()) for _ in range(2)]
+    threads = effective_cores()
+    cfg = hevcdl_amd.StreamConfig()
+    if lib.hevcdl_stream_config_default(ctypes.byref(cfg), width, height, qp) != 0:
+        raise RuntimeError("stream config")
+    cfg.sao_enabled = 1
+    cap = lib.hevcdl_access_unit_bound(width, height)
+    outs = [np.empty(cap, np.uint8) for _ in range(threads)]
+    free = list(range(threads))
+
+    def code(args):
+        poc, recs_np, sao_np = args
+        t = free.pop()
+        n = ctypes.c_size_t(0)
+        st = lib.hevcdl_write_access_unit(ctypes.byref(cfg), int(poc), recs_np.ctypes.data, sao_np.ctypes.data, outs[t].ctypes.data, cap, ctypes.byref(n))
+        free.append(t)
+        if st != 0:
+            raise RuntimeError("write_access_unit %d" % st)
+        return n.value
+
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    enc.encode_frames_dev(yuv.data_ptr(), n_frames, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), main.cuda_stream)
+    enc.deblock_frames_dev(recon.data_ptr(), n_frames, records.data_ptr(), recon.data_ptr(), main.cuda_stream)
+    enc.sao_frames_dev(yuv.data_ptr(), recon.data_ptr(), n_frames, sao.data_ptr(), final.data_ptr(), main.cuda_stream)
+    torch.cuda.synchronize(dev)
+    t_dev = time.perf_counter() - t0
+    recs2d = records.view(max(1, records.shape[0]), -1)
+
+    def fetch(ci):
+        b0 = ci * chunk
+        nb = min(chunk, n_frames - b0)
+        h = hbuf[ci & 1]
+        with torch.cuda.stream(copy_stream):
+            h[0][:nb].copy_(recs2d[b0:b0 + nb], non_blocking=True)
+            h[1][:nb].copy_(sao[b0:b0 + nb], non_blocking=True)
+            h[2][:nb].copy_(final[b0:b0 + nb], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        return ev, b0, nb
+
+    total_bytes = 0
+    n_chunks = (n_frames + chunk - 1) // chunk
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        nxt = fetch(0)
+        for ci in range(n_chunks):
+            ev, b0, nb = nxt
+            ev.synchronize()
+            h = hbuf[ci & 1]
+            r_np, s_np = h[0].numpy(), h[1].numpy()
+            fut = pool.map(code, [(b0 + i, r_np[i], s_np[i]) for i in range(nb)])
+            if ci + 1 < n_chunks:
+                nxt = fetch(ci + 1)              # into the other buffer: the host codes this chunk meanwhile
+            total_bytes += sum(fut)
+    dt = time.perf_counter() - t0
+    del final, sao, hbuf
+    return {"value": n_frames * ctus / dt, "unit": "CTUs/s", "pictures_per_s": n_frames / dt, "seconds": dt, "device_seconds": t_dev, "host_threads": threads,
+            "frames": n_frames, "stream_bytes": int(total_bytes), "stages": E2E_STAGES}
+
+
 def alloc(torch, hevcdl_amd, dev, n, frame_bytes, ctus):
     return (torch.zeros((n, ctus, 16), dtype=torch.uint8, device=dev), torch.zeros((n, ctus, hevcdl_amd.REC_DTYPE.itemsize), dtype=torch.uint8, device=dev),
             torch.zeros((n, frame_bytes), dtype=torch.uint8, device=dev), torch.zeros((n, hevcdl_amd.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev))
@@ -271,6 +370,8 @@ def main():
     ap.add_argument("--saturated-frames", type=int, default=2048, help="extra single-GPU measurement with this many frames in flight (0: skip)")
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-latency-floor", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=0)
     ap.add_argument("--cpu-baseline", default="reference", choices=["reference", "port"], help="reference: oracle/_ref/TAppEncoder_ref when present; port: the plain-C oracle")
     a = ap.parse_args()
@@ -311,6 +412,15 @@ def main():
     yuv = synth_frames_torch(torch, dev, W, H, list(mine), seed=1000)
     labels, records, recon, stats = alloc(torch, hevcdl_amd, dev, max(1, Fr), enc.frame_bytes, ctus)
     elapsed, prof = timed_steps(torch, enc, (yuv, labels, records, recon, stats), Fr, a.steps, a.warmup, barrier)
+    # one frame alone (outside the timed steps): the serial CTU chain of a frame bounds what any sharding of the job can reach
+    floor_s = None
+    if Fr > 0 and not a.no_latency_floor:
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        enc.encode_frames_dev(yuv.data_ptr(), 1, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize(dev)
+        floor_s = time.perf_counter() - t1
+        # (frame 0's records / reconstruction / statistics are rewritten with the values the whole job gave them: frames are independent, the kernel deterministic)
 
     # per-frame summaries (estimated bits) gathered to rank 0: the only collective of the path
     st = np.frombuffer(stats.cpu().numpy().tobytes(), dtype=hevcdl_amd.STATS_DTYPE)["est_bits"].astype(np.int64)[:Fr]
@@ -347,6 +457,10 @@ def main():
                          "units_per_launch": "%d frames x %d CTUs (rank 0)" % (Fr, ctus)},
             "est_bits_per_frame": total_bits / max(1, F),
         }
+        if floor_s:
+            out["latency_floor_s"] = floor_s
+            out["strong_scaling_ceiling"] = {"value": F * ctus / floor_s, "unit": "CTUs/s",
+                                             "note": "the whole job in the time one frame takes alone on a GPU (rank 0: %.3f s): more GPUs than frames-per-CU can use do not help" % floor_s}
         if world == 1:
             if not a.no_cpu_baseline:       # the CPU baseline is timed on rank 0 of the single-GPU run only
                 nb = min(Fr, 256)                      # frames sampled for the parity check
@@ -354,13 +468,20 @@ def main():
                 rows = 6
                 if os.path.exists(REF_ENC) and a.cpu_baseline != "port":
                     rec_h = np.frombuffer(records[:nb, :cx * rows].contiguous().cpu().numpy().tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nb, cx * rows)
+                    nw = min(Fr, a.cpu_procs or effective_cores())          # the frames the timed CPU leg encodes whole
+                    rec_w = np.frombuffer(records[:nw].contiguous().cpu().numpy().tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nw, ctus)
                     cb, parity = cpu_baseline_reference(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None, rows,
-                                                        gpu_records=rec_h, gpu_recon=recon[:nb].cpu().numpy())
+                                                        gpu_records=rec_h, gpu_recon=recon[:nb].cpu().numpy(), gpu_records_full=rec_w)
                 else:     # the reference build travels with the repository (oracle/_ref); without it the plain-C port stands in
                     cb, parity = cpu_baseline_port(yuv[:nb].cpu().numpy(), labels[:nb].cpu().numpy(), W, H, qp, a.cpu_procs or None)
                 out["cpu_baseline"] = cb
                 if parity is not None:
                     out["parity_check"] = parity
+            if not a.no_e2e:
+                out["e2e"] = e2e_leg(torch, hevcdl_amd, dev, enc, (yuv, labels, records, recon, stats), Fr, W, H, qp)
+                if "cpu_baseline" in out and out["cpu_baseline"].get("kind") == "reference":
+                    out["e2e"]["over_cpu_baseline"] = out["e2e"]["value"] / out["cpu_baseline"]["value"]
+                    out["e2e"]["stages_cpu"] = REF_STAGES
             del yuv, labels, records, recon, stats
             enc.close()
             torch.cuda.empty_cache()

@@ -57,7 +57,7 @@ class Config(ctypes.Structure):
                 ("lambda_", ctypes.c_double), ("sqrt_lambda", ctypes.c_double), ("chroma_weight", ctypes.c_double),
                 ("lambda_chroma", ctypes.c_double), ("err_scale", (ctypes.c_double * 4) * 2),
                 ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32),
-                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("exec_flags", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
                 ("lf_across_tiles", ctypes.c_int32)]
 

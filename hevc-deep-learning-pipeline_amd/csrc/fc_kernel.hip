@@ -146,23 +146,7 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
       if (q == 3 && zero && lab[8] != 0) d[0] = d[1] = d[2] = d[3] = 1;
       for (int k = 0; k < 4; k++) lab[quads[q][k]] = (uint8_t)d[k];
     }
-    if (p.clamp) {
-      int mxl = 0;
-      for (int c = 0; c < 16; c++) {
-        const int px = x0 + (c & 3) * 16, py = y0 + (c >> 2) * 16;
-        int md = 0;
-        if (px < p.width && py < p.height) {
-          while (md < 3) { const int s = 64 >> md; if ((px / s) * s + s <= p.width && (py / s) * s + s <= p.height) break; md++; }
-        }
-        if (lab[c] < md) lab[c] = (uint8_t)md;
-        if (lab[c] > mxl) mxl = lab[c];
-      }
-      if (mxl > 0) for (int c = 0; c < 16; c++) if (lab[c] < 1) lab[c] = 1;
-      for (int q = 0; q < 4; q++) {
-        int m = 0; for (int k = 0; k < 4; k++) if (lab[quads[q][k]] > m) m = lab[quads[q][k]];
-        if (m >= 2) for (int k = 0; k < 4; k++) if (lab[quads[q][k]] < 2) lab[quads[q][k]] = 2;
-      }
-    }
+    if (p.clamp) hevcdl_clamp_ctu_labels(lab, x0, y0, p.width, p.height);
     for (int c = 0; c < 16; c++) ((uint8_t GLB *)p.labels)[(size_t)(blockIdx.x * 16 + tid) * 16 + c] = lab[c];
   }
 }

@@ -33,22 +33,9 @@ __global__ void hevcdl_clamp_labels_kernel(uint8_t *labels, int n_ctus, int ctus
   if (g >= n_ctus) return;
   const int addr = g % ctus_per_frame, x0 = (addr % ctus_x) * 64, y0 = (addr / ctus_x) * 64;
   uint8_t *lab = labels + (size_t)g * 16;
-  const int quads[4][4] = { {0, 1, 4, 5}, {2, 3, 6, 7}, {8, 9, 12, 13}, {10, 11, 14, 15} };
-  int l[16], mxl = 0;
-  for (int c = 0; c < 16; c++) {
-    l[c] = lab[c];
-    if (l[c] > 3) { *bad = 1; l[c] = 3; }
-    const int px = x0 + (c & 3) * 16, py = y0 + (c >> 2) * 16;
-    int md = 0;
-    if (px < width && py < height) while (md < 3) { const int s = 64 >> md; if ((px / s) * s + s <= width && (py / s) * s + s <= height) break; md++; }
-    if (l[c] < md) l[c] = md;
-    if (l[c] > mxl) mxl = l[c];
-  }
-  if (mxl > 0) for (int c = 0; c < 16; c++) if (l[c] < 1) l[c] = 1;
-  for (int q = 0; q < 4; q++) {
-    int m = 0; for (int k = 0; k < 4; k++) if (l[quads[q][k]] > m) m = l[quads[q][k]];
-    if (m >= 2) for (int k = 0; k < 4; k++) if (l[quads[q][k]] < 2) l[quads[q][k]] = 2;
-  }
+  uint8_t l[16];
+  for (int c = 0; c < 16; c++) { l[c] = lab[c]; if (l[c] > 3) { *bad = 1; l[c] = 3; } }
+  hevcdl_clamp_ctu_labels(l, x0, y0, width, height);
   for (int c = 0; c < 16; c++) lab[c] = (uint8_t)l[c];
 }
 
@@ -174,7 +161,8 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   // keys that would change the path are rejected, not ignored
   if ((cfg->bit_depth != 8 && cfg->bit_depth != 10) || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
       cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
-      cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA))
+      cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA) ||
+      (cfg->exec_flags & ~HEVCDL_EXEC_NO_UNIT_HANDOVER))
     return HEVCDL_ERR_UNSUPPORTED;
   { // tiles: uniform spacing, every column at least 4 CTUs wide and every row 1 CTU high (TComPicSym.cpp:380-392), at most 20 x 22 (level 6.2)
     const int cx = (cfg->width + 63) >> 6, cy = (cfg->height + 63) >> 6;
@@ -360,7 +348,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // per workgroup.
   p.sched = ctx->d_sched;
   p.migrate = (n_units > groups && n_units % groups != 0 && n_units / groups <= 3 && groups <= 1024 && groups >= 8 && !d_cabac_in && !d_cabac_out &&
-               ctu_begin == 0 && p.ctu_end == ctx->ctus) ? 1 : 0;
+               ctu_begin == 0 && p.ctu_end == ctx->ctus && !(ctx->cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER)) ? 1 : 0;
   if (p.migrate) {
     std::vector<int> init(16 + groups, 0);
     const int base = n_units / groups, extra = n_units % groups;
@@ -369,10 +357,16 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
     HIPCHK(hipMemcpyAsync(ctx->d_sched, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));      // pageable source: the copy is staged before the call returns
   }
   prof_begin(ctx, ctx->ev_rd, s);
-  if (ctx->cfg.bit_depth == 8)
-    hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), hevcdl_rd_smem_bytes(), s, p);
-  else
-    hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), hevcdl_rd_smem_bytes_bd10(), s, p);
+  const void *kern = ctx->cfg.bit_depth == 8 ? (const void *)hevcdl_rd_frame_kernel : (const void *)hevcdl_rd_frame_kernel_bd10;
+  const size_t smem = ctx->cfg.bit_depth == 8 ? hevcdl_rd_smem_bytes() : hevcdl_rd_smem_bytes_bd10();
+  if (p.migrate) { // workgroups that wait for each other: a cooperative launch, which the runtime only accepts when the whole grid can be resident at once
+    void *args[] = { &p };
+    if (hipLaunchCooperativeKernel(kern, dim3(groups), dim3(threads), args, smem, s) != hipSuccess) { (void)hipGetLastError(); p.migrate = 0; }
+  }
+  if (!p.migrate) {
+    if (ctx->cfg.bit_depth == 8) hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), smem, s, p);
+    else hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), smem, s, p);
+  }
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
 #if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)

@@ -112,6 +112,38 @@ static inline int hevcdl_tile_bounds(int n_ctus, int n_tiles, int uniform, const
   return bd[n_tiles] == n_ctus ? 0 : -1;
 }
 
+// Boundary policy HEVCDL_BOUNDARY_CLAMP for the 16 labels of the CTU at (x0, y0) (shared by the CNN head kernel and the check of caller labels):
+//  1. a cell's label is raised to the smallest depth at which the CU containing the cell lies inside the picture;
+//  2. what the reference's walk then READS is made valid, nothing else is touched.  The walk (TEncCu.cpp:496-520) looks at ONE label per CU, the
+//     one of its top-left 16x16 cell: label == depth codes the CU, label > depth splits it, label < depth would leave it undecided.  So: a CTU
+//     inside the picture whose first label is 0 is one 64x64 CU and the other 15 labels are never read (use_model.py:101-119 does emit such sets:
+//     they stay as they are); otherwise every 32x32 quadrant inside the picture is visited -- a first label of 0 becomes 1 -- and where a
+//     quadrant is split (first label >= 2, or the picture edge forces it) each of its cells inside the picture is read and raised to 2.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+static inline void hevcdl_clamp_ctu_labels(uint8_t *lab, int x0, int y0, int width, int height)
+{
+  const int quads[4][4] = { {0, 1, 4, 5}, {2, 3, 6, 7}, {8, 9, 12, 13}, {10, 11, 14, 15} };
+  int md[16], inside[16], forced0 = 0;
+  for (int c = 0; c < 16; c++) {
+    const int px = x0 + (c & 3) * 16, py = y0 + (c >> 2) * 16;
+    md[c] = 0; inside[c] = px < width && py < height;
+    if (inside[c]) { while (md[c] < 3) { const int s = 64 >> md[c]; if ((px / s) * s + s <= width && (py / s) * s + s <= height) break; md[c]++; } }
+    if (lab[c] < md[c]) lab[c] = (uint8_t)md[c];
+    if (md[c] >= 1) forced0 = 1;
+  }
+  if (!forced0 && lab[0] == 0) return;
+  for (int q = 0; q < 4; q++) {
+    const int q0 = quads[q][0];
+    if (!inside[q0]) continue;
+    int forced1 = 0;
+    for (int k = 0; k < 4; k++) if (inside[quads[q][k]] && md[quads[q][k]] >= 2) forced1 = 1;
+    if (!forced1 && lab[q0] < 1) lab[q0] = 1;
+    if (forced1 || lab[q0] >= 2) for (int k = 0; k < 4; k++) if (inside[quads[q][k]] && lab[quads[q][k]] < 2) lab[quads[q][k]] = 2;
+  }
+}
+
 #ifdef __cplusplus
 extern "C" {
 #endif

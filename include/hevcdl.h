@@ -74,7 +74,14 @@ typedef struct hevcdl_config {
    * 1 x 1 = no tiles.  Every tile is at least 4 CTUs wide (the reference's own limit, TComPicSym.cpp:388).  Tiles are independent
    * units of the decision path: one wavefront per (frame, tile). */
   int32_t  tile_columns, tile_rows;
-  int32_t  reserved;
+  /* Execution options of the decision kernel (0 = default; formerly a reserved field that had to be 0).
+   * HEVCDL_EXEC_NO_UNIT_HANDOVER: never let a frame travel between workgroups.  With more frames than compute units and an uneven split (600 frames on
+   * 256 CUs) the kernel hands frames round a ring of workgroups so that every CU is crowded for the same share of the time; workgroups then wait for
+   * each other, which needs ALL of them resident at once.  The library therefore launches that form cooperatively (the runtime refuses the launch when
+   * it cannot co-schedule the grid -- another context holding CUs or LDS, a CU mask -- and the library falls back to the independent form by itself);
+   * set this bit to use the independent form always, e.g. when several contexts / processes share the device by design. */
+  int32_t  exec_flags;
+#define HEVCDL_EXEC_NO_UNIT_HANDOVER 1
   /* TileUniformSpacing 0: explicit sizes in CTUs of every tile column / row but the last (TileColumnWidthArray, TileRowHeightArray,
    * TAppEncCfg.cpp:1026-1028); ignored when tile_uniform_spacing != 0 (the default) */
   int32_t  tile_uniform_spacing;

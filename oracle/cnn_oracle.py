@@ -139,20 +139,47 @@ def min_depth_table(width, height):
     return t
 
 
+def clamp_ctu_labels(lab, md, inside):
+    """Boundary policy for the 16 labels of one CTU (restates hevcdl_clamp_ctu_labels, csrc/hevcdl_dev.h): raise every cell to the smallest
+    depth whose CU lies inside the picture, then make valid what the reference's walk reads -- ONE label per CU, the one of its top-left cell
+    (TEncCu.cpp:496-520) -- and nothing else: a first label of 0 in a CTU inside the picture means one 64x64 CU (the other labels are not
+    read and stay); otherwise a visited 32x32 quadrant whose first label is 0 gets 1, and the cells of a split quadrant get at least 2."""
+    lab = np.maximum(np.asarray(lab, np.uint8), md)
+    forced0 = bool((md[inside] >= 1).any())
+    if not forced0 and lab[0] == 0:
+        return lab
+    for q in QUADS:
+        q = list(q)
+        if not inside[q[0]]:
+            continue
+        forced1 = any(inside[c] and md[c] >= 2 for c in q)
+        if not forced1 and lab[q[0]] < 1:
+            lab[q[0]] = 1
+        if forced1 or lab[q[0]] >= 2:
+            for c in q:
+                if inside[c] and lab[c] < 2:
+                    lab[c] = 2
+    return lab
+
+
+def inside_table(width, height):
+    """Per CTU, per 16x16 cell: does the cell lie inside the picture."""
+    cx, cy = (width + 63) // 64, (height + 63) // 64
+    t = np.zeros((cy * cx, 16), bool)
+    for a in range(cx * cy):
+        for c in range(16):
+            t[a, c] = (a % cx) * 64 + (c % 4) * 16 < width and (a // cx) * 64 + (c // 4) * 16 < height
+    return t
+
+
 def clamp_labels(labels, width, height):
-    """Boundary policy of this project: raise labels to the minimum in-picture depth, then restore quadtree
-    validity (split CTU -> every cell >= 1; split 32x32 quadrant -> every cell >= 2)."""
-    md = min_depth_table(width, height)
-    out = np.maximum(labels.reshape(-1, md.shape[0], 16), md[None]).astype(np.uint8)
-    flat = out.reshape(-1, 16)
-    for lab in flat:
-        if lab.max() > 0:
-            np.maximum(lab, 1, out=lab)
-        for q in QUADS:
-            q = list(q)
-            if lab[q].max() >= 2:
-                lab[q] = np.maximum(lab[q], 2)
-    return flat.reshape(labels.shape)
+    """Boundary policy of this project for [frames, ctus, 16] labels: see clamp_ctu_labels."""
+    md, ins = min_depth_table(width, height), inside_table(width, height)
+    out = np.array(labels, np.uint8).reshape(-1, md.shape[0], 16)
+    for f in range(out.shape[0]):
+        for a in range(md.shape[0]):
+            out[f, a] = clamp_ctu_labels(out[f, a], md[a], ins[a])
+    return out.reshape(np.shape(labels))
 
 
 def yuv_to_rgb_ctus(yuv_frame, width, height, mode="rgb601"):

@@ -96,24 +96,21 @@ def fixup_labels(lab):
     return lab
 
 
-def clamp_labels(lab, md):
-    """Boundary policy: raise labels to the minimum depth that keeps every coded CU
-    inside the picture, then restore quadtree validity (a CTU that is split has every cell >= 1; a 32x32
-    quadrant that is split has every cell >= 2)."""
-    lab = np.maximum(np.asarray(lab, np.uint8), md)
-    if lab.max() > 0:
-        lab = np.maximum(lab, 1)
-    for q in ((0, 1, 4, 5), (2, 3, 6, 7), (8, 9, 12, 13), (10, 11, 14, 15)):
-        q = list(q)
-        if lab[q].max() >= 2:
-            lab[q] = np.maximum(lab[q], 2)
-    return lab
+def clamp_labels(lab, md, inside=None):
+    """Boundary policy for the 16 labels of one CTU (cnn_oracle.clamp_ctu_labels: raise to the in-picture depth, then make valid exactly what
+    the reference's walk reads)."""
+    import cnn_oracle
+    if inside is None:
+        inside = np.ones(16, bool)
+    return cnn_oracle.clamp_ctu_labels(lab, md, inside)
 
 
 def make_labels(width, height, n_frames, kind, seed=0):
     """kind: 0..3 = constant depth; 'rand' = random valid quadtrees.  Always clamped to the picture."""
     cx, cy = (width + 63) // 64, (height + 63) // 64
+    import cnn_oracle
     md = min_depth_table(width, height)
+    ins = cnn_oracle.inside_table(width, height)
     rng = np.random.default_rng(seed)
     labs = np.zeros((n_frames, cx * cy, 16), np.uint8)
     for f in range(n_frames):
@@ -127,7 +124,7 @@ def make_labels(width, height, n_frames, kind, seed=0):
                             lab[i] = t
             else:
                 lab = [int(kind)] * 16
-            labs[f, a] = clamp_labels(lab, md[a])
+            labs[f, a] = clamp_labels(lab, md[a], ins[a])
     return labs
 
 

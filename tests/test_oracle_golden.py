@@ -118,25 +118,49 @@ def test_label_postprocessing_matches_reference_lines():
     assert np.array_equal(cnn_oracle.labels_from_logits(fake), f["labels"])
 
 
+def walk_is_valid(lab, x0, y0, w, h):
+    """The reference's walk over one CTU (TEncCu.cpp:496-520: ONE label per CU, the one of its top-left 16x16 cell; a CU that straddles the picture edge is
+    split without asking): every CU it reaches inside the picture is either coded (label == depth) or split (label > depth), never left undecided, and every
+    coded CU lies inside the picture.  Returns the number of coded CUs, or -1."""
+    def cu(x, y, depth):
+        size = 64 >> depth
+        if x >= w or y >= h:
+            return 0
+        straddles = x + size > w or y + size > h
+        d = int(lab[4 * ((y - y0) // 16) + (x - x0) // 16])
+        if not straddles and d == depth:
+            return 1
+        if (straddles or d > depth) and depth < 3:
+            parts = [cu(x + (i & 1) * size // 2, y + (i >> 1) * size // 2, depth + 1) for i in range(4)]
+            return -1 if min(parts) < 0 else sum(parts)
+        return -1                        # label below the depth (or an 8x8 CU across the edge: sizes are multiples of 8, cannot happen)
+    return cu(x0, y0, 0)
+
+
 @pytest.mark.parametrize("w,h", [(416, 240), (1920, 1080), (3840, 2160), (7680, 4320), (200, 136), (128, 128)])
 def test_boundary_clamp_table_and_validity(w, h):
-    """F-cnn-4: the clamp keeps every coded CU inside the picture and the labels a valid quadtree."""
+    """F-cnn-4: after the clamp the reference's walk codes every CU inside the picture and leaves none undecided; label sets that already are valid for
+    the walk come back unchanged -- in particular a first label of 0 with other labels above it (use_model.py:101-119 emits those: one 64x64 CU)."""
     import cnn_oracle
     md = cnn_oracle.min_depth_table(w, h)
     rng = np.random.default_rng(w + h)
     raw = rng.integers(0, 4, (3, md.shape[0], 16)).astype(np.uint8)
     lab = cnn_oracle.clamp_labels(raw, w, h)
     assert (lab >= md[None]).all()
+    assert np.array_equal(cnn_oracle.clamp_labels(lab, w, h), lab)                     # idempotent
     cx = (w + 63) // 64
+    for f in range(3):
+        for a in range(md.shape[0]):
+            x0, y0 = (a % cx) * 64, (a // cx) * 64
+            assert walk_is_valid(lab[f, a], x0, y0, w, h) > 0, (f, a, raw[f, a], lab[f, a])
+            if md[a].max() == 0 and walk_is_valid(raw[f, a], x0, y0, w, h) > 0:
+                assert np.array_equal(lab[f, a], raw[f, a]), (f, a)                       # inside the picture a valid set is never touched
+    first0 = np.array([0, 0, 2, 3, 0, 0, 3, 2, 1, 1, 2, 2, 1, 1, 2, 2], np.uint8)         # what use_model.py gives when its first forward says "one CU"
+    out = cnn_oracle.clamp_labels(np.tile(first0, (1, md.shape[0], 1)), w, h)
+    ins = cnn_oracle.inside_table(w, h)
     for a in range(md.shape[0]):
-        for c in range(16):
-            px, py = (a % cx) * 64 + (c % 4) * 16, (a // cx) * 64 + (c // 4) * 16
-            if px < w and py < h:
-                s = 64 >> int(lab[0, a, c])
-                assert px // s * s + s <= w and py // s * s + s <= h
-        for q in cnn_oracle.QUADS:
-            v = lab[0, a, list(q)]
-            assert (v == 0).all() or (v == 1).all() or (v >= 2).all() or (lab[0, a].max() > 0 and (v >= 1).all())
+        if md[a].max() == 0 and ins[a].all():
+            assert np.array_equal(out[0, a], first0)
     if w % 64 == 0 and h % 64 == 0:
         assert md.max() == 0
     # known rows of SURVEY.md section 5 fact 2

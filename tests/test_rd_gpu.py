@@ -85,6 +85,77 @@ def test_whole_1080p_frame_matches_a_live_reference_run():
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
+def test_whole_2160p_frame_matches_a_live_reference_run():
+    """C4's picture size, every CTU: all 34 CTU rows of one 3840x2160 frame, the last one half outside the picture (forced splits, TEncCu.cpp:574-576),
+    against the reference encoder run now on this machine with the device CNN's labels -- every field of the 2040 CTU records and the reconstruction."""
+    import sys
+    import hevcdl_amd
+    import ref_tools
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), ".."))
+    import bench
+    w, h, qp = 3840, 2160, 32
+    yuv = ref_tools.synth_yuv(w, h, 1, 777)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1)
+    labels = enc.predict_depth(yuv)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    wall, per, dumps = bench.run_reference_pictures([yuv[0]], labels, w, h, qp, 1, dump=True)
+    res = bench.parity_against_dumps(dumps, recs, [recon[0]], w, h)
+    assert res["ctus"] == 2040 and res["mismatches"] == 0, res
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
+def test_first_label_zero_codes_one_cu_like_the_reference():
+    """The reference's walk reads ONE label per CU (its top-left cell, TEncCu.cpp:496-520) and use_model.py:101-119 does emit label sets whose first label is
+    0 while later quadrants are not: HM then codes one 64x64 CU.  Caller labels of that kind must reach the search as they are (the boundary policy only
+    repairs what the walk would otherwise leave undecided): records and reconstruction equal the reference encoder's, run now with the same label files."""
+    import sys
+    import hevcdl_amd
+    import ref_tools
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), ".."))
+    import bench
+    w, h, qp = 192, 128, 30
+    yuv = ref_tools.synth_yuv(w, h, 1, 31)
+    labels = np.zeros((1, 6, 16), np.uint8)
+    labels[0, 0] = [0, 0, 2, 3, 0, 0, 3, 2, 1, 1, 2, 2, 1, 1, 2, 2]          # first label 0: one 64x64 CU, whatever follows
+    labels[0, 1] = [1, 1, 2, 2, 1, 1, 2, 2, 1, 1, 3, 3, 1, 1, 3, 3]
+    labels[0, 2] = [0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2]
+    labels[0, 3] = [2, 2, 1, 1, 2, 3, 1, 1, 1, 1, 2, 2, 1, 1, 2, 2]
+    labels[0, 4] = [0] * 16
+    labels[0, 5] = [1, 0, 1, 3, 0, 0, 2, 0, 1, 2, 1, 0, 3, 0, 0, 0]          # valid for the walk (first labels 1, 1, 1, 1), ragged elsewhere
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    assert recs["depth"][0, 0].max() == 0 and recs["depth"][0, 2].max() == 0 and recs["depth"][0, 5].max() == 1
+    wall, per, dumps = bench.run_reference_pictures([yuv[0]], labels, w, h, qp, 1, dump=True)
+    res = bench.parity_against_dumps(dumps, recs, [recon[0]], w, h)
+    assert res["ctus"] == 6 and res["mismatches"] == 0, res
+
+
+def test_bench_two_ranks_on_one_gpu_give_the_single_rank_line(tmp_path):
+    """bench.py's own N > 1 path (frame shards, max-over-ranks timing, gather of the per-frame rate records) under torch.distributed.run with two ranks
+    sharing this GPU (HEVCDL_BENCH_BACKEND=gloo): the job's rate records must add up to the single-rank line's, and the line carries the latency floor."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(GOLD), "..")
+    common = ["--steps", "1", "--warmup", "0", "--width", "256", "--height", "192", "--frames", "6", "--no-cpu-baseline", "--no-c2", "--no-e2e", "--saturated-frames", "0"]
+    env = dict(os.environ, HEVCDL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stdout[-1500:] + r1.stderr[-1500:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                         os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-1500:]
+    two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "strong"
+    assert two["config"]["frames"] == one["config"]["frames"] == 6 and two["config"]["frames_per_gpu"] == 3
+    assert two["est_bits_per_frame"] == one["est_bits_per_frame"] and one["est_bits_per_frame"] > 0
+    for line in (one, two):
+        assert line["value"] > 0 and line["latency_floor_s"] > 0 and line["strong_scaling_ceiling"]["value"] > 0 and "roofline" in line
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
 @pytest.mark.parametrize("qp", [22, 27, 32, 37])
 def test_2160p_wide_bands_match_a_live_reference_run_at_the_sweep_qps(qp):
     """The four QPs of BASELINE.json's C3 sweep at the full 3840 width: the top 3840x384 band (6 CTU rows, 360 CTUs) of three 2160p frames,
@@ -448,11 +519,25 @@ def test_per_ctu_session_equals_batch_and_rejects_disorder():
     e.close()
 
 
+def walk_of_labels(labels):
+    """[..., 16] labels -> the depth the reference's walk decides for every 16x16 cell: it reads ONE label per CU, the one of its top-left cell
+    (TEncCu.cpp:496-520) -- a first label of 0 is one 64x64 CU whatever the other cells say, a quadrant whose first label is 1 one 32x32 CU; below
+    that every cell speaks for itself."""
+    walk = np.array(labels, np.uint8).reshape(-1, 16).copy()
+    whole = walk[:, 0] == 0
+    walk[whole] = 0
+    for q in ((0, 1, 4, 5), (2, 3, 6, 7), (8, 9, 12, 13), (10, 11, 14, 15)):
+        one = (~whole) & (walk[:, q[0]] == 1)
+        for c in q:
+            walk[one, c] = 1
+    return walk.reshape(np.shape(labels))
+
+
 @pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
 def test_full_size_properties(w, h):
     """BASELINE.json sizes, where the oracle would take minutes: size-independent properties of the path.
-    frame independence (batch == frame by frame), determinism, decided CU depth == CNN label (the reference evaluates
-    a CU only at its labelled depth), NxN only in 8x8 CUs, cbf <-> coefficients, statistics == recomputed SSE."""
+    frame independence (batch == frame by frame), determinism, decided CU depth == what the reference's walk makes of the CNN labels (a CU is
+    evaluated only at its labelled depth), NxN only in 8x8 CUs, cbf <-> coefficients, statistics == recomputed SSE."""
     import hevcdl_amd
     import ref_tools
     qp, nf = 32, 2
@@ -472,7 +557,8 @@ def test_full_size_properties(w, h):
         px |= ((z >> (2 * b)) & 1) << b; py |= ((z >> (2 * b + 1)) & 1) << b
     for a in range(cy * cx):
         inside[a] = ((a % cx) * 64 + px * 4 < w) & ((a // cx) * 64 + py * 4 < h)
-    lab_z = labels.reshape(nf, -1, 16)[:, :, blk_of_z]
+    walk = walk_of_labels(labels.reshape(nf, -1, 16))
+    lab_z = walk[:, :, blk_of_z]
     assert np.array_equal(recs["depth"][:, inside], lab_z[:, inside])
     assert (recs["part_size"][:, inside][recs["depth"][:, inside] < 3] == 0).all()
     # a CTU without coded coefficients carries no cbf, and vice versa
@@ -510,7 +596,7 @@ def test_c5_eight_k_ten_bit_tiles():
     z16 = np.arange(16); zx = (z16 & 1) | ((z16 >> 1) & 2); zy = ((z16 >> 1) & 1) | ((z16 >> 2) & 2)
     blk_of_z = (zy * 4 + zx)[np.arange(256) >> 4]
     full_rows = recs["depth"][0].reshape(cy, cx, 256)[:cy - 1]
-    assert np.array_equal(full_rows, labels.reshape(cy, cx, 16)[:cy - 1][:, :, blk_of_z])
+    assert np.array_equal(full_rows, walk_of_labels(labels.reshape(cy, cx, 16))[:cy - 1][:, :, blk_of_z])
     # tile 0 = CTU columns 0..29, rows 0..33 == its crop coded as a picture of its own
     tw, th = 30 * 64, 34 * 64
     ysz = w * h
