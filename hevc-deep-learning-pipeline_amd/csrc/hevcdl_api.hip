@@ -372,7 +372,14 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
 #if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)
   {
     std::vector<unsigned int> hb(8004); hipDeviceSynchronize(); hipMemcpy(hb.data(), d_dbg, 8004 * 4, hipMemcpyDeviceToHost);
+#ifdef HEVCDL_KERNEL_PROF
+    for (unsigned i = 0; i < hb[0] && i < 64; i++) { // accumulators of the kernel's timers: cycles in the low 40 bits, calls above -> kilocycles, calls
+      const unsigned long long v = (unsigned long long)hb[2 + 2 * i] | ((unsigned long long)hb[3 + 2 * i] << 32);
+      printf("DBGV %u %u\n", (unsigned)((v & 0xffffffffffull) >> 10), (unsigned)(v >> 40));
+    }
+#else
     for (unsigned i = 0; i < hb[0] && i < 4000; i++) printf("DBGV %u %u\n", hb[1 + 2 * i], hb[2 + 2 * i]);
+#endif
     fflush(stdout); hipFree(d_dbg);
   }
 #endif

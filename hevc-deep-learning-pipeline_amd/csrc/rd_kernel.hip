@@ -22,7 +22,8 @@
 // Inside a wave
 //   * pixel work is lane-parallel: reference gather, the 35-mode rough mode decision (one lane per
 //     (mode, 8x8 block) task: predict + Hadamard), prediction, residual, DCT/DST, dequant, reconstruction, SSE;
-//   * the inherently sequential parts (RDOQ reverse scan, CABAC bin counting) run on lane 0 out of LDS.
+//   * RDOQ decides the levels of up to four coefficient groups side by side (rdoq_wave), only its ordered fp64 sums are serial; CABAC bin counting runs
+//     wave-uniform with the contexts in registers (code_coeff_wave).
 // All decision arithmetic is the reference's: int32 transforms, fp64 costs without contraction (-ffp-contract=off),
 // lambda family computed on the host and passed as bits.
 #include <hip/hip_runtime.h>
@@ -49,11 +50,6 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #ifndef HEVCDL_NW
 #define HEVCDL_NW 8
 #endif
-#ifdef HEVCDL_RDOQ_V1
-#define HEVCDL_RDOQ rdoq_lane0
-#else
-#define HEVCDL_RDOQ rdoq_wave
-#endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
 constexpr int NPEND = BD == 8 ? 2 : 1;                         // second luma passes a master may leave running behind it (the 10-bit kernel has LDS for one more region only)
 constexpr int NREG = 1 + NPEND;                                // regions per wave: [0] first pass / chroma / rough-mode slices, [1..] the second passes (master: their tickets; chain owner: [1] its split tasks)
@@ -63,7 +59,7 @@ constexpr int NSLOT = 20;                                     // result slots of
 // per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
 constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while it runs one of its own split tasks (spec_children)
-constexpr int LEAF_LOG = 192, LOG_BYTES = 65 * LEAF_LOG;     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
+constexpr int LEAF_LOG = 192, LOG_BYTES = 66 * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast)     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
@@ -190,7 +186,7 @@ struct __attribute__((aligned(16))) RdSmem {
   // residual (row stride n+2: conflict-free column access) and transform / dequantised coefficients (raster) share
   // storage: the residual is dead once the forward transform has consumed it and is rebuilt by the inverse transform.
   // Every value fits 16 bits (HEVC transform dynamic range; the reference clips the inverse stages explicitly).
-  // For TUs up to 8x8 (95 % of all codings) the part behind the coefficients also holds RDOQ's per-position outputs (rdoq_lane0).
+  // For TUs up to 8x8 (95 % of all codings) the part behind the coefficients also holds RDOQ's per-position outputs (rdoq_wave).
   union __attribute__((aligned(16))) { int16_t resi[32 * 34]; int16_t tc[1024]; };
   // quantised levels of the current TU (raster); the transform intermediate (row stride n+1) lives behind the first 16
   // entries, i.e. a 4x4 block of levels survives the inverse transform (transform-skip bookkeeping needs it)
@@ -202,7 +198,12 @@ struct __attribute__((aligned(16))) RdSmem {
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
-  unsigned long long cfrac_last;      // coefficient part of the last intra_bits_qt count (fractional bits)
+  unsigned long long cfrac_last;      // coefficient part of the last intra_bits_qt count (fractional bits): luma
+  unsigned long long cfrac_last_c;    // ... chroma (both components)
+  // winners of the CU under test, for the short form of its syntax count (enc_cu_syntax_fast): coefficient bits of the luma / chroma winner, its slot
+  unsigned long long lw_cfrac, cw_cfrac; int lw_valid, cw_slot;
+  // SATD sums of the NEXT CU's rough mode decision, computed by the master while the workgroup's other waves run this CU's chroma search (rmd_prefetch)
+  unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pad_pre;
   // Second passes left running behind the master (compress_cu): carry_ok: the CU being coded may leave its pass pending; pend_*: the passes pending, oldest
   // first (index of their CU among the CTU's coded CUs, region of their ticket); restart: a pending pass chose the split -> the CTU is walked again, CUs
   // [0, replay_upto) from the log, CU nocarry_leaf without leaving its pass pending
@@ -210,11 +211,10 @@ struct __attribute__((aligned(16))) RdSmem {
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
-  unsigned long long prof[64]; int prof_task, prof_pad;     // timers of the profiling build (8-bit kernel only): cycles in the low 40 bits, calls above
+  GLB unsigned long long *my_prof; int prof_task, prof_pad; // timers of the profiling build (8-bit kernel, workgroup 0): 64 accumulators in HBM (cycles in the low 40 bits, calls above), added to with returnless atomics -- no LDS, no wait
 #endif
   double cg_cost[64];                 // RDOQ per-CG sig-flag cost
   union {
-    double chain[5][17];              // rdoq_lane0: per-position addends of the five ordered sums (rows padded)
     double chainb[3][RQ_ROWS * 16 + 1];  // rdoq_wave: zero-level cost, coded cost, significance cost of every position of a batch of groups
     double zb[2][64];                 // RDOQ, run of all-zero groups: zero-level costs / significance costs of 4 groups
     struct { double rmd_cost[36]; unsigned int satd[36]; };   // rough mode decision (never live during RDOQ)
@@ -244,7 +244,7 @@ DEV void wsync()
 #ifdef HEVCDL_KERNEL_PROF
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
 #define PROF_MARK0() unsigned long long prof_m_ = __builtin_readcyclecounter()
-#define PROF_ACC_(id, d) (lds().prof[id] += ((unsigned long long)(d) & 0xffffffffffull) + (1ull << 40))
+#define PROF_ACC_(id, d) do { GLB unsigned long long *pp_ = lds().my_prof; if (pp_) __hip_atomic_fetch_add(pp_ + (id), ((unsigned long long)(d) & 0xffffffffffull) + (1ull << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #define PROF_MARK(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - prof_m_); prof_m_ = n_; } else prof_m_ = 0; } while (0)
 #define PROF_ADD(k, id) do { if (lane_id() == 0) { PROF_ACC_(id, __builtin_readcyclecounter() - prof_t0_); } } while (0)
 #define PROF_ADD_T(k, id, tid) do { if (lane_id() == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - prof_t0_; PROF_ACC_(id, d_); if (lds().prof_task) { PROF_ACC_(tid, d_); } } } while (0)
@@ -265,7 +265,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5, T_CHROMA_C = 6 };
 enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14, SLOT_PSET = 5 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it); per second pass (set p = its region - 1, slots + 5 p): 10..13 its split tasks (by child), 14 its verdict + start state
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
@@ -274,7 +274,7 @@ struct __attribute__((aligned(8))) Region {
   int cu[7], tu[6], pad_;                   // the CU under test (struct Cu), the PU (luma) or the CU's root TU (chroma) (struct Tu)
   int modes[12];                            // the alternatives: intra directions
   uint32_t dist[12]; double cost[12];       // the answers
-  unsigned long long cfrac[8];              // second pass: coefficient fractional bits of a child's alternative ([0..3] split tasks, [4..7] the chain's unsplit codings)
+  unsigned long long cfrac[12];             // coefficient fractional bits of an alternative's final bit count: first pass / chroma by task; second pass [0..3] split tasks, [4..7] the chain's unsplit codings
 };
 typedef LDS Region LRegion;
 struct Tables {                        // read-only after kernel start, one copy per workgroup
@@ -836,470 +836,20 @@ DEV void last_ctx_params(int ch, int n, int &off, int &shift)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// RDOQ (TComTrQuant.cpp:2119-2661, helpers :2812-2996); executed by lane 0 on LDS data.
-// Rate tables (estBitsSbacStruct, TEncSbac.cpp:1726-1970) are read straight from the frozen contexts of `cab`.
+// RDOQ (TComTrQuant.cpp:2119-2661, helpers :2812-2996).  The rate tables (estBitsSbacStruct, TEncSbac.cpp:1726-1970) are the frozen contexts of `cab`.
 // ---------------------------------------------------------------------------------------------------
-DEV int ic_rate(const LCabac *cab, uint32_t abs_level, int ctx_one, int ctx_abs, int go_rice, uint32_t c1idx, uint32_t c2idx)
-{ // xGetICRate TComTrQuant.cpp:2881-2955
-  int rate = 32768;
-  const uint32_t base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
-  if (abs_level >= base) {
-    uint32_t symbol = abs_level - base, length;
-    if (symbol < (3u << go_rice)) { length = symbol >> go_rice; rate += (int)(length + 1 + go_rice) << 15; }
-    else {
-      length = go_rice; symbol -= (3u << go_rice);
-      while (symbol >= (1u << length)) symbol -= (1u << (length++));
-      rate += (int)(3 + length + 1 - go_rice + length) << 15;
-    }
-    if (c1idx < 8) { rate += ctx_bits(cab, CTX_ONE + ctx_one, 1); if (c2idx < 1) rate += ctx_bits(cab, CTX_ABS + ctx_abs, 1); }
-  } else if (abs_level == 1) rate += ctx_bits(cab, CTX_ONE + ctx_one, 0);
-  else if (abs_level == 2) { rate += ctx_bits(cab, CTX_ONE + ctx_one, 1); rate += ctx_bits(cab, CTX_ABS + ctx_abs, 0); }
-  else rate = 0;
-  return rate;
-}
-
-// xGetICRate (TComTrQuant.cpp:2881-2955) with the group's greater-1 / greater-2 rates held in a wave register:
-// lane 2*c1+bin = m_greaterOneBits[4*ctxSet + c1][bin], lane 8+bin = m_levelAbsBits[ctxSet][bin] (the greater-2 rate
-// is only ever read while c2 == 0, i.e. before the first level > 1 of the group)
-DEV int ic_rate_r(int rtab, uint32_t abs_level, int c1, int go_rice, uint32_t c1idx, uint32_t c2idx)
-{
-  int rate = 32768;
-  const uint32_t base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
-  if (abs_level >= base) {
-    uint32_t symbol = abs_level - base, length;
-    if (symbol < (3u << go_rice)) { length = symbol >> go_rice; rate += (int)(length + 1 + go_rice) << 15; }
-    else {
-      length = go_rice; symbol -= (3u << go_rice);
-      while (symbol >= (1u << length)) symbol -= (1u << (length++));
-      rate += (int)(3 + length + 1 - go_rice + length) << 15;
-    }
-    if (c1idx < 8) { rate += __builtin_amdgcn_readlane(rtab, 2 * c1 + 1); if (c2idx < 1) rate += __builtin_amdgcn_readlane(rtab, 9); }
-  } else if (abs_level == 1) rate += __builtin_amdgcn_readlane(rtab, 2 * c1);
-  else if (abs_level == 2) { rate += __builtin_amdgcn_readlane(rtab, 2 * c1 + 1); rate += __builtin_amdgcn_readlane(rtab, 8); }
-  else rate = 0;
-  return rate;
-}
 DEV double rl_d(double v, int l)
 { // value of lane l (wave-uniform l) of a per-lane double
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
 
-// RDOQ, whole wave.  s->tc -> s->lvl ; returns uiAbsSum.
-//   phase A (lane-parallel over scan positions): |coef|*scale and the clipped rounding level (-> s->lvl); the zero-level cost
-//     err^2*errScale of a position is recomputed wherever it is needed; wave-max gives the last nonzero scan position; everything
-//     above it only adds its zero-level cost to the running totals, in the reference's order;
-//   phase B, per 4x4 coefficient group (CG) in reverse scan order: lanes 0..15 own the 16 positions and compute
-//     everything that does not depend on the c1/c2/Rice state machine (level, significance context and its two
-//     rates, zero-level costs); the state machine then walks the 16 positions with wave-uniform control flow and
-//     reads those per-position values with v_readlane -- zero levels cost three fp64 adds, nonzero levels run the
-//     reference's level decision; per-position results go back to LDS lane-parallel;
-//   phase C: last-position search on lane 0, sign-data hiding with lane-parallel candidate costs.
-// Every fp64 accumulation is performed in the reference's order (the sums are not associative).
-DEV uint32_t rdoq_lane0(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
-{
-  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
-  LSmem &s = lds();
-  const int lane = lane_id();
-  const int ch = c ? 1 : 0, log2n = ilog2(n);
-  const int qp = uni(c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;      // + qpBdOffset (TComTrQuant.cpp:71-100)
-  const int tshift = 15 - BD - log2n, qbits = 14 + per + tshift;
-  const double lambda = c ? k.lambda_c : k.lambda;
-  const double err_scale = k.err_scale[ch][log2n - 2];
-  const int qcoef = uni(c_quant_scales[rem]);
-  const int ncoef = n * n;
-  CParam cp; get_cparam(cp, c, n, dir_mode);
-  const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
-  LDS const int16_t *src = s.tc; LDS int16_t *dst = s.lvl;
-  // Per-position outputs read again by the last-position search and by sign hiding: coded cost and significance cost by scan position, the
-  // four rate / error terms of sign hiding by raster position -- 32 bytes per position.  Up to 8x8 they fit behind the coefficients in LDS
-  // (the residual that shares that storage is dead until the inverse transform): 128 + 64 * 32 = 2176 bytes; larger TUs use the wave's HBM
-  // workspace.
-  const bool qlds = n <= 8;
-  GLB double *gq_cost = k.q_cost; GLB int32_t *gq_rate = k.q_rate;
-  LDS double *lq_cost = (LDS double *)((LDS char *)s.tc + 2 * ncoef); LDS int32_t *lq_rate = (LDS int32_t *)(lq_cost + 2 * ncoef);
-  enum { Q_COEFF = 0, Q_SIG = 1, Q_UP = 0, Q_DOWN = 1, Q_SIGDELTA = 2, Q_DELTAU = 3 };
-  auto q_cost_st = [&](int a, int i, double v) { if (qlds) lq_cost[a * ncoef + i] = v; else gq_cost[a * 1024 + i] = v; };
-  auto q_cost_ld = [&](int a, int i) -> double { double v; if (qlds) v = lq_cost[a * ncoef + i]; else v = gq_cost[a * 1024 + i]; return v; };
-  auto q_rate_st = [&](int a, int i, int32_t v) { if (qlds) lq_rate[a * ncoef + i] = v; else gq_rate[a * 1024 + i] = v; };
-  auto q_rate_ld = [&](int a, int i) -> int32_t { int32_t v; if (qlds) v = lq_rate[a * ncoef + i]; else v = gq_rate[a * 1024 + i]; return v; };
-  LDS double *cost_cg_sig = s.cg_cost; LDS uint8_t *cgf = s.cgf;
-  auto level_double = [&](int blk) -> int32_t {
-    const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
-    return (int32_t)(tmpl < lim ? tmpl : lim);
-  };
-  auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
-  // ---- phase A ----
 #ifdef HEVCDL_KERNEL_PROF
-  unsigned long long pt_ = __builtin_readcyclecounter();
 #define RDOQ_MARK(id) do { if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - pt_); pt_ = n_; } } while (0)
 #else
 #define RDOQ_MARK(id) do { } while (0)
 #endif
-  int my_last = -1;
-  for (int sp = lane; sp < ncoef; sp += 64) {
-    const int blk = scan[sp];
-    const int32_t ld = level_double(blk);
-    uint32_t ma = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
-    if (ma > 32767u) ma = 32767u;
-    dst[blk] = (int16_t)ma;
-    if (ma > 0) my_last = sp;                          // (the zero-level cost of a position is recomputed where it is needed: cost0_of)
-  }
-  const int last_pos = wave_max_i(my_last);
-  cost_cg_sig[lane] = 0; cgf[lane] = 0;
-  wsync();
-  if (last_pos < 0) return 0;
-  RDOQ_MARK(18);
-  const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
-  double block_uncoded = 0;
-  // zero-level costs above the last position, summed in scan order from the top: 64 positions per round, costs
-  // recomputed lane-parallel (a zero coefficient costs exactly 0.0: rounds without any are skipped), the ordered sum
-  // itself runs out of LDS
-  for (int top = ncoef - 1; top > last_pos; top -= 64) {
-    const int sp = top - lane;
-    const double c0 = (sp > last_pos) ? cost0_of(scan[sp]) : 0.0;
-    if (!__ballot(c0 != 0.0)) continue;
-    wsync();
-    s.zb[0][lane] = c0;
-    wsync();
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
-      double v[16];
-#pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = s.zb[0][h * 16 + t];
-#pragma unroll
-      for (int t = 0; t < 16; t++) block_uncoded += v[t];
-    }
-  }
-  double base_cost = block_uncoded;
-  RDOQ_MARK(19);
-  const int cg_last = last_pos >> 4;
-  int ctx_set = ctx_set_index(ch, cg_last, 0), c1 = 1, c2 = 0, go_rice = 0; uint32_t c1idx = 0, c2idx = 0;
-  // ---- phase B ----
-  for (int cgpos = cg_last; cgpos >= 0; cgpos--) {
-    if (cgpos != cg_last && cgpos >= 1) {
-      // Run of up to 4 groups (cgpos, cgpos-1, ...) without a nonzero rounded level: their levels stay zero, the state
-      // machine is not touched, and nothing per position is read again (phase C and sign hiding skip groups without
-      // levels) -- only the ordered sums and the group's sig-flag cost matter (TComTrQuant.cpp:2385-2412).  Lane group
-      // g = lane >> 4 owns group cgpos - g; block_uncoded runs on lane 0, base_cost on lane 1, the group's
-      // significance-cost sum on lane 2 + g, all in scan order.
-      const int g = lane >> 4, jj = lane & 15, cg_g = cgpos - g;
-      const bool gvalid = cg_g >= 1;
-      const int sp_b = (gvalid ? cg_g : 1) * 16 + jj, blk_b = scan[sp_b];
-      const unsigned long long nzb = __ballot(!gvalid || dst[blk_b] > 0);
-      int run = 0;
-      while (run < 4 && ((nzb >> (16 * run)) & 0xffffull) == 0) run++;
-      RDOQ_MARK(34);
-      if (run > 0) {
-        const bool act = g < run;
-        const int cgblk_b = scan_cg[gvalid ? cg_g : 1], gy_b = cgblk_b / cp.wg, gx_b = cgblk_b - gy_b * cp.wg;
-        const int32_t ld_b = level_double(blk_b);
-        const double c0_b = (double)ld_b * (double)ld_b * err_scale;
-        const int sigctx_b = sig_off + sig_ctx_inc(cp, scan, pattern_sig_ctx(cgf, gx_b, gy_b, cp.wg), sp_b);
-        const double cs0_b = lambda * (double)ctx_bits(cab, sigctx_b, 0);
-        const double r0_b = lambda * (double)ctx_bits(cab, cg_off + sig_cg_ctx(cgf, gx_b, gy_b, cp.wg), 0);
-        s.zb[0][lane] = act ? c0_b : 0.0; s.zb[1][lane] = act ? cs0_b : 0.0;
-        wsync();
-        double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
-        for (int gg = 0; gg < run; gg++) {
-          const bool on = lane < 2 || lane == 2 + gg;
-          double v0[16], v1[16];
-#pragma unroll
-          for (int t = 0; t < 16; t++) { v0[t] = s.zb[0][gg * 16 + 15 - t]; v1[t] = s.zb[1][gg * 16 + 15 - t]; }
-#pragma unroll
-          for (int t = 0; t < 16; t++) {
-            const double add = lane == 0 ? v0[t] : (lane == 1 ? v0[t] + v1[t] : v1[t]);      // c0 | c0 + cs0 | cs0
-            acc += on ? add : 0.0;
-          }
-          const double r0 = rl_d(r0_b, 16 * gg), adj = r0 - rl_d(acc, 2 + gg);                  // base_cost += r0 - sig_cost of the group
-          acc += (lane == 1) ? adj : 0.0;
-          if (lane == 0) cost_cg_sig[cgpos - gg] = r0;
-        }
-        block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1);
-        cgpos -= run - 1;
-        ctx_set = ctx_set_index(ch, cgpos - 1, 0);                  // the group before the next one had no level > 1
-        wsync();
-        RDOQ_MARK(35);
-        continue;
-      }
-    }
-    const int cgblk = uni(scan_cg[cgpos]), gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
-    const int pat = uni(pattern_sig_ctx(cgf, gx, gy, cp.wg));
-    const int start_pin = (cgpos == cg_last) ? (last_pos & 15) : 15;
-    const int cg_ctx_set = ctx_set;
-    // per-position, state-independent part (lane j <-> scan position cgpos*16 + j)
-    const int j = lane & 15, sp_j = cgpos * 16 + j, blk_j = scan[sp_j];
-    const int32_t ld_j = level_double(blk_j);
-    const int ma_j = dst[blk_j];
-    const double c0_j = (double)ld_j * (double)ld_j * err_scale;         // same arithmetic as phase A
-    const int is_last_j = (sp_j == last_pos);
-    const int sigctx_j = is_last_j ? 0 : sig_off + sig_ctx_inc(cp, scan, pat, sp_j);
-    const int b0_j = is_last_j ? 0 : ctx_bits(cab, sigctx_j, 0), b1_j = is_last_j ? 0 : ctx_bits(cab, sigctx_j, 1);
-    const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
-    const int rtab = (lane < 8) ? ctx_bits(cab, CTX_ONE + 4 * ctx_set + (lane >> 1), lane & 1)
-                   : ((lane < 10) ? ctx_bits(cab, CTX_ABS + ctx_set, lane & 1) : 0);
-    // per-position results: the zero-level outcome, overwritten at lane == pin for the positions the state machine visits
-    const int valid_j = (lane < 16) && (j <= start_pin);
-    int lvl_j = 0, c1_j = 1, ru_j = 0, rd_j = 0;
-    double cc_j = c0_j + cs0_j, cs_j = cs0_j;
-    RDOQ_MARK(4);
-    // Only positions whose rounded level is nonzero touch the c1/c2/Rice state (TComTrQuant.cpp:2300-2380): walk those,
-    // highest scan position first.  c1 is 1 at the start of every group; zero positions below a visited one see its c1.
-    unsigned nzmask = (unsigned)(__ballot(valid_j && ma_j > 0) & 0xffffull);
-    while (nzmask) {
-      const int pin = 31 - __clz((int)nzmask);
-      nzmask &= ~(1u << pin);
-      const int sp = cgpos * 16 + pin;
-      const int max_abs = __builtin_amdgcn_readlane(ma_j, pin);
-      const double c0 = rl_d(c0_j, pin);
-      const int32_t ld = __builtin_amdgcn_readlane(ld_j, pin);
-      const int is_last = (sp == last_pos);
-      double cost_c, cost_s = 0;
-      uint32_t level;
-      int r_hi = 0, r_lo = 0;
-      { // xGetCodedLevel TComTrQuant.cpp:2812-2879
-        double cur_sig = 0, best = MAX_DOUBLE; uint32_t best_lvl = 0;
-        if (!is_last && max_abs < 3) { cost_s = rl_d(cs0_j, pin); best = c0 + cost_s; }
-        if (!is_last) cur_sig = rl_d(cs1_j, pin);
-        const uint32_t min_abs = max_abs > 1 ? (uint32_t)max_abs - 1 : 1;
-        for (int al = max_abs; al >= (int)min_abs; al--) {
-          const double err = (double)(ld - (int32_t)((uint32_t)al << qbits));
-          const int rate = ic_rate_r(rtab, (uint32_t)al, c1, go_rice, c1idx, c2idx);
-          if (al == max_abs) r_hi = rate; else r_lo = rate;
-          double cur = err * err * err_scale + lambda * (double)rate;
-          cur += cur_sig;
-          if (cur < best) { best_lvl = (uint32_t)al; best = cur; cost_s = cur_sig; }
-        }
-        cost_c = best; level = best_lvl;
-      }
-      int rup, rdn = 0;
-      if (level > 0) { // rate deltas of level +-1 for sign hiding; the candidates' rates are reused (level is max_abs or max_abs - 1)
-        const bool top = (int)level == max_abs;
-        const int now = top ? r_hi : r_lo;
-        rup = (top ? ic_rate_r(rtab, level + 1, c1, go_rice, c1idx, c2idx) : r_hi) - now;
-        rdn = (level == 1 ? 0 : (top ? r_lo : ic_rate_r(rtab, level - 1, c1, go_rice, c1idx, c2idx))) - now;
-      } else rup = __builtin_amdgcn_readlane(rtab, 2 * c1);
-      if (lane == pin) { lvl_j = (int)level; cc_j = cost_c; cs_j = cost_s; ru_j = rup; rd_j = rdn; c1_j = -1; }
-      const uint32_t base_level = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
-      if (level >= base_level) { if (level > 3u * (1u << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4; }
-      if (level >= 1) c1idx++;
-      if (level > 1) { c1 = 0; c2 += (c2 < 2); c2idx++; }
-      else if (c1 < 3 && c1 > 0 && level) c1++;
-      if (lane < pin) c1_j = c1;
-    }
-    if (cgpos > 0) { ctx_set = ctx_set_index(ch, cgpos - 1, c1 == 0); c1 = 1; c2 = 0; c1idx = 0; c2idx = 0; go_rice = 0; }
-    // The five running fp64 sums of the group (each in scan order, pin = 15..0, as the reference accumulates them)
-    // run side by side on lanes 0..4: the per-position addends are transposed through LDS, then 16 dependent adds.
-    //   0 block_uncoded += c0      1 base_cost += cost_c      2 sig_cost += cost_s
-    //   3 coded += cost_c - cost_s (nonzero levels)           4 uncoded += c0 (nonzero levels)
-    // A position that does not contribute adds +0.0, which leaves a sum unchanged.
-    const int nz_j = valid_j && lvl_j != 0;
-    if (lane < 16) {
-      s.chain[0][j] = valid_j ? c0_j : 0.0; s.chain[1][j] = valid_j ? cc_j : 0.0; s.chain[2][j] = valid_j ? cs_j : 0.0;
-      s.chain[3][j] = nz_j ? cc_j - cs_j : 0.0; s.chain[4][j] = nz_j ? c0_j : 0.0;
-    }
-    wsync();
-    double st_sig_cost, st_sig_cost0, st_coded, st_uncoded;
-    {
-      const int row = lane < 4 ? lane : 4;
-      double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
-      double v[16];
-#pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = s.chain[row][t];
-#pragma unroll
-      for (int t = 15; t >= 0; t--) acc += v[t];
-      block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1); st_sig_cost = rl_d(acc, 2); st_coded = rl_d(acc, 3); st_uncoded = rl_d(acc, 4);
-      st_sig_cost0 = rl_d(cs_j, 0);
-    }
-    const unsigned nzfinal = (unsigned)(__ballot(nz_j) & 0xffffull);
-    const int st_nnz_before0 = __popc(nzfinal & 0xfffeu), cg_nonzero = nzfinal != 0;
-    RDOQ_MARK(5);
-    // lane-parallel write-back of the group (the bpermute runs with all lanes enabled: a disabled source lane reads 0)
-    const int ru0_j = __shfl(rtab, 2 * (c1_j & 3));
-    if (lane < 16 && j <= start_pin) {
-      dst[blk_j] = (int16_t)lvl_j;
-      q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j);
-      q_rate_st(Q_SIGDELTA, blk_j, b1_j - b0_j);                   // 0 at the last position
-      q_rate_st(Q_DELTAU, blk_j, (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8)));
-      q_rate_st(Q_UP, blk_j, (c1_j >= 0) ? ru0_j : ru_j);
-      q_rate_st(Q_DOWN, blk_j, rd_j);
-    }
-    if (cg_nonzero) cgf[cgblk] = 1;
-    wsync();
-    if (cgpos) {
-      if (!cg_nonzero) {
-        const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
-        const double r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
-        base_cost += r0 - st_sig_cost;
-        if (lane == 0) cost_cg_sig[cgpos] = r0;
-      } else if (cgpos < cg_last) {
-        if (st_nnz_before0 == 0) { base_cost -= st_sig_cost0; st_sig_cost -= st_sig_cost0; }
-        double zero_cost = base_cost;
-        const int cs = sig_cg_ctx(cgf, gx, gy, cp.wg);
-        const double r1 = lambda * (double)ctx_bits(cab, cg_off + cs, 1), r0 = lambda * (double)ctx_bits(cab, cg_off + cs, 0);
-        base_cost += r1; zero_cost += r0;
-        double cgc = r1;
-        zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
-        if (zero_cost < base_cost) {
-          base_cost = zero_cost; cgc = r0;
-          if (lane < 16 && lvl_j) { dst[blk_j] = 0; q_cost_st(Q_COEFF, sp_j, c0_j); q_cost_st(Q_SIG, sp_j, 0.0); }
-          if (lane == 0) cgf[cgblk] = 0;
-        }
-        if (lane == 0) cost_cg_sig[cgpos] = cgc;
-      }
-    } else if (lane == 0) cgf[cgblk] = 1;
-    wsync();
-    RDOQ_MARK(8);
-  }
-  RDOQ_MARK(20);
-  // ---- phase C: last position, TComTrQuant.cpp:2440-2528.  Per CG the 16 positions' costs are fetched
-  // lane-parallel, the walk itself is wave-uniform (readlane) and usually ends inside the first group ----
-  int best_last_p1 = 0;
-  {
-    double best_cost;
-    {
-      const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
-      best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
-      base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
-    }
-    LDS int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
-    { // TEncSbac.cpp:1910-1930 (prefix sums are integers: any evaluation order)
-      int off, shift; last_ctx_params(ch, n, off, shift);
-      const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
-      const int ng = tb().t_group_idx[n - 1];
-      { // lanes 0..15: X, lanes 16..31: Y; entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar
-        const int kk = lane & 15, isy = (lane >> 4) & 1;
-        const int cx_ = (isy ? by : bx) + off + (kk >> shift);
-        const int b1 = (kk < ng) ? ctx_bits(cab, cx_, 1) : 0, b0 = (kk < ng) ? ctx_bits(cab, cx_, 0) : 0;
-        int inc = b1;
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
-        if (lane < 32 && kk <= ng) s.last_bits[isy][kk] = inc - b1 + b0;
-      }
-      wsync();
-    }
-    RDOQ_MARK(54);
-    int found_last = 0;
-    for (int cgpos = cg_last; cgpos >= 0 && !found_last; cgpos--) {
-      const int cgblk = uni(scan_cg[cgpos]);
-      base_cost -= cost_cg_sig[cgpos];
-      if (!uni(cgf[cgblk])) continue;
-      const int j = lane & 15, sp_j = cgpos * 16 + j, blk_j = scan[sp_j];
-      const int lv_j = dst[blk_j];
-      const double cc_j = q_cost_ld(Q_COEFF, sp_j), cs_j = q_cost_ld(Q_SIG, sp_j), c0_j = cost0_of(blk_j);
-      int py = blk_j >> log2n, px = blk_j - (py << log2n);
-      if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
-      const int gx2 = tb().t_group_idx[px], gy2 = tb().t_group_idx[py];
-      double lc = (double)(last_x_bits[gx2] + last_y_bits[gy2]);
-      if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
-      if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
-      const double cl_j = lambda * lc;
-      RDOQ_MARK(55);
-      // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
-      // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
-      // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
-      // lane-parallel, then only the positions with a level are compared, highest scan position first.
-      const int start_pin = (cgpos == cg_last) ? (last_pos & 15) : 15;
-      const bool in_j = j <= start_pin;
-      const double a1_j = in_j ? (lv_j ? -cc_j : -cs_j) : 0.0, a2_j = (in_j && lv_j) ? c0_j : 0.0;
-      wsync();
-      if (lane < 16) { s.zb[0][j] = a1_j; s.zb[1][j] = a2_j; }
-      wsync();
-      double mine = base_cost, acc = base_cost;
-      {
-        double v1[16], v2[16];
-#pragma unroll
-        for (int t = 0; t < 16; t++) { v1[t] = s.zb[0][15 - t]; v2[t] = s.zb[1][15 - t]; }
-#pragma unroll
-        for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
-      }
-      const double total_j = (mine + cl_j) - cs_j;
-      RDOQ_MARK(44);
-      const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
-      const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
-      unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
-      while (cand) {
-        const int pin = 31 - __clz((int)cand);
-        cand &= ~(1u << pin);
-        const double total = rl_d(total_j, pin);
-        if (total < best_cost) { best_last_p1 = cgpos * 16 + pin + 1; best_cost = total; }
-      }
-      if (gt1) found_last = 1;
-      base_cost = acc;
-    }
-  }
-
-  RDOQ_MARK(21);
-  // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact)
-  uint32_t abs_sum = 0;
-  for (int sp = lane; sp <= last_pos; sp += 64) {
-    const int blk = scan[sp];
-    if (sp < best_last_p1) { const int lv = dst[blk]; abs_sum += (uint32_t)lv; dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv); }
-    else dst[blk] = 0;
-  }
-  abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
-  wsync();
-  if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660; lanes 0..15 own the positions of the current CG
-    const long long rd_factor = k.sbh[ch];
-    const long long I64MAX = 0x7fffffffffffffffll;
-    int last_cg = -1;
-    for (int subset = cg_last; subset >= 0; subset--) {
-      const int sub_pos = subset << 4, j = lane & 15, blk_j = scan[sub_pos + j];
-      const int lv_j = dst[blk_j];
-      const unsigned nzmask = (unsigned)(__ballot(lv_j != 0) & 0xffffull);
-      if (!nzmask) continue;                                       // lastCG stays -1 until the first CG with levels
-      const int last_nz = 31 - __clz((int)nzmask), first_nz = __ffs((int)nzmask) - 1;
-      if (last_cg == -1) last_cg = 1;
-      if (last_nz - first_nz >= 4) {
-        int sum = (j >= first_nz && j <= last_nz) ? lv_j : 0;
-        sum = row_sum_i(sum);
-        const int lv_first = __builtin_amdgcn_readlane(lv_j, first_nz);
-        const uint32_t signbit = lv_first > 0 ? 0 : 1;
-        if (signbit != ((uint32_t)sum & 1u)) {
-          long long cur_cost = I64MAX; int cur_change = 0;
-          const int nmax = (last_cg == 1) ? last_nz : 15;
-          if (j <= nmax) {
-            const int32_t du_j = q_rate_ld(Q_DELTAU, blk_j), riu_j = q_rate_ld(Q_UP, blk_j), rid_j = q_rate_ld(Q_DOWN, blk_j), srd_j = q_rate_ld(Q_SIGDELTA, blk_j);
-            if (lv_j != 0) {
-              const long long up = rd_factor * (-(long long)du_j) + riu_j;
-              long long down = rd_factor * ((long long)du_j) + rid_j - ((abs(lv_j) == 1) ? srd_j : 0);
-              if (last_cg == 1 && last_nz == j && abs(lv_j) == 1) down -= (4 << 15);
-              if (up < down) { cur_cost = up; cur_change = 1; }
-              else { cur_change = -1; cur_cost = (j == first_nz && abs(lv_j) == 1) ? I64MAX : down; }
-            } else {
-              cur_cost = rd_factor * (-(long long)abs(du_j)) + (1 << 15) + riu_j + srd_j;
-              cur_change = 1;
-              if (j < first_nz) { const uint32_t ts = src[blk_j] >= 0 ? 0 : 1; if (ts != signbit) cur_cost = I64MAX; }
-            }
-          }
-          // the reference scans n = nmax..0 and keeps the first strict minimum: smallest cost, ties -> largest n
-          long long bc = cur_cost; int bn = (j <= nmax && cur_cost != I64MAX) ? j : -1;
-          for (int m = 8; m >= 1; m >>= 1) {
-            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)bc, m), hi = (unsigned)__shfl_xor((int)(unsigned)(bc >> 32), m);
-            const long long oc = (long long)(((unsigned long long)hi << 32) | lo); const int on = __shfl_xor(bn, m);
-            if (on >= 0 && (bn < 0 || oc < bc || (oc == bc && on > bn))) { bc = oc; bn = on; }
-          }
-          const int min_n = __builtin_amdgcn_readlane(bn, 0);
-          if (min_n >= 0) {
-            int final_change = __builtin_amdgcn_readlane(cur_change, min_n);
-            const int lv_min = __builtin_amdgcn_readlane(lv_j, min_n);
-            if (lv_min == 32767 || lv_min == -32768) final_change = -1;
-            if (lane == min_n) { if (src[blk_j] >= 0) dst[blk_j] = (int16_t)(lv_j + final_change); else dst[blk_j] = (int16_t)(lv_j - final_change); }
-          }
-        }
-      }
-      if (last_cg == 1) last_cg = 0;
-    }
-  }
-  wsync();
-  RDOQ_MARK(22);
-  return (uint32_t)uni((int)abs_sum);
-}
-
-// RDOQ, whole wave, coefficient groups in batches (the version the kernel uses; rdoq_lane0 above is the group-by-group form it grew out of, kept
-// for A/B runs under HEVCDL_RDOQ_V1).  s->tc -> s->lvl ; returns uiAbsSum.  Same arithmetic, same order of every fp64 sum as the reference
+// RDOQ, whole wave, coefficient groups in batches.  s->tc -> s->lvl ; returns uiAbsSum.  Same arithmetic, same order of every fp64 sum as the reference
 // (TComTrQuant.cpp:2119-2661); what changes is how the work inside phase B is laid out:
 //   * What a group's level decisions depend on: its own positions (the c1 / c2 / Rice state machine runs inside a group and starts afresh in
 //     each), the context set (one carried bit: did the previous group in scan order end with c1 == 0), and the significance pattern (are the
@@ -1330,7 +880,10 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   CParam cp; get_cparam(cp, c, n, dir_mode);
   const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   LDS const int16_t *src = s.tc; LDS int16_t *dst = s.lvl;
-  const bool qlds = n <= 8;                          // per-position outputs: behind the coefficients in LDS up to 8x8, the wave's HBM workspace above (see rdoq_lane0)
+  // Per-position outputs read again by the last-position search and by sign hiding: coded cost and significance cost by scan position, the four rate / error terms of
+  // sign hiding by raster position -- 32 bytes per position.  Up to 8x8 they fit behind the coefficients in LDS (the residual that shares that storage is dead until the
+  // inverse transform: 128 + 64 * 32 = 2176 bytes); larger TUs use the wave's HBM workspace.
+  const bool qlds = n <= 8;
   GLB double *gq_cost = k.q_cost; GLB int32_t *gq_rate = k.q_rate;
   LDS double *lq_cost = (LDS double *)((LDS char *)s.tc + 2 * ncoef); LDS int32_t *lq_rate = (LDS int32_t *)(lq_cost + 2 * ncoef);
   enum { Q_COEFF = 0, Q_SIG = 1, Q_UP = 0, Q_DOWN = 1, Q_SIGDELTA = 2, Q_DELTAU = 3 };
@@ -1383,7 +936,8 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     wsync();
   }
   double block_uncoded = 0;
-  // zero-level costs above the last position, summed in scan order from the top (as rdoq_lane0)
+  // zero-level costs above the last position, summed in scan order from the top: 64 positions per round, costs recomputed lane-parallel (a zero coefficient costs
+  // exactly 0.0: rounds without any are skipped), the ordered sum itself runs out of LDS
   for (int top = ncoef - 1; top > last_pos; top -= 64) {
     const int sp = top - lane;
     const double c0 = (sp > last_pos) ? cost0_of(scan[sp]) : 0.0;
@@ -1631,7 +1185,6 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       }
       wsync();
     }
-    RDOQ_MARK(54);
     int found_last = 0;
     for (int cgp = cg_last; cgp >= 0 && !found_last; cgp--) {
       const int cgblk = uni(scan_cg[cgp]);
@@ -1647,7 +1200,6 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       if (gx2 > 3) lc += 32768.0 * (double)((gx2 - 2) >> 1);
       if (gy2 > 3) lc += 32768.0 * (double)((gy2 - 2) >> 1);
       const double cl_j = lambda * lc;
-      RDOQ_MARK(55);
       // the walk over the group (TComTrQuant.cpp:2478-2527) as one ordered chain: position pin subtracts its coded cost and
       // adds back its zero-level cost when it holds a level, subtracts its significance cost otherwise; the value of the
       // chain BEFORE a position is what its candidate "last position" is priced with.  Chain uniform in registers, prices
@@ -1667,7 +1219,6 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
       }
       const double total_j = (mine + cl_j) - cs_j;
-      RDOQ_MARK(44);
       const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
       const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
       unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
@@ -2036,7 +1587,12 @@ template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_
   if (luma) enc_coeff_qt<LOG2>(k, c, cu, tu, 0, 0);
   wsync();
   if (luma && lane_id() == 0) lds().cfrac_last = c->frac - f0_;
-  if (chroma) { enc_coeff_qt<LOG2>(k, c, cu, tu, 1, 0); enc_coeff_qt<LOG2>(k, c, cu, tu, 2, 0); }
+  if (chroma) {
+    const unsigned long long f1_ = c->frac;
+    enc_coeff_qt<LOG2>(k, c, cu, tu, 1, 0); enc_coeff_qt<LOG2>(k, c, cu, tu, 2, 0);
+    wsync();
+    if (lane_id() == 0) lds().cfrac_last_c = c->frac - f1_;
+  }
   wsync();
   PROF_ADD_T(k, 10, 49);
   return uni((int)get_bits(c));
@@ -2152,7 +1708,7 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
 #ifdef HEVCDL_STAGE_TRACE
   if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + n * n + i] = (unsigned)(int)s.tc[i];
 #endif
-  { PROF_T0(); const uint32_t as_ = HEVCDL_RDOQ(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
+  { PROF_T0(); const uint32_t as_ = rdoq_wave(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
   wsync();
   PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
@@ -2578,7 +2134,7 @@ template <int B> DEV unsigned rmd_block(KR k, const LSmem &s, int mode, int pn, 
 }
 // rounds [r0, r1) of the rough mode decision's (mode, block) tasks, 64 per round, of the PU at (x, y); the SATD sums go to acc.satd (the
 // owner's: integer atomics, any order).  The reference lines are the executing wave's (a helper copies the owner's first).
-DEVN void rmd_rounds(KR k, LSmem &acc, int x_, int y_, int pn_, int dcv_, int r0_, int r1_)
+DEVN void rmd_rounds(KR k, LDS unsigned int *satd_dst, int x_, int y_, int pn_, int dcv_, int r0_, int r1_)
 {
   const int x = uni(x_), y = uni(y_), pn = uni(pn_), dcv = uni(dcv_), r0 = uni(r0_), r1 = uni(r1_);
   LSmem &s = lds();
@@ -2589,7 +2145,7 @@ DEVN void rmd_rounds(KR k, LSmem &acc, int x_, int y_, int pn_, int dcv_, int r0
     if (t < ntask) {
       const int mode = t / nblk, blk = t - mode * nblk, bx = (blk % nbx) * b, by = (blk / nbx) * b;
       const unsigned sum = (b == 8) ? rmd_block<8>(k, s, mode, pn, log2n, x, y, bx, by, dcv) : rmd_block<4>(k, s, mode, pn, log2n, x, y, bx, by, dcv);
-      __hip_atomic_fetch_add(&acc.satd[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&satd_dst[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   wsync();
@@ -2612,15 +2168,51 @@ DEVN void rmd_satd(KR k, const Cu cu_, const Tu ptu_)
     if (lane_id() == 0) { r.modes[0] = dcv; r.modes[1] = nrounds; }
     region_open(r, T_RMD, ntasks, cu, ptu);
     region_run(k, r);
-  } else rmd_rounds(k, s, x, y, pn, dcv, 0, nrounds);
+  } else rmd_rounds(k, s.satd, x, y, pn, dcv, 0, nrounds);
   PROF_ADD(k, 2);
+}
+
+// The CU that follows `cu` in the CTU's walk, if it starts inside this CTU and the picture: the walk reads one label per CU (compress_cu)
+DEV bool next_leaf(KR k, const Cu &cu, int &nx, int &ny, int &nlog2)
+{
+  const int z = cu.zbase + cu.nparts;
+  if (z >= 256) return false;
+  int px = 0, py = 0;
+  for (int b = 0; b < 4; b++) { px |= ((z >> (2 * b)) & 1) << b; py |= ((z >> (2 * b + 1)) & 1) << b; }
+  const int x = k.cx * 64 + 4 * px, y = k.cy * 64 + 4 * py;
+  if (x >= k.W || y >= k.H) return false;
+  for (int d = 0; d <= 3; d++) {
+    const int size = 64 >> d, ox = x & ~(size - 1), oy = y & ~(size - 1);
+    const int straddles = ox + size > k.W || oy + size > k.H;
+    const int l = uni(k.labels[k.addr * 16 + 4 * ((oy & 63) / 16) + (ox & 63) / 16]);
+    if (!straddles && l == d) { if (ox != x || oy != y) return false; nx = x; ny = y; nlog2 = 6 - d; return true; }
+    if (!(straddles || l > d)) return false;
+  }
+  return false;
+}
+// Rough-mode SATD sums of the PU at (x, y) ahead of time: they depend on the reconstruction around the PU only (final once the CU before it has its first
+// pass's winner: a pending second pass is read through best_rec), not on the coder state -- est_intra_luma adds the mode bits when it gets there.
+DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_)
+{
+  const int x = uni(x_), y = uni(y_), log2 = uni(log2_), pn = 1 << log2;
+  LSmem &s = lds();
+  build_refs(k, 0, x, y, pn, 1);
+  filter_refs(k, pn);
+  if (lane_id() < 36) s.satd_pre[NPEND == 2 ? lane_id() : 0] = 0;
+  const int dcv = dc_value(k, s.line, pn);
+  wsync();
+  const int nbx = pn / 8, nrounds = (35 * nbx * nbx + 63) >> 6;
+  rmd_rounds(k, s.satd_pre, x, y, pn, dcv, 0, nrounds);
+  if (lane_id() == 0) s.pre_key = (log2 << 24) | (y << 12) | x;
+  wsync();
 }
 
 // Join the oldest second pass left pending (compress_cu).  Verdict "nothing changes": its CU is final as the walk assumed (the pass itself has put the
 // first pass's reconstruction back into the picture).  The split won: everything coded since stands on the wrong reconstruction and coder state -> the
 // other pending pass is waited for (its slots and the picture must be quiet) and the CTU is walked again from the log (process_unit).
-DEVN void pend_join_oldest(KR k)
+DEVN void pend_join_oldest(KR k, int site = 0)
 {
+  PROF_T0();
   LSmem &s = lds(); LDS K &kk = s.k;
   const int reg = uni(s.pend_reg[0]), leaf = uni(s.pend_leaf[0]), n = uni(s.pend_n);
   LRegion &rp = my_region(reg);
@@ -2635,6 +2227,9 @@ DEVN void pend_join_oldest(KR k)
     else { s.pend_leaf[0] = s.pend_leaf[1]; s.pend_reg[0] = s.pend_reg[1]; s.pend_n = n - 1; }
   }
   wsync();
+#ifdef HEVCDL_KERNEL_PROF
+  if (uni(site) == 0) PROF_ADD(k, 44); else if (uni(site) == 1) PROF_ADD(k, 54); else PROF_ADD(k, 55);
+#endif
 }
 
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
@@ -2652,9 +2247,17 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
     { LDS K &kk = s.k; wsync(); kk.lz = zp * 16; kk.lx = ptu.x; kk.ly = ptu.y; wsync(); }       // this wave's own layer set serves the PU (second pass)
     // ---- rough mode decision ----
-    build_refs(k, 0, ptu.x, ptu.y, pn, 1);
-    if (pn >= 8 && pn <= 32) filter_refs(k, pn);
-    rmd_satd(k, cu, ptu);
+    const int rkey = (pu_log2 << 24) | (ptu.y << 12) | ptu.x;
+    if (NPEND == 2 && npu == 1 && uni(s.pre_key) == rkey) { // the SATD sums were computed ahead (rmd_prefetch); the gathered lines are still in place
+      wsync();
+      if (lane_id() < 36) s.satd[lane_id()] = s.satd_pre[NPEND == 2 ? lane_id() : 0];
+      if (lane_id() == 0) { s.ref_key[0] = rkey; s.fline_key = rkey; s.pre_key = -1; }
+      wsync();
+    } else {
+      build_refs(k, 0, ptu.x, ptu.y, pn, 1);
+      if (pn >= 8 && pn <= 32) filter_refs(k, pn);
+      rmd_satd(k, cu, ptu);
+    }
     int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
     int nfull = c_num_rd_cand[pu_log2 - 2];
     { // mode bits (xModeBitsIntra :5530-5557): 3 possible values, from the [depth][CI_CURR_BEST] snapshot
@@ -2716,6 +2319,11 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         }
         wsync();
         set_result_cu(k, cu, ptu, 0, slot_coef(k.slots, win), slot_rec(k.slots, win), zp * 16, ptu.x, ptu.y);        // a first-pass slot's origin is the PU
+        if (npu == 1 && pu_log2 <= 5) { // the winner's coefficient bits and coder state, kept for the CU's syntax count (its slot may serve a chroma mode next)
+          GLB const unsigned long long *src = slot_state(k.slots, win, 1); GLB unsigned long long *dst = s.my_log + 65 * (LEAF_LOG / 8);
+          if (lane_id() < 21) dst[lane_id()] = src[lane_id()];
+          if (lane_id() == 0) { s.lw_cfrac = r.cfrac[win]; s.lw_valid = 1; }
+        }
       }
       region_close(r);
     }
@@ -2730,7 +2338,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         // Spare waves: the pass is handed to one of them and joined in check_rd_cost_intra, after the chroma search and the CU's syntax have
         // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time) -- or later still (compress_cu).  If the split
         // wins, what was built on the assumption is redone.
-        if (uni(s.pend_n) == NPEND) { pend_join_oldest(k); if (uni(s.restart)) return 0; }   // no ticket region free: the oldest pending pass first
+        if (uni(s.pend_n) == NPEND) { pend_join_oldest(k, 0); if (uni(s.restart)) return 0; }   // no ticket region free: the oldest pending pass first
         const int reg = (uni(s.pend_n) && uni(s.pend_reg[0]) == 1) ? 2 : 1;                 // a free ticket region = slot set + 1
         LRegion &r2 = my_region(reg);
         wsync();
@@ -2884,7 +2492,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   LSmem &ow = lds_of(uni(r.owner));
   const Cu cu = { uni(r.cu[0]), uni(r.cu[1]), uni(r.cu[2]), uni(r.cu[3]), uni(r.cu[4]), uni(r.cu[5]), uni(r.cu[6]) };
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
-  const int kind = uni(r.kind), mode = uni(r.modes[idx]);
+  const int kind = uni(r.kind), mode = uni(r.modes[uni(r.kind) == T_CHROMA_C ? idx >> 1 : idx]);
   wsync();
   if (kind == T_RMD) { // a slice of the rough mode decision's rounds (rmd_satd): SATD sums into the owner's array, nothing else
     const int nrounds = uni(r.modes[1]), ntasks = nrounds < NW ? nrounds : NW, per = (nrounds + ntasks - 1) / ntasks;
@@ -2893,16 +2501,17 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
       for (int i = lane_id(); i < 66; i += 64) { ((LDS unsigned long long *)s.line)[i] = ((LDS const unsigned long long *)ow.line)[i]; ((LDS unsigned long long *)s.fline)[i] = ((LDS const unsigned long long *)ow.fline)[i]; }
       wsync();
     }
-    rmd_rounds(k, ow, tu.x, tu.y, 1 << tu.log2, uni(r.modes[0]), idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
+    rmd_rounds(k, ow.satd, tu.x, tu.y, 1 << tu.log2, uni(r.modes[0]), idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
     return;
   }
   PROF_TASK(kind != T_LUMA_P2);
   PROF_MARK0();
   const int pset = kind == T_LUMA_P2 ? uni(r.modes[1]) : uni(kk.pset);    // slot set of the second pass: given with its ticket; a split task finds it in the chain owner's context
-  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
+  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_CHROMA_C ? SLOT_CHROMA + (idx >> 1) : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx)));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
-  kk.lz = (cu.zbase + (kind == T_CHROMA ? 0 : ttu.zrel)) * 16; kk.lx = kind == T_CHROMA ? cu.x : ttu.x; kk.ly = kind == T_CHROMA ? cu.y : ttu.y;
+  const bool chroma_kind = kind == T_CHROMA || kind == T_CHROMA_C;
+  kk.lz = (cu.zbase + (chroma_kind ? 0 : ttu.zrel)) * 16; kk.lx = chroma_kind ? cu.x : ttu.x; kk.ly = chroma_kind ? cu.y : ttu.y;
   if (kind == T_LUMA_P2) { // the whole second pass: trial samples go to the picture (the master keeps off the CU's luma until the join), levels to this wave's layers
     kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   } else {
@@ -2956,7 +2565,41 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
     PROF_MARK(51);
     dist = dc.dist; cost = dc.cost;
     wsync();
+    if (lane_id() == 0) r.cfrac[idx] = dc.cfrac;
+    state_to_global(slot_state(kk.slots, slot, 1), &s.go);          // coder state behind the candidate's bit count: its coefficient contexts are the CU's if it wins (enc_cu_syntax_fast)
     for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
+  } else if (kind == T_CHROMA_C) { // ONE COMPONENT of one chroma mode of a CU that is one TU per component (est_intra_chroma): Cb and Cr are quantised from the same
+    // coder state (nothing is counted between them, xRecurIntraChromaCodingQT :1941-2145), so the two codings run side by side; whichever finishes second counts
+    // the bits of both (Cb then Cr, as the reference) and prices the mode
+    const int m = idx >> 1, comp = 1 + (idx & 1), oc = 3 - comp;
+    if (&s != &ow) {
+      wsync();
+      for (int i = lane_id(); i < 66; i += 64) ((LDS unsigned long long *)s.cline)[i] = ((LDS const unsigned long long *)ow.cline)[i];
+      if (lane_id() < 2) s.ref_key[1 + lane_id()] = ow.ref_key[1 + lane_id()];
+      wsync();
+    }
+    cabac_copy(k, &s.go, start);
+    set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, mode);
+    set_parts(k, s.a[A_TSKIP + comp], cu.zbase, cu.nparts, 0); wsync();
+    dist = code_tu_block(k, cu, tu, comp, 0);
+    wsync();
+    for (int i = lane_id(); i < cu.nparts; i += 64) { at[(comp - 1) * 256 + i] = s.a[A_CBF + comp][cu.zbase + i]; at[(comp + 1) * 256 + i] = s.a[A_TSKIP + comp][cu.zbase + i]; }
+    if (lane_id() == 0) r.dist[idx] = dist;
+    wsync();
+    wg_release();                                                   // levels, arrays and distortion before the arrival count
+    const int arrived = lds_add(&r.modes[5 + m], 1);
+    if (arrived == 1) {
+      wg_acquire();
+      for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_CBF + oc][cu.zbase + i] = at[(oc - 1) * 256 + i]; s.a[A_TSKIP + oc][cu.zbase + i] = at[(oc + 1) * 256 + i]; }
+      wsync();
+      uint32_t bits;
+      if (cu.log2 == 5) bits = intra_bits_qt<5>(k, cu, tu, 0, 1); else bits = intra_bits_qt<4>(k, cu, tu, 0, 1);
+      const uint32_t dsum = (uint32_t)uni((int)r.dist[2 * m]) + (uint32_t)uni((int)r.dist[2 * m + 1]);
+      cost = calc_rd_cost(k, bits, dsum);
+      wsync();
+      if (lane_id() == 0) { r.cost[m] = cost; r.cfrac[m] = s.cfrac_last_c; }
+      state_to_global(slot_state(kk.slots, slot, 1), &s.go);
+    }
   } else { // one chroma mode (TEncSearch.cpp:2640-2700)
     if (&s != &ow && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0) { // one chroma TU per component: the master gathered both lines before it opened the region
       wsync();
@@ -2975,9 +2618,11 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
     }
     cost = calc_rd_cost(k, bits, dist);
     wsync();
+    if (lane_id() == 0) r.cfrac[idx] = s.cfrac_last_c;
+    state_to_global(slot_state(kk.slots, slot, 1), &s.go);
     for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { at[(c - 1) * 256 + i] = s.a[A_CBF + c][cu.zbase + i]; at[(c + 1) * 256 + i] = s.a[A_TSKIP + c][cu.zbase + i]; }
   }
-  if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
+  if (kind != T_CHROMA_C && lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
   if (kind == T_LUMA_P1) PROF_MARK(52);
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
@@ -2985,7 +2630,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   wsync();
   PROF_TASK(0);
 #ifdef HEVCDL_KERNEL_PROF
-  { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
+  { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA || kind == T_CHROMA_C) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
 #endif
 }
 
@@ -3065,14 +2710,23 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
       const int nc = (1 << cu.log2) >> 1;
       build_refs(k, 1, cu.x >> 1, cu.y >> 1, nc, 1); build_refs(k, 2, cu.x >> 1, cu.y >> 1, nc, 1);
     }
+    // With waves to spare (a frame that has the workgroup to itself) the two components of a mode are tasks of their own (run_task, T_CHROMA_C)
+    const int by_comp = cu.log2 >= 4 && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0 && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
     PROF_MARK0();
-    region_open(r, T_CHROMA, 5, cu, root);
+    if (by_comp) { wsync(); if (lane_id() < 5) r.modes[5 + lane_id()] = 0; region_open(r, T_CHROMA_C, 10, cu, root); }
+    else region_open(r, T_CHROMA, 5, cu, root);
+    if (NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX) { // the other waves have the chroma modes: the master looks ahead
+      // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
+      int nx, ny, nl;
+      if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) rmd_prefetch(k, nx, ny, nl);
+    }
     region_run(k, r);
     PROF_MARK(39);
     int win = -1;
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
     if (win >= 0) {
-      best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
+      best_mode = (uint32_t)uni(r.modes[win]); best_dist = by_comp ? (uint32_t)uni((int)r.dist[2 * win]) + (uint32_t)uni((int)r.dist[2 * win + 1]) : (uint32_t)uni((int)r.dist[win]);
+      if (lane_id() == 0) { s.cw_cfrac = r.cfrac[win]; s.cw_slot = SLOT_CHROMA + win; }
       GLB const uint8_t *at = slot_attr(k.slots, SLOT_CHROMA + win);
       wsync();
       for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 4; c++) s.sv[c][i] = at[c * 256 + i];
@@ -3100,6 +2754,42 @@ DEV void copy_best_rec_to_pic(KR k, const Cu &cu, int comp)
   wsync();
 }
 
+// The CU's syntax count (enc_cu_syntax) WITHOUT coding the coefficients again, for a 2Nx2N CU of one TU per component.  The count is: the mode / flag bins, then
+// the luma, Cb and Cr coefficients, all from the [depth][CI_CURR_BEST] snapshot.  Coefficient bins touch the coefficient contexts only (luma and chroma have
+// their own), the flags only the others; the first pass's winner counted exactly these luma coefficient bins from that snapshot, the chroma search's winner
+// exactly these chroma bins (Cb then Cr) -- so their fractional bits and final contexts are taken over (as split_bits does for a split TU) and only the flags
+// are coded here.  Leaves `c` exactly as the full count would.
+DEVN void enc_cu_syntax_fast(KR k, LCabac *c, const Cu cu_, GLB const unsigned long long *luma_end, GLB const unsigned long long *chroma_end, unsigned long long cfrac)
+{
+  PROF_T0();
+  const Cu cu = ucu(cu_);
+  const int lane = lane_id();
+  GLB const uint8_t *lb = (GLB const uint8_t *)luma_end, *cb = (GLB const uint8_t *)chroma_end;
+  uint8_t lv[3], cv[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) { const int i = lane + 64 * t; lv[t] = i < NUM_CTX ? lb[i] : (uint8_t)0; cv[t] = i < NUM_CTX ? cb[i] : (uint8_t)0; }      // in flight while the flags are coded
+  wsync();
+  if (cu.depth == 3 && lane == 0) enc_bin(c, CTX_PART_SIZE, 1);
+  code_luma_dirs(k, c, cu, 0, 1);
+  code_chroma_dir(k, c, cu);
+  const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
+  if (cu.log2 <= 5 && cu.log2 > 2 && cu.log2 != min_tu_log2(cu) && lane == 0) enc_bin(c, CTX_SUBDIV + 5 - cu.log2, 0);        // enc_transform: the root is not split
+  code_qt_cbf(k, c, cu, root, 1, 1); code_qt_cbf(k, c, cu, root, 2, 1); code_qt_cbf(k, c, cu, root, 0, 1);
+  wsync();
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int i = lane + 64 * t;
+    const bool is_l = i == 19 || i == 20 || (i >= CTX_SIG && i < CTX_SIG + 28) || (i >= CTX_LAST_X && i < CTX_LAST_X + 15) || (i >= CTX_LAST_Y && i < CTX_LAST_Y + 15) ||
+                      (i >= CTX_ONE && i < CTX_ONE + 16) || (i >= CTX_ABS && i < CTX_ABS + 4) || i == CTX_TSKIP;
+    const bool is_c = i == 21 || i == 22 || (i >= CTX_SIG + 28 && i < CTX_LAST_X) || (i >= CTX_LAST_X + 15 && i < CTX_LAST_Y) || (i >= CTX_LAST_Y + 15 && i < CTX_ONE) ||
+                      (i >= CTX_ONE + 16 && i < CTX_ABS) || (i >= CTX_ABS + 4 && i < CTX_TSKIP) || i == CTX_TSKIP + 1;
+    if (is_l) c->ctx[i] = lv[t]; else if (is_c) c->ctx[i] = cv[t];
+  }
+  if (lane == 0) c->frac += cfrac;
+  wsync();
+  PROF_ADD(k, 13);
+}
+
 // xCheckRDCostIntra TEncCu.cpp:1600-1665; the end state of the CU syntax is left in s->temp[depth]
 DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
 {
@@ -3115,10 +2805,15 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
   }
   wsync();
-  if (lane_id() == 0) { s.p2_pending = 0; s.left_pending = 0; }
+  if (lane_id() == 0) { s.p2_pending = 0; s.left_pending = 0; s.lw_valid = 0; }
   wsync();
   uint32_t dist_l = est_intra_luma(k, cu);
   int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma): the region of its ticket
+  if (pending) { // until the pass is joined this CU's luma in the picture belongs to it: whoever needs the samples meanwhile (rmd_prefetch, the next CUs) reads best_rec
+    wsync();
+    if (lane_id() == 0) s.k.srect[pending - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
+    wsync();
+  }
   Rd r = { 0.0, 0, 0 };
   if (uni(s.restart)) return r;                      // a pending pass of an earlier CU chose the split: the CTU is walked again (process_unit)
   for (;;) {
@@ -3126,7 +2821,9 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     const uint32_t dist = dist_l + est_intra_chroma(k, cu);
     wsync();
     if (lane_id() == 0) reset_bits(&s.go);
-    enc_cu_syntax(k, &s.go, cu);
+    if (part == SIZE_2Nx2N && cu.log2 <= 5 && uni(s.lw_valid) && uni(s.a[A_TRIDX][cu.zbase]) == 0)          // one TU per component, winners known: the short form
+      enc_cu_syntax_fast(k, &s.go, cu, s.my_log + 65 * (LEAF_LOG / 8), slot_state(k.slots, uni(s.cw_slot), 1), uni64(s.lw_cfrac) + uni64(s.cw_cfrac));
+    else enc_cu_syntax(k, &s.go, cu);
     cabac_copy(k, &s.temp[cu.depth], &s.go);
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
     if (!pending) break;
@@ -3135,7 +2832,6 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
       LDS K &kk = s.k;
       wsync();
       if (lane_id() == 0) {
-        kk.srect[pending - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
         const int n = s.pend_n; s.pend_leaf[n] = s.leaf_idx - 1; s.pend_reg[n] = pending; s.pend_n = n + 1; s.p2_pending = 0; s.left_pending = 1;
       }
       wsync();
@@ -3147,11 +2843,12 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
     const int pset = pending - 1;
     pending = 0;
     wsync();
-    if (lane_id() == 0) s.p2_pending = 0;
+    if (lane_id() == 0) { s.p2_pending = 0; s.k.srect[pset] = 0; }
     if (!ub(r2.cost[0] < r2.cost[4])) { copy_best_rec_to_pic(k, cu, 0); break; }      // nothing changed: chroma and syntax stand
     // the split won: take its distortion and arrays (its levels and reconstruction are in the record / best reconstruction already) and
     // repeat the chroma search and the syntax, which depend on the TU tree
     dist_l = (uint32_t)uni((int)r2.dist[0]);
+    if (lane_id() == 0) s.pre_key = -1;                           // sums computed ahead for the next CU stood on the old reconstruction
     GLB const uint8_t *at = slot_attr(k.slots, SLOT_P2 + SLOT_PSET * pset);
     for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_TRIDX][cu.zbase + i] = at[i]; s.a[A_CBF][cu.zbase + i] = at[256 + i]; s.a[A_TSKIP][cu.zbase + i] = at[512 + i]; }
     cabac_copy(k, &s.go, &s.curr[cu.depth]);
@@ -3223,7 +2920,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         state_from_global(&s.next[DEPTH], lg + 2);
       } else {
         // a pending pass that has finished meanwhile is joined right away: a restart costs the less the earlier it is seen
-        while (uni(s.pend_n) && lds_load(&my_region(uni(s.pend_reg[0])).done) >= 1) { pend_join_oldest(k); if (uni(s.restart)) return best; }
+        while (uni(s.pend_n) && lds_load(&my_region(uni(s.pend_reg[0])).done) >= 1) { pend_join_oldest(k, 2); if (uni(s.restart)) return best; }
         const int carry_ok = NPEND > 0 && DEPTH >= 1 && DEPTH <= 2 && li != uni(s.nocarry_leaf) && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
         wsync();
         if (lane_id() == 0) s.carry_ok = carry_ok;
@@ -3421,7 +3118,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.pend_n = 0; s.restart = 0; }
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.pend_n = 0; s.restart = 0; s.pre_key = -1; }
     wsync();
     PROF_MARK(47);
     Rd best;
@@ -3435,7 +3132,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
         if (lane == 0) reset_bits(truec);
         encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
         encoded = 1;
-        while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k);
+        while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k, 1);
         if (uni(s.restart)) { state_from_global(truec, keep); encoded = 0; }
       }
       if (!uni(s.restart)) break;
@@ -3445,7 +3142,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       if (lane == 0) PROF_ACC_(38, (unsigned long long)(s.leaf_idx - s.replay_upto) << 10);   // restarts, CUs thrown away
 #endif
       if (lane < 3) s.ref_key[lane] = -1;
-      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; }
+      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; }
       wsync();
       cabac_copy(k, &s.curr[0], truec);
       cabac_copy(k, &s.go, truec);
@@ -3544,7 +3241,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m; }
   }
 #ifdef HEVCDL_KERNEL_PROF
-  s.prof[lane] = 0; if (lane == 0) s.prof_task = 0;
+  s.my_prof = (blockIdx.x == 0 && p.dbgbuf) ? (GLB unsigned long long *)(p.dbgbuf + 2) : nullptr; if (lane == 0) s.prof_task = 0;
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
@@ -3577,13 +3274,9 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     { PROF_T0(); if (!helper_step()) { __builtin_amdgcn_s_sleep(32); PROF_ADD(0, 23); } }
   }
 #ifdef HEVCDL_KERNEL_PROF
-  // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): kilocycles and call counts (tools/phase_profile.py)
+  // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): the host decodes the accumulators (tools/phase_profile.py)
   wsync();
-  if (blockIdx.x == 0 && p.dbgbuf) {
-    if (lane == 14) s.prof[14] = ((__builtin_readcyclecounter() - prof_start_) & 0xffffffffffull) + (1ull << 40);
-    atomicAdd(&p.dbgbuf[1 + 2 * lane], (unsigned int)((s.prof[lane] & 0xffffffffffull) >> 10)); atomicAdd(&p.dbgbuf[2 + 2 * lane], (unsigned int)(s.prof[lane] >> 40));
-    if (lane == 0) p.dbgbuf[0] = 64;
-  }
+  if (blockIdx.x == 0 && p.dbgbuf && lane == 0) { PROF_ACC_(14, __builtin_readcyclecounter() - prof_start_); p.dbgbuf[0] = 64; }
 #endif
 }
 
