@@ -206,8 +206,8 @@ struct __attribute__((aligned(16))) RdSmem {
   unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pad_pre;
   // Second passes left running behind the master (compress_cu): carry_ok: the CU being coded may leave its pass pending; pend_*: the passes pending, oldest
   // first (index of their CU among the CTU's coded CUs, region of their ticket); restart: a pending pass chose the split -> the CTU is walked again, CUs
-  // [0, replay_upto) from the log, CU nocarry_leaf without leaving its pass pending
-  int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[2], pend_reg[2], left_pending, pad_pend;
+  // [0, replay_upto) from the log, CU nocarry_leaf with the result that pass reached (its luma is not searched again)
+  int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[2], pend_reg[2], left_pending, resume_reg;   // resume_reg: ticket region of the pass that won, whose result CU nocarry_leaf takes over
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
   uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
 #ifdef HEVCDL_KERNEL_PROF
@@ -265,7 +265,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5, T_CHROMA_C = 6 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5 };
 enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14, SLOT_PSET = 5 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it); per second pass (set p = its region - 1, slots + 5 p): 10..13 its split tasks (by child), 14 its verdict + start state
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
@@ -300,6 +300,9 @@ DEV LDS Tables &tb() { return wg_shared().tab; }
 #endif
 #ifndef HEVCDL_SPEC_MARGIN
 #define HEVCDL_SPEC_MARGIN 0
+#endif
+#ifndef HEVCDL_PREFETCH
+#define HEVCDL_PREFETCH 1
 #endif
 #ifndef HEVCDL_CARRY_MAX
 #define HEVCDL_CARRY_MAX 1      // a second pass stays pending across the CU boundary only in workgroups with this many masters at most (it costs throughput when waves are scarce)
@@ -2223,7 +2226,7 @@ DEVN void pend_join_oldest(KR k, int site = 0)
   wsync();
   if (lane_id() == 0) {
     kk.srect[reg - 1] = 0;
-    if (won) { kk.srect[0] = 0; kk.srect[1] = 0; s.restart = 1; s.replay_upto = leaf; s.nocarry_leaf = leaf; s.pend_n = 0; }
+    if (won) { kk.srect[0] = 0; kk.srect[1] = 0; s.restart = 1; s.replay_upto = leaf; s.nocarry_leaf = leaf; s.resume_reg = reg; s.pend_n = 0; }
     else { s.pend_leaf[0] = s.pend_leaf[1]; s.pend_reg[0] = s.pend_reg[1]; s.pend_n = n - 1; }
   }
   wsync();
@@ -2492,7 +2495,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   LSmem &ow = lds_of(uni(r.owner));
   const Cu cu = { uni(r.cu[0]), uni(r.cu[1]), uni(r.cu[2]), uni(r.cu[3]), uni(r.cu[4]), uni(r.cu[5]), uni(r.cu[6]) };
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
-  const int kind = uni(r.kind), mode = uni(r.modes[uni(r.kind) == T_CHROMA_C ? idx >> 1 : idx]);
+  const int kind = uni(r.kind), mode = uni(r.modes[idx]);
   wsync();
   if (kind == T_RMD) { // a slice of the rough mode decision's rounds (rmd_satd): SATD sums into the owner's array, nothing else
     const int nrounds = uni(r.modes[1]), ntasks = nrounds < NW ? nrounds : NW, per = (nrounds + ntasks - 1) / ntasks;
@@ -2507,10 +2510,10 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   PROF_TASK(kind != T_LUMA_P2);
   PROF_MARK0();
   const int pset = kind == T_LUMA_P2 ? uni(r.modes[1]) : uni(kk.pset);    // slot set of the second pass: given with its ticket; a split task finds it in the chain owner's context
-  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_CHROMA_C ? SLOT_CHROMA + (idx >> 1) : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx)));   // T_LUMA_SPLIT: child `mode` of r.tu
+  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
-  const bool chroma_kind = kind == T_CHROMA || kind == T_CHROMA_C;
+  const bool chroma_kind = kind == T_CHROMA;
   kk.lz = (cu.zbase + (chroma_kind ? 0 : ttu.zrel)) * 16; kk.lx = chroma_kind ? cu.x : ttu.x; kk.ly = chroma_kind ? cu.y : ttu.y;
   if (kind == T_LUMA_P2) { // the whole second pass: trial samples go to the picture (the master keeps off the CU's luma until the join), levels to this wave's layers
     kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
@@ -2568,38 +2571,6 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
     if (lane_id() == 0) r.cfrac[idx] = dc.cfrac;
     state_to_global(slot_state(kk.slots, slot, 1), &s.go);          // coder state behind the candidate's bit count: its coefficient contexts are the CU's if it wins (enc_cu_syntax_fast)
     for (int i = lane_id(); i < tu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zp + i]; at[256 + i] = s.a[A_CBF][zp + i]; at[512 + i] = s.a[A_TSKIP][zp + i]; }
-  } else if (kind == T_CHROMA_C) { // ONE COMPONENT of one chroma mode of a CU that is one TU per component (est_intra_chroma): Cb and Cr are quantised from the same
-    // coder state (nothing is counted between them, xRecurIntraChromaCodingQT :1941-2145), so the two codings run side by side; whichever finishes second counts
-    // the bits of both (Cb then Cr, as the reference) and prices the mode
-    const int m = idx >> 1, comp = 1 + (idx & 1), oc = 3 - comp;
-    if (&s != &ow) {
-      wsync();
-      for (int i = lane_id(); i < 66; i += 64) ((LDS unsigned long long *)s.cline)[i] = ((LDS const unsigned long long *)ow.cline)[i];
-      if (lane_id() < 2) s.ref_key[1 + lane_id()] = ow.ref_key[1 + lane_id()];
-      wsync();
-    }
-    cabac_copy(k, &s.go, start);
-    set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, mode);
-    set_parts(k, s.a[A_TSKIP + comp], cu.zbase, cu.nparts, 0); wsync();
-    dist = code_tu_block(k, cu, tu, comp, 0);
-    wsync();
-    for (int i = lane_id(); i < cu.nparts; i += 64) { at[(comp - 1) * 256 + i] = s.a[A_CBF + comp][cu.zbase + i]; at[(comp + 1) * 256 + i] = s.a[A_TSKIP + comp][cu.zbase + i]; }
-    if (lane_id() == 0) r.dist[idx] = dist;
-    wsync();
-    wg_release();                                                   // levels, arrays and distortion before the arrival count
-    const int arrived = lds_add(&r.modes[5 + m], 1);
-    if (arrived == 1) {
-      wg_acquire();
-      for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_CBF + oc][cu.zbase + i] = at[(oc - 1) * 256 + i]; s.a[A_TSKIP + oc][cu.zbase + i] = at[(oc + 1) * 256 + i]; }
-      wsync();
-      uint32_t bits;
-      if (cu.log2 == 5) bits = intra_bits_qt<5>(k, cu, tu, 0, 1); else bits = intra_bits_qt<4>(k, cu, tu, 0, 1);
-      const uint32_t dsum = (uint32_t)uni((int)r.dist[2 * m]) + (uint32_t)uni((int)r.dist[2 * m + 1]);
-      cost = calc_rd_cost(k, bits, dsum);
-      wsync();
-      if (lane_id() == 0) { r.cost[m] = cost; r.cfrac[m] = s.cfrac_last_c; }
-      state_to_global(slot_state(kk.slots, slot, 1), &s.go);
-    }
   } else { // one chroma mode (TEncSearch.cpp:2640-2700)
     if (&s != &ow && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0) { // one chroma TU per component: the master gathered both lines before it opened the region
       wsync();
@@ -2622,7 +2593,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
     state_to_global(slot_state(kk.slots, slot, 1), &s.go);
     for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { at[(c - 1) * 256 + i] = s.a[A_CBF + c][cu.zbase + i]; at[(c + 1) * 256 + i] = s.a[A_TSKIP + c][cu.zbase + i]; }
   }
-  if (kind != T_CHROMA_C && lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
+  if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
   if (kind == T_LUMA_P1) PROF_MARK(52);
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
@@ -2630,7 +2601,7 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   wsync();
   PROF_TASK(0);
 #ifdef HEVCDL_KERNEL_PROF
-  { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA || kind == T_CHROMA_C) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
+  { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
 #endif
 }
 
@@ -2710,12 +2681,9 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
       const int nc = (1 << cu.log2) >> 1;
       build_refs(k, 1, cu.x >> 1, cu.y >> 1, nc, 1); build_refs(k, 2, cu.x >> 1, cu.y >> 1, nc, 1);
     }
-    // With waves to spare (a frame that has the workgroup to itself) the two components of a mode are tasks of their own (run_task, T_CHROMA_C)
-    const int by_comp = cu.log2 >= 4 && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0 && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
     PROF_MARK0();
-    if (by_comp) { wsync(); if (lane_id() < 5) r.modes[5 + lane_id()] = 0; region_open(r, T_CHROMA_C, 10, cu, root); }
-    else region_open(r, T_CHROMA, 5, cu, root);
-    if (NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX) { // the other waves have the chroma modes: the master looks ahead
+    region_open(r, T_CHROMA, 5, cu, root);
+    if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX) { // the other waves have the chroma modes: the master looks ahead
       // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
       int nx, ny, nl;
       if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) rmd_prefetch(k, nx, ny, nl);
@@ -2725,7 +2693,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     int win = -1;
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
     if (win >= 0) {
-      best_mode = (uint32_t)uni(r.modes[win]); best_dist = by_comp ? (uint32_t)uni((int)r.dist[2 * win]) + (uint32_t)uni((int)r.dist[2 * win + 1]) : (uint32_t)uni((int)r.dist[win]);
+      best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
       if (lane_id() == 0) { s.cw_cfrac = r.cfrac[win]; s.cw_slot = SLOT_CHROMA + win; }
       GLB const uint8_t *at = slot_attr(k.slots, SLOT_CHROMA + win);
       wsync();
@@ -2791,8 +2759,8 @@ DEVN void enc_cu_syntax_fast(KR k, LCabac *c, const Cu cu_, GLB const unsigned l
 }
 
 // xCheckRDCostIntra TEncCu.cpp:1600-1665; the end state of the CU syntax is left in s->temp[depth]
-DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
-{
+DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
+{ // known_reg: the CU's luma search has been done -- by the second pass that was left pending in that ticket region and chose the split (compress_cu)
   CHECK_EXEC(8);
   LSmem &s = lds();
   const int part = uni(part_);
@@ -2807,7 +2775,17 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_)
   wsync();
   if (lane_id() == 0) { s.p2_pending = 0; s.left_pending = 0; s.lw_valid = 0; }
   wsync();
-  uint32_t dist_l = est_intra_luma(k, cu);
+  const int known_reg = uni(known_reg_);
+  uint32_t dist_l;
+  if (known_reg) { // distortion, mode and arrays of the pass's verdict; its levels are in the record, its reconstruction in best_rec and in the picture
+    LRegion &rk = my_region(known_reg);
+    dist_l = (uint32_t)uni((int)rk.dist[0]);
+    GLB const uint8_t *at = slot_attr(k.slots, SLOT_P2 + SLOT_PSET * (known_reg - 1));
+    set_parts(k, s.a[A_LDIR], cu.zbase, cu.nparts, uni(rk.modes[0]));
+    for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_TRIDX][cu.zbase + i] = at[i]; s.a[A_CBF][cu.zbase + i] = at[256 + i]; s.a[A_TSKIP][cu.zbase + i] = at[512 + i]; }
+    cabac_copy(k, &s.go, &s.curr[cu.depth]);
+    wsync();
+  } else dist_l = est_intra_luma(k, cu);
   int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma): the region of its ticket
   if (pending) { // until the pass is joined this CU's luma in the picture belongs to it: whoever needs the samples meanwhile (rmd_prefetch, the next CUs) reads best_rec
     wsync();
@@ -2925,7 +2903,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         wsync();
         if (lane_id() == 0) s.carry_ok = carry_ok;
         wsync();
-        Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N);
+        Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N, li == uni(s.nocarry_leaf) ? uni(s.resume_reg) : 0);
         if (uni(s.restart)) return t;
         if (ub(t.cost < best.cost)) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
         if (DEPTH == 3) {
@@ -3118,7 +3096,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.pend_n = 0; s.restart = 0; s.pre_key = -1; }
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; }
     wsync();
     PROF_MARK(47);
     Rd best;
