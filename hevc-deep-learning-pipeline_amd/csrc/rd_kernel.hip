@@ -305,7 +305,14 @@ DEV LDS Tables &tb() { return wg_shared().tab; }
 #define HEVCDL_PREFETCH 1
 #endif
 #ifndef HEVCDL_CARRY_MAX
-#define HEVCDL_CARRY_MAX 1      // a second pass stays pending across the CU boundary only in workgroups with this many masters at most (it costs throughput when waves are scarce)
+#define HEVCDL_CARRY_MAX 2      // second passes are left pending behind a master only in workgroups with this many masters at most (with waves scarcer the work thrown away at a restart
+                                // costs more than the waiting saved); measured on the 600-frame job (2-3 masters per workgroup): 1 -> 7.00 s, 2 -> 6.52 s, 3 -> 6.63 s
+#endif
+#ifndef HEVCDL_FG_FIRST_MAX
+#define HEVCDL_FG_FIRST_MAX HEVCDL_CARRY_MAX   // helpers serve the masters' own regions before the pending passes up to this many masters (helper_step)
+#endif
+#ifndef HEVCDL_PREFETCH_MAX
+#define HEVCDL_PREFETCH_MAX 3                 // the master computes the next CU's rough-mode SATD during the chroma search up to this many masters (est_intra_chroma)
 #endif
 DEV int lds_load(LDS int *p);
 // spare waves for the second-pass tasks: at least as many waves without a unit as with one (chain owners serve their own split tasks, so no
@@ -2640,7 +2647,7 @@ DEV int helper_step()
     int did = 0;
     // the second-pass regions first when they sit on the masters' critical paths; behind the masters' own regions when the passes are left pending
     // (compress_cu): then it is the first pass and the chroma search the master waits for
-    const int p2_first = lds_load(&sh.masters_active) > HEVCDL_CARRY_MAX;
+    const int p2_first = lds_load(&sh.masters_active) > HEVCDL_FG_FIRST_MAX;
     for (int j = 0; j < NREG * NW && !did; j++) {
       LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][p2_first ? (j < NPEND * NW ? 1 + j / NW : 0) : (j < NW ? 0 : j / NW)];
       const int t = lds_load(&r.ticket);
@@ -2683,7 +2690,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     }
     PROF_MARK0();
     region_open(r, T_CHROMA, 5, cu, root);
-    if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX) { // the other waves have the chroma modes: the master looks ahead
+    if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
       // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
       int nx, ny, nl;
       if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) rmd_prefetch(k, nx, ny, nl);
