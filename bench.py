@@ -241,15 +241,18 @@ def cpu_baseline_port(yuv_host, labels_host, width, height, qp, max_procs=None, 
 
 
 def measured_traffic(n_ctus):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS kernel source (profiles/r02_traffic.json names the sha of
-    rd_kernel.hip it was collected on); None when the source has changed since (the counters cannot be read from inside the process)."""
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(tpath):
-        return None, "no counter pass committed for this build"
-    tj = json.load(open(tpath))
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS kernel source (profiles/r*_traffic.json name the sha of
+    rd_kernel.hip they were collected on); None when the source has changed since (the counters cannot be read from inside the process)."""
+    import glob
     sha = hashlib.sha256(open(RD_KERNEL_SRC, "rb").read()).hexdigest()[:16]
-    if tj.get("rd_kernel_sha16") != sha:
-        return None, "profiles/r02_traffic.json was collected on another build of rd_kernel.hip (%s, now %s): not reported" % (tj.get("rd_kernel_sha16"), sha)
+    tj = None
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):       # the newest counter pass taken on this very kernel source
+        cand = json.load(open(tpath))
+        if cand.get("rd_kernel_sha16") == sha and cand.get("fetch_bytes_per_ctu") and cand.get("write_bytes_per_ctu"):
+            tj = cand
+            break
+    if tj is None:
+        return None, "no committed counter pass (profiles/r*_traffic.json) was taken on this build of rd_kernel.hip (%s): not reported" % sha
     return (tj["fetch_bytes_per_ctu"] + tj["write_bytes_per_ctu"]) * n_ctus, tj["source"] + "; " + tj["note"]
 
 

@@ -45,7 +45,11 @@ typedef enum {
 #define HEVCDL_CNN_INPUT_LUMA   1   /* R = G = B = Y */
 #define HEVCDL_BN_REFERENCE     0   /* training-mode BatchNorm, as use_model.py:61-63 runs it (the reference never calls model.eval()) */
 #define HEVCDL_BN_EVAL          1   /* BatchNorm with the checkpoint's running statistics (what model.eval() would give; NOT the reference pipeline's labels) */
-#define HEVCDL_BOUNDARY_CLAMP   0   /* clamp labels to the picture */
+/* HEVCDL_BOUNDARY_CLAMP: every label is raised to the smallest depth at which the CU containing its 16x16 cell lies inside the picture;
+ * then exactly what the reference's walk READS is made valid and nothing else is touched.  The walk (TEncCu.cpp:496-520) looks at one label per CU, the one of its
+ * top-left cell: a CTU inside the picture whose first label is 0 is ONE 64x64 CU whatever the other 15 labels say (use_model.py:101-119 does write such files, and HM
+ * codes them that way -- so does this library); otherwise a visited 32x32 quadrant whose first label is 0 gets 1 and the cells of a split quadrant at least 2. */
+#define HEVCDL_BOUNDARY_CLAMP   0
 
 #define HEVCDL_WEIGHT_FLOATS 637712 /* state_dict order of rec/hevc_encoder_model.pt, fp32 tensors only */
 
@@ -247,7 +251,8 @@ void hevcdl_host_free(void *p);
 /* All pointers are device pointers; stream is a hipStream_t (NULL = default stream). */
 hevcdl_status hevcdl_predict_depth_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels, void *d_logits_opt, void *stream);
 /* Labels that do NOT come from hevcdl_predict_depth* (e.g. the unclamped label files of the reference's use_model.py, TEncCu.cpp:244-287):
- * boundary policy HEVCDL_BOUNDARY_CLAMP + quadtree consistency, in place; a depth above 3 is HEVCDL_ERR_INVALID_ARG.  The host-pointer
+ * boundary policy HEVCDL_BOUNDARY_CLAMP (see there: label sets that are valid for the reference's walk pass unchanged), in place; a depth above 3 is
+ * HEVCDL_ERR_INVALID_ARG.  The host-pointer
  * entry points (labels_opt of hevcdl_compress_frames / hevcdl_encode_pictures / hevcdl_begin_frames) do this themselves; the device
  * entry points below take d_labels as they are and require them to satisfy the policy.  Synchronises `stream`.
  * One context = one launch in flight: the context owns the kernels' workspace, so calls on different streams of the same context must
