@@ -7,11 +7,15 @@
 //   label file IPC                        use_model.py:121-125 <-> TEncCu.cpp:244-253   (labels stay in HBM)
 // plus the YUV->RGB input transform and the boundary clamp defined by this project.
 //
-// The four convolutions are im2col GEMMs on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate,
-// bit-identical to an fmaf chain).  M = output positions (16 per tile, ordered so that the 4 accumulator registers
-// of a lane are the members of one max-pool window), N = 16 output channels per tile, K = taps x input channels.
-//   A operand: one ds_read_b32 per lane and MFMA out of zero-halo'd fp32 activation maps in LDS
-//   B operand: weights pre-packed on the host in lane order ([N-tile][k-step][64 lanes]) -> one coalesced dword load
+// The four convolutions are im2col GEMMs on the matrix cores.  M = output positions (16 per tile, ordered so that the 4 accumulator
+// registers of a lane are the members of one max-pool window), N = 16 output channels per tile, K = taps x input channels.
+//   conv1 / conv64 (3 input channels, 20 % of the FLOPs): v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate, bit-identical to an fmaf chain);
+//     A operand: one ds_read_b32 per lane and MFMA out of the zero-halo'd fp32 input tile, B: weights pre-packed in lane order.
+//   conv2 / conv3 (32 / 64 input channels, 76 % of the FLOPs): v_mfma_f32_16x16x32_f16 on SPLIT operands.  Every activation is stored in LDS as ONE
+//     32-bit word holding two halves, hi = f16(v) and lo = f16(v - hi) (22 significant bits: 4.8e-7 relative), the weights are split the same way on the
+//     host, and a product is hi*hi + hi*lo + lo*hi accumulated in f32 by three MFMAs (lo*lo, < 2^-21 relative, is dropped) -- f32-like accuracy (the
+//     logits stay within 1e-3 of the f32 reference, tests/test_cnn_gpu.py) at 16 / 3 times the f32 MFMA rate.  The maps keep their channel-major
+//     layout: a lane's 8 k-values are 8 channels of one position = the 8 dword reads the f32 form issued for 8 k-steps, repacked by two v_perm_b32 each.
 // conv+BN(train)+ReLU+pool are fused: BN statistics are per sample = per workgroup, so no global reduction exists;
 // x -> relu(x*alpha+beta) is monotone, so the pool runs before the affine map (max or min by the sign of gamma).
 // The conv64 branch is evaluated once and shared by the 4 quadrants (identical input, identical statistics).
@@ -22,6 +26,8 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #ifndef HEVCDL_CNN_SKEW
 #define HEVCDL_CNN_SKEW 40            // start offset of the second workgroup of a CU, in units of 8128 cycles (see the kernel)
 #endif
@@ -69,6 +75,28 @@ __device__ __forceinline__ void bn_fold(double s, double ss, double n, float gam
 }
 
 __device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// v -> one word: low half f16(v) (rounded toward zero), high half f16(v - low half)
+__device__ __forceinline__ float split_f16(float v)
+{
+  const auto h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+  const float r = v - (float)h[0];
+  return __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(v, r));
+}
+// 8 split activations (k = 0..7 of a lane) -> the hi and the lo operand of the f16 MFMA
+__device__ __forceinline__ void gather_hl(const unsigned (&w)[8], h8 &hi, h8 &lo)
+{
+  u4 a, b;
+#pragma unroll
+  for (int m = 0; m < 4; m++) { a[m] = __builtin_amdgcn_perm(w[2 * m + 1], w[2 * m], 0x05040100u); b[m] = __builtin_amdgcn_perm(w[2 * m + 1], w[2 * m], 0x07060302u); }
+  hi = __builtin_bit_cast(h8, a); lo = __builtin_bit_cast(h8, b);
+}
+// one product on split operands: acc += a * b with a = ah + al, b = bh + bl (al * bl dropped)
+__device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, const h8 &bl, v4f c)
+{
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+}
 
 // 5x5 conv (3 -> 16, zero pad 2 relative to the region) + BN(train) + ReLU + POOLxPOOL max pool -> 16 maps of 16x16.
 // tile: fp32 region with a 2-pixel zero halo (row pitch ROW, channel stride CH); koff: im2col offsets for that pitch.
@@ -154,7 +182,7 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
   { // in-place affine + ReLU of the 16 pooled maps: thread = pixel
     const int py = tid >> 4, px = tid & 15;
 #pragma unroll
-    for (int o = 0; o < 16; o++) { float LDS *d = out + o * A_CH + (py + 1) * A_ROW + px + 1; *d = fmaxf(*d * sm.alpha[o] + sm.beta[o], 0.f); }
+    for (int o = 0; o < 16; o++) { float LDS *d = out + o * A_CH + (py + 1) * A_ROW + px + 1; *d = split_f16(fmaxf(*d * sm.alpha[o] + sm.beta[o], 0.f)); }      // stored split: conv2's operand form
   }
   __syncthreads();
 }
@@ -267,43 +295,38 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     // wave w owns output channels [16w, 16w+16) (one N-tile) and all 16 M-tiles of the 16x16 map, so the BN
     // statistics of its channels never leave the wave.  k = tap * 32 + ic.
     {
-      const float GLB *w2 = W + HEVCDL_W_C2 + wave * (72 * 64) + lane, *b2 = W + HEVCDL_W_C2 + 18432;
+      // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> input channel 4 * j + (lane >> 4))
+      const u4 GLB *w2 = (const u4 GLB *)(W + HEVCDL_W_C2) + (size_t)wave * (9 * 128) + lane; const float GLB *b2 = W + HEVCDL_W_C2 + 18432;
       const int ch = wave * 16 + i16;
       const float bias = b2[ch];
       v4f acc[16];
 #pragma unroll
       for (int t = 0; t < 16; t++) acc[t] = (v4f){ bias, bias, bias, bias };
       // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4
-      const float LDS *abase = sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1);
-      float bq[8];                                                    // B operands of the current tap; the next tap's are in flight
-#pragma unroll
-      for (int kk = 0; kk < 8; kk++) bq[kk] = w2[kk * 64];
+      const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1);
+      u4 bh = w2[0], bl = w2[64];                                     // B operands of the current tap; the next tap's are in flight
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
-        const float LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
-        float bn[8];
+        const unsigned LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
         const int tn = tap < 8 ? tap + 1 : 8;
+        const u4 nh = w2[tn * 128], nl = w2[tn * 128 + 64];
+        const h8 Bh = __builtin_bit_cast(h8, bh), Bl = __builtin_bit_cast(h8, bl);
+        // A operands double-buffered in registers: the 8 LDS reads of tile t + 1 are issued before the MFMAs of tile t
+        unsigned w0[8], w1[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) bn[kk] = w2[(tn * 8 + kk) * 64];
-        // A operands double-buffered in registers: the 16 LDS reads of k-step kk+1 are issued before the 16 MFMAs of kk
-        // (left alone the compiler reads two operands, waits, issues two MFMAs: the LDS latency is exposed every 64 cycles)
-        float a0[16], a1[16];
+        for (int j = 0; j < 8; j++) w0[j] = ap[j * 4 * A_CH];
 #pragma unroll
-        for (int t = 0; t < 16; t++) a0[t] = ap[(2 * (t >> 1)) * A_ROW + 8 * (t & 1)];
+        for (int t = 0; t < 16; t++) {
+          unsigned (&wc)[8] = (t & 1) ? w1 : w0; unsigned (&wn)[8] = (t & 1) ? w0 : w1;
+          if (t < 15) {
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
-          float (&ac)[16] = (kk & 1) ? a1 : a0; float (&an)[16] = (kk & 1) ? a0 : a1;
-          if (kk < 7) {
-#pragma unroll
-            for (int t = 0; t < 16; t++) an[t] = ap[(kk + 1) * 4 * A_CH + (2 * (t >> 1)) * A_ROW + 8 * (t & 1)];
+            for (int j = 0; j < 8; j++) wn[j] = ap[j * 4 * A_CH + (2 * ((t + 1) >> 1)) * A_ROW + 8 * ((t + 1) & 1)];
           }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int t = 0; t < 16; t++) acc[t] = mfma4(ac[t], bq[kk], acc[t]);
-          __builtin_amdgcn_sched_barrier(0);
+          h8 ah, al;
+          gather_hl(wc, ah, al);
+          acc[t] = mfma3(ah, al, Bh, Bl, acc[t]);
         }
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) bq[kk] = bn[kk];
+        bh = nh; bl = nl;
       }
       double s = 0, ss = 0;
 #pragma unroll
@@ -320,14 +343,15 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       for (int t = 0; t < 16; t++) {
         const v4f a = acc[t];
         const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-        sm.q.a2[ch * A2_CH + ((t >> 1) + 1) * A2_ROW + 4 * (t & 1) + g4 + 1] = fmaxf(v, 0.f);
+        sm.q.a2[ch * A2_CH + ((t >> 1) + 1) * A2_ROW + 4 * (t & 1) + g4 + 1] = split_f16(fmaxf(v, 0.f));      // stored split: conv3's operand form
       }
       __syncthreads();
     }
     CNN_MARK(4);
     // ---- conv3: 64 -> 128, 3x3 (use_model.py:32-37); wave w owns output channels [32w, 32w+32) = 2 N-tiles, 4 M-tiles ----
     {
-      const float GLB *w3 = W + HEVCDL_W_C3 + (2 * wave) * (144 * 64) + lane, *b3 = W + HEVCDL_W_C3 + 73728;
+      // packed weights: [N-tile][tap][k-step s][hi | lo][64 lanes] x 16 bytes (k = 8 * (lane >> 4) + j <-> input channel 32 * s + 4 * j + (lane >> 4))
+      const u4 GLB *w3 = (const u4 GLB *)(W + HEVCDL_W_C3) + (size_t)(2 * wave) * (9 * 256) + lane; const float GLB *b3 = W + HEVCDL_W_C3 + 73728;
       v4f acc[2][4];
 #pragma unroll
       for (int n = 0; n < 2; n++) {
@@ -335,37 +359,39 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[n][t] = (v4f){ bias, bias, bias, bias };
       }
-      const float LDS *abase = sm.q.a2 + g4 * A2_CH + ((i16 >> 1) & 1) * A2_ROW + 2 * (i16 >> 2) + (i16 & 1);
-      float bq[32];
+      const unsigned LDS *abase = (const unsigned LDS *)sm.q.a2 + g4 * A2_CH + ((i16 >> 1) & 1) * A2_ROW + 2 * (i16 >> 2) + (i16 & 1);
+      u4 bq[8];                                                       // [N-tile n][k-step s][hi | lo] of the current tap
 #pragma unroll
-      for (int kk = 0; kk < 16; kk++) { bq[kk] = w3[kk * 64]; bq[16 + kk] = w3[(144 + kk) * 64]; }
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[n * 4 + q] = w3[n * (9 * 256) + q * 64];
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
-        const float LDS *ap = abase + (tap / 3) * A2_ROW + (tap % 3);
-        float bn[32];
+        const unsigned LDS *ap = abase + (tap / 3) * A2_ROW + (tap % 3);
+        u4 bn[8];
         const int tn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) { bn[kk] = w3[(tn * 16 + kk) * 64]; bn[16 + kk] = w3[(144 + tn * 16 + kk) * 64]; }
-        float a0[8], a1[8];                                        // two k-steps of A operands per buffer
+        for (int n = 0; n < 2; n++)
 #pragma unroll
-        for (int u = 0; u < 8; u++) a0[u] = ap[(u >> 2) * 4 * A2_CH + 2 * (u & 3) * A2_ROW];
+          for (int q = 0; q < 4; q++) bn[n * 4 + q] = w3[n * (9 * 256) + tn * 256 + q * 64];
+        unsigned w0[8], w1[8];                                      // (k-step, tile) pairs in flight: u = 4 * s + t
 #pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) {
-          float (&ac)[8] = (k2 & 1) ? a1 : a0; float (&an)[8] = (k2 & 1) ? a0 : a1;
-          if (k2 < 7) {
+        for (int j = 0; j < 8; j++) w0[j] = ap[j * 4 * A2_CH];
 #pragma unroll
-            for (int u = 0; u < 8; u++) an[u] = ap[(2 * (k2 + 1) + (u >> 2)) * 4 * A2_CH + 2 * (u & 3) * A2_ROW];
+        for (int u = 0; u < 8; u++) {
+          unsigned (&wc)[8] = (u & 1) ? w1 : w0; unsigned (&wn)[8] = (u & 1) ? w0 : w1;
+          if (u < 7) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) wn[j] = ap[(8 * ((u + 1) >> 2) + j) * 4 * A2_CH + 2 * ((u + 1) & 3) * A2_ROW];
           }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int kk = 2 * k2 + (u >> 2), t = u & 3;
-            acc[0][t] = mfma4(ac[u], bq[kk], acc[0][t]); acc[1][t] = mfma4(ac[u], bq[16 + kk], acc[1][t]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          const int sk = u >> 2, t = u & 3;
+          h8 ah, al;
+          gather_hl(wc, ah, al);
+          acc[0][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[2 * sk]), __builtin_bit_cast(h8, bq[2 * sk + 1]), acc[0][t]);
+          acc[1][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[4 + 2 * sk]), __builtin_bit_cast(h8, bq[4 + 2 * sk + 1]), acc[1][t]);
         }
 #pragma unroll
-        for (int kk = 0; kk < 32; kk++) bq[kk] = bn[kk];
+        for (int q = 0; q < 8; q++) bq[q] = bn[q];
       }
 #pragma unroll
       for (int n = 0; n < 2; n++) {

@@ -129,12 +129,44 @@ static void pack_conv5(const float *w, const float *b, const float *g, const flo
   for (int ks = 0; ks < 19; ks++) for (int l = 0; l < 64; l++) { const int k = ks * 4 + (l >> 4), oc = l & 15; dst[ks * 64 + l] = k < 75 ? w[oc * 75 + k] : 0.f; }
   memcpy(dst + 1216, b, 16 * sizeof(float)); memcpy(dst + 1232, g, 16 * sizeof(float)); memcpy(dst + 1248, be, 16 * sizeof(float));
 }
+// f32 -> IEEE half, round to nearest even (weights are small: no overflow handling beyond saturation to the largest finite half)
+static uint16_t f32_to_f16(float f)
+{
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);
+  if (x < 0x38800000u) { // subnormal half (or zero)
+    if (x < 0x33000000u) return (uint16_t)sign;
+    const int shift = 113 - (int)(x >> 23);
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const uint32_t r = m >> (shift + 13), rem = m & ((1u << (shift + 13)) - 1u), half = 1u << (shift + 12);
+    return (uint16_t)(sign | (r + ((rem > half || (rem == half && (r & 1u))) ? 1u : 0u)));
+  }
+  const uint32_t r = ((x - 0x38000000u) >> 13), rem = x & 0x1fffu;
+  return (uint16_t)(sign | (r + ((rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ? 1u : 0u)));
+}
+static float f16_to_f32(uint16_t h)
+{
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) { if (!m) x = sign; else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; sh++; } x = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13); } }
+  else x = sign | ((e + 112u) << 23) | (m << 13);
+  float f; memcpy(&f, &x, 4); return f;
+}
+// conv2 / conv3 on v_mfma_f32_16x16x32_f16 with SPLIT operands (cnn_kernel.hip): a weight w is the pair hi = half(w), lo = half(w - hi).  B-operand packing:
+// lane l supplies B[k = 8 * (l >> 4) + j][n = l & 15], j = 0..7, and k-value (l >> 4, j) of k-step s stands for input channel 32 s + 4 j + (l >> 4) (the order in
+// which a lane's 8 LDS reads walk the channel-major activation maps without bank conflicts).  Layout: [oc/16 N-tiles][9 taps][ic/32 k-steps][hi | lo][64 lanes][8 halves],
+// then bias, gamma, beta as floats -- the same number of bytes as the f32 packing it replaces.
 static void pack_conv3(const float *w, const float *b, const float *g, const float *be, int oc, int ic, float *dst)
-{ // [oc][ic][3][3] -> [oc/16 N-tiles][9*ic/4 k-steps][64] with k = tap * ic + input channel
-  const int ksn = 9 * ic / 4;
-  for (int nt = 0; nt < oc / 16; nt++) for (int ks = 0; ks < ksn; ks++) for (int l = 0; l < 64; l++) {
-    const int k = ks * 4 + (l >> 4), tap = k / ic, c = k % ic, o = nt * 16 + (l & 15);
-    dst[((size_t)nt * ksn + ks) * 64 + l] = w[((size_t)o * ic + c) * 9 + tap];
+{
+  uint16_t *d16 = (uint16_t *)dst;
+  const int ks = ic / 32;
+  for (int nt = 0; nt < oc / 16; nt++) for (int tap = 0; tap < 9; tap++) for (int s = 0; s < ks; s++) for (int l = 0; l < 64; l++) for (int j = 0; j < 8; j++) {
+    const int c = 32 * s + 4 * j + (l >> 4), o = nt * 16 + (l & 15);
+    const float v = w[((size_t)o * ic + c) * 9 + tap];
+    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+    const size_t base = ((((size_t)nt * 9 + tap) * ks + s) * 2) * 512;        // halves: 64 lanes x 8 per operand
+    d16[base + (size_t)l * 8 + j] = hi; d16[base + 512 + (size_t)l * 8 + j] = lo;
   }
   float *t = dst + (size_t)9 * ic * oc;
   memcpy(t, b, oc * sizeof(float)); memcpy(t + oc, g, oc * sizeof(float)); memcpy(t + 2 * oc, be, oc * sizeof(float));

@@ -1,11 +1,11 @@
 import sys, os, time, subprocess, tempfile
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch; torch.cuda.init()
 import bench
 nf, w, h = (int(sys.argv[1]) if len(sys.argv) > 1 else 128), 3840, 2160
 d = tempfile.mkdtemp(prefix="hevcdl_cli_")
 bench.synth_frames_torch(torch, torch.device("cuda", 0), w, h, list(range(nf)), seed=4000).cpu().numpy().tofile(os.path.join(d, "in.yuv"))
-app = "/root/repo/hevc-deep-learning-pipeline_amd/bin/TAppEncoderHevcdl"
+app = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hevc-deep-learning-pipeline_amd", "bin", "TAppEncoderHevcdl")
 for extra in ([], ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=3", "--NumTileRowsMinus1=1"]):
     t = time.time()
     r = subprocess.run([app, "-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", "32", "-b", "o.bin", "-o", "o.yuv", "--SEIDecodedPictureHash=1", "--Level=6.2"] + extra, cwd=d, capture_output=True, text=True)
