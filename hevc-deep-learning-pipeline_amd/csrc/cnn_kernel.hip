@@ -9,9 +9,8 @@
 //
 // The four convolutions are im2col GEMMs on the matrix cores.  M = output positions (16 per tile, ordered so that the 4 accumulator
 // registers of a lane are the members of one max-pool window), N = 16 output channels per tile, K = taps x input channels.
-//   conv1 / conv64 (3 input channels, 20 % of the FLOPs): v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate, bit-identical to an fmaf chain);
-//     A operand: one ds_read_b32 per lane and MFMA out of the zero-halo'd fp32 input tile, B: weights pre-packed in lane order.
-//   conv2 / conv3 (32 / 64 input channels, 76 % of the FLOPs): v_mfma_f32_16x16x32_f16 on SPLIT operands.  Every activation is stored in LDS as ONE
+//   All four run on v_mfma_f32_16x16x32_f16 with SPLIT operands (conv2 / conv3, 32 / 64 input channels, are 76 % of the FLOPs; the 5x5 convolutions gather 75 taps of
+//   the split input tile, padded to 3 k-steps).  Every activation is stored in LDS as ONE
 //     32-bit word holding two halves, hi = f16(v) and lo = f16(v - hi) (22 significant bits: 4.8e-7 relative), the weights are split the same way on the
 //     host, and a product is hi*hi + hi*lo + lo*hi accumulated in f32 by three MFMAs (lo*lo, < 2^-21 relative, is dropped) -- f32-like accuracy (the
 //     logits stay within 1e-3 of the f32 reference, tests/test_cnn_gpu.py) at 16 / 3 times the f32 MFMA rate.  The maps keep their channel-major
@@ -42,8 +41,8 @@ constexpr int T64_ROW = 72, T64_CH = 36 * 72;   // fp32 input tile of HALF the C
 constexpr int T32_ROW = 40, T32_CH = 36 * 40;   // fp32 input tile of one quadrant, halo 2
 
 struct CnnSmem {
-  float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95)
-  int koff64[76], koff32[76];              // im2col offset of tap k = (c*5+ky)*5+kx inside the input tiles
+  float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95), stored split (hi | lo halves): the operand form of the convolutions
+  int koff64[96], koff32[96];              // im2col offset of tap k = (c*5+ky)*5+kx inside the input tiles (k >= 75: padding, offset 0, zero weight)
   float act12[32 * A_CH];                  // conv1 output (channels 0..15) ++ conv64 output (16..31): cat of use_model.py:50
   union {
     float t64[3 * T64_CH];                 // conv64 input tile of one half of the CTU (only live before the quadrant loop)
@@ -74,7 +73,6 @@ __device__ __forceinline__ void bn_fold(double s, double ss, double n, float gam
   betap = (float)((double)beta - mean * inv * (double)gamma);
 }
 
-__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // v -> one word: low half f16(v) (rounded toward zero), high half f16(v - low half)
 __device__ __forceinline__ float split_f16(float v)
 {
@@ -113,13 +111,16 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
   constexpr int TILES = (POOL == 4) ? 32 : 16;      // per wave and call
   const int tile0 = (phase == 2) ? 128 : 0, yoff = (phase == 2) ? 32 : 0;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  float bw[19];
+  // B operands: 3 k-steps x (hi, lo); k-value j of lane group g in k-step s is tap 32 s + 8 g + j
+  const u4 GLB *wq = (const u4 GLB *)w + lane;
+  h8 bh[3], bl[3];
 #pragma unroll
-  for (int ks = 0; ks < 19; ks++) bw[ks] = w[ks * 64 + lane];
-  const float bias = w[1216 + i], gamma = w[1232 + i];
-  int ko[19];
+  for (int ks = 0; ks < 3; ks++) { bh[ks] = __builtin_bit_cast(h8, wq[(2 * ks) * 64]); bl[ks] = __builtin_bit_cast(h8, wq[(2 * ks + 1) * 64]); }
+  const float bias = w[HEVCDL_W_C5 + i], gamma = w[HEVCDL_W_C5 + 16 + i];
+  int ko[24];
 #pragma unroll
-  for (int ks = 0; ks < 19; ks++) ko[ks] = koff[ks * 4 + g];
+  for (int q = 0; q < 24; q++) ko[q] = koff[32 * (q >> 3) + 8 * g + (q & 7)];
+  const unsigned LDS *tw = (const unsigned LDS *)tile;
   double s = 0, ss = 0;
 #pragma unroll 1
   for (int t0 = 0; t0 < TILES; t0 += 4) {
@@ -133,22 +134,20 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
       base[u] = y * ROW + x;
       acc[u] = (v4f){ bias, bias, bias, bias };
     }
-    // A operands ping-pong between two register sets of 4 k-steps x 4 tiles: the LDS reads of chunk c+1 are issued
-    // before the MFMAs of chunk c (see conv2)
-    float a0[16], a1[16];
+    // A operands ping-pong between two register sets: the 8 LDS reads of (k-step, tile) pair p + 1 are issued before the MFMAs of pair p
+    unsigned w0[8], w1[8];
 #pragma unroll
-    for (int q = 0; q < 16; q++) a0[q] = tile[base[q & 3] + ko[q >> 2]];
+    for (int j = 0; j < 8; j++) w0[j] = tw[base[0] + ko[j]];
 #pragma unroll
-    for (int c4 = 0; c4 < 5; c4++) {
-      float (&ac)[16] = (c4 & 1) ? a1 : a0; float (&an)[16] = (c4 & 1) ? a0 : a1;
-      if (c4 < 4) {
+    for (int p = 0; p < 12; p++) {
+      unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
+      if (p < 11) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) if ((c4 + 1) * 4 + (q >> 2) < 19) an[q] = tile[base[q & 3] + ko[(c4 + 1) * 4 + (q >> 2)]];
+        for (int j = 0; j < 8; j++) wn[j] = tw[base[(p + 1) & 3] + ko[8 * ((p + 1) >> 2) + j]];
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 16; q++) if (c4 * 4 + (q >> 2) < 19) acc[q & 3] = mfma4(ac[q], bw[c4 * 4 + (q >> 2)], acc[q & 3]);
-      __builtin_amdgcn_sched_barrier(0);
+      h8 ah, al;
+      gather_hl(wc, ah, al);
+      acc[p & 3] = mfma3(ah, al, bh[p >> 2], bl[p >> 2], acc[p & 3]);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -174,8 +173,8 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     for (int k = 0; k < 4; k++) { a += sm.red[0][k][tid]; b += sm.red[1][k][tid]; }
     constexpr int SIZE = 16 * POOL;
     float al, be;
-    if (sm.bn_eval) { al = w[1232 + tid]; be = w[1248 + tid]; }      // eval mode: folded on the host (pack_bn)
-    else bn_fold(a, b, (double)(SIZE * SIZE), w[1232 + tid], w[1248 + tid], al, be);
+    if (sm.bn_eval) { al = w[HEVCDL_W_C5 + 16 + tid]; be = w[HEVCDL_W_C5 + 32 + tid]; }      // eval mode: folded on the host (fold_bn_eval)
+    else bn_fold(a, b, (double)(SIZE * SIZE), w[HEVCDL_W_C5 + 16 + tid], w[HEVCDL_W_C5 + 32 + tid], al, be);
     sm.alpha[tid] = al; sm.beta[tid] = be;
   }
   __syncthreads();
@@ -218,8 +217,8 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #endif
 
   // ---- stage 0: CTU input -> LDS (coalesced rows of the planes), LUT, im2col tables, zeroed halo'd maps --------
-  sm.lut[tid] = (float)tid / 255.0f;
-  if (tid < 76) {
+  sm.lut[tid] = split_f16((float)tid / 255.0f);
+  if (tid < 96) {
     const int k = tid < 75 ? tid : 0, c = k / 25, r = k - c * 25, ky = r / 5, kx = r - ky * 5;   // tap 75 is padding (zero weight)
     sm.koff64[tid] = c * T64_CH + ky * T64_ROW + kx; sm.koff32[tid] = c * T32_CH + ky * T32_ROW + kx;
   }

@@ -122,13 +122,6 @@ enum { B_C1W = 0, B_C1B = 1200, B_C1G = 1216, B_C1BE = 1232, B_C2W = 1280, B_C2B
        B_C3W = 20032, B_C3B = 93760, B_C3G = 93888, B_C3BE = 94016, B_F1W = 94400, B_F1B = 618688, B_F2W = 618944, B_F2B = 635328,
        B_F3W = 635392, B_F3B = 636416, B_C64W = 636432, B_C64B = 637632, B_C64G = 637648, B_C64BE = 637664 };
 
-// MFMA B-operand packing (v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][n = l & 15]): one k-step of one
-// 16-channel N-tile is 64 consecutive floats in lane order, then bias, gamma, beta.
-static void pack_conv5(const float *w, const float *b, const float *g, const float *be, float *dst)
-{ // [16][3*5*5] -> [19 k-steps][64]; tap 75 is zero padding
-  for (int ks = 0; ks < 19; ks++) for (int l = 0; l < 64; l++) { const int k = ks * 4 + (l >> 4), oc = l & 15; dst[ks * 64 + l] = k < 75 ? w[oc * 75 + k] : 0.f; }
-  memcpy(dst + 1216, b, 16 * sizeof(float)); memcpy(dst + 1232, g, 16 * sizeof(float)); memcpy(dst + 1248, be, 16 * sizeof(float));
-}
 // f32 -> IEEE half, round to nearest even (weights are small: no overflow handling beyond saturation to the largest finite half)
 static uint16_t f32_to_f16(float f)
 {
@@ -157,6 +150,18 @@ static float f16_to_f32(uint16_t h)
 // lane l supplies B[k = 8 * (l >> 4) + j][n = l & 15], j = 0..7, and k-value (l >> 4, j) of k-step s stands for input channel 32 s + 4 j + (l >> 4) (the order in
 // which a lane's 8 LDS reads walk the channel-major activation maps without bank conflicts).  Layout: [oc/16 N-tiles][9 taps][ic/32 k-steps][hi | lo][64 lanes][8 halves],
 // then bias, gamma, beta as floats -- the same number of bytes as the f32 packing it replaces.
+// the 5x5 convolutions (3 input channels, 16 output channels = one N-tile): k = (c * 5 + ky) * 5 + kx in natural order, 75 taps padded to 3 k-steps of 32 with zero weights
+static void pack_conv5(const float *w, const float *b, const float *g, const float *be, float *dst)
+{
+  uint16_t *d16 = (uint16_t *)dst;
+  for (int s = 0; s < 3; s++) for (int l = 0; l < 64; l++) for (int j = 0; j < 8; j++) {
+    const int k = 32 * s + 8 * (l >> 4) + j, oc = l & 15;
+    const float v = k < 75 ? w[oc * 75 + k] : 0.f;
+    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+    d16[(size_t)(s * 2) * 512 + (size_t)l * 8 + j] = hi; d16[(size_t)(s * 2 + 1) * 512 + (size_t)l * 8 + j] = lo;
+  }
+  memcpy(dst + HEVCDL_W_C5, b, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 16, g, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 32, be, 16 * sizeof(float));
+}
 static void pack_conv3(const float *w, const float *b, const float *g, const float *be, int oc, int ic, float *dst)
 {
   uint16_t *d16 = (uint16_t *)dst;
@@ -225,8 +230,8 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_conv3(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 32, pk.data() + HEVCDL_W_C2);
   pack_conv3(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 64, pk.data() + HEVCDL_W_C3);
   if (cfg->bn_mode == HEVCDL_BN_EVAL) {
-    fold_bn_eval(weights + B_C1G, weights + B_C1BE, 16, pk.data() + HEVCDL_W_C1 + 1232, pk.data() + HEVCDL_W_C1 + 1248);
-    fold_bn_eval(weights + B_C64G, weights + B_C64BE, 16, pk.data() + HEVCDL_W_C64 + 1232, pk.data() + HEVCDL_W_C64 + 1248);
+    fold_bn_eval(weights + B_C1G, weights + B_C1BE, 16, pk.data() + HEVCDL_W_C1 + HEVCDL_W_C5 + 16, pk.data() + HEVCDL_W_C1 + HEVCDL_W_C5 + 32);
+    fold_bn_eval(weights + B_C64G, weights + B_C64BE, 16, pk.data() + HEVCDL_W_C64 + HEVCDL_W_C5 + 16, pk.data() + HEVCDL_W_C64 + HEVCDL_W_C5 + 32);
     fold_bn_eval(weights + B_C2G, weights + B_C2BE, 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 128);
     fold_bn_eval(weights + B_C3G, weights + B_C3BE, 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 256);
   }

@@ -8,16 +8,17 @@
 #define HEVCDL_DEV_INPUT_LUMA    1
 #define HEVCDL_DEV_INPUT_RGB_CTU 2
 
-// packed CNN weights (floats): every conv is [N-tile][k-step][64 lanes] (MFMA B-operand order) + bias + gamma + beta,
-// every fc is [k][j] + bias
-#define HEVCDL_W_C1   0            // 19*64 + 3*16
-#define HEVCDL_W_C64  1264
-#define HEVCDL_W_C2   2528         // 4*72*64 + 3*64
-#define HEVCDL_W_C3   21152        // 8*144*64 + 3*128
-#define HEVCDL_W_FC1  95264        // 2048*256 + 256
-#define HEVCDL_W_FC2  619808       // 256*64 + 64
-#define HEVCDL_W_FC3  636256       // 64*16 + 16
-#define HEVCDL_W_TOTAL 637296
+// packed CNN weights (units of floats): every conv is split-f16 MFMA B operands ([N-tile][tap or k-step][hi | lo][64 lanes][8 halves], hevcdl_api.hip pack_conv*)
+// + bias + gamma + beta as floats, every fc is [k][j] floats + bias
+#define HEVCDL_W_C5   1536         // halves of a 5x5 conv: 3 k-steps x (hi + lo) x 1 KB = 1536 floats, then 3 * 16 floats
+#define HEVCDL_W_C1   0            // 1536 + 3*16
+#define HEVCDL_W_C64  1584
+#define HEVCDL_W_C2   3168         // 9*32*64 + 3*64
+#define HEVCDL_W_C3   21792        // 9*64*128 + 3*128
+#define HEVCDL_W_FC1  95904        // 2048*256 + 256
+#define HEVCDL_W_FC2  620448       // 256*64 + 64
+#define HEVCDL_W_FC3  636896       // 64*16 + 16
+#define HEVCDL_W_TOTAL 637936
 
 struct hevcdl_cnn_params {
   const uint8_t *input;            // planar 4:2:0 frames, or packed RGB CTUs (input_mode 2)
