@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+timeout 300 python tools/time_rd.py 1 600 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_rd_gpu.py -q -x -m gpu 2>&1 | tail -4
