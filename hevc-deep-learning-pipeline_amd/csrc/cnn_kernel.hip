@@ -50,7 +50,8 @@ struct CnnSmem {
       union { float t32[3 * T32_CH]; float a2[64 * A2_CH]; };   // conv1 input tile | conv2 output
     } q;
   };
-  double red[2][4][16];                    // per-wave partial sums / sums of squares
+  double red[2][4][16];                    // per-wave partial sums / sums of squares (5x5 layers)
+  double red2[2][4][64];                   // ... of conv2: every wave holds 4 of the 16 M-tiles of all 64 channels
   float alpha[16], beta[16];               // BN folded to y = x*alpha + beta (conv1 / conv64)
   int bn_eval;                             // HEVCDL_BN_EVAL: the packed gamma / beta slots already hold the folded running statistics
 };
@@ -291,58 +292,82 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     __syncthreads();
 
     // ---- conv2: 32 -> 64, 3x3, on cat(conv1, conv64) (use_model.py:26-31, 50) ----------------------
-    // wave w owns output channels [16w, 16w+16) (one N-tile) and all 16 M-tiles of the 16x16 map, so the BN
-    // statistics of its channels never leave the wave.  k = tap * 32 + ic.
+    // wave w owns M-tiles 4w .. 4w + 3 (two rows of pool windows) and ALL four N-tiles: an A tile is gathered from LDS once and multiplied into
+    // 64 output channels (gathering it per N-tile, one N-tile per wave, made the operand reads the bound).  The BN statistics of a channel are
+    // then spread over the four waves and meet in LDS.  k = tap * 32 + ic.
     {
       // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> input channel 4 * j + (lane >> 4))
-      const u4 GLB *w2 = (const u4 GLB *)(W + HEVCDL_W_C2) + (size_t)wave * (9 * 128) + lane; const float GLB *b2 = W + HEVCDL_W_C2 + 18432;
-      const int ch = wave * 16 + i16;
-      const float bias = b2[ch];
-      v4f acc[16];
+      const u4 GLB *w2 = (const u4 GLB *)(W + HEVCDL_W_C2) + lane; const float GLB *b2 = W + HEVCDL_W_C2 + 18432;
+      v4f acc[4][4];                                                  // [M-tile][N-tile]
 #pragma unroll
-      for (int t = 0; t < 16; t++) acc[t] = (v4f){ bias, bias, bias, bias };
-      // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4
-      const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1);
-      u4 bh = w2[0], bl = w2[64];                                     // B operands of the current tap; the next tap's are in flight
+      for (int n = 0; n < 4; n++) {
+        const float bias = b2[n * 16 + i16];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t][n] = (v4f){ bias, bias, bias, bias };
+      }
+      // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4; tile T = 4 * wave + t sits at rows 2 * (T >> 1), columns 8 * (T & 1)
+      const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1) + (4 * wave) * A_ROW;
+      u4 bq[8];                                                       // [N-tile][hi | lo] of the current tap; the next tap's are in flight
+#pragma unroll
+      for (int n = 0; n < 4; n++) { bq[2 * n] = w2[n * (9 * 128)]; bq[2 * n + 1] = w2[n * (9 * 128) + 64]; }
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
         const unsigned LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
         const int tn = tap < 8 ? tap + 1 : 8;
-        const u4 nh = w2[tn * 128], nl = w2[tn * 128 + 64];
-        const h8 Bh = __builtin_bit_cast(h8, bh), Bl = __builtin_bit_cast(h8, bl);
+        u4 bn[8];
+#pragma unroll
+        for (int n = 0; n < 4; n++) { bn[2 * n] = w2[n * (9 * 128) + tn * 128]; bn[2 * n + 1] = w2[n * (9 * 128) + tn * 128 + 64]; }
         // A operands double-buffered in registers: the 8 LDS reads of tile t + 1 are issued before the MFMAs of tile t
         unsigned w0[8], w1[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w0[j] = ap[j * 4 * A_CH];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
+        for (int t = 0; t < 4; t++) {
           unsigned (&wc)[8] = (t & 1) ? w1 : w0; unsigned (&wn)[8] = (t & 1) ? w0 : w1;
-          if (t < 15) {
+          if (t < 3) {
 #pragma unroll
             for (int j = 0; j < 8; j++) wn[j] = ap[j * 4 * A_CH + (2 * ((t + 1) >> 1)) * A_ROW + 8 * ((t + 1) & 1)];
           }
           h8 ah, al;
           gather_hl(wc, ah, al);
-          acc[t] = mfma3(ah, al, Bh, Bl, acc[t]);
+#pragma unroll
+          for (int n = 0; n < 4; n++) acc[t][n] = mfma3(ah, al, __builtin_bit_cast(h8, bq[2 * n]), __builtin_bit_cast(h8, bq[2 * n + 1]), acc[t][n]);
         }
-        bh = nh; bl = nl;
-      }
-      double s = 0, ss = 0;
 #pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const v4f a = acc[t];
-        s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
-        ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+        for (int q = 0; q < 8; q++) bq[q] = bn[q];
       }
-      s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
-      float al, be;
-      if (p.bn_eval) { al = b2[64 + ch]; be = b2[128 + ch]; }
-      else bn_fold(s, ss, 256.0, b2[64 + ch], b2[128 + ch], al, be);
+      // statistics: this wave's 64 positions of every channel, then the four waves through LDS
 #pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const v4f a = acc[t];
-        const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-        sm.q.a2[ch * A2_CH + ((t >> 1) + 1) * A2_ROW + 4 * (t & 1) + g4 + 1] = split_f16(fmaxf(v, 0.f));      // stored split: conv3's operand form
+      for (int n = 0; n < 4; n++) {
+        double s = 0, ss = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const v4f a = acc[t][n];
+          s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+          ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+        }
+        s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
+        if (lane < 16) { sm.red2[0][wave][n * 16 + lane] = s; sm.red2[1][wave][n * 16 + lane] = ss; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int ch = n * 16 + i16;
+        float al, be;
+        if (p.bn_eval) { al = b2[64 + ch]; be = b2[128 + ch]; }
+        else {
+          double s = 0, ss = 0;
+#pragma unroll
+          for (int wv = 0; wv < 4; wv++) { s += sm.red2[0][wv][ch]; ss += sm.red2[1][wv][ch]; }
+          bn_fold(s, ss, 256.0, b2[64 + ch], b2[128 + ch], al, be);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const v4f a = acc[t][n];
+          const int T = 4 * wave + t;
+          const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
+          sm.q.a2[ch * A2_CH + ((T >> 1) + 1) * A2_ROW + 4 * (T & 1) + g4 + 1] = split_f16(fmaxf(v, 0.f));      // stored split: conv3's operand form
+        }
       }
       __syncthreads();
     }
