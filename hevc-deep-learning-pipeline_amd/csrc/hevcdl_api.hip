@@ -51,6 +51,7 @@ struct hevcdl_ctx {
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
   uint8_t *d_yuv8;               // 8-bit copy of 10-bit input for the CNN stage
   uint8_t *d_picture;            // final pictures of hevcdl_encode_pictures (SAO output)
+  unsigned char *h_chunk[2]; size_t h_chunk_bytes; hipStream_t copy_stream; hipEvent_t copy_ev[2];   // hevcdl_encode_pictures_chunked: two page-locked chunk buffers
   float *d_a3; size_t a3_ctus;   // conv3 outputs of one chunk of CTUs (32 KB per CTU): the hand-over from the conv kernel to the head kernel
   hipStream_t stream;
   // per-CTU session (hevcdl_begin_frames / hevcdl_compress_ctu): coder state after the last CTU of every frame, next CTU expected
@@ -219,7 +220,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
   ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
-  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = ctx->d_sao_cand = nullptr; ctx->d_wide = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
+  ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->h_chunk[0] = ctx->h_chunk[1] = nullptr; ctx->h_chunk_bytes = 0; ctx->copy_stream = nullptr; ctx->copy_ev[0] = ctx->copy_ev[1] = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = ctx->d_sao_cand = nullptr; ctx->d_wide = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
   CK(hipSetDevice(cfg->device));
@@ -266,6 +267,8 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   hipDeviceSynchronize();
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
+  for (int i = 0; i < 2; i++) { if (ctx->h_chunk[i]) hipHostFree(ctx->h_chunk[i]); if (ctx->copy_ev[i]) hipEventDestroy(ctx->copy_ev[i]); }
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
   hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_sao_cand); hipFree(ctx->d_wide); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
   delete ctx;
@@ -684,6 +687,24 @@ extern "C" hevcdl_status hevcdl_sao_frames(hevcdl_ctx *ctx, const uint8_t *org, 
 
 // ---- whole picture pipeline for host buffers: the stages of TEncGOP::compressGOP between reading a picture and writing its NAL units, with
 // the picture staying in HBM in between (one upload of the originals, one download of records / final picture / SAO parameters) ----------
+// device side of hevcdl_encode_pictures*: upload, labels, decisions, in-loop filters; the results stay in HBM (*d_final: the output pictures)
+static hevcdl_status encode_pictures_device(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, int want_sao, uint8_t **d_final)
+{
+  hevcdl_status st = ensure_staging(ctx); if (st) return st;
+  if (want_sao && !ctx->d_sao_params) HIPCHK(hipMalloc(&ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * ctx->cfg.max_frames));
+  if (want_sao && !ctx->d_picture) HIPCHK(hipMalloc(&ctx->d_picture, ctx->frame_bytes * (size_t)ctx->cfg.max_frames));
+  HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
+  if (labels_opt) { HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice)); st = hevcdl_clamp_labels_dev(ctx, ctx->d_labels, n_frames, nullptr); if (st) return st; }
+  else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
+  st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;
+  *d_final = ctx->d_recon;
+  if (deblock) { st = hevcdl_deblock_frames_dev(ctx, ctx->d_recon, n_frames, ctx->d_records, ctx->d_recon, nullptr); if (st) return st; }      // in place
+  if (want_sao) { st = hevcdl_sao_frames_dev(ctx, ctx->d_yuv, ctx->d_recon, n_frames, ctx->d_sao_params, ctx->d_picture, nullptr); if (st) return st; *d_final = ctx->d_picture; }
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "picture pipeline", e);
+  return HEVCDL_OK;
+}
+
 extern "C" hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, hevcdl_ctu_record *records,
                                                 void *picture_out, hevcdl_sao_blk *sao_opt, hevcdl_frame_stats *stats_opt)
 {
@@ -691,22 +712,56 @@ extern "C" hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv
   if (n_frames == 0) return HEVCDL_OK;
   if (!yuv || !records || !picture_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
   if (sao_opt && !deblock) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "SAO runs on the deblocked picture only");
-  st = ensure_staging(ctx); if (st) return st;
-  if (sao_opt && !ctx->d_sao_params) HIPCHK(hipMalloc(&ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * ctx->cfg.max_frames));
-  if (sao_opt && !ctx->d_picture) HIPCHK(hipMalloc(&ctx->d_picture, ctx->frame_bytes * (size_t)ctx->cfg.max_frames));
-  HIPCHK(hipMemcpy(ctx->d_yuv, yuv, ctx->frame_bytes * n_frames, hipMemcpyHostToDevice));
-  if (labels_opt) { HIPCHK(hipMemcpy(ctx->d_labels, labels_opt, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyHostToDevice)); st = hevcdl_clamp_labels_dev(ctx, ctx->d_labels, n_frames, nullptr); if (st) return st; }
-  else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
-  st = hevcdl_compress_frames_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, ctx->d_records, ctx->d_recon, ctx->d_stats, nullptr); if (st) return st;
-  uint8_t *d_final = ctx->d_recon;
-  if (deblock) { st = hevcdl_deblock_frames_dev(ctx, ctx->d_recon, n_frames, ctx->d_records, ctx->d_recon, nullptr); if (st) return st; }      // in place
-  if (sao_opt) { st = hevcdl_sao_frames_dev(ctx, ctx->d_yuv, ctx->d_recon, n_frames, ctx->d_sao_params, ctx->d_picture, nullptr); if (st) return st; d_final = ctx->d_picture; }
-  hipError_t e = hipDeviceSynchronize();
-  if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "picture pipeline", e);
+  uint8_t *d_final = nullptr;
+  st = encode_pictures_device(ctx, yuv, n_frames, labels_opt, deblock, sao_opt != nullptr, &d_final); if (st) return st;
   HIPCHK(hipMemcpy(records, ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(picture_out, d_final, ctx->frame_bytes * n_frames, hipMemcpyDeviceToHost));
   if (sao_opt) HIPCHK(hipMemcpy(sao_opt, ctx->d_sao_params, (size_t)ctx->ctus * sizeof(hevcdl_sao_blk) * n_frames, hipMemcpyDeviceToHost));
   if (stats_opt) HIPCHK(hipMemcpy(stats_opt, ctx->d_stats, sizeof(hevcdl_frame_stats) * n_frames, hipMemcpyDeviceToHost));
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_encode_pictures_chunked(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, int want_sao,
+                                                        int chunk_frames, hevcdl_chunk_fn fn, void *user)
+{
+  hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
+  if (n_frames == 0) return HEVCDL_OK;
+  if (!yuv || !fn) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  if (want_sao && !deblock) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "SAO runs on the deblocked picture only");
+  const int chunk = std::min(n_frames, chunk_frames > 0 ? chunk_frames : 64);
+  const size_t rec_b = (size_t)ctx->ctus * sizeof(hevcdl_ctu_record), sao_b = (size_t)ctx->ctus * sizeof(hevcdl_sao_blk), pic_b = ctx->frame_bytes, stat_b = sizeof(hevcdl_frame_stats);
+  const size_t o_pic = rec_b * chunk, o_sao = o_pic + pic_b * chunk, o_stat = o_sao + sao_b * chunk, need = o_stat + stat_b * chunk;      // layout of a chunk buffer
+  if (ctx->h_chunk_bytes < need) {
+    for (int i = 0; i < 2; i++) { if (ctx->h_chunk[i]) hipHostFree(ctx->h_chunk[i]); ctx->h_chunk[i] = nullptr; }
+    ctx->h_chunk_bytes = 0;
+    for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&ctx->h_chunk[i], need, hipHostMallocDefault));
+    ctx->h_chunk_bytes = need;
+  }
+  if (!ctx->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)); for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ctx->copy_ev[i], hipEventDisableTiming)); }
+  uint8_t *d_final = nullptr;
+  st = encode_pictures_device(ctx, yuv, n_frames, labels_opt, deblock, want_sao, &d_final); if (st) return st;
+  auto fetch = [&](int ci) -> hipError_t { // chunk ci -> buffer ci & 1, asynchronously
+    const int first = ci * chunk, cnt = std::min(chunk, n_frames - first);
+    unsigned char *h = ctx->h_chunk[ci & 1];
+    hipError_t e = hipMemcpyAsync(h, ctx->d_records + rec_b * first, rec_b * cnt, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h + o_pic, d_final + pic_b * first, pic_b * cnt, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess && want_sao) e = hipMemcpyAsync(h + o_sao, ctx->d_sao_params + sao_b * first, sao_b * cnt, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h + o_stat, ctx->d_stats + stat_b * first, stat_b * cnt, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->copy_ev[ci & 1], ctx->copy_stream);
+    return e;
+  };
+  const int n_chunks = (n_frames + chunk - 1) / chunk;
+  HIPCHK(fetch(0));
+  for (int ci = 0; ci < n_chunks; ci++) {
+    HIPCHK(hipEventSynchronize(ctx->copy_ev[ci & 1]));
+    if (ci + 1 < n_chunks) HIPCHK(fetch(ci + 1));                   // into the other buffer, behind the caller's work on this one
+    const int first = ci * chunk, cnt = std::min(chunk, n_frames - first);
+    unsigned char *h = ctx->h_chunk[ci & 1];
+    if (fn(user, first, cnt, (const hevcdl_ctu_record *)h, h + o_pic, want_sao ? (const hevcdl_sao_blk *)(h + o_sao) : nullptr, (const hevcdl_frame_stats *)(h + o_stat)) != 0) {
+      hipStreamSynchronize(ctx->copy_stream);
+      return fail(ctx, HEVCDL_ERR_INVALID_ARG, "the chunk callback asked to stop");
+    }
+  }
   return HEVCDL_OK;
 }
 

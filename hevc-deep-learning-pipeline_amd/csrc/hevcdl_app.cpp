@@ -197,13 +197,14 @@ int main(int argc, char **argv)
   const long avail = (long)(fsize / (long long)frame_bytes) - frame_skip;
   if (avail <= 0) { fprintf(stderr, "Error: input holds no frame after FrameSkip\n"); return 2; }
   if (n_frames <= 0 || n_frames > avail) n_frames = avail;                    // TAppEncTop: stops at end of file
-  // pictures per device call: the decision kernel runs one wavefront per (picture, tile) and the GPU holds 2048 of them, so the default
-  // is as many pictures as fill it, bounded by 16 GiB of host staging (originals, reconstruction, CTU records)
-  const long per_frame_host = (long)(2 * frame_bytes + (size_t)hevcdl_ctus_per_frame(width, height) * sizeof(hevcdl_ctu_record));
-  const long auto_batch = std::max<long>(1, std::min<long>(2048 / (tile_cols * tile_rows), (16L << 30) / per_frame_host));
-  // (several device calls: equal shares -- a call costs about the same from 1 to ~250 pictures, so a short last call would be wasted time)
+  // Pictures per device call.  A frame is a serial chain of CTUs: a call costs about the same from 1 to ~250 pictures and grows slowly beyond (the decision kernel
+  // keeps one workgroup of 8 wavefronts per CU busy with 1..8 pictures), so the default is the whole sequence, bounded by the 2048 (picture, tile) units the GPU holds
+  // and by 24 GiB of originals on the host.  The results of a call come back chunk by chunk (hevcdl_encode_pictures_chunked): the host never holds more than the
+  // originals of a batch and two chunks of results.  Several device calls: equal shares.
+  const long auto_batch = std::max<long>(1, std::min<long>(2048 / (tile_cols * tile_rows), (24L << 30) / (long)frame_bytes));
   const long even_batch = (n_frames + ((n_frames + auto_batch - 1) / auto_batch) - 1) / ((n_frames + auto_batch - 1) / auto_batch);
   const int batch = (int)std::min<long>(n_frames, std::max<long>(1, opt.geti("BatchFrames", even_batch)));
+  const int chunk = (int)std::max<long>(1, std::min<long>(batch, opt.geti("ChunkFrames", 48)));
 
   hevcdl_config cfg;
   hevcdl_status st = hevcdl_config_default_bd(&cfg, width, height, qp, bit_depth);
@@ -238,25 +239,7 @@ int main(int argc, char **argv)
     printf("\n");
   }
   const int ctus = hevcdl_ctus_per_frame(width, height);
-  // The batch buffers the library copies from / to are page-locked (hevcdl_host_alloc): the copies then run at the PCIe DMA rate instead
-  // of through the runtime's pageable staging path (a batch of 2160p pictures moves 12 MB in and 43 MB out per picture).
-  struct Pinned { void *p = nullptr; Pinned(size_t n) { p = hevcdl_host_alloc(n); } ~Pinned() { hevcdl_host_free(p); } uint8_t *data() const { return (uint8_t *)p; } };
-  // Two sets of batch buffers when the sequence takes more than one device call: while the host codes the access units of batch k (the
-  // arithmetic coder, hashes, file writes), a second thread reads batch k + 1 and runs it on the device (the context has one call in flight).
-  struct Stage {
-    Pinned yuv, recon, recs_mem; std::vector<uint8_t> labels; std::vector<hevcdl_frame_stats> stats; std::vector<hevcdl_sao_blk> sao_params;
-    int nb = 0, rc = 0; long f0 = 0; double t_read = 0, t_dev = 0, et = 0;
-    Stage(size_t fb, int ctus_, int batch_, bool sao_) : yuv(fb * batch_), recon(fb * batch_), recs_mem((size_t)ctus_ * batch_ * sizeof(hevcdl_ctu_record)),
-      labels((size_t)ctus_ * 16 * batch_), stats(batch_), sao_params(sao_ ? (size_t)ctus_ * batch_ : 0) { }
-    hevcdl_ctu_record *recs() const { return (hevcdl_ctu_record *)recs_mem.p; }
-  };
-  const long n_batches = (n_frames + batch - 1) / batch;
-  const int n_stages = n_batches > 1 ? 2 : 1;
-  std::unique_ptr<Stage> stages[2];
-  for (int i = 0; i < n_stages; i++) {
-    stages[i].reset(new Stage(frame_bytes, ctus, batch, sao != 0));
-    if (!stages[i]->yuv.p || !stages[i]->recon.p || !stages[i]->recs_mem.p) { fprintf(stderr, "Error: cannot allocate the host staging buffers of %d pictures\n", batch); return 3; }
-  }
+  std::vector<uint8_t> yuv_mem((size_t)frame_bytes * batch), labels_mem(label_dir.empty() ? 0 : (size_t)ctus * 16 * batch);       // originals (and label files) of one device call
   FILE *frec = recon_path.empty() ? nullptr : fopen(recon_path.c_str(), "wb");
   if (!recon_path.empty() && !frec) { fprintf(stderr, "Error: cannot open reconstruction file '%s'\n", recon_path.c_str()); return 2; }
   const std::string record_path = native_path(opt.get("RecordFile"));
@@ -273,73 +256,51 @@ int main(int argc, char **argv)
   double t_read = 0, t_dev = 0, t_host = 0, t_write = 0;          // where the wall clock goes (printed to stderr at the end)
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-  // producer: file -> labels -> device (CNN -> decisions -> deblocking (TEncGOP.cpp:1742) -> SAO (:1797) in one call: the pictures stay in HBM
-  // between the stages)
-  auto produce = [&](Stage *bp, long f0) {
-    Stage &B = *bp;
-    B.f0 = f0; B.nb = (int)std::min<long>(batch, n_frames - f0); B.rc = 0;
-    const auto tr0 = now();
-    fseek(fin, (long)((frame_skip + f0) * (long long)frame_bytes), SEEK_SET);
-    if (fread(B.yuv.data(), frame_bytes, B.nb, fin) != (size_t)B.nb) { fprintf(stderr, "Error: short read of '%s'\n", input.c_str()); B.rc = 2; return; }
-    const uint8_t *lab = nullptr;
-    if (!label_dir.empty()) {
-      for (int i = 0; i < B.nb && B.rc == 0; i++) for (int a = 0; a < ctus; a++) {
-        const std::string p = label_dir + "/" + std::to_string(f0 + i) + "/ctu" + std::to_string(a) + ".txt";
-        std::ifstream lf(p); int v;
-        for (int j = 0; j < 16; j++) { if (!(lf >> v) || v < 0 || v > 3) { fprintf(stderr, "Error: label file '%s' must hold 16 depths 0..3\n", p.c_str()); B.rc = 2; break; } B.labels[((size_t)i * ctus + a) * 16 + j] = (uint8_t)v; }
-        if (B.rc) break;
-      }
-      lab = B.labels.data();
-    }
-    if (B.rc) return;
-    const auto t0 = now();
-    B.t_read = secs(tr0, t0);
-    const hevcdl_status est = hevcdl_encode_pictures(ctx, B.yuv.data(), B.nb, lab, deblock ? 1 : 0, B.recs(), B.recon.data(), sao ? B.sao_params.data() : nullptr, B.stats.data());
-    B.t_dev = secs(t0, now()); B.et = B.t_dev / B.nb;
-    if (est != HEVCDL_OK) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)est); B.rc = 3; }
-  };
-  std::thread producer;
-  produce(stages[0].get(), 0);
-  for (long bi = 0; bi < n_batches && rc == 0; bi++) {
-    if (bi > 0) producer.join();
-    Stage &B = *stages[bi % n_stages];
-    if (B.rc) { rc = B.rc; break; }
-    if (bi + 1 < n_batches) producer = std::thread(produce, stages[(bi + 1) % n_stages].get(), (bi + 1) * (long)batch);
-    const int nb = B.nb; const long f0 = B.f0; const double et = B.et;
-    Pinned &yuv = B.yuv, &recon = B.recon; std::vector<hevcdl_frame_stats> &stats = B.stats; std::vector<hevcdl_sao_blk> &sao_params = B.sao_params;
-    struct { hevcdl_ctu_record *p; hevcdl_ctu_record *data() const { return p; } } recs = { B.recs() };
-    const bool filtered = deblock;            // the picture statistics follow the filtered picture: recomputed per picture below
-    t_read += B.t_read; t_dev += B.t_dev;
+  // host threads for the per-picture work: the CPUs this process may really use (a container's CPU quota is often far below the node's thread count)
+  unsigned cpus = std::max(1u, std::thread::hardware_concurrency());
+  { FILE *fq = fopen("/sys/fs/cgroup/cpu.max", "r"); long long q = 0, per = 0; char qs[32];
+    if (fq) { if (fscanf(fq, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) { q = atoll(qs); if (q > 0) cpus = (unsigned)std::max<long long>(1, std::min<long long>(cpus, q / per)); } fclose(fq); } }
+  const int max_threads = (int)std::min(cpus, 64u);
+  // per chunk of pictures handed over by the library (hevcdl_encode_pictures_chunked; the next chunk is being copied meanwhile): SSE of the output picture, the access
+  // unit (the arithmetic coder), the picture hash -- pictures are independent: a pool of threads fills per-picture results, the output stays in POC order
+  struct ChunkCtx { long f0; double et; const uint8_t *yuv; std::chrono::steady_clock::time_point t0; int nb; } cc = { 0, 0.0, nullptr, now(), 1 };
+  struct PicOut { std::vector<uint8_t> bytes; size_t au_len = 0; char md5_text[128]; unsigned long long sse[3]; hevcdl_status st = HEVCDL_OK; };
+  auto on_chunk = [&](int first, int count, const hevcdl_ctu_record *recs, const void *pictures, const hevcdl_sao_blk *sao_params, const hevcdl_frame_stats *stats) -> int {
     const auto th0 = now();
-    // per picture on the host: SSE of the output picture, the access unit (the arithmetic coder: ~35 ms for a 2160p picture), the
-    // picture hash.  Pictures are independent: a pool of threads fills per-picture results, the output stays in POC order.
-    struct PicOut { std::vector<uint8_t> bytes; size_t au_len = 0; char md5_text[128]; hevcdl_status st = HEVCDL_OK; };
-    std::vector<PicOut> pics(nb);
+    if (first == 0) cc.et = secs(cc.t0, th0) / cc.nb;                // device seconds per picture of this call (the log line's ET)
+    const uint8_t *recon = (const uint8_t *)pictures;
+    std::vector<PicOut> pics(count);
     {
       std::atomic<int> next(0);
       auto work = [&]() {
         std::vector<uint8_t> buf(hevcdl_access_unit_bound(width, height));
-        for (int i = next++; i < nb; i = next++) {
+        for (int i = next++; i < count; i = next++) {
           PicOut &po = pics[i]; po.md5_text[0] = 0;
-          if (filtered) {
-            const uint8_t *o = yuv.data() + frame_bytes * i, *r = recon.data() + frame_bytes * i;
+          for (int c = 0; c < 3; c++) po.sse[c] = stats[i].sse[c];
+          if (deblock) { // the picture statistics follow the filtered picture: recomputed here
+            const uint8_t *o = cc.yuv + frame_bytes * (size_t)(first + i), *r = recon + frame_bytes * (size_t)i;
             const size_t n[3] = { (size_t)width * height, (size_t)width * height / 4, (size_t)width * height / 4 };
             size_t off = 0;
             for (int c = 0; c < 3; c++) {
               unsigned long long sse = 0;
-              if (bit_depth == 8) for (size_t k = 0; k < n[c]; k++) { const int d = (int)o[off + k] - (int)r[off + k]; sse += (unsigned long long)(d * d); }
-              else { const uint16_t *o16 = (const uint16_t *)o, *r16 = (const uint16_t *)r; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o16[off + k] - (int)r16[off + k]; sse += (unsigned long long)(d * d); } }
-              stats[i].sse[c] = sse; off += n[c];
+              if (bit_depth == 8) {
+                for (size_t k0 = 0; k0 < n[c]; k0 += 4096) { // 32-bit partial sums over short runs: the loop vectorises
+                  unsigned part = 0; const size_t k1 = std::min(n[c], k0 + 4096);
+                  for (size_t k = k0; k < k1; k++) { const int d = (int)o[off + k] - (int)r[off + k]; part += (unsigned)(d * d); }
+                  sse += part;
+                }
+              } else { const uint16_t *o16 = (const uint16_t *)o, *r16 = (const uint16_t *)r; for (size_t k = 0; k < n[c]; k++) { const int d = (int)o16[off + k] - (int)r16[off + k]; sse += (unsigned long long)(d * d); } }
+              po.sse[c] = sse; off += n[c];
             }
           }
           // the access unit: VPS+SPS+PPS+slice, written to -b; its size is the picture's bit count (TEncGOP.cpp:2420-2447)
-          po.st = hevcdl_write_access_unit(&scfg, (int)(f0 + i), recs.data() + (size_t)ctus * i, sao ? sao_params.data() + (size_t)ctus * i : nullptr, buf.data(), buf.size(), &po.au_len);
+          po.st = hevcdl_write_access_unit(&scfg, (int)(cc.f0 + first + i), recs + (size_t)ctus * i, sao ? sao_params + (size_t)ctus * i : nullptr, buf.data(), buf.size(), &po.au_len);
           if (po.st != HEVCDL_OK) continue;
           po.bytes.assign(buf.begin(), buf.begin() + po.au_len);
           if (hash_sei) { // suffix SEI after the slice; not part of the picture's bit count (as in the reference)
             uint8_t sei[128], dg[48]; size_t sei_len = 0;
-            po.st = hevcdl_write_picture_hash_sei(&scfg, recon.data() + frame_bytes * i, sei, sizeof sei, &sei_len);
-            if (po.st == HEVCDL_OK) po.st = hevcdl_picture_md5(&scfg, recon.data() + frame_bytes * i, dg);
+            po.st = hevcdl_picture_md5(&scfg, recon + frame_bytes * (size_t)i, dg);
+            if (po.st == HEVCDL_OK) po.st = hevcdl_write_digest_sei(dg, sei, sizeof sei, &sei_len);
             if (po.st != HEVCDL_OK) continue;
             po.bytes.insert(po.bytes.end(), sei, sei + sei_len);
             char *q = po.md5_text + sprintf(po.md5_text, " [MD5:");
@@ -348,7 +309,7 @@ int main(int argc, char **argv)
           }
         }
       };
-      const int nthreads = (int)std::max(1u, std::min<unsigned>({ (unsigned)nb, std::thread::hardware_concurrency(), 32u }));
+      const int nthreads = std::max(1, std::min(count, max_threads));
       std::vector<std::thread> pool;
       for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
       work();
@@ -356,25 +317,52 @@ int main(int argc, char **argv)
     }
     const auto tw0 = now();
     t_host += secs(th0, tw0);
-    for (int i = 0; i < nb; i++) {
+    for (int i = 0; i < count; i++) {
       const PicOut &po = pics[i];
-      if (po.st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)po.st); rc = 3; break; }
+      if (po.st != HEVCDL_OK) { fprintf(stderr, "Error: bitstream writer failed (status %d)\n", (int)po.st); rc = 3; return 1; }
       const double maxval = (double)(255 << (bit_depth - 8));
-      const double p[3] = { psnr_of(stats[i].sse[0], ny, maxval), psnr_of(stats[i].sse[1], nc, maxval), psnr_of(stats[i].sse[2], nc, maxval) };
+      const double p[3] = { psnr_of(po.sse[0], ny, maxval), psnr_of(po.sse[1], nc, maxval), psnr_of(po.sse[2], nc, maxval) };
       if (fbits) fwrite(po.bytes.data(), 1, po.bytes.size(), fbits);
-      printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]%s\n", f0 + i, 0, 'I', qp,
-             (unsigned long long)po.au_len * 8, p[0], p[1], p[2], et, po.md5_text);
+      printf("POC %4ld TId: %1d ( %c-SLICE, QP %d ) %10llu bits [Y %6.4lf dB    U %6.4lf dB    V %6.4lf dB] [ET %5.0f ]%s\n", cc.f0 + first + i, 0, 'I', qp,
+             (unsigned long long)po.au_len * 8, p[0], p[1], p[2], cc.et, po.md5_text);
       sum_bits += (double)po.au_len * 8;
-      for (int c = 0; c < 3; c++) { sum_psnr[c] += p[c]; sum_mse[c] += (double)stats[i].sse[c] / (c ? nc : ny); }
+      for (int c = 0; c < 3; c++) { sum_psnr[c] += p[c]; sum_mse[c] += (double)po.sse[c] / (c ? nc : ny); }
       done++;
     }
-    if (frec) fwrite(recon.data(), frame_bytes, nb, frec);
-    if (frecords) fwrite(recs.data(), sizeof(hevcdl_ctu_record), (size_t)ctus * nb, frecords);
+    if (frec) fwrite(recon, frame_bytes, count, frec);
+    if (frecords) fwrite(recs, sizeof(hevcdl_ctu_record), (size_t)ctus * count, frecords);
     t_write += secs(tw0, now());
+    return 0;
+  };
+  struct Tramp { static int call(void *u, int first, int count, const hevcdl_ctu_record *recs, const void *pics, const hevcdl_sao_blk *sp, const hevcdl_frame_stats *st)
+                 { return (*(decltype(on_chunk) *)u)(first, count, recs, pics, sp, st); } };
+  const long n_batches = (n_frames + batch - 1) / batch;
+  for (long bi = 0; bi < n_batches && rc == 0; bi++) {
+    const long f0 = bi * (long)batch; const int nb = (int)std::min<long>(batch, n_frames - f0);
+    const auto tr0 = now();
+    fseek(fin, (long)((frame_skip + f0) * (long long)frame_bytes), SEEK_SET);
+    if (fread(yuv_mem.data(), frame_bytes, nb, fin) != (size_t)nb) { fprintf(stderr, "Error: short read of '%s'\n", input.c_str()); rc = 2; break; }
+    const uint8_t *lab = nullptr;
+    if (!label_dir.empty()) {
+      for (int i = 0; i < nb && rc == 0; i++) for (int a = 0; a < ctus; a++) {
+        const std::string p = label_dir + "/" + std::to_string(f0 + i) + "/ctu" + std::to_string(a) + ".txt";
+        std::ifstream lf(p); int v;
+        for (int j = 0; j < 16; j++) { if (!(lf >> v) || v < 0 || v > 3) { fprintf(stderr, "Error: label file '%s' must hold 16 depths 0..3\n", p.c_str()); rc = 2; break; } labels_mem[((size_t)i * ctus + a) * 16 + j] = (uint8_t)v; }
+        if (rc) break;
+      }
+      lab = labels_mem.data();
+    }
+    if (rc) break;
+    const auto t0 = now();
+    t_read += secs(tr0, t0);
+    cc.f0 = f0; cc.yuv = yuv_mem.data(); cc.et = 0.0; cc.t0 = t0; cc.nb = nb;
+    const double host_before = t_host + t_write;
+    const hevcdl_status est = hevcdl_encode_pictures_chunked(ctx, yuv_mem.data(), nb, lab, deblock ? 1 : 0, sao ? 1 : 0, chunk, &Tramp::call, &on_chunk);
+    t_dev += secs(t0, now()) - ((t_host + t_write) - host_before);
+    if (est != HEVCDL_OK && rc == 0) { fprintf(stderr, "Error: %s (status %d)\n", hevcdl_last_error(ctx), (int)est); rc = 3; }
   }
-  if (producer.joinable()) producer.join();
-  fprintf(stderr, "stage seconds: read %.2f  device (copies + CNN + decisions + filters) %.2f  host (entropy coding, hashes) %.2f  write %.2f%s\n", t_read, t_dev, t_host, t_write,
-          n_stages > 1 ? "  (read + device of a batch overlap host + write of the batch before)" : "");
+  fprintf(stderr, "stage seconds: read %.2f  device (upload + CNN + decisions + filters; its chunk copies run behind the host work) %.2f  host (entropy coding, hashes, %d threads) %.2f  write %.2f\n",
+          t_read, t_dev, max_threads, t_host, t_write);
   if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
     const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
     printf("\n\nSUMMARY --------------------------------------------------------\n");

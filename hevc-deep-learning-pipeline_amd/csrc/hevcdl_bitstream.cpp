@@ -102,27 +102,45 @@ uint32_t count_emulations(const std::vector<uint8_t> &b)
 struct Md5 {
   uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u }; uint64_t len = 0; uint8_t buf[64]; int fill = 0;
   static uint32_t rol(uint32_t v, int s) { return (v << s) | (v >> (32 - s)); }
+  static const uint32_t *sines()
+  { // K[i] = floor(2^32 * |sin(i + 1)|), RFC 1321 section 3.4, computed once
+    struct Table { uint32_t k[64]; Table() { for (int i = 0; i < 64; i++) k[i] = (uint32_t)(int64_t)floor(fabs(sin((double)(i + 1))) * 4294967296.0); } };
+    static const Table t;                                               // initialised once, thread-safe
+    return t.k;
+  }
+  const uint32_t *K = sines();
   void block(const uint8_t *p)
   {
-    static const int S[64] = { 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
-                               4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21 };
     uint32_t m[16], a = h[0], b = h[1], c = h[2], d = h[3];
-    for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
-    for (int i = 0; i < 64; i++) {
-      uint32_t f; int g;
-      if (i < 16) { f = (b & c) | (~b & d); g = i; }
-      else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
-      else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
-      else { f = c ^ (b | ~d); g = (7 * i) & 15; }
-      const uint32_t k = (uint32_t)(int64_t)floor(fabs(sin((double)(i + 1))) * 4294967296.0);
-      const uint32_t t = d; d = c; c = b; b = b + rol(a + f + k + m[g], S[i]); a = t;
-    }
+    memcpy(m, p, 64);                                                   // little-endian hosts only, like the rest of the byte packing here
+#define MD5_STEP(F, a, b, c, d, g, i, s) a = b + rol(a + F(b, c, d) + K[i] + m[g], s)
+#define MD5_F(x, y, z) (z ^ (x & (y ^ z)))
+#define MD5_G(x, y, z) (y ^ (z & (x ^ y)))
+#define MD5_H(x, y, z) (x ^ y ^ z)
+#define MD5_I(x, y, z) (y ^ (x | ~z))
+#define MD5_ROUND(F, g0, gs, i0, s0, s1, s2, s3) \
+    for (int q = 0; q < 4; q++) { const int i = i0 + 4 * q; \
+      MD5_STEP(F, a, b, c, d, (g0 + gs * (i - i0)) & 15, i, s0); MD5_STEP(F, d, a, b, c, (g0 + gs * (i + 1 - i0)) & 15, i + 1, s1); \
+      MD5_STEP(F, c, d, a, b, (g0 + gs * (i + 2 - i0)) & 15, i + 2, s2); MD5_STEP(F, b, c, d, a, (g0 + gs * (i + 3 - i0)) & 15, i + 3, s3); }
+    MD5_ROUND(MD5_F, 0, 1, 0, 7, 12, 17, 22)
+    MD5_ROUND(MD5_G, 1, 5, 16, 5, 9, 14, 20)
+    MD5_ROUND(MD5_H, 5, 3, 32, 4, 11, 16, 23)
+    MD5_ROUND(MD5_I, 0, 7, 48, 6, 10, 15, 21)
+#undef MD5_ROUND
+#undef MD5_STEP
+#undef MD5_F
+#undef MD5_G
+#undef MD5_H
+#undef MD5_I
     h[0] += a; h[1] += b; h[2] += c; h[3] += d;
   }
   void update(const uint8_t *p, size_t n)
   {
     len += n;
-    while (n) { const size_t take = std::min<size_t>(n, 64 - fill); memcpy(buf + fill, p, take); fill += (int)take; p += take; n -= take; if (fill == 64) { block(buf); fill = 0; } }
+    while (n) {
+      if (!fill && n >= 64) { block(p); p += 64; n -= 64; continue; }   // whole blocks straight from the caller's memory
+      const size_t take = std::min<size_t>(n, 64 - fill); memcpy(buf + fill, p, take); fill += (int)take; p += take; n -= take; if (fill == 64) { block(buf); fill = 0; }
+    }
   }
   void final(uint8_t out[16])
   {
@@ -521,16 +539,12 @@ extern "C" hevcdl_status hevcdl_picture_md5(const hevcdl_stream_config *cfg, con
   return HEVCDL_OK;
 }
 
-extern "C" hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, const void *picture, uint8_t *out, size_t capacity, size_t *out_len)
+extern "C" hevcdl_status hevcdl_write_digest_sei(const uint8_t digest[48], uint8_t *out, size_t capacity, size_t *out_len)
 { // SEIDecodedPictureHash 1 (MD5): suffix SEI NAL after the slice (TEncGOP.cpp:1938-1960, SEIwrite.cpp xWriteSEIDecodedPictureHash)
-  if (!cfg || cfg->struct_size != sizeof *cfg || !picture || !out || !out_len) return HEVCDL_ERR_INVALID_ARG;
-  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7)) return HEVCDL_ERR_INVALID_ARG;
-  uint8_t d[48];
-  const hevcdl_status st = hevcdl_picture_md5(cfg, picture, d);
-  if (st != HEVCDL_OK) return st;
+  if (!digest || !out || !out_len) return HEVCDL_ERR_INVALID_ARG;
   BitOut w;
   w.write(132, 8); w.write(49, 8); w.write(0, 8);          // payload type decoded_picture_hash, size 1 + 3 * 16, hash_type 0 = MD5
-  for (int i = 0; i < 48; i++) w.write(d[i], 8);
+  for (int i = 0; i < 48; i++) w.write(digest[i], 8);
   w.trailing();
   std::vector<uint8_t> nal;
   put_nal(nal, 40, w.b, false);                           // SUFFIX_SEI_NUT
@@ -538,6 +552,16 @@ extern "C" hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_confi
   if (nal.size() > capacity) return HEVCDL_ERR_INVALID_ARG;
   memcpy(out, nal.data(), nal.size());
   return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, const void *picture, uint8_t *out, size_t capacity, size_t *out_len)
+{ // the digests of `picture`, then the SEI above
+  if (!cfg || cfg->struct_size != sizeof *cfg || !picture || !out || !out_len) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7)) return HEVCDL_ERR_INVALID_ARG;
+  uint8_t d[48];
+  const hevcdl_status st = hevcdl_picture_md5(cfg, picture, d);
+  if (st != HEVCDL_OK) return st;
+  return hevcdl_write_digest_sei(d, out, capacity, out_len);
 }
 
 extern "C" size_t hevcdl_access_unit_bound(int width, int height)

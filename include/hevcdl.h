@@ -185,6 +185,16 @@ hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_org, const vo
  * the in-loop filters and estimated bits, as hevcdl_compress_frames.  Replaces TEncGOP::compressGOP's per-picture stages (TEncGOP.cpp:1560-1800). */
 hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, hevcdl_ctu_record *records,
                                      void *picture_out, hevcdl_sao_blk *sao_opt, hevcdl_frame_stats *stats_opt);
+/* The same pipeline with the results handed over CHUNK BY CHUNK instead of into caller buffers for the whole batch: the device works on all n_frames at once (a
+ * frame is a serial chain of CTUs, so a call costs about the same from 1 to ~250 pictures: large batches are what the GPU wants), then `fn` is called on the
+ * calling thread for pictures [first, first + count) -- records, output pictures, SAO parameters (NULL when want_sao == 0) and statistics of the chunk, in
+ * page-locked memory owned by the library and valid only during the call -- while the next chunk is copied from HBM behind it.  The host work per picture
+ * (hevcdl_write_access_unit, hashes, PSNR: TEncGOP.cpp:1895-1935, 2420-2447) thus overlaps the copies, and the host never holds more than two chunks
+ * (a 2160p picture is 43 MB of results).  chunk_frames <= 0: a default (64).  A non-zero return of fn stops the hand-over: HEVCDL_ERR_INVALID_ARG. */
+typedef int (*hevcdl_chunk_fn)(void *user, int first, int count, const hevcdl_ctu_record *records, const void *pictures, const hevcdl_sao_blk *sao_opt,
+                               const hevcdl_frame_stats *stats);
+hevcdl_status hevcdl_encode_pictures_chunked(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, int want_sao,
+                                             int chunk_frames, hevcdl_chunk_fn fn, void *user);
 
 /* ---- bitstream writer (host side; no GPU needed) ---------------------------------------------------
  * One access unit per picture exactly as the reference emits it for its all-intra configuration: VPS, SPS, PPS
@@ -220,6 +230,8 @@ hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cfg, int poc,
 hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, const void *picture, uint8_t *out, size_t capacity, size_t *out_len);
 /* The three 16-byte MD5 digests (Y, Cb, Cr) themselves, as the reference prints them behind a picture's line (TEncGOP.cpp:2529-2540). */
 hevcdl_status hevcdl_picture_md5(const hevcdl_stream_config *cfg, const void *picture, uint8_t digest[48]);
+/* The same SEI NAL from digests already computed by hevcdl_picture_md5 (an application that also prints them hashes the picture once). */
+hevcdl_status hevcdl_write_digest_sei(const uint8_t digest[48], uint8_t *out, size_t capacity, size_t *out_len);
 
 /* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------
  *   TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)   TEncCu.h:120, called at TEncSlice.cpp:879
