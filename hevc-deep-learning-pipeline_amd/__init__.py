@@ -367,6 +367,30 @@ class Encoder:
                                                     params.ctypes.data if sao else None, stats.ctypes.data))
         return recs, out, params, stats
 
+    def encode_pictures_chunked(self, yuv, labels=None, deblock=True, sao=True, chunk_frames=0):
+        """The same pipeline with the results handed over chunk by chunk (hevcdl_encode_pictures_chunked): a generator-like list of
+        (first, records [count, ctus], pictures [count, samples], SAO parameters or None, stats [count]) copies, one per chunk."""
+        yuv, n = self._frames(yuv)
+        lab_ptr = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, np.uint8).reshape(n, self.ctus, 16)
+            lab_ptr = labels.ctypes.data
+        chunks = []
+        fn_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+
+        def view(ptr, dtype, shape):
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer(ctypes.string_at(ptr, nbytes), dtype).reshape(shape).copy()
+
+        def on_chunk(_user, first, count, recs, pics, sao_p, stats):
+            chunks.append((first, view(recs, REC_DTYPE, (count, self.ctus)), view(pics, yuv.dtype, (count, yuv.shape[1])),
+                           view(sao_p, SAO_DTYPE, (count, self.ctus, 3)) if sao_p else None, view(stats, STATS_DTYPE, (count,))))
+            return 0
+        cb = fn_t(on_chunk)
+        self.lib.hevcdl_encode_pictures_chunked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, fn_t, ctypes.c_void_p]
+        self._check(self.lib.hevcdl_encode_pictures_chunked(self._h, yuv.ctypes.data, n, lab_ptr, int(bool(deblock)), int(bool(sao)), int(chunk_frames), cb, None))
+        return chunks
+
     # ---- deblocking filter (TComLoopFilter::loopFilterPic) ----
     def deblock_frames(self, recon, records):
         """recon [n, frame_bytes] (before the in-loop filters) + records [n, ctus] -> deblocked pictures."""

@@ -855,7 +855,10 @@ DEV double rl_d(double v, int l)
 }
 
 #ifdef HEVCDL_KERNEL_PROF
-#define RDOQ_MARK(id) do { if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - pt_); pt_ = n_; } } while (0)
+#ifndef HEVCDL_PROF_N
+#define HEVCDL_PROF_N 0                                 // != 0: the RDOQ phase timers count TUs of this size only
+#endif
+#define RDOQ_MARK(id) do { if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); if (HEVCDL_PROF_N == 0 || n == HEVCDL_PROF_N) PROF_ACC_(id, n_ - pt_); pt_ = n_; } } while (0)
 #else
 #define RDOQ_MARK(id) do { } while (0)
 #endif
@@ -2493,7 +2496,7 @@ DEV void import_owner(int owner)
 }
 
 // one alternative, on the executing wave's private state; levels / reconstruction go to the result slot, trial samples to the overlay
-template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
+template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
 { // LEAF: the instance a chain owner uses for its own split tasks (spec_children): every kind but the second-pass task, no nested regions
   CHECK_EXEC(3);
   const int idx = uni(idx_);
@@ -2611,6 +2614,9 @@ template <bool LEAF> DEVN void run_task(LRegion &r, int idx_)
   { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
 #endif
 }
+// The call form: a master deep inside the search (region_run, spec_children).  Helpers run the body inside the kernel's own frame (helper_step):
+// a kernel has no caller whose registers it must preserve, so the ~27 register saves + restores per task (256 B of scratch each) are not made there.
+template <bool LEAF> DEVN void run_task(LRegion &r, int idx_) { run_task_body<LEAF>(r, idx_); }
 
 // claim a task of region r: its index, or -1.  Compare-and-swap, not a blind add: the count grows while a region is open (region_publish),
 // and an index taken by a failed claim would be skipped when it becomes valid later.
@@ -2656,7 +2662,7 @@ DEV int helper_step()
       if (idx < 0) continue;
       wg_acquire();
       { PROF_T0(); import_owner(uni(r.owner)); PROF_ADD(0, 53); }
-      run_task<false>(r, idx);
+      run_task_body<false>(r, idx);
       wg_release();
       lds_add(&r.done, 1);
       did = 1;

@@ -208,6 +208,32 @@ def test_unclamped_caller_labels_get_the_boundary_policy(oracle_built):
     enc.close()
 
 
+@pytest.mark.parametrize("chunk,sao", [(3, True), (16, True), (5, False)])
+def test_chunked_hand_over_equals_the_whole_batch_call(chunk, sao):
+    """hevcdl_encode_pictures_chunked hands the results of the same device batch over chunk by chunk (two pinned buffers, a copy stream): every
+    chunk must hold, picture for picture, what hevcdl_encode_pictures writes into the caller's buffers -- ragged last chunk, chunk larger than the
+    batch, CNN labels (labels == None) and no SAO included."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf = 200, 136, 31, 11
+    yuv = ref_tools.synth_yuv(w, h, nf, 17)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    recs, pics, params, stats = enc.encode_pictures(yuv, None, sao=sao)
+    chunks = enc.encode_pictures_chunked(yuv, None, sao=sao, chunk_frames=chunk)
+    enc.close()
+    assert [c[0] for c in chunks] == list(range(0, nf, chunk))
+    assert sum(c[1].shape[0] for c in chunks) == nf
+    for first, r, p, sp, st in chunks:
+        n = r.shape[0]
+        assert_records_equal(r, recs[first:first + n], "chunk at %d" % first)
+        assert np.array_equal(p, pics[first:first + n])
+        assert (sp is None) == (not sao)
+        if sao:
+            assert sp.tobytes() == params[first:first + n].tobytes()
+        for k in ("sse", "est_bits", "ctus"):
+            assert np.array_equal(st[k], stats[k][first:first + n]), k
+
+
 def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built):
     """600 frames on 256 workgroups do not divide evenly: the surplus frames travel round the ring of workgroups (a frame is handed over at a CTU
     boundary: position + coder state).  The launch that migrates must give, frame by frame, what launches without migration give (<= one frame

@@ -11,7 +11,7 @@ yuv=np.concatenate([ref_tools.synth_yuv(W,H,min(F,4),seed=1)]*((F+3)//4))[:F]
 enc=hevcdl_amd.Encoder(W,H,32,max_frames=F); lab=enc.predict_depth(yuv); enc.compress_frames(yuv,lab); enc.close()
 """%(sys.argv[1],sys.argv[2])
 code=code.replace("sys.argv[3]", repr(sys.argv[3]) if len(sys.argv)>3 else "'1'").replace("len(sys.argv)>3","True")
-out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_LIB='/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so'),capture_output=True,text=True)
+out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_LIB=os.environ.get('PROF_LIB','/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so')),capture_output=True,text=True)
 rows=[l.split()[1:] for l in out.stdout.splitlines() if l.startswith('DBGV')]
 tot=int(rows[14][0]) if len(rows)>14 else 1
 for i,r in enumerate(rows[:len(names)]):
