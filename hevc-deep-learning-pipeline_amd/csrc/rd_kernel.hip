@@ -52,14 +52,20 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
 constexpr int NPEND = BD == 8 ? 2 : 1;                         // second luma passes a master may leave running behind it (the 10-bit kernel has LDS for one more region only)
-constexpr int NREG = 1 + NPEND;                                // regions per wave: [0] first pass / chroma / rough-mode slices, [1..] the second passes (master: their tickets; chain owner: [1] its split tasks)
+#ifndef HEVCDL_AHEAD
+#define HEVCDL_AHEAD 1
+#endif
+constexpr int AHEAD = (BD == 8 && HEVCDL_AHEAD) ? 1 : 0;       // first-pass candidates of the NEXT CU coded during this CU's chroma search (est_intra_chroma); needs one more region per wave
+constexpr int NREG = 1 + NPEND + AHEAD;                        // regions per wave: [0] first pass / chroma / rough-mode slices, [1..NPEND] the second passes (master: their tickets; chain owner: [1] its split tasks), [REG_AHEAD] the look-ahead
+constexpr int REG_AHEAD = 1 + NPEND;
 constexpr int NSLOT = 20;                                     // result slots of a master: 0..9 first pass, 5..9 chroma, then one set of 5 per second pass that can be pending
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
 // per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
 constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while it runs one of its own split tasks (spec_children)
-constexpr int LEAF_LOG = 192, LOG_BYTES = 66 * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast)     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
+constexpr int LOG_AHEAD = 68, LOG_AHEAD_N = 17;               // entries 68..84: the master's context as the look-ahead candidates see it (ahead_open)
+constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_AHEAD + LOG_AHEAD_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
@@ -209,7 +215,10 @@ struct __attribute__((aligned(16))) RdSmem {
   // [0, replay_upto) from the log, CU nocarry_leaf with the result that pass reached (its luma is not searched again)
   int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[2], pend_reg[2], left_pending, resume_reg;   // resume_reg: ticket region of the pass that won, whose result CU nocarry_leaf takes over
   Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
-  uint8_t c8a[11][4]; int16_t c8coef[96]; pel_t c8rec[96];   // saved 2Nx2N candidate of an 8x8 CU
+  uint8_t c8a[11][4];                 // saved 2Nx2N candidate of an 8x8 CU: attribute entries (levels and samples: entries 66 / 67 of the wave's log in HBM)
+  // Look-ahead (est_intra_chroma -> est_intra_luma of the next CU): ahead_open 0 none / 1 region open / 2 frozen (no further claims); key of the PU, number of
+  // candidates, tasks claimed before the freeze, fractional bits the candidates started from
+  int ahead_open, ahead_key, ahead_n, ahead_claimed; unsigned int ahead_f0, pad_ahead;
 #ifdef HEVCDL_KERNEL_PROF
   GLB unsigned long long *my_prof; int prof_task, prof_pad; // timers of the profiling build (8-bit kernel, workgroup 0): 64 accumulators in HBM (cycles in the low 40 bits, calls above), added to with returnless atomics -- no LDS, no wait
 #endif
@@ -265,7 +274,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5, T_LUMA_AHEAD = 6 };
 enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14, SLOT_PSET = 5 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it); per second pass (set p = its region - 1, slots + 5 p): 10..13 its split tasks (by child), 14 its verdict + start state
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
@@ -2245,6 +2254,116 @@ DEVN void pend_join_oldest(KR k, int site = 0)
 #endif
 }
 
+// Candidates of the first RD pass: rough-mode costs = SATD + mode bits (xModeBitsIntra :5530-5557: 3 possible values, from fractional bits f0 and the state st of
+// the prev_intra_luma_pred context), the c_num_rd_cand best in xUpdateCandList's order, then the most probable modes not among them (:2320-2350).  -> s.rd_list, count
+template <bool TRACE> DEV int rmd_candidates(KR k, int x, int y, int pu_log2, unsigned long long f0, int st, LDS const unsigned int *satd)
+{
+  LSmem &s = lds();
+  int preds[3], nm; get_mpm(k, x, y, preds, &nm);
+  int nfull = c_num_rd_cand[pu_log2 - 2];
+  if (lane_id() < 35) {
+    const int mode = lane_id();
+    int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
+    const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
+    s.rmd_cost[mode] = (double)(satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
+  }
+#ifdef HEVCDL_STAGE_TRACE
+  if (TRACE) {  // "1st pass mode" lines, TEncSearch.cpp:2315-2317
+    const bool on = lane_id() < 35; const int mode = on ? lane_id() : 0; int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
+    const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
+    stage_line(k, 0, mode, satd[mode] >> HAD_SH, (unsigned)(fr >> 15), (double)(satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda, on);
+  }
+#endif
+  wsync();
+  // xUpdateCandList :5562-5585 == stable sort by (cost, mode); keep the nfull best
+  if (lane_id() < 35) {
+    const double mc = s.rmd_cost[lane_id()]; int rank = 0;
+    for (int j = 0; j < 35; j++) { const double oc = s.rmd_cost[j]; rank += (oc < mc) || (oc == mc && j < lane_id()); }
+    if (rank < nfull) s.rd_list[rank] = (unsigned)lane_id();
+  }
+  wsync();
+  if (lane_id() == 0) {
+    int nf = nfull;
+    for (int j = 0; j < nm; j++) { int inc = 0; for (int i = 0; i < nf; i++) inc |= (preds[j] == (int)s.rd_list[i]); if (!inc) s.rd_list[nf++] = (unsigned)preds[j]; }
+    s.bc_u32[1] = (unsigned)nf;
+  }
+  wsync();
+  return uni((int)s.bc_u32[1]);
+}
+
+// ---- look-ahead: the next CU's first RD pass during this CU's chroma search -------------------------------------------------------------
+// What a first-pass candidate of a one-TU PU needs: the reconstruction around the PU (final once the CU before it has its first pass's winner; a pending second
+// pass is read through best_rec), the neighbours' modes, and of the coder state the LUMA-SIDE contexts (part size, prev_intra_luma_pred, transform subdivision, luma
+// cbf, luma coefficient contexts) -- the chroma search and the chroma syntax of the CU before touch none of them (chroma has its own contexts), so they are what the
+// first pass's winner of that CU left behind (entry 65 of the log).  The fractional bits the count starts from (15 bits) do depend on the chroma syntax: a candidate
+// coded ahead of time starts from a guess, and its bit count is corrected when the real value is known (est_intra_luma): bits = (f0 + S) >> 15 with S the candidate's
+// own sum, which is in the end state it stored.  Candidate LIST: rough-mode costs with the guessed f0; if the real f0 gives another list, or any luma-side context
+// differs after all, the work is dropped.  Claims end when the chroma search does (the master's context is quiet only while it sits in region_run).
+#ifndef HEVCDL_AHEAD_MAX
+#define HEVCDL_AHEAD_MAX 1                      // measured: with two or three masters per workgroup the candidates coded ahead only take waves from work that is needed now (600 frames: 6.45 -> 6.70 s at 3)
+#endif
+DEVN void ahead_open(KR k, const Cu cu_, int nx_, int ny_, int nl_)
+{
+  const Cu cu = ucu(cu_); const int nx = uni(nx_), ny = uni(ny_), nl = uni(nl_);
+  LSmem &s = lds();
+  LRegion &r = my_region(REG_AHEAD);
+  const int depth = 6 - nl, nparts = 1 << (2 * (nl - 2)), zb = cu.zbase + cu.nparts;
+  const Cu ncu = { nx, ny, nl, depth, zb, nparts, SIZE_2Nx2N };
+  const Tu ptu = { nx, ny, nl, 0, 0, nparts };
+  wsync();
+  for (int i = lane_id(); i < nparts; i += 64) { // initEstData of the next CU (check_rd_cost_intra does it again): the candidates' tasks copy these arrays
+    const int z = zb + i;
+    s.a[A_DEPTH][z] = (uint8_t)depth; s.a[A_PART][z] = (uint8_t)SIZE_2Nx2N; s.a[A_LDIR][z] = DC; s.a[A_CDIR][z] = 0; s.a[A_TRIDX][z] = 0;
+    for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
+  }
+  wsync();
+  { // the context the candidates' waves take over (import_ahead): this wave's own keeps changing while the CU is finished
+    static_assert(sizeof(K) + 11 * 256 <= LOG_AHEAD_N * LEAF_LOG, "look-ahead snapshot");
+    GLB unsigned long long *d = s.my_log + LOG_AHEAD * (LEAF_LOG / 8);
+    LDS const unsigned long long *qk = (LDS const unsigned long long *)&s.k, *qa = (LDS const unsigned long long *)&s.a[0][0];
+    for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = qk[i];
+    for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[sizeof(K) / 8 + i] = qa[i];
+  }
+  GLB const unsigned long long *sp = s.my_log + 65 * (LEAF_LOG / 8);
+  const unsigned long long f0 = uni64(sp[offsetof(Cabac, frac) / 8]) & 32767ull;
+  const int st = uni((int)((GLB const uint8_t *)sp)[CTX_INTRA_PRED]);
+  const int nfull = rmd_candidates<false>(k, nx, ny, nl, f0, st, s.satd_pre);
+  const int n = nfull < 5 ? nfull : 5;                     // result slots 0..4 (5..9 hold this CU's chroma modes)
+  wsync();
+  if (lane_id() < n) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
+  if (lane_id() == 0) { s.ahead_open = 1; s.ahead_key = (nl << 24) | (ny << 12) | nx; s.ahead_n = n; s.ahead_claimed = 0; s.ahead_f0 = (unsigned)f0; r.pad_ = 0x7fffffff; }
+  region_open(r, T_LUMA_AHEAD, n, ncu, ptu);
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64
+  if (lane_id() == 0) PROF_ACC_(4, (unsigned long long)n << 10);
+#endif
+}
+DEV void ahead_freeze()
+{ // no further claims: count := next
+  LSmem &s = lds();
+  if (!AHEAD || uni(s.ahead_open) != 1) return;
+  LRegion &r = my_region(REG_AHEAD);
+  int c = 0;
+  if (lane_id() == 0) {
+    int t = __hip_atomic_load(&r.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) { c = t & 0xffff; if (__hip_atomic_compare_exchange_strong(&r.ticket, &t, (c << 16) | c, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break; }
+    s.ahead_claimed = c; s.ahead_open = 2;
+  }
+  wsync();
+}
+DEVN void ahead_drain()
+{ // drop the look-ahead: the tasks under way still write their slots and their region
+  LSmem &s = lds();
+  if (!AHEAD || !uni(s.ahead_open)) return;
+  ahead_freeze();
+  LRegion &r = my_region(REG_AHEAD);
+  const int c = uni(s.ahead_claimed);
+  while (lds_load(&r.done) < c) __builtin_amdgcn_s_sleep(2);
+  wg_acquire();
+  wsync();
+  if (lane_id() == 0) { s.ahead_open = 0; s.ahead_key = -1; }
+  wsync();
+}
+
 // estIntraPredLumaQT TEncSearch.cpp:2203-2582
 DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 {
@@ -2271,49 +2390,62 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       if (pn >= 8 && pn <= 32) filter_refs(k, pn);
       rmd_satd(k, cu, ptu);
     }
-    int preds[3], nm; get_mpm(k, ptu.x, ptu.y, preds, &nm);
-    int nfull = c_num_rd_cand[pu_log2 - 2];
-    { // mode bits (xModeBitsIntra :5530-5557): 3 possible values, from the [depth][CI_CURR_BEST] snapshot
-      const LCabac *cur = &s.curr[cu.depth];
-      const unsigned long long f0 = cur->frac & 32767ull; const int st = cur->ctx[CTX_INTRA_PRED];
-      if (lane_id() < 35) {
-        const int mode = lane_id();
-        int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
-        const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
-        s.rmd_cost[mode] = (double)(s.satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda;
-      }
-#ifdef HEVCDL_STAGE_TRACE
-      {  // "1st pass mode" lines, TEncSearch.cpp:2315-2317
-        const bool on = lane_id() < 35; const int mode = on ? lane_id() : 0; int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
-        const unsigned long long fr = f0 + (unsigned long long)tb().t_ebits[st ^ (idx != -1)] + 32768ull * (unsigned long long)(idx != -1 ? (idx ? 2 : 1) : 5);
-        stage_line(k, 0, mode, s.satd[mode] >> HAD_SH, (unsigned)(fr >> 15), (double)(s.satd[mode] >> HAD_SH) + (double)(uint32_t)(fr >> 15) * k.sqrt_lambda, on);
-      }
-#endif
-      wsync();
-      // xUpdateCandList :5562-5585 == stable sort by (cost, mode); keep the nfull best
-      if (lane_id() < 35) {
-        const double mc = s.rmd_cost[lane_id()]; int rank = 0;
-        for (int j = 0; j < 35; j++) { const double oc = s.rmd_cost[j]; rank += (oc < mc) || (oc == mc && j < lane_id()); }
-        if (rank < nfull) s.rd_list[rank] = (unsigned)lane_id();
-      }
-      wsync();
-      if (lane_id() == 0) {
-        int nf = nfull;
-        for (int j = 0; j < nm; j++) { int inc = 0; for (int i = 0; i < nf; i++) inc |= (preds[j] == (int)s.rd_list[i]); if (!inc) s.rd_list[nf++] = (unsigned)preds[j]; }
-        s.bc_u32[1] = (unsigned)nf;
-      }
-      wsync();
-      nfull = uni((int)s.bc_u32[1]);
-    }
+    int nfull;
+    { const LCabac *cur = &s.curr[cu.depth]; nfull = rmd_candidates<true>(k, ptu.x, ptu.y, pu_log2, cur->frac & 32767ull, cur->ctx[CTX_INTRA_PRED], s.satd); }   // from the [depth][CI_CURR_BEST] snapshot
     // ---- RD pass 1 (:2355-2443): the candidates are independent (each starts from the [depth][CI_CURR_BEST] snapshot) -> a region ----
     uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
     {
-      LRegion &r = my_region();
+      // candidates coded ahead of time (ahead_open)?  Accepted when they are the PU's candidates in the same order and every context they read is what it was
+      // assumed to be; the tasks nobody had claimed when the chroma search of the CU before ended are run now
+      bool use_ahead = false;
+      if (AHEAD && uni(s.ahead_open)) {
+        ahead_freeze();                                                  // claims have gone on while the CU before was finished
+        LRegion &ra = my_region(REG_AHEAD);
+        const int n_s = uni(s.ahead_n), c = uni(s.ahead_claimed);
+        bool ok = npu == 1 && uni(s.ahead_key) == rkey && c > 0 && n_s == (nfull < 5 ? nfull : 5);
+        if (ok) ok = __ballot(lane_id() < n_s && ra.modes[lane_id() < n_s ? lane_id() : 0] != (int)s.rd_list[lane_id() < n_s ? lane_id() : 0]) == 0ull;
+        if (ok) {
+          GLB const uint8_t *sp = (GLB const uint8_t *)(s.my_log + 65 * (LEAF_LOG / 8)); const LCabac *cur = &s.curr[cu.depth];
+          bool diff = false;
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            const int i = lane_id() + 64 * t;
+            const bool luma_side = i == CTX_PART_SIZE || i == CTX_INTRA_PRED || (i >= CTX_QT_CBF && i < CTX_QT_CBF + 5) || (i >= CTX_SUBDIV && i < CTX_SUBDIV + 3) || i == 19 || i == 20 ||
+                                   (i >= CTX_SIG && i < CTX_SIG + 28) || (i >= CTX_LAST_X && i < CTX_LAST_X + 15) || (i >= CTX_LAST_Y && i < CTX_LAST_Y + 15) ||
+                                   (i >= CTX_ONE && i < CTX_ONE + 16) || (i >= CTX_ABS && i < CTX_ABS + 4) || i == CTX_TSKIP;
+            if (luma_side && sp[i] != cur->ctx[i]) diff = true;
+          }
+          ok = __ballot(diff) == 0ull;
+        }
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64
+        if (lane_id() == 0) { if (ok) PROF_ACC_(5, (unsigned long long)c << 10); else PROF_ACC_(8, (unsigned long long)((npu == 1 && uni(s.ahead_key) == rkey ? 0 : 1) + (c > 0 ? 0 : 2) + (n_s == (nfull < 5 ? nfull : 5) ? 0 : 4)) << 10); }
+#endif
+        if (ok) use_ahead = true; else ahead_drain();
+      }
+      LRegion &r = use_ahead ? my_region(REG_AHEAD) : my_region();
       wsync();
-      if (lane_id() < nfull) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
       PROF_MARK0();
-      region_open(r, T_LUMA_P1, nfull, cu, ptu);
-      region_run(k, r);
+      if (use_ahead) {
+        const int n_s = uni(s.ahead_n), c = uni(s.ahead_claimed);
+        if (lane_id() >= n_s && lane_id() < nfull) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
+        if (lane_id() == 0) r.pad_ = c;                                // tasks from c on are ordinary candidates: this wave's live context, the real snapshot
+        wsync();
+        wg_release();
+        if (lane_id() == 0) __hip_atomic_store(&r.ticket, (nfull << 16) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        region_run(k, r);
+        // the bit counts of the candidates coded ahead, from the fractional bits the CU really starts with
+        const unsigned long long f0t = s.curr[cu.depth].frac & 32767ull, f0s = (unsigned long long)s.ahead_f0;
+        if (lane_id() < c) {
+          const unsigned long long sum = slot_state(k.slots, lane_id(), 1)[offsetof(Cabac, frac) / 8] - f0s;
+          r.cost[lane_id()] = calc_rd_cost(k, (uint32_t)((f0t + sum) >> 15), r.dist[lane_id()]);
+        }
+        if (lane_id() == 0) { s.ahead_open = 0; s.ahead_key = -1; }
+        wsync();
+      } else {
+        if (lane_id() < nfull) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
+        region_open(r, T_LUMA_P1, nfull, cu, ptu);
+        region_run(k, r);
+      }
       PROF_MARK(36);
 #ifdef HEVCDL_STAGE_TRACE
       { const bool on = lane_id() < nfull; stage_line(k, 1, on ? r.modes[lane_id()] : 0, 0u, 0u, on ? r.cost[lane_id()] : 0.0, on); }   // "2nd pass" lines, :2395-2397
@@ -2495,6 +2627,21 @@ DEV void import_owner(int owner)
   wsync();
 }
 
+// the same for a candidate coded ahead of time: the master's context as it was when it opened the look-ahead (ahead_open), from its log in HBM
+DEV void import_ahead(int owner)
+{
+  LSmem &s = lds(); LSmem &ow = lds_of(owner);
+  GLB const unsigned long long *q = ow.my_log + LOG_AHEAD * (LEAF_LOG / 8);
+  wsync();
+  { LDS unsigned long long *d = (LDS unsigned long long *)&s.k; for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = q[i]; }
+  { LDS unsigned long long *d = (LDS unsigned long long *)&s.a[0][0]; for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[i] = q[sizeof(K) / 8 + i]; }
+  wsync();
+  s.k.q_cost = s.my_qcost; s.k.q_rate = s.my_qrate; s.k.ovl = s.my_ovl;      // every lane stores the same values
+  if (lane_id() < 3) s.ref_key[lane_id()] = -1;
+  if (lane_id() == 0) s.fline_key = -1;
+  wsync();
+}
+
 // one alternative, on the executing wave's private state; levels / reconstruction go to the result slot, trial samples to the overlay
 template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
 { // LEAF: the instance a chain owner uses for its own split tasks (spec_children): every kind but the second-pass task, no nested regions
@@ -2543,7 +2690,11 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
     wsync();
     state_from_global(&s.go, slot_state(kk.slots, slot, 0));    // the master's [depth][CI_CURR_BEST] snapshot as it was when the pass was handed over
     DistCost dc = { 0, 0.0, 0 };
+#ifdef HEVCDL_XP2
+    dc.cost = MAX_DOUBLE;                                       // timing experiment: the second pass costs nothing (as if another workgroup ran it)
+#else
     if constexpr (!LEAF) dc = recur_luma_any<true>(k, cu, tu, 0, 1, memo_dist, memo_cost);
+#endif
     dist = memo_dist; cost = memo_cost;
     if (ub(dc.cost < memo_cost)) { // the split wins: levels -> record, reconstruction -> the master's best, arrays -> the verdict slot
       dist = dc.dist; cost = dc.cost;
@@ -2559,10 +2710,12 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
     if (lane_id() == 0) r.cfrac[idx] = dc.cfrac;
     state_to_global(slot_state(kk.slots, slot, 1), &s.go);
     for (int i = lane_id(); i < ttu.nparts; i += 64) { at[i] = s.a[A_TRIDX][zc + i]; at[256 + i] = s.a[A_CBF][zc + i]; at[512 + i] = s.a[A_TSKIP][zc + i]; }
-  } else if (kind == T_LUMA_P1) { // one candidate of the first RD pass (TEncSearch.cpp:2378-2443)
+  } else if (kind == T_LUMA_P1 || kind == T_LUMA_AHEAD) { // one candidate of the first RD pass (TEncSearch.cpp:2378-2443)
     const int zp = cu.zbase + tu.zrel;
     set_parts(k, s.a[A_LDIR], zp, tu.nparts, mode);
-    cabac_copy(k, &s.go, start);
+    // look-ahead (ahead_open): the CU before this one is still in its chroma search; what the candidate reads of the coder state -- the luma-side contexts -- is
+    // what the first pass's winner of that CU left (entry 65 of the owner's log); the fractional bits it starts from are a guess the master corrects
+    if (kind == T_LUMA_AHEAD && idx < uni(r.pad_)) state_from_global(&s.go, ow.my_log + 65 * (LEAF_LOG / 8)); else cabac_copy(k, &s.go, start);
     // a candidate of a PU that is one TU writes its reconstruction to the layer only (code_tu_block mode 3)
     const int one_tu = tu.log2 >= 3 && tu.log2 <= 5;
     if (&s != &ow && tu.log2 <= 5) {
@@ -2605,13 +2758,13 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
   }
   if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
-  if (kind == T_LUMA_P1) PROF_MARK(52);
+  if (kind == T_LUMA_P1 || kind == T_LUMA_AHEAD) PROF_MARK(52);
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   kk.lz = olz; kk.lx = olx; kk.ly = oly;
   wsync();
   PROF_TASK(0);
 #ifdef HEVCDL_KERNEL_PROF
-  { if (kind == T_LUMA_P1) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
+  { if (kind == T_LUMA_P1 || kind == T_LUMA_AHEAD) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
 #endif
 }
 // The call form: a master deep inside the search (region_run, spec_children).  Helpers run the body inside the kernel's own frame (helper_step):
@@ -2655,13 +2808,15 @@ DEV int helper_step()
     // (compress_cu): then it is the first pass and the chroma search the master waits for
     const int p2_first = lds_load(&sh.masters_active) > HEVCDL_FG_FIRST_MAX;
     for (int j = 0; j < NREG * NW && !did; j++) {
-      LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][p2_first ? (j < NPEND * NW ? 1 + j / NW : 0) : (j < NW ? 0 : j / NW)];
+      const int b = j / NW;             // block of the scan: one region index of every wave; the look-ahead comes right behind the masters' own regions, or last
+      const int ri = p2_first ? (b < NPEND ? 1 + b : (b == NPEND ? 0 : REG_AHEAD)) : (b == 0 ? 0 : (AHEAD ? (b == 1 ? REG_AHEAD : b - 1) : b));
+      LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][ri];
       const int t = lds_load(&r.ticket);
       if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
       const int idx = region_claim(r);
       if (idx < 0) continue;
       wg_acquire();
-      { PROF_T0(); import_owner(uni(r.owner)); PROF_ADD(0, 53); }
+      { PROF_T0(); if (AHEAD && uni(r.kind) == T_LUMA_AHEAD && idx < uni(r.pad_)) import_ahead(uni(r.owner)); else import_owner(uni(r.owner)); PROF_ADD(0, 53); }
       run_task_body<false>(r, idx);
       wg_release();
       lds_add(&r.done, 1);
@@ -2699,7 +2854,14 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
       // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
       int nx, ny, nl;
-      if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) rmd_prefetch(k, nx, ny, nl);
+      if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
+        rmd_prefetch(k, nx, ny, nl);
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64
+        if (lane_id() == 0) PROF_ACC_(18, (unsigned long long)((uni(s.lw_valid) ? 0 : 1) + (uni(s.a[A_TRIDX][cu.zbase]) == 0 ? 0 : 2) + (uni(s.ahead_open) ? 4 : 0) + (spare_waves() ? 0 : 8)) << 10);
+#endif
+        if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()
+            && lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX) ahead_open(k, cu, nx, ny, nl);
+      }
     }
     region_run(k, r);
     PROF_MARK(39);
@@ -2839,7 +3001,8 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
     // the split won: take its distortion and arrays (its levels and reconstruction are in the record / best reconstruction already) and
     // repeat the chroma search and the syntax, which depend on the TU tree
     dist_l = (uint32_t)uni((int)r2.dist[0]);
-    if (lane_id() == 0) s.pre_key = -1;                           // sums computed ahead for the next CU stood on the old reconstruction
+    ahead_drain();
+    if (lane_id() == 0) s.pre_key = -1;                           // sums (and candidates) computed ahead for the next CU stood on the old reconstruction
     GLB const uint8_t *at = slot_attr(k.slots, SLOT_P2 + SLOT_PSET * pset);
     for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_TRIDX][cu.zbase + i] = at[i]; s.a[A_CBF][cu.zbase + i] = at[256 + i]; s.a[A_TSKIP][cu.zbase + i] = at[512 + i]; }
     cabac_copy(k, &s.go, &s.curr[cu.depth]);
@@ -2851,28 +3014,30 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
 DEV void save_cand8(KR k, const Cu &cu)
 {
   LSmem &s = lds();
+  GLB int16_t *c8coef = (GLB int16_t *)(s.my_log + 66 * (LEAF_LOG / 8)); GLB pel_t *c8rec = (GLB pel_t *)(s.my_log + 67 * (LEAF_LOG / 8));
   GLB const int16_t *rc = (GLB const int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
   wsync();
   if (lane_id() < 44) s.c8a[lane_id() >> 2][lane_id() & 3] = s.a[lane_id() >> 2][cu.zbase + (lane_id() & 3)];
   for (int i = lane_id(); i < 96; i += 64) {
     const int c = i < 64 ? 0 : (i < 80 ? 1 : 2), j = i < 64 ? i : (i - 64) & 15;
-    s.c8coef[i] = rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j];
+    c8coef[i] = rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j];
     const int n = c ? 4 : 8, sx = c ? 32 : 64, bo = comp_off(c) + boff(k, c, cu.x >> (c ? 1 : 0), cu.y >> (c ? 1 : 0));
-    s.c8rec[i] = k.best_rec[bo + (j / n) * sx + (j % n)];
+    c8rec[i] = k.best_rec[bo + (j / n) * sx + (j % n)];
   }
   wsync();
 }
 DEV void load_cand8(KR k, const Cu &cu)
 {
   LSmem &s = lds();
+  GLB const int16_t *c8coef = (GLB const int16_t *)(s.my_log + 66 * (LEAF_LOG / 8)); GLB const pel_t *c8rec = (GLB const pel_t *)(s.my_log + 67 * (LEAF_LOG / 8));
   GLB int16_t *rc = (GLB int16_t *)(k.records + (size_t)k.addr * REC_SIZE + REC_COEF);
   wsync();
   if (lane_id() < 44) s.a[lane_id() >> 2][cu.zbase + (lane_id() & 3)] = s.c8a[lane_id() >> 2][lane_id() & 3];
   for (int i = lane_id(); i < 96; i += 64) {
     const int c = i < 64 ? 0 : (i < 80 ? 1 : 2), j = i < 64 ? i : (i - 64) & 15;
-    rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j] = s.c8coef[i];
+    rc[comp_off(c) + (c ? cu.zbase * 4 : cu.zbase * 16) + j] = c8coef[i];
     const int n = c ? 4 : 8, sx = c ? 32 : 64, bo = comp_off(c) + boff(k, c, cu.x >> (c ? 1 : 0), cu.y >> (c ? 1 : 0));
-    k.best_rec[bo + (j / n) * sx + (j % n)] = s.c8rec[i];
+    k.best_rec[bo + (j / n) * sx + (j % n)] = c8rec[i];
   }
   wsync();
 }
@@ -3109,7 +3274,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; }
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.ahead_open = 0; s.ahead_key = -1; }
     wsync();
     PROF_MARK(47);
     Rd best;
@@ -3133,6 +3298,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       if (lane == 0) PROF_ACC_(38, (unsigned long long)(s.leaf_idx - s.replay_upto) << 10);   // restarts, CUs thrown away
 #endif
       if (lane < 3) s.ref_key[lane] = -1;
+      ahead_drain();
       if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; }
       wsync();
       cabac_copy(k, &s.curr[0], truec);
