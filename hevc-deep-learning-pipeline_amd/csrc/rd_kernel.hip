@@ -2727,7 +2727,18 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
       wsync();
     }
     PROF_MARK(50);
-    const DistCost dc = recur_luma_any(k, cu, tu, one_tu ? 2 : 1);
+    DistCost dc;
+    if (one_tu) { // the single-TU branch of recur_luma (first pass: no split to check, no transform-skip trial above 4x4) without its call frame
+      set_parts(k, s.a[A_TSKIP + 0], zp, tu.nparts, 0); wsync();
+      dc.dist = code_tu_block(k, cu, tu, 0, 3);
+      uint32_t bits;
+      switch (tu.log2) {
+        case 5: bits = intra_bits_qt<5>(k, cu, tu, 1, 0); break;
+        case 4: bits = intra_bits_qt<4>(k, cu, tu, 1, 0); break;
+        default: bits = intra_bits_qt<3>(k, cu, tu, 1, 0); break;
+      }
+      dc.cost = calc_rd_cost(k, bits, dc.dist); dc.cfrac = uni64(s.cfrac_last);
+    } else dc = recur_luma_any(k, cu, tu, 1);
     PROF_MARK(51);
     dist = dc.dist; cost = dc.cost;
     wsync();
