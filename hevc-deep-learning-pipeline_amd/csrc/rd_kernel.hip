@@ -863,6 +863,16 @@ DEV double rl_d(double v, int l)
   return __hiloint2double(hi, lo);
 }
 
+#if defined(HEVCDL_KERNEL_PROF) && defined(HEVCDL_PROF_MASTER)
+// the master's serial sections, on the accumulators of the RDOQ phase timers (build with -DHEVCDL_PROF_N=64: those then stay silent)
+#define MT0() unsigned long long mt_ = __builtin_readcyclecounter()
+#define MT(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - mt_); mt_ = n_; } else mt_ = 0; } while (0)
+#define MTR() do { mt_ = __builtin_readcyclecounter(); } while (0)
+#else
+#define MTR() do { } while (0)
+#define MT0() do { } while (0)
+#define MT(id) do { } while (0)
+#endif
 #ifdef HEVCDL_KERNEL_PROF
 #ifndef HEVCDL_PROF_N
 #define HEVCDL_PROF_N 0                                 // != 0: the RDOQ phase timers count TUs of this size only
@@ -967,8 +977,8 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     wsync();
     s.zb[0][lane] = c0;
     wsync();
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
+    const int nb = (((top - last_pos) < 64 ? (top - last_pos) : 64) + 15) >> 4;     // lanes from top - last_pos on hold +0.0, which leaves the sum as it is
+    for (int h = 0; h < nb; h++) {
       double v[16];
 #pragma unroll
       for (int t = 0; t < 16; t++) v[t] = s.zb[0][h * 16 + t];
@@ -985,6 +995,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   unsigned long long cgf_mask = 0;                     // significant-group flags after RDOQ, bit = raster index of the group
   auto cgf_at = [&](int gx, int gy) -> int { return (int)((cgf_mask >> (gy * wg + gx)) & 1ull); };
   int carry = 0;                                       // the previous group in scan order ended with c1 == 0
+  bool cc_needed = true;                               // no group that keeps a level > 1 yet: the last-position search will walk the groups still to come
   const unsigned long long dstart = wg == 8 ? 0xA44208101020844Bull : (wg == 4 ? 0xA44Bull : 0xBull);
   // ---- phase B ----
   int cgpos = cg_last;
@@ -1108,7 +1119,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       RDOQ_MARK(5);
       if (valid) {
         dst[blk_j] = (int16_t)lvl_j;
-        q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j);
+        if (cc_needed) { q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j); }   // read again by the last-position search only
         q_rate_st(Q_SIGDELTA, blk_j, b1_j - b0_j);                   // 0 at the last position
         q_rate_st(Q_DELTAU, blk_j, (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8)));
         q_rate_st(Q_UP, blk_j, ru_j);
@@ -1165,12 +1176,12 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
           zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
           if (zero_cost < base_cost) {
             base_cost = zero_cost; cgc = r0; flag = 0;
-            if (row == r && lvl_j) { dst[blk_j] = 0; q_cost_st(Q_COEFF, sp_j, c0_j); q_cost_st(Q_SIG, sp_j, 0.0); }
+            if (row == r && lvl_j) dst[blk_j] = 0;                       // (its per-position costs are never read: the last-position search skips a group without the flag)
           }
           if (lane == 0) cost_cg_sig[qq] = cgc;
         }
       } else flag = 1;
-      if (flag) cgf_mask |= 1ull << cb;
+      if (flag) { cgf_mask |= 1ull << cb; if ((g1m >> (16 * r)) & 0xffffull) cc_needed = false; }   // the last-position search ends in this group (a level > 1 stays)
       RDOQ_MARK(35);
     }
     carry = (int)(((g1m >> (16 * (R - 1))) & 0xffffull) != 0ull);
@@ -2333,7 +2344,7 @@ DEVN void ahead_open(KR k, const Cu cu_, int nx_, int ny_, int nl_)
   if (lane_id() < n) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
   if (lane_id() == 0) { s.ahead_open = 1; s.ahead_key = (nl << 24) | (ny << 12) | nx; s.ahead_n = n; s.ahead_claimed = 0; s.ahead_f0 = (unsigned)f0; r.pad_ = 0x7fffffff; }
   region_open(r, T_LUMA_AHEAD, n, ncu, ptu);
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
   if (lane_id() == 0) PROF_ACC_(4, (unsigned long long)n << 10);
 #endif
 }
@@ -2374,6 +2385,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
   const int init_trd = cu.part == SIZE_NxN ? 1 : 0, npu = init_trd ? 4 : 1;
   const int pu_log2 = cu.log2 - init_trd, pn = 1 << pu_log2, pu_parts = cu.nparts >> (2 * init_trd);
   uint32_t overall = 0;
+  MT0();
   for (int pu = 0; pu < npu; pu++) {
     const int poff = pu * pu_parts, zp = cu.zbase + poff;
     const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
@@ -2417,13 +2429,14 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           }
           ok = __ballot(diff) == 0ull;
         }
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
         if (lane_id() == 0) { if (ok) PROF_ACC_(5, (unsigned long long)c << 10); else PROF_ACC_(8, (unsigned long long)((npu == 1 && uni(s.ahead_key) == rkey ? 0 : 1) + (c > 0 ? 0 : 2) + (n_s == (nfull < 5 ? nfull : 5) ? 0 : 4)) << 10); }
 #endif
         if (ok) use_ahead = true; else ahead_drain();
       }
       LRegion &r = use_ahead ? my_region(REG_AHEAD) : my_region();
       wsync();
+      MT(4);
       PROF_MARK0();
       if (use_ahead) {
         const int n_s = uni(s.ahead_n), c = uni(s.ahead_claimed);
@@ -2447,6 +2460,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         region_run(k, r);
       }
       PROF_MARK(36);
+      MT(34);
 #ifdef HEVCDL_STAGE_TRACE
       { const bool on = lane_id() < nfull; stage_line(k, 1, on ? r.modes[lane_id()] : 0, 0u, 0u, on ? r.cost[lane_id()] : 0.0, on); }   // "2nd pass" lines, :2395-2397
 #endif
@@ -2524,6 +2538,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     wsync();
   }
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
+  MT(5);
   PROF_ADD(k, 16);
   return overall;
 }
@@ -2820,7 +2835,11 @@ DEV int helper_step()
     const int p2_first = lds_load(&sh.masters_active) > HEVCDL_FG_FIRST_MAX;
     for (int j = 0; j < NREG * NW && !did; j++) {
       const int b = j / NW;             // block of the scan: one region index of every wave; the look-ahead comes right behind the masters' own regions, or last
+      #ifdef HEVCDL_AHEAD_LAST
+      const int ri = p2_first ? (b < NPEND ? 1 + b : (b == NPEND ? 0 : REG_AHEAD)) : b;
+#else
       const int ri = p2_first ? (b < NPEND ? 1 + b : (b == NPEND ? 0 : REG_AHEAD)) : (b == 0 ? 0 : (AHEAD ? (b == 1 ? REG_AHEAD : b - 1) : b));
+#endif
       LRegion &r = sh.reg[(me + 1 + (j % NW)) % NW][ri];
       const int t = lds_load(&r.ticket);
       if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
@@ -2846,6 +2865,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   LSmem &s = lds();
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
   uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+  MT0();
   wsync();
   if (lane_id() < 2) s.ref_key[1 + lane_id()] = -1;
   wsync();
@@ -2861,20 +2881,23 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
       build_refs(k, 1, cu.x >> 1, cu.y >> 1, nc, 1); build_refs(k, 2, cu.x >> 1, cu.y >> 1, nc, 1);
     }
     PROF_MARK0();
+    MT(8);
     region_open(r, T_CHROMA, 5, cu, root);
     if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
       // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
       int nx, ny, nl;
       if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
         rmd_prefetch(k, nx, ny, nl);
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
         if (lane_id() == 0) PROF_ACC_(18, (unsigned long long)((uni(s.lw_valid) ? 0 : 1) + (uni(s.a[A_TRIDX][cu.zbase]) == 0 ? 0 : 2) + (uni(s.ahead_open) ? 4 : 0) + (spare_waves() ? 0 : 8)) << 10);
 #endif
         if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()
             && lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX) ahead_open(k, cu, nx, ny, nl);
       }
     }
+    MT(18);
     region_run(k, r);
+    MT(35);
     PROF_MARK(39);
     int win = -1;
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
@@ -2893,6 +2916,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv[c - 1][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv[c + 1][i]; }
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
+  MT(19);
   PROF_ADD(k, 17);
   return best_dist;
 }
@@ -2951,6 +2975,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
   LSmem &s = lds();
   const int part = uni(part_);
   Cu cu = ucu(cu_); cu.part = part;
+  MT0();
   wsync();
   if (lane_id() < 3) s.ref_key[lane_id()] = -1;
   for (int i = lane_id(); i < cu.nparts; i += 64) { // initEstData TComDataCU.cpp:525-592 + part size / pred mode
@@ -2971,7 +2996,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
     for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_TRIDX][cu.zbase + i] = at[i]; s.a[A_CBF][cu.zbase + i] = at[256 + i]; s.a[A_TSKIP][cu.zbase + i] = at[512 + i]; }
     cabac_copy(k, &s.go, &s.curr[cu.depth]);
     wsync();
-  } else dist_l = est_intra_luma(k, cu);
+  } else { MT(20); dist_l = est_intra_luma(k, cu); MTR(); }
   int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma): the region of its ticket
   if (pending) { // until the pass is joined this CU's luma in the picture belongs to it: whoever needs the samples meanwhile (rmd_prefetch, the next CUs) reads best_rec
     wsync();
@@ -2982,7 +3007,9 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
   if (uni(s.restart)) return r;                      // a pending pass of an earlier CU chose the split: the CTU is walked again (process_unit)
   for (;;) {
     if (!pending) copy_best_rec_to_pic(k, cu, 0);
+    MT(21);
     const uint32_t dist = dist_l + est_intra_chroma(k, cu);
+    MTR();
     wsync();
     if (lane_id() == 0) reset_bits(&s.go);
     if (part == SIZE_2Nx2N && cu.log2 <= 5 && uni(s.lw_valid) && uni(s.a[A_TRIDX][cu.zbase]) == 0)          // one TU per component, winners known: the short form
@@ -2990,6 +3017,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
     else enc_cu_syntax(k, &s.go, cu);
     cabac_copy(k, &s.temp[cu.depth], &s.go);
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
+    MT(22);
     if (!pending) break;
     if (uni(s.carry_ok)) { // the walk goes on while this pass is still running (compress_cu); until it is joined this CU's luma in the picture belongs to
       // the pass, the search reads best_rec instead
