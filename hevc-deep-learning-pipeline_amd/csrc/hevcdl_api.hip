@@ -46,7 +46,7 @@ struct hevcdl_ctx {
   size_t frame_bytes;
   float *d_weights;
   unsigned char *d_scratch;      // decision kernel workspace: one block per wave of every workgroup a launch can have
-  size_t scratch_per_wave; int rd_groups;   // workgroups of a launch: one per CU, fewer when the context cannot hold that many units
+  size_t scratch_per_wave; int rd_groups, remote_groups;   // workgroups of a launch: one per CU, fewer when the context cannot hold that many units
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
   uint8_t *d_yuv8;               // 8-bit copy of 10-bit input for the CNN stage
@@ -246,7 +246,9 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
   ctx->scratch_per_wave = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
   ctx->rd_groups = (int)std::min<long long>(ctx->n_cus, (long long)cfg->max_frames * cfg->tile_columns * cfg->tile_rows);
-  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_wave * (size_t)ctx->rd_groups * hevcdl_rd_waves_per_group()));
+  // (launches of few units run on every CU: the workgroups without a unit take second luma passes from the others, launch_rd -- they need a workspace too)
+  ctx->remote_groups = (cfg->bit_depth == 8 && !(cfg->exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) && ctx->n_cus >= 8 && ctx->n_cus <= 1024) ? ctx->n_cus : 0;
+  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_wave * (size_t)std::max(ctx->rd_groups, ctx->remote_groups) * hevcdl_rd_waves_per_group()));
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_fc_smem_bytes()));
   { // conv -> head hand-over buffer for one chunk of CTUs, allocated up front so that no step pays for it
@@ -396,14 +398,18 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
     HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 8192 + (size_t)groups * 192, s));
     HIPCHK(hipMemcpyAsync(ctx->d_sched, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));      // pageable source: the copy is staged before the call returns
   }
+  // Few units (one frame, ten, a GPU's share of a sharded job): a frame is bound by the work of its CU's eight waves while most CUs have nothing to do -> the
+  // kernel runs on ALL CUs and the workgroups without a unit take the second luma passes the others post (rd_kernel.hip, remote_post / remote_serve)
+  p.remote = (!p.migrate && ctx->remote_groups && 2 * n_units <= ctx->remote_groups && !d_cabac_in && !d_cabac_out && ctu_begin == 0 && p.ctu_end == ctx->ctus) ? 1 : 0;
+  if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 8192, s));      // finished counter, queue head / tail, the ring
   prof_begin(ctx, ctx->ev_rd, s);
   const void *kern = ctx->cfg.bit_depth == 8 ? (const void *)hevcdl_rd_frame_kernel : (const void *)hevcdl_rd_frame_kernel_bd10;
   const size_t smem = ctx->cfg.bit_depth == 8 ? hevcdl_rd_smem_bytes() : hevcdl_rd_smem_bytes_bd10();
-  if (p.migrate) { // workgroups that wait for each other: a cooperative launch, which the runtime only accepts when the whole grid can be resident at once
+  if (p.migrate || p.remote) { // workgroups that wait for each other: a cooperative launch, which the runtime only accepts when the whole grid can be resident at once
     void *args[] = { &p };
-    if (hipLaunchCooperativeKernel(kern, dim3(groups), dim3(threads), args, smem, s) != hipSuccess) { (void)hipGetLastError(); p.migrate = 0; }
+    if (hipLaunchCooperativeKernel(kern, dim3(p.remote ? ctx->remote_groups : groups), dim3(threads), args, smem, s) != hipSuccess) { (void)hipGetLastError(); p.migrate = 0; p.remote = 0; }
   }
-  if (!p.migrate) {
+  if (!p.migrate && !p.remote) {
     if (ctx->cfg.bit_depth == 8) hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), smem, s, p);
     else hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), smem, s, p);
   }

@@ -65,7 +65,8 @@ constexpr int NSLOT = 20;                                     // result slots of
 constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
 constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while it runs one of its own split tasks (spec_children)
 constexpr int LOG_AHEAD = 68, LOG_AHEAD_N = 17;               // entries 68..84: the master's context as the look-ahead candidates see it (ahead_open)
-constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_AHEAD + LOG_AHEAD_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
+constexpr int LOG_JOB = LOG_AHEAD + LOG_AHEAD_N, LOG_JOB_N = 1 + LOG_AHEAD_N;   // per pending second pass: its job block when another workgroup runs it (remote_post): header entry + context snapshot
+constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_JOB + NPEND * LOG_JOB_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
@@ -274,7 +275,7 @@ DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define CHECK_EXEC(id) do { } while (0)
 #endif
 // ---- regions: alternatives of the search handed to the waves of the workgroup (see the header comment) ----
-enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5, T_LUMA_AHEAD = 6 };
+enum { T_LUMA_P1 = 1, T_CHROMA = 2, T_LUMA_SPLIT = 3, T_LUMA_P2 = 4, T_RMD = 5, T_LUMA_AHEAD = 6, T_REMOTE = 7 };   // T_REMOTE: a second pass run by another workgroup (no ticket here; answered through HBM)
 enum { SLOT_CHROMA = 5, SLOT_SPLIT = 10, SLOT_P2 = 14, SLOT_PSET = 5 };   // result slots: 0..9 the first pass, 5..9 the chroma modes (after it); per second pass (set p = its region - 1, slots + 5 p): 10..13 its split tasks (by child), 14 its verdict + start state
 struct __attribute__((aligned(8))) Region {
   // ticket = (number of tasks << 16) | next task: ONE word, so that a claim (atomic add) returns a consistent pair -- a task index below
@@ -298,7 +299,8 @@ struct Tables {                        // read-only after kernel start, one copy
 };
 struct __attribute__((aligned(16))) WgShared {
   Region reg[NW][NREG];               // see NREG
-  int masters_active, pad_[3];                  // waves that currently walk a unit
+  int masters_active, quit, remote, pad_;       // waves that currently walk a unit; quit: a workgroup without units has seen the last unit finish; remote: hevcdl_rd_params.remote
+  GLB unsigned char *sched; unsigned long long pad2_;
   Tables tab;
 };
 DEV LDS WgShared &wg_shared() { return *(LDS WgShared *)(lds_base() + (size_t)NW * sizeof(RdSmem)); }
@@ -1820,7 +1822,15 @@ DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_)
 DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
 DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
-DEV void region_wait(LRegion &r, int n) { PROF_T0(); while (lds_load(&r.done) < n) __builtin_amdgcn_s_sleep(2); wg_acquire(); PROF_ADD(0, 33); }
+DEVN int remote_poll(LRegion &r);
+DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist);
+DEV void region_wait(LRegion &r, int n)
+{
+  PROF_T0();
+  while (lds_load(&r.done) < n) { if (uni(r.kind) == T_REMOTE) { if (!remote_poll(r)) __builtin_amdgcn_s_sleep(8); } else __builtin_amdgcn_s_sleep(2); }
+  wg_acquire();
+  PROF_ADD(0, 33);
+}
 DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()]; wsync(); }
 DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
 struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
@@ -2243,6 +2253,7 @@ DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_)
 // Join the oldest second pass left pending (compress_cu).  Verdict "nothing changes": its CU is final as the walk assumed (the pass itself has put the
 // first pass's reconstruction back into the picture).  The split won: everything coded since stands on the wrong reconstruction and coder state -> the
 // other pending pass is waited for (its slots and the picture must be quiet) and the CTU is walked again from the log (process_unit).
+DEV void copy_best_rec_to_pic(KR k, const Cu &cu, int comp);
 DEVN void pend_join_oldest(KR k, int site = 0)
 {
   PROF_T0();
@@ -2252,6 +2263,10 @@ DEVN void pend_join_oldest(KR k, int site = 0)
   region_wait(rp, 1);
   wsync();
   const int won = ub(rp.cost[0] < rp.cost[4]);
+  if (!won && uni(rp.kind) == T_REMOTE) { // another workgroup ran the pass: the first pass's samples are written back here, by the waves that will read them (remote_poll)
+    const Cu pc = { uni(rp.cu[0]), uni(rp.cu[1]), uni(rp.cu[2]), uni(rp.cu[3]), uni(rp.cu[4]), uni(rp.cu[5]), uni(rp.cu[6]) };
+    copy_best_rec_to_pic(k, pc, 0);
+  }
   if (won && n > 1) region_wait(my_region(uni(s.pend_reg[1])), 1);
   wsync();
   if (lane_id() == 0) {
@@ -2493,7 +2508,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       cabac_copy(k, &s.go, &s.curr[cu.depth]);
       const int memo = pu_log2 <= 5;
       if (memo && !(pu_log2 > min_tu_log2(cu))) break;              // no split possible: the pass cannot change anything
-      if (memo && npu == 1 && spare_waves()) {
+      if (memo && npu == 1 && (spare_waves() || lds_load(&wg_shared().remote))) {
         // Spare waves: the pass is handed to one of them and joined in check_rd_cost_intra, after the chroma search and the CU's syntax have
         // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time) -- or later still (compress_cu).  If the split
         // wins, what was built on the assumption is redone.
@@ -2503,7 +2518,8 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         wsync();
         if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.modes[1] = reg - 1; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = reg; }
         state_to_global(slot_state(k.slots, SLOT_P2 + SLOT_PSET * (reg - 1), 0), &s.curr[cu.depth]);
-        region_open(r2, T_LUMA_P2, 1, cu, ptu);
+        if (lds_load(&wg_shared().remote)) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist);    // a workgroup without a unit runs it (few units in the launch)
+        else region_open(r2, T_LUMA_P2, 1, cu, ptu);
         break;
       }
       PROF_MARK0();
@@ -3115,7 +3131,12 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         state_from_global(&s.next[DEPTH], lg + 2);
       } else {
         // a pending pass that has finished meanwhile is joined right away: a restart costs the less the earlier it is seen
-        while (uni(s.pend_n) && lds_load(&my_region(uni(s.pend_reg[0])).done) >= 1) { pend_join_oldest(k, 2); if (uni(s.restart)) return best; }
+        while (uni(s.pend_n)) {
+          LRegion &rp0 = my_region(uni(s.pend_reg[0]));
+          if (uni(rp0.kind) == T_REMOTE && lds_load(&rp0.done) < 1) remote_poll(rp0);
+          if (lds_load(&rp0.done) < 1) break;
+          pend_join_oldest(k, 2); if (uni(s.restart)) return best;
+        }
         const int carry_ok = NPEND > 0 && DEPTH >= 1 && DEPTH <= 2 && li != uni(s.nocarry_leaf) && lds_load(&wg_shared().masters_active) <= HEVCDL_CARRY_MAX;
         wsync();
         if (lane_id() == 0) s.carry_ok = carry_ok;
@@ -3225,6 +3246,114 @@ DEVN int glb_cas(GLB int *q, int expect, int desired)
   int ok = 0;
   if (lane_id() == 0) { int e = expect; ok = __hip_atomic_compare_exchange_strong(q, &e, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0; }
   return uni(ok);
+}
+
+
+// ---- second passes on a CU that has nothing to do ------------------------------------------------------------------------------------------------
+// A launch of few units (one frame, C2's ten, a GPU's share of a sharded job) leaves most CUs empty, while a frame is bound by the work of its own CU's eight
+// waves.  The deferred second pass of a PU is self-contained: start state, result slots, levels and reconstruction already live in HBM.  With
+// hevcdl_rd_params.remote the kernel is launched on ALL CUs (cooperatively: the workgroups wait for each other); a master POSTS the pass -- header + the context
+// a task takes over (kernel context, attribute arrays), an agent-scope release, a pointer in the ring at sched + 4096 -- and wave 0 of a workgroup without units
+// takes it, runs it as the chain owner of ITS workgroup (the split alternatives go to that workgroup's other waves: spec_children) and answers through the block.
+// Memory: the workgroups sit on different XCDs, whose L2s are not coherent with each other.  Poster: release before the pointer.  Taker: acquire before the
+// context is read, release before the answer.  Joiner: acquire behind the answer; an acquire drops clean lines only, and a 128-byte line of the picture can hold
+// samples of the pass's CU next to samples this XCD wrote meanwhile (dirty here, stale in the pass's part) -- so after a pass that changed nothing the joiner
+// writes the first pass's samples itself (what the pass restored: same values), and after one that chose the split it writes its own dirty lines back first
+// (release) and drops them (acquire): the next read comes from memory, where both parts are.
+DEV GLB unsigned long long *job_block(int pset) { return lds().my_log + (size_t)(LOG_JOB + LOG_JOB_N * pset) * (LEAF_LOG / 8); }
+DEV GLB int *rq_tail(GLB unsigned char *sched) { return (GLB int *)sched + 4; }
+DEV GLB int *rq_head(GLB unsigned char *sched) { return (GLB int *)sched + 8; }
+DEV GLB unsigned long long *rq_ring(GLB unsigned char *sched) { return (GLB unsigned long long *)(sched + 4096); }
+enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_CTX = 24 };   // int / 8-byte-word offsets in the block
+DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist)
+{
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int reg = uni(reg_), mode = uni(mode_), pset = reg - 1;
+  LSmem &s = lds(); LRegion &r = my_region(reg);
+  GLB unsigned long long *job = job_block(pset); GLB int *hi = (GLB int *)job;
+  static_assert(JOB_CTX * 8 <= LEAF_LOG && sizeof(K) + 11 * 256 <= LOG_AHEAD_N * LEAF_LOG, "job block");
+  wsync();
+  { GLB unsigned long long *d = job + JOB_CTX;
+    LDS const unsigned long long *qk = (LDS const unsigned long long *)&s.k, *qa = (LDS const unsigned long long *)&s.a[0][0];
+    for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = qk[i];
+    for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[sizeof(K) / 8 + i] = qa[i]; }
+  if (lane_id() == 0) {
+    hi[JOB_DONE] = 0; hi[JOB_MODE] = mode; hi[JOB_PSET] = pset; hi[JOB_MDIST] = (int)memo_dist; *(GLB double *)(hi + JOB_MCOST) = memo_cost;
+    hi[JOB_CU] = cu.x; hi[JOB_CU + 1] = cu.y; hi[JOB_CU + 2] = cu.log2; hi[JOB_CU + 3] = cu.depth; hi[JOB_CU + 4] = cu.zbase; hi[JOB_CU + 5] = cu.nparts; hi[JOB_CU + 6] = cu.part;
+    hi[JOB_TU] = tu.x; hi[JOB_TU + 1] = tu.y; hi[JOB_TU + 2] = tu.log2; hi[JOB_TU + 3] = tu.trd; hi[JOB_TU + 4] = tu.zrel; hi[JOB_TU + 5] = tu.nparts;
+    r.kind = T_REMOTE; r.owner = wave_id(); r.done = 0;               // no ticket: nobody in this workgroup claims it
+    r.cu[0] = cu.x; r.cu[1] = cu.y; r.cu[2] = cu.log2; r.cu[3] = cu.depth; r.cu[4] = cu.zbase; r.cu[5] = cu.nparts; r.cu[6] = cu.part;
+  }
+  wsync();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // the block, the start state in the slot, the picture around the CU: before the pointer
+  if (lane_id() == 0) {
+    GLB unsigned char *sched = wg_shared().sched;
+    const int i = __hip_atomic_fetch_add(rq_tail(sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rq_ring(sched) + (i & (RQ_SIZE - 1)), (unsigned long long)job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  wsync();
+}
+DEVN int remote_poll(LRegion &r)
+{ // the master asks for the answer of the pass it posted from region r: 1 when it is there (r.cost[0], r.dist[0], r.done as a local pass would leave them)
+  const int pset = uni(r.modes[1]);
+  GLB int *hi = (GLB int *)job_block(pset);
+  int d = 0;
+  if (lane_id() == 0) d = __hip_atomic_load(hi + JOB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!uni(d)) return 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const double cost = *(GLB const double *)(hi + JOB_COST); const int dist = hi[JOB_DIST];
+  wsync();
+  if (lane_id() == 0) { r.cost[0] = cost; r.dist[0] = (uint32_t)dist; }
+  wsync();
+  if (ub(r.cost[0] < r.cost[4])) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // see above
+  if (lane_id() == 0) r.done = 1;
+  wsync();
+  return 1;
+}
+// wave 0 of a workgroup without units: one posted pass, if there is one
+DEVN int remote_serve(GLB unsigned char *sched_)
+{
+  GLB unsigned char *sched = sched_;
+  LSmem &s = lds();
+  unsigned long long jv = 0;
+  if (lane_id() == 0) {
+    int h = __hip_atomic_load(rq_head(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load(rq_ring(sched) + (h & (RQ_SIZE - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v && __hip_atomic_compare_exchange_strong(rq_head(sched), &h, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      jv = v;                                                          // head == h when v was read non-zero: the entry of this lap
+      __hip_atomic_store(rq_ring(sched) + (h & (RQ_SIZE - 1)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  jv = uni64(jv);
+  if (!jv) return 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  GLB unsigned long long *job = (GLB unsigned long long *)jv; GLB int *hi = (GLB int *)job;
+  { // the poster's context (import_owner's part, from the block)
+    GLB const unsigned long long *q = job + JOB_CTX;
+    wsync();
+    { LDS unsigned long long *d = (LDS unsigned long long *)&s.k; for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = q[i]; }
+    { LDS unsigned long long *d = (LDS unsigned long long *)&s.a[0][0]; for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[i] = q[sizeof(K) / 8 + i]; }
+    wsync();
+    s.k.q_cost = s.my_qcost; s.k.q_rate = s.my_qrate; s.k.ovl = s.my_ovl;
+    if (lane_id() < 3) s.ref_key[lane_id()] = -1;
+    if (lane_id() == 0) s.fline_key = -1;
+    wsync();
+  }
+  LRegion &r = my_region(0);                                           // stands in for the poster's ticket region
+  if (lane_id() == 0) {
+    r.kind = T_LUMA_P2; r.owner = wave_id(); r.done = 0; r.ticket = 0;
+    for (int i = 0; i < 7; i++) r.cu[i] = hi[JOB_CU + i];
+    for (int i = 0; i < 6; i++) r.tu[i] = hi[JOB_TU + i];
+    r.modes[0] = hi[JOB_MODE]; r.modes[1] = hi[JOB_PSET]; r.dist[4] = (uint32_t)hi[JOB_MDIST]; r.cost[4] = *(GLB const double *)(hi + JOB_MCOST);
+  }
+  wsync();
+  run_task<false>(r, 0);
+  wsync();
+  if (lane_id() == 0) { hi[JOB_DIST] = (int)r.dist[0]; *(GLB double *)(hi + JOB_COST) = r.cost[0]; }
+  wsync();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // verdict, arrays, levels, samples: before the flag
+  if (lane_id() == 0) __hip_atomic_store(hi + JOB_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wsync();
+  return 1;
 }
 
 // -> 0: the unit is finished, 1: handed over to the next workgroup.  i_resume >= 0: continue a unit taken from this workgroup's mailbox.
@@ -3434,13 +3563,26 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       int l2 = 0, c2 = 0;
       for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
     }
-    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m; }
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m;
+                     sh.quit = 0; sh.remote = p.remote; sh.sched = (GLB unsigned char *)p.sched; }
   }
 #ifdef HEVCDL_KERNEL_PROF
   s.my_prof = (blockIdx.x == 0 && p.dbgbuf) ? (GLB unsigned long long *)(p.dbgbuf + 2) : nullptr; if (lane == 0) s.prof_task = 0;
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
+  if (p.remote && (int)blockIdx.x >= n_units) { // a workgroup without units: wave 0 takes second passes other workgroups post, the other waves serve its regions
+    for (;;) {
+      if (wave == 0) {
+        if (glb_load(sched_finished(p)) >= n_units) { wsync(); if (lane == 0) __hip_atomic_store(&sh.quit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        if (!remote_serve((GLB unsigned char *)p.sched)) __builtin_amdgcn_s_sleep(32);
+      } else {
+        if (lds_load(&sh.quit)) break;
+        if (!helper_step()) __builtin_amdgcn_s_sleep(32);
+      }
+    }
+    return;
+  }
   // a wave walks a unit (master) or serves the workgroup's regions (helper); with p.migrate units arrive and leave through the mailboxes
   int unit = first < n_units ? first : -1, i_resume = -1;
   for (;;) {
@@ -3451,6 +3593,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       int next = -1;
       if (!moved) {
         if (p.migrate) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); glb_add(sched_count(p, (int)blockIdx.x), -1); glb_add(sched_finished(p), 1); }
+        else if (p.remote) glb_add(sched_finished(p), 1);               // (every pass this unit posted has been joined)
         else if (unit + G * NW < n_units) next = unit + G * NW;        // more units than wave slots: the next one of this wave's list
       }
       unit = next; i_resume = -1;
