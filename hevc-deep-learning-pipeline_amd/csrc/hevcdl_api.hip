@@ -401,6 +401,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // Few units (one frame, ten, a GPU's share of a sharded job): a frame is bound by the work of its CU's eight waves while most CUs have nothing to do -> the
   // kernel runs on ALL CUs and the workgroups without a unit take the second luma passes the others post (rd_kernel.hip, remote_post / remote_serve)
   p.remote = (!p.migrate && ctx->remote_groups && 2 * n_units <= ctx->remote_groups && !d_cabac_in && !d_cabac_out && ctu_begin == 0 && p.ctu_end == ctx->ctus) ? 1 : 0;
+  if (p.remote && 16 * n_units <= ctx->remote_groups) p.remote = 2;    // very few units: enough idle workgroups for the chroma modes of every master as well
   if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 8192, s));      // finished counter, queue head / tail, the ring
   prof_begin(ctx, ctx->ev_rd, s);
   const void *kern = ctx->cfg.bit_depth == 8 ? (const void *)hevcdl_rd_frame_kernel : (const void *)hevcdl_rd_frame_kernel_bd10;

@@ -66,7 +66,8 @@ constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
 constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while it runs one of its own split tasks (spec_children)
 constexpr int LOG_AHEAD = 68, LOG_AHEAD_N = 17;               // entries 68..84: the master's context as the look-ahead candidates see it (ahead_open)
 constexpr int LOG_JOB = LOG_AHEAD + LOG_AHEAD_N, LOG_JOB_N = 1 + LOG_AHEAD_N;   // per pending second pass: its job block when another workgroup runs it (remote_post): header entry + context snapshot
-constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_JOB + NPEND * LOG_JOB_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
+constexpr int LOG_CJOB = LOG_JOB + NPEND * LOG_JOB_N, LOG_CJOB_N = 5 + LOG_AHEAD_N + 1;   // the five chroma modes of the CU under test as jobs for other workgroups: five headers, one context (+ the coder state they start from)
+constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_CJOB + LOG_CJOB_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
@@ -1823,11 +1824,13 @@ DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
 DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
 DEVN int remote_poll(LRegion &r);
+DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4);
+DEVN void chroma_collect(LRegion &r);
 DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist);
 DEV void region_wait(LRegion &r, int n)
 {
   PROF_T0();
-  while (lds_load(&r.done) < n) { if (uni(r.kind) == T_REMOTE) { if (!remote_poll(r)) __builtin_amdgcn_s_sleep(8); } else __builtin_amdgcn_s_sleep(2); }
+  while (lds_load(&r.done) < n) { if (uni(r.kind) == T_REMOTE) { if (!remote_poll(r)) __builtin_amdgcn_s_sleep(32); } else __builtin_amdgcn_s_sleep(2); }
   wg_acquire();
   PROF_ADD(0, 33);
 }
@@ -2208,7 +2211,7 @@ DEVN void rmd_satd(KR k, const Cu cu_, const Tu ptu_)
     LRegion &r = my_region();
     const int ntasks = nrounds < NW ? nrounds : NW;
     wsync();
-    if (lane_id() == 0) { r.modes[0] = dcv; r.modes[1] = nrounds; }
+    if (lane_id() == 0) { r.modes[0] = dcv; r.modes[1] = nrounds; r.modes[2] = 0; }
     region_open(r, T_RMD, ntasks, cu, ptu);
     region_run(k, r);
   } else rmd_rounds(k, s.satd, x, y, pn, dcv, 0, nrounds);
@@ -2235,9 +2238,9 @@ DEV bool next_leaf(KR k, const Cu &cu, int &nx, int &ny, int &nlog2)
 }
 // Rough-mode SATD sums of the PU at (x, y) ahead of time: they depend on the reconstruction around the PU only (final once the CU before it has its first
 // pass's winner: a pending second pass is read through best_rec), not on the coder state -- est_intra_luma adds the mode bits when it gets there.
-DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_)
+DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_, int sliced_ = 0)
 {
-  const int x = uni(x_), y = uni(y_), log2 = uni(log2_), pn = 1 << log2;
+  const int x = uni(x_), y = uni(y_), log2 = uni(log2_), pn = 1 << log2, sliced = uni(sliced_);
   LSmem &s = lds();
   build_refs(k, 0, x, y, pn, 1);
   filter_refs(k, pn);
@@ -2245,7 +2248,15 @@ DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_)
   const int dcv = dc_value(k, s.line, pn);
   wsync();
   const int nbx = pn / 8, nrounds = (35 * nbx * nbx + 63) >> 6;
-  rmd_rounds(k, s.satd_pre, x, y, pn, dcv, 0, nrounds);
+  if (sliced && nrounds >= HEVCDL_RMD_SLICE_ROUNDS) { // the workgroup's other waves are free (the caller's ticket region too): the rounds in slices, as rmd_satd deals them
+    LRegion &r = my_region();
+    const int ntasks = nrounds < NW ? nrounds : NW;
+    const Cu ncu = { x, y, log2, 6 - log2, 0, 1 << (2 * (log2 - 2)), SIZE_2Nx2N }; const Tu ptu = { x, y, log2, 0, 0, 1 << (2 * (log2 - 2)) };
+    wsync();
+    if (lane_id() == 0) { r.modes[0] = dcv; r.modes[1] = nrounds; r.modes[2] = 1; }      // [2]: the sums go to satd_pre
+    region_open(r, T_RMD, ntasks, ncu, ptu);
+    region_run(k, r);
+  } else rmd_rounds(k, s.satd_pre, x, y, pn, dcv, 0, nrounds);
   if (lane_id() == 0) s.pre_key = (log2 << 24) | (y << 12) | x;
   wsync();
 }
@@ -2683,7 +2694,10 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
   LSmem &ow = lds_of(uni(r.owner));
   const Cu cu = { uni(r.cu[0]), uni(r.cu[1]), uni(r.cu[2]), uni(r.cu[3]), uni(r.cu[4]), uni(r.cu[5]), uni(r.cu[6]) };
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
-  const int kind = uni(r.kind), mode = uni(r.modes[idx]);
+  const int kind = uni(r.kind);
+  // chroma modes by component (est_intra_chroma, workgroups with waves to spare): task idx = component (idx & 1) of mode idx >> 1; the two share the mode's slot
+  const bool csplit = kind == T_CHROMA && uni(r.pad_) == 1;
+  const int mode = uni(r.modes[csplit ? idx >> 1 : idx]);
   wsync();
   if (kind == T_RMD) { // a slice of the rough mode decision's rounds (rmd_satd): SATD sums into the owner's array, nothing else
     const int nrounds = uni(r.modes[1]), ntasks = nrounds < NW ? nrounds : NW, per = (nrounds + ntasks - 1) / ntasks;
@@ -2692,13 +2706,13 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
       for (int i = lane_id(); i < 66; i += 64) { ((LDS unsigned long long *)s.line)[i] = ((LDS const unsigned long long *)ow.line)[i]; ((LDS unsigned long long *)s.fline)[i] = ((LDS const unsigned long long *)ow.fline)[i]; }
       wsync();
     }
-    rmd_rounds(k, ow.satd, tu.x, tu.y, 1 << tu.log2, uni(r.modes[0]), idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
+    rmd_rounds(k, uni(r.modes[2]) ? ow.satd_pre : ow.satd, tu.x, tu.y, 1 << tu.log2, uni(r.modes[0]), idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
     return;
   }
   PROF_TASK(kind != T_LUMA_P2);
   PROF_MARK0();
   const int pset = kind == T_LUMA_P2 ? uni(r.modes[1]) : uni(kk.pset);    // slot set of the second pass: given with its ticket; a split task finds it in the chain owner's context
-  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + idx : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
+  const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + (csplit ? idx >> 1 : idx) : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
   const int olz = uni(kk.lz), olx = uni(kk.lx), oly = uni(kk.ly);          // the owner's own origin (it may run this task itself)
   const bool chroma_kind = kind == T_CHROMA;
@@ -2785,20 +2799,59 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
     }
     cabac_copy(k, &s.go, start);
     set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, mode); wsync();
-    uint32_t bits;
+    bool counted = true;
+    if (csplit) { // one component of the mode (a CU of one TU per component, no transform-skip trial: the single-TU branch of recur_chroma); the component that
+      // finishes second counts the mode's bits -- it finds the other one's levels in the slot they share and its flags in the slot's arrays
+      const int m = idx >> 1, comp = 1 + (idx & 1), other = 3 - comp;
+      GLB uint32_t *half = (GLB uint32_t *)(slot_state(kk.slots, slot, 1) + 32);        // behind the coder state: the two components' distortions
+      set_parts(k, s.a[A_TSKIP + comp], cu.zbase, cu.nparts, 0); wsync();
+      const uint32_t d = code_tu_block(k, cu, tu, comp, 0);
+      wsync();
+      for (int i = lane_id(); i < cu.nparts; i += 64) { at[(comp - 1) * 256 + i] = s.a[A_CBF + comp][cu.zbase + i]; at[(comp + 1) * 256 + i] = 0; }
+      if (lane_id() == 0) half[comp - 1] = d;
+      wsync();
+      wg_release();
+      int prev = 0;
+      if (lane_id() == 0) prev = __hip_atomic_fetch_add(&r.modes[5 + m], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      counted = uni(prev) == 1;
+      if (counted) {
+        wg_acquire();
+        wsync();
+        for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_CBF + other][cu.zbase + i] = at[(other - 1) * 256 + i]; s.a[A_TSKIP + other][cu.zbase + i] = 0; }
+        dist = uni((int)half[0]) + uni((int)half[1]);
+        wsync();
+      }
+    }
+    uint32_t bits = 0;
+    if (csplit) {
+      if (counted) {
+        cabac_copy(k, &s.go, start);
+        switch (cu.log2) { case 5: bits = intra_bits_qt<5>(k, cu, tu, 0, 1); break; default: bits = intra_bits_qt<4>(k, cu, tu, 0, 1); break; }
+      }
+    } else
     switch (cu.log2) {
       case 6: dist = recur_chroma<6>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<6>(k, cu, tu, 0, 1); break;
       case 5: dist = recur_chroma<5>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<5>(k, cu, tu, 0, 1); break;
       case 4: dist = recur_chroma<4>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<4>(k, cu, tu, 0, 1); break;
       default: dist = recur_chroma<3>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<3>(k, cu, tu, 0, 1); break;
     }
+    if (csplit) {
+      if (counted) { // the mode's answer, where est_intra_chroma looks for it: cost / fractional bits by mode, distortion behind the fractional bits
+        const int m = idx >> 1;
+        cost = calc_rd_cost(k, bits, dist);
+        wsync();
+        if (lane_id() == 0) { r.cost[m] = cost; r.cfrac[m] = s.cfrac_last_c; r.cfrac[5 + m] = (unsigned long long)dist; }
+        state_to_global(slot_state(kk.slots, slot, 1), &s.go);
+      }
+    } else {
     cost = calc_rd_cost(k, bits, dist);
     wsync();
     if (lane_id() == 0) r.cfrac[idx] = s.cfrac_last_c;
     state_to_global(slot_state(kk.slots, slot, 1), &s.go);
     for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { at[(c - 1) * 256 + i] = s.a[A_CBF + c][cu.zbase + i]; at[(c + 1) * 256 + i] = s.a[A_TSKIP + c][cu.zbase + i]; }
+    }
   }
-  if (lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
+  if (!csplit && lane_id() == 0) { r.cost[idx] = cost; r.dist[idx] = dist; }
   wsync();
   if (kind == T_LUMA_P1 || kind == T_LUMA_AHEAD) PROF_MARK(52);
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
@@ -2891,34 +2944,50 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   { // the five modes are independent (each starts from the [depth][CI_CURR_BEST] snapshot, TEncSearch.cpp:2640-2660) -> a region
     LRegion &r = my_region();
     wsync();
-    if (lane_id() == 0) for (int m = 0; m < 5; m++) r.modes[m] = (int)mode_list[m];
+    const bool rich = lds_load(&wg_shared().remote) != 0;    // waves to spare: the second passes run on other CUs
+    auto look_ahead = [&](int sliced) {
+      if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
+        // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
+        int nx, ny, nl;
+        if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
+          rmd_prefetch(k, nx, ny, nl, sliced);
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
+          if (lane_id() == 0) PROF_ACC_(18, (unsigned long long)((uni(s.lw_valid) ? 0 : 1) + (uni(s.a[A_TRIDX][cu.zbase]) == 0 ? 0 : 2) + (uni(s.ahead_open) ? 4 : 0) + (spare_waves() ? 0 : 8)) << 10);
+#endif
+          if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()
+              && lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX) ahead_open(k, cu, nx, ny, nl);
+        }
+      }
+    };
+    // The chain that bounds a frame once waves are plentiful is luma only: reconstruction of this CU -> rough modes of the next -> its candidates.  There the
+    // look-ahead runs FIRST, its SATD rounds dealt to the idle waves (this wave's ticket region is still free), and the chroma search of this CU follows.
+    // Launches of very few units: the five chroma modes go to other workgroups as well (posted first: they take longest to come back), this workgroup's waves
+    // have the candidates of the next CU
+    const bool cremote = lds_load(&wg_shared().remote) == 2;
+    if (cremote) chroma_post(k, cu, root, (int)mode_list[0], (int)mode_list[1], (int)mode_list[2], (int)mode_list[3], (int)mode_list[4]);
+    if (rich) look_ahead(1);
+    // with waves to spare the two components of a mode are tasks of their own
+    const bool csplit = rich && !cremote && cu.log2 >= 4 && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0;
+    PROF_MARK0();
+    if (cremote) { MT(8); chroma_collect(r); }
+    else {
+    if (lane_id() == 0) { for (int m = 0; m < 5; m++) { r.modes[m] = (int)mode_list[m]; r.modes[5 + m] = 0; } r.pad_ = csplit ? 1 : 0; }
     if (cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0) { // the five modes of an unsplit CU share their reference samples: gather them once, the tasks copy them
       const int nc = (1 << cu.log2) >> 1;
       build_refs(k, 1, cu.x >> 1, cu.y >> 1, nc, 1); build_refs(k, 2, cu.x >> 1, cu.y >> 1, nc, 1);
     }
-    PROF_MARK0();
     MT(8);
-    region_open(r, T_CHROMA, 5, cu, root);
-    if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
-      // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
-      int nx, ny, nl;
-      if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
-        rmd_prefetch(k, nx, ny, nl);
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
-        if (lane_id() == 0) PROF_ACC_(18, (unsigned long long)((uni(s.lw_valid) ? 0 : 1) + (uni(s.a[A_TRIDX][cu.zbase]) == 0 ? 0 : 2) + (uni(s.ahead_open) ? 4 : 0) + (spare_waves() ? 0 : 8)) << 10);
-#endif
-        if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()
-            && lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX) ahead_open(k, cu, nx, ny, nl);
-      }
+    region_open(r, T_CHROMA, csplit ? 10 : 5, cu, root);
+    if (!rich) look_ahead(0);
     }
     MT(18);
-    region_run(k, r);
+    if (!cremote) region_run(k, r);
     MT(35);
     PROF_MARK(39);
     int win = -1;
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
     if (win >= 0) {
-      best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
+      best_mode = (uint32_t)uni(r.modes[win]); best_dist = csplit ? (uint32_t)uni((int)(unsigned)r.cfrac[5 + win]) : (uint32_t)uni((int)r.dist[win]);
       if (lane_id() == 0) { s.cw_cfrac = r.cfrac[win]; s.cw_slot = SLOT_CHROMA + win; }
       GLB const uint8_t *at = slot_attr(k.slots, SLOT_CHROMA + win);
       wsync();
@@ -3261,10 +3330,19 @@ DEVN int glb_cas(GLB int *q, int expect, int desired)
 // writes the first pass's samples itself (what the pass restored: same values), and after one that chose the split it writes its own dirty lines back first
 // (release) and drops them (acquire): the next read comes from memory, where both parts are.
 DEV GLB unsigned long long *job_block(int pset) { return lds().my_log + (size_t)(LOG_JOB + LOG_JOB_N * pset) * (LEAF_LOG / 8); }
-DEV GLB int *rq_tail(GLB unsigned char *sched) { return (GLB int *)sched + 4; }
-DEV GLB int *rq_head(GLB unsigned char *sched) { return (GLB int *)sched + 8; }
+DEV GLB int *rq_tail(GLB unsigned char *sched) { return (GLB int *)(sched + 2048); }      // posters add here, takers there: lines of their own
+DEV GLB int *rq_head(GLB unsigned char *sched) { return (GLB int *)(sched + 2304); }
 DEV GLB unsigned long long *rq_ring(GLB unsigned char *sched) { return (GLB unsigned long long *)(sched + 4096); }
-enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_CTX = 24 };   // int / 8-byte-word offsets in the block
+enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_KIND = 22, JOB_IDX = 23,
+       JOB_CFRAC = 24, JOB_CTXP = 26,        // int offsets in the header (8-byte values at even offsets)
+       JOB_CTX = 24 };                        // 8-byte-word offset of a second pass's own context behind its header
+DEV GLB unsigned long long *cjob_block(int m) { return lds().my_log + (size_t)(LOG_CJOB + m) * (LEAF_LOG / 8); }
+DEV void job_push(GLB unsigned long long *job)
+{ // lane 0
+  GLB unsigned char *sched = wg_shared().sched;
+  const int i = __hip_atomic_fetch_add(rq_tail(sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(rq_ring(sched) + (i & (RQ_SIZE - 1)), (unsigned long long)job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist)
 {
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int reg = uni(reg_), mode = uni(mode_), pset = reg - 1;
@@ -3278,6 +3356,7 @@ DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, dou
     for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[sizeof(K) / 8 + i] = qa[i]; }
   if (lane_id() == 0) {
     hi[JOB_DONE] = 0; hi[JOB_MODE] = mode; hi[JOB_PSET] = pset; hi[JOB_MDIST] = (int)memo_dist; *(GLB double *)(hi + JOB_MCOST) = memo_cost;
+    hi[JOB_KIND] = T_LUMA_P2; hi[JOB_IDX] = 0; *(GLB unsigned long long *)(hi + JOB_CTXP) = (unsigned long long)(job + JOB_CTX);
     hi[JOB_CU] = cu.x; hi[JOB_CU + 1] = cu.y; hi[JOB_CU + 2] = cu.log2; hi[JOB_CU + 3] = cu.depth; hi[JOB_CU + 4] = cu.zbase; hi[JOB_CU + 5] = cu.nparts; hi[JOB_CU + 6] = cu.part;
     hi[JOB_TU] = tu.x; hi[JOB_TU + 1] = tu.y; hi[JOB_TU + 2] = tu.log2; hi[JOB_TU + 3] = tu.trd; hi[JOB_TU + 4] = tu.zrel; hi[JOB_TU + 5] = tu.nparts;
     r.kind = T_REMOTE; r.owner = wave_id(); r.done = 0;               // no ticket: nobody in this workgroup claims it
@@ -3285,10 +3364,48 @@ DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, dou
   }
   wsync();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // the block, the start state in the slot, the picture around the CU: before the pointer
-  if (lane_id() == 0) {
-    GLB unsigned char *sched = wg_shared().sched;
-    const int i = __hip_atomic_fetch_add(rq_tail(sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(rq_ring(sched) + (i & (RQ_SIZE - 1)), (unsigned long long)job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane_id() == 0) job_push(job);
+  wsync();
+}
+// The five chroma modes of a CU as jobs (launches of very few units: there are enough idle workgroups for every mode of every master).  A mode's trial levels and
+// reconstruction go to its result slot, never to the picture, so the only lines two XCDs write are slot lines -- the release below also writes back what this XCD
+// still holds dirty of them (first-pass candidates used slots 5..9 before), the acquire in chroma_collect drops the then clean copies.
+DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4)
+{
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
+  LSmem &s = lds();
+  GLB unsigned long long *ctx = cjob_block(5);
+  static_assert(sizeof(K) + 11 * 256 + sizeof(Cabac) <= (LOG_AHEAD_N + 1) * LEAF_LOG, "chroma job context");
+  wsync();
+  { LDS const unsigned long long *qk = (LDS const unsigned long long *)&s.k, *qa = (LDS const unsigned long long *)&s.a[0][0], *qs = (LDS const unsigned long long *)&s.curr[cu.depth];
+    for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) ctx[i] = qk[i];
+    for (int i = lane_id(); i < 11 * 256 / 8; i += 64) ctx[sizeof(K) / 8 + i] = qa[i];
+    if (lane_id() < 21) ctx[sizeof(K) / 8 + 11 * 256 / 8 + lane_id()] = qs[lane_id()]; }
+  if (lane_id() < 5) {
+    const int m = lane_id(), mode = m == 0 ? m0 : (m == 1 ? m1 : (m == 2 ? m2 : (m == 3 ? m3 : m4)));
+    GLB int *hi = (GLB int *)cjob_block(m);
+    hi[JOB_DONE] = 0; hi[JOB_MODE] = mode; hi[JOB_PSET] = 0; hi[JOB_KIND] = T_CHROMA; hi[JOB_IDX] = m; *(GLB unsigned long long *)(hi + JOB_CTXP) = (unsigned long long)ctx;
+    hi[JOB_CU] = cu.x; hi[JOB_CU + 1] = cu.y; hi[JOB_CU + 2] = cu.log2; hi[JOB_CU + 3] = cu.depth; hi[JOB_CU + 4] = cu.zbase; hi[JOB_CU + 5] = cu.nparts; hi[JOB_CU + 6] = cu.part;
+    hi[JOB_TU] = tu.x; hi[JOB_TU + 1] = tu.y; hi[JOB_TU + 2] = tu.log2; hi[JOB_TU + 3] = tu.trd; hi[JOB_TU + 4] = tu.zrel; hi[JOB_TU + 5] = tu.nparts;
+  }
+  wsync();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane_id() == 0) for (int m = 0; m < 5; m++) job_push(cjob_block(m));
+  wsync();
+}
+DEVN void chroma_collect(LRegion &r)
+{ // wait for the five answers; they go where the tasks of a local chroma region leave theirs
+  for (;;) {
+    int d = 1;
+    if (lane_id() < 5) d = __hip_atomic_load((GLB int *)cjob_block(lane_id()) + JOB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__ballot(d == 0) == 0ull) break;
+    __builtin_amdgcn_s_sleep(48);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  wsync();
+  if (lane_id() < 5) {
+    GLB const int *hi = (GLB const int *)cjob_block(lane_id());
+    r.modes[lane_id()] = hi[JOB_MODE]; r.dist[lane_id()] = (uint32_t)hi[JOB_DIST]; r.cost[lane_id()] = *(GLB const double *)(hi + JOB_COST); r.cfrac[lane_id()] = *(GLB const unsigned long long *)(hi + JOB_CFRAC);
   }
   wsync();
 }
@@ -3327,11 +3444,13 @@ DEVN int remote_serve(GLB unsigned char *sched_)
   if (!jv) return 0;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   GLB unsigned long long *job = (GLB unsigned long long *)jv; GLB int *hi = (GLB int *)job;
+  const int kind = uni(hi[JOB_KIND]), idx = uni(hi[JOB_IDX]), depth = uni(hi[JOB_CU + 3]);
   { // the poster's context (import_owner's part, from the block)
-    GLB const unsigned long long *q = job + JOB_CTX;
+    GLB const unsigned long long *q = (GLB const unsigned long long *)uni64(*(GLB const unsigned long long *)(hi + JOB_CTXP));
     wsync();
     { LDS unsigned long long *d = (LDS unsigned long long *)&s.k; for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = q[i]; }
     { LDS unsigned long long *d = (LDS unsigned long long *)&s.a[0][0]; for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[i] = q[sizeof(K) / 8 + i]; }
+    if (kind == T_CHROMA && lane_id() < 21) ((LDS unsigned long long *)&s.curr[depth])[lane_id()] = q[sizeof(K) / 8 + 11 * 256 / 8 + lane_id()];    // the snapshot the modes start from
     wsync();
     s.k.q_cost = s.my_qcost; s.k.q_rate = s.my_qrate; s.k.ovl = s.my_ovl;
     if (lane_id() < 3) s.ref_key[lane_id()] = -1;
@@ -3340,17 +3459,18 @@ DEVN int remote_serve(GLB unsigned char *sched_)
   }
   LRegion &r = my_region(0);                                           // stands in for the poster's ticket region
   if (lane_id() == 0) {
-    r.kind = T_LUMA_P2; r.owner = wave_id(); r.done = 0; r.ticket = 0;
+    r.kind = kind; r.owner = wave_id(); r.done = 0; r.ticket = 0; r.pad_ = 0;
     for (int i = 0; i < 7; i++) r.cu[i] = hi[JOB_CU + i];
     for (int i = 0; i < 6; i++) r.tu[i] = hi[JOB_TU + i];
-    r.modes[0] = hi[JOB_MODE]; r.modes[1] = hi[JOB_PSET]; r.dist[4] = (uint32_t)hi[JOB_MDIST]; r.cost[4] = *(GLB const double *)(hi + JOB_MCOST);
+    if (kind == T_LUMA_P2) { r.modes[0] = hi[JOB_MODE]; r.modes[1] = hi[JOB_PSET]; r.dist[4] = (uint32_t)hi[JOB_MDIST]; r.cost[4] = *(GLB const double *)(hi + JOB_MCOST); }
+    else r.modes[idx] = hi[JOB_MODE];
   }
   wsync();
-  run_task<false>(r, 0);
+  run_task<false>(r, idx);
   wsync();
-  if (lane_id() == 0) { hi[JOB_DIST] = (int)r.dist[0]; *(GLB double *)(hi + JOB_COST) = r.cost[0]; }
+  if (lane_id() == 0) { hi[JOB_DIST] = (int)r.dist[idx]; *(GLB double *)(hi + JOB_COST) = r.cost[idx]; *(GLB unsigned long long *)(hi + JOB_CFRAC) = r.cfrac[idx]; }
   wsync();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // verdict, arrays, levels, samples: before the flag
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // answer, arrays, levels, samples: before the flag
   if (lane_id() == 0) __hip_atomic_store(hi + JOB_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   wsync();
   return 1;
@@ -3575,7 +3695,9 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
     for (;;) {
       if (wave == 0) {
         if (glb_load(sched_finished(p)) >= n_units) { wsync(); if (lane == 0) __hip_atomic_store(&sh.quit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
-        if (!remote_serve((GLB unsigned char *)p.sched)) __builtin_amdgcn_s_sleep(32);
+        // a taker that found nothing waits ~7 us: with hundreds of idle workgroups somebody still looks every few tens of nanoseconds, and the queue's two words
+        // are not hammered while the posters need them
+        if (!remote_serve((GLB unsigned char *)p.sched)) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
       } else {
         if (lds_load(&sh.quit)) break;
         if (!helper_step()) __builtin_amdgcn_s_sleep(32);
