@@ -425,7 +425,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
       printf("DBGV %u %u\n", (unsigned)((v & 0xffffffffffull) >> 10), (unsigned)(v >> 40));
     }
 #else
-    for (unsigned i = 0; i < hb[0] && i < 4000; i++) printf("DBGV %u %u\n", hb[1 + 2 * i], hb[2 + 2 * i]);
+    for (unsigned i = 0; i < hb[0] && i < 3990; i++) printf("DBGV %u %u\n", hb[1 + 2 * i], hb[2 + 2 * i]);
 #endif
     fflush(stdout); hipFree(d_dbg);
   }

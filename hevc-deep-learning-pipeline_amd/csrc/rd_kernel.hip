@@ -269,6 +269,16 @@ DEV void wsync()
 #define PROF_TASK(v) do { } while (0)
 #endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// -DHEVCDL_TIMELINE (build with -DHEVCDL_KERNEL_DEBUG for the buffer): workgroup 0 logs (clock, wave, event, argument) while it codes CTUs [HEVCDL_TL_CTU0, +4) -- tools/timeline.py
+#ifdef HEVCDL_TIMELINE
+#ifndef HEVCDL_TL_CTU0
+#define HEVCDL_TL_CTU0 300
+#endif
+#define TL(ev, arg) do { if (lane_id() == 0 && blockIdx.x == 0) { GLB unsigned int *b_ = lds().k.dbgbuf; const int a_ = lds().k.addr; if (b_ && a_ >= HEVCDL_TL_CTU0 && a_ < HEVCDL_TL_CTU0 + 4) { \
+  const unsigned i_ = __hip_atomic_fetch_add(b_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (i_ < 3990) { b_[1 + 2 * i_] = (unsigned)__builtin_readcyclecounter(); b_[2 + 2 * i_] = ((unsigned)wave_id() << 24) | ((unsigned)(ev) << 16) | ((unsigned)(arg) & 0xffffu); } } } } while (0)
+#else
+#define TL(ev, arg) do { } while (0)
+#endif
 // -DHEVCDL_DBG_EXEC: trap (s99 = site) when a function that needs the whole wave is entered with lanes masked off; run under rocgdb
 #ifdef HEVCDL_DBG_EXEC
 #define CHECK_EXEC(id) do { if (__builtin_amdgcn_read_exec() != ~0ull) { asm volatile("s_mov_b32 s99, %0\n s_trap 2" :: "i"(id) : "s99"); } } while (0)
@@ -438,7 +448,7 @@ DEV void stage_line(KR k, int kind, int a, unsigned b, unsigned c, double cost, 
 #endif
 DEV double calc_rd_cost(KR k, uint32_t bits, uint32_t dist)
 { // TComRdCost.cpp:62-107
-#ifdef HEVCDL_KERNEL_DEBUG
+#if defined(HEVCDL_KERNEL_DEBUG) && !defined(HEVCDL_TIMELINE)
   if (k.dbgbuf && lane_id() == 0) { unsigned int n_ = k.dbgbuf[0]; if (n_ < 100000) { k.dbgbuf[1 + 2 * n_] = bits; k.dbgbuf[2 + 2 * n_] = dist; k.dbgbuf[0] = n_ + 1; } }
 #endif
   return (double)dist + ((double)bits * k.lambda);
@@ -2242,12 +2252,22 @@ DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_, int sliced_ = 0)
 {
   const int x = uni(x_), y = uni(y_), log2 = uni(log2_), pn = 1 << log2, sliced = uni(sliced_);
   LSmem &s = lds();
+  const int nbx = pn / 8, nrounds = (35 * nbx * nbx + 63) >> 6;
+  if (sliced == 2 && nrounds >= HEVCDL_RMD_SLICE_ROUNDS) { // open only: every slice gathers the PU's reference lines itself (rmd_prefetch_end gathers this wave's)
+    LRegion &r = my_region();
+    const int ntasks = nrounds < NW ? nrounds : NW;
+    const Cu ncu = { x, y, log2, 6 - log2, 0, 1 << (2 * (log2 - 2)), SIZE_2Nx2N }; const Tu ptu = { x, y, log2, 0, 0, 1 << (2 * (log2 - 2)) };
+    wsync();
+    if (lane_id() < 36) s.satd_pre[NPEND == 2 ? lane_id() : 0] = 0;
+    if (lane_id() == 0) { r.modes[0] = 0; r.modes[1] = nrounds; r.modes[2] = 2; s.pre_key = -1; }
+    region_open(r, T_RMD, ntasks, ncu, ptu);
+    return;
+  }
   build_refs(k, 0, x, y, pn, 1);
   filter_refs(k, pn);
   if (lane_id() < 36) s.satd_pre[NPEND == 2 ? lane_id() : 0] = 0;
   const int dcv = dc_value(k, s.line, pn);
   wsync();
-  const int nbx = pn / 8, nrounds = (35 * nbx * nbx + 63) >> 6;
   if (sliced && nrounds >= HEVCDL_RMD_SLICE_ROUNDS) { // the workgroup's other waves are free (the caller's ticket region too): the rounds in slices, as rmd_satd deals them
     LRegion &r = my_region();
     const int ntasks = nrounds < NW ? nrounds : NW;
@@ -2257,6 +2277,19 @@ DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_, int sliced_ = 0)
     region_open(r, T_RMD, ntasks, ncu, ptu);
     region_run(k, r);
   } else rmd_rounds(k, s.satd_pre, x, y, pn, dcv, 0, nrounds);
+  if (lane_id() == 0) s.pre_key = (log2 << 24) | (y << 12) | x;
+  wsync();
+}
+DEVN void rmd_prefetch_end(KR k, int x_, int y_, int log2_)
+{ // behind rmd_prefetch(..., 2): this wave takes what slices are left and waits for the others (no-op when the rounds were not sliced: the key is set)
+  const int x = uni(x_), y = uni(y_), log2 = uni(log2_);
+  LSmem &s = lds();
+  if (uni(s.pre_key) == ((log2 << 24) | (y << 12) | x)) return;
+  build_refs(k, 0, x, y, 1 << log2, 1);                    // this wave's own lines: the candidates coded ahead copy them, est_intra_luma finds them in place
+  filter_refs(k, 1 << log2);
+  region_run(k, my_region());
+  build_refs(k, 0, x, y, 1 << log2, 0);                    // (a slice run by this wave has gathered them again: same lines; nothing to do when the key matches)
+  filter_refs(k, 1 << log2);
   if (lane_id() == 0) s.pre_key = (log2 << 24) | (y << 12) | x;
   wsync();
 }
@@ -2412,6 +2445,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
   const int pu_log2 = cu.log2 - init_trd, pn = 1 << pu_log2, pu_parts = cu.nparts >> (2 * init_trd);
   uint32_t overall = 0;
   MT0();
+  TL(1, cu.zbase);
   for (int pu = 0; pu < npu; pu++) {
     const int poff = pu * pu_parts, zp = cu.zbase + poff;
     const Tu ptu = { cu.x + (pu & 1) * pn * init_trd, cu.y + (pu >> 1) * pn * init_trd, pu_log2, init_trd, poff, pu_parts };
@@ -2463,6 +2497,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       LRegion &r = use_ahead ? my_region(REG_AHEAD) : my_region();
       wsync();
       MT(4);
+      TL(2, use_ahead ? uni(s.ahead_claimed) : 0);
       PROF_MARK0();
       if (use_ahead) {
         const int n_s = uni(s.ahead_n), c = uni(s.ahead_claimed);
@@ -2487,6 +2522,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       }
       PROF_MARK(36);
       MT(34);
+      TL(3, nfull);
 #ifdef HEVCDL_STAGE_TRACE
       { const bool on = lane_id() < nfull; stage_line(k, 1, on ? r.modes[lane_id()] : 0, 0u, 0u, on ? r.cost[lane_id()] : 0.0, on); }   // "2nd pass" lines, :2395-2397
 #endif
@@ -2566,6 +2602,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
   }
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
   MT(5);
+  TL(4, 0);
   PROF_ADD(k, 16);
   return overall;
 }
@@ -2695,18 +2732,27 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
   const Cu cu = { uni(r.cu[0]), uni(r.cu[1]), uni(r.cu[2]), uni(r.cu[3]), uni(r.cu[4]), uni(r.cu[5]), uni(r.cu[6]) };
   const Tu tu = { uni(r.tu[0]), uni(r.tu[1]), uni(r.tu[2]), uni(r.tu[3]), uni(r.tu[4]), uni(r.tu[5]) };
   const int kind = uni(r.kind);
+  TL(20 + kind, idx);
   // chroma modes by component (est_intra_chroma, workgroups with waves to spare): task idx = component (idx & 1) of mode idx >> 1; the two share the mode's slot
   const bool csplit = kind == T_CHROMA && uni(r.pad_) == 1;
   const int mode = uni(r.modes[csplit ? idx >> 1 : idx]);
   wsync();
   if (kind == T_RMD) { // a slice of the rough mode decision's rounds (rmd_satd): SATD sums into the owner's array, nothing else
     const int nrounds = uni(r.modes[1]), ntasks = nrounds < NW ? nrounds : NW, per = (nrounds + ntasks - 1) / ntasks;
-    if (&s != &ow) { // the owner's gathered / smoothed reference lines
+    int dcv = uni(r.modes[0]);
+    if (uni(r.modes[2]) == 2) { // the slice gathers the lines itself (the owner is busy posting)
+      build_refs(k, 0, tu.x, tu.y, 1 << tu.log2, 1);
+      filter_refs(k, 1 << tu.log2);
+      dcv = dc_value(k, s.line, 1 << tu.log2);
+      wsync();
+    } else if (&s != &ow) { // the owner's gathered / smoothed reference lines
       wsync();
       for (int i = lane_id(); i < 66; i += 64) { ((LDS unsigned long long *)s.line)[i] = ((LDS const unsigned long long *)ow.line)[i]; ((LDS unsigned long long *)s.fline)[i] = ((LDS const unsigned long long *)ow.fline)[i]; }
       wsync();
     }
-    rmd_rounds(k, uni(r.modes[2]) ? ow.satd_pre : ow.satd, tu.x, tu.y, 1 << tu.log2, uni(r.modes[0]), idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
+    TL(19, idx);
+    rmd_rounds(k, uni(r.modes[2]) ? ow.satd_pre : ow.satd, tu.x, tu.y, 1 << tu.log2, dcv, idx * per, (idx + 1) * per < nrounds ? (idx + 1) * per : nrounds);
+    TL(40 + T_RMD, idx);
     return;
   }
   PROF_TASK(kind != T_LUMA_P2);
@@ -2857,6 +2903,7 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
   kk.coef_l = s.my_coef; kk.rec_l = s.my_rec; kk.in_task = 0;
   kk.lz = olz; kk.lx = olx; kk.ly = oly;
   wsync();
+  TL(40 + kind, idx);
   PROF_TASK(0);
 #ifdef HEVCDL_KERNEL_PROF
   { if (kind == T_LUMA_P1 || kind == T_LUMA_AHEAD) PROF_ADD(k, 40); else if (kind == T_CHROMA) PROF_ADD(k, 41); else if (kind == T_LUMA_SPLIT) PROF_ADD(k, 42); else PROF_ADD(k, 43); }
@@ -2935,6 +2982,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
   uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
   MT0();
+  TL(5, cu.zbase);
   wsync();
   if (lane_id() < 2) s.ref_key[1 + lane_id()] = -1;
   wsync();
@@ -2951,6 +2999,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
         int nx, ny, nl;
         if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
           rmd_prefetch(k, nx, ny, nl, sliced);
+          TL(7, 0);
 #if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
           if (lane_id() == 0) PROF_ACC_(18, (unsigned long long)((uni(s.lw_valid) ? 0 : 1) + (uni(s.a[A_TRIDX][cu.zbase]) == 0 ? 0 : 2) + (uni(s.ahead_open) ? 4 : 0) + (spare_waves() ? 0 : 8)) << 10);
 #endif
@@ -2964,8 +3013,18 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     // Launches of very few units: the five chroma modes go to other workgroups as well (posted first: they take longest to come back), this workgroup's waves
     // have the candidates of the next CU
     const bool cremote = lds_load(&wg_shared().remote) == 2;
-    if (cremote) chroma_post(k, cu, root, (int)mode_list[0], (int)mode_list[1], (int)mode_list[2], (int)mode_list[3], (int)mode_list[4]);
-    if (rich) look_ahead(1);
+    int anx = 0, any = 0, anl = 0;
+    const bool la = rich && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX && next_leaf(k, cu, anx, any, anl) && anl >= 4 && anl <= 5;
+    if (la) rmd_prefetch(k, anx, any, anl, 2);               // reference lines of the next PU, its SATD rounds handed to the idle waves ...
+    if (cremote) chroma_post(k, cu, root, (int)mode_list[0], (int)mode_list[1], (int)mode_list[2], (int)mode_list[3], (int)mode_list[4]);   // ... while the chroma modes are posted
+    TL(6, 0);
+    if (la) {
+      rmd_prefetch_end(k, anx, any, anl);
+      TL(7, 0);
+      if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()
+          && lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX) ahead_open(k, cu, anx, any, anl);
+    }
+    TL(8, uni(s.ahead_open));
     // with waves to spare the two components of a mode are tasks of their own
     const bool csplit = rich && !cremote && cu.log2 >= 4 && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0;
     PROF_MARK0();
@@ -2983,6 +3042,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     MT(18);
     if (!cremote) region_run(k, r);
     MT(35);
+    TL(9, 0);
     PROF_MARK(39);
     int win = -1;
     for (int m = 0; m < 5; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
@@ -3002,6 +3062,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
   MT(19);
+  TL(10, 0);
   PROF_ADD(k, 17);
   return best_dist;
 }
@@ -3103,6 +3164,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
     cabac_copy(k, &s.temp[cu.depth], &s.go);
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
     MT(22);
+    TL(11, 0);
     if (!pending) break;
     if (uni(s.carry_ok)) { // the walk goes on while this pass is still running (compress_cu); until it is joined this CU's luma in the picture belongs to
       // the pass, the search reads best_rec instead
@@ -3222,6 +3284,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         wsync();
         if (lane_id() == 0) { lg[0] = (unsigned long long)__double_as_longlong(best.cost); lg[1] = (unsigned long long)best.bits | ((unsigned long long)best.dist << 32); }
         state_to_global(lg + 2, &s.next[DEPTH]);
+        TL(12, 0);
       }
     } else { best.cost = MAX_DOUBLE / 16; best.dist = 0xffffffffu >> 3; best.bits = 0xffffffffu >> 3; }
     // split flag of the unsplit candidate (:858-867); for the dummy candidate the loaded state is stale and irrelevant
