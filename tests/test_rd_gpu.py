@@ -234,6 +234,31 @@ def test_chunked_hand_over_equals_the_whole_batch_call(chunk, sao):
             assert np.array_equal(st[k], stats[k][first:first + n]), k
 
 
+@pytest.mark.parametrize("nf,tiles", [(1, (1, 1)), (6, (1, 1)), (20, (1, 1)), (3, (2, 2))])
+def test_few_units_form_equals_the_independent_form(nf, tiles):
+    """A launch of at most half as many units as CUs runs on ALL CUs: the workgroups without a unit take the second luma passes (and, with very few
+    units, the chroma modes) the others post through HBM.  It must give, byte for byte, what the independent form gives (exec_flags
+    HEVCDL_EXEC_NO_UNIT_HANDOVER: one workgroup per unit, nothing crosses workgroups) -- records, reconstruction and statistics."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp = 512, 320, 30
+    base = ref_tools.synth_yuv(w, h, 4, 123)
+    rng = np.random.default_rng(9)
+    yuv = np.stack([np.clip(base[i % 4].astype(np.int16) + rng.integers(-3, 4, base.shape[1]) * (i // 4), 0, 255).astype(np.uint8) for i in range(nf)])
+    out = []
+    for flags in (0, 1):
+        cfg = hevcdl_amd.default_config(w, h, qp, max_frames=nf, tiles=tiles)
+        cfg.exec_flags = flags
+        enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
+        labels = enc.predict_depth(yuv)
+        out.append(enc.compress_frames(yuv, labels))
+        enc.close()
+    assert_records_equal(out[0][0], out[1][0], "few-units form vs independent form")
+    assert np.array_equal(out[0][1], out[1][1])
+    for k in ("sse", "est_bits", "ctus"):
+        assert np.array_equal(out[0][2][k], out[1][2][k]), k
+
+
 def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built):
     """600 frames on 256 workgroups do not divide evenly: the surplus frames travel round the ring of workgroups (a frame is handed over at a CTU
     boundary: position + coder state).  The launch that migrates must give, frame by frame, what launches without migration give (<= one frame
