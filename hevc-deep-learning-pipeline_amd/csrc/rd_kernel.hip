@@ -211,7 +211,7 @@ struct __attribute__((aligned(16))) RdSmem {
   // winners of the CU under test, for the short form of its syntax count (enc_cu_syntax_fast): coefficient bits of the luma / chroma winner, its slot
   unsigned long long lw_cfrac, cw_cfrac; int lw_valid, cw_slot;
   // SATD sums of the NEXT CU's rough mode decision, computed by the master while the workgroup's other waves run this CU's chroma search (rmd_prefetch)
-  unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pad_pre;
+  unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pre_open;      // pre_open: key of the PU whose SATD slices are open in this wave's ticket region (0: none)
   // Second passes left running behind the master (compress_cu): carry_ok: the CU being coded may leave its pass pending; pend_*: the passes pending, oldest
   // first (index of their CU among the CTU's coded CUs, region of their ticket); restart: a pending pass chose the split -> the CTU is walked again, CUs
   // [0, replay_upto) from the log, CU nocarry_leaf with the result that pass reached (its luma is not searched again)
@@ -2564,6 +2564,20 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         LRegion &r2 = my_region(reg);
         wsync();
         if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.modes[1] = reg - 1; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = reg; }
+        if (lds_load(&wg_shared().remote) && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) {
+          // The chain that bounds a frame in this form is luma only: this CU's winner -> rough modes of the next PU -> its candidates.  The winner's samples
+          // are in best_rec now: mark the CU as the pending pass's (readers take best_rec; check_rd_cost_intra writes the same word again) and hand the SATD
+          // rounds of the next PU to the idle waves BEFORE the pass and the chroma modes are posted (est_intra_chroma collects them)
+          int nx, ny, nl;
+          if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
+            wsync();
+            if (lane_id() == 0) s.k.srect[reg - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
+            wsync();
+            rmd_prefetch(k, nx, ny, nl, 2);
+            if (lane_id() == 0) s.pre_open = (nl << 24) | (ny << 12) | nx;
+            wsync();
+          }
+        }
         state_to_global(slot_state(k.slots, SLOT_P2 + SLOT_PSET * (reg - 1), 0), &s.curr[cu.depth]);
         if (lds_load(&wg_shared().remote)) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist);    // a workgroup without a unit runs it (few units in the launch)
         else region_open(r2, T_LUMA_P2, 1, cu, ptu);
@@ -3015,11 +3029,13 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     const bool cremote = lds_load(&wg_shared().remote) == 2;
     int anx = 0, any = 0, anl = 0;
     const bool la = rich && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX && next_leaf(k, cu, anx, any, anl) && anl >= 4 && anl <= 5;
-    if (la) rmd_prefetch(k, anx, any, anl, 2);               // reference lines of the next PU, its SATD rounds handed to the idle waves ...
+    if (uni(s.pre_open) && (!la || uni(s.pre_open) != ((anl << 24) | (any << 12) | anx))) { region_run(k, r); if (lane_id() == 0) s.pre_open = 0; wsync(); }   // (slices opened for another PU: cannot happen by construction)
+    if (la && !uni(s.pre_open)) rmd_prefetch(k, anx, any, anl, 2);               // reference lines of the next PU, its SATD rounds handed to the idle waves (est_intra_luma may have done it already) ...
     if (cremote) chroma_post(k, cu, root, (int)mode_list[0], (int)mode_list[1], (int)mode_list[2], (int)mode_list[3], (int)mode_list[4]);   // ... while the chroma modes are posted
     TL(6, 0);
     if (la) {
       rmd_prefetch_end(k, anx, any, anl);
+      if (lane_id() == 0) s.pre_open = 0;
       TL(7, 0);
       if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()
           && lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX) ahead_open(k, cu, anx, any, anl);
@@ -3625,7 +3641,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.ahead_open = 0; s.ahead_key = -1; }
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; }
     wsync();
     PROF_MARK(47);
     Rd best;
@@ -3650,6 +3666,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
 #endif
       if (lane < 3) s.ref_key[lane] = -1;
       ahead_drain();
+      if (uni(s.pre_open)) { region_run(k, my_region()); if (lane == 0) s.pre_open = 0; wsync(); }      // SATD slices still out
       if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; }
       wsync();
       cabac_copy(k, &s.curr[0], truec);
