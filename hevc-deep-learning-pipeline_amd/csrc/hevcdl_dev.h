@@ -60,7 +60,7 @@ struct hevcdl_rd_params {
   unsigned int *dbgbuf;
   unsigned char *sched;            // hand-over of units between workgroups: [0] finished units, [16 + g] units walked by workgroup g, +8192: one mailbox per workgroup
   int migrate;                     // 1: units travel round the ring of workgroups (uneven dealing)
-  int remote;                      // 1: fewer units than half the workgroups: the workgroups without a unit run second luma passes posted by the others (queue at sched + 4096)
+  int remote;                      // fewer units than workgroups: the workgroups without a unit run second luma passes posted by the others (queue at sched + 4096); 2: the chroma modes too (very few units); 3: passes only while a taker is free (more units than takers)
   const unsigned char *cabac_in;   // [frame] 168-byte coder state to start from, or NULL: slice-start state (only with ctu_begin == 0)
   unsigned char *cabac_out;        // [frame] coder state after the last CTU processed, or NULL
   int ctu_begin, ctu_end;          // CTU address range [begin, end) in coding order

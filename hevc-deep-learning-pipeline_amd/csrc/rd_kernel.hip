@@ -1834,6 +1834,7 @@ DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
 DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
 DEVN int remote_poll(LRegion &r);
+DEVN int remote_room();
 DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4);
 DEVN void chroma_collect(LRegion &r);
 DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist);
@@ -2579,7 +2580,8 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           }
         }
         state_to_global(slot_state(k.slots, SLOT_P2 + SLOT_PSET * (reg - 1), 0), &s.curr[cu.depth]);
-        if (lds_load(&wg_shared().remote)) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist);    // a workgroup without a unit runs it (few units in the launch)
+        const int rm = lds_load(&wg_shared().remote);
+        if (rm && (rm != 3 || remote_room())) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist);    // a workgroup without a unit runs it (few units in the launch)
         else region_open(r2, T_LUMA_P2, 1, cu, ptu);
         break;
       }
@@ -3412,6 +3414,20 @@ DEV GLB unsigned long long *job_block(int pset) { return lds().my_log + (size_t)
 DEV GLB int *rq_tail(GLB unsigned char *sched) { return (GLB int *)(sched + 2048); }      // posters add here, takers there: lines of their own
 DEV GLB int *rq_head(GLB unsigned char *sched) { return (GLB int *)(sched + 2304); }
 DEV GLB unsigned long long *rq_ring(GLB unsigned char *sched) { return (GLB unsigned long long *)(sched + 4096); }
+DEV GLB int *rq_idle(GLB unsigned char *sched) { return (GLB int *)(sched + 2560); }     // takers that are not running a job
+// hevcdl_rd_params.remote == 3 (more units than takers): a pass is posted only while some taker has nothing to do and nothing waits in the ring; otherwise it
+// stays in its own workgroup, as in a launch without takers
+DEVN int remote_room()
+{
+  int ok = 0;
+  if (lane_id() == 0) {
+    GLB unsigned char *sched = wg_shared().sched;
+    const int idle = __hip_atomic_load(rq_idle(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int tail = __hip_atomic_load(rq_tail(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), head = __hip_atomic_load(rq_head(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = idle - (tail - head) > 0;
+  }
+  return uni(ok);
+}
 enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_KIND = 22, JOB_IDX = 23,
        JOB_CFRAC = 24, JOB_CTXP = 26,        // int offsets in the header (8-byte values at even offsets)
        JOB_CTX = 24 };                        // 8-byte-word offset of a second pass's own context behind its header
@@ -3521,6 +3537,7 @@ DEVN int remote_serve(GLB unsigned char *sched_)
   }
   jv = uni64(jv);
   if (!jv) return 0;
+  if (lane_id() == 0) __hip_atomic_fetch_add(rq_idle(sched), -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   GLB unsigned long long *job = (GLB unsigned long long *)jv; GLB int *hi = (GLB int *)job;
   const int kind = uni(hi[JOB_KIND]), idx = uni(hi[JOB_IDX]), depth = uni(hi[JOB_CU + 3]);
@@ -3550,7 +3567,7 @@ DEVN int remote_serve(GLB unsigned char *sched_)
   if (lane_id() == 0) { hi[JOB_DIST] = (int)r.dist[idx]; *(GLB double *)(hi + JOB_COST) = r.cost[idx]; *(GLB unsigned long long *)(hi + JOB_CFRAC) = r.cfrac[idx]; }
   wsync();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // answer, arrays, levels, samples: before the flag
-  if (lane_id() == 0) __hip_atomic_store(hi + JOB_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane_id() == 0) { __hip_atomic_store(hi + JOB_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(rq_idle(sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   wsync();
   return 1;
 }
@@ -3772,6 +3789,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 #endif
   __syncthreads();
   if (p.remote && (int)blockIdx.x >= n_units) { // a workgroup without units: wave 0 takes second passes other workgroups post, the other waves serve its regions
+    if (wave == 0 && lane == 0) __hip_atomic_fetch_add(rq_idle((GLB unsigned char *)p.sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
       if (wave == 0) {
         if (glb_load(sched_finished(p)) >= n_units) { wsync(); if (lane == 0) __hip_atomic_store(&sh.quit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }

@@ -234,10 +234,10 @@ def test_chunked_hand_over_equals_the_whole_batch_call(chunk, sao):
             assert np.array_equal(st[k], stats[k][first:first + n]), k
 
 
-@pytest.mark.parametrize("nf,tiles", [(1, (1, 1)), (6, (1, 1)), (20, (1, 1)), (3, (2, 2))])
+@pytest.mark.parametrize("nf,tiles", [(1, (1, 1)), (6, (1, 1)), (20, (1, 1)), (150, (1, 1)), (3, (2, 2))])
 def test_few_units_form_equals_the_independent_form(nf, tiles):
-    """A launch of at most half as many units as CUs runs on ALL CUs: the workgroups without a unit take the second luma passes (and, with very few
-    units, the chroma modes) the others post through HBM.  It must give, byte for byte, what the independent form gives (exec_flags
+    """A launch of at most two thirds as many units as CUs runs on ALL CUs: the workgroups without a unit take the second luma passes (with very few
+    units also the chroma modes; with more units than takers only while a taker is free: the 150-frame case) the others post through HBM.  It must give, byte for byte, what the independent form gives (exec_flags
     HEVCDL_EXEC_NO_UNIT_HANDOVER: one workgroup per unit, nothing crosses workgroups) -- records, reconstruction and statistics."""
     import hevcdl_amd
     import ref_tools

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 txt = open(os.path.join(ROOT, "gpurun_out", "prof", tag + "_summary.txt")).read()
 vals = {}
 for m in re.finditer(r"hevcdl_rd_frame_kernel[^|]*\| (FETCH_SIZE|WRITE_SIZE) = ([\d.eE+]+)", txt):
