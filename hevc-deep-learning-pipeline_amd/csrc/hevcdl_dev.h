@@ -121,7 +121,7 @@ static inline int hevcdl_tile_bounds(int n_ctus, int n_tiles, int uniform, const
 //     inside the picture whose first label is 0 is one 64x64 CU and the other 15 labels are never read (use_model.py:101-119 does emit such sets:
 //     they stay as they are); otherwise every 32x32 quadrant inside the picture is visited -- a first label of 0 becomes 1 -- and where a
 //     quadrant is split (first label >= 2, or the picture edge forces it) each of its cells inside the picture is read and raised to 2.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline void hevcdl_clamp_ctu_labels(uint8_t *lab, int x0, int y0, int width, int height)

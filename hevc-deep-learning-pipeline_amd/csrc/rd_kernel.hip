@@ -183,6 +183,7 @@ struct __attribute__((aligned(16))) RdSmem {
   K k;
   // the executing wave's own scratch (K is copied from the master when a helper runs one of its tasks; these are not)
   GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save; GLB unsigned char *my_slots; GLB unsigned long long *my_log;
+  int bound_reg, bound_child;          // a T_LUMA_SPLIT task under way: the chain owner's wave (its region [1] holds the chain's answers) and the child it is the split alternative of (recur_luma's early exit); -1: none
   int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task (value: the region that holds its ticket); joined in check_rd_cost_intra or left pending
   Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
   uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
@@ -206,6 +207,7 @@ struct __attribute__((aligned(16))) RdSmem {
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
   unsigned int red_u32;
   unsigned long long est_bits, sse_acc[3];
+  unsigned long long ctu_frac;        // fractional bits of the CU syntax of the CTU's coded CUs so far (compress_cu; advance_state)
   unsigned long long cfrac_last;      // coefficient part of the last intra_bits_qt count (fractional bits): luma
   unsigned long long cfrac_last_c;    // ... chroma (both components)
   // winners of the CU under test, for the short form of its syntax count (enc_cu_syntax_fast): coefficient bits of the luma / chroma winner, its slot
@@ -894,6 +896,18 @@ DEV double rl_d(double v, int l)
 #else
 #define RDOQ_MARK(id) do { } while (0)
 #endif
+#ifdef HEVCDL_RDOQ_STOP
+#define RDOQ_STOP(id) do { if (HEVCDL_RDOQ_STOP == (id)) return 0; } while (0)
+#define RDOQ_SKIP(id) if (HEVCDL_RDOQ_STOP == (id)) { cgpos -= R; continue; }
+#else
+#define RDOQ_STOP(id) do { } while (0)
+#define RDOQ_SKIP(id)
+#endif
+#ifdef HEVCDL_RDOQ_STOP
+#define HEVCDL_RDOQ_STOPV HEVCDL_RDOQ_STOP
+#else
+#define HEVCDL_RDOQ_STOPV 0
+#endif
 // RDOQ, whole wave, coefficient groups in batches.  s->tc -> s->lvl ; returns uiAbsSum.  Same arithmetic, same order of every fp64 sum as the reference
 // (TComTrQuant.cpp:2119-2661); what changes is how the work inside phase B is laid out:
 //   * What a group's level decisions depend on: its own positions (the c1 / c2 / Rice state machine runs inside a group and starts afresh in
@@ -972,6 +986,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   wsync();
   if (last_pos < 0) return 0;
   RDOQ_MARK(18);
+  RDOQ_STOP(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
   { // rate tables: one pair of dependent LDS reads here instead of one per batch and use
     const int set0 = ch ? 4 : 0;
@@ -1001,6 +1016,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   }
   double base_cost = block_uncoded;
   RDOQ_MARK(19);
+  RDOQ_STOP(19);
   const int cg_last = last_pos >> 4, wg = cp.wg, lwg = log2n - 2;
   // rates of the significant-group flag, by context (0 / 1) and value
   const double cgr00 = lambda * (double)ctx_bits(cab, cg_off, 0), cgr01 = lambda * (double)ctx_bits(cab, cg_off, 1);
@@ -1043,6 +1059,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     const int b0_j = is_last ? 0 : s.rq_sig[sc_j][0], b1_j = is_last ? 0 : s.rq_sig[sc_j][1];
     const double cs0_j = lambda * (double)b0_j, cs1_j = lambda * (double)b1_j;
     RDOQ_MARK(4);
+    RDOQ_SKIP(4)
     int lvl_j = 0, ru_j = 0, rd_j = 0;
     double cc_j = c0_j + cs0_j, cs_j = cs0_j;
     unsigned long long g1m = 0;
@@ -1058,22 +1075,16 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       const bool vis = valid && ma_j > 0;
       int c1s = 1, c1idx = 0, c2idx = 0, gr = 0, rate_a = 0, rate_b = 0;
       // xGetICRate TComTrQuant.cpp:2881-2955 under this position's state
-      auto ic_rate = [&](int al, int r1_0, int r1_1) -> int {
-        const int base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
-        int rate = 32768;
-        if (al >= base) {
-          uint32_t symbol = (uint32_t)(al - base), length;
-          if (symbol < (3u << gr)) { length = symbol >> gr; rate += (int)(length + 1 + gr) << 15; }
-          else {
-            length = (uint32_t)gr; symbol -= (3u << gr);
-            while (symbol >= (1u << length)) symbol -= (1u << (length++));
-            rate += (int)(3 + length + 1 - gr + length) << 15;
-          }
-          if (c1idx < 8) { rate += r1_1; if (c2idx < 1) rate += g2r1; }
-        } else if (al == 1) rate += r1_0;
-        else if (al == 2) { rate += r1_1; rate += g2r0; }
-        else rate = 0;
-        return rate;
+      auto ic_rate = [&](int al, int r1_0, int r1_1) -> int { // branch-free: every lane evaluates both forms of the remainder code
+        const bool c1ok = c1idx < 8, c2ok = c2idx < 1;
+        const int base = c1ok ? (2 + (c2ok ? 1 : 0)) : 1;
+        const uint32_t symbol = (uint32_t)(al - base), thr = 3u << gr;
+        // escape: the prefix grows while the remainder reaches 1 << length (xWriteCoefRemainExGolomb's loop) <=> length = floor(log2(symbol - thr + (1 << gr)))
+        const int elen = 31 - __clz((int)(symbol - thr + (1u << gr)));
+        const uint32_t plen = symbol < thr ? (symbol >> gr) + 1u + (uint32_t)gr : (uint32_t)(3 + elen + 1 - gr + elen);     // (meaningless, and unused, below `base`)
+        const int hi = (int)(32768u + (plen << 15)) + (c1ok ? r1_1 + (c2ok ? g2r1 : 0) : 0);
+        const int lo = al == 1 ? 32768 + r1_0 : (al == 2 ? 32768 + r1_1 + g2r0 : 0);
+        return al >= base ? hi : lo;
       };
       int r1_0 = g1r0[1], r1_1 = g1r1[1];
       lvl_j = vis ? ma_j : 0;
@@ -1085,14 +1096,17 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         c1idx = __popc(f_nz); c2idx = __popc(f_g1);
         { const int e = 1 + __popc(f_e1); c1s = f_g1 ? 0 : (e < 3 ? e : 3); }
         gr = 0;
-        if (__ballot(lvl_j > 3)) { // the Rice parameter moves only at a level above 3 << parameter that is coded with an escape (:2360-2366)
+        if (__ballot(lvl_j > 3)) { // the Rice parameter moves only at a level above 3 << parameter that is coded with an escape (:2360-2366): from 0 at
+          // the first such level above 3, then at the next one above 6, above 12, above 24 -- four row masks and four leading-bit searches per lane
           const int base = (c1idx < 8) ? (2 + (c2idx < 1)) : 1;
           const int e_j = (lvl_j >= base) ? lvl_j : 0;
-#pragma unroll
-          for (int t = 15; t >= 1; t--) {
-            const int e_t = __shfl(e_j, (lane & 48) | t);
-            if (t > j && e_t > (3 << gr)) gr = gr + 1 < 4 ? gr + 1 : 4;
-          }
+          const unsigned long long m3 = __ballot(e_j > 3), m6 = __ballot(e_j > 6), m12 = __ballot(e_j > 12), m24 = __ballot(e_j > 24);
+          const unsigned r3 = (unsigned)(m3 >> (16 * row)) & 0xffffu, r6 = (unsigned)(m6 >> (16 * row)) & 0xffffu, r12 = (unsigned)(m12 >> (16 * row)) & 0xffffu, r24 = (unsigned)(m24 >> (16 * row)) & 0xffffu;
+          const int p1 = 31 - __clz((int)r3);
+          const int p2 = p1 > 0 ? 31 - __clz((int)(r6 & ((1u << p1) - 1u))) : -1;
+          const int p3 = p2 > 0 ? 31 - __clz((int)(r12 & ((1u << p2) - 1u))) : -1;
+          const int p4 = p3 > 0 ? 31 - __clz((int)(r24 & ((1u << p3) - 1u))) : -1;
+          gr = (p1 > j) + (p2 > j) + (p3 > j) + (p4 > j);
         }
         r1_0 = c1s == 0 ? g1r0[0] : (c1s == 1 ? g1r0[1] : (c1s == 2 ? g1r0[2] : g1r0[3]));
         r1_1 = c1s == 0 ? g1r1[0] : (c1s == 1 ? g1r1[1] : (c1s == 2 ? g1r1[2] : g1r1[3]));
@@ -1139,6 +1153,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         q_rate_st(Q_DOWN, blk_j, rd_j);
       }
     }
+    RDOQ_SKIP(5)
     // --- the ordered sums, group by group (each in scan order, pin = 15..0, as the reference accumulates them), on lanes 0..4:
     //   0 block_uncoded += c0      1 base_cost += cost_c      2 sig_cost += cost_s
     //   3 coded += cost_c - cost_s (nonzero levels)           4 uncoded += c0 (nonzero levels)
@@ -1173,6 +1188,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         }
       }
       RDOQ_MARK(34);
+      if (HEVCDL_RDOQ_STOPV == 34) continue;
       const int st_nnz_before0 = __popc(nzrow & 0xfffeu), cg_nonzero = nzrow != 0;
       int flag = cg_nonzero;
       if (qq) {
@@ -1203,6 +1219,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     cgpos -= R;
   }
   RDOQ_MARK(20);
+  RDOQ_STOP(20);
   // ---- phase C: last position, TComTrQuant.cpp:2440-2528.  Per CG the 16 positions' costs are fetched
   // lane-parallel, the walk itself is wave-uniform (readlane) and usually ends inside the first group ----
   int best_last_p1 = 0;
@@ -1278,8 +1295,8 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       base_cost = acc;
     }
   }
-
   RDOQ_MARK(21);
+  RDOQ_STOP(21);
   // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact)
   uint32_t abs_sum = 0;
   for (int sp = lane; sp <= last_pos; sp += 64) {
@@ -1911,7 +1928,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       else cabac_copy(k, &s.root[full_depth], &s.go);
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       unsigned long long split_cfrac = 0;
-      bool spec = false;
+      bool spec = false, aborted = false;
       if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) spec = memo && !uni(k.in_task) && spare_waves() && (LOG2 - 1 > min_tu_log2(cu));
       if (spec) { // second pass of a PU, spare waves in the workgroup: the children's two alternatives run concurrently (spec_children)
         if constexpr (SPEC && LOG2 >= 4 && LOG2 <= 5) { const DistCbf dc = spec_children<LOG2>(k, cu, tu); split_dist = dc.dist; split_cbf = dc.cbf; split_cfrac = dc.cfrac; }
@@ -1919,11 +1936,31 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
         const Tu ch = tu_child(tu, i);
         { const DistCost r = recur_luma<LOG2 - 1>(k, cu, ch, check_first); split_dist += r.dist; split_cost += r.cost; split_cfrac += r.cfrac; }
         split_cbf |= (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
+#ifndef HEVCDL_STAGE_TRACE
+        // The split can no longer win: its cost is (distortion of the four children) + lambda * ((fraction + flag bins + the children's coefficient bins) >> 15), both
+        // terms only grow with every child, and calc_rd_cost is monotone in both -- so once the children coded so far reach the unsplit cost, `split < unsplit`
+        // (strict, TEncSearch.cpp:1703) is decided and the remaining children are not coded (nothing they would leave behind is read when the unsplit TU wins).
+        // (The stage-trace build codes them: the reference's trace lists their blocks.)
+        if (i < 3) {
+          double bound = single_cost;
+          if (memo && single_cost == MAX_DOUBLE && uni(s.bound_child) >= 0) { // the split alternative of a child of a second pass (T_LUMA_SPLIT): it is up against the
+            // chain's unsplit coding of that child, which runs meanwhile (spec_children) -- once that cost is there, it is the bound
+            LRegion &rr = wg_shared().reg[uni(s.bound_reg)][1];
+            if (lds_load(&rr.modes[8 + uni(s.bound_child)])) { wg_acquire(); bound = rr.cost[4 + uni(s.bound_child)]; }
+          }
+          if (ub(bound < MAX_DOUBLE) && ub(!(calc_rd_cost(k, (uint32_t)(split_cfrac >> 15), split_dist) < bound))) {
+            if (memo && single_cost == MAX_DOUBLE) { const DistCost r = { 0, MAX_DOUBLE, 0 }; return r; }     // the task's answer: not cheaper than the unsplit child
+            aborted = true; break;
+          }
+        }
+#endif
       }
+      if (!aborted) {
       if (split_cbf) { for (int i = lane_id(); i < tu.nparts; i += 64) s.a[A_CBF][zabs + i] |= (uint8_t)(1 << tu.trd); }
       const uint32_t bits = split_bits<LOG2>(k, cu, tu, &s.root[full_depth], split_cfrac);
       split_cost = calc_rd_cost(k, bits, split_dist);
       if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost, split_cfrac }; return r; }
+      }
       if (memo) { // the saved best candidate of the first pass IS the unsplit coding (sv_* / best_rec, est_intra_luma)
         wsync();
         for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = s.sv[0][i]; s.a[A_CBF][zabs + i] = s.sv[1][i]; s.a[A_TSKIP][zabs + i] = s.sv[2][i]; }
@@ -2009,7 +2046,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
   int j = 0;
   while (j < 4) {
     wsync();
-    if (lane_id() < 4) r.modes[lane_id()] = j + lane_id();          // task i: the split alternative of child j + i
+    if (lane_id() < 4) { r.modes[lane_id()] = j + lane_id(); r.modes[8 + lane_id()] = 0; }          // task i: the split alternative of child j + i; [8 + c]: the chain's answer for child c is there
     if (lane_id() == 0) s.ref_key[0] = -1;                          // a restarted chain meets the same block again with new neighbours
     region_open(r, T_LUMA_SPLIT, 0, cu, tu);
     for (int c = j; c < 4; c++) {
@@ -2023,6 +2060,9 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       const uint32_t bits = intra_bits_qt<LOG2 - 1>(k, cu, ch, 1, 0);
       const double cost = calc_rd_cost(k, bits, d);
       if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; r.cfrac[4 + c] = s.cfrac_last; }
+      wsync();
+      wg_release();
+      if (lane_id() == 0) __hip_atomic_store(&r.modes[8 + c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // the child's split task may give up against this cost
     }
     { // wait for the split tasks; those nobody has claimed yet this wave runs itself: its own state (everything a task overwrites: kernel context,
       // coder snapshots, attribute arrays) goes to its global scratch and comes back afterwards, the cached reference lines are dropped
@@ -2812,7 +2852,10 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
   } else if (kind == T_LUMA_SPLIT) { // second RD pass: the four grandchildren of one child, from the state the chain of unsplit children had there
     const int zc = cu.zbase + ttu.zrel;
     state_from_global(&s.go, slot_state(kk.slots, slot, 0));
-    const DistCost dc = recur_luma_any(k, cu, ttu, 0, 1, 0, MAX_DOUBLE);     // memo form with an unlimited unsplit cost: the split is evaluated and taken
+    if (lane_id() == 0) { s.bound_reg = uni(r.owner); s.bound_child = mode; }
+    const DistCost dc = recur_luma_any(k, cu, ttu, 0, 1, 0, MAX_DOUBLE);     // memo form with an unlimited unsplit cost: the split is evaluated and taken (or given up: recur_luma's early exit)
+    wsync();
+    if (lane_id() == 0) s.bound_child = -1;
     dist = dc.dist; cost = dc.cost;
     if (lane_id() == 0) r.cfrac[idx] = dc.cfrac;
     state_to_global(slot_state(kk.slots, slot, 1), &s.go);
@@ -3275,9 +3318,10 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
       wsync();
       GLB unsigned long long *lg = s.my_log + (size_t)(li & 63) * (LEAF_LOG / 8);
       if (li < uni(s.replay_upto)) { // walked before and final: its result and the coder state behind it from the log
-        const unsigned long long w0 = lg[0], w1 = lg[1];
+        const unsigned long long w0 = lg[0], w1 = lg[1], w23 = lg[23];
         best.cost = __longlong_as_double((long long)uni64(w0)); best.bits = (uint32_t)uni((int)(unsigned)w1); best.dist = (uint32_t)uni((int)(unsigned)(w1 >> 32));
         state_from_global(&s.next[DEPTH], lg + 2);
+        if (lane_id() == 0) s.ctu_frac += w23;
       } else {
         // a pending pass that has finished meanwhile is joined right away: a restart costs the less the earlier it is seen
         while (uni(s.pend_n)) {
@@ -3300,7 +3344,12 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
           else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
         }
         wsync();
-        if (lane_id() == 0) { lg[0] = (unsigned long long)__double_as_longlong(best.cost); lg[1] = (unsigned long long)best.bits | ((unsigned long long)best.dist << 32); }
+        if (lane_id() == 0) {
+          // what this CU's syntax cost in fractional bits: its count started from the fraction of the CU's entry state (reset_bits keeps the low 15 bits)
+          const unsigned long long sf = s.next[DEPTH].frac - (s.curr[DEPTH].frac & 32767ull);
+          lg[0] = (unsigned long long)__double_as_longlong(best.cost); lg[1] = (unsigned long long)best.bits | ((unsigned long long)best.dist << 32); lg[23] = sf;
+          s.ctu_frac += sf;
+        }
         state_to_global(lg + 2, &s.next[DEPTH]);
         TL(12, 0);
       }
@@ -3372,6 +3421,47 @@ template <int DEPTH> DEVN void encode_cu_tree(KR k, LCabac *c, int x_, int y_)
   }
   const Cu cu = { x, y, 6 - DEPTH, DEPTH, z, 256 >> (2 * DEPTH), uni(s.a[A_PART][z]) };
   enc_cu_syntax(k, c, cu);
+}
+
+// The coder state behind a CTU WITHOUT coding it again (the reference does: encodeCtu with the RD coder, TEncSlice.cpp:886-893, xEncodeCU TEncCu.cpp:1167-1271).
+// The state-advancing encode codes, in z-order, every split flag where its CU starts and every CU's syntax.  The search's own chain (compress_cu) coded the same
+// CU syntax, CU by CU in the same order, each from the state its predecessor left -- plus the split flags, but those at other places of the sequence (behind
+// a CU, behind the four children).  A bin only touches its own context, so every context but the three split-flag ones has seen exactly the encode's bins in
+// the encode's order: their end states are the search's (s.next[0]), and the fractional bits of the CU syntax are the sums the search counted (ctu_frac).  What
+// is left are the <= 21 split flags: replayed here in the encode's order on the split-flag contexts of the state the CTU started from.
+DEVN void advance_state(KR k, LCabac *truec, int x0_, int y0_)
+{
+  const int x0 = uni(x0_), y0 = uni(y0_), lane = lane_id();
+  LSmem &s = lds();
+  // node of lane L in the encode's order: 0 the CTU, 1 + 5 i the 32x32 block i, 2 + 5 i + j its 16x16 block j
+  int code = 0;
+  if (lane < 21) {
+    const int r5 = (lane - 1) % 5, i1 = (lane - 1) / 5, d = lane == 0 ? 0 : (r5 == 0 ? 1 : 2);
+    auto dz_at = [&](int xx, int yy) { return (int)s.a[A_DEPTH][tb().r2z[(((yy & 63) >> 2) << 4) | ((xx & 63) >> 2)]]; };
+    auto inside = [&](int xx, int yy, int size) { return xx + size <= k.W && yy + size <= k.H; };
+    int x = x0, y = y0; bool ex = true;
+    if (d >= 1) {
+      ex = dz_at(x0, y0) > 0 || !inside(x0, y0, 64);                  // the walk goes below a CU that is split or reaches over the picture's edge
+      x = x0 + (i1 & 1) * 32; y = y0 + (i1 >> 1) * 32;
+      ex = ex && x < k.W && y < k.H;
+      if (d == 2) {
+        ex = ex && (dz_at(x, y) > 1 || !inside(x, y, 32));
+        x += ((r5 - 1) & 1) * 16; y += ((r5 - 1) >> 1) * 16;
+        ex = ex && x < k.W && y < k.H;
+      }
+    }
+    if (ex && inside(x, y, 64 >> d)) code = 8 | split_ctx(k, x, y, d) | ((dz_at(x, y) > d) ? 4 : 0);
+  }
+  wsync();
+  s.cgf[lane] = (uint8_t)code;
+  wsync();
+  if (lane == 0) {
+    reset_bits(truec);
+    for (int i = 0; i < 21; i++) { const int v = s.cgf[i]; if (v & 8) enc_bin(truec, CTX_SPLIT + (v & 3), (v >> 2) & 1); }
+    truec->frac += s.ctu_frac;
+  }
+  for (int i = 3 + lane; i < NUM_CTX; i += 64) truec->ctx[i] = s.next[0].ctx[i];
+  wsync();
 }
 
 // one unit = one (frame, tile): tiles are coded from a fresh coder state and see nothing of each other (TEncSlice.cpp:804-807)
@@ -3658,23 +3748,13 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; }
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; s.ctu_frac = 0; }
     wsync();
     PROF_MARK(47);
     Rd best;
-    int encoded = 0;
     for (;;) {
       best = compress_cu<0>(k, cx * 64, cy * 64);
-      if (!uni(s.restart) && uni(s.pend_n)) { // passes still pending at the end of the CTU: the state-advancing encode below runs first, on the same assumption as
-        // the walk did (they change nothing), and they are joined behind it; the coder state it started from is kept (entry 64 of the log) in case one does
-        GLB unsigned long long *keep = s.my_log + 64 * (LEAF_LOG / 8);
-        state_to_global(keep, truec);
-        if (lane == 0) reset_bits(truec);
-        encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
-        encoded = 1;
-        while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k, 1);
-        if (uni(s.restart)) { state_from_global(truec, keep); encoded = 0; }
-      }
+      while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k, 1);      // passes still pending at the end of the CTU
       if (!uni(s.restart)) break;
       // a pending second pass chose the split: the walk again, replaying the CUs before its own (compress_cu)
       wsync();
@@ -3684,19 +3764,15 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       if (lane < 3) s.ref_key[lane] = -1;
       ahead_drain();
       if (uni(s.pre_open)) { region_run(k, my_region()); if (lane == 0) s.pre_open = 0; wsync(); }      // SATD slices still out
-      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; }
+      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; s.ctu_frac = 0; }
       wsync();
       cabac_copy(k, &s.curr[0], truec);
       cabac_copy(k, &s.go, truec);
     }
     PROF_MARK(45);
-    // the state-advancing encode (TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
+    // the coder state behind the CTU (the reference's state-advancing encode, TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
     wsync();
-    if (!encoded) {
-      if (lane == 0) reset_bits(truec);
-      encode_cu_tree<0>(k, truec, cx * 64, cy * 64);
-    }
-    wsync();
+    advance_state(k, truec, cx * 64, cy * 64);
     if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)tb().t_ebits[126]; s.est_bits += truec->frac >> 15; }
     PROF_MARK(46);
     // flush the CTU record
@@ -3733,6 +3809,32 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   return 0;
 }
 
+// the workgroup's read-only tables (z-scan map, CABAC tables, scans): wave 0, once per kernel
+DEV void init_tables(LDS Tables &t)
+{
+  const int lane = lane_id();
+  for (int r = lane; r < 256; r += 64) {
+    const int x = r & 15, y = r >> 4; int z = 0;
+    for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+    t.r2z[r] = (uint8_t)z;
+  }
+  for (int i = lane; i < 128; i += 64) { t.t_ebits[i] = c_entropy_bits[i]; t.t_next[1][i] = c_next_mps[i]; t.t_next[0][i] = c_next_lps[i]; }
+  if (lane < 9) { t.t_ang[lane] = c_ang_table[lane]; t.t_inv_ang[lane] = c_inv_ang_table[lane]; }
+  if (lane < 16) t.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
+  if (lane < 32) t.t_group_idx[lane] = c_group_idx[lane];
+  if (lane < 5) t.t_filter_thr[lane] = c_intra_filter_thr[lane];
+  if (lane < 12) { // CG order of every (scan type, block size)
+    const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
+    LDS uint8_t *cg = t.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
+    int ln = 0, c = 0;
+    for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
+  }
+  if (lane < 3) { // order inside a CG, per scan type
+    int l2 = 0, c2 = 0;
+    for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
+  }
+}
+
 } // namespace
 
 extern "C" __global__ __launch_bounds__(NW * 64)
@@ -3758,28 +3860,9 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   }
   LDS WgShared &sh = wg_shared();
   if (lane == 0) for (int q = 0; q < NREG; q++) { sh.reg[wave][q].ticket = 0; sh.reg[wave][q].done = 0; sh.reg[wave][q].owner = wave; }
+  if (lane == 0) { s.bound_reg = 0; s.bound_child = -1; }
   if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
-    LDS Tables &t = sh.tab;
-    for (int r = lane; r < 256; r += 64) {
-      const int x = r & 15, y = r >> 4; int z = 0;
-      for (int b = 0; b < 4; b++) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
-      t.r2z[r] = (uint8_t)z;
-    }
-    for (int i = lane; i < 128; i += 64) { t.t_ebits[i] = c_entropy_bits[i]; t.t_next[1][i] = c_next_mps[i]; t.t_next[0][i] = c_next_lps[i]; }
-    if (lane < 9) { t.t_ang[lane] = c_ang_table[lane]; t.t_inv_ang[lane] = c_inv_ang_table[lane]; }
-    if (lane < 16) t.t_ctx_map4[lane] = c_ctx_ind_map_4x4[lane];
-    if (lane < 32) t.t_group_idx[lane] = c_group_idx[lane];
-    if (lane < 5) t.t_filter_thr[lane] = c_intra_filter_thr[lane];
-    if (lane < 12) { // CG order of every (scan type, block size)
-      const int type = lane >> 2, l = lane & 3, wg = 1 << l, ng = wg * wg;
-      LDS uint8_t *cg = t.scan_cg_all[type] + (l == 0 ? 0 : (l == 1 ? 1 : (l == 2 ? 5 : 21)));
-      int ln = 0, c = 0;
-      for (int g = 0; g < ng; g++) { cg[g] = (uint8_t)(ln * wg + c); scan_next(type, wg, wg, ln, c); }
-    }
-    if (lane < 3) { // order inside a CG, per scan type
-      int l2 = 0, c2 = 0;
-      for (int q = 0; q < 16; q++) { t.scan_in_cg[lane][q] = (uint8_t)((l2 << 2) | c2); scan_next(lane, 4, 4, l2, c2); }
-    }
+    init_tables(sh.tab);
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m;
                      sh.quit = 0; sh.remote = p.remote; sh.sched = (GLB unsigned char *)p.sched; }
   }
@@ -3842,3 +3925,88 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return (size_t)NW * sizeof(RdSmem) + sizeof(WgShared); }
 extern "C" size_t RD_SYM(hevcdl_rd_scratch_bytes)(void) { return SCR_WAVE; }        // per wave
 extern "C" int RD_SYM(hevcdl_rd_waves_per_group)(void) { return NW; }
+
+#if defined(HEVCDL_MICRO) && HEVCDL_BD == 8
+// -DHEVCDL_MICRO (tools/micro_rd.py; never in the product library): the leaf routines of a TU coding timed on their own, on synthetic residual blocks.
+// Every wave of every workgroup runs `reps` codings (what: 0 RDOQ, 1 the bit counter, 2 forward transform + RDOQ + bit counter + dequant + inverse);
+// out[wave] = { cycles inside the timed routine, checksum }.
+extern "C" __global__ __launch_bounds__(NW * 64)
+void hevcdl_micro_kernel(hevcdl_rd_params p, const int16_t *resi_, int n_blocks, int n, int comp, int mode, int reps, int what, unsigned long long *out_)
+{
+  LSmem &s = lds();
+  const int lane = lane_id(), wave = wave_id();
+  GLB const int16_t *resi = (GLB const int16_t *)resi_; GLB unsigned long long *out = (GLB unsigned long long *)out_;
+  {
+    GLB unsigned char *scr = (GLB unsigned char *)p.scratch + ((size_t)blockIdx.x * NW + wave) * p.scratch_per_wave;
+    s.my_coef = (GLB int16_t *)scr; s.my_rec = (GLB pel_t *)(scr + 4 * 6144 * 2); s.my_ovl = s.my_rec + 5 * 6144; s.my_save = (GLB unsigned long long *)(s.my_ovl + 6144);
+    s.my_log = s.my_save + N_SAVE * (SAVE_BYTES / 8);
+    s.my_qcost = (GLB double *)(scr + SCR_LAYERS); s.my_qrate = (GLB int32_t *)(scr + SCR_LAYERS + 16384);
+    s.my_slots = scr + SCR_LAYERS + SCR_RDOQ;
+  }
+  if (wave == 0) init_tables(wg_shared().tab);
+  __syncthreads();
+  const int active = what >> 8; what &= 255;                        // waves per workgroup that run (0: all)
+  if (active && wave >= active) { if (lane == 0) { out[2 * (blockIdx.x * NW + wave)] = 0; out[2 * (blockIdx.x * NW + wave) + 1] = 0; } return; }
+  LDS K &k = s.k;
+  if (lane == 0) { s.bound_reg = 0; s.bound_child = -1; }
+  k.q_cost = s.my_qcost; k.q_rate = s.my_qrate;
+  k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
+  for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
+  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = 0; k.dbgbuf = nullptr;
+  LCabac *c0 = &s.truec;
+  for (int i = lane; i < NUM_CTX; i += 64) {
+    const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
+    int st = ((slope * p.k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+    const int mps = st >= 64;
+    c0->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
+  }
+  if (lane == 0) { c0->ctx[159] = 0; c0->frac = 0; }
+  wsync();
+  const int log2n = ilog2(n);
+  unsigned long long total = 0, sum = 0;
+  for (int rep = 0; rep < reps; rep++) {
+    GLB const int16_t *src = resi + (size_t)((int)(blockIdx.x * NW + wave + rep) % n_blocks) * 1024;
+    wsync();
+    for (int i = lane; i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = src[i];
+    cabac_copy(k, &s.go, c0);
+    wsync();
+    unsigned long long t0 = __builtin_readcyclecounter();
+    fwd_transform(k, n, !comp && n == 4);
+    if (what != 2) t0 = __builtin_readcyclecounter();
+    const uint32_t as = rdoq_wave(k, &s.go, comp, n, mode, 1);
+    wsync();
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (what != 0) {
+      if (what == 1) t0 = __builtin_readcyclecounter();
+      if (as) code_coeff_wave(k, &s.go, comp, n, mode, 0);
+      if (what == 2 && as) { dequant(k, comp, n); inv_transform(k, n, !comp && n == 4); }
+      wsync();
+      t1 = __builtin_readcyclecounter();
+    }
+    total += t1 - t0; sum += as + (s.go.frac >> 15);
+  }
+  if (lane == 0) { out[2 * (blockIdx.x * NW + wave)] = total; out[2 * (blockIdx.x * NW + wave) + 1] = sum; }
+}
+
+// host side: consts = { lambda, sqrt_lambda, chroma_weight, lambda_chroma, err_scale[2][4] }, sbh[2]; resi: n_blocks x 1024 int16; out: groups * NW * 2 values
+extern "C" int hevcdl_micro_run(const double *consts, const long long *sbh, int qp, int qp_c, const int16_t *resi, int n_blocks, int n, int comp, int mode, int reps, int what, int groups,
+                                unsigned long long *out)
+{
+  hevcdl_rd_params p = {};
+  p.k.lambda = consts[0]; p.k.sqrt_lambda = consts[1]; p.k.chroma_weight = consts[2]; p.k.lambda_chroma = consts[3];
+  for (int a = 0; a < 2; a++) for (int b = 0; b < 4; b++) p.k.err_scale[a][b] = consts[4 + 4 * a + b];
+  p.k.sbh_rd_factor[0] = sbh[0]; p.k.sbh_rd_factor[1] = sbh[1]; p.k.qp = qp; p.k.qp_chroma = qp_c;
+  p.scratch_per_wave = SCR_WAVE;
+  int16_t *d_resi = nullptr; unsigned long long *d_out = nullptr; unsigned char *d_scr = nullptr;
+  const size_t smem = (size_t)NW * sizeof(RdSmem) + sizeof(WgShared);
+  if (hipMalloc(&d_resi, (size_t)n_blocks * 2048) != hipSuccess || hipMalloc(&d_out, (size_t)groups * NW * 16) != hipSuccess || hipMalloc(&d_scr, (size_t)groups * NW * SCR_WAVE) != hipSuccess) return -1;
+  p.scratch = d_scr;
+  hipMemcpy(d_resi, resi, (size_t)n_blocks * 2048, hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void *)hevcdl_micro_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(hevcdl_micro_kernel, dim3(groups), dim3(NW * 64), smem, 0, p, (const int16_t *)d_resi, n_blocks, n, comp, mode, reps, what, d_out);
+  const hipError_t e = hipDeviceSynchronize();
+  hipMemcpy(out, d_out, (size_t)groups * NW * 16, hipMemcpyDeviceToHost);
+  hipFree(d_resi); hipFree(d_out); hipFree(d_scr);
+  return e == hipSuccess ? 0 : -2;
+}
+#endif
