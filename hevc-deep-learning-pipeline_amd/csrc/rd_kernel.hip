@@ -169,6 +169,8 @@ struct K {                             // wave-uniform kernel context (lives in 
   // inside such a CU's rectangle come from best_rec, which holds the reconstruction the search continued with (the first pass's winner).
   // -> srect[p]: (x0 | y0 << 16 | x1 << 32 | y1 << 48), 0 = none; ONE 8-byte word each, so that a helper copying this context never sees half a rectangle
   unsigned long long srect[2];
+  GLB const pel_t *ssrc[2];            // ... and where the samples inside srect[p] are read: a plane of row stride 64 whose sample (0, 0) is the picture's (sorg & 0xffff, sorg >> 16)
+  int sorg[2];
   int pset, pad_pset;                  // the slot set of the second pass this wave is running (run_task)
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
@@ -512,7 +514,8 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   const unsigned long long sr0 = k.srect[0], sr1 = k.srect[1];
   const int spx0 = (int)(sr0 & 0xffff), spy0 = (int)((sr0 >> 16) & 0xffff), spx1 = (int)((sr0 >> 32) & 0xffff), spy1 = (int)(sr0 >> 48);
   const int sqx0 = (int)(sr1 & 0xffff), sqy0 = (int)((sr1 >> 16) & 0xffff), sqx1 = (int)((sr1 >> 32) & 0xffff), sqy1 = (int)(sr1 >> 48);
-  GLB const pel_t *pbest = k.best_rec;
+  GLB const pel_t *ps0 = k.ssrc[0], *ps1 = k.ssrc[1];
+  const int so0x = k.sorg[0] & 0xffff, so0y = k.sorg[0] >> 16, so1x = k.sorg[1] & 0xffff, so1y = k.sorg[1] >> 16;
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
   auto sample_ptr = [&](int i) -> GLB const pel_t * {        // the sample behind line index i
@@ -521,7 +524,8 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
     else if (i == 2 * n) { sy = y - 1; sx = x - 1; }
     else { sy = y - 1; sx = x + (i - 2 * n - 1); }
     if (task && sx >= rx0 && sx < rx1 && sy >= ry0 && sy < ry1) return po + (sy - oy) * cs_ + (sx - ox);
-    if (!c && ((sx >= spx0 && sx < spx1 && sy >= spy0 && sy < spy1) || (sx >= sqx0 && sx < sqx1 && sy >= sqy0 && sy < sqy1))) return pbest + (sy - oy) * 64 + (sx - ox);     // an earlier CU whose second pass is pending
+    if (!c && sx >= spx0 && sx < spx1 && sy >= spy0 && sy < spy1) return ps0 + (sy - so0y) * 64 + (sx - so0x);     // an earlier CU whose second pass is pending
+    if (!c && sx >= sqx0 && sx < sqx1 && sy >= sqy0 && sy < sqy1) return ps1 + (sy - so1y) * 64 + (sx - so1x);
     return p + (size_t)sy * st + sx;
   };
   // Every line element is ONE picture sample: its own when its unit is available, otherwise the last sample of the nearest
@@ -2507,6 +2511,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     { const LCabac *cur = &s.curr[cu.depth]; nfull = rmd_candidates<true>(k, ptu.x, ptu.y, pu_log2, cur->frac & 32767ull, cur->ctx[CTX_INTRA_PRED], s.satd); }   // from the [depth][CI_CURR_BEST] snapshot
     // ---- RD pass 1 (:2355-2443): the candidates are independent (each starts from the [depth][CI_CURR_BEST] snapshot) -> a region ----
     uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
+    int early_reg = 0;                                               // the next PU's SATD rounds were opened right behind the first pass's verdict: the ticket region of this CU's second pass
     {
       // candidates coded ahead of time (ahead_open)?  Accepted when they are the PU's candidates in the same order and every context they read is what it was
       // assumed to be; the tasks nobody had claimed when the chroma search of the CU before ended are run now
@@ -2572,6 +2577,27 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       for (int m = 0; m < nfull; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
       if (win >= 0) { // xSetIntraResultLumaQT + the saved arrays, from the winner's result slot
         best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
+        // Launches of few units: the chain that bounds a frame is luma only -- this CU's winner -> rough modes of the next PU -> its candidates.  The winner's samples
+        // sit in its result slot: the SATD rounds of the next PU are handed to the idle waves NOW, reading them there (srect / ssrc), while this wave copies the
+        // winner's levels, samples and arrays (the slot is not written again before the rounds are collected: est_intra_chroma, ahead_open)
+        if (win < SLOT_CHROMA && npu == 1 && pu_log2 <= 5 && pu_log2 > min_tu_log2(cu) && lds_load(&wg_shared().remote) && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3      // (slots from SLOT_CHROMA on take this CU's chroma modes)
+            && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) {
+          int nx, ny, nl;
+          if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
+            if (uni(s.pend_n) == NPEND) { pend_join_oldest(k, 0); if (uni(s.restart)) return 0; }   // the ticket region (= slot set, = srect entry) the second pass below will take
+            early_reg = (uni(s.pend_n) && uni(s.pend_reg[0]) == 1) ? 2 : 1;
+            wsync();
+            if (lane_id() == 0) {
+              LDS K &kk = s.k;
+              kk.ssrc[early_reg - 1] = slot_rec(k.slots, win) + (5 - pu_log2) * 6144; kk.sorg[early_reg - 1] = ptu.x | (ptu.y << 16);
+              kk.srect[early_reg - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
+            }
+            wsync();
+            rmd_prefetch(k, nx, ny, nl, 2);
+            if (lane_id() == 0) s.pre_open = (nl << 24) | (ny << 12) | nx;
+            wsync();
+          }
+        }
         GLB const uint8_t *at = slot_attr(k.slots, win);
         wsync();
         for (int i = lane_id(); i < pu_parts; i += 64) {
@@ -2588,6 +2614,11 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         }
       }
       region_close(r);
+      if (early_reg) { // the copy is in best_rec: from here on the samples are read there (the slot will serve the next CU's candidates)
+        wg_release();
+        if (lane_id() == 0) s.k.ssrc[early_reg - 1] = k.best_rec + boff(k, 0, ptu.x, ptu.y);        // ONE word changes (a helper may be copying this context): same origin, the PU's corner
+        wsync();
+      }
     }
     // ---- RD pass 2 (:2445-2512) = the best first-pass mode again, now with TU splitting allowed.  Its unsplit coding is a bit-exact
     // repeat of the first pass (same mode, same references, same coder state): reuse it (memo) ----
@@ -2610,9 +2641,10 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           // are in best_rec now: mark the CU as the pending pass's (readers take best_rec; check_rd_cost_intra writes the same word again) and hand the SATD
           // rounds of the next PU to the idle waves BEFORE the pass and the chroma modes are posted (est_intra_chroma collects them)
           int nx, ny, nl;
-          if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
+          if (!early_reg && next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
             wsync();
-            if (lane_id() == 0) s.k.srect[reg - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
+            if (lane_id() == 0) { LDS K &kk = s.k; kk.ssrc[reg - 1] = k.best_rec + boff(k, 0, cu.x, cu.y); kk.sorg[reg - 1] = cu.x | (cu.y << 16);
+              kk.srect[reg - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48); }
             wsync();
             rmd_prefetch(k, nx, ny, nl, 2);
             if (lane_id() == 0) s.pre_open = (nl << 24) | (ny << 12) | nx;
@@ -3207,7 +3239,8 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
   int pending = uni(s.p2_pending);                   // the second luma pass is running on another wave (est_intra_luma): the region of its ticket
   if (pending) { // until the pass is joined this CU's luma in the picture belongs to it: whoever needs the samples meanwhile (rmd_prefetch, the next CUs) reads best_rec
     wsync();
-    if (lane_id() == 0) s.k.srect[pending - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48);
+    if (lane_id() == 0) { LDS K &kk = s.k; kk.ssrc[pending - 1] = k.best_rec + boff(k, 0, cu.x, cu.y); kk.sorg[pending - 1] = cu.x | (cu.y << 16);
+      kk.srect[pending - 1] = (unsigned long long)cu.x | ((unsigned long long)cu.y << 16) | ((unsigned long long)(cu.x + (1 << cu.log2)) << 32) | ((unsigned long long)(cu.y + (1 << cu.log2)) << 48); }
     wsync();
   }
   Rd r = { 0.0, 0, 0 };
@@ -3681,7 +3714,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
   k.q_cost = s.my_qcost; k.q_rate = s.my_qrate; k.slots = s.my_slots;        // (a wave that served other masters' tasks holds their context)
-  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.srect[0] = k.srect[1] = 0; k.pset = 0; k.pad_pset = 0;
+  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.srect[0] = k.srect[1] = 0; k.ssrc[0] = k.ssrc[1] = k.best_rec; k.sorg[0] = k.sorg[1] = 0; k.pset = 0; k.pad_pset = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
@@ -3751,9 +3784,11 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; s.ctu_frac = 0; }
     wsync();
     PROF_MARK(47);
+    TL(13, a);
     Rd best;
     for (;;) {
       best = compress_cu<0>(k, cx * 64, cy * 64);
+      TL(14, uni(s.pend_n));
       while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k, 1);      // passes still pending at the end of the CTU
       if (!uni(s.restart)) break;
       // a pending second pass chose the split: the walk again, replaying the CUs before its own (compress_cu)
@@ -3770,10 +3805,12 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       cabac_copy(k, &s.go, truec);
     }
     PROF_MARK(45);
+    TL(15, 0);
     // the coder state behind the CTU (the reference's state-advancing encode, TEncSlice.cpp:886-893) + end_of_slice_segment_flag = 0 (finishCU TEncCu.cpp:1112-1128)
     wsync();
     advance_state(k, truec, cx * 64, cy * 64);
     if (lane == 0) { if (a != nctu - 1) truec->frac += (unsigned long long)tb().t_ebits[126]; s.est_bits += truec->frac >> 15; }
+    TL(16, 0);
     PROF_MARK(46);
     // flush the CTU record
     GLB unsigned char *rec = records + (size_t)a * REC_SIZE;

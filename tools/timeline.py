@@ -13,7 +13,8 @@ enc=hevcdl_amd.Encoder(W,H,32,max_frames=max(F,256)); lab=enc.predict_depth(yuv)
 out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
 ev = [tuple(int(v) for v in l.split()[1:3]) for l in out.stdout.splitlines() if l.startswith('DBGV')]
 names = {1: 'luma: start', 2: 'luma: P1 region (arg: claimed ahead)', 3: 'luma: P1 done', 4: 'luma: end', 5: 'chroma: start', 6: 'chroma: posted', 7: 'ahead: SATD done', 8: 'ahead: opened',
-         9: 'chroma: answers in', 10: 'chroma: end', 11: 'CU syntax done', 12: 'CU logged'}
+         9: 'chroma: answers in', 10: 'chroma: end', 11: 'CU syntax done', 12: 'CU logged',
+         13: 'CTU: start', 14: 'CTU: walk done (arg: passes pending)', 15: 'CTU: passes joined', 16: 'CTU: state advanced'}
 kinds = {1: 'P1', 2: 'chroma', 3: 'split', 4: 'P2', 5: 'RMD', 6: 'AHEAD'}
 if not ev:
     print(out.stderr[-2000:]); sys.exit(1)
