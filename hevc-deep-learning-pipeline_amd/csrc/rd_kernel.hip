@@ -228,7 +228,9 @@ struct __attribute__((aligned(16))) RdSmem {
 #ifdef HEVCDL_KERNEL_PROF
   GLB unsigned long long *my_prof; int prof_task, prof_pad; // timers of the profiling build (8-bit kernel, workgroup 0): 64 accumulators in HBM (cycles in the low 40 bits, calls above), added to with returnless atomics -- no LDS, no wait
 #endif
-  double cg_cost[64];                 // RDOQ per-CG sig-flag cost
+#ifdef HEVCDL_MICRO_T
+  unsigned long long mt_acc[12];      // -DHEVCDL_MICRO_T (tools/micro_rd.py --phases): cycles per phase of rdoq_wave, accumulated in scalar registers and added here once per call
+#endif
   union {
     double chainb[3][RQ_ROWS * 16 + 1];  // rdoq_wave: zero-level cost, coded cost, significance cost of every position of a batch of groups
     double zb[2][64];                 // RDOQ, run of all-zero groups: zero-level costs / significance costs of 4 groups
@@ -892,7 +894,11 @@ DEV double rl_d(double v, int l)
 #define MT0() do { } while (0)
 #define MT(id) do { } while (0)
 #endif
-#ifdef HEVCDL_KERNEL_PROF
+#if defined(HEVCDL_MICRO_T)
+// phase timers of the micro-benchmark build: a mark costs one s_memtime and two scalar additions (no memory traffic inside the routine)
+constexpr int mt_slot(int id) { return id == 18 ? 0 : id == 19 ? 1 : id == 4 ? 2 : id == 5 ? 3 : id == 34 ? 4 : id == 8 ? 5 : id == 20 ? 6 : id == 21 ? 7 : id == 22 ? 8 : id == 6 ? 9 : 10; }
+#define RDOQ_MARK(id) do { const unsigned long long n_ = __builtin_readcyclecounter(); mt_[mt_slot(id)] += n_ - pt_; pt_ = n_; } while (0)
+#elif defined(HEVCDL_KERNEL_PROF)
 #ifndef HEVCDL_PROF_N
 #define HEVCDL_PROF_N 0                                 // != 0: the RDOQ phase timers count TUs of this size only
 #endif
@@ -954,13 +960,18 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   auto q_cost_ld = [&](int a, int i) -> double { double v; if (qlds) v = lq_cost[a * ncoef + i]; else v = gq_cost[a * 1024 + i]; return v; };
   auto q_rate_st = [&](int a, int i, int32_t v) { if (qlds) lq_rate[a * ncoef + i] = v; else gq_rate[a * 1024 + i] = v; };
   auto q_rate_ld = [&](int a, int i) -> int32_t { int32_t v; if (qlds) v = lq_rate[a * ncoef + i]; else v = gq_rate[a * 1024 + i]; return v; };
-  LDS double *cost_cg_sig = s.cg_cost;
+  // the rate of every group's significance flag as it entered the cost (read again by the last-position search) is one of four values -- flag 0 / 1 under context 0 / 1 --
+  // or nothing: three masks over the groups (bit = index in scan order) instead of an array of costs
+  unsigned long long cgs_set = 0, cgs_ctx = 0, cgs_one = 0;
   auto level_double = [&](int blk) -> int32_t {
     const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
     return (int32_t)(tmpl < lim ? tmpl : lim);
   };
   auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
-#ifdef HEVCDL_KERNEL_PROF
+#if defined(HEVCDL_MICRO_T)
+  unsigned long long mt_[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  unsigned long long pt_ = __builtin_readcyclecounter();
+#elif defined(HEVCDL_KERNEL_PROF)
   unsigned long long pt_ = __builtin_readcyclecounter();
 #endif
   // ---- phase A: rounded levels; per group (bit = its index in scan order): any level, any level > 1, any level > 2 ----
@@ -986,7 +997,6 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       if ((b3 >> (16 * r)) & 0xffffull) cg_ge3 |= 1ull << g;
     }
   }
-  cost_cg_sig[lane] = 0;
   wsync();
   if (last_pos < 0) return 0;
   RDOQ_MARK(18);
@@ -1018,7 +1028,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       for (int t = 0; t < 16; t++) block_uncoded += v[t];
     }
   }
-  double base_cost = block_uncoded;
+  double acc = lane < 2 ? block_uncoded : 0.0;          // lanes 0 / 1 / 2: block_uncoded, base_cost, the current group's significance cost (phase B)
   RDOQ_MARK(19);
   RDOQ_STOP(19);
   const int cg_last = last_pos >> 4, wg = cp.wg, lwg = log2n - 2;
@@ -1150,18 +1160,24 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       RDOQ_MARK(5);
       if (valid) {
         dst[blk_j] = (int16_t)lvl_j;
-        if (cc_needed) { q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j); }   // read again by the last-position search only
-        q_rate_st(Q_SIGDELTA, blk_j, b1_j - b0_j);                   // 0 at the last position
-        q_rate_st(Q_DELTAU, blk_j, (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8)));
-        q_rate_st(Q_UP, blk_j, ru_j);
-        q_rate_st(Q_DOWN, blk_j, rd_j);
+        // Who reads the per-position outputs again: the last-position search walks the groups that keep their flag -- a group with a level, or group 0 -- and sign
+        // hiding only touches a group whose first and last level are at least four positions apart (levels only disappear after this point, so the distance
+        // can only shrink): the other rows store nothing
+        const unsigned nzr = (unsigned)(__ballot(lvl_j > 0) >> (16 * row)) & 0xffffu;
+        if (cc_needed && (nzr || q == 0)) { q_cost_st(Q_COEFF, sp_j, cc_j); q_cost_st(Q_SIG, sp_j, cs_j); }   // read again by the last-position search only
+        if (nzr && (31 - __clz((int)nzr)) - (__ffs((int)nzr) - 1) >= 4) {
+          q_rate_st(Q_SIGDELTA, blk_j, b1_j - b0_j);                   // 0 at the last position
+          q_rate_st(Q_DELTAU, blk_j, (int32_t)((ld_j - (int32_t)((uint32_t)lvl_j << qbits)) >> (qbits - 8)));
+          q_rate_st(Q_UP, blk_j, ru_j);
+          q_rate_st(Q_DOWN, blk_j, rd_j);
+        }
       }
     }
     RDOQ_SKIP(5)
-    // --- the ordered sums, group by group (each in scan order, pin = 15..0, as the reference accumulates them), on lanes 0..4:
-    //   0 block_uncoded += c0      1 base_cost += cost_c      2 sig_cost += cost_s
-    //   3 coded += cost_c - cost_s (nonzero levels)           4 uncoded += c0 (nonzero levels)
-    // A position that does not contribute adds +0.0, which leaves a sum unchanged.
+    // --- the ordered sums, group by group (each in scan order, pin = 15..0, as the reference accumulates them).  Three of them ride in ONE chain of 16 additions on
+    // lanes 0..2 of `acc` (addends transposed through LDS):   0 block_uncoded += c0      1 base_cost += cost_c      2 sig_cost += cost_s (from zero, per group)
+    // and stay in their lanes from group to group and from batch to batch: the group's test runs on lane 1 (lane 2's sum comes over the DPP crossbar), nothing is
+    // broadcast.  A position that does not contribute adds +0.0, which leaves a sum unchanged.  The two sums over the levels only (coded, uncoded) are wave-uniform.
     const bool nz_j = valid && lvl_j != 0;
     const unsigned long long nzfin = __ballot(nz_j);
     const double d_j = cc_j - cs_j;
@@ -1170,58 +1186,68 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       s.chainb[0][o] = valid ? c0_j : 0.0; s.chainb[1][o] = valid ? cc_j : 0.0; s.chainb[2][o] = valid ? cs_j : 0.0;
     }
     wsync();
+    LDS const double *cbl = &s.chainb[lane < 2 ? lane : 2][0];
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = cbl[t];
     for (int r = 0; r < R; r++) {
       const int qq = cgpos - r;
       const int cb = __builtin_amdgcn_readlane(cgblk, 16 * r), ggy = cb >> lwg, ggx = cb & (wg - 1);
-      double st_sig_cost, st_sig_cost0, st_coded = 0.0, st_uncoded = 0.0;
       const unsigned nzrow = (unsigned)(nzfin >> (16 * r)) & 0xffffu;
-      {
-        const int arow = lane < 2 ? lane : 2;
-        double acc = lane == 0 ? block_uncoded : (lane == 1 ? base_cost : 0.0);
-        double v[16];
+      double vn[16];
+      if (r + 1 < R) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) v[t] = s.chainb[arow][r * 16 + t];
-#pragma unroll
-        for (int t = 15; t >= 0; t--) acc += v[t];
-        block_uncoded = rl_d(acc, 0); base_cost = rl_d(acc, 1); st_sig_cost = rl_d(acc, 2);
-        st_sig_cost0 = rl_d(cs_j, 16 * r);
-        // sums 3 and 4 run over the positions with a level only (adding +0.0 for the others would change nothing): a handful, highest position first
-        for (unsigned m = nzrow; m; ) {
-          const int t = 31 - __clz((int)m); m &= ~(1u << t);
-          st_coded += rl_d(d_j, 16 * r + t); st_uncoded += rl_d(c0_j, 16 * r + t);
-        }
+        for (int t = 0; t < 16; t++) vn[t] = cbl[(r + 1) * 16 + t];         // the next group's addends arrive while this one is summed
       }
-      RDOQ_MARK(34);
-      if (HEVCDL_RDOQ_STOPV == 34) continue;
+#pragma unroll
+      for (int t = 15; t >= 0; t--) acc += v[t];
       const int st_nnz_before0 = __popc(nzrow & 0xfffeu), cg_nonzero = nzrow != 0;
       int flag = cg_nonzero;
+      double nb = acc;                                   // lane 1: base_cost behind this group
       if (qq) {
         const int csx = (((ggx < wg - 1) ? cgf_at(ggx + 1, ggy) : 0) + ((ggy < wg - 1) ? cgf_at(ggx, ggy + 1) : 0)) != 0;    // TComTrQuant.cpp:3023-3049
         const double r0 = csx ? cgr10 : cgr00, r1 = csx ? cgr11 : cgr01;
+        // lane l takes lane l + 1's sum: lane 1 sees the group's significance cost
+        const double sig = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0x101, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0x101, 0xf, 0xf, false));
         if (!cg_nonzero) {
-          base_cost += r0 - st_sig_cost;
-          if (lane == 0) cost_cg_sig[qq] = r0;
+          nb = acc + (r0 - sig);
+          cgs_set |= 1ull << qq; if (csx) cgs_ctx |= 1ull << qq;
         } else if (qq < cg_last) {
-          if (st_nnz_before0 == 0) { base_cost -= st_sig_cost0; st_sig_cost -= st_sig_cost0; }
-          double zero_cost = base_cost;
-          base_cost += r1; zero_cost += r0;
-          double cgc = r1;
-          zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= st_sig_cost;
-          if (zero_cost < base_cost) {
-            base_cost = zero_cost; cgc = r0; flag = 0;
-            if (row == r && lvl_j) dst[blk_j] = 0;                       // (its per-position costs are never read: the last-position search skips a group without the flag)
+          // sums 3 and 4 run over the positions with a level only (adding +0.0 for the others would change nothing): a handful, highest position first
+          double st_coded = 0.0, st_uncoded = 0.0;
+          for (unsigned m = nzrow; m; ) {
+            const int t = 31 - __clz((int)m); m &= ~(1u << t);
+            st_coded += rl_d(d_j, 16 * r + t); st_uncoded += rl_d(c0_j, 16 * r + t);
           }
-          if (lane == 0) cost_cg_sig[qq] = cgc;
+          const double st_sig_cost0 = rl_d(cs_j, 16 * r);
+          double b = acc, sg = sig;
+          if (st_nnz_before0 == 0) { b -= st_sig_cost0; sg -= st_sig_cost0; }
+          double zero_cost = b;
+          b += r1; zero_cost += r0;
+          zero_cost += st_uncoded; zero_cost -= st_coded; zero_cost -= sg;
+          cgs_set |= 1ull << qq; if (csx) cgs_ctx |= 1ull << qq;
+          const int take = (int)((__ballot(zero_cost < b) >> 1) & 1ull);                 // lane 1's verdict
+          if (take) {
+            nb = zero_cost; flag = 0;
+            if (row == r && lvl_j) dst[blk_j] = 0;                       // (its per-position costs are never read: the last-position search skips a group without the flag)
+          } else { nb = b; cgs_one |= 1ull << qq; }
         }
       } else flag = 1;
+      acc = lane == 1 ? nb : (lane == 2 ? 0.0 : acc);
       if (flag) { cgf_mask |= 1ull << cb; if ((g1m >> (16 * r)) & 0xffffull) cc_needed = false; }   // the last-position search ends in this group (a level > 1 stays)
-      RDOQ_MARK(35);
+      RDOQ_MARK(34);
+      if (r + 1 < R) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = vn[t];
+      }
     }
     carry = (int)(((g1m >> (16 * (R - 1))) & 0xffffull) != 0ull);
     wsync();
     RDOQ_MARK(8);
     cgpos -= R;
   }
+  block_uncoded = rl_d(acc, 0);
+  double base_cost = rl_d(acc, 1);
   RDOQ_MARK(20);
   RDOQ_STOP(20);
   // ---- phase C: last position, TComTrQuant.cpp:2440-2528.  Per CG the 16 positions' costs are fetched
@@ -1255,7 +1281,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     int found_last = 0;
     for (int cgp = cg_last; cgp >= 0 && !found_last; cgp--) {
       const int cgblk = uni(scan_cg[cgp]);
-      base_cost -= cost_cg_sig[cgp];
+      if ((cgs_set >> cgp) & 1ull) base_cost -= ((cgs_ctx >> cgp) & 1ull) ? (((cgs_one >> cgp) & 1ull) ? cgr11 : cgr10) : (((cgs_one >> cgp) & 1ull) ? cgr01 : cgr00);
       if (!((cgf_mask >> cgblk) & 1ull)) continue;
       const int j = lane & 15, sp_j = cgp * 16 + j, blk_j = scan[sp_j];
       const int lv_j = dst[blk_j];
@@ -1301,32 +1327,51 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   }
   RDOQ_MARK(21);
   RDOQ_STOP(21);
-  // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact)
+  // signs, absolute sum, uncoded tail (lane-parallel; integer sum is exact) -- and, in the same walk, which groups sign data hiding (TComTrQuant.cpp:2530-2660) has to
+  // visit at all: a group whose first and last level are four positions or more apart and whose level parity disagrees with the sign of its first level.  A visit only
+  // changes levels of its own group, so the tests of all groups can be made beforehand, four groups (one per row of 16 lanes) at a time.
   uint32_t abs_sum = 0;
-  for (int sp = lane; sp <= last_pos; sp += 64) {
-    const int blk = scan[sp];
-    if (sp < best_last_p1) { const int lv = dst[blk]; abs_sum += (uint32_t)lv; dst[blk] = (int16_t)(src[blk] < 0 ? -lv : lv); }
-    else dst[blk] = 0;
+  unsigned long long sbh_need = 0;                         // bit = group in scan order
+  int top_group = -1;                                      // the first group from the top that holds a level (the reference's lastCG == 1)
+  for (int base = 0; base <= last_pos; base += 64) {
+    const int sp = base + lane;
+    int lv = 0;
+    if (sp <= last_pos) {
+      const int blk = scan[sp];
+      if (sp < best_last_p1) { const int a = dst[blk]; abs_sum += (uint32_t)a; lv = src[blk] < 0 ? -a : a; }
+      dst[blk] = (int16_t)lv;
+    }
+    const unsigned long long nzb = __ballot(lv != 0);
+    if (nzb) {
+      const unsigned long long ngb = __ballot(lv < 0);
+      const int row = lane >> 4;
+      const unsigned rm = (unsigned)(nzb >> (16 * row)) & 0xffffu;
+      const int first = rm ? __ffs((int)rm) - 1 : 0, last = rm ? 31 - __clz((int)rm) : 0;
+      const int sum = row_sum_i(lv);
+      const unsigned signbit = (unsigned)(ngb >> (16 * row + first)) & 1u;
+      const unsigned long long ndb = __ballot((lane & 15) == 0 && last - first >= 4 && signbit != ((unsigned)sum & 1u));
+#pragma unroll
+      for (int r = 0; r < 4; r++) if ((ndb >> (16 * r)) & 1ull) sbh_need |= 1ull << ((base >> 4) + r);
+      top_group = (base >> 4) + ((63 - __clzll((long long)nzb)) >> 4);
+    }
   }
   abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
   wsync();
-  if (abs_sum >= 2) { // sign data hiding TComTrQuant.cpp:2530-2660; lanes 0..15 own the positions of the current CG
+  if (abs_sum >= 2) { // lanes 0..15 own the positions of the group being visited
     const long long rd_factor = k.sbh[ch];
     const long long I64MAX = 0x7fffffffffffffffll;
-    int last_cg = -1;
-    for (int subset = cg_last; subset >= 0; subset--) {
+    while (sbh_need) {
+      const int subset = 63 - __clzll((long long)sbh_need);
+      sbh_need &= ~(1ull << subset);
+      const int last_cg = subset == top_group ? 1 : 0;
       const int sub_pos = subset << 4, j = lane & 15, blk_j = scan[sub_pos + j];
       const int lv_j = dst[blk_j];
       const unsigned nzmask = (unsigned)(__ballot(lv_j != 0) & 0xffffull);
-      if (!nzmask) continue;                                       // lastCG stays -1 until the first CG with levels
       const int last_nz = 31 - __clz((int)nzmask), first_nz = __ffs((int)nzmask) - 1;
-      if (last_cg == -1) last_cg = 1;
-      if (last_nz - first_nz >= 4) {
-        int sum = (j >= first_nz && j <= last_nz) ? lv_j : 0;
-        sum = row_sum_i(sum);
-        const int lv_first = __builtin_amdgcn_readlane(lv_j, first_nz);
-        const uint32_t signbit = lv_first > 0 ? 0 : 1;
-        if (signbit != ((uint32_t)sum & 1u)) {
+      const int lv_first = __builtin_amdgcn_readlane(lv_j, first_nz);
+      const uint32_t signbit = lv_first > 0 ? 0 : 1;
+      {
+        {
           long long cur_cost = I64MAX; int cur_change = 0;
           const int nmax = (last_cg == 1) ? last_nz : 15;
           if (j <= nmax) {
@@ -1359,11 +1404,16 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
           }
         }
       }
-      if (last_cg == 1) last_cg = 0;
     }
   }
   wsync();
   RDOQ_MARK(22);
+#ifdef HEVCDL_MICRO_T
+  if (lane < 11) { unsigned long long a_ = 0;
+#pragma unroll
+    for (int i = 0; i < 11; i++) if (lane == i) a_ = mt_[i];
+    s.mt_acc[lane] += a_; }
+#endif
   return (uint32_t)uni((int)abs_sum);
 }
 
@@ -4001,6 +4051,10 @@ void hevcdl_micro_kernel(hevcdl_rd_params p, const int16_t *resi_, int n_blocks,
   wsync();
   const int log2n = ilog2(n);
   unsigned long long total = 0, sum = 0;
+#ifdef HEVCDL_MICRO_T
+  if (lane < 12) s.mt_acc[lane] = 0;
+  wsync();
+#endif
   for (int rep = 0; rep < reps; rep++) {
     GLB const int16_t *src = resi + (size_t)((int)(blockIdx.x * NW + wave + rep) % n_blocks) * 1024;
     wsync();
@@ -4023,6 +4077,10 @@ void hevcdl_micro_kernel(hevcdl_rd_params p, const int16_t *resi_, int n_blocks,
     total += t1 - t0; sum += as + (s.go.frac >> 15);
   }
   if (lane == 0) { out[2 * (blockIdx.x * NW + wave)] = total; out[2 * (blockIdx.x * NW + wave) + 1] = sum; }
+#ifdef HEVCDL_MICRO_T
+  wsync();
+  if (lane < 11 && blockIdx.x == 0 && wave == 0) out[2 * gridDim.x * NW + lane] = s.mt_acc[lane];      // behind the per-wave pairs: workgroup 0, wave 0
+#endif
 }
 
 // host side: consts = { lambda, sqrt_lambda, chroma_weight, lambda_chroma, err_scale[2][4] }, sbh[2]; resi: n_blocks x 1024 int16; out: groups * NW * 2 values
@@ -4036,13 +4094,13 @@ extern "C" int hevcdl_micro_run(const double *consts, const long long *sbh, int 
   p.scratch_per_wave = SCR_WAVE;
   int16_t *d_resi = nullptr; unsigned long long *d_out = nullptr; unsigned char *d_scr = nullptr;
   const size_t smem = (size_t)NW * sizeof(RdSmem) + sizeof(WgShared);
-  if (hipMalloc(&d_resi, (size_t)n_blocks * 2048) != hipSuccess || hipMalloc(&d_out, (size_t)groups * NW * 16) != hipSuccess || hipMalloc(&d_scr, (size_t)groups * NW * SCR_WAVE) != hipSuccess) return -1;
+  if (hipMalloc(&d_resi, (size_t)n_blocks * 2048) != hipSuccess || hipMalloc(&d_out, (size_t)groups * NW * 16 + 128) != hipSuccess || hipMalloc(&d_scr, (size_t)groups * NW * SCR_WAVE) != hipSuccess) return -1;
   p.scratch = d_scr;
   hipMemcpy(d_resi, resi, (size_t)n_blocks * 2048, hipMemcpyHostToDevice);
   hipFuncSetAttribute((const void *)hevcdl_micro_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(hevcdl_micro_kernel, dim3(groups), dim3(NW * 64), smem, 0, p, (const int16_t *)d_resi, n_blocks, n, comp, mode, reps, what, d_out);
   const hipError_t e = hipDeviceSynchronize();
-  hipMemcpy(out, d_out, (size_t)groups * NW * 16, hipMemcpyDeviceToHost);
+  hipMemcpy(out, d_out, (size_t)groups * NW * 16 + 128, hipMemcpyDeviceToHost);      // + 16 values: the phase timers of -DHEVCDL_MICRO_T
   hipFree(d_resi); hipFree(d_out); hipFree(d_scr);
   return e == hipSuccess ? 0 : -2;
 }
