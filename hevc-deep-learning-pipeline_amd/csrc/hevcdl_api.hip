@@ -16,6 +16,10 @@ extern "C" __global__ void hevcdl_rd_frame_kernel_bd10(hevcdl_rd_params p);     
 extern "C" size_t hevcdl_rd_smem_bytes_bd10(void);
 extern "C" size_t hevcdl_rd_scratch_bytes_bd10(void);
 extern "C" int hevcdl_rd_waves_per_group(void);
+extern "C" __global__ void hevcdl_rd_frame_kernel_wide(hevcdl_rd_params p);       // rd_kernel_wide.hip: the 8-bit kernel with more wavefronts per workgroup
+extern "C" size_t hevcdl_rd_smem_bytes_wide(void);
+extern "C" size_t hevcdl_rd_scratch_bytes_wide(void);
+extern "C" int hevcdl_rd_waves_per_group_wide(void);
 
 // 10-bit samples -> the 8-bit planes the CNN stage reads (the reference's label producer works on 8-bit frames: gen_frames.py)
 __global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, size_t n, int shift)
@@ -45,7 +49,8 @@ struct hevcdl_ctx {
   int col_bd[21], row_bd[23];    // tile boundaries in CTUs
   size_t frame_bytes;
   float *d_weights;
-  unsigned char *d_scratch;      // decision kernel workspace: one block per wave of every workgroup a launch can have
+  unsigned char *d_scratch;      // decision kernel workspace: one block per wave of every workgroup of a launch; allocated by the first launch that needs it, grown when a later one needs more (ensure_scratch)
+  size_t scratch_bytes;
   size_t scratch_per_wave; int rd_groups, remote_groups;   // workgroups of a launch: one per CU, fewer when the context cannot hold that many units
   // staging buffers for the host-pointer entry points
   uint8_t *d_yuv, *d_labels, *d_recon; unsigned char *d_records, *d_stats; float *d_logits; uint8_t *d_rgb; size_t rgb_cap;
@@ -200,7 +205,8 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if ((cfg->bit_depth != 8 && cfg->bit_depth != 10) || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
       cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
       cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA) ||
-      (cfg->exec_flags & ~HEVCDL_EXEC_NO_UNIT_HANDOVER))
+      (cfg->exec_flags & ~(HEVCDL_EXEC_NO_UNIT_HANDOVER | HEVCDL_EXEC_RD_WIDE | HEVCDL_EXEC_RD_NARROW)) ||
+      ((cfg->exec_flags & HEVCDL_EXEC_RD_WIDE) && (cfg->exec_flags & HEVCDL_EXEC_RD_NARROW)))
     return HEVCDL_ERR_UNSUPPORTED;
   { // tiles: uniform spacing, every column at least 4 CTUs wide and every row 1 CTU high (TComPicSym.cpp:380-392), at most 20 x 22 (level 6.2)
     const int cx = (cfg->width + 63) >> 6, cy = (cfg->height + 63) >> 6;
@@ -219,7 +225,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   ctx->frame_bytes = hevcdl_frame_bytes_bd(cfg->width, cfg->height, cfg->bit_depth);
   hevcdl_tile_bounds(ctx->ctus_x, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, 1, ctx->col_bd);
   hevcdl_tile_bounds(ctx->ctus_y, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, ctx->row_bd);
-  ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
+  ctx->d_weights = nullptr; ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; ctx->d_yuv = ctx->d_labels = ctx->d_recon = nullptr; ctx->d_records = ctx->d_stats = nullptr;
   ctx->d_logits = nullptr; ctx->d_yuv8 = nullptr; ctx->d_a3 = nullptr; ctx->a3_ctus = 0; ctx->d_picture = nullptr; ctx->h_chunk[0] = ctx->h_chunk[1] = nullptr; ctx->h_chunk_bytes = 0; ctx->copy_stream = nullptr; ctx->copy_ev[0] = ctx->copy_ev[1] = nullptr; ctx->d_rgb = nullptr; ctx->rgb_cap = 0; ctx->stream = nullptr; ctx->d_cabac = nullptr; ctx->session_frames = 0; ctx->d_sao_stats = ctx->d_sao_recon = ctx->d_sao_params = ctx->d_sao_cand = nullptr; ctx->d_wide = nullptr; ctx->d_flag = nullptr; ctx->d_sched = nullptr;
   hipError_t e;
 #define CK(call) if ((e = (call)) != hipSuccess) { hevcdl_status s_ = (e == hipErrorOutOfMemory) ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP; hevcdl_destroy(ctx); return s_; }
@@ -244,11 +250,12 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (cfg->bit_depth > 8) CK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(cfg->width, cfg->height) * (size_t)cfg->max_frames));    // the CNN stage's 8-bit copy
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
-  ctx->scratch_per_wave = cfg->bit_depth == 8 ? hevcdl_rd_scratch_bytes() : hevcdl_rd_scratch_bytes_bd10();
+  ctx->scratch_per_wave = cfg->bit_depth == 8 ? std::max(hevcdl_rd_scratch_bytes(), hevcdl_rd_scratch_bytes_wide()) : hevcdl_rd_scratch_bytes_bd10();
   ctx->rd_groups = (int)std::min<long long>(ctx->n_cus, (long long)cfg->max_frames * cfg->tile_columns * cfg->tile_rows);
   // (launches of few units run on every CU: the workgroups without a unit take second luma passes from the others, launch_rd -- they need a workspace too)
   ctx->remote_groups = (cfg->bit_depth == 8 && !(cfg->exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) && ctx->n_cus >= 8 && ctx->n_cus <= 1024) ? ctx->n_cus : 0;
-  CK(hipMalloc(&ctx->d_scratch, ctx->scratch_per_wave * (size_t)std::max(ctx->rd_groups, ctx->remote_groups) * hevcdl_rd_waves_per_group()));
+  // (the workspace itself -- 1.6 MB per wave -- is sized by the launches: a context that only ever codes a frame or two in the independent form holds a few MB, not the
+  // several GB a launch on every CU needs)
   CK(hipFuncSetAttribute((const void *)hevcdl_cnn_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_cnn_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_fc_smem_bytes()));
   { // conv -> head hand-over buffer for one chunk of CTUs, allocated up front so that no step pays for it
@@ -257,6 +264,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   }
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_bd10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_bd10()));
+  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_wide()));
 #undef CK
   *out = ctx;
   return HEVCDL_OK;
@@ -384,7 +392,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
 #endif
   // One workgroup (hevcdl_rd_waves_per_group() wavefronts, the whole LDS) per CU; the units (frame x tile) are dealt round-robin to the
   // workgroups, a wave per unit; waves left without a unit help the others (rd_kernel.hip).
-  const int n_units = n_frames * p.tile_count, groups = std::min(n_units, ctx->rd_groups), threads = 64 * hevcdl_rd_waves_per_group();
+  const int n_units = n_frames * p.tile_count, groups = std::min(n_units, ctx->rd_groups);
   // Uneven dealing (e.g. 600 frames on 256 workgroups): the surplus units travel round the ring of workgroups so that every workgroup --
   // and every frame -- is crowded for the same share of the time (rd_kernel.hip, process_unit).  Only for whole-unit launches of a few units
   // per workgroup.
@@ -405,17 +413,42 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // posted only while a taker is free (rd_kernel.hip, remote_room)
   if (p.remote && 2 * n_units > ctx->remote_groups) p.remote = 3;
   if (p.remote && 16 * n_units <= ctx->remote_groups) p.remote = 2;    // very few units: enough idle workgroups for the chroma modes of every master as well
+  // the ring of posted jobs has 512 entries (rd_kernel.hip RQ_SIZE): a unit has at most two passes posted, in the last form its five chroma modes as well
+  if (p.remote && (p.remote == 2 ? 7 : 2) * n_units > 512) p.remote = 0;
   if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 8192, s));      // finished counter, queue head / tail, the ring
+  // Which build of the 8-bit kernel.  The ten-wave build (rd_kernel_wide.hip) pays where it brings more MASTERS onto a CU, i.e. when the launch has more units than
+  // the eight-wave build has waves: measured at 2160p on 256 CUs, 2560 frames 22.3 -> 19.5 s (+14 %; against the eight-wave build's best case, 2048 frames, +7 % per
+  // frame).  Extra HELPERS do not pay: 600 frames (2-3 masters per workgroup) 6.40 -> 6.55 s, 2048 frames 16.75 -> 17.0 s -- a round of the wide build lasts 1.17 x as
+  // long (168 registers per lane instead of 256), so it is chosen when it needs fewer rounds by more than that factor.
+  bool wide = false;
+  if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW)) {
+    const long long slots_n = (long long)groups * hevcdl_rd_waves_per_group(), slots_w = (long long)groups * hevcdl_rd_waves_per_group_wide();
+    const long long rounds_n = (n_units + slots_n - 1) / slots_n, rounds_w = (n_units + slots_w - 1) / slots_w;
+    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && !p.migrate && 7 * rounds_w < 6 * rounds_n);
+  }
+  if (wide) p.remote = 0;
+  const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
+  const int threads = 64 * waves;
+  const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (const void *)hevcdl_rd_frame_kernel) : (const void *)hevcdl_rd_frame_kernel_bd10;
+  const size_t smem = ctx->cfg.bit_depth == 8 ? (wide ? hevcdl_rd_smem_bytes_wide() : hevcdl_rd_smem_bytes()) : hevcdl_rd_smem_bytes_bd10();
+  { // the workspace: one block per wave of every workgroup of this launch
+    const size_t need = ctx->scratch_per_wave * (size_t)(p.remote ? ctx->remote_groups : groups) * (size_t)waves;
+    if (need > ctx->scratch_bytes) {
+      if (ctx->d_scratch) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
+      if (hipMalloc(&ctx->d_scratch, need) != hipSuccess) { (void)hipGetLastError(); ctx->d_scratch = nullptr; return HEVCDL_ERR_OOM; }
+      ctx->scratch_bytes = need;
+    }
+    p.scratch = ctx->d_scratch;
+  }
   prof_begin(ctx, ctx->ev_rd, s);
-  const void *kern = ctx->cfg.bit_depth == 8 ? (const void *)hevcdl_rd_frame_kernel : (const void *)hevcdl_rd_frame_kernel_bd10;
-  const size_t smem = ctx->cfg.bit_depth == 8 ? hevcdl_rd_smem_bytes() : hevcdl_rd_smem_bytes_bd10();
   if (p.migrate || p.remote) { // workgroups that wait for each other: a cooperative launch, which the runtime only accepts when the whole grid can be resident at once
     void *args[] = { &p };
     if (hipLaunchCooperativeKernel(kern, dim3(p.remote ? ctx->remote_groups : groups), dim3(threads), args, smem, s) != hipSuccess) { (void)hipGetLastError(); p.migrate = 0; p.remote = 0; }
   }
   if (!p.migrate && !p.remote) {
-    if (ctx->cfg.bit_depth == 8) hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), smem, s, p);
-    else hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), smem, s, p);
+    if (ctx->cfg.bit_depth != 8) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), smem, s, p);
+    else if (wide) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_wide, dim3(groups), dim3(threads), smem, s, p);
+    else hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), smem, s, p);
   }
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());

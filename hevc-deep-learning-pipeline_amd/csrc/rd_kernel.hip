@@ -39,7 +39,11 @@
 #endif
 #if HEVCDL_BD == 8
 typedef uint8_t pel_t;
+#ifdef HEVCDL_RD_WIDE
+#define RD_SYM(name) name##_wide      // rd_kernel_wide.hip: more wavefronts per workgroup (launches with a unit for most CUs)
+#else
 #define RD_SYM(name) name
+#endif
 #else
 typedef uint16_t pel_t;
 #define RD_SYM(name) name##_bd10
@@ -56,7 +60,15 @@ constexpr int NPEND = BD == 8 ? 2 : 1;                         // second luma pa
 #define HEVCDL_AHEAD 1
 #endif
 constexpr int AHEAD = (BD == 8 && HEVCDL_AHEAD) ? 1 : 0;       // first-pass candidates of the NEXT CU coded during this CU's chroma search (est_intra_chroma); needs one more region per wave
-constexpr int NREG = 1 + NPEND + AHEAD;                        // regions per wave: [0] first pass / chroma / rough-mode slices, [1..NPEND] the second passes (master: their tickets; chain owner: [1] its split tasks), [REG_AHEAD] the look-ahead
+#ifdef HEVCDL_MICRO_SMALL
+// -DHEVCDL_MICRO -DHEVCDL_MICRO_SMALL -DHEVCDL_NW=12|16: the occupancy experiment of tools/micro_rd.py.  Only hevcdl_micro_kernel of such a library may be launched: the
+// LDS block of a wave is cut down to what the leaf routines of a TU coding touch (so that 12 / 16 waves fit a CU) and the search functions index beyond it.
+constexpr int MSM = 1;
+constexpr int NREG = 1;
+#else
+constexpr int MSM = 0;
+constexpr int NREG = 1 + NPEND + AHEAD;
+#endif                        // regions per wave: [0] first pass / chroma / rough-mode slices, [1..NPEND] the second passes (master: their tickets; chain owner: [1] its split tasks), [REG_AHEAD] the look-ahead
 constexpr int REG_AHEAD = 1 + NPEND;
 constexpr int NSLOT = 20;                                     // result slots of a master: 0..9 first pass, 5..9 chroma, then one set of 5 per second pass that can be pending
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
@@ -67,7 +79,8 @@ constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while 
 constexpr int LOG_AHEAD = 68, LOG_AHEAD_N = 17;               // entries 68..84: the master's context as the look-ahead candidates see it (ahead_open)
 constexpr int LOG_JOB = LOG_AHEAD + LOG_AHEAD_N, LOG_JOB_N = 1 + LOG_AHEAD_N;   // per pending second pass: its job block when another workgroup runs it (remote_post): header entry + context snapshot
 constexpr int LOG_CJOB = LOG_JOB + NPEND * LOG_JOB_N, LOG_CJOB_N = 5 + LOG_AHEAD_N + 1;   // the five chroma modes of the CU under test as jobs for other workgroups: five headers, one context (+ the coder state they start from)
-constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_CJOB + LOG_CJOB_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
+constexpr int LOG_COLD = LOG_CJOB + LOG_CJOB_N, LOG_COLD_N = 16;   // what a wave touches too rarely to keep in LDS: the coder snapshots next[4] / temp[4] (the CU walk, masters only) and test[4] (unsplit-vs-split of a first-pass TU), 21 words each, then the saved arrays of the best candidate (4 x 256 bytes)
+constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_COLD + LOG_COLD_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
 constexpr int SCR_RDOQ = 16384 + 16384;
 constexpr int SLOT_BYTES = (LAYER_SET + 2048 + 2047) & ~2047;   // layer set, 1 KB of attribute arrays, coder state in (168 B at +1024) / out (+1280)
@@ -187,10 +200,10 @@ struct __attribute__((aligned(16))) RdSmem {
   GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save; GLB unsigned char *my_slots; GLB unsigned long long *my_log;
   int bound_reg, bound_child;          // a T_LUMA_SPLIT task under way: the chain owner's wave (its region [1] holds the chain's answers) and the child it is the split alternative of (recur_luma's early exit); -1: none
   int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task (value: the region that holds its ticket); joined in check_rd_cost_intra or left pending
-  Cabac go, curr[4], next[4], temp[4], root[5], test[4], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4)
-  uint8_t a[11][256];                 // attribute arrays of the current CTU (flushed to the record at CTU end)
-  int16_t line[264], fline[264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
-  int16_t cline[2][132];              // chroma reference samples (n <= 32, never filtered in 4:2:0)
+  Cabac go, curr[MSM ? 1 : 4], root[MSM ? 1 : 5], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4); next[] / temp[] / test[] live in the wave's HBM workspace (cold_state)
+  uint8_t a[11][MSM ? 16 : 256];      // attribute arrays of the current CTU (flushed to the record at CTU end)
+  int16_t line[MSM ? 8 : 264], fline[MSM ? 8 : 264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
+  int16_t cline[2][MSM ? 4 : 132];    // chroma reference samples (n <= 32, never filtered in 4:2:0)
   // the reference lines are kept across consecutive TU codings of the same block (candidate modes of one PU share
   // their neighbours): key = (log2 n, y, x) of the block each line currently holds, -1 = none
   int ref_key[3], fline_key;
@@ -202,8 +215,7 @@ struct __attribute__((aligned(16))) RdSmem {
   // quantised levels of the current TU (raster); the transform intermediate (row stride n+1) lives behind the first 16
   // entries, i.e. a 4x4 block of levels survives the inverse transform (transform-skip bookkeeping needs it)
   int16_t lvl[16 + 32 * 33];
-  pel_t pred[1024];                 // prediction, then reconstruction, of the current TU
-  uint8_t sv[4][256];                 // saved best candidate: luma search trIdx / cbf / tskip in [0..2]; chroma search (later, disjoint in time) cbf Cb, Cr, tskip Cb, Cr
+  pel_t pred[MSM ? 16 : 1024];     // prediction, then reconstruction, of the current TU
   pel_t ts_pred[3][16], ts_rec[3][16]; int16_t ts_coef[3][16];
   unsigned int rd_list[16];
   unsigned int bc_u32[4];             // lane-0 -> wave broadcasts
@@ -1918,6 +1930,12 @@ DEV void region_wait(LRegion &r, int n)
 }
 DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()]; wsync(); }
 DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
+DEV void state_copy_global(GLB unsigned long long *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = src[lane_id()]; wsync(); }
+// the executing wave's cold coder snapshots and saved candidate arrays (its HBM workspace: LOG_COLD)
+enum { COLD_NEXT = 0, COLD_TEMP = 4, COLD_TEST = 8 };
+DEV GLB unsigned long long *cold_state(int which, int depth) { return lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + (size_t)(which + depth) * 21; }
+DEV GLB uint8_t *cold_sv(int c) { return (GLB uint8_t *)(lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + 12 * 21) + c * 256; }   // saved best candidate: luma search trIdx / cbf / tskip in [0..2]; chroma search (later, disjoint in time) cbf Cb, Cr, tskip Cb, Cr
+static_assert(12 * 21 * 8 + 4 * 256 <= LOG_COLD_N * LEAF_LOG, "cold area");
 struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
 template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_);
 DEVN int region_claim(LRegion &r);
@@ -1978,7 +1996,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
   if constexpr (LOG2 > 2) {
     if (check_split) {
       if (memo) { }
-      else if (check_full) { cabac_copy(k, &s.test[full_depth], &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
+      else if (check_full) { state_to_global(cold_state(COLD_TEST, full_depth), &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
       else cabac_copy(k, &s.root[full_depth], &s.go);
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       unsigned long long split_cfrac = 0;
@@ -2017,9 +2035,9 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       }
       if (memo) { // the saved best candidate of the first pass IS the unsplit coding (sv_* / best_rec, est_intra_luma)
         wsync();
-        for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = s.sv[0][i]; s.a[A_CBF][zabs + i] = s.sv[1][i]; s.a[A_TSKIP][zabs + i] = s.sv[2][i]; }
+        for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = cold_sv(0)[i]; s.a[A_CBF][zabs + i] = cold_sv(1)[i]; s.a[A_TSKIP][zabs + i] = cold_sv(2)[i]; }
       } else {
-        cabac_copy(k, &s.go, &s.test[full_depth]);
+        state_from_global(&s.go, cold_state(COLD_TEST, full_depth));
         set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
         set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
         set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
@@ -2652,7 +2670,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         wsync();
         for (int i = lane_id(); i < pu_parts; i += 64) {
           const uint8_t t0 = at[i], t1 = at[256 + i], t2 = at[512 + i];
-          s.sv[0][i] = t0; s.sv[1][i] = t1; s.sv[2][i] = t2;
+          cold_sv(0)[i] = t0; cold_sv(1)[i] = t1; cold_sv(2)[i] = t2;
           s.a[A_TRIDX][zp + i] = t0; s.a[A_CBF][zp + i] = t1; s.a[A_TSKIP][zp + i] = t2;
         }
         wsync();
@@ -2714,7 +2732,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         best_dist = dc.dist; best_cost = dc.cost;
         set_result_cu(k, cu, ptu, 0, k.coef_l, k.rec_l, k.lz, k.lx, k.ly);
         for (int i = lane_id(); i < pu_parts; i += 64) {
-          s.sv[0][i] = s.a[A_TRIDX][zp + i]; s.sv[1][i] = s.a[A_CBF][zp + i]; s.sv[2][i] = s.a[A_TSKIP][zp + i];   // the luma search leaves chroma entries alone
+          cold_sv(0)[i] = s.a[A_TRIDX][zp + i]; cold_sv(1)[i] = s.a[A_CBF][zp + i]; cold_sv(2)[i] = s.a[A_TSKIP][zp + i];   // the luma search leaves chroma entries alone
         }
         wsync();
       }
@@ -2722,7 +2740,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     overall += best_dist;
     wsync();
     for (int i = lane_id(); i < pu_parts; i += 64) {
-      s.a[A_TRIDX][zp + i] = s.sv[0][i]; s.a[A_CBF][zp + i] = s.sv[1][i]; s.a[A_TSKIP][zp + i] = s.sv[2][i];
+      s.a[A_TRIDX][zp + i] = cold_sv(0)[i]; s.a[A_CBF][zp + i] = cold_sv(1)[i]; s.a[A_TSKIP][zp + i] = cold_sv(2)[i];
     }
     if (pu != npu - 1) {
       GLB pel_t *rp = k.rec[0] + (size_t)ptu.y * k.W + ptu.x; GLB const pel_t *br = k.best_rec + boff(k, 0, ptu.x, ptu.y);
@@ -3194,14 +3212,14 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
       if (lane_id() == 0) { s.cw_cfrac = r.cfrac[win]; s.cw_slot = SLOT_CHROMA + win; }
       GLB const uint8_t *at = slot_attr(k.slots, SLOT_CHROMA + win);
       wsync();
-      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 4; c++) s.sv[c][i] = at[c * 256 + i];
+      for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 0; c < 4; c++) cold_sv(c)[i] = at[c * 256 + i];
       wsync();
       for (int c = 1; c < 3; c++) set_result_cu(k, cu, root, c, slot_coef(k.slots, SLOT_CHROMA + win), slot_rec(k.slots, SLOT_CHROMA + win), cu.zbase * 16, cu.x, cu.y);   // a chroma slot's origin is the CU
     }
     region_close(r);
   }
   wsync();
-  for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = s.sv[c - 1][i]; s.a[A_TSKIP + c][cu.zbase + i] = s.sv[c + 1][i]; }
+  for (int i = lane_id(); i < cu.nparts; i += 64) for (int c = 1; c < 3; c++) { s.a[A_CBF + c][cu.zbase + i] = cold_sv(c - 1)[i]; s.a[A_TSKIP + c][cu.zbase + i] = cold_sv(c + 1)[i]; }
   set_parts(k, s.a[A_CDIR], cu.zbase, cu.nparts, (int)best_mode);
   cabac_copy(k, &s.go, &s.curr[cu.depth]);
   MT(19);
@@ -3305,7 +3323,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
     if (part == SIZE_2Nx2N && cu.log2 <= 5 && uni(s.lw_valid) && uni(s.a[A_TRIDX][cu.zbase]) == 0)          // one TU per component, winners known: the short form
       enc_cu_syntax_fast(k, &s.go, cu, s.my_log + 65 * (LEAF_LOG / 8), slot_state(k.slots, uni(s.cw_slot), 1), uni64(s.lw_cfrac) + uni64(s.cw_cfrac));
     else enc_cu_syntax(k, &s.go, cu);
-    cabac_copy(k, &s.temp[cu.depth], &s.go);
+    state_to_global(cold_state(COLD_TEMP, cu.depth), &s.go);
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
     MT(22);
     TL(11, 0);
@@ -3403,7 +3421,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
       if (li < uni(s.replay_upto)) { // walked before and final: its result and the coder state behind it from the log
         const unsigned long long w0 = lg[0], w1 = lg[1], w23 = lg[23];
         best.cost = __longlong_as_double((long long)uni64(w0)); best.bits = (uint32_t)uni((int)(unsigned)w1); best.dist = (uint32_t)uni((int)(unsigned)(w1 >> 32));
-        state_from_global(&s.next[DEPTH], lg + 2);
+        state_copy_global(cold_state(COLD_NEXT, DEPTH), lg + 2);
         if (lane_id() == 0) s.ctu_frac += w23;
       } else {
         // a pending pass that has finished meanwhile is joined right away: a restart costs the less the earlier it is seen
@@ -3419,32 +3437,32 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         wsync();
         Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N, li == uni(s.nocarry_leaf) ? uni(s.resume_reg) : 0);
         if (uni(s.restart)) return t;
-        if (ub(t.cost < best.cost)) { best = t; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); best_is_real = 1; }
+        if (ub(t.cost < best.cost)) { best = t; state_copy_global(cold_state(COLD_NEXT, DEPTH), cold_state(COLD_TEMP, DEPTH)); best_is_real = 1; }
         if (DEPTH == 3) {
           save_cand8(k, cu);
           Rd t2 = check_rd_cost_intra(k, cu, SIZE_NxN);
-          if (ub(t2.cost < best.cost)) { best = t2; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+          if (ub(t2.cost < best.cost)) { best = t2; state_copy_global(cold_state(COLD_NEXT, DEPTH), cold_state(COLD_TEMP, DEPTH)); }
           else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
         }
         wsync();
         if (lane_id() == 0) {
           // what this CU's syntax cost in fractional bits: its count started from the fraction of the CU's entry state (reset_bits keeps the low 15 bits)
-          const unsigned long long sf = s.next[DEPTH].frac - (s.curr[DEPTH].frac & 32767ull);
+          const unsigned long long sf = cold_state(COLD_NEXT, DEPTH)[offsetof(Cabac, frac) / 8] - (s.curr[DEPTH].frac & 32767ull);
           lg[0] = (unsigned long long)__double_as_longlong(best.cost); lg[1] = (unsigned long long)best.bits | ((unsigned long long)best.dist << 32); lg[23] = sf;
           s.ctu_frac += sf;
         }
-        state_to_global(lg + 2, &s.next[DEPTH]);
+        state_copy_global(lg + 2, cold_state(COLD_NEXT, DEPTH));
         TL(12, 0);
       }
     } else { best.cost = MAX_DOUBLE / 16; best.dist = 0xffffffffu >> 3; best.bits = 0xffffffffu >> 3; }
     // split flag of the unsplit candidate (:858-867); for the dummy candidate the loaded state is stale and irrelevant
-    cabac_copy(k, &s.go, &s.next[DEPTH]);
+    state_from_global(&s.go, cold_state(COLD_NEXT, DEPTH));
     const int sctx = (DEPTH < 3) ? split_ctx(k, x, y, DEPTH) : 0;
     if (lane_id() == 0) { reset_bits(&s.go); if (DEPTH < 3) enc_bin(&s.go, CTX_SPLIT + sctx, 0); }
     wsync();
     best.bits += (uint32_t)uni((int)get_bits(&s.go));
     best.cost = calc_rd_cost(k, best.bits, best.dist);
-    cabac_copy(k, &s.next[DEPTH], &s.go);
+    state_to_global(cold_state(COLD_NEXT, DEPTH), &s.go);
   }
   if (best_is_real) for (int c = uni(s.left_pending) ? 1 : 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093 (luma stays with a pass that is still running)
   if constexpr (DEPTH < 3) {
@@ -3453,7 +3471,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
       if (ub(sx < k.W && sy < k.H)) {
-        cabac_copy(k, &s.curr[DEPTH + 1], (i == 0) ? &s.curr[DEPTH] : &s.next[DEPTH + 1]);
+        if (i == 0) cabac_copy(k, &s.curr[DEPTH + 1], &s.curr[DEPTH]); else state_from_global(&s.curr[DEPTH + 1], cold_state(COLD_NEXT, DEPTH + 1));
         Rd sub;
         if (check_next) sub = compress_cu<DEPTH + 1>(k, sx, sy);
         else { sub.cost = MAX_DOUBLE / 16; sub.dist = 0xffffffffu >> 3; sub.bits = 0xffffffffu >> 3; }
@@ -3469,7 +3487,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         wsync();
       }
     }
-    cabac_copy(k, &s.go, &s.next[DEPTH + 1]);
+    state_from_global(&s.go, cold_state(COLD_NEXT, DEPTH + 1));
     if (!boundary) {
       const int sctx = split_ctx(k, x, y, DEPTH);
       if (lane_id() == 0) { reset_bits(&s.go); enc_bin(&s.go, CTX_SPLIT + sctx, 1); }
@@ -3477,8 +3495,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
       temp.bits += (uint32_t)uni((int)get_bits(&s.go));
     }
     temp.cost = calc_rd_cost(k, temp.bits, temp.dist);
-    cabac_copy(k, &s.temp[DEPTH], &s.go);
-    if (ub(temp.cost < best.cost)) { best = temp; cabac_copy(k, &s.next[DEPTH], &s.temp[DEPTH]); }
+    if (ub(temp.cost < best.cost)) { best = temp; state_to_global(cold_state(COLD_NEXT, DEPTH), &s.go); }      // (the split's end state is in `go`)
   }
   return best;
 }
@@ -3543,7 +3560,7 @@ DEVN void advance_state(KR k, LCabac *truec, int x0_, int y0_)
     for (int i = 0; i < 21; i++) { const int v = s.cgf[i]; if (v & 8) enc_bin(truec, CTX_SPLIT + (v & 3), (v >> 2) & 1); }
     truec->frac += s.ctu_frac;
   }
-  for (int i = 3 + lane; i < NUM_CTX; i += 64) truec->ctx[i] = s.next[0].ctx[i];
+  { GLB const uint8_t *nx = (GLB const uint8_t *)cold_state(COLD_NEXT, 0); for (int i = 3 + lane; i < NUM_CTX; i += 64) truec->ctx[i] = nx[i]; }
   wsync();
 }
 
@@ -4013,7 +4030,7 @@ extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return (size_t)NW * sizeo
 extern "C" size_t RD_SYM(hevcdl_rd_scratch_bytes)(void) { return SCR_WAVE; }        // per wave
 extern "C" int RD_SYM(hevcdl_rd_waves_per_group)(void) { return NW; }
 
-#if defined(HEVCDL_MICRO) && HEVCDL_BD == 8
+#if defined(HEVCDL_MICRO) && HEVCDL_BD == 8 && !defined(HEVCDL_RD_WIDE)
 // -DHEVCDL_MICRO (tools/micro_rd.py; never in the product library): the leaf routines of a TU coding timed on their own, on synthetic residual blocks.
 // Every wave of every workgroup runs `reps` codings (what: 0 RDOQ, 1 the bit counter, 2 forward transform + RDOQ + bit counter + dequant + inverse);
 // out[wave] = { cycles inside the timed routine, checksum }.

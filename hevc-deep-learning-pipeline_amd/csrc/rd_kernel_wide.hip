@@ -1,0 +1,14 @@
+// The CTU-decision kernel with ten wavefronts per workgroup (8-bit samples): rd_kernel.hip compiled with HEVCDL_NW 10.
+// Exports hevcdl_rd_frame_kernel_wide, hevcdl_rd_smem_bytes_wide, hevcdl_rd_scratch_bytes_wide, hevcdl_rd_waves_per_group_wide.
+//
+// Why a second build: a wave of this kernel spends most of its cycles waiting on its own dependent operations (LDS round trips, ordered fp64 sums), so a CU's
+// throughput grows almost linearly with the waves resident on it (tools/micro_rd.py on the leaf routines of a TU coding: 8 -> 10 -> 12 waves per CU = +20 % -> +40 %
+// codings per cycle).  Residency is bound by LDS (a wave's private block) and by registers (512 per SIMD lane: 2 waves at 256, 3 at 168).
+// This build drops the look-ahead region (it only serves workgroups with ONE master: launches of few units, which keep the 8-wave kernel) and is held to 168
+// registers by its launch bound.  The whole kernel gains less than its leaves (2560 frames of 2160p: +7 % per frame over the 8-wave build at its best), and only through
+// more MASTERS per CU -- launch_rd (hevcdl_api.hip) picks it for launches with more units than the 8-wave build has waves.
+#define HEVCDL_NW 10
+#define HEVCDL_AHEAD 0
+#define HEVCDL_RD_WIDE 1
+#undef HEVCDL_KERNEL_PROF       // the in-kernel timers belong to the 8-wave build (no LDS to spare here)
+#include "rd_kernel.hip"

@@ -44,6 +44,28 @@ def test_golden_records_bit_exact(path):
             assert np.array_equal(y, f["rec_y"][fr, a]) and np.array_equal(u, f["rec_cb"][fr, a]) and np.array_equal(v, f["rec_cr"][fr, a]), (fr, a)
 
 
+@pytest.mark.parametrize("flags", [2, 4], ids=["ten-wave-build", "eight-wave-build"])
+@pytest.mark.parametrize("path", [p for p in sorted(glob.glob(os.path.join(GOLD, "rd_*.npz"))) if not os.path.basename(p).startswith("rd_x") and "_b10" not in os.path.basename(p)], ids=lambda p: os.path.basename(p)[3:-4])
+def test_golden_records_bit_exact_on_either_build_of_the_kernel(path, flags):
+    """The 8-bit decision kernel exists in two builds (8 wavefronts per workgroup with the look-ahead of the few-units form; 10 without it, csrc/rd_kernel_wide.hip) and the
+    library picks by the shape of the launch -- small fixtures would only ever meet one of them.  exec_flags HEVCDL_EXEC_RD_WIDE (2) / HEVCDL_EXEC_RD_NARROW (4) force a build:
+    both must reproduce every reference fixture."""
+    import hevcdl_amd
+    f = np.load(path)
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    yuv, labels, ref = f["yuv"], f["labels"], f["records"]
+    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=yuv.shape[0], tiles=fixture_tiles(f))
+    cfg.exec_flags = flags
+    enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    assert_records_equal(recs, ref, os.path.basename(path))
+    for fr in range(yuv.shape[0]):
+        for a in range(labels.shape[1]):
+            y, u, v = ctu_blocks(recon[fr], w, h, a)
+            assert np.array_equal(y, f["rec_y"][fr, a]) and np.array_equal(u, f["rec_cb"][fr, a]) and np.array_equal(v, f["rec_cr"][fr, a]), (fr, a)
+
+
 def test_whole_1080p_frame_matches_the_reference_golden():
     """Full-size parity against the reference itself: one 1920x1080 frame (510 CTUs), records bit for bit and the reconstruction of every CTU
     by checksum (tests/golden/full_f1080_q32.npz: a run of the reference encoder, oracle/gen_fixtures.py gen_full)."""
@@ -246,17 +268,18 @@ def test_few_units_form_equals_the_independent_form(nf, tiles):
     rng = np.random.default_rng(9)
     yuv = np.stack([np.clip(base[i % 4].astype(np.int16) + rng.integers(-3, 4, base.shape[1]) * (i // 4), 0, 255).astype(np.uint8) for i in range(nf)])
     out = []
-    for flags in (0, 1):
+    for flags in (0, 1, 1 | 4, 2):                          # few-units form (8 waves) | independent, the library's choice (10 waves) | independent, 8 waves | 10 waves forced
         cfg = hevcdl_amd.default_config(w, h, qp, max_frames=nf, tiles=tiles)
         cfg.exec_flags = flags
         enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
         labels = enc.predict_depth(yuv)
         out.append(enc.compress_frames(yuv, labels))
         enc.close()
-    assert_records_equal(out[0][0], out[1][0], "few-units form vs independent form")
-    assert np.array_equal(out[0][1], out[1][1])
-    for k in ("sse", "est_bits", "ctus"):
-        assert np.array_equal(out[0][2][k], out[1][2][k]), k
+    for o in out[1:]:
+        assert_records_equal(out[0][0], o[0], "few-units form vs independent form")
+        assert np.array_equal(out[0][1], o[1])
+        for k in ("sse", "est_bits", "ctus"):
+            assert np.array_equal(out[0][2][k], o[2][k]), k
 
 
 def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built):

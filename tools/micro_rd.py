@@ -38,12 +38,13 @@ def run(lib, n, what, active, amp, reps, groups=256, comp=0, mode=1, qp=32):
     consts = (ctypes.c_double * 12)(cfg.lambda_, cfg.sqrt_lambda, cfg.chroma_weight, cfg.lambda_chroma, *[cfg.err_scale[a][b] for a in range(2) for b in range(4)])
     sbh = (ctypes.c_longlong * 2)(cfg.sbh_rd_factor[0], cfg.sbh_rd_factor[1])
     res = blocks(n, amp) if amp > 0 else np.ascontiguousarray(np.load(DATA)["n%d" % n])
-    out = np.zeros(groups * 8 * 2 + 16, np.uint64)
+    nw = lib.hevcdl_rd_waves_per_group()
+    out = np.zeros(groups * nw * 2 + 16, np.uint64)
     rc = lib.hevcdl_micro_run(consts, sbh, qp, cfg.qp_chroma, res.ctypes.data_as(ctypes.c_void_p), res.shape[0], n, comp, mode, reps, what | (active << 8), groups, out.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, rc
     global PHASES
-    PHASES = out[groups * 8 * 2:groups * 8 * 2 + 11].astype(np.float64) / reps
-    o = out[:groups * 8 * 2].reshape(-1, 2)
+    PHASES = out[groups * nw * 2:groups * nw * 2 + 11].astype(np.float64) / reps
+    o = out[:groups * nw * 2].reshape(-1, 2)
     live = o[:, 0] > 0
     return float(o[live, 0].mean()) / reps, float(o[live, 1].mean()) / reps, int(o[:, 1].sum() % (1 << 32))
 
@@ -67,7 +68,8 @@ if __name__ == "__main__":
         for what in (0, 1, 2):
             c8, s8, ck8 = run(lib, n, what, 0, amp, reps)
             c1, s1, ck1 = run(lib, n, what, 1, amp, reps)
-            print("n %2d  %-18s  8 waves/CU %8.0f   1 wave/CU %8.0f   sum %9.1f  check %08x" % (n, names[what], c8, c1, s8, ck8), flush=True)
+            nw = lib.hevcdl_rd_waves_per_group()
+            print("n %2d  %-18s  %d waves/CU %8.0f   1 wave/CU %8.0f   sum %9.1f  check %08x   codings per Mcycle and CU at full occupancy %.1f" % (n, names[what], nw, c8, c1, s8, ck8, 1e6 * nw / c8), flush=True)
             if "--phases" in args and what == 0:      # -DHEVCDL_MICRO_T build: cycles per call and phase of rdoq_wave (one wave per CU, workgroup 0)
                 pn = ["A: rounded levels", "zero tail", "B: per-position", "B: level walk", "B: sums + group test", "B: batch end", "(B exit)", "C: last position", "signs + hiding"]
                 print("      " + "   ".join("%s %.0f" % (pn[i], PHASES[i]) for i in range(9)), flush=True)
