@@ -30,6 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_CTU = 27408        # orig 6144 + recon 6144 + levels 12288 + record 2816 + labels 16
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (no sparsity)
+# The convolutions of the label CNN per CTU (use_model.py:16-58; conv64 once per CTU, the other three per 32x32 quadrant), in multiply-accumulates:
+#   conv64 64x64 positions x 16 channels x 75 taps, conv1 4 x 32x32 x 16 x 75, conv2 4 x 16x16 x 64 x 288, conv3 4 x 8x8 x 128 x 576
+CNN_CONV_MACS = 64 * 64 * 16 * 75 + 4 * 32 * 32 * 16 * 75 + 4 * 16 * 16 * 64 * 288 + 4 * 8 * 8 * 128 * 576
+# what the kernel executes for them (csrc/cnn_kernel.hip): every product as three f16 MFMA products of split operands (hi*hi + hi*lo + lo*hi, f32 accumulate),
+# the 75 taps of the 5x5 layers padded to three k-steps of 32
+CNN_CONV_MACS_EXECUTED = 3 * ((64 * 64 * 16 + 4 * 32 * 32 * 16) * 96 + 4 * 16 * 16 * 64 * 288 + 4 * 8 * 8 * 128 * 576)
 RD_KERNEL_SRC = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "csrc", "rd_kernel.hip")
 
 
@@ -370,7 +377,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--frames", type=int, default=600, help="frames of the job (C4: 600), split over the ranks")
-    ap.add_argument("--saturated-frames", type=int, default=2048, help="extra single-GPU measurement with this many frames in flight (0: skip)")
+    ap.add_argument("--saturated-frames", type=int, default=2560, help="extra single-GPU measurement with this many frames in flight (0: skip); 2560 = one frame per wave of the ten-wave build on 256 CUs")
+    ap.add_argument("--no-projection", action="store_true", help="skip the 300 / 150 / 75-frame launches behind scale_projection / share_8gpu_s")
+    ap.add_argument("--no-label-check", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -450,7 +459,7 @@ def main():
         out = {
             "metric": "all-intra CTUs/s at 2160p QP32", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8/int32/f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "decisions: u8 samples / int32 transforms / f64 costs (the reference's arithmetic); label CNN: f16 hi/lo split operands x3 on MFMA, f32 accumulate (logits within 1e-3 of fp32)", "data": "synthetic",
             "config": {"workload": "%dx%d 8-bit 4:2:0 all-intra QP%d, %d frames%s, frame-sharded (contiguous blocks of %d frames per GPU), on-device CNN labels + depth-pruned CTU decisions"
                                    % (W, H, qp, F, " (C4 of BASELINE.json)" if is_c4 else "", per_rank),
                        "frames": F, "frames_per_gpu": per_rank, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
@@ -460,6 +469,35 @@ def main():
                          "units_per_launch": "%d frames x %d CTUs (rank 0)" % (Fr, ctus)},
             "est_bits_per_frame": total_bits / max(1, F),
         }
+        cnn_s = (prof["cnn_conv_ms"] / max(1, prof["cnn_launches"])) / 1e3 if "cnn_conv_ms" in prof else 0.0
+        if cnn_s > 0:    # the other stage, the other bound: the convolution kernel against the dense f16 MFMA peak
+            ex = 2.0 * CNN_CONV_MACS_EXECUTED * Fr * ctus / cnn_s / 1e12
+            us = 2.0 * CNN_CONV_MACS * Fr * ctus / cnn_s / 1e12
+            out["roofline_cnn"] = {"bound": "mfma", "kernel": "hevcdl_cnn_ctu_kernel", "operand": "f16 hi/lo split x3, f32 acc", "executed_tflops": ex, "useful_tflops": us,
+                                   "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / MFMA_F16_PEAK_TFLOPS, "kernel_ms": 1e3 * cnn_s,
+                                   "executed_mflop_per_ctu": 2e-6 * CNN_CONV_MACS_EXECUTED, "useful_mflop_per_ctu": 2e-6 * CNN_CONV_MACS,
+                                   "head_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]) - 1e3 * cnn_s,
+                                   "note": "executed = three MFMA products per multiply-accumulate and the 5x5 layers' 75 taps padded to 96; measured with HIP events on the launch stream over the timed steps"}
+        if world == 1 and is_c4 and not a.no_projection:
+            # What the frame-sharded job will take on N GPUs, from this GPU alone: a rank's share of the job is a launch of 600 / N frames (frames are independent, the
+            # only collective gathers 8 bytes per frame), timed here as one whole step (label CNN + decisions) each.  The driver's SCALE run can be checked against it.
+            proj = {1: elapsed / a.steps}
+            stream = torch.cuda.current_stream().cuda_stream
+            for n_gpu in (2, 4, 8):
+                share = len(sharding.shard_frames(F, n_gpu, 0))
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                enc.encode_frames_dev(yuv.data_ptr(), share, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)
+                torch.cuda.synchronize(dev)
+                proj[n_gpu] = time.perf_counter() - t1
+            out["scale_projection"] = {"seconds": {str(k): v for k, v in proj.items()}, "value": {str(k): F * ctus / v for k, v in proj.items()}, "unit": "CTUs/s",
+                                       "note": "seconds of one step over a rank's share of the 600 frames (600 / 300 / 150 / 75 frames), measured as single launches on this GPU; "
+                                               "N-GPU value = 1 224 000 CTUs / that time"}
+            out["share_8gpu_s"] = proj[8]
+            # (the shares' records / reconstruction equal what the whole job wrote for those frames: frames are independent, the kernel deterministic -- re-run the job's step so that
+            #  the legs below see the state of the timed job)
+            enc.encode_frames_dev(yuv.data_ptr(), Fr, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
         if floor_s:
             out["latency_floor_s"] = floor_s
             out["strong_scaling_ceiling"] = {"value": F * ctus / floor_s, "unit": "CTUs/s",
@@ -480,6 +518,15 @@ def main():
                 out["cpu_baseline"] = cb
                 if parity is not None:
                     out["parity_check"] = parity
+            if not a.no_label_check:      # the labels of the split-f16 MFMA kernel against the same graph in fp32 (checker: oracle/cnn_torch.py), outside the timed region
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import cnn_oracle
+                import cnn_torch
+                nl = min(Fr, 16)
+                t1 = time.perf_counter()
+                chk = cnn_torch.label_check(torch, cnn_oracle.load_weights(hevcdl_amd.WEIGHTS_PATH), yuv[:nl].cpu().numpy(), W, H, dev, labels[:nl].cpu().numpy())
+                chk["sample"] = "the first %d frames of the timed job, %.1f s" % (nl, time.perf_counter() - t1)
+                out["cnn_label_check"] = chk
             if not a.no_e2e:
                 out["e2e"] = e2e_leg(torch, hevcdl_amd, dev, enc, (yuv, labels, records, recon, stats), Fr, W, H, qp)
                 if "cpu_baseline" in out and out["cpu_baseline"].get("kind") == "reference":
@@ -496,7 +543,9 @@ def main():
                 t2 = alloc(torch, hevcdl_amd, dev, S, e2.frame_bytes, ctus)
                 el2, pr2 = timed_steps(torch, e2, (y2,) + t2, S, 1, 0, barrier)
                 out["saturated"] = {"frames_per_gpu": S, "value": S * ctus / el2, "unit": "CTUs/s", "ms_per_step": 1e3 * el2, "kernel_ms": pr2["rd_ms"], "cnn_kernel_ms": pr2["cnn_ms"],
-                                    "note": "one step, %d distinct frames repeated; not the headline: the job of BASELINE.json has 600 frames" % min(S, 64)}
+                                    "per_cu": S * ctus / el2 / torch.cuda.get_device_properties(dev).multi_processor_count,
+                                    "note": "one step, %d distinct frames repeated; a frame per wave of the ten-wave build of the decision kernel (csrc/rd_kernel_wide.hip); not the "
+                                            "headline: the job of BASELINE.json has 600 frames" % min(S, 64)}
                 del y2, t2
                 e2.close()
                 torch.cuda.empty_cache()

@@ -93,7 +93,7 @@ class StreamConfig(ctypes.Structure):
 
 
 class Profile(ctypes.Structure):
-    _fields_ = [("cnn_ms", ctypes.c_double), ("rd_ms", ctypes.c_double), ("cnn_launches", ctypes.c_uint32), ("rd_launches", ctypes.c_uint32)]
+    _fields_ = [("cnn_ms", ctypes.c_double), ("rd_ms", ctypes.c_double), ("cnn_launches", ctypes.c_uint32), ("rd_launches", ctypes.c_uint32), ("cnn_conv_ms", ctypes.c_double)]
 
 
 def build_ext(force=False, verbose=False, defines=(), out=None, extra_flags=()):
@@ -466,4 +466,4 @@ class Encoder:
     def profile_get(self):
         p = Profile()
         self._check(self.lib.hevcdl_profile_get(self._h, ctypes.byref(p)))
-        return {"cnn_ms": p.cnn_ms, "rd_ms": p.rd_ms, "cnn_launches": p.cnn_launches, "rd_launches": p.rd_launches}
+        return {"cnn_ms": p.cnn_ms, "rd_ms": p.rd_ms, "cnn_launches": p.cnn_launches, "rd_launches": p.rd_launches, "cnn_conv_ms": p.cnn_conv_ms}

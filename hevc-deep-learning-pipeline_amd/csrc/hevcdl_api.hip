@@ -66,7 +66,7 @@ struct hevcdl_ctx {
   int *d_flag;                   // device-side error flag of the label check
   unsigned char *d_sched;        // decision kernel: hand-over of units between workgroups (finished counter, per-workgroup unit counts, mailboxes)
   bool profile;
-  std::vector<hipEvent_t> ev_cnn, ev_rd;       // start/stop pairs
+  std::vector<hipEvent_t> ev_cnn, ev_rd, ev_conv;       // start/stop pairs (ev_conv: the convolution kernel alone, one pair per chunk of CTUs)
   char err[256];
 };
 
@@ -277,6 +277,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   hipDeviceSynchronize();
   for (hipEvent_t e : ctx->ev_cnn) hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_rd) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_conv) hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (ctx->h_chunk[i]) hipHostFree(ctx->h_chunk[i]); if (ctx->copy_ev[i]) hipEventDestroy(ctx->copy_ev[i]); }
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
@@ -287,6 +288,14 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
 extern "C" const char *hevcdl_last_error(const hevcdl_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
 
 // page-locked host memory for the buffers of the host-pointer entry points (optional: any host memory works, pinned memory copies faster)
+extern "C" hevcdl_status hevcdl_device_memory(int device, size_t *free_bytes, size_t *total_bytes)
+{
+  if (!free_bytes || !total_bytes) return HEVCDL_ERR_INVALID_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return HEVCDL_ERR_NO_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess) { (void)hipGetLastError(); return HEVCDL_ERR_HIP; }
+  return HEVCDL_OK;
+}
 extern "C" void *hevcdl_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 extern "C" void hevcdl_host_free(void *p) { if (p) hipHostFree(p); }
 
@@ -334,7 +343,9 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   for (size_t base = 0; base < (size_t)n_ctus; base += chunk) {
     const int n = (int)std::min<size_t>(chunk, (size_t)n_ctus - base);
     p.ctu_base = (int)base;
+    prof_begin(ctx, ctx->ev_conv, s);
     hipLaunchKernelGGL(hevcdl_cnn_ctu_kernel, dim3(n), dim3(256), hevcdl_cnn_smem_bytes(), s, p);
+    prof_end(ctx, ctx->ev_conv, s);
     f.n_ctus = n; f.ctu_base = (int)base; f.labels = (uint8_t *)d_labels + base * 16;
     f.logits = d_logits ? (float *)d_logits + base * 64 : nullptr;
 #ifdef HEVCDL_CNN_PROF
@@ -881,5 +892,8 @@ extern "C" hevcdl_status hevcdl_profile_get(hevcdl_ctx *ctx, hevcdl_profile *out
     v.clear();
     if (which) { out->rd_ms = ms; out->rd_launches = n; } else { out->cnn_ms = ms; out->cnn_launches = n; }
   }
+  { std::vector<hipEvent_t> &v = ctx->ev_conv; double ms = 0;
+    for (size_t i = 0; i + 1 < v.size(); i += 2) { float t = 0; if (hipEventElapsedTime(&t, v[i], v[i + 1]) == hipSuccess) ms += t; hipEventDestroy(v[i]); hipEventDestroy(v[i + 1]); }
+    v.clear(); out->cnn_conv_ms = ms; }
   return HEVCDL_OK;
 }

@@ -121,6 +121,7 @@ typedef struct hevcdl_frame_stats {
 typedef struct hevcdl_profile {
   double   cnn_ms, rd_ms;        /* accumulated kernel time measured with HIP events on the launch stream */
   uint32_t cnn_launches, rd_launches;
+  double   cnn_conv_ms;          /* of cnn_ms: the convolution kernel alone (the rest is the fully connected head), summed over the same launches */
 } hevcdl_profile;
 
 typedef struct hevcdl_ctx hevcdl_ctx;
@@ -263,6 +264,9 @@ hevcdl_status hevcdl_get_recon(hevcdl_ctx *ctx, int frame, uint8_t *recon);
 
 /* Page-locked host memory for the yuv / records / picture buffers handed to the host-pointer entry points (optional; ordinary memory works,
  * page-locked memory is copied at the DMA rate).  NULL when no GPU runtime is available. */
+/* free / total bytes of a device's memory (hipMemGetInfo): what a front end sizes cfg.max_frames by -- a picture of a call holds about 3 frame buffers, its CTU
+ * records (15 120 B per CTU), labels / logits and SAO parameters in HBM */
+hevcdl_status hevcdl_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
 void *hevcdl_host_alloc(size_t bytes);
 void hevcdl_host_free(void *p);
 

@@ -134,6 +134,32 @@ def test_cli_encode_matches_the_api(app, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp_path):
+    """--Devices: contiguous blocks of frames, one host thread and one context per entry, the per-picture rows (POC, bits, squared errors) gathered with
+    ncclAllGather from librccl, access units written in POC order.  Two entries naming the SAME device (what one GPU can test: two contexts side by side, the
+    library then keeps them from waiting on each other; RCCL runs with one rank per physical device) and three entries for five frames (uneven blocks) must give
+    the single-device bitstream, reconstruction file, record file, log lines and summary byte for byte."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_tools
+    w, h, nf, qp = 256, 192, 5, 30
+    ref_tools.synth_yuv(w, h, nf, seed=77).tofile(tmp_path / "in.yuv")
+    base = ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "--SEIDecodedPictureHash=1"]
+    outs = []
+    for tag, extra in (("one", []), ("two", ["--Devices=0,0"]), ("three", ["--Devices", "0,0,0", "--BatchFrames=1"])):
+        r = run(app, base + ["-b", tag + ".bin", "-o", tag + ".yuv", "--RecordFile=" + tag + ".rec"] + extra, tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        log = [l.rsplit(" [ET", 1)[0] + l[l.index("[MD5:"):] for l in r.stdout.splitlines() if l.startswith("POC")]
+        summary = r.stdout[r.stdout.index("SUMMARY"):]
+        outs.append(((tmp_path / (tag + ".bin")).read_bytes(), (tmp_path / (tag + ".yuv")).read_bytes(), (tmp_path / (tag + ".rec")).read_bytes(), log, summary, r.stdout))
+    assert len(outs[0][3]) == nf
+    for o in outs[1:]:
+        for k in range(5):
+            assert o[k] == outs[0][k], k
+    assert "Devices: 0 (frames 0..2) 0 (frames 3..4)" in outs[1][5] and "Devices: 0 (frames 0..1) 0 (frames 2..3) 0 (frames 4..4)" in outs[2][5]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
     """b416_q32_r is C1 of BASELINE.json (416x240, one frame, QP32, untiled 8-bit, the reference's default configuration); c192 / b200 are

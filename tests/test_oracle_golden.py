@@ -96,6 +96,25 @@ def test_cnn_oracle_matches_reference_logits_and_labels():
     assert np.array_equal(cnn_oracle.labels_from_logits(lg), f["labels"][:n])
 
 
+def test_torch_restatement_of_the_cnn_oracle_matches_it():
+    """oracle/cnn_torch.py (the fp32 checker bench.py's `cnn_label_check` leg runs on whole frames, where the numpy oracle would take hours) gives the numpy
+    oracle's logits on the CTUs of a small picture, and the same labels."""
+    import torch
+    import cnn_oracle
+    import cnn_torch
+    import ref_tools
+    import hevcdl_amd
+    w = cnn_oracle.load_weights(hevcdl_amd.WEIGHTS_PATH)
+    yuv = ref_tools.synth_yuv(192, 128, 1, seed=3)
+    rgb = cnn_oracle.yuv_to_rgb_ctus(yuv[0], 192, 128)
+    a = cnn_oracle.ctu_logits(w, rgb)
+    b = cnn_torch.ctu_logits(torch, cnn_torch.weights_to(torch, w, "cpu"), rgb).numpy()
+    assert np.abs(a - b).max() < 1e-4
+    assert np.array_equal(cnn_oracle.labels_from_logits(a), cnn_oracle.labels_from_logits(b))
+    chk = cnn_torch.label_check(torch, w, yuv, 192, 128, "cpu", cnn_oracle.predict_labels(w, yuv, 192, 128)[0])
+    assert chk["ctus"] == 6 and chk["labels_differing_from_fp32_oracle"] == 0
+
+
 def test_cnn_oracle_eval_mode_matches_reference_model_in_eval_mode():
     """The selectable eval-mode BatchNorm (running statistics of the checkpoint; tests/golden/cnn_f1_eval.npz from the reference model after
     model.eval(), oracle/gen_fixtures.py gen_cnn_eval)."""

@@ -81,8 +81,11 @@ def test_whole_1080p_frame_matches_the_reference_golden():
     enc.close()
     assert_records_equal(recs, f["records"], "full_f1080_q32")
     assert np.array_equal(full_frame_crc(recon[0], w, h, recs.shape[1]), f["recon_crc32"])
-    # the fixture's labels are the numpy CNN's; the device CNN agrees on (nearly) every CTU of this frame
-    assert (gpu_labels == f["labels"]).mean() > 0.99
+    # the fixture's labels are the numpy fp32 CNN's (report, do not just threshold): the device CNN -- split-f16 operands on the
+    # matrix cores -- may only differ where two logits of the fp32 graph are closer than its own error (tests/test_cnn_gpu.py bounds that at 1e-3)
+    diff_cells = int((gpu_labels != f["labels"]).sum()); diff_ctus = int((gpu_labels != f["labels"]).any(axis=2).sum())
+    print("CNN labels, device vs fp32 numpy oracle on full_f1080_q32: %d of %d CTUs differ (%d of %d cells)" % (diff_ctus, gpu_labels.shape[1], diff_cells, gpu_labels.size))
+    assert diff_ctus <= gpu_labels.shape[1] // 200, "%d CTUs carry other labels than the fp32 oracle's" % diff_ctus
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
@@ -124,6 +127,38 @@ def test_whole_2160p_frame_matches_a_live_reference_run():
     wall, per, dumps = bench.run_reference_pictures([yuv[0]], labels, w, h, qp, 1, dump=True)
     res = bench.parity_against_dumps(dumps, recs, [recon[0]], w, h)
     assert res["ctus"] == 2040 and res["mismatches"] == 0, res
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
+def test_c4_regime_launch_matches_live_reference_runs():
+    """The regime of the timed job of bench.py inside the suite: MORE frames than CUs in one launch (320 frames of 3840x384: 2-3 masters per workgroup,
+    frames travelling between workgroups, second passes left pending), labels from the device CNN -- a sample of its frames against the reference encoder
+    run now on this machine (CTU records and reconstruction, bit for bit), and every frame against a second launch of the same frames in the independent
+    form of the other build of the kernel."""
+    import sys
+    import hevcdl_amd
+    import ref_tools
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), ".."))
+    import bench
+    w, h, qp, nf = 3840, 384, 32, 320
+    base = ref_tools.synth_yuv(w, h, 8, 4242)
+    rng = np.random.default_rng(17)
+    yuv = np.stack([np.clip(base[i % 8].astype(np.int16) + rng.integers(-2, 3, base.shape[1]) * (i // 8 % 3), 0, 255).astype(np.uint8) for i in range(nf)])
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    labels = enc.predict_depth(yuv)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    pick = [0, 1, 127, 128, 255, 256, 257, 319]             # first / last frames of the workgroups' lists, frames that start as surplus units
+    wall, per, dumps = bench.run_reference_pictures([yuv[i] for i in pick], labels[pick], w, h, qp, len(pick), dump=True)
+    res = bench.parity_against_dumps(dumps, recs[pick], [recon[i] for i in pick], w, h)
+    assert res["ctus"] == len(pick) * recs.shape[1] and res["mismatches"] == 0, res
+    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=nf)
+    cfg.exec_flags = 1 | 2                                   # no hand-over between workgroups, the ten-wave build
+    enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
+    recs2, recon2, stats2 = enc.compress_frames(yuv, labels)
+    enc.close()
+    assert_records_equal(recs, recs2, "C4-regime launch vs independent form")
+    assert np.array_equal(recon, recon2) and np.array_equal(stats["est_bits"], stats2["est_bits"])
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
