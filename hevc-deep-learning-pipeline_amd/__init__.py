@@ -185,7 +185,7 @@ def load_library():
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_planes", "hevcdl_compress_frames_planes", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_encode_pictures_chunked", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
+           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_device_memory", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_encode_pictures_chunked", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5", "hevcdl_write_digest_sei"]
 
