@@ -200,7 +200,11 @@ struct __attribute__((aligned(16))) RdSmem {
   GLB int16_t *my_coef; GLB pel_t *my_rec, *my_ovl; GLB double *my_qcost; GLB int32_t *my_qrate; GLB unsigned long long *my_save; GLB unsigned char *my_slots; GLB unsigned long long *my_log;
   int bound_reg, bound_child;          // a T_LUMA_SPLIT task under way: the chain owner's wave (its region [1] holds the chain's answers) and the child it is the split alternative of (recur_luma's early exit); -1: none
   int p2_pending, pad_p2;              // the second luma pass of the CU under test runs as a task (value: the region that holds its ticket); joined in check_rd_cost_intra or left pending
-  Cabac go, curr[MSM ? 1 : 4], root[MSM ? 1 : 5], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4); next[] / temp[] / test[] live in the wave's HBM workspace (cold_state)
+  Cabac go, curr[MSM ? 1 : 4], root[MSM ? 1 : 5], tbest, truec;   // snapshot slots by CU depth (0..3) / CU+TU depth (root: 0..4); test[] lives in the wave's HBM workspace, and so do next[] / temp[] in the ten-wave build (cold_state)
+#if !defined(HEVCDL_RD_WIDE) && !defined(HEVCDL_MICRO_SMALL)
+  Cabac nt[8];                        // next[4], temp[4]: the CU walk's snapshots (masters only)
+  uint8_t sv[4][256];                 // saved best candidate: luma search trIdx / cbf / tskip in [0..2]; chroma search (later, disjoint in time) cbf Cb, Cr, tskip Cb, Cr
+#endif
   uint8_t a[11][MSM ? 16 : 256];      // attribute arrays of the current CTU (flushed to the record at CTU end)
   int16_t line[MSM ? 8 : 264], fline[MSM ? 8 : 264];      // luma reference samples: bottom-left ... corner(2n) ... top-right; [1 2 1]-filtered copy
   int16_t cline[2][MSM ? 4 : 132];    // chroma reference samples (n <= 32, never filtered in 4:2:0)
@@ -227,12 +231,12 @@ struct __attribute__((aligned(16))) RdSmem {
   // winners of the CU under test, for the short form of its syntax count (enc_cu_syntax_fast): coefficient bits of the luma / chroma winner, its slot
   unsigned long long lw_cfrac, cw_cfrac; int lw_valid, cw_slot;
   // SATD sums of the NEXT CU's rough mode decision, computed by the master while the workgroup's other waves run this CU's chroma search (rmd_prefetch)
-  unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pre_open;      // pre_open: key of the PU whose SATD slices are open in this wave's ticket region (0: none)
+  unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pre_open, chroma_key, pad_ck;      // chroma_key: key of the CU whose five chroma modes were posted together with its second pass (est_intra_luma; 0: none)   pre_open: key of the PU whose SATD slices are open in this wave's ticket region (0: none)
   // Second passes left running behind the master (compress_cu): carry_ok: the CU being coded may leave its pass pending; pend_*: the passes pending, oldest
   // first (index of their CU among the CTU's coded CUs, region of their ticket); restart: a pending pass chose the split -> the CTU is walked again, CUs
   // [0, replay_upto) from the log, CU nocarry_leaf with the result that pass reached (its luma is not searched again)
   int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[2], pend_reg[2], left_pending, resume_reg;   // resume_reg: ticket region of the pass that won, whose result CU nocarry_leaf takes over
-  Cabac spl;                          // end state of a split's children while its header is counted (split_bits)
+  uint8_t lab16[16];                  // the CTU's labels (the walk and the look-ahead read one per CU)
   uint8_t c8a[11][4];                 // saved 2Nx2N candidate of an 8x8 CU: attribute entries (levels and samples: entries 66 / 67 of the wave's log in HBM)
   // Look-ahead (est_intra_chroma -> est_intra_luma of the next CU): ahead_open 0 none / 1 region open / 2 frozen (no further claims); key of the PU, number of
   // candidates, tasks claimed before the freeze, fractional bits the candidates started from
@@ -1740,13 +1744,13 @@ template <int LOG2> DEVN uint32_t split_bits(KR k, const Cu cu_, const Tu tu_, L
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
   LCabac *c = &s.go;
-  cabac_copy(k, &s.spl, c);                     // the children's end state: coefficient contexts
+  cabac_copy(k, &s.tbest, c);                   // the children's end state: coefficient contexts (tbest: the transform-skip trial's snapshot, dead once the children are coded)
   cabac_copy(k, c, root);
   if (lane_id() == 0) reset_bits(c);
   enc_intra_header(k, c, cu, tu, 1, 0);
   enc_subdiv_cbf<LOG2>(k, c, cu, tu, 1, 0);
   wsync();
-  for (int i = CTX_SIG_CG + lane_id(); i < NUM_CTX; i += 64) c->ctx[i] = s.spl.ctx[i];
+  for (int i = CTX_SIG_CG + lane_id(); i < NUM_CTX; i += 64) c->ctx[i] = s.tbest.ctx[i];
   if (lane_id() == 0) c->frac += cfrac;
   wsync();
   PROF_ADD_T(k, 10, 49);
@@ -1912,15 +1916,21 @@ DEV void load_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
   wsync();
 }
 
+DEV void chroma_mode_list(int luma_mode, uint32_t (&mode_list)[5])
+{ // getAllowedChromaDir TComDataCU.cpp:1334-1353
+  mode_list[0] = PLANAR; mode_list[1] = VER; mode_list[2] = HOR; mode_list[3] = DC; mode_list[4] = DM_CHROMA;
+  for (int i = 0; i < 4; i++) if ((int)mode_list[i] == luma_mode) { mode_list[i] = 34; break; }
+}
 DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_);
 DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
 DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
 DEVN int remote_poll(LRegion &r);
 DEVN int remote_room();
-DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4);
+DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4, int prepare_only);
+DEV void chroma_mode_list(int luma_mode, uint32_t (&mode_list)[5]);
 DEVN void chroma_collect(LRegion &r);
-DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist);
+DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist, int with_chroma);
 DEV void region_wait(LRegion &r, int n)
 {
   PROF_T0();
@@ -1930,11 +1940,24 @@ DEV void region_wait(LRegion &r, int n)
 }
 DEV void state_to_global(GLB unsigned long long *dst, const LCabac *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = ((LDS const unsigned long long *)src)[lane_id()]; wsync(); }
 DEV void state_from_global(LCabac *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) ((LDS unsigned long long *)dst)[lane_id()] = src[lane_id()]; wsync(); }
-DEV void state_copy_global(GLB unsigned long long *dst, GLB const unsigned long long *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = src[lane_id()]; wsync(); }
-// the executing wave's cold coder snapshots and saved candidate arrays (its HBM workspace: LOG_COLD)
+// coder snapshots as 21 words, whichever side they live on
+typedef unsigned long long u64_;
+DEV void st_copy(GLB u64_ *dst, GLB const u64_ *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = src[lane_id()]; wsync(); }
+DEV void st_copy(GLB u64_ *dst, LDS const u64_ *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = src[lane_id()]; wsync(); }
+DEV void st_copy(LDS u64_ *dst, GLB const u64_ *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = src[lane_id()]; wsync(); }
+DEV void st_copy(LDS u64_ *dst, LDS const u64_ *src) { wsync(); if (lane_id() < 21) dst[lane_id()] = src[lane_id()]; wsync(); }
+DEV LDS u64_ *st_of(LCabac *c) { return (LDS u64_ *)c; }
+// The CU walk's snapshots next[depth] / temp[depth] and the saved arrays of the best candidate: in LDS where a wave's block has the room (the eight-wave builds), in the
+// executing wave's HBM workspace (LOG_COLD) in the ten-wave build; test[depth] (unsplit-vs-split of a first-pass TU: rare) always in the workspace.
 enum { COLD_NEXT = 0, COLD_TEMP = 4, COLD_TEST = 8 };
-DEV GLB unsigned long long *cold_state(int which, int depth) { return lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + (size_t)(which + depth) * 21; }
-DEV GLB uint8_t *cold_sv(int c) { return (GLB uint8_t *)(lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + 12 * 21) + c * 256; }   // saved best candidate: luma search trIdx / cbf / tskip in [0..2]; chroma search (later, disjoint in time) cbf Cb, Cr, tskip Cb, Cr
+DEV GLB u64_ *cold_test(int depth) { return lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + (size_t)(COLD_TEST + depth) * 21; }
+#if !defined(HEVCDL_RD_WIDE) && !defined(HEVCDL_MICRO_SMALL)
+DEV LDS u64_ *cold_state(int which, int depth) { return (LDS u64_ *)&lds().nt[which + depth]; }
+DEV LDS uint8_t *cold_sv(int c) { return lds().sv[c]; }
+#else
+DEV GLB u64_ *cold_state(int which, int depth) { return lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + (size_t)(which + depth) * 21; }
+DEV GLB uint8_t *cold_sv(int c) { return (GLB uint8_t *)(lds().my_log + (size_t)LOG_COLD * (LEAF_LOG / 8) + 12 * 21) + c * 256; }
+#endif
 static_assert(12 * 21 * 8 + 4 * 256 <= LOG_COLD_N * LEAF_LOG, "cold area");
 struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
 template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_);
@@ -1996,7 +2019,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
   if constexpr (LOG2 > 2) {
     if (check_split) {
       if (memo) { }
-      else if (check_full) { state_to_global(cold_state(COLD_TEST, full_depth), &s.go); cabac_copy(k, &s.go, &s.root[full_depth]); }
+      else if (check_full) { st_copy(cold_test(full_depth), st_of(&s.go)); cabac_copy(k, &s.go, &s.root[full_depth]); }
       else cabac_copy(k, &s.root[full_depth], &s.go);
       double split_cost = 0; uint32_t split_dist = 0, split_cbf = 0;
       unsigned long long split_cfrac = 0;
@@ -2037,7 +2060,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
         wsync();
         for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = cold_sv(0)[i]; s.a[A_CBF][zabs + i] = cold_sv(1)[i]; s.a[A_TSKIP][zabs + i] = cold_sv(2)[i]; }
       } else {
-        state_from_global(&s.go, cold_state(COLD_TEST, full_depth));
+        st_copy(st_of(&s.go), cold_test(full_depth));
         set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
         set_parts(k, s.a[A_CBF], zabs, tu.nparts, (int)(single_cbf << tu.trd));
         set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, best_ts);
@@ -2353,7 +2376,7 @@ DEV bool next_leaf(KR k, const Cu &cu, int &nx, int &ny, int &nlog2)
   for (int d = 0; d <= 3; d++) {
     const int size = 64 >> d, ox = x & ~(size - 1), oy = y & ~(size - 1);
     const int straddles = ox + size > k.W || oy + size > k.H;
-    const int l = uni(k.labels[k.addr * 16 + 4 * ((oy & 63) / 16) + (ox & 63) / 16]);
+    const int l = uni(lds().lab16[4 * ((oy & 63) / 16) + (ox & 63) / 16]);
     if (!straddles && l == d) { if (ox != x || oy != y) return false; nx = x; ny = y; nlog2 = 6 - d; return true; }
     if (!(straddles || l > d)) return false;
   }
@@ -2721,7 +2744,9 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         }
         state_to_global(slot_state(k.slots, SLOT_P2 + SLOT_PSET * (reg - 1), 0), &s.curr[cu.depth]);
         const int rm = lds_load(&wg_shared().remote);
-        if (rm && (rm != 3 || remote_room())) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist);    // a workgroup without a unit runs it (few units in the launch)
+        // (very few units: the CU's five chroma modes are posted in the same breath -- everything a chroma mode reads is settled once the luma winner is imported, and
+        //  posting here instead of in est_intra_chroma brings their answers, which the walk waits for, ~15 k cycles forward and saves a release of its own)
+        if (rm && (rm != 3 || remote_room())) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist, rm == 2 && cu.part == SIZE_2Nx2N);    // a workgroup without a unit runs it (few units in the launch)
         else region_open(r2, T_LUMA_P2, 1, cu, ptu);
         break;
       }
@@ -3139,14 +3164,14 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
   const Cu cu = ucu(cu_);
   LSmem &s = lds();
   const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
-  uint32_t mode_list[5] = { PLANAR, VER, HOR, DC, DM_CHROMA };
+  uint32_t mode_list[5];
   MT0();
   TL(5, cu.zbase);
   wsync();
   if (lane_id() < 2) s.ref_key[1 + lane_id()] = -1;
   wsync();
   const int luma_mode = uni(s.a[A_LDIR][cu.zbase]);
-  for (int i = 0; i < 4; i++) if ((int)mode_list[i] == luma_mode) { mode_list[i] = 34; break; }   // getAllowedChromaDir TComDataCU.cpp:1334-1353
+  chroma_mode_list(luma_mode, mode_list);
   uint32_t best_mode = 0, best_dist = 0; double best_cost = MAX_DOUBLE;
   { // the five modes are independent (each starts from the [depth][CI_CURR_BEST] snapshot, TEncSearch.cpp:2640-2660) -> a region
     LRegion &r = my_region();
@@ -3176,7 +3201,10 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     const bool la = rich && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX && next_leaf(k, cu, anx, any, anl) && anl >= 4 && anl <= 5;
     if (uni(s.pre_open) && (!la || uni(s.pre_open) != ((anl << 24) | (any << 12) | anx))) { region_run(k, r); if (lane_id() == 0) s.pre_open = 0; wsync(); }   // (slices opened for another PU: cannot happen by construction)
     if (la && !uni(s.pre_open)) rmd_prefetch(k, anx, any, anl, 2);               // reference lines of the next PU, its SATD rounds handed to the idle waves (est_intra_luma may have done it already) ...
-    if (cremote) chroma_post(k, cu, root, (int)mode_list[0], (int)mode_list[1], (int)mode_list[2], (int)mode_list[3], (int)mode_list[4]);   // ... while the chroma modes are posted
+    const bool posted = cremote && uni(s.chroma_key) == ((cu.log2 << 24) | (cu.y << 12) | cu.x);     // together with the second pass (remote_post)
+    wsync();
+    if (lane_id() == 0) s.chroma_key = 0;
+    if (cremote && !posted) chroma_post(k, cu, root, (int)mode_list[0], (int)mode_list[1], (int)mode_list[2], (int)mode_list[3], (int)mode_list[4], 0);   // ... while the chroma modes are posted
     TL(6, 0);
     if (la) {
       rmd_prefetch_end(k, anx, any, anl);
@@ -3323,7 +3351,7 @@ DEVN Rd check_rd_cost_intra(KR k, const Cu cu_, int part_, int known_reg_ = 0)
     if (part == SIZE_2Nx2N && cu.log2 <= 5 && uni(s.lw_valid) && uni(s.a[A_TRIDX][cu.zbase]) == 0)          // one TU per component, winners known: the short form
       enc_cu_syntax_fast(k, &s.go, cu, s.my_log + 65 * (LEAF_LOG / 8), slot_state(k.slots, uni(s.cw_slot), 1), uni64(s.lw_cfrac) + uni64(s.cw_cfrac));
     else enc_cu_syntax(k, &s.go, cu);
-    state_to_global(cold_state(COLD_TEMP, cu.depth), &s.go);
+    st_copy(cold_state(COLD_TEMP, cu.depth), st_of(&s.go));
     r.bits = (uint32_t)uni((int)get_bits(&s.go)); r.dist = dist; r.cost = calc_rd_cost(k, r.bits, r.dist);
     MT(22);
     TL(11, 0);
@@ -3407,7 +3435,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
   const int log2 = 6 - DEPTH, size = 1 << log2;
   Cu cu = { x, y, log2, DEPTH, (int)tb().r2z[(((y & 63) >> 2) << 4) | ((x & 63) >> 2)], 256 >> (2 * DEPTH), SIZE_2Nx2N };
   const int boundary = uni(!(x + size <= k.W && y + size <= k.H));
-  const int pred_depth = uni(k.labels[k.addr * 16 + 4 * ((y & 63) / 16) + (x & 63) / 16]);
+  const int pred_depth = uni(s.lab16[4 * ((y & 63) / 16) + (x & 63) / 16]);
   const int check_cur = pred_depth == DEPTH, check_next = pred_depth > DEPTH;
   Rd best = { MAX_DOUBLE, 0, 0 };
   int best_is_real = 0;
@@ -3421,7 +3449,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
       if (li < uni(s.replay_upto)) { // walked before and final: its result and the coder state behind it from the log
         const unsigned long long w0 = lg[0], w1 = lg[1], w23 = lg[23];
         best.cost = __longlong_as_double((long long)uni64(w0)); best.bits = (uint32_t)uni((int)(unsigned)w1); best.dist = (uint32_t)uni((int)(unsigned)(w1 >> 32));
-        state_copy_global(cold_state(COLD_NEXT, DEPTH), lg + 2);
+        st_copy(cold_state(COLD_NEXT, DEPTH), lg + 2);
         if (lane_id() == 0) s.ctu_frac += w23;
       } else {
         // a pending pass that has finished meanwhile is joined right away: a restart costs the less the earlier it is seen
@@ -3437,11 +3465,11 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         wsync();
         Rd t = check_rd_cost_intra(k, cu, SIZE_2Nx2N, li == uni(s.nocarry_leaf) ? uni(s.resume_reg) : 0);
         if (uni(s.restart)) return t;
-        if (ub(t.cost < best.cost)) { best = t; state_copy_global(cold_state(COLD_NEXT, DEPTH), cold_state(COLD_TEMP, DEPTH)); best_is_real = 1; }
+        if (ub(t.cost < best.cost)) { best = t; st_copy(cold_state(COLD_NEXT, DEPTH), cold_state(COLD_TEMP, DEPTH)); best_is_real = 1; }
         if (DEPTH == 3) {
           save_cand8(k, cu);
           Rd t2 = check_rd_cost_intra(k, cu, SIZE_NxN);
-          if (ub(t2.cost < best.cost)) { best = t2; state_copy_global(cold_state(COLD_NEXT, DEPTH), cold_state(COLD_TEMP, DEPTH)); }
+          if (ub(t2.cost < best.cost)) { best = t2; st_copy(cold_state(COLD_NEXT, DEPTH), cold_state(COLD_TEMP, DEPTH)); }
           else { load_cand8(k, cu); cu.part = SIZE_2Nx2N; }
         }
         wsync();
@@ -3451,18 +3479,18 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
           lg[0] = (unsigned long long)__double_as_longlong(best.cost); lg[1] = (unsigned long long)best.bits | ((unsigned long long)best.dist << 32); lg[23] = sf;
           s.ctu_frac += sf;
         }
-        state_copy_global(lg + 2, cold_state(COLD_NEXT, DEPTH));
+        st_copy(lg + 2, cold_state(COLD_NEXT, DEPTH));
         TL(12, 0);
       }
     } else { best.cost = MAX_DOUBLE / 16; best.dist = 0xffffffffu >> 3; best.bits = 0xffffffffu >> 3; }
     // split flag of the unsplit candidate (:858-867); for the dummy candidate the loaded state is stale and irrelevant
-    state_from_global(&s.go, cold_state(COLD_NEXT, DEPTH));
+    st_copy(st_of(&s.go), cold_state(COLD_NEXT, DEPTH));
     const int sctx = (DEPTH < 3) ? split_ctx(k, x, y, DEPTH) : 0;
     if (lane_id() == 0) { reset_bits(&s.go); if (DEPTH < 3) enc_bin(&s.go, CTX_SPLIT + sctx, 0); }
     wsync();
     best.bits += (uint32_t)uni((int)get_bits(&s.go));
     best.cost = calc_rd_cost(k, best.bits, best.dist);
-    state_to_global(cold_state(COLD_NEXT, DEPTH), &s.go);
+    st_copy(cold_state(COLD_NEXT, DEPTH), st_of(&s.go));
   }
   if (best_is_real) for (int c = uni(s.left_pending) ? 1 : 0; c < 3; c++) copy_best_rec_to_pic(k, cu, c);     // xCopyYuv2Pic :1093 (luma stays with a pass that is still running)
   if constexpr (DEPTH < 3) {
@@ -3471,7 +3499,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
     for (int i = 0; i < 4; i++) {
       const int sx = x + (i & 1) * h, sy = y + (i >> 1) * h;
       if (ub(sx < k.W && sy < k.H)) {
-        if (i == 0) cabac_copy(k, &s.curr[DEPTH + 1], &s.curr[DEPTH]); else state_from_global(&s.curr[DEPTH + 1], cold_state(COLD_NEXT, DEPTH + 1));
+        if (i == 0) cabac_copy(k, &s.curr[DEPTH + 1], &s.curr[DEPTH]); else st_copy(st_of(&s.curr[DEPTH + 1]), cold_state(COLD_NEXT, DEPTH + 1));
         Rd sub;
         if (check_next) sub = compress_cu<DEPTH + 1>(k, sx, sy);
         else { sub.cost = MAX_DOUBLE / 16; sub.dist = 0xffffffffu >> 3; sub.bits = 0xffffffffu >> 3; }
@@ -3487,7 +3515,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
         wsync();
       }
     }
-    state_from_global(&s.go, cold_state(COLD_NEXT, DEPTH + 1));
+    st_copy(st_of(&s.go), cold_state(COLD_NEXT, DEPTH + 1));
     if (!boundary) {
       const int sctx = split_ctx(k, x, y, DEPTH);
       if (lane_id() == 0) { reset_bits(&s.go); enc_bin(&s.go, CTX_SPLIT + sctx, 1); }
@@ -3495,7 +3523,7 @@ template <int DEPTH> DEVN Rd compress_cu(KR k, int x_, int y_)
       temp.bits += (uint32_t)uni((int)get_bits(&s.go));
     }
     temp.cost = calc_rd_cost(k, temp.bits, temp.dist);
-    if (ub(temp.cost < best.cost)) { best = temp; state_to_global(cold_state(COLD_NEXT, DEPTH), &s.go); }      // (the split's end state is in `go`)
+    if (ub(temp.cost < best.cost)) { best = temp; st_copy(cold_state(COLD_NEXT, DEPTH), st_of(&s.go)); }      // (the split's end state is in `go`)
   }
   return best;
 }
@@ -3560,7 +3588,7 @@ DEVN void advance_state(KR k, LCabac *truec, int x0_, int y0_)
     for (int i = 0; i < 21; i++) { const int v = s.cgf[i]; if (v & 8) enc_bin(truec, CTX_SPLIT + (v & 3), (v >> 2) & 1); }
     truec->frac += s.ctu_frac;
   }
-  { GLB const uint8_t *nx = (GLB const uint8_t *)cold_state(COLD_NEXT, 0); for (int i = 3 + lane; i < NUM_CTX; i += 64) truec->ctx[i] = nx[i]; }
+  { const auto nx = cold_state(COLD_NEXT, 0); wsync(); for (int i = 3 + lane; i < NUM_CTX; i += 64) truec->ctx[i] = (uint8_t)(nx[i >> 3] >> (8 * (i & 7))); }
   wsync();
 }
 
@@ -3622,15 +3650,9 @@ enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_
        JOB_CFRAC = 24, JOB_CTXP = 26,        // int offsets in the header (8-byte values at even offsets)
        JOB_CTX = 24 };                        // 8-byte-word offset of a second pass's own context behind its header
 DEV GLB unsigned long long *cjob_block(int m) { return lds().my_log + (size_t)(LOG_CJOB + m) * (LEAF_LOG / 8); }
-DEV void job_push(GLB unsigned long long *job)
-{ // lane 0
-  GLB unsigned char *sched = wg_shared().sched;
-  const int i = __hip_atomic_fetch_add(rq_tail(sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(rq_ring(sched) + (i & (RQ_SIZE - 1)), (unsigned long long)job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist)
+DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist, int with_chroma_)
 {
-  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int reg = uni(reg_), mode = uni(mode_), pset = reg - 1;
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int reg = uni(reg_), mode = uni(mode_), pset = reg - 1, with_chroma = uni(with_chroma_);
   LSmem &s = lds(); LRegion &r = my_region(reg);
   GLB unsigned long long *job = job_block(pset); GLB int *hi = (GLB int *)job;
   static_assert(JOB_CTX * 8 <= LEAF_LOG && sizeof(K) + 11 * 256 <= LOG_AHEAD_N * LEAF_LOG, "job block");
@@ -3648,14 +3670,27 @@ DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, dou
     r.cu[0] = cu.x; r.cu[1] = cu.y; r.cu[2] = cu.log2; r.cu[3] = cu.depth; r.cu[4] = cu.zbase; r.cu[5] = cu.nparts; r.cu[6] = cu.part;
   }
   wsync();
+  if (with_chroma) { // the CU's chroma modes ride on the same release (the CU is one PU: its luma mode and TU arrays are final unless this very pass chooses the split -- then the chroma search is repeated anyway)
+    uint32_t ml[5]; chroma_mode_list(mode, ml);
+    const Tu root = { cu.x, cu.y, cu.log2, 0, 0, cu.nparts };
+    chroma_post(k, cu, root, (int)ml[0], (int)ml[1], (int)ml[2], (int)ml[3], (int)ml[4], 1);
+    if (lane_id() == 0) s.chroma_key = (cu.log2 << 24) | (cu.y << 12) | cu.x;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // the block, the start state in the slot, the picture around the CU: before the pointer
-  if (lane_id() == 0) job_push(job);
+  { // one reservation for all the jobs (a taker that finds a reserved entry still empty looks again later), the pointers stored side by side
+    GLB unsigned char *sched = wg_shared().sched;
+    const int n = with_chroma ? 6 : 1;
+    int i0 = 0;
+    if (lane_id() == 0) i0 = __hip_atomic_fetch_add(rq_tail(sched), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    i0 = uni(i0);
+    if (lane_id() < n) __hip_atomic_store(rq_ring(sched) + ((i0 + lane_id()) & (RQ_SIZE - 1)), (unsigned long long)(lane_id() == 0 ? job : cjob_block(lane_id() - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   wsync();
 }
 // The five chroma modes of a CU as jobs (launches of very few units: there are enough idle workgroups for every mode of every master).  A mode's trial levels and
 // reconstruction go to its result slot, never to the picture, so the only lines two XCDs write are slot lines -- the release below also writes back what this XCD
 // still holds dirty of them (first-pass candidates used slots 5..9 before), the acquire in chroma_collect drops the then clean copies.
-DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4)
+DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4, int prepare_only)
 {
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
@@ -3674,8 +3709,15 @@ DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, 
     hi[JOB_TU] = tu.x; hi[JOB_TU + 1] = tu.y; hi[JOB_TU + 2] = tu.log2; hi[JOB_TU + 3] = tu.trd; hi[JOB_TU + 4] = tu.zrel; hi[JOB_TU + 5] = tu.nparts;
   }
   wsync();
+  if (uni(prepare_only)) return;                                      // the caller releases and pushes (remote_post)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane_id() == 0) for (int m = 0; m < 5; m++) job_push(cjob_block(m));
+  {
+    GLB unsigned char *sched = wg_shared().sched;
+    int i0 = 0;
+    if (lane_id() == 0) i0 = __hip_atomic_fetch_add(rq_tail(sched), 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    i0 = uni(i0);
+    if (lane_id() < 5) __hip_atomic_store(rq_ring(sched) + ((i0 + lane_id()) & (RQ_SIZE - 1)), (unsigned long long)cjob_block(lane_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   wsync();
 }
 DEVN void chroma_collect(LRegion &r)
@@ -3837,6 +3879,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     wsync();
     PROF_MARK0();
     k.addr = a; k.cx = cx; k.cy = cy;
+    if (lane < 16) s.lab16[lane] = k.labels[a * 16 + lane];
     // initCtu TComDataCU.cpp:420-500
     for (int i = lane; i < 256; i += 64) {
       for (int f = 0; f < 11; f++) s.a[f][i] = 0;
@@ -3848,7 +3891,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; s.ctu_frac = 0; }
+    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; s.ctu_frac = 0; s.chroma_key = 0; }
     wsync();
     PROF_MARK(47);
     TL(13, a);
@@ -3866,6 +3909,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       if (lane < 3) s.ref_key[lane] = -1;
       ahead_drain();
       if (uni(s.pre_open)) { region_run(k, my_region()); if (lane == 0) s.pre_open = 0; wsync(); }      // SATD slices still out
+      if (uni(s.chroma_key)) { chroma_collect(my_region()); if (lane == 0) s.chroma_key = 0; wsync(); }  // (chroma modes posted for a CU whose search was abandoned: cannot happen by construction)
       if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; s.ctu_frac = 0; }
       wsync();
       cabac_copy(k, &s.curr[0], truec);
