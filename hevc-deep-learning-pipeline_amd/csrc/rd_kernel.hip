@@ -240,7 +240,7 @@ struct __attribute__((aligned(16))) RdSmem {
   uint8_t c8a[11][4];                 // saved 2Nx2N candidate of an 8x8 CU: attribute entries (levels and samples: entries 66 / 67 of the wave's log in HBM)
   // Look-ahead (est_intra_chroma -> est_intra_luma of the next CU): ahead_open 0 none / 1 region open / 2 frozen (no further claims); key of the PU, number of
   // candidates, tasks claimed before the freeze, fractional bits the candidates started from
-  int ahead_open, ahead_key, ahead_n, ahead_claimed; unsigned int ahead_f0, pad_ahead;
+  int ahead_open, ahead_key, ahead_n, ahead_claimed; unsigned int ahead_f0; int xctu;     // xctu: address of the CTU whose first CU the look-ahead was opened for while the CTU before it was finished (-1: none)
 #ifdef HEVCDL_KERNEL_PROF
   GLB unsigned long long *my_prof; int prof_task, prof_pad; // timers of the profiling build (8-bit kernel, workgroup 0): 64 accumulators in HBM (cycles in the low 40 bits, calls above), added to with returnless atomics -- no LDS, no wait
 #endif
@@ -496,8 +496,9 @@ DEV int unit_avail(KR k, int x4, int y4, int cur_x4, int cur_y4)
 { // inside the picture and already coded: earlier CTU, or earlier z-order in this CTU (TComDataCU.cpp:985-1200)
   if (x4 < 0 || y4 < 0 || x4 * 4 >= k.W || y4 * 4 >= k.H) return 0;
   if (x4 * 4 < k.tx0 || y4 * 4 < k.ty0 || x4 * 4 >= k.tx1 || y4 * 4 >= k.ty1) return 0;   // another tile is never available (bEnforceTileRestriction)
-  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4);
-  if (a != k.addr) return a < k.addr;                   // CTUs of one tile are coded in raster order
+  // (the CTU of the block the line is gathered for, not k.addr: the look-ahead gathers for the first CU of the NEXT CTU while this one is finished -- process_unit)
+  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), ca = (cur_y4 >> 4) * k.ctus_x + (cur_x4 >> 4);
+  if (a != ca) return a < ca;                           // CTUs of one tile are coded in raster order
   return tb().r2z[((y4 & 15) << 4) | (x4 & 15)] < tb().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
 }
 
@@ -2382,6 +2383,20 @@ DEV bool next_leaf(KR k, const Cu &cu, int &nx, int &ny, int &nlog2)
   }
   return false;
 }
+// The first CU of the CTU at column / row (ncx, ncy), address na -- the same walk over its labels (read from HBM: the CTU is not the one being coded)
+DEV bool ctu_first_leaf(KR k, int na, int ncx, int ncy, int &nx, int &ny, int &nlog2)
+{
+  const int x = ncx * 64, y = ncy * 64;
+  if (x >= k.W || y >= k.H) return false;
+  const int l = uni(k.labels[na * 16]);                   // the top-left cell's label is the one every depth of the walk reads there
+  for (int d = 0; d <= 3; d++) {
+    const int size = 64 >> d;
+    const int straddles = x + size > k.W || y + size > k.H;
+    if (!straddles && l == d) { nx = x; ny = y; nlog2 = 6 - d; return true; }
+    if (!(straddles || l > d)) return false;
+  }
+  return false;
+}
 // Rough-mode SATD sums of the PU at (x, y) ahead of time: they depend on the reconstruction around the PU only (final once the CU before it has its first
 // pass's winner: a pending second pass is read through best_rec), not on the coder state -- est_intra_luma adds the mode bits when it gets there.
 DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_, int sliced_ = 0)
@@ -2508,16 +2523,18 @@ template <bool TRACE> DEV int rmd_candidates(KR k, int x, int y, int pu_log2, un
 #ifndef HEVCDL_AHEAD_MAX
 #define HEVCDL_AHEAD_MAX 1                      // measured: with two or three masters per workgroup the candidates coded ahead only take waves from work that is needed now (600 frames: 6.45 -> 6.70 s at 3)
 #endif
-DEVN void ahead_open(KR k, const Cu cu_, int nx_, int ny_, int nl_)
+// xaddr >= 0: the PU is the first CU of the NEXT CTU (address xaddr, column / row xcx / xcy), opened while this CTU is finished (process_unit): the candidates then take
+// over a context that names that CTU and attribute arrays as initCtu leaves them (this wave's own stay untouched: the CTU may still be walked again).
+DEVN void ahead_open(KR k, const Cu cu_, int nx_, int ny_, int nl_, int xaddr_ = -1, int xcx_ = 0, int xcy_ = 0)
 {
-  const Cu cu = ucu(cu_); const int nx = uni(nx_), ny = uni(ny_), nl = uni(nl_);
+  const Cu cu = ucu(cu_); const int nx = uni(nx_), ny = uni(ny_), nl = uni(nl_), xaddr = uni(xaddr_), xcx = uni(xcx_), xcy = uni(xcy_);
   LSmem &s = lds();
   LRegion &r = my_region(REG_AHEAD);
-  const int depth = 6 - nl, nparts = 1 << (2 * (nl - 2)), zb = cu.zbase + cu.nparts;
+  const int depth = 6 - nl, nparts = 1 << (2 * (nl - 2)), zb = xaddr >= 0 ? 0 : cu.zbase + cu.nparts;
   const Cu ncu = { nx, ny, nl, depth, zb, nparts, SIZE_2Nx2N };
   const Tu ptu = { nx, ny, nl, 0, 0, nparts };
   wsync();
-  for (int i = lane_id(); i < nparts; i += 64) { // initEstData of the next CU (check_rd_cost_intra does it again): the candidates' tasks copy these arrays
+  if (xaddr < 0) for (int i = lane_id(); i < nparts; i += 64) { // initEstData of the next CU (check_rd_cost_intra does it again): the candidates' tasks copy these arrays
     const int z = zb + i;
     s.a[A_DEPTH][z] = (uint8_t)depth; s.a[A_PART][z] = (uint8_t)SIZE_2Nx2N; s.a[A_LDIR][z] = DC; s.a[A_CDIR][z] = 0; s.a[A_TRIDX][z] = 0;
     for (int c = 0; c < 3; c++) { s.a[A_CBF + c][z] = 0; s.a[A_TSKIP + c][z] = 0; }
@@ -2527,8 +2544,19 @@ DEVN void ahead_open(KR k, const Cu cu_, int nx_, int ny_, int nl_)
     static_assert(sizeof(K) + 11 * 256 <= LOG_AHEAD_N * LEAF_LOG, "look-ahead snapshot");
     GLB unsigned long long *d = s.my_log + LOG_AHEAD * (LEAF_LOG / 8);
     LDS const unsigned long long *qk = (LDS const unsigned long long *)&s.k, *qa = (LDS const unsigned long long *)&s.a[0][0];
-    for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) d[i] = qk[i];
-    for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[sizeof(K) / 8 + i] = qa[i];
+    static_assert(offsetof(K, addr) == 16 && offsetof(K, cx) == 20 && offsetof(K, cy) == 24 && offsetof(K, nctu) == 28, "K: words 2 and 3 hold addr | cx, cy | nctu");
+    for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) {
+      unsigned long long w = qk[i];
+      if (xaddr >= 0 && i == 2) w = (unsigned long long)(unsigned)xaddr | ((unsigned long long)(unsigned)xcx << 32);
+      if (xaddr >= 0 && i == 3) w = (w & 0xffffffff00000000ull) | (unsigned long long)(unsigned)xcy;
+      d[i] = w;
+    }
+    if (xaddr < 0) { for (int i = lane_id(); i < 11 * 256 / 8; i += 64) d[sizeof(K) / 8 + i] = qa[i]; }
+    else for (int i = lane_id(); i < 11 * 256 / 8; i += 64) { // initCtu (process_unit) + initEstData of the first CU: eight partitions per word
+      const int f = i >> 5, z = (i & 31) * 8;
+      const unsigned b = z < nparts ? (f == A_DEPTH ? (unsigned)depth : (f == A_LDIR ? (unsigned)DC : 0u)) : (f == A_PART ? (unsigned)SIZE_NONE : (f == A_LDIR ? (unsigned)DC : 0u));
+      d[sizeof(K) / 8 + i] = 0x0101010101010101ull * (unsigned long long)b;
+    }
   }
   GLB const unsigned long long *sp = s.my_log + 65 * (LEAF_LOG / 8);
   const unsigned long long f0 = uni64(sp[offsetof(Cabac, frac) / 8]) & 32767ull;
@@ -3891,7 +3919,11 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     cabac_copy(k, &s.curr[0], truec);                         // TEncSlice.cpp:826-832
     cabac_copy(k, &s.go, truec);
-    if (lane == 0) { s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; s.ctu_frac = 0; s.chroma_key = 0; }
+    if (lane == 0) {
+      s.leaf_idx = 0; s.replay_upto = 0; s.nocarry_leaf = -1; s.resume_reg = 0; s.pend_n = 0; s.restart = 0; s.ctu_frac = 0; s.chroma_key = 0;
+      if (!(i > i_begin && s.xctu == a)) { s.pre_key = -1; s.pre_open = 0; s.ahead_open = 0; s.ahead_key = -1; }      // (a look-ahead opened for this very CTU while the one before was finished stays)
+      s.xctu = -1;
+    }
     wsync();
     PROF_MARK(47);
     TL(13, a);
@@ -3899,6 +3931,28 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     for (;;) {
       best = compress_cu<0>(k, cx * 64, cy * 64);
       TL(14, uni(s.pend_n));
+      // Second passes are still out and this wave is about to wait for them, its workgroup's other waves idle: the look-ahead for the FIRST CU of the next CTU -- its
+      // rough-mode sums, then its first-pass candidates.  Nothing of this CTU is touched (the candidates get a context of their own naming the next CTU, ahead_open);
+      // what they assume is checked when the CU is reached (est_intra_luma), and a restart of this CTU drops them like any other look-ahead.
+      if (AHEAD && HEVCDL_PREFETCH && NPEND == 2 && !p.migrate && !uni(s.restart) && uni(s.pend_n) && i + 1 < i_end && uni(s.lw_valid) && !uni(s.ahead_open) && !uni(s.pre_open) &&
+          lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX && spare_waves()) {
+        const int ni = i + 1, ncx = cx0 + ni % tw, ncy = cy0 + ni / tw, na = ncy * p.ctus_x + ncx;
+        int nx = 0, ny = 0, nl = 0;
+        if (ctu_first_leaf(k, na, ncx, ncy, nx, ny, nl) && nl >= 4 && nl <= 5) {
+          { // the candidates read their left neighbours' modes in this CTU's record: its attribute arrays as they stand (written again behind the joins)
+            GLB unsigned char *rec = records + (size_t)a * REC_SIZE;
+            wsync();
+            for (int q = lane; q < 11 * 256 / 4; q += 64) ((GLB uint32_t *)rec)[q] = ((LDS const uint32_t *)&s.a[0][0])[q];
+            wsync();
+          }
+          rmd_prefetch(k, nx, ny, nl, 1);
+          const Cu none = { 0, 0, 0, 0, 0, 0, 0 };
+          ahead_open(k, none, nx, ny, nl, na, ncx, ncy);
+          if (lane == 0) s.xctu = na;
+          wsync();
+          TL(17, na);
+        }
+      }
       while (!uni(s.restart) && uni(s.pend_n)) pend_join_oldest(k, 1);      // passes still pending at the end of the CTU
       if (!uni(s.restart)) break;
       // a pending second pass chose the split: the walk again, replaying the CUs before its own (compress_cu)
@@ -3910,7 +3964,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       ahead_drain();
       if (uni(s.pre_open)) { region_run(k, my_region()); if (lane == 0) s.pre_open = 0; wsync(); }      // SATD slices still out
       if (uni(s.chroma_key)) { chroma_collect(my_region()); if (lane == 0) s.chroma_key = 0; wsync(); }  // (chroma modes posted for a CU whose search was abandoned: cannot happen by construction)
-      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; s.ctu_frac = 0; }
+      if (lane == 0) { s.fline_key = -1; s.restart = 0; s.leaf_idx = 0; s.carry_ok = 0; s.p2_pending = 0; s.left_pending = 0; s.pre_key = -1; s.ctu_frac = 0; s.xctu = -1; }
       wsync();
       cabac_copy(k, &s.curr[0], truec);
       cabac_copy(k, &s.go, truec);
