@@ -78,7 +78,7 @@ constexpr int LAYER_SET = 4 * 6144 * 2 + 4 * 6144 * (int)sizeof(pel_t);
 constexpr int SAVE_BYTES = 8192, N_SAVE = 1;   // the chain owner's state while it runs one of its own split tasks (spec_children)
 constexpr int LOG_AHEAD = 68, LOG_AHEAD_N = 17;               // entries 68..84: the master's context as the look-ahead candidates see it (ahead_open)
 constexpr int LOG_JOB = LOG_AHEAD + LOG_AHEAD_N, LOG_JOB_N = 1 + LOG_AHEAD_N;   // per pending second pass: its job block when another workgroup runs it (remote_post): header entry + context snapshot
-constexpr int LOG_CJOB = LOG_JOB + NPEND * LOG_JOB_N, LOG_CJOB_N = 5 + LOG_AHEAD_N + 1;   // the five chroma modes of the CU under test as jobs for other workgroups: five headers, one context (+ the coder state they start from)
+constexpr int LOG_CJOB = LOG_JOB + NPEND * LOG_JOB_N, LOG_CJOB_N = 10 + LOG_AHEAD_N + 1;   // the five chroma modes of the CU under test as jobs for other workgroups: five headers, one context (+ the coder state they start from)
 constexpr int LOG_COLD = LOG_CJOB + LOG_CJOB_N, LOG_COLD_N = 16;   // what a wave touches too rarely to keep in LDS: the coder snapshots next[4] / temp[4] (the CU walk, masters only) and test[4] (unsplit-vs-split of a first-pass TU), 21 words each, then the saved arrays of the best candidate (4 x 256 bytes)
 constexpr int LEAF_LOG = 192, LOG_BYTES = (LOG_COLD + LOG_COLD_N) * LEAF_LOG;     // + entry 64: the CTU's entry coder state, 65: end state of the first pass's winner (enc_cu_syntax_fast), 66 / 67: levels / samples of the saved 2Nx2N candidate of an 8x8 CU     // per coded CU of the CTU: cost triple + coder state behind it (compress_cu: replay after a restart)
 constexpr int SCR_LAYERS = (LAYER_SET + 2 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES + LOG_BYTES + 2047) & ~2047;
@@ -240,6 +240,9 @@ struct __attribute__((aligned(16))) RdSmem {
   uint8_t c8a[11][4];                 // saved 2Nx2N candidate of an 8x8 CU: attribute entries (levels and samples: entries 66 / 67 of the wave's log in HBM)
   // Look-ahead (est_intra_chroma -> est_intra_luma of the next CU): ahead_open 0 none / 1 region open / 2 frozen (no further claims); key of the PU, number of
   // candidates, tasks claimed before the freeze, fractional bits the candidates started from
+  // a chroma component run for ANOTHER workgroup (remote_serve): where the pair of components of a mode meets -- a counter and the two distortions in the poster's job headers
+  GLB int *rp_pair; GLB uint32_t *rp_half_mine, *rp_half_other;
+  int chroma_jobs, pad_cj;            // chroma modes posted to other workgroups: 5 jobs (a mode each) or 10 (a component each)
   int ahead_open, ahead_key, ahead_n, ahead_claimed; unsigned int ahead_f0; int xctu;     // xctu: address of the CTU whose first CU the look-ahead was opened for while the CTU before it was finished (-1: none)
 #ifdef HEVCDL_KERNEL_PROF
   GLB unsigned long long *my_prof; int prof_task, prof_pad; // timers of the profiling build (8-bit kernel, workgroup 0): 64 accumulators in HBM (cycles in the low 40 bits, calls above), added to with returnless atomics -- no LDS, no wait
@@ -1204,20 +1207,18 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     }
     wsync();
     LDS const double *cbl = &s.chainb[lane < 2 ? lane : 2][0];
-    double v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = cbl[t];
     for (int r = 0; r < R; r++) {
       const int qq = cgpos - r;
       const int cb = __builtin_amdgcn_readlane(cgblk, 16 * r), ggy = cb >> lwg, ggx = cb & (wg - 1);
       const unsigned nzrow = (unsigned)(nzfin >> (16 * r)) & 0xffffu;
-      double vn[16];
-      if (r + 1 < R) {
+      { // (the addends of the next group are NOT fetched ahead: the sixteen register pairs that takes push code_tu_block over its register budget -- twenty more
+        //  registers saved and restored per call, 2 MB of scratch traffic per CTU -- for no measurable gain)
+        double v[16];
 #pragma unroll
-        for (int t = 0; t < 16; t++) vn[t] = cbl[(r + 1) * 16 + t];         // the next group's addends arrive while this one is summed
+        for (int t = 0; t < 16; t++) v[t] = cbl[r * 16 + t];
+#pragma unroll
+        for (int t = 15; t >= 0; t--) acc += v[t];
       }
-#pragma unroll
-      for (int t = 15; t >= 0; t--) acc += v[t];
       const int st_nnz_before0 = __popc(nzrow & 0xfffeu), cg_nonzero = nzrow != 0;
       int flag = cg_nonzero;
       double nb = acc;                                   // lane 1: base_cost behind this group
@@ -1253,10 +1254,6 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       acc = lane == 1 ? nb : (lane == 2 ? 0.0 : acc);
       if (flag) { cgf_mask |= 1ull << cb; if ((g1m >> (16 * r)) & 0xffffull) cc_needed = false; }   // the last-position search ends in this group (a level > 1 stays)
       RDOQ_MARK(34);
-      if (r + 1 < R) {
-#pragma unroll
-        for (int t = 0; t < 16; t++) v[t] = vn[t];
-      }
     }
     carry = (int)(((g1m >> (16 * (R - 1))) & 0xffffull) != 0ull);
     wsync();
@@ -3066,17 +3063,25 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
       const uint32_t d = code_tu_block(k, cu, tu, comp, 0);
       wsync();
       for (int i = lane_id(); i < cu.nparts; i += 64) { at[(comp - 1) * 256 + i] = s.a[A_CBF + comp][cu.zbase + i]; at[(comp + 1) * 256 + i] = 0; }
-      if (lane_id() == 0) half[comp - 1] = d;
-      wsync();
-      wg_release();
+      GLB int *pair = (GLB int *)uni64((unsigned long long)s.rp_pair);          // != 0: the other component runs in another workgroup, on another XCD (remote_serve)
       int prev = 0;
-      if (lane_id() == 0) prev = __hip_atomic_fetch_add(&r.modes[5 + m], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (pair) { // the two meet in the poster's job headers (a line each): agent-scope release before the counter, acquire behind it
+        if (lane_id() == 0) *s.rp_half_mine = d;
+        wsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane_id() == 0) prev = __hip_atomic_fetch_add(pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (lane_id() == 0) half[comp - 1] = d;
+        wsync();
+        wg_release();
+        if (lane_id() == 0) prev = __hip_atomic_fetch_add(&r.modes[5 + m], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       counted = uni(prev) == 1;
       if (counted) {
-        wg_acquire();
+        if (pair) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); else wg_acquire();
         wsync();
         for (int i = lane_id(); i < cu.nparts; i += 64) { s.a[A_CBF + other][cu.zbase + i] = at[(other - 1) * 256 + i]; s.a[A_TSKIP + other][cu.zbase + i] = 0; }
-        dist = uni((int)half[0]) + uni((int)half[1]);
+        dist = pair ? d + (uint32_t)uni((int)*s.rp_half_other) : (uint32_t)(uni((int)half[0]) + uni((int)half[1]));
         wsync();
       }
     }
@@ -3675,7 +3680,7 @@ DEVN int remote_room()
   return uni(ok);
 }
 enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_KIND = 22, JOB_IDX = 23,
-       JOB_CFRAC = 24, JOB_CTXP = 26,        // int offsets in the header (8-byte values at even offsets)
+       JOB_CFRAC = 24, JOB_CTXP = 26, JOB_SPLIT = 28, JOB_PAIR = 29, JOB_HALF = 30, JOB_COUNTED = 31,       // int offsets in the header (8-byte values at even offsets)
        JOB_CTX = 24 };                        // 8-byte-word offset of a second pass's own context behind its header
 DEV GLB unsigned long long *cjob_block(int m) { return lds().my_log + (size_t)(LOG_CJOB + m) * (LEAF_LOG / 8); }
 DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist, int with_chroma_)
@@ -3707,7 +3712,7 @@ DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, dou
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // the block, the start state in the slot, the picture around the CU: before the pointer
   { // one reservation for all the jobs (a taker that finds a reserved entry still empty looks again later), the pointers stored side by side
     GLB unsigned char *sched = wg_shared().sched;
-    const int n = with_chroma ? 6 : 1;
+    const int n = with_chroma ? 1 + uni(s.chroma_jobs) : 1;
     int i0 = 0;
     if (lane_id() == 0) i0 = __hip_atomic_fetch_add(rq_tail(sched), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     i0 = uni(i0);
@@ -3722,44 +3727,50 @@ DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, 
 {
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
-  GLB unsigned long long *ctx = cjob_block(5);
+  GLB unsigned long long *ctx = cjob_block(10);
   static_assert(sizeof(K) + 11 * 256 + sizeof(Cabac) <= (LOG_AHEAD_N + 1) * LEAF_LOG, "chroma job context");
+  // a CU of one TU per component (no transform-skip trial): Cb and Cr of a mode are jobs of their own, the component that finishes second counts the mode's bits (run_task_body)
+  const int split = (cu.log2 >= 4 && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0) ? 1 : 0, n = split ? 10 : 5;
   wsync();
   { LDS const unsigned long long *qk = (LDS const unsigned long long *)&s.k, *qa = (LDS const unsigned long long *)&s.a[0][0], *qs = (LDS const unsigned long long *)&s.curr[cu.depth];
     for (int i = lane_id(); i < (int)(sizeof(K) / 8); i += 64) ctx[i] = qk[i];
     for (int i = lane_id(); i < 11 * 256 / 8; i += 64) ctx[sizeof(K) / 8 + i] = qa[i];
     if (lane_id() < 21) ctx[sizeof(K) / 8 + 11 * 256 / 8 + lane_id()] = qs[lane_id()]; }
-  if (lane_id() < 5) {
-    const int m = lane_id(), mode = m == 0 ? m0 : (m == 1 ? m1 : (m == 2 ? m2 : (m == 3 ? m3 : m4)));
-    GLB int *hi = (GLB int *)cjob_block(m);
-    hi[JOB_DONE] = 0; hi[JOB_MODE] = mode; hi[JOB_PSET] = 0; hi[JOB_KIND] = T_CHROMA; hi[JOB_IDX] = m; *(GLB unsigned long long *)(hi + JOB_CTXP) = (unsigned long long)ctx;
+  if (lane_id() < n) {
+    const int j = lane_id(), m = split ? j >> 1 : j, mode = m == 0 ? m0 : (m == 1 ? m1 : (m == 2 ? m2 : (m == 3 ? m3 : m4)));
+    GLB int *hi = (GLB int *)cjob_block(j);
+    hi[JOB_DONE] = 0; hi[JOB_MODE] = mode; hi[JOB_PSET] = 0; hi[JOB_KIND] = T_CHROMA; hi[JOB_IDX] = j; *(GLB unsigned long long *)(hi + JOB_CTXP) = (unsigned long long)ctx;
+    hi[JOB_SPLIT] = split; hi[JOB_PAIR] = 0; hi[JOB_HALF] = 0; hi[JOB_COUNTED] = 0;
     hi[JOB_CU] = cu.x; hi[JOB_CU + 1] = cu.y; hi[JOB_CU + 2] = cu.log2; hi[JOB_CU + 3] = cu.depth; hi[JOB_CU + 4] = cu.zbase; hi[JOB_CU + 5] = cu.nparts; hi[JOB_CU + 6] = cu.part;
     hi[JOB_TU] = tu.x; hi[JOB_TU + 1] = tu.y; hi[JOB_TU + 2] = tu.log2; hi[JOB_TU + 3] = tu.trd; hi[JOB_TU + 4] = tu.zrel; hi[JOB_TU + 5] = tu.nparts;
   }
+  if (lane_id() == 0) s.chroma_jobs = n;
   wsync();
   if (uni(prepare_only)) return;                                      // the caller releases and pushes (remote_post)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   {
     GLB unsigned char *sched = wg_shared().sched;
     int i0 = 0;
-    if (lane_id() == 0) i0 = __hip_atomic_fetch_add(rq_tail(sched), 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane_id() == 0) i0 = __hip_atomic_fetch_add(rq_tail(sched), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     i0 = uni(i0);
-    if (lane_id() < 5) __hip_atomic_store(rq_ring(sched) + ((i0 + lane_id()) & (RQ_SIZE - 1)), (unsigned long long)cjob_block(lane_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane_id() < n) __hip_atomic_store(rq_ring(sched) + ((i0 + lane_id()) & (RQ_SIZE - 1)), (unsigned long long)cjob_block(lane_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   wsync();
 }
 DEVN void chroma_collect(LRegion &r)
-{ // wait for the five answers; they go where the tasks of a local chroma region leave theirs
+{ // wait for the answers; they go where the tasks of a local chroma region leave theirs
+  const int n = uni(lds().chroma_jobs);
   for (;;) {
     int d = 1;
-    if (lane_id() < 5) d = __hip_atomic_load((GLB int *)cjob_block(lane_id()) + JOB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane_id() < n) d = __hip_atomic_load((GLB int *)cjob_block(lane_id()) + JOB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__ballot(d == 0) == 0ull) break;
     __builtin_amdgcn_s_sleep(48);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   wsync();
   if (lane_id() < 5) {
-    GLB const int *hi = (GLB const int *)cjob_block(lane_id());
+    GLB const int *hi = (GLB const int *)cjob_block(n == 10 ? 2 * lane_id() : lane_id());
+    if (n == 10 && !hi[JOB_COUNTED]) hi = (GLB const int *)cjob_block(2 * lane_id() + 1);      // the component that finished second carries the mode's answer
     r.modes[lane_id()] = hi[JOB_MODE]; r.dist[lane_id()] = (uint32_t)hi[JOB_DIST]; r.cost[lane_id()] = *(GLB const double *)(hi + JOB_COST); r.cfrac[lane_id()] = *(GLB const unsigned long long *)(hi + JOB_CFRAC);
   }
   wsync();
@@ -3821,10 +3832,23 @@ DEVN int remote_serve(GLB unsigned char *sched_)
     if (kind == T_LUMA_P2) { r.modes[0] = hi[JOB_MODE]; r.modes[1] = hi[JOB_PSET]; r.dist[4] = (uint32_t)hi[JOB_MDIST]; r.cost[4] = *(GLB const double *)(hi + JOB_MCOST); }
     else r.modes[idx] = hi[JOB_MODE];
   }
+  const int split = kind == T_CHROMA && uni(hi[JOB_SPLIT]);
+  if (split && lane_id() == 0) { // one component of a chroma mode: job idx = 2 * mode index + component; its twin's header is the neighbouring log entry
+    r.pad_ = 1; r.modes[idx >> 1] = hi[JOB_MODE]; r.cost[idx >> 1] = -1.0;
+    GLB int *h0 = (idx & 1) ? hi - LEAF_LOG / 4 : hi, *ho = (idx & 1) ? hi - LEAF_LOG / 4 : hi + LEAF_LOG / 4;
+    s.rp_pair = h0 + JOB_PAIR; s.rp_half_mine = (GLB uint32_t *)(hi + JOB_HALF); s.rp_half_other = (GLB uint32_t *)(ho + JOB_HALF);
+  }
   wsync();
   run_task<false>(r, idx);
   wsync();
-  if (lane_id() == 0) { hi[JOB_DIST] = (int)r.dist[idx]; *(GLB double *)(hi + JOB_COST) = r.cost[idx]; *(GLB unsigned long long *)(hi + JOB_CFRAC) = r.cfrac[idx]; }
+  if (split) {
+    if (lane_id() == 0) {
+      const int m = idx >> 1, counted = r.cost[m] >= 0.0;
+      hi[JOB_COUNTED] = counted;
+      if (counted) { hi[JOB_DIST] = (int)(unsigned)r.cfrac[5 + m]; *(GLB double *)(hi + JOB_COST) = r.cost[m]; *(GLB unsigned long long *)(hi + JOB_CFRAC) = r.cfrac[m]; }
+      s.rp_pair = nullptr;
+    }
+  } else if (lane_id() == 0) { hi[JOB_DIST] = (int)r.dist[idx]; *(GLB double *)(hi + JOB_COST) = r.cost[idx]; *(GLB unsigned long long *)(hi + JOB_CFRAC) = r.cfrac[idx]; }
   wsync();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // answer, arrays, levels, samples: before the flag
   if (lane_id() == 0) { __hip_atomic_store(hi + JOB_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add(rq_idle(sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -4062,7 +4086,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   }
   LDS WgShared &sh = wg_shared();
   if (lane == 0) for (int q = 0; q < NREG; q++) { sh.reg[wave][q].ticket = 0; sh.reg[wave][q].done = 0; sh.reg[wave][q].owner = wave; }
-  if (lane == 0) { s.bound_reg = 0; s.bound_child = -1; }
+  if (lane == 0) { s.bound_reg = 0; s.bound_child = -1; s.rp_pair = nullptr; s.chroma_jobs = 5; }
   if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
     init_tables(sh.tab);
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m;
