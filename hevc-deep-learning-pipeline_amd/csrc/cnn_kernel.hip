@@ -11,7 +11,7 @@
 // registers of a lane are the members of one max-pool window), N = 16 output channels per tile, K = taps x input channels.
 //   All four run on v_mfma_f32_16x16x32_f16 with SPLIT operands (conv2 / conv3, 32 / 64 input channels, are 76 % of the FLOPs; the 5x5 convolutions gather 75 taps of
 //   the split input tile, padded to 3 k-steps).  Every activation is stored in LDS as ONE
-//     32-bit word holding two halves, hi = f16(v) and lo = f16(v - hi) (22 significant bits: 4.8e-7 relative), the weights are split the same way on the
+//     32-bit word holding two halves, hi = f16(v) and lo = f16(v - hi) (22 significant bits for |v| >= 2^-3, an absolute floor of 2^-25 below: see split_f16), the weights are split the same way on the
 //     host, and a product is hi*hi + hi*lo + lo*hi accumulated in f32 by three MFMAs (lo*lo, < 2^-21 relative, is dropped) -- f32-like accuracy (the
 //     logits stay within 1e-3 of the f32 reference, tests/test_cnn_gpu.py) at 16 / 3 times the f32 MFMA rate.  The maps keep their channel-major
 //     layout: a lane's 8 k-values are 8 channels of one position = the 8 dword reads the f32 form issued for 8 k-steps, repacked by two v_perm_b32 each.
@@ -74,7 +74,15 @@ __device__ __forceinline__ void bn_fold(double s, double ss, double n, float gam
   betap = (float)((double)beta - mean * inv * (double)gamma);
 }
 
-// v -> one word: low half f16(v) (rounded toward zero), high half f16(v - low half)
+// v -> one word: low half f16(v) (rounded toward zero), high half f16(v - low half).
+// Accuracy of the pair, stated exactly: hi carries 11 significant bits, lo the next 11 WHILE v - hi is a normal f16, i.e. for |v| >= 2^-3 (22 bits, 4.8e-7
+// relative); below that lo is an f16 subnormal and the pair's error is bounded absolutely instead, by 2^-25 (lo's last place), and a |v| < 2^-25 remainder is
+// lost.  The operands here are activations in [0, ~8] and weights of magnitude 1e-3 .. 1: the absolute floor (3e-8 per operand) is what the 4.2e-5 logit error
+// measured against the fp32 graph consists of (tests/test_cnn_gpu.py bounds it at 1e-3; bench.py cnn_label_check counts the labels that differ: 0 of 32 640).
+// This relies on the MFMA NOT flushing f16 subnormal inputs, which holds on gfx950 (CDNA3 / 4) and not on gfx90a: hence the guard.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "cnn_kernel.hip: the split-f16 operand form is validated for gfx950 only (f16 subnormal MFMA inputs must not be flushed)"
+#endif
 __device__ __forceinline__ float split_f16(float v)
 {
   const auto h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);

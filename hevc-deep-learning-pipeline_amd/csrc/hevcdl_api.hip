@@ -784,7 +784,8 @@ extern "C" hevcdl_status hevcdl_encode_pictures_chunked(hevcdl_ctx *ctx, const v
   if (want_sao && !deblock) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "SAO runs on the deblocked picture only");
   const int chunk = std::min(n_frames, chunk_frames > 0 ? chunk_frames : 64);
   const size_t rec_b = (size_t)ctx->ctus * sizeof(hevcdl_ctu_record), sao_b = (size_t)ctx->ctus * sizeof(hevcdl_sao_blk), pic_b = ctx->frame_bytes, stat_b = sizeof(hevcdl_frame_stats);
-  const size_t o_pic = rec_b * chunk, o_sao = o_pic + pic_b * chunk, o_stat = o_sao + sao_b * chunk, need = o_stat + stat_b * chunk;      // layout of a chunk buffer
+  auto up64 = [](size_t v) { return (v + 63) & ~(size_t)63; };      // every section of a chunk buffer starts on a 64-byte boundary (the callback gets pointers to structs with 64-bit members)
+  const size_t o_pic = up64(rec_b * chunk), o_sao = up64(o_pic + pic_b * chunk), o_stat = up64(o_sao + sao_b * chunk), need = o_stat + stat_b * chunk;      // layout of a chunk buffer
   if (ctx->h_chunk_bytes < need) {
     for (int i = 0; i < 2; i++) { if (ctx->h_chunk[i]) hipHostFree(ctx->h_chunk[i]); ctx->h_chunk[i] = nullptr; }
     ctx->h_chunk_bytes = 0;
@@ -807,8 +808,9 @@ extern "C" hevcdl_status hevcdl_encode_pictures_chunked(hevcdl_ctx *ctx, const v
   const int n_chunks = (n_frames + chunk - 1) / chunk;
   HIPCHK(fetch(0));
   for (int ci = 0; ci < n_chunks; ci++) {
-    HIPCHK(hipEventSynchronize(ctx->copy_ev[ci & 1]));
-    if (ci + 1 < n_chunks) HIPCHK(fetch(ci + 1));                   // into the other buffer, behind the caller's work on this one
+    { hipError_t e_ = hipEventSynchronize(ctx->copy_ev[ci & 1]);
+      if (e_ == hipSuccess && ci + 1 < n_chunks) e_ = fetch(ci + 1);                   // into the other buffer, behind the caller's work on this one
+      if (e_ != hipSuccess) { (void)hipStreamSynchronize(ctx->copy_stream); return fail(ctx, HEVCDL_ERR_HIP, "chunk copy", e_); } }     // no copy into the library's buffers is left in flight
     const int first = ci * chunk, cnt = std::min(chunk, n_frames - first);
     unsigned char *h = ctx->h_chunk[ci & 1];
     if (fn(user, first, cnt, (const hevcdl_ctu_record *)h, h + o_pic, want_sao ? (const hevcdl_sao_blk *)(h + o_sao) : nullptr, (const hevcdl_frame_stats *)(h + o_stat)) != 0) {

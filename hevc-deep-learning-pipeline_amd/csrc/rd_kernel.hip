@@ -55,7 +55,10 @@ constexpr int BD = HEVCDL_BD, PEL_MAX = (1 << BD) - 1, QP_BD_OFFSET = 6 * (BD - 
 #define HEVCDL_NW 8
 #endif
 constexpr int NW = HEVCDL_NW;                                 // wavefronts per workgroup (one workgroup per CU)
-constexpr int NPEND = BD == 8 ? 2 : 1;                         // second luma passes a master may leave running behind it (the 10-bit kernel has LDS for one more region only)
+#ifndef HEVCDL_NPEND
+#define HEVCDL_NPEND 2          // measured with three (the code handles up to three; LDS has room in the eight-wave build): one frame 2.81 -> 2.85 s, 600 frames 6.19 -> 6.34 s -- more work thrown away at a restart, a quarter more workspace per wave
+#endif
+constexpr int NPEND = BD == 8 ? HEVCDL_NPEND : 1;                         // second luma passes a master may leave running behind it (the 10-bit kernel has LDS for one more region only)
 #ifndef HEVCDL_AHEAD
 #define HEVCDL_AHEAD 1
 #endif
@@ -70,7 +73,7 @@ constexpr int MSM = 0;
 constexpr int NREG = 1 + NPEND + AHEAD;
 #endif                        // regions per wave: [0] first pass / chroma / rough-mode slices, [1..NPEND] the second passes (master: their tickets; chain owner: [1] its split tasks), [REG_AHEAD] the look-ahead
 constexpr int REG_AHEAD = 1 + NPEND;
-constexpr int NSLOT = 20;                                     // result slots of a master: 0..9 first pass, 5..9 chroma, then one set of 5 per second pass that can be pending
+constexpr int NSLOT = 10 + 5 * NPEND;                                     // result slots of a master: 0..9 first pass, 5..9 chroma, then one set of 5 per second pass that can be pending
 // per-wave global scratch: one LAYER SET = coefficient layers [4][6144] int16 + reconstruction layers [4][6144]; the wave's own set is
 // followed by the best reconstruction of the CU under test and the task overlay (a CTU of trial reconstruction), then the RDOQ
 // per-position arrays, then NSLOT result slots (a layer set + attribute arrays + coder states each)
@@ -181,9 +184,9 @@ struct K {                             // wave-uniform kernel context (lives in 
   // The second luma passes of up to two EARLIER CUs of the CTU may still be running (their trial samples are in the picture): luma reference samples
   // inside such a CU's rectangle come from best_rec, which holds the reconstruction the search continued with (the first pass's winner).
   // -> srect[p]: (x0 | y0 << 16 | x1 << 32 | y1 << 48), 0 = none; ONE 8-byte word each, so that a helper copying this context never sees half a rectangle
-  unsigned long long srect[2];
-  GLB const pel_t *ssrc[2];            // ... and where the samples inside srect[p] are read: a plane of row stride 64 whose sample (0, 0) is the picture's (sorg & 0xffff, sorg >> 16)
-  int sorg[2];
+  unsigned long long srect[3];
+  GLB const pel_t *ssrc[3];            // ... and where the samples inside srect[p] are read: a plane of row stride 64 whose sample (0, 0) is the picture's (sorg & 0xffff, sorg >> 16)
+  int sorg[4];
   int pset, pad_pset;                  // the slot set of the second pass this wave is running (run_task)
   double lambda, sqrt_lambda, cweight, lambda_c;
   double err_scale[2][4];
@@ -231,11 +234,11 @@ struct __attribute__((aligned(16))) RdSmem {
   // winners of the CU under test, for the short form of its syntax count (enc_cu_syntax_fast): coefficient bits of the luma / chroma winner, its slot
   unsigned long long lw_cfrac, cw_cfrac; int lw_valid, cw_slot;
   // SATD sums of the NEXT CU's rough mode decision, computed by the master while the workgroup's other waves run this CU's chroma search (rmd_prefetch)
-  unsigned int satd_pre[NPEND == 2 ? 36 : 2]; int pre_key, pre_open, chroma_key, pad_ck;      // chroma_key: key of the CU whose five chroma modes were posted together with its second pass (est_intra_luma; 0: none)   pre_open: key of the PU whose SATD slices are open in this wave's ticket region (0: none)
+  unsigned int satd_pre[NPEND >= 2 ? 36 : 2]; int pre_key, pre_open, chroma_key, pad_ck;      // chroma_key: key of the CU whose five chroma modes were posted together with its second pass (est_intra_luma; 0: none)   pre_open: key of the PU whose SATD slices are open in this wave's ticket region (0: none)
   // Second passes left running behind the master (compress_cu): carry_ok: the CU being coded may leave its pass pending; pend_*: the passes pending, oldest
   // first (index of their CU among the CTU's coded CUs, region of their ticket); restart: a pending pass chose the split -> the CTU is walked again, CUs
   // [0, replay_upto) from the log, CU nocarry_leaf with the result that pass reached (its luma is not searched again)
-  int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[2], pend_reg[2], left_pending, resume_reg;   // resume_reg: ticket region of the pass that won, whose result CU nocarry_leaf takes over
+  int carry_ok, restart, leaf_idx, replay_upto, nocarry_leaf, pend_n, pend_leaf[3], pend_reg[3], left_pending, resume_reg;   // resume_reg: ticket region of the pass that won, whose result CU nocarry_leaf takes over
   uint8_t lab16[16];                  // the CTU's labels (the walk and the look-ahead read one per CU)
   uint8_t c8a[11][4];                 // saved 2Nx2N candidate of an 8x8 CU: attribute entries (levels and samples: entries 66 / 67 of the wave's log in HBM)
   // Look-ahead (est_intra_chroma -> est_intra_luma of the next CU): ahead_open 0 none / 1 region open / 2 frozen (no further claims); key of the PU, number of
@@ -357,6 +360,9 @@ DEV LDS Tables &tb() { return wg_shared().tab; }
 #endif
 #ifndef HEVCDL_FG_FIRST_MAX
 #define HEVCDL_FG_FIRST_MAX HEVCDL_CARRY_MAX   // helpers serve the masters' own regions before the pending passes up to this many masters (helper_step)
+#endif
+#ifndef HEVCDL_OWNER_LENDS
+#define HEVCDL_OWNER_LENDS 0                  // 1: the owner of a split chain runs other masters' tasks while it waits for its split tasks (spec_children).  Measured on the 600-frame job: 6.23 -> 6.28 s (it returns late to its own chain, and the join of its pass waits), so off
 #endif
 #ifndef HEVCDL_PREFETCH_MAX
 #define HEVCDL_PREFETCH_MAX 3                 // the master computes the next CU's rough-mode SATD during the chroma search up to this many masters (est_intra_chroma)
@@ -533,10 +539,11 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   const int rx0 = k.trx0 >> csh, ry0 = k.try0 >> csh, rx1 = k.trx1 >> csh, ry1 = k.try1 >> csh;
   GLB const pel_t *po = k.ovl + comp_off(c);
   const int ox = k.cx * cs_, oy = k.cy * cs_;
-  const unsigned long long sr0 = k.srect[0], sr1 = k.srect[1];
+  const unsigned long long sr0 = k.srect[0], sr1 = k.srect[1], sr2 = k.srect[2];
   const int spx0 = (int)(sr0 & 0xffff), spy0 = (int)((sr0 >> 16) & 0xffff), spx1 = (int)((sr0 >> 32) & 0xffff), spy1 = (int)(sr0 >> 48);
   const int sqx0 = (int)(sr1 & 0xffff), sqy0 = (int)((sr1 >> 16) & 0xffff), sqx1 = (int)((sr1 >> 32) & 0xffff), sqy1 = (int)(sr1 >> 48);
-  GLB const pel_t *ps0 = k.ssrc[0], *ps1 = k.ssrc[1];
+  GLB const pel_t *ps0 = k.ssrc[0], *ps1 = k.ssrc[1], *ps2 = k.ssrc[2];
+  const int srx0 = (int)(sr2 & 0xffff), sry0 = (int)((sr2 >> 16) & 0xffff), srx1 = (int)((sr2 >> 32) & 0xffff), sry1 = (int)(sr2 >> 48), so2x = k.sorg[2] & 0xffff, so2y = k.sorg[2] >> 16;
   const int so0x = k.sorg[0] & 0xffff, so0y = k.sorg[0] >> 16, so1x = k.sorg[1] & 0xffff, so1y = k.sorg[1] >> 16;
   auto unit_start = [&](int kk) { return kk < 2 * nu ? kk * u : (kk == 2 * nu ? 2 * n : 2 * n + 1 + (kk - 2 * nu - 1) * u); };
   auto unit_len = [&](int kk) { return kk == 2 * nu ? 1 : u; };
@@ -548,6 +555,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
     if (task && sx >= rx0 && sx < rx1 && sy >= ry0 && sy < ry1) return po + (sy - oy) * cs_ + (sx - ox);
     if (!c && sx >= spx0 && sx < spx1 && sy >= spy0 && sy < spy1) return ps0 + (sy - so0y) * 64 + (sx - so0x);     // an earlier CU whose second pass is pending
     if (!c && sx >= sqx0 && sx < sqx1 && sy >= sqy0 && sy < sqy1) return ps1 + (sy - so1y) * 64 + (sx - so1x);
+    if (!c && sx >= srx0 && sx < srx1 && sy >= sry0 && sy < sry1) return ps2 + (sy - so2y) * 64 + (sx - so2x);
     return p + (size_t)sy * st + sx;
   };
   // Every line element is ONE picture sample: its own when its unit is available, otherwise the last sample of the nearest
@@ -1960,6 +1968,7 @@ static_assert(12 * 21 * 8 + 4 * 256 <= LOG_COLD_N * LEAF_LOG, "cold area");
 struct DistCbf { uint32_t dist, cbf; unsigned long long cfrac; };
 template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_);
 DEVN int region_claim(LRegion &r);
+DEV void import_owner(int owner);
 template <bool LEAF> DEVN void run_task(LRegion &r, int idx_);
 
 // xRecurIntraCodingLumaQT TEncSearch.cpp:1430-1738
@@ -2140,6 +2149,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
   while (j < 4) {
     wsync();
     if (lane_id() < 4) { r.modes[lane_id()] = j + lane_id(); r.modes[8 + lane_id()] = 0; }          // task i: the split alternative of child j + i; [8 + c]: the chain's answer for child c is there
+    if (lane_id() == 0) r.dist[11] = 0;                                 // context copies made by the waves that took split tasks (helper_step)
     if (lane_id() == 0) s.ref_key[0] = -1;                          // a restarted chain meets the same block again with new neighbours
     region_open(r, T_LUMA_SPLIT, 0, cu, tu);
     for (int c = j; c < 4; c++) {
@@ -2162,9 +2172,48 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       PROF_MARK0();
       constexpr int SAVE_WORDS = (int)(offsetof(RdSmem, line) / 8);
       static_assert(offsetof(RdSmem, line) % 8 == 0 && offsetof(RdSmem, line) <= SAVE_BYTES, "state save area");
+      int mine = 0;                                                   // split tasks of this chain run by this wave itself
       while (lds_load(&r.done) < 4 - j) {
         const int idx = region_claim(r);
-        if (idx < 0) { __builtin_amdgcn_s_sleep(2); continue; }
+        if (idx < 0) {
+#if HEVCDL_OWNER_LENDS
+          // Every split task is taken and this wave would only wait (8.9 % of all wave time on the 600-frame job): it lends itself to the workgroup's masters -- one task
+          // of a first-pass / chroma / rough-mode region at a time, its own state parked in its workspace meanwhile, exactly as for a split task of its own.  Not before
+          // the waves that took its split tasks have copied its context (helper_step counts the copies in dist[11] of the region).
+          const int taken = (int)(lds_load(&r.ticket) & 0xffff) - mine;
+          if (lds_load((LDS int *)&r.dist[11]) >= taken) {
+            LDS WgShared &sh = wg_shared();
+            const int me = wave_id();
+            int ran = 0;
+            for (int q = 1; q < NW && !ran; q++) {
+              LRegion &fr = sh.reg[(me + q) % NW][0];
+              const int t = lds_load(&fr.ticket);
+              if ((t & 0xffff) >= (int)((unsigned)t >> 16)) continue;
+              const int fk = uni(fr.kind);
+              if (fk != T_LUMA_P1 && fk != T_CHROMA && fk != T_RMD) continue;
+              const int fi = region_claim(fr);
+              if (fi < 0) continue;
+              wsync();
+              for (int i = lane_id(); i < SAVE_WORDS; i += 64) s.my_save[i] = ((LDS const unsigned long long *)&s)[i];
+              wg_acquire();
+              import_owner(uni(fr.owner));
+              run_task<true>(fr, fi);
+              wg_release();
+              lds_add(&fr.done, 1);
+              wsync();
+              for (int i = lane_id(); i < SAVE_WORDS; i += 64) ((LDS unsigned long long *)&s)[i] = s.my_save[i];
+              wsync();
+              if (lane_id() < 3) s.ref_key[lane_id()] = -1;
+              if (lane_id() == 0) s.fline_key = -1;
+              wsync();
+              ran = 1;
+            }
+            if (ran) continue;
+          }
+#endif
+          __builtin_amdgcn_s_sleep(2); continue;
+        }
+        mine++;
         wsync();
         for (int i = lane_id(); i < SAVE_WORDS; i += 64) s.my_save[i] = ((LDS const unsigned long long *)&s)[i];
         run_task<true>(r, idx);
@@ -2406,14 +2455,14 @@ DEVN void rmd_prefetch(KR k, int x_, int y_, int log2_, int sliced_ = 0)
     const int ntasks = nrounds < NW ? nrounds : NW;
     const Cu ncu = { x, y, log2, 6 - log2, 0, 1 << (2 * (log2 - 2)), SIZE_2Nx2N }; const Tu ptu = { x, y, log2, 0, 0, 1 << (2 * (log2 - 2)) };
     wsync();
-    if (lane_id() < 36) s.satd_pre[NPEND == 2 ? lane_id() : 0] = 0;
+    if (lane_id() < 36) s.satd_pre[NPEND >= 2 ? lane_id() : 0] = 0;
     if (lane_id() == 0) { r.modes[0] = 0; r.modes[1] = nrounds; r.modes[2] = 2; s.pre_key = -1; }
     region_open(r, T_RMD, ntasks, ncu, ptu);
     return;
   }
   build_refs(k, 0, x, y, pn, 1);
   filter_refs(k, pn);
-  if (lane_id() < 36) s.satd_pre[NPEND == 2 ? lane_id() : 0] = 0;
+  if (lane_id() < 36) s.satd_pre[NPEND >= 2 ? lane_id() : 0] = 0;
   const int dcv = dc_value(k, s.line, pn);
   wsync();
   if (sliced && nrounds >= HEVCDL_RMD_SLICE_ROUNDS) { // the workgroup's other waves are free (the caller's ticket region too): the rounds in slices, as rmd_satd deals them
@@ -2446,6 +2495,15 @@ DEVN void rmd_prefetch_end(KR k, int x_, int y_, int log2_)
 // first pass's reconstruction back into the picture).  The split won: everything coded since stands on the wrong reconstruction and coder state -> the
 // other pending pass is waited for (its slots and the picture must be quiet) and the CTU is walked again from the log (process_unit).
 DEV void copy_best_rec_to_pic(KR k, const Cu &cu, int comp);
+DEV int free_pend_reg()
+{ // a ticket region 1..NPEND (= slot set + 1 = srect entry + 1) that no pending pass holds
+  LSmem &s = lds();
+  unsigned used = 0;
+  const int n = uni(s.pend_n);
+  for (int i = 0; i < NPEND; i++) if (i < n) used |= 1u << uni(s.pend_reg[i]);
+  for (int r = 1; r <= NPEND; r++) if (!((used >> r) & 1u)) return r;
+  return 1;
+}
 DEVN void pend_join_oldest(KR k, int site = 0)
 {
   PROF_T0();
@@ -2459,12 +2517,12 @@ DEVN void pend_join_oldest(KR k, int site = 0)
     const Cu pc = { uni(rp.cu[0]), uni(rp.cu[1]), uni(rp.cu[2]), uni(rp.cu[3]), uni(rp.cu[4]), uni(rp.cu[5]), uni(rp.cu[6]) };
     copy_best_rec_to_pic(k, pc, 0);
   }
-  if (won && n > 1) region_wait(my_region(uni(s.pend_reg[1])), 1);
+  if (won) for (int o = 1; o < n; o++) region_wait(my_region(uni(s.pend_reg[o])), 1);
   wsync();
   if (lane_id() == 0) {
     kk.srect[reg - 1] = 0;
-    if (won) { kk.srect[0] = 0; kk.srect[1] = 0; s.restart = 1; s.replay_upto = leaf; s.nocarry_leaf = leaf; s.resume_reg = reg; s.pend_n = 0; }
-    else { s.pend_leaf[0] = s.pend_leaf[1]; s.pend_reg[0] = s.pend_reg[1]; s.pend_n = n - 1; }
+    if (won) { kk.srect[0] = 0; kk.srect[1] = 0; kk.srect[2] = 0; s.restart = 1; s.replay_upto = leaf; s.nocarry_leaf = leaf; s.resume_reg = reg; s.pend_n = 0; }
+    else { s.pend_leaf[0] = s.pend_leaf[1]; s.pend_reg[0] = s.pend_reg[1]; s.pend_leaf[1] = s.pend_leaf[2]; s.pend_reg[1] = s.pend_reg[2]; s.pend_n = n - 1; }
   }
   wsync();
 #ifdef HEVCDL_KERNEL_PROF
@@ -2613,9 +2671,9 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
     { LDS K &kk = s.k; wsync(); kk.lz = zp * 16; kk.lx = ptu.x; kk.ly = ptu.y; wsync(); }       // this wave's own layer set serves the PU (second pass)
     // ---- rough mode decision ----
     const int rkey = (pu_log2 << 24) | (ptu.y << 12) | ptu.x;
-    if (NPEND == 2 && npu == 1 && uni(s.pre_key) == rkey) { // the SATD sums were computed ahead (rmd_prefetch); the gathered lines are still in place
+    if (NPEND >= 2 && npu == 1 && uni(s.pre_key) == rkey) { // the SATD sums were computed ahead (rmd_prefetch); the gathered lines are still in place
       wsync();
-      if (lane_id() < 36) s.satd[lane_id()] = s.satd_pre[NPEND == 2 ? lane_id() : 0];
+      if (lane_id() < 36) s.satd[lane_id()] = s.satd_pre[NPEND >= 2 ? lane_id() : 0];
       if (lane_id() == 0) { s.ref_key[0] = rkey; s.fline_key = rkey; s.pre_key = -1; }
       wsync();
     } else {
@@ -2696,12 +2754,12 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         // Launches of few units: the chain that bounds a frame is luma only -- this CU's winner -> rough modes of the next PU -> its candidates.  The winner's samples
         // sit in its result slot: the SATD rounds of the next PU are handed to the idle waves NOW, reading them there (srect / ssrc), while this wave copies the
         // winner's levels, samples and arrays (the slot is not written again before the rounds are collected: est_intra_chroma, ahead_open)
-        if (win < SLOT_CHROMA && npu == 1 && pu_log2 <= 5 && pu_log2 > min_tu_log2(cu) && lds_load(&wg_shared().remote) && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3      // (slots from SLOT_CHROMA on take this CU's chroma modes)
+        if (win < SLOT_CHROMA && npu == 1 && pu_log2 <= 5 && pu_log2 > min_tu_log2(cu) && lds_load(&wg_shared().remote) && HEVCDL_PREFETCH && NPEND >= 2 && cu.depth < 3      // (slots from SLOT_CHROMA on take this CU's chroma modes)
             && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) {
           int nx, ny, nl;
           if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
             if (uni(s.pend_n) == NPEND) { pend_join_oldest(k, 0); if (uni(s.restart)) return 0; }   // the ticket region (= slot set, = srect entry) the second pass below will take
-            early_reg = (uni(s.pend_n) && uni(s.pend_reg[0]) == 1) ? 2 : 1;
+            early_reg = free_pend_reg();
             wsync();
             if (lane_id() == 0) {
               LDS K &kk = s.k;
@@ -2748,11 +2806,11 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         // run on the assumption that it changes nothing (the unsplit TU wins ~95 % of the time) -- or later still (compress_cu).  If the split
         // wins, what was built on the assumption is redone.
         if (uni(s.pend_n) == NPEND) { pend_join_oldest(k, 0); if (uni(s.restart)) return 0; }   // no ticket region free: the oldest pending pass first
-        const int reg = (uni(s.pend_n) && uni(s.pend_reg[0]) == 1) ? 2 : 1;                 // a free ticket region = slot set + 1
+        const int reg = early_reg ? early_reg : free_pend_reg();                 // a free ticket region = slot set + 1 (the one the early SATD rounds named, if any)
         LRegion &r2 = my_region(reg);
         wsync();
         if (lane_id() == 0) { r2.modes[0] = (int)best_mode; r2.modes[1] = reg - 1; r2.cost[4] = best_cost; r2.dist[4] = best_dist; s.p2_pending = reg; }
-        if (lds_load(&wg_shared().remote) && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) {
+        if (lds_load(&wg_shared().remote) && HEVCDL_PREFETCH && NPEND >= 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) {
           // The chain that bounds a frame in this form is luma only: this CU's winner -> rough modes of the next PU -> its candidates.  The winner's samples
           // are in best_rec now: mark the CU as the pending pass's (readers take best_rec; check_rd_cost_intra writes the same word again) and hand the SATD
           // rounds of the next PU to the idle waves BEFORE the pass and the chroma modes are posted (est_intra_chroma collects them)
@@ -3149,7 +3207,11 @@ DEVN void region_run(KR k, LRegion &r)
   for (;;) {
     const int idx = region_claim(r);
     if (idx < 0) break;
+#ifdef HEVCDL_RR_INLINE
+    run_task_body<false>(r, idx);          // inside this function's frame: its registers are saved once per region, not once per task
+#else
     run_task<false>(r, idx);
+#endif
     wg_release();
     lds_add(&r.done, 1);
   }
@@ -3180,6 +3242,7 @@ DEV int helper_step()
       if (idx < 0) continue;
       wg_acquire();
       { PROF_T0(); if (AHEAD && uni(r.kind) == T_LUMA_AHEAD && idx < uni(r.pad_)) import_ahead(uni(r.owner)); else import_owner(uni(r.owner)); PROF_ADD(0, 53); }
+      if (uni(r.kind) == T_LUMA_SPLIT) lds_add((LDS int *)&r.dist[11], 1);          // the chain owner's context has been copied: it may lend its wave to other masters now (spec_children)
       run_task_body<false>(r, idx);
       wg_release();
       lds_add(&r.done, 1);
@@ -3211,7 +3274,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     wsync();
     const bool rich = lds_load(&wg_shared().remote) != 0;    // waves to spare: the second passes run on other CUs
     auto look_ahead = [&](int sliced) {
-      if (HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
+      if (HEVCDL_PREFETCH && NPEND >= 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX) { // the other waves have the chroma modes: the master looks ahead
         // (not from an 8x8 CU: its 2Nx2N / NxN choice is still open, so is the reconstruction the next CU will see)
         int nx, ny, nl;
         if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
@@ -3231,7 +3294,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     // have the candidates of the next CU
     const bool cremote = lds_load(&wg_shared().remote) == 2;
     int anx = 0, any = 0, anl = 0;
-    const bool la = rich && HEVCDL_PREFETCH && NPEND == 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX && next_leaf(k, cu, anx, any, anl) && anl >= 4 && anl <= 5;
+    const bool la = rich && HEVCDL_PREFETCH && NPEND >= 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX && next_leaf(k, cu, anx, any, anl) && anl >= 4 && anl <= 5;
     if (uni(s.pre_open) && (!la || uni(s.pre_open) != ((anl << 24) | (any << 12) | anx))) { region_run(k, r); if (lane_id() == 0) s.pre_open = 0; wsync(); }   // (slices opened for another PU: cannot happen by construction)
     if (la && !uni(s.pre_open)) rmd_prefetch(k, anx, any, anl, 2);               // reference lines of the next PU, its SATD rounds handed to the idle waves (est_intra_luma may have done it already) ...
     const bool posted = cremote && uni(s.chroma_key) == ((cu.log2 << 24) | (cu.y << 12) | cu.x);     // together with the second pass (remote_post)
@@ -3875,7 +3938,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   k.labels = (GLB const uint8_t *)p.labels + (size_t)frame * nctu * 16;
   k.coef_l = s.my_coef; k.rec_l = s.my_rec; k.best_rec = s.my_rec + 4 * 6144; k.ovl = s.my_ovl;
   k.q_cost = s.my_qcost; k.q_rate = s.my_qrate; k.slots = s.my_slots;        // (a wave that served other masters' tasks holds their context)
-  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.srect[0] = k.srect[1] = 0; k.ssrc[0] = k.ssrc[1] = k.best_rec; k.sorg[0] = k.sorg[1] = 0; k.pset = 0; k.pad_pset = 0;
+  k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.srect[0] = k.srect[1] = k.srect[2] = 0; k.ssrc[0] = k.ssrc[1] = k.ssrc[2] = k.best_rec; k.sorg[0] = k.sorg[1] = k.sorg[2] = k.sorg[3] = 0; k.pset = 0; k.pad_pset = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
   k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
@@ -3958,7 +4021,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       // Second passes are still out and this wave is about to wait for them, its workgroup's other waves idle: the look-ahead for the FIRST CU of the next CTU -- its
       // rough-mode sums, then its first-pass candidates.  Nothing of this CTU is touched (the candidates get a context of their own naming the next CTU, ahead_open);
       // what they assume is checked when the CU is reached (est_intra_luma), and a restart of this CTU drops them like any other look-ahead.
-      if (AHEAD && HEVCDL_PREFETCH && NPEND == 2 && !p.migrate && !uni(s.restart) && uni(s.pend_n) && i + 1 < i_end && uni(s.lw_valid) && !uni(s.ahead_open) && !uni(s.pre_open) &&
+      if (AHEAD && HEVCDL_PREFETCH && NPEND >= 2 && !p.migrate && !uni(s.restart) && uni(s.pend_n) && i + 1 < i_end && uni(s.lw_valid) && !uni(s.ahead_open) && !uni(s.pre_open) &&
           lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX && spare_waves()) {
         const int ni = i + 1, ncx = cx0 + ni % tw, ncy = cy0 + ni / tw, na = ncy * p.ctus_x + ncx;
         int nx = 0, ny = 0, nl = 0;
