@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof/<tag>_summary.txt (tools/profile_round.sh: rocprofv3 kernel trace + the FETCH_SIZE / WRITE_SIZE counter passes of a 128-frame launch)
+"""gpurun_out/prof/<tag>_summary.txt (tools/profile_round.sh: rocprofv3 kernel trace + the FETCH_SIZE / WRITE_SIZE counter passes of a 300-frame launch)
 -> profiles/<tag>_traffic.json, the file bench.py reports `roofline.traffic` from while the hash of rd_kernel.hip matches.
     python tools/traffic_json.py <tag> [frames of the counter launch, default 128]"""
 import hashlib
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 txt = open(os.path.join(ROOT, "gpurun_out", "prof", tag + "_summary.txt")).read()
 vals = {}
 for m in re.finditer(r"hevcdl_rd_frame_kernel[^|]*\| (FETCH_SIZE|WRITE_SIZE) = ([\d.eE+]+)", txt):
@@ -23,7 +23,8 @@ out = {"kernel": "hevcdl_rd_frame_kernel", "rd_kernel_sha16": sha,
        "fetch_bytes_per_ctu": vals["FETCH_SIZE"] * 1024 / ctus if "FETCH_SIZE" in vals else None,
        "write_bytes_per_ctu": vals["WRITE_SIZE"] * 1024 / ctus if "WRITE_SIZE" in vals else None,
        "note": "raw counter values (KB) of the L2 <-> fabric interface (requests served by the 256 MB Infinity Cache are counted as well); the guide's x2 FETCH_SIZE correction "
-               "is calibrated for wide coalesced streaming reads only and is NOT applied to this narrow access pattern (uncalibrated), WRITE_SIZE is uncalibrated; taken on a "
-               "%d-frame launch because the counter pass of the 600-frame launch does not finish within 20 minutes under the profiler" % frames}
+               "is calibrated for wide coalesced streaming reads only and is NOT applied to this narrow access pattern (uncalibrated), WRITE_SIZE is uncalibrated; one counter per "
+               "pass (--kernel-include-regex hevcdl_rd_frame_kernel) on a %d-frame launch: the regime of the timed 600-frame launch (more frames than CUs, frames migrate "
+               "between workgroups, two or three masters per workgroup)" % frames}
 json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
