@@ -1064,6 +1064,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   const double cgr00 = lambda * (double)ctx_bits(cab, cg_off, 0), cgr01 = lambda * (double)ctx_bits(cab, cg_off, 1);
   const double cgr10 = lambda * (double)ctx_bits(cab, cg_off + 1, 0), cgr11 = lambda * (double)ctx_bits(cab, cg_off + 1, 1);
   unsigned long long cgf_mask = 0;                     // significant-group flags after RDOQ, bit = raster index of the group
+  unsigned long long cgf_scan = 0;                     // the same flags, bit = index of the group in scan order (the last-position search walks them)
   auto cgf_at = [&](int gx, int gy) -> int { return (int)((cgf_mask >> (gy * wg + gx)) & 1ull); };
   int carry = 0;                                       // the previous group in scan order ended with c1 == 0
   bool cc_needed = true;                               // no group that keeps a level > 1 yet: the last-position search will walk the groups still to come
@@ -1260,7 +1261,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
         }
       } else flag = 1;
       acc = lane == 1 ? nb : (lane == 2 ? 0.0 : acc);
-      if (flag) { cgf_mask |= 1ull << cb; if ((g1m >> (16 * r)) & 0xffffull) cc_needed = false; }   // the last-position search ends in this group (a level > 1 stays)
+      if (flag) { cgf_mask |= 1ull << cb; cgf_scan |= 1ull << qq; if ((g1m >> (16 * r)) & 0xffffull) cc_needed = false; }   // the last-position search ends in this group (a level > 1 stays)
       RDOQ_MARK(34);
     }
     carry = (int)(((g1m >> (16 * (R - 1))) & 0xffffull) != 0ull);
@@ -1301,13 +1302,24 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
       wsync();
     }
     int found_last = 0;
+    // the per-position costs of the larger TUs come back from the wave's HBM workspace: those of the NEXT group that keeps its flag are asked for while this one is
+    // walked (a round trip of ~1.5 k cycles per group otherwise, a quarter of the routine's time)
+    int pg = -1; double pcc = 0.0, pcs = 0.0;
+    auto prefetch = [&](int below) {
+      const unsigned long long m = below > 0 ? (cgf_scan & ((1ull << below) - 1ull)) : 0ull;
+      if (!qlds && m) { pg = 63 - __clzll((long long)m); const int sp = pg * 16 + (lane & 15); pcc = gq_cost[Q_COEFF * 1024 + sp]; pcs = gq_cost[Q_SIG * 1024 + sp]; }
+      else pg = -1;
+    };
+    prefetch(cg_last + 1);
     for (int cgp = cg_last; cgp >= 0 && !found_last; cgp--) {
-      const int cgblk = uni(scan_cg[cgp]);
       if ((cgs_set >> cgp) & 1ull) base_cost -= ((cgs_ctx >> cgp) & 1ull) ? (((cgs_one >> cgp) & 1ull) ? cgr11 : cgr10) : (((cgs_one >> cgp) & 1ull) ? cgr01 : cgr00);
-      if (!((cgf_mask >> cgblk) & 1ull)) continue;
+      if (!((cgf_scan >> cgp) & 1ull)) continue;
       const int j = lane & 15, sp_j = cgp * 16 + j, blk_j = scan[sp_j];
       const int lv_j = dst[blk_j];
-      const double cc_j = q_cost_ld(Q_COEFF, sp_j), cs_j = q_cost_ld(Q_SIG, sp_j), c0_j = cost0_of(blk_j);
+      double cc_j, cs_j;
+      if (pg == cgp) { cc_j = pcc; cs_j = pcs; } else { cc_j = q_cost_ld(Q_COEFF, sp_j); cs_j = q_cost_ld(Q_SIG, sp_j); }
+      prefetch(cgp);
+      const double c0_j = cost0_of(blk_j);
       int py = blk_j >> log2n, px = blk_j - (py << log2n);
       if (cp.scan_type == SCAN_VER) { const int t = px; px = py; py = t; }
       const int gx2 = tb().t_group_idx[px], gy2 = tb().t_group_idx[py];
