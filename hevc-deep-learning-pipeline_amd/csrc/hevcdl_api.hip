@@ -423,10 +423,12 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // more units than takers (up to two units per taker; measured on 256 CUs: 150 frames 3.89 -> 3.79 s, 200 frames 3.92 -> 4.00 s, hence the limit): a pass is
   // posted only while a taker is free (rd_kernel.hip, remote_room)
   if (p.remote && 2 * n_units > ctx->remote_groups) p.remote = 3;
-  if (p.remote && 16 * n_units <= ctx->remote_groups) p.remote = 2;    // very few units: enough idle workgroups for the chroma modes of every master as well
-  // the ring of posted jobs has 512 entries (rd_kernel.hip RQ_SIZE): a unit has at most two passes posted, in the last form its five chroma modes as well
-  if (p.remote && (p.remote == 2 ? 7 : 2) * n_units > 512) p.remote = 0;
-  if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 8192, s));      // finished counter, queue head / tail, the ring
+  // very few units: enough idle workgroups for the chroma modes of every master as well (eleven jobs per unit in flight).  Measured on 256 CUs, chroma jobs posted /
+  // kept in the unit's own workgroup: 1 frame 2.84 / 3.10 s, 10 frames 2.95 / 3.17 s, 16 frames 3.38 / 3.18 s -- hence a twenty-second of the CUs, not a sixteenth
+  if (p.remote && 22 * n_units <= ctx->remote_groups) p.remote = 2;
+  // the ring of posted jobs has 2048 entries (rd_kernel.hip RQ_SIZE): a unit has at most two passes and the ten component jobs of its chroma modes posted
+  if (p.remote && 12 * n_units > 2048) p.remote = 0;
+  if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 4096 + 2048 * 8, s));      // finished counter, queue head / tail, the ring (2048 pointers behind byte 4096)
   // Which build of the 8-bit kernel.  The ten-wave build (rd_kernel_wide.hip) pays where it brings more MASTERS onto a CU, i.e. when the launch has more units than
   // the eight-wave build has waves: measured at 2160p on 256 CUs, 2560 frames 22.3 -> 19.5 s (+14 %; against the eight-wave build's best case, 2048 frames, +7 % per
   // frame).  Extra HELPERS do not pay: 600 frames (2-3 masters per workgroup) 6.40 -> 6.55 s, 2048 frames 16.75 -> 17.0 s -- a round of the wide build lasts 1.17 x as

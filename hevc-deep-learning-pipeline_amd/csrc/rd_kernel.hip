@@ -364,6 +364,9 @@ DEV LDS Tables &tb() { return wg_shared().tab; }
 #ifndef HEVCDL_OWNER_LENDS
 #define HEVCDL_OWNER_LENDS 0                  // 1: the owner of a split chain runs other masters' tasks while it waits for its split tasks (spec_children).  Measured on the 600-frame job: 6.23 -> 6.28 s (it returns late to its own chain, and the join of its pass waits), so off
 #endif
+#ifndef HEVCDL_CHROMA_ROOM
+#define HEVCDL_CHROMA_ROOM 0                 // launches of 17..170 units: > 0 posts a CU's chroma modes to other workgroups when at least this many of them are idle beyond the jobs already queued.  Measured (16 / 48): 20 frames 3.16 -> 3.9 s, 40 frames 3.17 -> 4.2 / 3.9 s, 75 frames 3.21 -> 3.66 / 3.46 s -- the takers are needed for the second passes; 0 = never
+#endif
 #ifndef HEVCDL_PREFETCH_MAX
 #define HEVCDL_PREFETCH_MAX 3                 // the master computes the next CU's rough-mode SATD during the chroma search up to this many masters (est_intra_chroma)
 #endif
@@ -1944,7 +1947,7 @@ DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
 DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
 DEVN int remote_poll(LRegion &r);
-DEVN int remote_room();
+DEVN int remote_room(int need = 1);
 DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4, int prepare_only);
 DEV void chroma_mode_list(int luma_mode, uint32_t (&mode_list)[5]);
 DEVN void chroma_collect(LRegion &r);
@@ -2841,7 +2844,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         const int rm = lds_load(&wg_shared().remote);
         // (very few units: the CU's five chroma modes are posted in the same breath -- everything a chroma mode reads is settled once the luma winner is imported, and
         //  posting here instead of in est_intra_chroma brings their answers, which the walk waits for, ~15 k cycles forward and saves a release of its own)
-        if (rm && (rm != 3 || remote_room())) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist, rm == 2 && cu.part == SIZE_2Nx2N);    // a workgroup without a unit runs it (few units in the launch)
+        if (rm && (rm != 3 || remote_room())) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist, cu.part == SIZE_2Nx2N && (rm == 2 || (rm == 1 && HEVCDL_CHROMA_ROOM > 0 && remote_room(HEVCDL_CHROMA_ROOM))));    // a workgroup without a unit runs it (few units in the launch)
         else region_open(r2, T_LUMA_P2, 1, cu, ptu);
         break;
       }
@@ -3304,7 +3307,8 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
     // look-ahead runs FIRST, its SATD rounds dealt to the idle waves (this wave's ticket region is still free), and the chroma search of this CU follows.
     // Launches of very few units: the five chroma modes go to other workgroups as well (posted first: they take longest to come back), this workgroup's waves
     // have the candidates of the next CU
-    const bool cremote = lds_load(&wg_shared().remote) == 2;
+    // (with more units the chroma modes go to other workgroups only while enough of them have nothing to do: est_intra_luma decided and posted them already)
+    const bool cremote = lds_load(&wg_shared().remote) == 2 || uni(s.chroma_key) == ((cu.log2 << 24) | (cu.y << 12) | cu.x);
     int anx = 0, any = 0, anl = 0;
     const bool la = rich && HEVCDL_PREFETCH && NPEND >= 2 && cu.depth < 3 && lds_load(&wg_shared().masters_active) <= HEVCDL_PREFETCH_MAX && next_leaf(k, cu, anx, any, anl) && anl >= 4 && anl <= 5;
     if (uni(s.pre_open) && (!la || uni(s.pre_open) != ((anl << 24) | (any << 12) | anx))) { region_run(k, r); if (lane_id() == 0) s.pre_open = 0; wsync(); }   // (slices opened for another PU: cannot happen by construction)
@@ -3743,18 +3747,19 @@ DEV GLB unsigned long long *rq_ring(GLB unsigned char *sched) { return (GLB unsi
 DEV GLB int *rq_idle(GLB unsigned char *sched) { return (GLB int *)(sched + 2560); }     // takers that are not running a job
 // hevcdl_rd_params.remote == 3 (more units than takers): a pass is posted only while some taker has nothing to do and nothing waits in the ring; otherwise it
 // stays in its own workgroup, as in a launch without takers
-DEVN int remote_room()
+DEVN int remote_room(int need_)
 {
+  const int need = uni(need_);
   int ok = 0;
   if (lane_id() == 0) {
     GLB unsigned char *sched = wg_shared().sched;
     const int idle = __hip_atomic_load(rq_idle(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int tail = __hip_atomic_load(rq_tail(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), head = __hip_atomic_load(rq_head(sched), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok = idle - (tail - head) > 0;
+    ok = idle - (tail - head) >= need;
   }
   return uni(ok);
 }
-enum { RQ_SIZE = 512, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_KIND = 22, JOB_IDX = 23,
+enum { RQ_SIZE = 2048, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB_TU = 11, JOB_MODE = 17, JOB_PSET = 18, JOB_MDIST = 19, JOB_MCOST = 20, JOB_KIND = 22, JOB_IDX = 23,
        JOB_CFRAC = 24, JOB_CTXP = 26, JOB_SPLIT = 28, JOB_PAIR = 29, JOB_HALF = 30, JOB_COUNTED = 31,       // int offsets in the header (8-byte values at even offsets)
        JOB_CTX = 24 };                        // 8-byte-word offset of a second pass's own context behind its header
 DEV GLB unsigned long long *cjob_block(int m) { return lds().my_log + (size_t)(LOG_CJOB + m) * (LEAF_LOG / 8); }

@@ -84,7 +84,7 @@ typedef struct hevcdl_config {
    * each other, which needs ALL of them resident at once.  The library therefore launches that form cooperatively (the runtime refuses the launch when
    * it cannot co-schedule the grid -- another context holding CUs or LDS, a CU mask -- and the library falls back to the independent form by itself);
    * set this bit to use the independent form always, e.g. when several contexts / processes share the device by design.  The same holds for launches of at most
-   * two thirds as many frames (x tiles) as CUs, which run on ALL CUs so that the empty ones take second luma passes (and, below a sixteenth, chroma modes) from the
+   * two thirds as many frames (x tiles) as CUs, which run on ALL CUs so that the empty ones take second luma passes (and, below a twenty-second, chroma modes) from the
    * others: cooperative as well, same fall-back, switched off by this bit (the context then also allocates workspace for its own frames only). */
   int32_t  exec_flags;
 #define HEVCDL_EXEC_NO_UNIT_HANDOVER 1
