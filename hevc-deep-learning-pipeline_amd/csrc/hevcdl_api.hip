@@ -448,7 +448,8 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
     const size_t need = ctx->scratch_per_wave * (size_t)(p.remote ? ctx->remote_groups : groups) * (size_t)waves;
     if (need > ctx->scratch_bytes) {
       if (ctx->d_scratch) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(ctx->d_scratch)); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
-      if (hipMalloc(&ctx->d_scratch, need) != hipSuccess) { (void)hipGetLastError(); ctx->d_scratch = nullptr; return HEVCDL_ERR_OOM; }
+      { const hipError_t e_ = hipMalloc(&ctx->d_scratch, need);
+        if (e_ != hipSuccess) { (void)hipGetLastError(); ctx->d_scratch = nullptr; return fail(ctx, HEVCDL_ERR_OOM, "decision-kernel workspace (1.6 MB per wave of the launch)", e_); } }
       ctx->scratch_bytes = need;
     }
     p.scratch = ctx->d_scratch;

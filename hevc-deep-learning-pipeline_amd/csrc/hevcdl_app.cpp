@@ -174,22 +174,23 @@ bool gather_rows_rccl(size_t n_blocks, const std::function<int(size_t)> &dev_of,
   for (const auto &c : contrib) words = std::max(words, c.size());
   for (auto &c : contrib) c.resize(words, ~0ull);
   std::vector<void *> comms(R, nullptr), d_send(R, nullptr), d_recv(R, nullptr);
-  auto fail = [&](const std::string &what, int code, bool nccl) { err = what + (nccl ? std::string(": ") + api.GetErrorString(code) : " failed (hip error " + std::to_string(code) + ")"); return false; };
+  auto cleanup = [&]() { for (int r = 0; r < R; r++) { api.hipSetDevice(ranks[r]); if (d_send[r]) api.hipFree(d_send[r]); if (d_recv[r]) api.hipFree(d_recv[r]); if (comms[r]) api.CommDestroy(comms[r]); } };
+  auto fail = [&](const std::string &what, int code, bool nccl) { err = what + (nccl ? std::string(": ") + api.GetErrorString(code) : " failed (hip error " + std::to_string(code) + ")"); cleanup(); return false; };
   int e = api.CommInitAll(comms.data(), R, ranks.data());
-  if (e) return fail("ncclCommInitAll", e, true);
+  if (e) { std::fill(comms.begin(), comms.end(), nullptr); return fail("ncclCommInitAll", e, true); }
   for (int r = 0; r < R; r++) {
     if ((e = api.hipSetDevice(ranks[r]))) return fail("hipSetDevice", e, false);
     if ((e = api.hipMalloc(&d_send[r], words * 8)) || (e = api.hipMalloc(&d_recv[r], words * 8 * (size_t)R))) return fail("hipMalloc", e, false);
     if ((e = api.hipMemcpy(d_send[r], contrib[r].data(), words * 8, 1 /* hipMemcpyHostToDevice */))) return fail("hipMemcpy", e, false);
   }
   if ((e = api.GroupStart())) return fail("ncclGroupStart", e, true);
-  for (int r = 0; r < R; r++) { api.hipSetDevice(ranks[r]); if ((e = api.AllGather(d_send[r], d_recv[r], words, 5 /* ncclUint64 */, comms[r], nullptr))) return fail("ncclAllGather", e, true); }
+  for (int r = 0; r < R; r++) { api.hipSetDevice(ranks[r]); if ((e = api.AllGather(d_send[r], d_recv[r], words, 5 /* ncclUint64 */, comms[r], nullptr))) { api.GroupEnd(); return fail("ncclAllGather", e, true); } }
   if ((e = api.GroupEnd())) return fail("ncclGroupEnd", e, true);
   for (int r = 0; r < R; r++) { api.hipSetDevice(ranks[r]); if ((e = api.hipDeviceSynchronize())) return fail("hipDeviceSynchronize", e, false); }
   table.resize(words * (size_t)R);
   api.hipSetDevice(ranks[0]);
   if ((e = api.hipMemcpy(table.data(), d_recv[0], words * 8 * (size_t)R, 2 /* hipMemcpyDeviceToHost */))) return fail("hipMemcpy", e, false);
-  for (int r = 0; r < R; r++) { api.hipSetDevice(ranks[r]); api.hipFree(d_send[r]); api.hipFree(d_recv[r]); api.CommDestroy(comms[r]); }
+  cleanup();
   return true;
 }
 
