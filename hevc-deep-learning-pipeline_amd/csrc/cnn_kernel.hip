@@ -443,7 +443,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[n][t];
           const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-          a3_out[(size_t)q * 2048 + ch * 16 + t * 4 + g4] = fmaxf(v, 0.f);      // flatten order (C,H,W), use_model.py:53; row 4 * ctu + q of the head's input
+          a3_out[(size_t)q * 2048 + ch * 16 + t * 4 + g4] = split_f16(fmaxf(v, 0.f));      // flatten order (C,H,W), use_model.py:53; row 4 * ctu + q of the head's input, stored split: fc1's operand form (fc_kernel.hip)
         }
       }
       __syncthreads();

@@ -2,9 +2,12 @@
 // but the last) and the label post-processing (use_model.py:101-119 + the boundary clamp), batched over CTUs for gfx950 (MI355X).
 //
 // cnn_kernel.hip leaves the flattened conv3 output of every (CTU, quadrant) in HBM: A[row = 4 * ctu + quadrant][2048].  Here a workgroup
-// takes 64 rows (16 CTUs) and runs the three layers as GEMMs on v_mfma_f32_16x16x4_f32:
+// takes 64 rows (16 CTUs) and runs the three layers as GEMMs on the matrix cores:
 //   fc1  D[64][256] = A[64][2048] x W1[2048][256]   wave w owns output columns [64w, 64w + 64): 4 M-tiles x 4 N-tiles = 16 accumulators;
-//        the 2 MB of fc1 weights are read once per 16 CTUs (once per CTU when the head lived in the per-CTU kernel: L2 bound there)
+//        the 2 MB of fc1 weights are read once per 16 CTUs (once per CTU when the head lived in the per-CTU kernel: L2 bound there).
+//        97 % of the head's arithmetic: on v_mfma_f32_16x16x32_f16 with SPLIT operands like the convolutions (cnn_kernel.hip: hi = f16(v), lo = f16(v - hi), a product
+//        is hi*hi + hi*lo + lo*hi in f32) -- the conv kernel leaves its outputs as such pairs (one 32-bit word each, so the row layout of A is unchanged) and the host
+//        packs W1 as pairs in B-operand lane order in exactly the bytes the f32 matrix took (hevcdl_api.hip pack_fc1).  fc2 / fc3 stay on v_mfma_f32_16x16x4_f32.
 //   fc2  D[64][64]  = H1[64][256] x W2[256][64]     wave w owns N-tile w, 4 M-tiles; H1 from LDS
 //   fc3  D[64][16]  = H2[64][64]  x W3[64][16]      wave w owns M-tile w; H2 from LDS
 // Operand layout of the instruction: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; result register r of lane l
@@ -16,6 +19,24 @@
 namespace {
 #define GLB __attribute__((address_space(1)))
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+// 8 split values (k = 0..7 of a lane, one word each: low half hi, high half lo) -> the hi and the lo operand of the f16 MFMA
+__device__ __forceinline__ void gather_hl(const u4 &x, const u4 &y, h8 &hi, h8 &lo)
+{
+  u4 a, b;
+  a[0] = __builtin_amdgcn_perm(x[1], x[0], 0x05040100u); b[0] = __builtin_amdgcn_perm(x[1], x[0], 0x07060302u);
+  a[1] = __builtin_amdgcn_perm(x[3], x[2], 0x05040100u); b[1] = __builtin_amdgcn_perm(x[3], x[2], 0x07060302u);
+  a[2] = __builtin_amdgcn_perm(y[1], y[0], 0x05040100u); b[2] = __builtin_amdgcn_perm(y[1], y[0], 0x07060302u);
+  a[3] = __builtin_amdgcn_perm(y[3], y[2], 0x05040100u); b[3] = __builtin_amdgcn_perm(y[3], y[2], 0x07060302u);
+  hi = __builtin_bit_cast(h8, a); lo = __builtin_bit_cast(h8, b);
+}
+__device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, const h8 &bl, v4f c)
+{ // acc += (ah + al) * (bh + bl) without al * bl
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+}
 __device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 constexpr int H1_ROW = 260, H2_ROW = 68;     // LDS pitches: + 4 floats keep the 16 rows of an A fragment on different banks
 struct FcSmem { float h1[64 * H1_ROW]; float h2[64 * H2_ROW]; float lg[64][16]; };
@@ -32,46 +53,45 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
   const float GLB *W = (const float GLB *)p.weights;
 
   { // ---- fc1 ----------------------------------------------------------------------------------------------------
-    const float GLB *W1 = W + HEVCDL_W_FC1 + (size_t)g4 * 256 + wave * 64 + i16;     // B[k0 + g4][64 * wave + 16 * nt + i16]
-    const float GLB *a_ptr[4]; bool a_ok[4];
+    // B: [k-step of 32][N-tile of 16][hi | lo][64 lanes] x 16 bytes (8 halves: k = 32 * step + 8 * (lane >> 4) + j, n = 16 * tile + (lane & 15))
+    const u4 GLB *W1 = (const u4 GLB *)(W + HEVCDL_W_FC1) + lane + (size_t)(4 * wave) * 128;
+    const u4 GLB *a_ptr[4]; bool a_ok[4];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
       const int r = row0 + mt * 16 + i16;
       a_ok[mt] = r < n_rows;
-      a_ptr[mt] = (const float GLB *)p.a3 + (size_t)(a_ok[mt] ? r : 0) * 2048 + g4;
+      a_ptr[mt] = (const u4 GLB *)((const float GLB *)p.a3 + (size_t)(a_ok[mt] ? r : 0) * 2048 + 8 * g4);     // A[i16][k = 32 * step + 8 * g4 + j]: two 16-byte loads per k-step
     }
     v4f acc[4][4];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (v4f){ 0.f, 0.f, 0.f, 0.f };
-    // two register sets of 4 k-steps (A: 4 M-tiles, B: 4 N-tiles): the loads of the next set are in flight under 64 MFMAs
-    float a0[4][4], b0[4][4], a1[4][4], b1[4][4];
-    auto load_set = [&](float (&a)[4][4], float (&b)[4][4], int k0) {
+    // two register sets of one k-step (A: 4 M-tiles x 2 loads, B: 4 N-tiles x hi / lo): the loads of the next step are in flight under 48 MFMAs
+    u4 a0[4][2], b0[4][2], a1[4][2], b1[4][2];
+    auto load_set = [&](u4 (&a)[4][2], u4 (&b)[4][2], int ks) {
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
+      for (int mt = 0; mt < 4; mt++) { a[mt][0] = a_ptr[mt][8 * ks]; a[mt][1] = a_ptr[mt][8 * ks + 1]; }
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) a[s][mt] = a_ptr[mt][k0 + 4 * s];
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) b[s][nt] = W1[(size_t)(k0 + 4 * s) * 256 + nt * 16];
-      }
+      for (int nt = 0; nt < 4; nt++) { b[nt][0] = W1[((size_t)ks * 16 + nt) * 128]; b[nt][1] = W1[((size_t)ks * 16 + nt) * 128 + 64]; }
     };
-    auto mac_set = [&](float (&a)[4][4], float (&b)[4][4]) {
+    auto mac_set = [&](u4 (&a)[4][2], u4 (&b)[4][2]) {
 #pragma unroll
-      for (int s = 0; s < 4; s++)
+      for (int mt = 0; mt < 4; mt++) {
+        h8 ah, al;
+        gather_hl(a[mt][0], a[mt][1], ah, al);
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-          for (int nt = 0; nt < 4; nt++) acc[mt][nt] = mfma4(a[s][mt], b[s][nt], acc[mt][nt]);
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = mfma3(ah, al, __builtin_bit_cast(h8, b[nt][0]), __builtin_bit_cast(h8, b[nt][1]), acc[mt][nt]);
+      }
     };
     load_set(a0, b0, 0);
 #pragma unroll 1
-    for (int k0 = 0; k0 < 2048; k0 += 32) {
-      load_set(a1, b1, k0 + 16);
+    for (int ks = 0; ks < 64; ks += 2) {
+      load_set(a1, b1, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
       mac_set(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      load_set(a0, b0, k0 + 32 < 2048 ? k0 + 32 : 0);
+      load_set(a0, b0, ks + 2 < 64 ? ks + 2 : 0);
       __builtin_amdgcn_sched_barrier(0);
       mac_set(a1, b1);
       __builtin_amdgcn_sched_barrier(0);

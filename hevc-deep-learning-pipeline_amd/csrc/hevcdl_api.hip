@@ -193,6 +193,20 @@ static void fold_bn_eval(const float *g, const float *be, int oc, float *dst_g, 
     dst_g[c] = (float)a; dst_be[c] = (float)((double)be[c] - (double)rm[c] * a);
   }
 }
+// fc1 (2048 -> 256) for the split-f16 MFMA of fc_kernel.hip: [k-step of 32][N-tile of 16][hi | lo][64 lanes][8 halves], lane l element j <-> k = 32 * step + 8 * (l >> 4) + j,
+// n = 16 * tile + (l & 15); the pairs take exactly the bytes of the f32 matrix, the bias follows as before
+static void pack_fc1(const float *w, const float *b, float *dst)
+{
+  uint16_t *d16 = (uint16_t *)dst;
+  for (int ks = 0; ks < 64; ks++) for (int nt = 0; nt < 16; nt++) for (int l = 0; l < 64; l++) for (int j = 0; j < 8; j++) {
+    const int k = 32 * ks + 8 * (l >> 4) + j, n = nt * 16 + (l & 15);
+    const float v = w[(size_t)n * 2048 + k];
+    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+    const size_t base = (((size_t)ks * 16 + nt) * 2) * 512;
+    d16[base + (size_t)l * 8 + j] = hi; d16[base + 512 + (size_t)l * 8 + j] = lo;
+  }
+  memcpy(dst + (size_t)2048 * 256, b, 256 * sizeof(float));
+}
 static void pack_fc(const float *w, const float *b, int out, int in, float *dst)
 { for (int j = 0; j < out; j++) for (int k = 0; k < in; k++) dst[(size_t)k * out + j] = w[(size_t)j * in + k]; memcpy(dst + (size_t)in * out, b, out * sizeof(float)); }
 
@@ -242,7 +256,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
     fold_bn_eval(weights + B_C2G, weights + B_C2BE, 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 128);
     fold_bn_eval(weights + B_C3G, weights + B_C3BE, 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 256);
   }
-  pack_fc(weights + B_F1W, weights + B_F1B, 256, 2048, pk.data() + HEVCDL_W_FC1);
+  pack_fc1(weights + B_F1W, weights + B_F1B, pk.data() + HEVCDL_W_FC1);
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_flag, sizeof(int)));
