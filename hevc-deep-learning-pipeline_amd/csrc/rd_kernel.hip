@@ -3763,6 +3763,12 @@ enum { RQ_SIZE = 2048, JOB_DONE = 0, JOB_DIST = 1, JOB_COST = 2, JOB_CU = 4, JOB
        JOB_CFRAC = 24, JOB_CTXP = 26, JOB_SPLIT = 28, JOB_PAIR = 29, JOB_HALF = 30, JOB_COUNTED = 31,       // int offsets in the header (8-byte values at even offsets)
        JOB_CTX = 24 };                        // 8-byte-word offset of a second pass's own context behind its header
 DEV GLB unsigned long long *cjob_block(int m) { return lds().my_log + (size_t)(LOG_CJOB + m) * (LEAF_LOG / 8); }
+// Two takers on different XCDs write into neighbouring job headers (a chroma mode's two components: distortion, counter, answer, done flag -- the first 128 bytes of a
+// 192-byte log entry).  Their L2s only merge dirty BYTES of a line, and an acquire keeps a line its own XCD has written to, so no two headers may share a 128-byte line:
+// with entries 192 bytes apart and the first one 0 or 64 bytes into a line, header e covers bytes [o + 192 e, o + 192 e + 128) and never ends in the line the next begins in.
+static_assert(LEAF_LOG == 192 && (LOG_CJOB * LEAF_LOG) % 64 == 0 && (BD != 8 || (4 * 6144 * 2 + 6 * 6144 * (int)sizeof(pel_t) + N_SAVE * SAVE_BYTES) % 128 == 0) && SCR_WAVE % 128 == 0,
+              "job headers: the log starts on a line, every header 0 or 64 bytes into one");
+static_assert(JOB_COUNTED * 4 + 4 <= 128, "job header fits the first 128 bytes of its log entry");
 DEVN void remote_post(KR k, const Cu cu_, const Tu tu_, int reg_, int mode_, double memo_cost, uint32_t memo_dist, int with_chroma_)
 {
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int reg = uni(reg_), mode = uni(mode_), pset = reg - 1, with_chroma = uni(with_chroma_);
