@@ -464,7 +464,9 @@ def main():
                                    % (W, H, qp, F, " (C4 of BASELINE.json)" if is_c4 else "", per_rank),
                        "frames": F, "frames_per_gpu": per_rank, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         # (launch_rd's rule: the ten-wave build of the kernel from four frames per workgroup on)
+                         "kernel": "hevcdl_rd_frame_kernel_wide" if Fr >= 4 * min(Fr, torch.cuda.get_device_properties(dev).multi_processor_count) else "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
                          "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
                          "units_per_launch": "%d frames x %d CTUs (rank 0)" % (Fr, ctus)},
             "est_bits_per_frame": total_bits / max(1, F),

@@ -443,12 +443,14 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // the ring of posted jobs has 2048 entries (rd_kernel.hip RQ_SIZE): a unit has at most two passes and the ten component jobs of its chroma modes posted
   if (p.remote && 12 * n_units > 2048) p.remote = 0;
   if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 4096 + 2048 * 8, s));      // finished counter, queue head / tail, the ring (2048 pointers behind byte 4096)
-  // Which build of the 8-bit kernel.  The ten-wave build (rd_kernel_wide.hip: 168 registers per lane instead of 256, no look-ahead region) pays from about two units per
-  // workgroup on.  Measured at 2160p on 256 CUs, eight- / ten-wave build: 200 frames 3.53 / 4.21 s, 300 frames 4.16 / 4.59 s, 450 frames 5.17 / 5.21 s, 600 frames
-  // 6.24 / 6.11 s, 1024 frames 10.33 / 9.50 s, 2048 frames 16.08 / 15.66 s, 2560 frames 21.47 / 18.14 s.  Launches in the few-units form keep the eight-wave build.
+  // Which build of the 8-bit kernel.  Measured at 2160p on 256 CUs, eight- / ten-wave build (rd_kernel_wide.hip: 168 registers per lane instead of 256, no look-ahead
+  // region): 200 frames 3.53 / 4.21 s, 300 frames 4.16 / 4.59 s, 450 frames 5.17 / 5.21 s, 600 frames 6.24 / 6.11 s, 1024 frames 10.33 / 9.50 s, 2048 frames
+  // 16.08 / 15.66 s, 2560 frames 21.47 / 18.14 s -- but the ten-wave build moves three times the bytes (600 frames: 5.8 MB per CTU through the L2s against 1.85 MB:
+  // register spills at 168 registers, the CU walk's snapshots in HBM).  It is chosen where it clearly pays: from four units per workgroup on.  Launches in the
+  // few-units form keep the eight-wave build.
   bool wide = false;
   if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW))
-    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 2 * groups);
+    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 4 * groups);
   if (wide) p.remote = 0;
   const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
   const int threads = 64 * waves;
