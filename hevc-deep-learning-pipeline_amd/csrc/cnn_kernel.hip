@@ -31,18 +31,20 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define HEVCDL_CNN_SKEW 40            // start offset of the second workgroup of a CU, in units of 8128 cycles (see the kernel)
 #endif
 #define LDS __attribute__((address_space(3)))
+// keeps eight loaded registers from being re-expressed as a load of a loop-carried address (which would put the load next to its use)
+#define PIN8(r) do { _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) asm volatile("" : "+v"(r[i_])); } while (0)
 #define GLB __attribute__((address_space(1)))
 
-constexpr int A_CH = 328;                  // 18x18 halo'd 16x16 map, channel stride == 8 (mod 32 banks)
+constexpr int A_CH = 336;                  // 18x18 halo'd 16x16 map, channel stride == 16 (mod 32 banks): see the bank note at conv2
 constexpr int A_ROW = 18;
-constexpr int A2_CH = 104;                 // 10x10 halo'd 8x8 map
+constexpr int A2_CH = 112;                 // 10x10 halo'd 8x8 map, channel stride == 16 (mod 32 banks)
 constexpr int A2_ROW = 10;
-constexpr int T64_ROW = 72, T64_CH = 36 * 72;   // fp32 input tile of HALF the CTU (32 rows + halo 2; conv64 runs in two halves), row pitch == 8 (mod 32)
-constexpr int T32_ROW = 40, T32_CH = 36 * 40;   // fp32 input tile of one quadrant, halo 2
+constexpr int T64_ROW = 72, T64_CH = 36 * 72 + 16;   // input tile of HALF the CTU (32 rows + halo 2; conv64 runs in two halves): row pitch == 8, channel stride == 16 (mod 32 banks)
+constexpr int T32_ROW = 40, T32_CH = 36 * 40 + 16;   // input tile of one quadrant, halo 2: row pitch == 8, channel stride == 16 (mod 32 banks); hevcdl_conv5_slot_tap
 
 struct CnnSmem {
   float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95), stored split (hi | lo halves): the operand form of the convolutions
-  int koff64[96], koff32[96];              // im2col offset of tap k = (c*5+ky)*5+kx inside the input tiles (k >= 75: padding, offset 0, zero weight)
+  int koff64[80], koff32[80];              // im2col offset, inside the input tiles, of the tap in K slot k (hevcdl_conv5_slot_tap; a padding slot reads a tap that keeps the gather conflict-free, zero weight)
   float act12[32 * A_CH];                  // conv1 output (channels 0..15) ++ conv64 output (16..31): cat of use_model.py:50
   union {
     float t64[3 * T64_CH];                 // conv64 input tile of one half of the CTU (only live before the quadrant loop)
@@ -106,70 +108,84 @@ __device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, c
 }
 
 // 5x5 conv (3 -> 16, zero pad 2 relative to the region) + BN(train) + ReLU + POOLxPOOL max pool -> 16 maps of 16x16.
-// tile: fp32 region with a 2-pixel zero halo (row pitch ROW, channel stride CH); koff: im2col offsets for that pitch.
-// POOL == 4 (conv64, 64x64 region): one M-tile = one 4x4 pool window.   POOL == 2 (conv1, 32x32 quadrant): one
-// M-tile = 4 horizontally adjacent 2x2 windows, lane group g = lane >> 4 ends up with window g in its 4 registers.
-// The pooled extreme (max for gamma >= 0, min otherwise) is written straight into the halo'd destination map and
-// rescaled in place once the statistics of the whole map are known.
+// tile: region of split words with a 2-pixel zero halo (row pitch ROW, channel stride CH); koff: im2col offsets of the 80 K slots for that pitch.
+// Operand form (round 4): the A operand of a k-step is FOUR RAW WORDS of the tile -- the (hi, lo) halves of four taps, exactly as they lie in LDS, no repacking -- and
+// the step is two MFMAs: B1 holds the weight's hi half against both halves of the word (a * bh), B2 its lo half against the word's hi half only (ah * bl): the same three
+// partial products as conv2 / conv3 form with three MFMAs and eight v_perm per 32 taps.  75 taps -> 5 k-steps of 16 -> 10 MFMAs per tile (9 before), 20 LDS words per lane
+// and tile (24 before), no VALU between the reads and the MFMAs of k-steps 0..3: their four words are kx = 0..3 of one tile row (hevcdl_conv5_slot_tap), read through ONE
+// per-lane pointer by two ds_read2_b32 into four consecutive registers; step 4 (the kx = 4 column) has a pointer per word.  Everything else in an address is an
+// immediate offset (the 4 tiles of an iteration and the words of a row are at fixed distances).
+// An M-tile is an 8 x 2 block of positions for BOTH pool sizes (its 16 words cover 16 banks at a row pitch == 8 (mod 32); hevcdl_conv5_slot_tap pairs the taps of
+// the two lane groups of a read 16 banks apart).  POOL == 2 (conv1, 32x32 quadrant): row i of the tile = member i & 3 of the 2x2 window i >> 2, lane group g = lane >> 4 ends up with
+// window g in its 4 registers.  POOL == 4 (conv64): row i = column i & 3, row (i >> 2) & 1 of the upper or lower half of the 4x4 window i >> 3; a window is finished from the
+// two vertically adjacent tiles of an iteration (in registers) and one exchange between lane groups g and g ^ 1.
+// The pooled extreme (max for gamma >= 0, min otherwise) is written straight into the halo'd destination map and rescaled in place once the statistics of the whole map are known.
 // phase 0: the whole map in one call (conv1 on a quadrant).  phase 1 / 2: upper / lower half of the CTU for conv64 (tile rows are then
 // relative to the half); the statistics of the halves meet in sm.red and the map is normalised after the second.
 template <int POOL>
 __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *out, int tid, int phase)
 {
   constexpr int ROW = (POOL == 4) ? T64_ROW : T32_ROW;
-  constexpr int TILES = (POOL == 4) ? 32 : 16;      // per wave and call
-  const int tile0 = (phase == 2) ? 128 : 0, yoff = (phase == 2) ? 32 : 0;
+  constexpr int ITERS = (POOL == 4) ? 8 : 4;        // per wave and call: 8 rows of the region, 4 tiles an iteration
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  // B operands: 3 k-steps x (hi, lo); k-value j of lane group g in k-step s is tap 32 s + 8 g + j
   const u4 GLB *wq = (const u4 GLB *)w + lane;
-  h8 bh[3], bl[3];
+  h8 b1[5], b2[5];
 #pragma unroll
-  for (int ks = 0; ks < 3; ks++) { bh[ks] = __builtin_bit_cast(h8, wq[(2 * ks) * 64]); bl[ks] = __builtin_bit_cast(h8, wq[(2 * ks + 1) * 64]); }
+  for (int ks = 0; ks < 5; ks++) { b1[ks] = __builtin_bit_cast(h8, wq[(2 * ks) * 64]); b2[ks] = __builtin_bit_cast(h8, wq[(2 * ks + 1) * 64]); }
   const float bias = w[HEVCDL_W_C5 + i], gamma = w[HEVCDL_W_C5 + 16 + i];
-  int ko[24];
+  const int px = (POOL == 4) ? 4 * (i >> 3) + (i & 3) : 2 * (i >> 2) + (i & 1), py = (POOL == 4) ? (i >> 2) & 1 : (i >> 1) & 1;
+  const unsigned LDS *kp[8];                         // this lane's pointers into the wave's first tile: [s] word 0 of k-step s < 4 (words 1..3 follow it), [4 + j] word j of step 4
 #pragma unroll
-  for (int q = 0; q < 24; q++) ko[q] = koff[32 * (q >> 3) + 8 * g + (q & 7)];
-  const unsigned LDS *tw = (const unsigned LDS *)tile;
+  for (int q = 0; q < 8; q++) kp[q] = (const unsigned LDS *)tile + (8 * wave + py) * ROW + px + koff[q < 4 ? 16 * q + 4 * g : 64 + 4 * g + (q - 4)];
+  auto word = [&](int ks, int j, int off) { return ks < 4 ? kp[ks][off + j] : kp[4 + j][off]; };
   double s = 0, ss = 0;
 #pragma unroll 1
-  for (int t0 = 0; t0 < TILES; t0 += 4) {
-    v4f acc[4]; int base[4];
+  for (int it = 0; it < ITERS; it++) {
+    v4f acc[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int t = tile0 + wave * TILES + t0 + u;
-      int y, x;
-      if (POOL == 4) { y = 4 * (t >> 4) + (i >> 2) - yoff; x = 4 * (t & 15) + (i & 3); }
-      else { y = 2 * (t >> 2) + ((i >> 1) & 1); x = 2 * (4 * (t & 3) + (i >> 2)) + (i & 1); }
-      base[u] = y * ROW + x;
-      acc[u] = (v4f){ bias, bias, bias, bias };
-    }
-    // A operands ping-pong between two register sets: the 8 LDS reads of (k-step, tile) pair p + 1 are issued before the MFMAs of pair p
-    unsigned w0[8], w1[8];
+    for (int u = 0; u < 4; u++) acc[u] = (v4f){ bias, bias, bias, bias };
+    // tile u of the iteration: POOL 2: columns 8u of one tile row;  POOL 4: tile row u >> 1, columns 8 (u & 1) of a 16 x 4 block (four windows)
+    auto toff = [](int u) { return (POOL == 4) ? (u >> 1) * 2 * ROW + 8 * (u & 1) : 8 * u; };
+    // A operands ping-pong between two register sets: the 4 LDS reads of (k-step, tile) pair p + 1 are issued before the MFMAs of pair p
+    u4 w0, w1;
 #pragma unroll
-    for (int j = 0; j < 8; j++) w0[j] = tw[base[0] + ko[j]];
+    for (int j = 0; j < 4; j++) w0[j] = word(0, j, toff(0));
 #pragma unroll
-    for (int p = 0; p < 12; p++) {
-      unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
-      if (p < 11) {
+    for (int p = 0; p < 20; p++) {
+      u4 &wc = (p & 1) ? w1 : w0; u4 &wn = (p & 1) ? w0 : w1;
+      if (p < 19) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) wn[j] = tw[base[(p + 1) & 3] + ko[8 * ((p + 1) >> 2) + j]];
+        for (int j = 0; j < 4; j++) wn[j] = word((p + 1) >> 2, j, toff((p + 1) & 3));
       }
-      h8 ah, al;
-      gather_hl(wc, ah, al);
-      acc[p & 3] = mfma3(ah, al, bh[p >> 2], bl[p >> 2], acc[p & 3]);
+      const h8 a = __builtin_bit_cast(h8, wc);
+      acc[p & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2[p >> 2], acc[p & 3], 0, 0, 0);
+      acc[p & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1[p >> 2], acc[p & 3], 0, 0, 0);
     }
+    { // next iteration: POOL 2: two rows down;  POOL 4: 16 columns to the right, after four of them four rows down
+      const int step = (POOL == 4) ? (((it & 3) == 3) ? 4 * ROW - 48 : 16) : 2 * ROW;
+#pragma unroll
+      for (int q = 0; q < 8; q++) kp[q] += step;
+    }
+    float e[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int t = tile0 + wave * TILES + t0 + u;
       const v4f a = acc[u];
       s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
       ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
-      float e = (gamma >= 0.f) ? fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)) : fminf(fminf(a.x, a.y), fminf(a.z, a.w));
-      if (POOL == 4) {
-        const float o1 = __shfl_xor(e, 16); e = (gamma >= 0.f) ? fmaxf(e, o1) : fminf(e, o1);
-        const float o2 = __shfl_xor(e, 32); e = (gamma >= 0.f) ? fmaxf(e, o2) : fminf(e, o2);
-        if (g == 0) out[i * A_CH + ((t >> 4) + 1) * A_ROW + (t & 15) + 1] = e;
-      } else out[i * A_CH + ((t >> 2) + 1) * A_ROW + 4 * (t & 3) + g + 1] = e;
+      e[u] = (gamma >= 0.f) ? fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)) : fminf(fminf(a.x, a.y), fminf(a.z, a.w));
+    }
+    if (POOL == 4) {
+      const int prow = 2 * wave + (it >> 2) + ((phase == 2) ? 8 : 0);      // pooled row of the iteration's windows
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++) {
+        float v = (gamma >= 0.f) ? fmaxf(e[tc], e[2 + tc]) : fminf(e[tc], e[2 + tc]);
+        const float o = __shfl_xor(v, 16); v = (gamma >= 0.f) ? fmaxf(v, o) : fminf(v, o);
+        if (!(g & 1)) out[i * A_CH + (prow + 1) * A_ROW + 4 * (it & 3) + 2 * tc + (g >> 1) + 1] = v;
+      }
+    } else {
+      const int prow = 4 * wave + it;
+#pragma unroll
+      for (int u = 0; u < 4; u++) out[i * A_CH + (prow + 1) * A_ROW + 4 * u + g + 1] = e[u];
     }
   }
   // per-channel statistics over the whole map: lane groups, then waves
@@ -227,8 +243,8 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 
   // ---- stage 0: CTU input -> LDS (coalesced rows of the planes), LUT, im2col tables, zeroed halo'd maps --------
   sm.lut[tid] = split_f16((float)tid / 255.0f);
-  if (tid < 96) {
-    const int k = tid < 75 ? tid : 0, c = k / 25, r = k - c * 25, ky = r / 5, kx = r - ky * 5;   // tap 75 is padding (zero weight)
+  if (tid < 80) {
+    const int v = hevcdl_conv5_slot_tap(tid), k = v >= 0 ? v : -v - 1, c = k / 25, r = k - c * 25, ky = r / 5, kx = r - ky * 5;
     sm.koff64[tid] = c * T64_CH + ky * T64_ROW + kx; sm.koff32[tid] = c * T32_CH + ky * T32_ROW + kx;
   }
   // The CTU's RGB samples are read from HBM where a tile is filled (twice per sample: conv64's half tile and conv1's quadrant tile);
@@ -300,9 +316,13 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     __syncthreads();
 
     // ---- conv2: 32 -> 64, 3x3, on cat(conv1, conv64) (use_model.py:26-31, 50) ----------------------
-    // wave w owns M-tiles 4w .. 4w + 3 (two rows of pool windows) and ALL four N-tiles: an A tile is gathered from LDS once and multiplied into
+    // wave w owns M-tiles 4w .. 4w + 3 and ALL four N-tiles: an A tile is gathered from LDS once and multiplied into
     // 64 output channels (gathering it per N-tile, one N-tile per wave, made the operand reads the bound).  The BN statistics of a channel are
     // then spread over the four waves and meet in LDS.  k = tap * 32 + ic.
+    // Banks: a ds_read_b32 is served in two halves of 32 lanes = 16 positions x 2 adjacent input channels.  An M-tile is 2 columns x 8 rows (four pool
+    // windows stacked): with a row pitch of 18 (10 for conv3's maps) its 16 words fall into 16 banks whose translate by 16 is the complement, and the
+    // channel stride is == 16 (mod 32): no two lanes of a half share a bank.  (The 8 x 2 tiles of round 3 had a 2-way conflict in every read: 43 % of
+    // the kernel's LDS cycles, SQ_LDS_BANK_CONFLICT.)
     {
       // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> input channel 4 * j + (lane >> 4))
       const u4 GLB *w2 = (const u4 GLB *)(W + HEVCDL_W_C2) + lane; const float GLB *b2 = W + HEVCDL_W_C2 + 18432;
@@ -313,11 +333,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t][n] = (v4f){ bias, bias, bias, bias };
       }
-      // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4; tile T = 4 * wave + t sits at rows 2 * (T >> 1), columns 8 * (T & 1)
-      const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + ((i16 >> 1) & 1) * A_ROW + 2 * (i16 >> 2) + (i16 & 1) + (4 * wave) * A_ROW;
+      // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4; tile T = 4 * wave + t sits at rows 8 * (T >> 3), columns 2 * (T & 7)
+      const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A_ROW + (i16 & 1) + (8 * (wave >> 1)) * A_ROW + 8 * (wave & 1);
       u4 bq[8];                                                       // [N-tile][hi | lo] of the current tap; the next tap's are in flight
 #pragma unroll
       for (int n = 0; n < 4; n++) { bq[2 * n] = w2[n * (9 * 128)]; bq[2 * n + 1] = w2[n * (9 * 128) + 64]; }
+      PIN8(bq);
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
         const unsigned LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
@@ -325,6 +346,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         u4 bn[8];
 #pragma unroll
         for (int n = 0; n < 4; n++) { bn[2 * n] = w2[n * (9 * 128) + tn * 128]; bn[2 * n + 1] = w2[n * (9 * 128) + tn * 128 + 64]; }
+        __builtin_amdgcn_sched_barrier(0);                            // the next tap's weights are requested before this tap's MFMAs (left alone the loads sink to their use)
         // A operands double-buffered in registers: the 8 LDS reads of tile t + 1 are issued before the MFMAs of tile t
         unsigned w0[8], w1[8];
 #pragma unroll
@@ -334,7 +356,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
           unsigned (&wc)[8] = (t & 1) ? w1 : w0; unsigned (&wn)[8] = (t & 1) ? w0 : w1;
           if (t < 3) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) wn[j] = ap[j * 4 * A_CH + (2 * ((t + 1) >> 1)) * A_ROW + 8 * ((t + 1) & 1)];
+            for (int j = 0; j < 8; j++) wn[j] = ap[j * 4 * A_CH + 2 * (t + 1)];
           }
           h8 ah, al;
           gather_hl(wc, ah, al);
@@ -374,7 +396,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
           const v4f a = acc[t][n];
           const int T = 4 * wave + t;
           const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-          sm.q.a2[ch * A2_CH + ((T >> 1) + 1) * A2_ROW + 4 * (T & 1) + g4 + 1] = split_f16(fmaxf(v, 0.f));      // stored split: conv3's operand form
+          sm.q.a2[ch * A2_CH + (4 * (T >> 3) + g4 + 1) * A2_ROW + (T & 7) + 1] = split_f16(fmaxf(v, 0.f));      // window g4 of tile T; stored split: conv3's operand form
         }
       }
       __syncthreads();
@@ -391,12 +413,13 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[n][t] = (v4f){ bias, bias, bias, bias };
       }
-      const unsigned LDS *abase = (const unsigned LDS *)sm.q.a2 + g4 * A2_CH + ((i16 >> 1) & 1) * A2_ROW + 2 * (i16 >> 2) + (i16 & 1);
+      const unsigned LDS *abase = (const unsigned LDS *)sm.q.a2 + g4 * A2_CH + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A2_ROW + (i16 & 1);      // M-tile t: columns 2t, 2t + 1, all 8 rows
       u4 bq[8];                                                       // [N-tile n][k-step s][hi | lo] of the current tap
 #pragma unroll
       for (int n = 0; n < 2; n++)
 #pragma unroll
         for (int q = 0; q < 4; q++) bq[n * 4 + q] = w3[n * (9 * 256) + q * 64];
+      PIN8(bq);
 #pragma unroll 1
       for (int tap = 0; tap < 9; tap++) {
         const unsigned LDS *ap = abase + (tap / 3) * A2_ROW + (tap % 3);
@@ -406,6 +429,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int n = 0; n < 2; n++)
 #pragma unroll
           for (int q = 0; q < 4; q++) bn[n * 4 + q] = w3[n * (9 * 256) + tn * 256 + q * 64];
+        __builtin_amdgcn_sched_barrier(0);
         unsigned w0[8], w1[8];                                      // (k-step, tile) pairs in flight: u = 4 * s + t
 #pragma unroll
         for (int j = 0; j < 8; j++) w0[j] = ap[j * 4 * A2_CH];
@@ -414,7 +438,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
           unsigned (&wc)[8] = (u & 1) ? w1 : w0; unsigned (&wn)[8] = (u & 1) ? w0 : w1;
           if (u < 7) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) wn[j] = ap[(8 * ((u + 1) >> 2) + j) * 4 * A2_CH + 2 * ((u + 1) & 3) * A2_ROW];
+            for (int j = 0; j < 8; j++) wn[j] = ap[(8 * ((u + 1) >> 2) + j) * 4 * A2_CH + 2 * ((u + 1) & 3)];
           }
           const int sk = u >> 2, t = u & 3;
           h8 ah, al;
@@ -443,7 +467,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[n][t];
           const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-          a3_out[(size_t)q * 2048 + ch * 16 + t * 4 + g4] = split_f16(fmaxf(v, 0.f));      // flatten order (C,H,W), use_model.py:53; row 4 * ctu + q of the head's input, stored split: fc1's operand form (fc_kernel.hip)
+          a3_out[(size_t)q * 2048 + ch * 16 + g4 * 4 + t] = split_f16(fmaxf(v, 0.f));      // flatten order (C,H,W), use_model.py:53; row 4 * ctu + q of the head's input, stored split: fc1's operand form (fc_kernel.hip)
         }
       }
       __syncthreads();

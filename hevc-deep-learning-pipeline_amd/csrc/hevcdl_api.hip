@@ -156,15 +156,16 @@ static float f16_to_f32(uint16_t h)
 // lane l supplies B[k = 8 * (l >> 4) + j][n = l & 15], j = 0..7, and k-value (l >> 4, j) of k-step s stands for input channel 32 s + 4 j + (l >> 4) (the order in
 // which a lane's 8 LDS reads walk the channel-major activation maps without bank conflicts).  Layout: [oc/16 N-tiles][9 taps][ic/32 k-steps][hi | lo][64 lanes][8 halves],
 // then bias, gamma, beta as floats -- the same number of bytes as the f32 packing it replaces.
-// the 5x5 convolutions (3 input channels, 16 output channels = one N-tile): k = (c * 5 + ky) * 5 + kx in natural order, 75 taps padded to 3 k-steps of 32 with zero weights
+// the 5x5 convolutions (3 input channels, 16 output channels = one N-tile): the 75 taps (c * 5 + ky) * 5 + kx in the order of hevcdl_conv5_slot_tap, 5 k-steps of 16.
+// The A operand of a step is four raw split words (hi, lo, hi, lo, ...): B1 carries the weight's hi half against both halves, B2 its lo half against the hi half only.
 static void pack_conv5(const float *w, const float *b, const float *g, const float *be, float *dst)
 {
   uint16_t *d16 = (uint16_t *)dst;
-  for (int s = 0; s < 3; s++) for (int l = 0; l < 64; l++) for (int j = 0; j < 8; j++) {
-    const int k = 32 * s + 8 * (l >> 4) + j, oc = l & 15;
-    const float v = k < 75 ? w[oc * 75 + k] : 0.f;
+  for (int s = 0; s < 5; s++) for (int l = 0; l < 64; l++) for (int e = 0; e < 8; e++) {
+    const int k = hevcdl_conv5_slot_tap(16 * s + 4 * (l >> 4) + (e >> 1)), oc = l & 15;
+    const float v = k >= 0 ? w[oc * 75 + k] : 0.f;
     const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
-    d16[(size_t)(s * 2) * 512 + (size_t)l * 8 + j] = hi; d16[(size_t)(s * 2 + 1) * 512 + (size_t)l * 8 + j] = lo;
+    d16[(size_t)(s * 2) * 512 + (size_t)l * 8 + e] = hi; d16[(size_t)(s * 2 + 1) * 512 + (size_t)l * 8 + e] = (e & 1) ? (uint16_t)0 : lo;
   }
   memcpy(dst + HEVCDL_W_C5, b, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 16, g, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 32, be, 16 * sizeof(float));
 }

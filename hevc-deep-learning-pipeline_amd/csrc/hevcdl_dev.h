@@ -10,15 +10,41 @@
 
 // packed CNN weights (units of floats): every conv is split-f16 MFMA B operands ([N-tile][tap or k-step][hi | lo][64 lanes][8 halves], hevcdl_api.hip pack_conv*)
 // + bias + gamma + beta as floats, every fc is [k][j] floats + bias
-#define HEVCDL_W_C5   1536         // halves of a 5x5 conv: 3 k-steps x (hi + lo) x 1 KB = 1536 floats, then 3 * 16 floats
-#define HEVCDL_W_C1   0            // 1536 + 3*16
-#define HEVCDL_W_C64  1584
-#define HEVCDL_W_C2   3168         // 9*32*64 + 3*64
-#define HEVCDL_W_C3   21792        // 9*64*128 + 3*128
-#define HEVCDL_W_FC1  95904        // 2048*256 + 256
-#define HEVCDL_W_FC2  620448       // 256*64 + 64
-#define HEVCDL_W_FC3  636896       // 64*16 + 16
-#define HEVCDL_W_TOTAL 637936
+#define HEVCDL_W_C5   2560         // halves of a 5x5 conv: 5 k-steps x (B1 + B2) x 1 KB = 2560 floats, then 3 * 16 floats
+#define HEVCDL_W_C1   0            // 2560 + 3*16
+#define HEVCDL_W_C64  2608
+#define HEVCDL_W_C2   5216         // 9*32*64 + 3*64
+#define HEVCDL_W_C3   23840        // 9*64*128 + 3*128
+#define HEVCDL_W_FC1  97952        // 2048*256 + 256
+#define HEVCDL_W_FC2  622496       // 256*64 + 64
+#define HEVCDL_W_FC3  638944       // 64*16 + 16
+#define HEVCDL_W_TOTAL 639984
+
+// K order of the 5x5 convolutions (cnn_kernel.hip conv5_mfma, hevcdl_api.hip pack_conv5): 5 k-steps of 16 taps; slot = 16 s + 4 g + j is word j of lane group g in
+// k-step s.  Two rules shape it.  (1) One half of a ds_read_b32 serves lane groups 2h and 2h + 1: their words must lie 16 banks apart in the input tile (the 16
+// positions of an M-tile, an 8 x 2 block at a row pitch == 8 (mod 32), cover 16 banks whose translate by 16 is the complement) -- partners are (c0, ky, kx) and
+// (c1, ky, kx) (channel stride == 16 mod 32), (c2, ky, kx) and (c2, ky + 2, kx), and for what is left a padding slot (weight 0) on the same tap of c1.  (2) In k-steps
+// 0..3 the four words of a lane group are kx = 0..3 of ONE row (c, ky): one pointer, two ds_read2_b32 into four consecutive registers = the MFMA operand as it is.
+// Step 4 holds the kx = 4 column.  Returns the tap (c * 5 + ky) * 5 + kx, or -(tap + 1) for a padding slot (reads `tap`).
+#ifdef __HIPCC__
+#define HEVCDL_HD __host__ __device__
+#else
+#define HEVCDL_HD
+#endif
+static inline HEVCDL_HD int hevcdl_conv5_slot_tap(int slot)
+{
+  const int s = slot >> 4, g = (slot >> 2) & 3, j = slot & 3, second = g & 1;
+  int c, ky, kx, pad = 0;
+  // the eight partner pairs of rows: (c0, ky) | (c1, ky) for ky = 0..4, (c2, 0) | (c2, 2), (c2, 1) | (c2, 3), (c2, 4) | padding on (c1, 4)
+  int P;
+  if (s < 4) { P = 2 * s + (g >> 1); kx = j; }
+  else { kx = 4; P = g < 2 ? j : (j == 0 ? 4 : 4 + j); }        // step 4: lane groups 0 | 1 take pairs 0..3 (words = ky), groups 2 | 3 pairs 4..7
+  if (P < 5) { c = second; ky = P; }
+  else if (P < 7) { c = 2; ky = (P - 5) + (second ? 2 : 0); }
+  else { c = second ? 1 : 2; ky = 4; pad = second; }
+  const int tap = (c * 5 + ky) * 5 + kx;
+  return pad ? -(tap + 1) : tap;
+}
 
 struct hevcdl_cnn_params {
   const uint8_t *input;            // planar 4:2:0 frames, or packed RGB CTUs (input_mode 2)
