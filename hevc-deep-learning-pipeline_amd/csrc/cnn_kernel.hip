@@ -68,10 +68,15 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m)
 // BN in training mode folded to an affine map (nn.BatchNorm2d defaults: biased variance, eps 1e-5)
 __device__ __forceinline__ void bn_fold(double s, double ss, double n, float gamma, float beta, float &alpha, float &betap)
 {
-  double mean = s / n;
-  double var = ss / n - mean * mean;
+  const double rn = 1.0 / n;                       // (n is a power of two at every call: exact)
+  double mean = s * rn;
+  double var = ss * rn - mean * mean;
   if (var < 0) var = 0;
-  double inv = 1.0 / sqrt(var + 1e-5);
+  // 1 / sqrt(x): the f32 reciprocal square root (1 ulp) refined by one Newton step in f64 -- 1e-14 relative, against 6e-8 of the float the result is rounded to;
+  // the library's f64 sqrt and division are ~70 instructions, this is 8
+  const double x = var + 1e-5;
+  const double r0 = (double)__builtin_amdgcn_rsqf((float)x);
+  const double inv = r0 * (1.5 - (0.5 * x) * (r0 * r0));
   alpha = (float)(inv * (double)gamma);
   betap = (float)((double)beta - mean * inv * (double)gamma);
 }
@@ -171,7 +176,7 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     for (int u = 0; u < 4; u++) {
       const v4f a = acc[u];
       s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
-      ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+      ss = __builtin_fma((double)a.x, (double)a.x, ss); ss = __builtin_fma((double)a.y, (double)a.y, ss); ss = __builtin_fma((double)a.z, (double)a.z, ss); ss = __builtin_fma((double)a.w, (double)a.w, ss);
       e[u] = (gamma >= 0.f) ? fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)) : fminf(fminf(a.x, a.y), fminf(a.z, a.w));
     }
     if (POOL == 4) {
@@ -266,7 +271,48 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       }
     }
   };
+  // four horizontally adjacent samples (x a multiple of 4) as split words, one row of loads for the strip: a dword of luma + two bytes of each chroma plane
+  // (or three dwords of packed RGB) instead of twelve byte loads; strips that straddle the picture's right edge take the per-sample path
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  auto strip = [&](int x, int y, float (&v0)[4], float (&v1)[4], float (&v2)[4]) {
+    int rr[4], gg[4], bb[4];
+    if (p.input_mode == HEVCDL_DEV_INPUT_RGB_CTU) {
+      const unsigned GLB *q = (const unsigned GLB *)(srcRGB + (y * 64 + x) * 3);
+      const unsigned a = q[0], b = q[1], c = q[2];                     // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+      rr[0] = a & 255; gg[0] = (a >> 8) & 255; bb[0] = (a >> 16) & 255; rr[1] = a >> 24; gg[1] = b & 255; bb[1] = (b >> 8) & 255;
+      rr[2] = (b >> 16) & 255; gg[2] = b >> 24; bb[2] = c & 255; rr[3] = (c >> 8) & 255; gg[3] = (c >> 16) & 255; bb[3] = c >> 24;
+    } else {
+      const int gx = x0 + x, gy = y0 + y;
+      if (gy < p.height && gx + 3 < p.width) {
+        const uint8_t GLB *yq = Yp + (size_t)gy * p.width + gx;
+        typedef unsigned u32u __attribute__((aligned(1))); typedef unsigned short u16u __attribute__((aligned(1)));      // (a row need not start on a dword)
+        const unsigned yw = *(const u32u GLB *)yq;
+        if (p.input_mode == HEVCDL_DEV_INPUT_LUMA) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) rr[k] = gg[k] = bb[k] = (yw >> (8 * k)) & 255;
+        } else {
+          const size_t co = (size_t)(gy >> 1) * (p.width >> 1) + (gx >> 1);
+          const unsigned uw = *(const u16u GLB *)(Up + co), vw = *(const u16u GLB *)(Vp + co);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int c = (int)((yw >> (8 * k)) & 255) - 16, d = (int)((uw >> (8 * (k >> 1))) & 255) - 128, e = (int)((vw >> (8 * (k >> 1))) & 255) - 128;
+            int r = (298 * c + 409 * e + 128) >> 8, g = (298 * c - 100 * d - 208 * e + 128) >> 8, b = (298 * c + 516 * d + 128) >> 8;
+            rr[k] = r < 0 ? 0 : (r > 255 ? 255 : r); gg[k] = g < 0 ? 0 : (g > 255 ? 255 : g); bb[k] = b < 0 ? 0 : (b > 255 ? 255 : b);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) pixel(x + k, y, rr[k], gg[k], bb[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v0[k] = sm.lut[rr[k]]; v1[k] = sm.lut[gg[k]]; v2[k] = sm.lut[bb[k]]; }
+  };
   // zero halos only: the interiors of the maps / tiles are rewritten before they are read
+  for (int i = tid; i < 3 * 36 * 8; i += 256) {                      // the conv64 tile's columns outside the CTU (2 left, 6 right of the 72): both halves keep them
+    const int c = i / (36 * 8), r = (i >> 3) % 36, k = i & 7;
+    sm.t64[c * T64_CH + r * T64_ROW + (k < 2 ? k : 64 + k)] = 0.f;
+  }
   for (int i = tid; i < 32 * 72; i += 256) {                       // 18x18 map + 4 pad words: 68 border words + 4 = 72 per channel
     const int c = i / 72, r = i - c * 72;
     const int o = r < 18 ? r : (r < 36 ? 17 * 18 + (r - 18) : (r < 52 ? (r - 35) * 18 : (r < 68 ? (r - 51) * 18 + 17 : 324 + (r - 68))));
@@ -276,11 +322,14 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
   CNN_MARK(0);
   // ---- conv64 branch, once per CTU (use_model.py:38-43), in two halves of 32 rows: the tile holds input rows 32h - 2 .. 32h + 33 ----
   for (int h = 0; h < 2; h++) {
-    for (int i = tid; i < 36 * T64_ROW; i += 256) {
-      const int r = i / T64_ROW, cc = i - r * T64_ROW, x = cc - 2, y = 32 * h - 2 + r;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (x >= 0 && x < 64 && y >= 0 && y < 64) { int rr, gg, bb; pixel(x, y, rr, gg, bb); v0 = sm.lut[rr]; v1 = sm.lut[gg]; v2 = sm.lut[bb]; }
-      sm.t64[i] = v0; sm.t64[T64_CH + i] = v1; sm.t64[2 * T64_CH + i] = v2;
+    for (int i = tid; i < 36 * 16; i += 256) {                       // strips of 4 samples: 16 a row
+      const int r = i >> 4, x = (i & 15) * 4, y = 32 * h - 2 + r;
+      float v0[4] = { 0.f, 0.f, 0.f, 0.f }, v1[4] = { 0.f, 0.f, 0.f, 0.f }, v2[4] = { 0.f, 0.f, 0.f, 0.f };
+      if (y >= 0 && y < 64) strip(x, y, v0, v1, v2);
+      f2 LDS *d = (f2 LDS *)(sm.t64 + r * T64_ROW + x + 2);             // (even word offsets: 8-byte stores)
+      d[0] = (f2){ v0[0], v0[1] }; d[1] = (f2){ v0[2], v0[3] };
+      d[T64_CH / 2] = (f2){ v1[0], v1[1] }; d[T64_CH / 2 + 1] = (f2){ v1[2], v1[3] };
+      d[T64_CH] = (f2){ v2[0], v2[1] }; d[T64_CH + 1] = (f2){ v2[2], v2[3] };
     }
     __syncthreads();
     conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12 + 16 * A_CH, tid, h + 1);
@@ -298,20 +347,26 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       else { const int q2 = r - 4 * T32_ROW, y = q2 >> 3, k = q2 & 7; o = (y + 2) * T32_ROW + (k < 2 ? k : 32 + k); }
       sm.q.t32[c * T32_CH + o] = 0.f;
     }
-    for (int i = tid; i < 32 * 32; i += 256) {
-      const int y = i >> 5, x = i & 31;
-      int rr, gg, bb; pixel((q & 1) * 32 + x, (q >> 1) * 32 + y, rr, gg, bb);
-      float LDS *d = sm.q.t32 + (y + 2) * T32_ROW + x + 2;
-      d[0] = sm.lut[rr]; d[T32_CH] = sm.lut[gg]; d[2 * T32_CH] = sm.lut[bb];
+    { // one strip of 4 samples per thread
+      const int y = tid >> 3, x = (tid & 7) * 4;
+      float v0[4], v1[4], v2[4];
+      strip((q & 1) * 32 + x, (q >> 1) * 32 + y, v0, v1, v2);
+      f2 LDS *d = (f2 LDS *)(sm.q.t32 + (y + 2) * T32_ROW + x + 2);
+      d[0] = (f2){ v0[0], v0[1] }; d[1] = (f2){ v0[2], v0[3] };
+      d[T32_CH / 2] = (f2){ v1[0], v1[1] }; d[T32_CH / 2 + 1] = (f2){ v1[2], v1[3] };
+      d[T32_CH] = (f2){ v2[0], v2[1] }; d[T32_CH + 1] = (f2){ v2[2], v2[3] };
     }
     __syncthreads();
     CNN_MARK(2);
     conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, tid, 0);
     CNN_MARK(3);
-    for (int i = tid; i < 64 * 40; i += 256) {                        // the input tile is dead: zero the halo of conv2's output (36 border words + 4 pad per channel)
-      const int c = i / 40, r = i - c * 40;
-      const int o = r < 10 ? r : (r < 20 ? 90 + (r - 10) : (r < 28 ? (r - 19) * 10 : (r < 36 ? (r - 27) * 10 + 9 : 100 + (r - 36))));
-      sm.q.a2[c * A2_CH + o] = 0.f;
+    { // the input tile is dead: zero the halo of conv2's output.  Four threads per channel, nine of the 36 border words of its 10 x 10 map each
+      float LDS *d = sm.q.a2 + (tid >> 2) * A2_CH;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int r = (tid & 3) * 9 + k;                               // 0..9 top row, 10..19 bottom row, 20..35 the sides of rows 1..8
+        d[r < 10 ? r : (r < 20 ? 80 + r : (1 + ((r - 20) >> 1)) * 10 + ((r - 20) & 1) * 9)] = 0.f;
+      }
     }
     __syncthreads();
 
@@ -325,7 +380,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     // the kernel's LDS cycles, SQ_LDS_BANK_CONFLICT.)
     {
       // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> input channel 4 * j + (lane >> 4))
-      const u4 GLB *w2 = (const u4 GLB *)(W + HEVCDL_W_C2) + lane; const float GLB *b2 = W + HEVCDL_W_C2 + 18432;
+      // (the layer's base is made opaque per quadrant and the lane's offset is a 32-bit register: every weight load is then `scalar base + register + immediate`;
+      // with 64-bit lane pointers the unrolled sequence's 72 addresses were computed ahead of the quadrant loop and spilled)
+      const char GLB *wb2 = (const char GLB *)(W + HEVCDL_W_C2); asm volatile("" : "+s"(wb2));
+      const unsigned lb = lane * 16u;
+      auto w2 = [&](int idx) { return *(const u4 GLB *)(wb2 + (size_t)(lb + (unsigned)idx * 1024u)); };      // idx: 1 KB rows of 64 lanes x 16 bytes
+      const float GLB *b2 = W + HEVCDL_W_C2 + 18432;
       v4f acc[4][4];                                                  // [M-tile][N-tile]
 #pragma unroll
       for (int n = 0; n < 4; n++) {
@@ -335,36 +395,33 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       }
       // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4; tile T = 4 * wave + t sits at rows 8 * (T >> 3), columns 2 * (T & 7)
       const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A_ROW + (i16 & 1) + (8 * (wave >> 1)) * A_ROW + 8 * (wave & 1);
-      u4 bq[8];                                                       // [N-tile][hi | lo] of the current tap; the next tap's are in flight
+      // The 36 (tap, tile) steps are one unrolled sequence: the 8 LDS reads of step p + 1 are issued before the MFMAs of step p -- across taps too --, and the weights
+      // of tap + 1 ([N-tile][hi | lo], two register sets) are requested when tap begins.  The scheduling barriers keep that order (left alone the loads sink to their uses).
+      u4 bq[2][8];
 #pragma unroll
-      for (int n = 0; n < 4; n++) { bq[2 * n] = w2[n * (9 * 128)]; bq[2 * n + 1] = w2[n * (9 * 128) + 64]; }
-      PIN8(bq);
-#pragma unroll 1
-      for (int tap = 0; tap < 9; tap++) {
-        const unsigned LDS *ap = abase + (tap / 3) * A_ROW + (tap % 3);
-        const int tn = tap < 8 ? tap + 1 : 8;
-        u4 bn[8];
+      for (int n = 0; n < 4; n++) { bq[0][2 * n] = w2(n * 18); bq[0][2 * n + 1] = w2(n * 18 + 1); }
+      auto aoff = [](int p) { return ((p >> 2) / 3) * A_ROW + ((p >> 2) % 3) + 2 * (p & 3); };
+      unsigned w0[8], w1[8];
 #pragma unroll
-        for (int n = 0; n < 4; n++) { bn[2 * n] = w2[n * (9 * 128) + tn * 128]; bn[2 * n + 1] = w2[n * (9 * 128) + tn * 128 + 64]; }
-        __builtin_amdgcn_sched_barrier(0);                            // the next tap's weights are requested before this tap's MFMAs (left alone the loads sink to their use)
-        // A operands double-buffered in registers: the 8 LDS reads of tile t + 1 are issued before the MFMAs of tile t
-        unsigned w0[8], w1[8];
+      for (int j = 0; j < 8; j++) w0[j] = abase[j * 4 * A_CH + aoff(0)];
 #pragma unroll
-        for (int j = 0; j < 8; j++) w0[j] = ap[j * 4 * A_CH];
+      for (int p = 0; p < 36; p++) {
+        const int tap = p >> 2, t = p & 3;
+        if (t == 0 && tap < 8) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-          unsigned (&wc)[8] = (t & 1) ? w1 : w0; unsigned (&wn)[8] = (t & 1) ? w0 : w1;
-          if (t < 3) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) wn[j] = ap[j * 4 * A_CH + 2 * (t + 1)];
-          }
-          h8 ah, al;
-          gather_hl(wc, ah, al);
-#pragma unroll
-          for (int n = 0; n < 4; n++) acc[t][n] = mfma3(ah, al, __builtin_bit_cast(h8, bq[2 * n]), __builtin_bit_cast(h8, bq[2 * n + 1]), acc[t][n]);
+          for (int n = 0; n < 4; n++) { bq[(tap + 1) & 1][2 * n] = w2(n * 18 + (tap + 1) * 2); bq[(tap + 1) & 1][2 * n + 1] = w2(n * 18 + (tap + 1) * 2 + 1); }
         }
+        unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
+        if (p < 35) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) bq[q] = bn[q];
+          for (int j = 0; j < 8; j++) wn[j] = abase[j * 4 * A_CH + aoff(p + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h8 ah, al;
+        gather_hl(wc, ah, al);
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[t][n] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][2 * n]), __builtin_bit_cast(h8, bq[tap & 1][2 * n + 1]), acc[t][n]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // statistics: this wave's 64 positions of every channel, then the four waves through LDS
 #pragma unroll
@@ -374,23 +431,24 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[t][n];
           s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
-          ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+          ss = __builtin_fma((double)a.x, (double)a.x, ss); ss = __builtin_fma((double)a.y, (double)a.y, ss); ss = __builtin_fma((double)a.z, (double)a.z, ss); ss = __builtin_fma((double)a.w, (double)a.w, ss);
         }
         s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
         if (lane < 16) { sm.red2[0][wave][n * 16 + lane] = s; sm.red2[1][wave][n * 16 + lane] = ss; }
       }
       __syncthreads();
+      float al_l, be_l;                                               // the affine map of channel `lane` (every wave folds all 64: it needs them for its own tiles)
+      if (p.bn_eval) { al_l = b2[64 + lane]; be_l = b2[128 + lane]; }
+      else {
+        double s = 0, ss = 0;
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) { s += sm.red2[0][wv][lane]; ss += sm.red2[1][wv][lane]; }
+        bn_fold(s, ss, 256.0, b2[64 + lane], b2[128 + lane], al_l, be_l);
+      }
 #pragma unroll
       for (int n = 0; n < 4; n++) {
         const int ch = n * 16 + i16;
-        float al, be;
-        if (p.bn_eval) { al = b2[64 + ch]; be = b2[128 + ch]; }
-        else {
-          double s = 0, ss = 0;
-#pragma unroll
-          for (int wv = 0; wv < 4; wv++) { s += sm.red2[0][wv][ch]; ss += sm.red2[1][wv][ch]; }
-          bn_fold(s, ss, 256.0, b2[64 + ch], b2[128 + ch], al, be);
-        }
+        const float al = __shfl(al_l, ch), be = __shfl(be_l, ch);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[t][n];
@@ -405,7 +463,10 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     // ---- conv3: 64 -> 128, 3x3 (use_model.py:32-37); wave w owns output channels [32w, 32w+32) = 2 N-tiles, 4 M-tiles ----
     {
       // packed weights: [N-tile][tap][k-step s][hi | lo][64 lanes] x 16 bytes (k = 8 * (lane >> 4) + j <-> input channel 32 * s + 4 * j + (lane >> 4))
-      const u4 GLB *w3 = (const u4 GLB *)(W + HEVCDL_W_C3) + (size_t)(2 * wave) * (9 * 256) + lane; const float GLB *b3 = W + HEVCDL_W_C3 + 73728;
+      const char GLB *wb3 = (const char GLB *)(W + HEVCDL_W_C3) + (size_t)(2 * wave) * (9 * 4096); asm volatile("" : "+s"(wb3));
+      const unsigned lb = lane * 16u;
+      auto w3 = [&](int idx) { return *(const u4 GLB *)(wb3 + (size_t)(lb + (unsigned)idx * 1024u)); };
+      const float GLB *b3 = W + HEVCDL_W_C3 + 73728;
       v4f acc[2][4];
 #pragma unroll
       for (int n = 0; n < 2; n++) {
@@ -414,40 +475,36 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) acc[n][t] = (v4f){ bias, bias, bias, bias };
       }
       const unsigned LDS *abase = (const unsigned LDS *)sm.q.a2 + g4 * A2_CH + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A2_ROW + (i16 & 1);      // M-tile t: columns 2t, 2t + 1, all 8 rows
-      u4 bq[8];                                                       // [N-tile n][k-step s][hi | lo] of the current tap
+      // 72 (tap, k-step, tile) steps as one unrolled sequence, as in conv2; weights [N-tile n][k-step s][hi | lo] of a tap in two register sets
+      u4 bq[2][8];
 #pragma unroll
       for (int n = 0; n < 2; n++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq[n * 4 + q] = w3[n * (9 * 256) + q * 64];
-      PIN8(bq);
-#pragma unroll 1
-      for (int tap = 0; tap < 9; tap++) {
-        const unsigned LDS *ap = abase + (tap / 3) * A2_ROW + (tap % 3);
-        u4 bn[8];
-        const int tn = tap < 8 ? tap + 1 : 8;
+        for (int q = 0; q < 4; q++) bq[0][n * 4 + q] = w3(n * 36 + q);
+      auto aoff = [](int p) { return (8 * ((p >> 2) & 1)) * 4 * A2_CH + ((p >> 3) / 3) * A2_ROW + ((p >> 3) % 3) + 2 * (p & 3); };
+      unsigned w0[8], w1[8];
 #pragma unroll
-        for (int n = 0; n < 2; n++)
+      for (int j = 0; j < 8; j++) w0[j] = abase[j * 4 * A2_CH + aoff(0)];
 #pragma unroll
-          for (int q = 0; q < 4; q++) bn[n * 4 + q] = w3[n * (9 * 256) + tn * 256 + q * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned w0[8], w1[8];                                      // (k-step, tile) pairs in flight: u = 4 * s + t
+      for (int p = 0; p < 72; p++) {
+        const int tap = p >> 3, sk = (p >> 2) & 1, t = p & 3;
+        if ((p & 7) == 0 && tap < 8) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) w0[j] = ap[j * 4 * A2_CH];
+          for (int n = 0; n < 2; n++)
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          unsigned (&wc)[8] = (u & 1) ? w1 : w0; unsigned (&wn)[8] = (u & 1) ? w0 : w1;
-          if (u < 7) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) wn[j] = ap[(8 * ((u + 1) >> 2) + j) * 4 * A2_CH + 2 * ((u + 1) & 3)];
-          }
-          const int sk = u >> 2, t = u & 3;
-          h8 ah, al;
-          gather_hl(wc, ah, al);
-          acc[0][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[2 * sk]), __builtin_bit_cast(h8, bq[2 * sk + 1]), acc[0][t]);
-          acc[1][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[4 + 2 * sk]), __builtin_bit_cast(h8, bq[4 + 2 * sk + 1]), acc[1][t]);
+            for (int q = 0; q < 4; q++) bq[(tap + 1) & 1][n * 4 + q] = w3(n * 36 + (tap + 1) * 4 + q);
         }
+        unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
+        if (p < 71) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) bq[q] = bn[q];
+          for (int j = 0; j < 8; j++) wn[j] = abase[j * 4 * A2_CH + aoff(p + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h8 ah, al;
+        gather_hl(wc, ah, al);
+        acc[0][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][2 * sk]), __builtin_bit_cast(h8, bq[tap & 1][2 * sk + 1]), acc[0][t]);
+        acc[1][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][4 + 2 * sk]), __builtin_bit_cast(h8, bq[tap & 1][4 + 2 * sk + 1]), acc[1][t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int n = 0; n < 2; n++) {
@@ -457,7 +514,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[n][t];
           s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
-          ss += ((double)a.x * (double)a.x + (double)a.y * (double)a.y) + ((double)a.z * (double)a.z + (double)a.w * (double)a.w);
+          ss = __builtin_fma((double)a.x, (double)a.x, ss); ss = __builtin_fma((double)a.y, (double)a.y, ss); ss = __builtin_fma((double)a.z, (double)a.z, ss); ss = __builtin_fma((double)a.w, (double)a.w, ss);
         }
         s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
         float al, be;
