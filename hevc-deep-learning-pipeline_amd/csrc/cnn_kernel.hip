@@ -144,32 +144,34 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
   for (int q = 0; q < 8; q++) kp[q] = (const unsigned LDS *)tile + (8 * wave + py) * ROW + px + koff[q < 4 ? 16 * q + 4 * g : 64 + 4 * g + (q - 4)];
   auto word = [&](int ks, int j, int off) { return ks < 4 ? kp[ks][off + j] : kp[4 + j][off]; };
   double s = 0, ss = 0;
+  // tile u of an iteration: POOL 2: columns 8u of one tile row;  POOL 4: tile row u >> 1, columns 8 (u & 1) of a 16 x 4 block (four windows)
+  auto toff = [](int u) { return (POOL == 4) ? (u >> 1) * 2 * ROW + 8 * (u & 1) : 8 * u; };
+  // A operands: a ring of six register sets, the reads of (k-step, tile) pair p + 5 are issued before the two MFMAs of pair p (32 cycles a pair against an LDS
+  // round trip of 64 and more); the first five pairs of the NEXT iteration are requested before this iteration's statistics
+  auto rd = [&](int pr) { u4 r; r[0] = word(pr >> 2, 0, toff(pr & 3)); r[1] = word(pr >> 2, 1, toff(pr & 3)); r[2] = word(pr >> 2, 2, toff(pr & 3)); r[3] = word(pr >> 2, 3, toff(pr & 3)); return r; };
+  u4 wr[6];
+#pragma unroll
+  for (int pr = 0; pr < 5; pr++) wr[pr] = rd(pr);
 #pragma unroll 1
   for (int it = 0; it < ITERS; it++) {
     v4f acc[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) acc[u] = (v4f){ bias, bias, bias, bias };
-    // tile u of the iteration: POOL 2: columns 8u of one tile row;  POOL 4: tile row u >> 1, columns 8 (u & 1) of a 16 x 4 block (four windows)
-    auto toff = [](int u) { return (POOL == 4) ? (u >> 1) * 2 * ROW + 8 * (u & 1) : 8 * u; };
-    // A operands ping-pong between two register sets: the 4 LDS reads of (k-step, tile) pair p + 1 are issued before the MFMAs of pair p
-    u4 w0, w1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) w0[j] = word(0, j, toff(0));
 #pragma unroll
     for (int p = 0; p < 20; p++) {
-      u4 &wc = (p & 1) ? w1 : w0; u4 &wn = (p & 1) ? w0 : w1;
-      if (p < 19) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) wn[j] = word((p + 1) >> 2, j, toff((p + 1) & 3));
-      }
-      const h8 a = __builtin_bit_cast(h8, wc);
+      if (p + 5 < 20) wr[(p + 5) % 6] = rd(p + 5);
+      const h8 a = __builtin_bit_cast(h8, wr[p % 6]);
       acc[p & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2[p >> 2], acc[p & 3], 0, 0, 0);
       acc[p & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1[p >> 2], acc[p & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                      // (left alone the reads are moved next to their use)
     }
     { // next iteration: POOL 2: two rows down;  POOL 4: 16 columns to the right, after four of them four rows down
       const int step = (POOL == 4) ? (((it & 3) == 3) ? 4 * ROW - 48 : 16) : 2 * ROW;
 #pragma unroll
       for (int q = 0; q < 8; q++) kp[q] += step;
+#pragma unroll
+      for (int pr = 0; pr < 5; pr++) wr[pr] = rd(pr);       // (behind the last iteration: words below the wave's rows, never used)
+      __builtin_amdgcn_sched_barrier(0);
     }
     float e[4];
 #pragma unroll
