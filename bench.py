@@ -34,9 +34,9 @@ MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 MFMA p
 # The convolutions of the label CNN per CTU (use_model.py:16-58; conv64 once per CTU, the other three per 32x32 quadrant), in multiply-accumulates:
 #   conv64 64x64 positions x 16 channels x 75 taps, conv1 4 x 32x32 x 16 x 75, conv2 4 x 16x16 x 64 x 288, conv3 4 x 8x8 x 128 x 576
 CNN_CONV_MACS = 64 * 64 * 16 * 75 + 4 * 32 * 32 * 16 * 75 + 4 * 16 * 16 * 64 * 288 + 4 * 8 * 8 * 128 * 576
-# what the kernel executes for them (csrc/cnn_kernel.hip): every product as three f16 MFMA products of split operands (hi*hi + hi*lo + lo*hi, f32 accumulate),
-# the 75 taps of the 5x5 layers padded to three k-steps of 32
-CNN_CONV_MACS_EXECUTED = 3 * ((64 * 64 * 16 + 4 * 32 * 32 * 16) * 96 + 4 * 16 * 16 * 64 * 288 + 4 * 8 * 8 * 128 * 576)
+# what the kernel executes for them (csrc/cnn_kernel.hip): conv2 / conv3 every product as three f16 MFMA products of split operands (hi*hi + hi*lo + lo*hi, f32
+# accumulate); the 5x5 layers on raw split words: the 75 taps padded to five k-steps of 16, two MFMAs (K = 32 halves) a step = 320 MFMA products per output
+CNN_CONV_MACS_EXECUTED = (64 * 64 * 16 + 4 * 32 * 32 * 16) * 320 + 3 * (4 * 16 * 16 * 64 * 288 + 4 * 8 * 8 * 128 * 576)
 RD_KERNEL_SRC = os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "csrc", "rd_kernel.hip")
 
 
@@ -479,7 +479,7 @@ def main():
                                    "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / MFMA_F16_PEAK_TFLOPS, "kernel_ms": 1e3 * cnn_s,
                                    "executed_mflop_per_ctu": 2e-6 * CNN_CONV_MACS_EXECUTED, "useful_mflop_per_ctu": 2e-6 * CNN_CONV_MACS,
                                    "head_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]) - 1e3 * cnn_s,
-                                   "note": "executed = three MFMA products per multiply-accumulate and the 5x5 layers' 75 taps padded to 96; measured with HIP events on the launch stream over the timed steps"}
+                                   "note": "executed = the MFMA products issued: three per multiply-accumulate in conv2 / conv3, 320 per output of the 5x5 layers (75 taps as 5 k-steps of 16 raw split words, two MFMAs a step); measured with HIP events on the launch stream over the timed steps"}
         if world == 1 and is_c4 and not a.no_projection:
             # What the frame-sharded job will take on N GPUs, from this GPU alone: a rank's share of the job is a launch of 600 / N frames (frames are independent, the
             # only collective gathers 8 bytes per frame), timed here as one whole step (label CNN + decisions) each.  The driver's SCALE run can be checked against it.

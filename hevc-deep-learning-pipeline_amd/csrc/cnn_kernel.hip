@@ -42,6 +42,8 @@ constexpr int A2_ROW = 10;
 constexpr int T64_ROW = 72, T64_CH = 36 * 72 + 16;   // input tile of HALF the CTU (32 rows + halo 2; conv64 runs in two halves): row pitch == 8, channel stride == 16 (mod 32 banks)
 constexpr int T32_ROW = 40, T32_CH = 36 * 40 + 16;   // input tile of one quadrant, halo 2: row pitch == 8, channel stride == 16 (mod 32 banks); hevcdl_conv5_slot_tap
 
+static_assert(A_CH % 32 == 16 && A2_CH % 32 == 16 && T64_CH % 32 == 16 && T32_CH % 32 == 16 && T64_ROW % 32 == 8 && T32_ROW % 32 == 8 && A_ROW == 18 && A2_ROW == 10,
+              "the operand reads are bank-conflict-free only at these strides (conv2 / conv3: 2 x 8 M-tiles; 5x5 layers: 8 x 2 M-tiles, hevcdl_conv5_slot_tap)");
 struct CnnSmem {
   float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95), stored split (hi | lo halves): the operand form of the convolutions
   int koff64[80], koff32[80];              // im2col offset, inside the input tiles, of the tap in K slot k (hevcdl_conv5_slot_tap; a padding slot reads a tap that keeps the gather conflict-free, zero weight)

@@ -107,3 +107,31 @@ def test_weight_blob_matches_manifest():
     assert man["floats"] == hevcdl_amd.WEIGHT_FLOATS == hevcdl_amd.load_weights().size
     names = [t["name"] for t in man["tensors"]]
     assert names[0] == "conv1.0.weight" and names[-1] == "conv64.1.running_var" and len(names) == 30
+
+
+def test_k_slot_map_of_the_5x5_layers_covers_every_tap_once_without_bank_conflicts(tmp_path):
+    """hevcdl_conv5_slot_tap (csrc/hevcdl_dev.h) is shared by the host's weight packing and the kernel's operand reads: all 75 taps exactly once in the 80 slots,
+    the four words of a lane group in k-steps 0..3 are consecutive taps of one tile row, and the two lane groups of one half of a ds_read_b32 (slots a, a + 4) read
+    words 16 LDS banks apart at both tile pitches -- the properties cnn_kernel.hip's conv5_mfma is built on."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = tmp_path / "slotmap.cpp"
+    src.write_text('#include <cstdio>\n#include "hevcdl.h"\n#include "hevcdl_dev.h"\nint main() { for (int s = 0; s < 80; s++) printf("%d\\n", hevcdl_conv5_slot_tap(s)); return 0; }\n')
+    exe = tmp_path / "slotmap"
+    subprocess.run(["g++", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert len(vals) == 80
+    real = sorted(v for v in vals if v >= 0)
+    assert real == list(range(75)), "every tap exactly once"
+    tap = [v if v >= 0 else -v - 1 for v in vals]
+    for slot in range(64):
+        if slot & 3:
+            assert tap[slot] == tap[slot & ~3] + (slot & 3), "k-steps 0..3: four consecutive words of a row"
+    for row, ch in ((72, 36 * 72 + 16), (40, 36 * 40 + 16)):          # T64 / T32 pitches of cnn_kernel.hip
+        def off(t):
+            return (t // 25) * ch + ((t % 25) // 5) * row + t % 5
+        for slot in range(80):
+            if not (slot >> 2) & 1:
+                assert (off(tap[slot + 4]) - off(tap[slot])) % 32 == 16, (slot, tap[slot], tap[slot + 4])
