@@ -9,12 +9,15 @@
 //
 // The four convolutions are im2col GEMMs on the matrix cores.  M = output positions (16 per tile, ordered so that the 4 accumulator
 // registers of a lane are the members of one max-pool window), N = 16 output channels per tile, K = taps x input channels.
-//   All four run on v_mfma_f32_16x16x32_f16 with SPLIT operands (conv2 / conv3, 32 / 64 input channels, are 76 % of the FLOPs; the 5x5 convolutions gather 75 taps of
-//   the split input tile, padded to 3 k-steps).  Every activation is stored in LDS as ONE
-//     32-bit word holding two halves, hi = f16(v) and lo = f16(v - hi) (22 significant bits for |v| >= 2^-3, an absolute floor of 2^-25 below: see split_f16), the weights are split the same way on the
-//     host, and a product is hi*hi + hi*lo + lo*hi accumulated in f32 by three MFMAs (lo*lo, < 2^-21 relative, is dropped) -- f32-like accuracy (the
-//     logits stay within 1e-3 of the f32 reference, tests/test_cnn_gpu.py) at 16 / 3 times the f32 MFMA rate.  The maps keep their channel-major
-//     layout: a lane's 8 k-values are 8 channels of one position = the 8 dword reads the f32 form issued for 8 k-steps, repacked by two v_perm_b32 each.
+//   All four run on v_mfma_f32_16x16x32_f16 with SPLIT operands: a value v is the pair hi = f16(v), lo = f16(v - hi) (22 significant bits for |v| >= 2^-3, an
+//   absolute floor of 2^-25 below: see split_f16), the weights are split the same way on the host, and a product is hi*hi + hi*lo + lo*hi accumulated in f32 (lo*lo,
+//   < 2^-21 relative, is dropped) -- f32-like accuracy (the logits stay within 1e-3 of the f32 reference, tests/test_cnn_gpu.py) at 16 / 3 times the f32 MFMA rate.
+//   No instruction stands between an LDS read and the MFMA that consumes it (round 4):
+//     conv2 / conv3 (76 % of the FLOPs): the maps hold PAIRS of channels per 32-bit word, hi halves and lo halves in separate planes, so four words of a hi plane are
+//       the hi operand and four of a lo plane the lo operand as they are; three MFMAs per 32 channels (split_pair, pack_conv3);
+//     the 5x5 layers: the input tile holds one word (hi | lo) per sample, four RAW words are the A operand, and the two products come from two B operands
+//       (conv5_mfma, pack_conv5): 75 taps as 5 k-steps of 16, two MFMAs a step.
+//   Every operand read is bank-conflict-free by construction (the strides asserted below, hevcdl_conv5_slot_tap, the 2 x 8 M-tiles of conv2 / conv3).
 // conv+BN(train)+ReLU+pool are fused: BN statistics are per sample = per workgroup, so no global reduction exists;
 // x -> relu(x*alpha+beta) is monotone, so the pool runs before the affine map (max or min by the sign of gamma).
 // The conv64 branch is evaluated once and shared by the 4 quadrants (identical input, identical statistics).
@@ -98,13 +101,13 @@ __device__ __forceinline__ float split_f16(float v)
   const float r = v - (float)h[0];
   return __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(v, r));
 }
-// 8 split activations (k = 0..7 of a lane) -> the hi and the lo operand of the f16 MFMA
-__device__ __forceinline__ void gather_hl(const unsigned (&w)[8], h8 &hi, h8 &lo)
+// two activations -> the word of their hi halves (a in the low half) and the word of their lo halves: the operand form of conv2 / conv3, whose maps hold PAIRS of
+// channels per word in separate hi and lo planes, so that four words of a plane are an MFMA operand as they are (no repacking between the LDS read and the MFMA)
+__device__ __forceinline__ void split_pair(float a, float b, float &hi, float &lo)
 {
-  u4 a, b;
-#pragma unroll
-  for (int m = 0; m < 4; m++) { a[m] = __builtin_amdgcn_perm(w[2 * m + 1], w[2 * m], 0x05040100u); b[m] = __builtin_amdgcn_perm(w[2 * m + 1], w[2 * m], 0x07060302u); }
-  hi = __builtin_bit_cast(h8, a); lo = __builtin_bit_cast(h8, b);
+  const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  hi = __builtin_bit_cast(float, h);
+  lo = __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
 }
 // one product on split operands: acc += a * b with a = ah + al, b = bh + bl (al * bl dropped)
 __device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, const h8 &bl, v4f c)
@@ -212,10 +215,15 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     sm.alpha[tid] = al; sm.beta[tid] = be;
   }
   __syncthreads();
-  { // in-place affine + ReLU of the 16 pooled maps: thread = pixel
+  { // in-place affine + ReLU of the 16 pooled maps: thread = pixel.  The 16 planes of the block then hold conv2's operand form: plane m < 8 the hi halves of
+    // channels 2m | 2m + 1, plane 8 + m their lo halves
     const int py = tid >> 4, px = tid & 15;
+    float LDS *d = out + (py + 1) * A_ROW + px + 1;
+    float y[16];
 #pragma unroll
-    for (int o = 0; o < 16; o++) { float LDS *d = out + o * A_CH + (py + 1) * A_ROW + px + 1; *d = split_f16(fmaxf(*d * sm.alpha[o] + sm.beta[o], 0.f)); }      // stored split: conv2's operand form
+    for (int o = 0; o < 16; o++) y[o] = fmaxf(d[o * A_CH] * sm.alpha[o] + sm.beta[o], 0.f);
+#pragma unroll
+    for (int m = 0; m < 8; m++) { float hi, lo; split_pair(y[2 * m], y[2 * m + 1], hi, lo); d[m * A_CH] = hi; d[(8 + m) * A_CH] = lo; }
   }
   __syncthreads();
 }
@@ -383,7 +391,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     // channel stride is == 16 (mod 32): no two lanes of a half share a bank.  (The 8 x 2 tiles of round 3 had a 2-way conflict in every read: 43 % of
     // the kernel's LDS cycles, SQ_LDS_BANK_CONFLICT.)
     {
-      // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> input channel 4 * j + (lane >> 4))
+      // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> half j & 1 of channel pair 4 * (j >> 1) + (lane >> 4), pack_conv3)
       // (the layer's base is made opaque per quadrant and the lane's offset is a 32-bit register: every weight load is then `scalar base + register + immediate`;
       // with 64-bit lane pointers the unrolled sequence's 72 addresses were computed ahead of the quadrant loop and spilled)
       const char GLB *wb2 = (const char GLB *)(W + HEVCDL_W_C2); asm volatile("" : "+s"(wb2));
@@ -405,9 +413,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
       for (int n = 0; n < 4; n++) { bq[0][2 * n] = w2(n * 18); bq[0][2 * n + 1] = w2(n * 18 + 1); }
       auto aoff = [](int p) { return ((p >> 2) / 3) * A_ROW + ((p >> 2) % 3) + 2 * (p & 3); };
+      // word j of the operand pair: j < 4 the hi word of channel pair 4 j + g4 (channels 8 j + 2 g4 | + 1), j >= 4 the lo word of pair 4 (j - 4) + g4; pairs 0..7 live in
+      // conv1's block of planes, 8..15 in conv64's (conv5_mfma's affine pass); the lane group's g4 planes are in abase
+      auto aplane = [](int j) { const int m = 4 * (j & 3); return (m < 8 ? m : m + 8) + (j >> 2) * 8; };
       unsigned w0[8], w1[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) w0[j] = abase[j * 4 * A_CH + aoff(0)];
+      for (int j = 0; j < 8; j++) w0[j] = abase[aplane(j) * A_CH + aoff(0)];
 #pragma unroll
       for (int p = 0; p < 36; p++) {
         const int tap = p >> 2, t = p & 3;
@@ -418,11 +429,10 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
         if (p < 35) {
 #pragma unroll
-          for (int j = 0; j < 8; j++) wn[j] = abase[j * 4 * A_CH + aoff(p + 1)];
+          for (int j = 0; j < 8; j++) wn[j] = abase[aplane(j) * A_CH + aoff(p + 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
-        h8 ah, al;
-        gather_hl(wc, ah, al);
+        const h8 ah = __builtin_bit_cast(h8, (u4){ wc[0], wc[1], wc[2], wc[3] }), al = __builtin_bit_cast(h8, (u4){ wc[4], wc[5], wc[6], wc[7] });
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[t][n] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][2 * n]), __builtin_bit_cast(h8, bq[tap & 1][2 * n + 1]), acc[t][n]);
         __builtin_amdgcn_sched_barrier(0);
@@ -449,16 +459,22 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int wv = 0; wv < 4; wv++) { s += sm.red2[0][wv][lane]; ss += sm.red2[1][wv][lane]; }
         bn_fold(s, ss, 256.0, b2[64 + lane], b2[128 + lane], al_l, be_l);
       }
+      // conv3's operand form: plane m < 32 holds the hi halves of a PAIR of channels, plane 32 + m their lo halves; a lane pairs its N-tiles 0 | 1 (channels i16 | 16 + i16,
+      // pair i16) and 2 | 3 (32 + i16 | 48 + i16, pair 16 + i16)
 #pragma unroll
-      for (int n = 0; n < 4; n++) {
-        const int ch = n * 16 + i16;
-        const float al = __shfl(al_l, ch), be = __shfl(be_l, ch);
+      for (int np = 0; np < 2; np++) {
+        const int c0 = 32 * np + i16, c1 = c0 + 16;
+        const float al0 = __shfl(al_l, c0), be0 = __shfl(be_l, c0), al1 = __shfl(al_l, c1), be1 = __shfl(be_l, c1);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-          const v4f a = acc[t][n];
+          const v4f a = acc[t][2 * np], b = acc[t][2 * np + 1];
           const int T = 4 * wave + t;
-          const float v = fmaxf(fmaxf(a.x * al + be, a.y * al + be), fmaxf(a.z * al + be, a.w * al + be));
-          sm.q.a2[ch * A2_CH + (4 * (T >> 3) + g4 + 1) * A2_ROW + (T & 7) + 1] = split_f16(fmaxf(v, 0.f));      // window g4 of tile T; stored split: conv3's operand form
+          const float v0 = fmaxf(fmaxf(a.x * al0 + be0, a.y * al0 + be0), fmaxf(a.z * al0 + be0, a.w * al0 + be0));
+          const float v1 = fmaxf(fmaxf(b.x * al1 + be1, b.y * al1 + be1), fmaxf(b.z * al1 + be1, b.w * al1 + be1));
+          float hi, lo;
+          split_pair(fmaxf(v0, 0.f), fmaxf(v1, 0.f), hi, lo);
+          float LDS *d = sm.q.a2 + (16 * np + i16) * A2_CH + (4 * (T >> 3) + g4 + 1) * A2_ROW + (T & 7) + 1;      // window g4 of tile T
+          d[0] = hi; d[32 * A2_CH] = lo;
         }
       }
       __syncthreads();
@@ -466,7 +482,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     CNN_MARK(4);
     // ---- conv3: 64 -> 128, 3x3 (use_model.py:32-37); wave w owns output channels [32w, 32w+32) = 2 N-tiles, 4 M-tiles ----
     {
-      // packed weights: [N-tile][tap][k-step s][hi | lo][64 lanes] x 16 bytes (k = 8 * (lane >> 4) + j <-> input channel 32 * s + 4 * j + (lane >> 4))
+      // packed weights: [N-tile][tap][k-step s][hi | lo][64 lanes] x 16 bytes (k = 8 * (lane >> 4) + j <-> half j & 1 of channel pair 16 * s + 4 * (j >> 1) + (lane >> 4), pack_conv3)
       const char GLB *wb3 = (const char GLB *)(W + HEVCDL_W_C3) + (size_t)(2 * wave) * (9 * 4096); asm volatile("" : "+s"(wb3));
       const unsigned lb = lane * 16u;
       auto w3 = [&](int idx) { return *(const u4 GLB *)(wb3 + (size_t)(lb + (unsigned)idx * 1024u)); };
@@ -485,10 +501,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       for (int n = 0; n < 2; n++)
 #pragma unroll
         for (int q = 0; q < 4; q++) bq[0][n * 4 + q] = w3(n * 36 + q);
-      auto aoff = [](int p) { return (8 * ((p >> 2) & 1)) * 4 * A2_CH + ((p >> 3) / 3) * A2_ROW + ((p >> 3) % 3) + 2 * (p & 3); };
+      // word j of the operand pair in k-step sk: j < 4 the hi word of channel pair 16 sk + 4 j + g4, j >= 4 the lo word of pair 16 sk + 4 (j - 4) + g4
+      auto aoff = [](int p) { return 16 * ((p >> 2) & 1) * A2_CH + ((p >> 3) / 3) * A2_ROW + ((p >> 3) % 3) + 2 * (p & 3); };
+      auto aplane = [](int j) { return 4 * (j & 3) + 32 * (j >> 2); };
       unsigned w0[8], w1[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) w0[j] = abase[j * 4 * A2_CH + aoff(0)];
+      for (int j = 0; j < 8; j++) w0[j] = abase[aplane(j) * A2_CH + aoff(0)];
 #pragma unroll
       for (int p = 0; p < 72; p++) {
         const int tap = p >> 3, sk = (p >> 2) & 1, t = p & 3;
@@ -501,11 +519,10 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
         if (p < 71) {
 #pragma unroll
-          for (int j = 0; j < 8; j++) wn[j] = abase[j * 4 * A2_CH + aoff(p + 1)];
+          for (int j = 0; j < 8; j++) wn[j] = abase[aplane(j) * A2_CH + aoff(p + 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
-        h8 ah, al;
-        gather_hl(wc, ah, al);
+        const h8 ah = __builtin_bit_cast(h8, (u4){ wc[0], wc[1], wc[2], wc[3] }), al = __builtin_bit_cast(h8, (u4){ wc[4], wc[5], wc[6], wc[7] });
         acc[0][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][2 * sk]), __builtin_bit_cast(h8, bq[tap & 1][2 * sk + 1]), acc[0][t]);
         acc[1][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][4 + 2 * sk]), __builtin_bit_cast(h8, bq[tap & 1][4 + 2 * sk + 1]), acc[1][t]);
         __builtin_amdgcn_sched_barrier(0);

@@ -153,8 +153,8 @@ static float f16_to_f32(uint16_t h)
   float f; memcpy(&f, &x, 4); return f;
 }
 // conv2 / conv3 on v_mfma_f32_16x16x32_f16 with SPLIT operands (cnn_kernel.hip): a weight w is the pair hi = half(w), lo = half(w - hi).  B-operand packing:
-// lane l supplies B[k = 8 * (l >> 4) + j][n = l & 15], j = 0..7, and k-value (l >> 4, j) of k-step s stands for input channel 32 s + 4 j + (l >> 4) (the order in
-// which a lane's 8 LDS reads walk the channel-major activation maps without bank conflicts).  Layout: [oc/16 N-tiles][9 taps][ic/32 k-steps][hi | lo][64 lanes][8 halves],
+// lane l supplies B[k = 8 * (l >> 4) + j][n = l & 15], j = 0..7, and k-value (l >> 4, j) of k-step s stands for half j & 1 of the channel PAIR 16 s + 4 (j >> 1) + (l >> 4)
+// of the kernel's activation maps (a word of a map holds the hi -- or the lo -- halves of two channels: four words are an operand as they lie in LDS).  Layout: [oc/16 N-tiles][9 taps][ic/32 k-steps][hi | lo][64 lanes][8 halves],
 // then bias, gamma, beta as floats -- the same number of bytes as the f32 packing it replaces.
 // the 5x5 convolutions (3 input channels, 16 output channels = one N-tile): the 75 taps (c * 5 + ky) * 5 + kx in the order of hevcdl_conv5_slot_tap, 5 k-steps of 16.
 // The A operand of a step is four raw split words (hi, lo, hi, lo, ...): B1 carries the weight's hi half against both halves, B2 its lo half against the hi half only.
@@ -174,7 +174,10 @@ static void pack_conv3(const float *w, const float *b, const float *g, const flo
   uint16_t *d16 = (uint16_t *)dst;
   const int ks = ic / 32;
   for (int nt = 0; nt < oc / 16; nt++) for (int tap = 0; tap < 9; tap++) for (int s = 0; s < ks; s++) for (int l = 0; l < 64; l++) for (int j = 0; j < 8; j++) {
-    const int c = 32 * s + 4 * j + (l >> 4), o = nt * 16 + (l & 15);
+    // element j of lane group g = l >> 4: half j & 1 of the map's channel PAIR m = 16 s + 4 (j >> 1) + g (cnn_kernel.hip: the operand is four words of a plane of pairs).
+    // conv2's input (32 channels): pair m = channels 2m | 2m + 1;  conv3's input (64): pairs 0..15 = channels m | m + 16, pairs 16..31 = 16 + m | 32 + m
+    const int m = 16 * s + 4 * (j >> 1) + (l >> 4), hf = j & 1;
+    const int c = ic == 32 ? 2 * m + hf : (m < 16 ? m + 16 * hf : 16 + m + 16 * hf), o = nt * 16 + (l & 15);
     const float v = w[((size_t)o * ic + c) * 9 + tap];
     const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
     const size_t base = ((((size_t)nt * 9 + tap) * ks + s) * 2) * 512;        // halves: 64 lanes x 8 per operand
