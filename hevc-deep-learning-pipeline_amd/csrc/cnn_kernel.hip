@@ -13,8 +13,8 @@
 //   absolute floor of 2^-25 below: see split_f16), the weights are split the same way on the host, and a product is hi*hi + hi*lo + lo*hi accumulated in f32 (lo*lo,
 //   < 2^-21 relative, is dropped) -- f32-like accuracy (the logits stay within 1e-3 of the f32 reference, tests/test_cnn_gpu.py) at 16 / 3 times the f32 MFMA rate.
 //   No instruction stands between an LDS read and the MFMA that consumes it (round 4):
-//     conv2 / conv3 (76 % of the FLOPs): the maps hold PAIRS of channels per 32-bit word, hi halves and lo halves in separate planes, so four words of a hi plane are
-//       the hi operand and four of a lo plane the lo operand as they are; three MFMAs per 32 channels (split_pair, pack_conv3);
+//     conv2 / conv3 (76 % of the FLOPs): the maps hold PAIRS of channels per 32-bit word, hi halves and lo halves in separate arrays, position-major with the four
+//       words of an operand next to each other: one ds_read_b128 is the hi operand, one the lo operand; three MFMAs per 32 channels (split_pair, pack_conv3);
 //     the 5x5 layers: the input tile holds one word (hi | lo) per sample, four RAW words are the A operand, and the two products come from two B operands
 //       (conv5_mfma, pack_conv5): 75 taps as 5 k-steps of 16, two MFMAs a step.
 //   Every operand read is bank-conflict-free by construction (the strides asserted below, hevcdl_conv5_slot_tap, the 2 x 8 M-tiles of conv2 / conv3).
@@ -38,23 +38,25 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define PIN8(r) do { _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) asm volatile("" : "+v"(r[i_])); } while (0)
 #define GLB __attribute__((address_space(1)))
 
-constexpr int A_CH = 336;                  // 18x18 halo'd 16x16 map, channel stride == 16 (mod 32 banks): see the bank note at conv2
-constexpr int A_ROW = 18;
-constexpr int A2_CH = 112;                 // 10x10 halo'd 8x8 map, channel stride == 16 (mod 32 banks)
-constexpr int A2_ROW = 10;
+// conv2's / conv3's input maps are POSITION-major: the four words of an MFMA operand -- channel pairs 4 j + g, j = 0..3, of lane group g; hi halves and lo halves
+// in separate arrays -- lie next to each other, one ds_read_b128 per operand.  act12 = [g][hi | lo][18 x 18 positions][4 words], a2 = [k-step][g][hi | lo][10 x 10][4].
+// A ds_read_b128 is served 16 lanes at a time, 16 positions of one or two lane groups: with row pitches of 18 / 10 positions the 16 positions of an M-tile (2 columns x
+// 8 rows) are distinct mod 16 = distinct quarters of the 64 banks, and an array size == 0 (mod 32 words) keeps the two lane groups of a service group on the same footing.
+constexpr int A_ROW = 18, AP = 18 * 18 * 4 + 16;        // words per (g, hi | lo) array of act12
+constexpr int A2_ROW = 10, A2P = 10 * 10 * 4 + 16;      // ... of a2
 constexpr int T64_ROW = 72, T64_CH = 36 * 72 + 16;   // input tile of HALF the CTU (32 rows + halo 2; conv64 runs in two halves): row pitch == 8, channel stride == 16 (mod 32 banks)
 constexpr int T32_ROW = 40, T32_CH = 36 * 40 + 16;   // input tile of one quadrant, halo 2: row pitch == 8, channel stride == 16 (mod 32 banks); hevcdl_conv5_slot_tap
 
-static_assert(A_CH % 32 == 16 && A2_CH % 32 == 16 && T64_CH % 32 == 16 && T32_CH % 32 == 16 && T64_ROW % 32 == 8 && T32_ROW % 32 == 8 && A_ROW == 18 && A2_ROW == 10,
+static_assert(AP % 32 == 0 && A2P % 32 == 0 && T64_CH % 32 == 16 && T32_CH % 32 == 16 && T64_ROW % 32 == 8 && T32_ROW % 32 == 8 && A_ROW == 18 && A2_ROW == 10,
               "the operand reads are bank-conflict-free only at these strides (conv2 / conv3: 2 x 8 M-tiles; 5x5 layers: 8 x 2 M-tiles, hevcdl_conv5_slot_tap)");
 struct CnnSmem {
   float lut[256];                          // u8 -> u8/255 (ToTensor, use_model.py:94-95), stored split (hi | lo halves): the operand form of the convolutions
   int koff64[80], koff32[80];              // im2col offset, inside the input tiles, of the tap in K slot k (hevcdl_conv5_slot_tap; a padding slot reads a tap that keeps the gather conflict-free, zero weight)
-  float act12[32 * A_CH];                  // conv1 output (channels 0..15) ++ conv64 output (16..31): cat of use_model.py:50
+  float act12[8 * AP];                     // conv1 output (channels 0..15 = pairs 0..7) ++ conv64 output (16..31 = pairs 8..15): cat of use_model.py:50; pair m: lane group m & 3, word m >> 2
   union {
     float t64[3 * T64_CH];                 // conv64 input tile of one half of the CTU (only live before the quadrant loop)
     struct {
-      union { float t32[3 * T32_CH]; float a2[64 * A2_CH]; };   // conv1 input tile | conv2 output
+      union { float t32[3 * T32_CH]; float a2[16 * A2P]; };   // conv1 input tile | conv2 output (pair m of 32: k-step m >> 4, lane group m & 3, word (m & 15) >> 2)
     } q;
   };
   double red[2][4][16];                    // per-wave partial sums / sums of squares (5x5 layers)
@@ -133,7 +135,7 @@ __device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, c
 // phase 0: the whole map in one call (conv1 on a quadrant).  phase 1 / 2: upper / lower half of the CTU for conv64 (tile rows are then
 // relative to the half); the statistics of the halves meet in sm.red and the map is normalised after the second.
 template <int POOL>
-__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *out, int tid, int phase)
+__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *map, int pb, int tid, int phase)
 {
   constexpr int ROW = (POOL == 4) ? T64_ROW : T32_ROW;
   constexpr int ITERS = (POOL == 4) ? 8 : 4;        // per wave and call: 8 rows of the region, 4 tiles an iteration
@@ -148,6 +150,8 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
 #pragma unroll
   for (int q = 0; q < 8; q++) kp[q] = (const unsigned LDS *)tile + (8 * wave + py) * ROW + px + koff[q < 4 ? 16 * q + 4 * g : 64 + 4 * g + (q - 4)];
   auto word = [&](int ks, int j, int off) { return ks < 4 ? kp[ks][off + j] : kp[4 + j][off]; };
+  // the pooled extremes are staged where the operand words of their channel will be: channel i = half i & 1 of pair pb + (i >> 1) -> the hi (even) / lo (odd) array
+  float LDS *const out = map + (((pb + (i >> 1)) & 3) * 2 + (i & 1)) * AP + ((pb + (i >> 1)) >> 2);
   double s = 0, ss = 0;
   // tile u of an iteration: POOL 2: columns 8u of one tile row;  POOL 4: tile row u >> 1, columns 8 (u & 1) of a 16 x 4 block (four windows)
   auto toff = [](int u) { return (POOL == 4) ? (u >> 1) * 2 * ROW + 8 * (u & 1) : 8 * u; };
@@ -192,12 +196,12 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
       for (int tc = 0; tc < 2; tc++) {
         float v = (gamma >= 0.f) ? fmaxf(e[tc], e[2 + tc]) : fminf(e[tc], e[2 + tc]);
         const float o = __shfl_xor(v, 16); v = (gamma >= 0.f) ? fmaxf(v, o) : fminf(v, o);
-        if (!(g & 1)) out[i * A_CH + (prow + 1) * A_ROW + 4 * (it & 3) + 2 * tc + (g >> 1) + 1] = v;
+        if (!(g & 1)) out[((prow + 1) * A_ROW + 4 * (it & 3) + 2 * tc + (g >> 1) + 1) * 4] = v;
       }
     } else {
       const int prow = 4 * wave + it;
 #pragma unroll
-      for (int u = 0; u < 4; u++) out[i * A_CH + (prow + 1) * A_ROW + 4 * u + g + 1] = e[u];
+      for (int u = 0; u < 4; u++) out[((prow + 1) * A_ROW + 4 * u + g + 1) * 4] = e[u];
     }
   }
   // per-channel statistics over the whole map: lane groups, then waves
@@ -215,15 +219,16 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     sm.alpha[tid] = al; sm.beta[tid] = be;
   }
   __syncthreads();
-  { // in-place affine + ReLU of the 16 pooled maps: thread = pixel.  The 16 planes of the block then hold conv2's operand form: plane m < 8 the hi halves of
-    // channels 2m | 2m + 1, plane 8 + m their lo halves
+  { // in-place affine + ReLU of the 16 pooled maps: thread = pixel.  The slots then hold conv2's operand form: the hi halves of channels 2m | 2m + 1 in the hi array's
+    // word of pair pb + m, their lo halves in the lo array's
     const int py = tid >> 4, px = tid & 15;
-    float LDS *d = out + (py + 1) * A_ROW + px + 1;
-    float y[16];
+    float LDS *d = map + ((py + 1) * A_ROW + px + 1) * 4 + (pb >> 2);
 #pragma unroll
-    for (int o = 0; o < 16; o++) y[o] = fmaxf(d[o * A_CH] * sm.alpha[o] + sm.beta[o], 0.f);
-#pragma unroll
-    for (int m = 0; m < 8; m++) { float hi, lo; split_pair(y[2 * m], y[2 * m + 1], hi, lo); d[m * A_CH] = hi; d[(8 + m) * A_CH] = lo; }
+    for (int m = 0; m < 8; m++) {                                   // pair pb + m: lane group m & 3, word (pb + m) >> 2; its two channels staged in the hi / lo slots
+      float LDS *q = d + ((m & 3) * 2) * AP + (m >> 2);
+      const float y0 = fmaxf(q[0] * sm.alpha[2 * m] + sm.beta[2 * m], 0.f), y1 = fmaxf(q[AP] * sm.alpha[2 * m + 1] + sm.beta[2 * m + 1], 0.f);
+      float hi, lo; split_pair(y0, y1, hi, lo); q[0] = hi; q[AP] = lo;
+    }
   }
   __syncthreads();
 }
@@ -325,10 +330,10 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     const int c = i / (36 * 8), r = (i >> 3) % 36, k = i & 7;
     sm.t64[c * T64_CH + r * T64_ROW + (k < 2 ? k : 64 + k)] = 0.f;
   }
-  for (int i = tid; i < 32 * 72; i += 256) {                       // 18x18 map + 4 pad words: 68 border words + 4 = 72 per channel
-    const int c = i / 72, r = i - c * 72;
-    const int o = r < 18 ? r : (r < 36 ? 17 * 18 + (r - 18) : (r < 52 ? (r - 35) * 18 : (r < 68 ? (r - 51) * 18 + 17 : 324 + (r - 68))));
-    sm.act12[c * A_CH + o] = 0.f;
+  for (int i = tid; i < 8 * 68; i += 256) {                        // the 68 border positions of the 18x18 maps, four words each, in the 8 arrays of act12
+    const int c = i / 68, r = i - c * 68;
+    const int o = r < 18 ? r : (r < 36 ? 17 * 18 + (r - 18) : (r < 52 ? (r - 35) * 18 : (r - 51) * 18 + 17));
+    *(u4 LDS *)(sm.act12 + c * AP + o * 4) = (u4){ 0u, 0u, 0u, 0u };
   }
   __syncthreads();
   CNN_MARK(0);
@@ -344,7 +349,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       d[T64_CH] = (f2){ v2[0], v2[1] }; d[T64_CH + 1] = (f2){ v2[2], v2[3] };
     }
     __syncthreads();
-    conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12 + 16 * A_CH, tid, h + 1);
+    conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12, 8, tid, h + 1);
   }
 
   CNN_MARK(1);
@@ -370,15 +375,12 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     }
     __syncthreads();
     CNN_MARK(2);
-    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, tid, 0);
+    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, 0, tid, 0);
     CNN_MARK(3);
-    { // the input tile is dead: zero the halo of conv2's output.  Four threads per channel, nine of the 36 border words of its 10 x 10 map each
-      float LDS *d = sm.q.a2 + (tid >> 2) * A2_CH;
-#pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const int r = (tid & 3) * 9 + k;                               // 0..9 top row, 10..19 bottom row, 20..35 the sides of rows 1..8
-        d[r < 10 ? r : (r < 20 ? 80 + r : (1 + ((r - 20) >> 1)) * 10 + ((r - 20) & 1) * 9)] = 0.f;
-      }
+    for (int i = tid; i < 16 * 36; i += 256) {                       // the input tile is dead: zero the 36 border positions of conv2's 10 x 10 output maps, four words each, 16 arrays
+      const int c = i / 36, r = i - c * 36;                          // 0..9 top row, 10..19 bottom row, 20..35 the sides of rows 1..8
+      const int o = r < 10 ? r : (r < 20 ? 80 + r : (1 + ((r - 20) >> 1)) * 10 + ((r - 20) & 1) * 9);
+      *(u4 LDS *)(sm.q.a2 + c * A2P + o * 4) = (u4){ 0u, 0u, 0u, 0u };
     }
     __syncthreads();
 
@@ -386,10 +388,9 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     // wave w owns M-tiles 4w .. 4w + 3 and ALL four N-tiles: an A tile is gathered from LDS once and multiplied into
     // 64 output channels (gathering it per N-tile, one N-tile per wave, made the operand reads the bound).  The BN statistics of a channel are
     // then spread over the four waves and meet in LDS.  k = tap * 32 + ic.
-    // Banks: a ds_read_b32 is served in two halves of 32 lanes = 16 positions x 2 adjacent input channels.  An M-tile is 2 columns x 8 rows (four pool
-    // windows stacked): with a row pitch of 18 (10 for conv3's maps) its 16 words fall into 16 banks whose translate by 16 is the complement, and the
-    // channel stride is == 16 (mod 32): no two lanes of a half share a bank.  (The 8 x 2 tiles of round 3 had a 2-way conflict in every read: 43 % of
-    // the kernel's LDS cycles, SQ_LDS_BANK_CONFLICT.)
+    // Banks: an operand is one ds_read_b128 (the map layouts at the top of the file).  An M-tile is 2 columns x 8 rows (four pool windows stacked): with a row
+    // pitch of 18 positions (10 for conv3's maps) its 16 positions are distinct mod 16, i.e. the 16 lanes a b128 read serves at a time hit 16 different quarters of
+    // the 64 banks.  (The 8 x 2 tiles of round 3, read word by word from channel-major maps, had a 2-way conflict in every read: 43 % of the kernel's LDS cycles.)
     {
       // packed weights: [N-tile][tap][hi | lo][64 lanes] x 16 bytes (8 halves: k = 8 * (lane >> 4) + j <-> half j & 1 of channel pair 4 * (j >> 1) + (lane >> 4), pack_conv3)
       // (the layer's base is made opaque per quadrant and the lane's offset is a 32-bit register: every weight load is then `scalar base + register + immediate`;
@@ -406,19 +407,15 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         for (int t = 0; t < 4; t++) acc[t][n] = (v4f){ bias, bias, bias, bias };
       }
       // lane -> (pool window i16 >> 2 of the tile, member i16 & 3), input channel group g4; tile T = 4 * wave + t sits at rows 8 * (T >> 3), columns 2 * (T & 7)
-      const unsigned LDS *abase = (const unsigned LDS *)sm.act12 + g4 * A_CH + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A_ROW + (i16 & 1) + (8 * (wave >> 1)) * A_ROW + 8 * (wave & 1);
+      const u4 LDS *abase = (const u4 LDS *)(sm.act12 + (2 * g4) * AP) + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A_ROW + (i16 & 1) + (8 * (wave >> 1)) * A_ROW + 8 * (wave & 1);      // (in positions = 16 bytes)
       // The 36 (tap, tile) steps are one unrolled sequence: the 8 LDS reads of step p + 1 are issued before the MFMAs of step p -- across taps too --, and the weights
       // of tap + 1 ([N-tile][hi | lo], two register sets) are requested when tap begins.  The scheduling barriers keep that order (left alone the loads sink to their uses).
       u4 bq[2][8];
 #pragma unroll
       for (int n = 0; n < 4; n++) { bq[0][2 * n] = w2(n * 18); bq[0][2 * n + 1] = w2(n * 18 + 1); }
       auto aoff = [](int p) { return ((p >> 2) / 3) * A_ROW + ((p >> 2) % 3) + 2 * (p & 3); };
-      // word j of the operand pair: j < 4 the hi word of channel pair 4 j + g4 (channels 8 j + 2 g4 | + 1), j >= 4 the lo word of pair 4 (j - 4) + g4; pairs 0..7 live in
-      // conv1's block of planes, 8..15 in conv64's (conv5_mfma's affine pass); the lane group's g4 planes are in abase
-      auto aplane = [](int j) { const int m = 4 * (j & 3); return (m < 8 ? m : m + 8) + (j >> 2) * 8; };
-      unsigned w0[8], w1[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) w0[j] = abase[aplane(j) * A_CH + aoff(0)];
+      // the operand pair of a step: the lane group's hi array at the position, and its lo array (AP words on)
+      u4 h0 = abase[aoff(0)], l0 = abase[AP / 4 + aoff(0)], h1, l1;
 #pragma unroll
       for (int p = 0; p < 36; p++) {
         const int tap = p >> 2, t = p & 3;
@@ -426,13 +423,10 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
           for (int n = 0; n < 4; n++) { bq[(tap + 1) & 1][2 * n] = w2(n * 18 + (tap + 1) * 2); bq[(tap + 1) & 1][2 * n + 1] = w2(n * 18 + (tap + 1) * 2 + 1); }
         }
-        unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
-        if (p < 35) {
-#pragma unroll
-          for (int j = 0; j < 8; j++) wn[j] = abase[aplane(j) * A_CH + aoff(p + 1)];
-        }
+        u4 &hc = (p & 1) ? h1 : h0, &lc = (p & 1) ? l1 : l0, &hn = (p & 1) ? h0 : h1, &ln = (p & 1) ? l0 : l1;
+        if (p < 35) { hn = abase[aoff(p + 1)]; ln = abase[AP / 4 + aoff(p + 1)]; }
         __builtin_amdgcn_sched_barrier(0);
-        const h8 ah = __builtin_bit_cast(h8, (u4){ wc[0], wc[1], wc[2], wc[3] }), al = __builtin_bit_cast(h8, (u4){ wc[4], wc[5], wc[6], wc[7] });
+        const h8 ah = __builtin_bit_cast(h8, hc), al = __builtin_bit_cast(h8, lc);
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[t][n] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][2 * n]), __builtin_bit_cast(h8, bq[tap & 1][2 * n + 1]), acc[t][n]);
         __builtin_amdgcn_sched_barrier(0);
@@ -473,8 +467,8 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
           const float v1 = fmaxf(fmaxf(b.x * al1 + be1, b.y * al1 + be1), fmaxf(b.z * al1 + be1, b.w * al1 + be1));
           float hi, lo;
           split_pair(fmaxf(v0, 0.f), fmaxf(v1, 0.f), hi, lo);
-          float LDS *d = sm.q.a2 + (16 * np + i16) * A2_CH + (4 * (T >> 3) + g4 + 1) * A2_ROW + (T & 7) + 1;      // window g4 of tile T
-          d[0] = hi; d[32 * A2_CH] = lo;
+          float LDS *d = sm.q.a2 + ((4 * np + (i16 & 3)) * 2) * A2P + ((4 * (T >> 3) + g4 + 1) * A2_ROW + (T & 7) + 1) * 4 + (i16 >> 2);      // window g4 of tile T; pair 16 np + i16
+          d[0] = hi; d[A2P] = lo;
         }
       }
       __syncthreads();
@@ -494,19 +488,16 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[n][t] = (v4f){ bias, bias, bias, bias };
       }
-      const unsigned LDS *abase = (const unsigned LDS *)sm.q.a2 + g4 * A2_CH + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A2_ROW + (i16 & 1);      // M-tile t: columns 2t, 2t + 1, all 8 rows
+      const u4 LDS *abase = (const u4 LDS *)(sm.q.a2 + (2 * g4) * A2P) + (2 * (i16 >> 2) + ((i16 >> 1) & 1)) * A2_ROW + (i16 & 1);      // M-tile t: columns 2t, 2t + 1, all 8 rows (in positions = 16 bytes)
       // 72 (tap, k-step, tile) steps as one unrolled sequence, as in conv2; weights [N-tile n][k-step s][hi | lo] of a tap in two register sets
       u4 bq[2][8];
 #pragma unroll
       for (int n = 0; n < 2; n++)
 #pragma unroll
         for (int q = 0; q < 4; q++) bq[0][n * 4 + q] = w3(n * 36 + q);
-      // word j of the operand pair in k-step sk: j < 4 the hi word of channel pair 16 sk + 4 j + g4, j >= 4 the lo word of pair 16 sk + 4 (j - 4) + g4
-      auto aoff = [](int p) { return 16 * ((p >> 2) & 1) * A2_CH + ((p >> 3) / 3) * A2_ROW + ((p >> 3) % 3) + 2 * (p & 3); };
-      auto aplane = [](int j) { return 4 * (j & 3) + 32 * (j >> 2); };
-      unsigned w0[8], w1[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) w0[j] = abase[aplane(j) * A2_CH + aoff(0)];
+      // the operand pair of a step: k-step sk's arrays of the lane group (8 arrays of A2P words on), hi at the position, lo A2P words on
+      auto aoff = [](int p) { return ((p >> 2) & 1) * (8 * A2P / 4) + ((p >> 3) / 3) * A2_ROW + ((p >> 3) % 3) + 2 * (p & 3); };
+      u4 h0 = abase[aoff(0)], l0 = abase[A2P / 4 + aoff(0)], h1, l1;
 #pragma unroll
       for (int p = 0; p < 72; p++) {
         const int tap = p >> 3, sk = (p >> 2) & 1, t = p & 3;
@@ -516,13 +507,10 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #pragma unroll
             for (int q = 0; q < 4; q++) bq[(tap + 1) & 1][n * 4 + q] = w3(n * 36 + (tap + 1) * 4 + q);
         }
-        unsigned (&wc)[8] = (p & 1) ? w1 : w0; unsigned (&wn)[8] = (p & 1) ? w0 : w1;
-        if (p < 71) {
-#pragma unroll
-          for (int j = 0; j < 8; j++) wn[j] = abase[aplane(j) * A2_CH + aoff(p + 1)];
-        }
+        u4 &hc = (p & 1) ? h1 : h0, &lc = (p & 1) ? l1 : l0, &hn = (p & 1) ? h0 : h1, &ln = (p & 1) ? l0 : l1;
+        if (p < 71) { hn = abase[aoff(p + 1)]; ln = abase[A2P / 4 + aoff(p + 1)]; }
         __builtin_amdgcn_sched_barrier(0);
-        const h8 ah = __builtin_bit_cast(h8, (u4){ wc[0], wc[1], wc[2], wc[3] }), al = __builtin_bit_cast(h8, (u4){ wc[4], wc[5], wc[6], wc[7] });
+        const h8 ah = __builtin_bit_cast(h8, hc), al = __builtin_bit_cast(h8, lc);
         acc[0][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][2 * sk]), __builtin_bit_cast(h8, bq[tap & 1][2 * sk + 1]), acc[0][t]);
         acc[1][t] = mfma3(ah, al, __builtin_bit_cast(h8, bq[tap & 1][4 + 2 * sk]), __builtin_bit_cast(h8, bq[tap & 1][4 + 2 * sk + 1]), acc[1][t]);
         __builtin_amdgcn_sched_barrier(0);
