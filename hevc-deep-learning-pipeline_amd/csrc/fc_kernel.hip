@@ -39,7 +39,9 @@ __device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, c
 }
 __device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 constexpr int H1_ROW = 260, H2_ROW = 68;     // LDS pitches: + 4 floats keep the 16 rows of an A fragment on different banks
-struct FcSmem { float h1[64 * H1_ROW]; float h2[64 * H2_ROW]; float lg[64][16]; };
+// h2 and the logits share h1's storage (fc2's results wait in registers behind a barrier until every wave has read h1): 65 KB, TWO workgroups per CU -- with one, a
+// SIMD held a single wave and nothing covered its load latencies
+struct FcSmem { union { float h1[64 * H1_ROW]; struct { float h2[64 * H2_ROW]; float lg[64][16]; } s; }; };
 }
 
 extern "C" __global__ __launch_bounds__(256)
@@ -119,9 +121,10 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
       for (int mt = 0; mt < 4; mt++) acc[mt] = mfma4(sm.h1[(mt * 16 + i16) * H1_ROW + k0 + g4], b, acc[mt]);
     }
     const float b = W[HEVCDL_W_FC2 + 256 * 64 + wave * 16 + i16];
+    __syncthreads();                          // (h2 overlays h1)
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
-      float *d = sm.h2 + (mt * 16 + g4 * 4) * H2_ROW + wave * 16 + i16;
+      float *d = sm.s.h2 + (mt * 16 + g4 * 4) * H2_ROW + wave * 16 + i16;
       d[0] = fmaxf(acc[mt].x + b, 0.f); d[H2_ROW] = fmaxf(acc[mt].y + b, 0.f); d[2 * H2_ROW] = fmaxf(acc[mt].z + b, 0.f); d[3 * H2_ROW] = fmaxf(acc[mt].w + b, 0.f);
     }
   }
@@ -130,13 +133,13 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
     const float GLB *W3 = W + HEVCDL_W_FC3 + (size_t)g4 * 16 + i16;
     v4f acc = { 0, 0, 0, 0 };
 #pragma unroll
-    for (int k0 = 0; k0 < 64; k0 += 4) acc = mfma4(sm.h2[(wave * 16 + i16) * H2_ROW + k0 + g4], W3[(size_t)k0 * 16], acc);
+    for (int k0 = 0; k0 < 64; k0 += 4) acc = mfma4(sm.s.h2[(wave * 16 + i16) * H2_ROW + k0 + g4], W3[(size_t)k0 * 16], acc);
     const float b = W[HEVCDL_W_FC3 + 64 * 16 + i16];
     const float v[4] = { acc.x + b, acc.y + b, acc.z + b, acc.w + b };
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = wave * 16 + g4 * 4 + r;
-      sm.lg[row][i16] = v[r];
+      sm.s.lg[row][i16] = v[r];
       if (p.logits && row0 + row < n_rows) ((float GLB *)p.logits)[(size_t)(row0 + row) * 16 + i16] = v[r];
     }
   }
@@ -146,7 +149,7 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
   if (tid < 16 && blockIdx.x * 16 + tid < p.n_ctus) {
     const int gctu = p.ctu_base + blockIdx.x * 16 + tid;
     const int addr = gctu % p.ctus_per_frame, x0 = (addr % p.ctus_x) * 64, y0 = (addr / p.ctus_x) * 64;
-    const float (*lg)[16] = &sm.lg[tid * 4];
+    const float (*lg)[16] = &sm.s.lg[tid * 4];
     uint8_t lab[16];
     const int quads[4][4] = { {0, 1, 4, 5}, {2, 3, 6, 7}, {8, 9, 12, 13}, {10, 11, 14, 15} };
     for (int q = 0; q < 4; q++) {
