@@ -76,3 +76,23 @@ def test_boundary_picture_zero_fill_and_clamp():
     md = cnn_oracle.min_depth_table(w_, h_)
     assert (labels[0] >= md).all()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,cnn_input", [("rgb601", 0), ("luma", 1)])
+def test_frame_input_modes_equal_the_rgb_ctu_path_on_the_same_samples(mode, cnn_input):
+    """The three input forms of the kernel's tile fill (planar 4:2:0 converted on the fly, luma only, packed RGB CTUs) put the same samples into the tiles: the
+    logits of a frame must equal, bit for bit, those of its CTUs converted by the oracle's tiling (oracle/cnn_oracle.py yuv_to_rgb_ctus: use_model.py:80-95 + this
+    project's YUV -> RGB transform) and handed over as RGB -- on a picture whose right and bottom CTUs are partly outside (zero fill)."""
+    import cnn_oracle
+    import hevcdl_amd
+    import ref_tools
+    w_, h_ = 168, 104
+    yuv = ref_tools.synth_yuv(w_, h_, 2, seed=21)
+    e = hevcdl_amd.Encoder(w_, h_, 32, max_frames=2, cnn_input=cnn_input)
+    labels, logits = e.predict_depth(yuv, want_logits=True)
+    for f in range(2):
+        ctus = cnn_oracle.yuv_to_rgb_ctus(yuv[f], w_, h_, mode=mode)
+        r_labels, r_logits = e.predict_depth_rgb(ctus)
+        assert np.array_equal(logits[f].reshape(r_logits.shape), r_logits)
+    e.close()
