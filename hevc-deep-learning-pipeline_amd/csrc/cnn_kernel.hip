@@ -34,8 +34,6 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define HEVCDL_CNN_SKEW 40            // start offset of the second workgroup of a CU, in units of 8128 cycles (see the kernel)
 #endif
 #define LDS __attribute__((address_space(3)))
-// keeps eight loaded registers from being re-expressed as a load of a loop-carried address (which would put the load next to its use)
-#define PIN8(r) do { _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) asm volatile("" : "+v"(r[i_])); } while (0)
 #define GLB __attribute__((address_space(1)))
 
 // conv2's / conv3's input maps are POSITION-major: the four words of an MFMA operand -- channel pairs 4 j + g, j = 0..3, of lane group g; hi halves and lo halves
