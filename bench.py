@@ -418,7 +418,7 @@ def main():
     W, H, qp, F = a.width, a.height, a.qp, a.frames
     mine = sharding.shard_frames(F, world, rank)                   # contiguous block of the job's frames
     Fr = len(mine)
-    per_rank = len(sharding.shard_frames(F, world, 0))
+    per_rank = sharding.max_shard(F, world)
     enc = hevcdl_amd.Encoder(W, H, qp, max_frames=max(1, per_rank), device=local)
     ctus = enc.ctus
     yuv = synth_frames_torch(torch, dev, W, H, list(mine), seed=1000)
@@ -486,7 +486,7 @@ def main():
             proj = {1: elapsed / a.steps}
             stream = torch.cuda.current_stream().cuda_stream
             for n_gpu in (2, 4, 8):
-                share = len(sharding.shard_frames(F, n_gpu, 0))
+                share = sharding.max_shard(F, n_gpu)
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
                 enc.encode_frames_dev(yuv.data_ptr(), share, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)

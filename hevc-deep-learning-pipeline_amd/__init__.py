@@ -96,21 +96,54 @@ class Profile(ctypes.Structure):
     _fields_ = [("cnn_ms", ctypes.c_double), ("rd_ms", ctypes.c_double), ("cnn_launches", ctypes.c_uint32), ("rd_launches", ctypes.c_uint32), ("cnn_conv_ms", ctypes.c_double)]
 
 
-def build_ext(force=False, verbose=False, defines=(), out=None, extra_flags=()):
-    """Compile every HIP source for gfx950 into lib/libhevcdl_hip.so (hipcc cross-compiles without a GPU)."""
+def _includes(path, seen):
+    """The project-local files `path` includes (transitively): the dependency set of one object."""
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for ln in open(path, encoding="utf-8", errors="replace"):
+        ln = ln.strip()
+        if ln.startswith("#include \""):
+            name = ln.split('"')[1]
+            for d in (os.path.dirname(path), os.path.join(ROOT, "include"), os.path.join(PKG_DIR, "csrc")):
+                if os.path.exists(os.path.join(d, name)):
+                    _includes(os.path.join(d, name), seen)
+                    break
+    return seen
+
+
+def build_ext(force=False, verbose=False, defines=(), out=None, extra_flags=(), jobs=None):
+    """Compile every HIP source for gfx950 into lib/libhevcdl_hip.so (hipcc cross-compiles without a GPU).  One object per source under build/<variant>/,
+    recompiled only when the source or a header it includes is newer, the stale ones in parallel (the decision kernel is three translation units of ~80 s each)."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(PKG_DIR, "csrc", s) for s in SOURCES]
-    deps = srcs + [os.path.join(PKG_DIR, "csrc", "hevcdl_dev.h"), os.path.join(ROOT, "include", "hevcdl.h")]
     out = out or os.path.join(PKG_DIR, "lib", "libhevcdl_hip.so")
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wno-unused-value",
-           "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + ["-D" + d for d in defines] + list(extra_flags) + srcs + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG_DIR, "csrc")] + ["-D" + d for d in defines] + list(extra_flags)
+    import hashlib
+    variant = os.path.splitext(os.path.basename(out))[0] + "-" + hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    odir = os.path.join(PKG_DIR, "build", variant)
+    os.makedirs(odir, exist_ok=True)
+    objs, stale = [], []
+    for src in srcs:
+        obj = os.path.join(odir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _includes(src, set())):
+            stale.append((src, obj))
+    if not stale and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(o) for o in objs):
+        return out
+
+    def compile_one(job):
+        cmd = [hipcc] + flags + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(stale), os.cpu_count() or 1) or 1) as pool:
+        list(pool.map(compile_one, stale))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out], check=True)
     return out
 
 
@@ -126,7 +159,7 @@ def build_app(force=False):
     os.makedirs(os.path.dirname(APP_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     subprocess.run([hipcc, "-O2", "-std=c++17", "-x", "c++", src, "-x", "none", "-I" + os.path.join(ROOT, "include"), "-L" + os.path.dirname(lib), "-lhevcdl_hip",
-                    "-Wl,-rpath,$ORIGIN/../lib", "-pthread", "-o", APP_PATH], check=True)
+                    "-Wl,-rpath,$ORIGIN/../lib", "-pthread", "-ldl", "-o", APP_PATH], check=True)
     return APP_PATH
 
 
@@ -151,6 +184,7 @@ def load_library():
     lib.hevcdl_last_error.restype = ctypes.c_char_p
     lib.hevcdl_predict_depth.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_predict_depth_rgb.argtypes = [vp, vp, ci, vp, vp]
+    lib.hevcdl_labels_from_logits.argtypes = [vp, vp, ci, ci, vp]
     lib.hevcdl_compress_frames.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     lib.hevcdl_predict_depth_planes.argtypes = [vp, vp, ci, vp, vp]
     lib.hevcdl_compress_frames_planes.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -184,7 +218,7 @@ def load_library():
 
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
-           "hevcdl_predict_depth_rgb", "hevcdl_compress_frames", "hevcdl_predict_depth_planes", "hevcdl_compress_frames_planes", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
+           "hevcdl_predict_depth_rgb", "hevcdl_labels_from_logits", "hevcdl_compress_frames", "hevcdl_predict_depth_planes", "hevcdl_compress_frames_planes", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_device_memory", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_encode_pictures_chunked", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5", "hevcdl_write_digest_sei"]
@@ -297,6 +331,15 @@ class Encoder:
         logits = np.zeros((n, self.ctus, 4, 16), np.float32) if want_logits else None
         self._check(self.lib.hevcdl_predict_depth(self._h, yuv.ctypes.data, n, labels.ctypes.data, logits.ctypes.data if want_logits else None))
         return (labels, logits) if want_logits else labels
+
+    def labels_from_logits(self, logits, clamp=False):
+        """logits [n,4,16] float32 -> labels [n,16]: the device's label stage alone (use_model.py:101-119; clamp: + the boundary policy)."""
+        logits = np.ascontiguousarray(logits, np.float32)
+        n = logits.shape[0]
+        assert logits.shape == (n, 4, 16)
+        labels = np.zeros((n, 16), np.uint8)
+        self._check(self.lib.hevcdl_labels_from_logits(self._h, logits.ctypes.data, n, int(bool(clamp)), labels.ctypes.data))
+        return labels
 
     def predict_depth_rgb(self, ctu_rgb):
         ctu_rgb = np.ascontiguousarray(ctu_rgb, np.uint8).reshape(-1, 64, 64, 3)

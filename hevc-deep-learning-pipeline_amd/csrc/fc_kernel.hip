@@ -54,6 +54,11 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
   const int n_rows = p.n_ctus * 4, row0 = blockIdx.x * 64;
   const float GLB *W = (const float GLB *)p.weights;
 
+  if (p.logits_in) {       // label stage alone (hevcdl_labels_from_logits): the caller's logits take the place of fc3's
+    if (row0 + (tid >> 2) < n_rows)
+#pragma unroll
+      for (int j = 0; j < 4; j++) sm.s.lg[tid >> 2][4 * (tid & 3) + j] = ((const float GLB *)p.logits_in)[(size_t)(row0 + (tid >> 2)) * 16 + 4 * (tid & 3) + j];
+  } else {
   { // ---- fc1 ----------------------------------------------------------------------------------------------------
     // B: [k-step of 32][N-tile of 16][hi | lo][64 lanes] x 16 bytes (8 halves: k = 32 * step + 8 * (lane >> 4) + j, n = 16 * tile + (lane & 15))
     const u4 GLB *W1 = (const u4 GLB *)(W + HEVCDL_W_FC1) + lane + (size_t)(4 * wave) * 128;
@@ -142,6 +147,7 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
       sm.s.lg[row][i16] = v[r];
       if (p.logits && row0 + row < n_rows) ((float GLB *)p.logits)[(size_t)(row0 + row) * 16 + i16] = v[r];
     }
+  }
   }
   __syncthreads();
 

@@ -356,6 +356,7 @@ static hevcdl_status launch_cnn(hevcdl_ctx *ctx, const void *d_in, int mode, int
   if (ctx->a3_ctus < chunk) { hipFree(ctx->d_a3); ctx->d_a3 = nullptr; ctx->a3_ctus = 0; HIPCHK(hipMalloc(&ctx->d_a3, chunk * 4 * 2048 * sizeof(float))); ctx->a3_ctus = chunk; }
   p.a3 = ctx->d_a3; p.n_cus = ctx->n_cus; p.bn_eval = ctx->cfg.bn_mode == HEVCDL_BN_EVAL;
   hevcdl_fc_params f;
+  f.logits_in = nullptr;
   f.a3 = ctx->d_a3; f.weights = ctx->d_weights; f.width = p.width; f.height = p.height; f.ctus_x = p.ctus_x; f.ctus_per_frame = p.ctus_per_frame; f.clamp = clamp;
   prof_begin(ctx, ctx->ev_cnn, s);
   for (size_t base = 0; base < (size_t)n_ctus; base += chunk) {
@@ -642,6 +643,29 @@ extern "C" hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t
     if (logits_opt) hipMemcpy(logits_opt, d_lg, (size_t)n_ctus * 64 * sizeof(float), hipMemcpyDeviceToHost);
   }
   hipFree(d_in); hipFree(d_lab); hipFree(d_lg);
+  return st;
+}
+
+extern "C" hevcdl_status hevcdl_labels_from_logits(hevcdl_ctx *ctx, const float *logits, int n_ctus, int clamp, uint8_t *labels)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  if (n_ctus < 0) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "n_ctus < 0");
+  if (n_ctus == 0) return HEVCDL_OK;
+  if (!logits || !labels) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
+  HIPCHK(hipSetDevice(ctx->cfg.device));
+  uint8_t *d_lab = nullptr; float *d_lg = nullptr;
+  hipError_t e0 = hipMalloc(&d_lab, (size_t)n_ctus * 16);
+  if (e0 == hipSuccess) e0 = hipMalloc(&d_lg, (size_t)n_ctus * 64 * sizeof(float));
+  if (e0 == hipSuccess) e0 = hipMemcpy(d_lg, logits, (size_t)n_ctus * 64 * sizeof(float), hipMemcpyHostToDevice);
+  if (e0 != hipSuccess) { hipFree(d_lab); hipFree(d_lg); return fail(ctx, e0 == hipErrorOutOfMemory ? HEVCDL_ERR_OOM : HEVCDL_ERR_HIP, "labels_from_logits buffers", e0); }
+  hevcdl_fc_params f;
+  f.a3 = nullptr; f.weights = ctx->d_weights; f.labels = d_lab; f.logits = nullptr; f.logits_in = d_lg;
+  f.n_ctus = n_ctus; f.ctu_base = 0; f.width = ctx->cfg.width; f.height = ctx->cfg.height; f.ctus_x = ctx->ctus_x; f.ctus_per_frame = ctx->ctus; f.clamp = clamp ? 1 : 0;
+  hipLaunchKernelGGL(hevcdl_fc_kernel, dim3((n_ctus + 15) / 16), dim3(256), hevcdl_fc_smem_bytes(), nullptr, f);
+  hipError_t e = hipDeviceSynchronize();
+  hevcdl_status st = e == hipSuccess ? HEVCDL_OK : fail(ctx, HEVCDL_ERR_HIP, "label kernel", e);
+  if (st == HEVCDL_OK) hipMemcpy(labels, d_lab, (size_t)n_ctus * 16, hipMemcpyDeviceToHost);
+  hipFree(d_lab); hipFree(d_lg);
   return st;
 }
 

@@ -279,7 +279,7 @@ int main(int argc, char **argv)
   const bool multi = devices.size() > 1;
   bool shared_device = false;
   for (size_t i = 0; i < devices.size(); i++) for (size_t j = 0; j < i; j++) if (devices[i] == devices[j]) shared_device = true;
-  const long per_shard = (n_frames + n_shards - 1) / n_shards;                // sharding.shard_frames: contiguous blocks of ceil(n / shards) frames
+  const long per_shard = (n_frames + n_shards - 1) / n_shards;                // the largest block: sharding.shard_frames deals contiguous blocks [i * n / shards, (i + 1) * n / shards), none empty
   // Pictures per device call.  A frame is a serial chain of CTUs: a call costs about the same from 1 to ~250 pictures and grows slowly beyond (the decision kernel
   // keeps one workgroup per CU busy with 1..8 pictures), so the default is a device's whole share, bounded by the 2048 (picture, tile) units the GPU holds, by 24 GiB
   // of originals on the host and by the DEVICE's free memory: a picture of a call occupies 3 frame buffers (original, reconstruction, filtered picture), its CTU
@@ -288,8 +288,9 @@ int main(int argc, char **argv)
   const int ctus = hevcdl_ctus_per_frame(width, height);
   const long per_picture_dev = 3 * (long)frame_bytes + (long)ctus * ((long)sizeof(hevcdl_ctu_record) + 16 + 256 + 3 * 140) + (2L << 20);
   long dev_cap = 2048;
-  { size_t free_b = 0, total_b = 0;
-    if (hevcdl_device_memory(devices[0], &free_b, &total_b) == HEVCDL_OK && free_b > 0) dev_cap = std::max<long>(1, (long)((double)free_b * 0.8 / (shared_device ? (double)devices.size() : 1.0)) / per_picture_dev); }
+  { size_t free_b = 0, total_b = 0;       // the smallest free memory over the devices named: every shard's batch is sized from it
+    for (size_t i = 0; i < devices.size(); i++) { size_t f = 0, t = 0; if (hevcdl_device_memory(devices[i], &f, &t) == HEVCDL_OK && f > 0 && (free_b == 0 || f < free_b)) { free_b = f; total_b = t; } }
+    if (free_b > 0) dev_cap = std::max<long>(1, (long)((double)free_b * 0.8 / (shared_device ? (double)devices.size() : 1.0)) / per_picture_dev); }
   const long auto_batch = std::max<long>(1, std::min<long>(std::min<long>(2048 / (tile_cols * tile_rows), dev_cap), (24L << 30) / (long)frame_bytes));
   const long even_batch = (per_shard + ((per_shard + auto_batch - 1) / auto_batch) - 1) / ((per_shard + auto_batch - 1) / auto_batch);
   int batch = (int)std::min<long>(per_shard, std::max<long>(1, opt.geti("BatchFrames", even_batch)));
@@ -326,7 +327,7 @@ int main(int argc, char **argv)
   };
   enum { ROW = 8 };
   std::vector<Shard> shards(n_shards);
-  for (int i = 0; i < n_shards; i++) { shards[i].dev = devices[i]; shards[i].f_lo = std::min<long>(n_frames, i * per_shard); shards[i].f_hi = std::min<long>(n_frames, (i + 1) * per_shard); }
+  for (int i = 0; i < n_shards; i++) { shards[i].dev = devices[i]; shards[i].f_lo = (long)i * n_frames / n_shards; shards[i].f_hi = (long)(i + 1) * n_frames / n_shards; }
   for (int i = 0; i < n_shards; i++) { // contexts: created one after the other (a refused allocation halves the batch of every shard)
     for (;;) {
       cfg.max_frames = batch; cfg.device = shards[i].dev;
@@ -521,7 +522,8 @@ int main(int argc, char **argv)
       if ((long)rows.size() != n_frames) { fprintf(stderr, "Error: %zu rows gathered for %ld pictures\n", rows.size(), n_frames); rc = 3; }
       for (size_t r = 0; r < rows.size() && rc == 0; r++) { // POC order: blocks are contiguous, so this is the blocks one after the other
         const long poc = (long)rows[r][0];
-        const Shard &S = shards[std::min<long>(n_shards - 1, poc / per_shard)];
+        int si = 0; while (si + 1 < n_shards && poc >= shards[si].f_hi) si++;
+        const Shard &S = shards[si];
         const size_t li = (size_t)(poc - S.f_lo);
         if (fbits) fwrite(S.aus[li].data(), 1, S.aus[li].size(), fbits);
         log_picture(poc, rows[r][1], rows[r] + 2, (double)rows[r][6] * 1e-9, S.md5[li].c_str());

@@ -65,6 +65,7 @@ struct hevcdl_fc_params {
   uint8_t *labels;                 // [n_ctus][16] of this launch
   float *logits;                   // [n_ctus][4][16] of this launch, or NULL
   int n_ctus, ctu_base, width, height, ctus_x, ctus_per_frame, clamp;
+  const float *logits_in;          // not NULL: skip the three layers and label these logits [n_ctus][4][16] (hevcdl_labels_from_logits)
 };
 
 // decision constants (bit patterns computed on the host, see include/hevcdl.h)

@@ -52,7 +52,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     mine = sharding.shard_frames(n_frames, world, rank)
-    per_rank = len(sharding.shard_frames(n_frames, world, 0))
+    per_rank = sharding.max_shard(n_frames, world)
     rows = np.full((per_rank + 1, 5), -1, np.int64)
     part_bits = (bitstream_path + ".part%d" % rank) if bitstream_path else None
     part_rec = (recon_path + ".part%d" % rank) if recon_path else None

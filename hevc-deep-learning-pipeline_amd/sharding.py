@@ -25,9 +25,14 @@ REC_BYTES = 15120                      # sizeof(hevcdl_ctu_record)
 
 
 def shard_frames(n_frames, world, rank):
-    """Contiguous frame ranges (better for file reads than a stride)."""
-    per = (n_frames + world - 1) // world
-    return range(min(n_frames, rank * per), min(n_frames, (rank + 1) * per))
+    """Contiguous frame ranges (better for file reads than a stride): rank r takes [r * n / world, (r + 1) * n / world) -- sizes differ by at most one and no
+    rank is empty while world <= n_frames (blocks of ceil(n / world) left trailing ranks without a frame: 5 frames on 4 ranks, 9 on 8)."""
+    return range(rank * n_frames // world, (rank + 1) * n_frames // world)
+
+
+def max_shard(n_frames, world):
+    """Frames of the largest block shard_frames deals: what per-rank buffers and gather rows are sized for."""
+    return (n_frames + world - 1) // world
 
 
 def shard_tiles(n_tiles, world, rank):

@@ -145,6 +145,10 @@ hevcdl_status hevcdl_predict_depth(hevcdl_ctx *ctx, const uint8_t *yuv, int n_fr
 /* Fixture entry: n_ctus RGB CTUs [n][64][64][3] (the tensor the reference feeds ConvNet2) -> raw labels
  * (use_model.py:101-119, no clamping) and logits[n][4][16]. */
 hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t *ctu_rgb, int n_ctus, uint8_t *labels, float *logits_opt);
+/* The label stage alone: logits[n_ctus][4][16] (the four forwards of a CTU, use_model.py:100) -> labels[n_ctus][16] by the 4x argmax and the
+ * fix-ups of use_model.py:101-119, run by the same device code that follows the fully connected head.  clamp != 0 also applies the boundary
+ * policy, taking CTU i as CTU (i mod ctus-per-frame) of the context's picture. */
+hevcdl_status hevcdl_labels_from_logits(hevcdl_ctx *ctx, const float *logits, int n_ctus, int clamp, uint8_t *labels);
 /* Replaces the compressCtu loop of TEncSlice::compressSlice for n_frames independent frames.
  * labels_opt == NULL -> labels come from the on-device CNN.  recon_opt / stats_opt may be NULL. */
 hevcdl_status hevcdl_compress_frames(hevcdl_ctx *ctx, const uint8_t *yuv, int n_frames, const uint8_t *labels_opt,

@@ -182,9 +182,8 @@ def clamp_labels(labels, width, height):
     return out.reshape(np.shape(labels))
 
 
-def yuv_to_rgb_ctus(yuv_frame, width, height, mode="rgb601"):
-    """One planar 8-bit 4:2:0 frame -> [ctus,64,64,3] uint8 RGB CTUs in raster order, zero-filled past the
-    picture edge (PIL crop semantics, use_model.py:92-93).
+def yuv_to_rgb_picture(yuv_frame, width, height, mode="rgb601"):
+    """One planar 8-bit 4:2:0 frame -> [height, width, 3] uint8 RGB: this project's input transform (the reference's own is ffmpeg -> JPEG -> PIL, unpinned).
     mode 'rgb601': BT.601 limited-range integer conversion, nearest-neighbour chroma:
         C=Y-16, D=U-128, E=V-128; R=clip((298C+409E+128)>>8), G=clip((298C-100D-208E+128)>>8), B=clip((298C+516D+128)>>8)
     mode 'luma': R=G=B=Y."""
@@ -201,11 +200,22 @@ def yuv_to_rgb_ctus(yuv_frame, width, height, mode="rgb601"):
         G = (298 * C - 100 * D - 208 * E + 128) >> 8
         B = (298 * C + 516 * D + 128) >> 8
         rgb = np.stack([R, G, B], axis=-1)
-    rgb = np.clip(rgb, 0, 255).astype(np.uint8)
+    return np.clip(rgb, 0, 255).astype(np.uint8)
+
+
+def rgb_picture_to_ctus(rgb):
+    """The tiling of use_model.py:80-95: [height, width, 3] uint8 -> [ctus,64,64,3] CTUs in raster order (ceil(w/64) per row, :80,:86-87), what lies past the
+    picture edge zero-filled (PIL's img.crop beyond the picture, :91-92).  Pinned by tests/golden/cnn_f3.npz (the reference's loop itself on whole pictures)."""
+    height, width = rgb.shape[:2]
     cx, cy = (width + 63) // 64, (height + 63) // 64
     pad = np.zeros((cy * 64, cx * 64, 3), np.uint8)
     pad[:height, :width] = rgb
     return pad.reshape(cy, 64, cx, 64, 3).transpose(0, 2, 1, 3, 4).reshape(cy * cx, 64, 64, 3)
+
+
+def yuv_to_rgb_ctus(yuv_frame, width, height, mode="rgb601"):
+    """One planar 8-bit 4:2:0 frame -> RGB CTUs: the input transform, then the reference's tiling."""
+    return rgb_picture_to_ctus(yuv_to_rgb_picture(yuv_frame, width, height, mode))
 
 
 def predict_labels(w, yuv_frames, width, height, mode="rgb601", clamp=True):

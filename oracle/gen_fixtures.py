@@ -170,6 +170,41 @@ def gen_weights(sd):
     print("weights:", off, "floats,", len(tensors), "tensors")
 
 
+def ref_label_fn(src):
+    """Label post-processing through the reference's own lines (use_model.py:101-119), driven with given outputs: -> f(logits [4,16]) -> 16 labels."""
+    import torch
+    lines = src.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.strip().startswith("pred = str(int(torch.argmax"))
+    end = next(i for i, l in enumerate(lines) if "label[10],label[11],label[14],label[15]" in l)
+    body = "\n".join(l[16:] if len(l) > 16 else l.strip() for l in lines[start:end + 1])
+    code = compile(body, "use_model_101_119", "exec")
+
+    def ref_labels(lg4):                           # lg4 [4,16] logits
+        label = [str(i) for i in range(16)]
+        for layer2 in range(4):
+            ns = {"torch": torch, "output": torch.from_numpy(lg4[layer2:layer2 + 1].copy()), "layer2": layer2, "label": label}
+            exec(code, ns)
+        return [int(v) for v in label]
+    return ref_labels
+
+
+def gen_cnn_label_chain(src):
+    """F-cnn-2, second set: uniformly random digits make a quadrant '0000' once in 256, so the `pred == "0000" and label[..] != "0"` chain of
+    use_model.py:111-119 is hardly walked by cnn_f2.npz (43 of 10 000 sets start with label 0).  Here every quadrant is '0000' with probability 1/2, otherwise
+    random digits: 20 000 tuples, half of the sets start with 0, all 16 zero / non-zero patterns of the four quadrants occur ~1 250 times each."""
+    rng = np.random.default_rng(4321)
+    ref_labels = ref_label_fn(src)
+    m = 20000
+    digits = rng.integers(0, 4, (m, 4, 4))
+    digits[rng.integers(0, 2, (m, 4)) == 1] = 0
+    fake = np.zeros((m, 4, 16), np.float32)
+    for k in range(4):
+        fake[:, :, 4 * k:4 * k + 4] = np.eye(4, dtype=np.float32)[digits[:, :, k]]
+    lab = np.array([ref_labels(fake[i]) for i in range(m)], np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "cnn_f2b.npz"), digits=digits.astype(np.uint8), labels=lab)
+    print("cnn label-chain fixture:", m, "tuples; first label 0 in", int((lab[:, 0] == 0).sum()), "; label histogram", np.bincount(lab.ravel(), minlength=4))
+
+
 def gen_cnn(model, src):
     import torch
     rng = np.random.default_rng(1234)
@@ -208,20 +243,7 @@ def gen_cnn(model, src):
             for q in range(4):
                 ox, oy = (q % 2) * 32, (q // 2) * 32
                 logits[i, q] = model(x[:, oy:oy + 32, ox:ox + 32].unsqueeze(0).contiguous(), x.unsqueeze(0))[0].numpy()
-    # label post-processing through the reference's own lines (use_model.py:101-119), driven with fake outputs
-    lines = src.splitlines()
-    start = next(i for i, l in enumerate(lines) if l.strip().startswith("pred = str(int(torch.argmax"))
-    end = next(i for i, l in enumerate(lines) if "label[10],label[11],label[14],label[15]" in l)
-    body = "\n".join(l[16:] if len(l) > 16 else l.strip() for l in lines[start:end + 1])
-    code = compile(body, "use_model_101_119", "exec")
-
-    def ref_labels(lg4):                           # lg4 [4,16] logits
-        label = [str(i) for i in range(16)]
-        for layer2 in range(4):
-            ns = {"torch": torch, "output": torch.from_numpy(lg4[layer2:layer2 + 1].copy()), "layer2": layer2, "label": label}
-            exec(code, ns)
-        return [int(v) for v in label]
-
+    ref_labels = ref_label_fn(src)
     labels = np.array([ref_labels(logits[i]) for i in range(n)], np.uint8)
     np.savez_compressed(os.path.join(GOLD, "cnn_f1.npz"), ctu_rgb=ctus, logits=logits, labels=labels)
     m = 10000                                      # F-cnn-2: >= 10 000 tuples
@@ -232,6 +254,84 @@ def gen_cnn(model, src):
     lab2 = np.array([ref_labels(fake[i]) for i in range(m)], np.uint8)
     np.savez_compressed(os.path.join(GOLD, "cnn_f2.npz"), digits=digits.astype(np.uint8), labels=lab2)
     print("cnn fixtures:", n, "CTUs,", m, "label tuples; label histogram", np.bincount(labels.ravel(), minlength=4))
+
+
+def gen_cnn_pictures(model, src):
+    """F-cnn-3: whole pictures through the reference's OWN frame loop -- use_model.py from `total_frames = ...` to the end of
+    the file (lines 72-125: CTU count :80, raster order :86-87, quadrant origin :89-90, img.crop beyond the picture :91-92, ToTensor :93-94, the four
+    forwards, argmax + fix-ups :101-119, one label file per CTU :121-125), exec()'d as it stands.  What the namespace supplies instead of the files the
+    loop expects: `Image.open` hands back an in-memory PIL picture (the JPEG the reference reads is a lossy copy of exactly such a picture),
+    `transforms.ToTensor` is torchvision's published rule for 8-bit RGB PIL pictures (HWC uint8 -> CHW float32 / 255; torchvision is not installed here),
+    `model` records every output it returns; `os` is the real module in a scratch directory, so the label files are the loop's own.  Stored: the pictures,
+    the labels read back from pred/<frame>/ctu<i>.txt and the logits of every (CTU, quadrant) forward.  Sizes: 416x240 (C1) and 200x136, both ragged on
+    both edges; one colour and one grey picture each (a grey one can also enter the product's frame path through HEVCDL_CNN_INPUT_LUMA sample for sample)."""
+    import tempfile
+    import torch
+    from PIL import Image as PILImage
+    pics = []
+    for w, h, seed in ((416, 240, 501), (200, 136, 502)):
+        yuv = rt.synth_yuv(w, h, 1, seed)[0]
+        import cnn_oracle
+        rgb = cnn_oracle.yuv_to_rgb_picture(yuv, w, h, "rgb601")
+        rng = np.random.default_rng(seed)
+        rgb = np.clip(rgb.astype(np.int32) + rng.integers(-6, 7, rgb.shape), 0, 255).astype(np.uint8)      # decorrelate the three channels a little
+        grey = np.repeat(yuv[:w * h].reshape(h, w)[..., None], 3, axis=2).astype(np.uint8)
+        pics += [rgb, grey]
+    lines = src.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("total_frames = "))
+    code = compile("\n".join(lines[start:]), "use_model_72_125", "exec")
+    recorded = []
+
+    class Recorder:
+        def __call__(self, a, b):
+            out = model(a, b)
+            recorded.append(out[0].detach().numpy().copy())
+            return out
+
+    class ImageShim:
+        @staticmethod
+        def open(path):
+            n = int(re.search(r"(\d+)\.jpg$", path).group(1))
+            return PILImage.fromarray(pics[n - 1], "RGB")
+
+    class ToTensorShim:
+        def __call__(self, pic):
+            a = np.array(pic, np.uint8, copy=True)
+            assert a.ndim == 3 and a.shape[2] == 3
+            return torch.from_numpy(a).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    class TransformsShim:
+        ToTensor = ToTensorShim
+
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="cnnf3_")
+    try:
+        os.chdir(tmp)
+        os.makedirs("rec/frames")
+        os.mkdir("pred")
+        for n in range(len(pics)):
+            open("rec/frames/%d.jpg" % (n + 1), "wb").close()          # the loop counts and removes these; it never reads them (Image.open is the shim)
+        import math
+        ns = {"torch": torch, "os": os, "math": math, "Image": ImageShim, "transforms": TransformsShim, "model": Recorder(),
+              "DEVICE": torch.device("cpu"), "frame_tobe_encoded": str(len(pics))}
+        exec(code, ns)
+        out = {}
+        pos = 0
+        for n, pic in enumerate(pics):
+            h, w = pic.shape[:2]
+            nctu = ((w + 63) // 64) * ((h + 63) // 64)
+            lab = np.array([[int(v) for v in open("pred/%d/ctu%d.txt" % (n, i)).read().split()] for i in range(nctu)], np.uint8)
+            assert lab.shape == (nctu, 16) and not os.path.exists("rec/frames/%d.jpg" % (n + 1))
+            out["rgb%d" % n], out["labels%d" % n] = pic, lab
+            out["logits%d" % n] = np.array(recorded[pos:pos + 4 * nctu], np.float32).reshape(nctu, 4, 16)
+            pos += 4 * nctu
+        assert pos == len(recorded)
+    finally:
+        os.chdir(cwd)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(GOLD, "cnn_f3.npz"), n_pictures=len(pics), **out)
+    print("cnn picture fixture:", [(out["rgb%d" % n].shape, np.bincount(out["labels%d" % n].ravel(), minlength=4).tolist()) for n in range(len(pics))])
 
 
 def gen_full():
@@ -312,7 +412,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
     if "stage" in what:
         gen_stage_traces()
     if "rd" in what:
@@ -331,6 +431,11 @@ if __name__ == "__main__":
             gen_cnn(model, src)
     if "cnneval" in what:
         gen_cnn_eval()
+    if "cnnpic" in what:
+        model, sd, src = load_ref_model()
+        gen_cnn_pictures(model, src)
+    if "cnnchain" in what:
+        gen_cnn_label_chain(load_ref_model()[2])
     if "bd" in what:
         gen_bd()
     if "full" in what:

@@ -137,7 +137,7 @@ def test_cli_encode_matches_the_api(app, tmp_path):
 def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp_path):
     """--Devices: contiguous blocks of frames, one host thread and one context per entry, the per-picture rows (POC, bits, squared errors) gathered with
     ncclAllGather from librccl, access units written in POC order.  Two entries naming the SAME device (what one GPU can test: two contexts side by side, the
-    library then keeps them from waiting on each other; RCCL runs with one rank per physical device) and three entries for five frames (uneven blocks) must give
+    library then keeps them from waiting on each other; RCCL runs with one rank per physical device) and three, four and seven entries for five frames (uneven blocks; more entries than frames) must give
     the single-device bitstream, reconstruction file, record file, log lines and summary byte for byte."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -146,7 +146,7 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
     ref_tools.synth_yuv(w, h, nf, seed=77).tofile(tmp_path / "in.yuv")
     base = ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "--SEIDecodedPictureHash=1"]
     outs = []
-    for tag, extra in (("one", []), ("two", ["--Devices=0,0"]), ("three", ["--Devices", "0,0,0", "--BatchFrames=1"])):
+    for tag, extra in (("one", []), ("two", ["--Devices=0,0"]), ("three", ["--Devices", "0,0,0", "--BatchFrames=1"]), ("four", ["--Devices", "0,0,0,0"]), ("seven", ["--Devices", "0,0,0,0,0,0,0"])):
         r = run(app, base + ["-b", tag + ".bin", "-o", tag + ".yuv", "--RecordFile=" + tag + ".rec"] + extra, tmp_path)
         assert r.returncode == 0, r.stdout + r.stderr
         log = [l.rsplit(" [ET", 1)[0] + l[l.index("[MD5:"):] for l in r.stdout.splitlines() if l.startswith("POC")]
@@ -156,7 +156,11 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
     for o in outs[1:]:
         for k in range(5):
             assert o[k] == outs[0][k], k
-    assert "Devices: 0 (frames 0..2) 0 (frames 3..4)" in outs[1][5] and "Devices: 0 (frames 0..1) 0 (frames 2..3) 0 (frames 4..4)" in outs[2][5]
+    # blocks [i * n / shards, (i + 1) * n / shards): none empty (blocks of ceil(5 / 4) = 2 frames left the fourth entry without a frame and divided by its
+    # batch of zero); more entries than frames: one frame each, the surplus entries unused
+    assert "Devices: 0 (frames 0..1) 0 (frames 2..4)" in outs[1][5] and "Devices: 0 (frames 0..0) 0 (frames 1..2) 0 (frames 3..4)" in outs[2][5]
+    assert "Devices: 0 (frames 0..0) 0 (frames 1..1) 0 (frames 2..2) 0 (frames 3..4)" in outs[3][5]
+    assert "Devices: 0 (frames 0..0) 0 (frames 1..1) 0 (frames 2..2) 0 (frames 3..3) 0 (frames 4..4)\n" in outs[4][5]
 
 
 @pytest.mark.gpu

@@ -96,3 +96,68 @@ def test_frame_input_modes_equal_the_rgb_ctu_path_on_the_same_samples(mode, cnn_
         r_labels, r_logits = e.predict_depth_rgb(ctus)
         assert np.array_equal(logits[f].reshape(r_logits.shape), r_logits)
     e.close()
+
+
+def test_whole_pictures_give_the_label_files_of_the_reference_loop():
+    """F-cnn-3 on the device (tests/golden/cnn_f3.npz: whole 416x240 / 200x136 pictures through use_model.py:72-125 itself).  (a) every picture cut by the
+    oracle's tiling and handed to the kernel as RGB CTUs: logits within the tolerance, label files exact outside the gap band; (b) the grey pictures also
+    through the product's own FRAME path (HEVCDL_CNN_INPUT_LUMA puts R = G = B = Y into the tiles, i.e. sample for sample what the reference loop cropped):
+    the kernel's tile fill -- CTU raster order, quadrant origins, zero fill past the right and bottom edge -- against the reference loop itself, labels ==
+    the reference's label files after this project's boundary clamp."""
+    import cnn_oracle
+    import hevcdl_amd
+    f = np.load(os.path.join(GOLD, "cnn_f3.npz"))
+    e = hevcdl_amd.Encoder(128, 128, 32, max_frames=1)
+    for n in range(int(f["n_pictures"])):
+        ref_lab, ref_lg = f["labels%d" % n], f["logits%d" % n]
+        labels, logits = e.predict_depth_rgb(cnn_oracle.rgb_picture_to_ctus(f["rgb%d" % n]))
+        assert np.abs(logits - ref_lg).max() < LOGIT_TOL
+        srt = np.sort(ref_lg.reshape(-1, 4, 4, 4), axis=-1)
+        safe = ((srt[..., -1] - srt[..., -2]) > 1e-2).all(axis=(1, 2))
+        assert safe.sum() >= len(ref_lab) // 2
+        assert np.array_equal(labels[safe], ref_lab[safe])
+    e.close()
+    for n in (1, 3):                                   # the grey pictures
+        rgb = f["rgb%d" % n]
+        h_, w_ = rgb.shape[:2]
+        assert np.array_equal(rgb[..., 0], rgb[..., 1]) and np.array_equal(rgb[..., 0], rgb[..., 2])
+        yuv = np.concatenate([rgb[..., 0].reshape(-1), np.full(w_ * h_ // 2, 128, np.uint8)])[None]
+        e = hevcdl_amd.Encoder(w_, h_, 32, max_frames=1, cnn_input=1)
+        labels, logits = e.predict_depth(yuv, want_logits=True)
+        e.close()
+        ref_lab, ref_lg = f["labels%d" % n], f["logits%d" % n]
+        assert np.abs(logits[0] - ref_lg).max() < LOGIT_TOL
+        srt = np.sort(ref_lg.reshape(-1, 4, 4, 4), axis=-1)
+        safe = ((srt[..., -1] - srt[..., -2]) > 1e-2).all(axis=(1, 2))
+        assert np.array_equal(labels[0][safe], cnn_oracle.clamp_labels(ref_lab[None], w_, h_)[0][safe])
+
+
+def _one_hot(d):
+    fake = np.zeros((len(d), 4, 16), np.float32)
+    for k in range(4):
+        fake[:, :, 4 * k:4 * k + 4] = np.eye(4, dtype=np.float32)[d[:, :, k]]
+    return fake
+
+
+def test_label_stage_on_the_device_gives_the_reference_lines_on_30000_tuples(enc):
+    """F-cnn-2 on the device (row a-3): the digit tuples of tests/golden/cnn_f2.npz (10 000 uniformly random: all 256 raw tuples of a quadrant occur) and
+    cnn_f2b.npz (20 000 with every quadrant '0000' half of the time: half of the label sets start with 0, the `pred == "0000" and label[..] != "0"` chain of
+    use_model.py:111-119 in all 16 zero / non-zero patterns) -- labels by the reference's own lines -- as one-hot logits through hevcdl_labels_from_logits,
+    i.e. through the label stage of hevcdl_fc_kernel itself (same code, the fully connected layers skipped).  Exact; and argmax ties go to the first
+    maximum as torch.argmax does."""
+    import cnn_oracle
+    f, g = np.load(os.path.join(GOLD, "cnn_f2.npz")), np.load(os.path.join(GOLD, "cnn_f2b.npz"))
+    assert len(np.unique(f["digits"].reshape(-1, 4) @ np.array([64, 16, 4, 1]))) == 256
+    assert 0.4 < (g["labels"][:, 0] == 0).mean() < 0.6
+    zero_pat = (g["digits"].reshape(-1, 4, 4).max(axis=2) == 0) @ np.array([8, 4, 2, 1])
+    assert len(np.unique(zero_pat)) == 16
+    for fx in (f, g):
+        fake = _one_hot(fx["digits"])
+        assert np.array_equal(enc.labels_from_logits(fake), fx["labels"])
+        # other values, same order: only the order matters
+        assert np.array_equal(enc.labels_from_logits(fake * 7.5 - 30.0), fx["labels"])
+    ties = np.zeros((4, 4, 16), np.float32)
+    ties[1][:, [1, 2]] = 3.0
+    ties[2][:, [3, 0]] = 1.0
+    ties[3][:, 2:4] = 2.0
+    assert np.array_equal(enc.labels_from_logits(ties), cnn_oracle.labels_from_logits(ties))

@@ -128,6 +128,33 @@ def test_cnn_oracle_eval_mode_matches_reference_model_in_eval_mode():
     assert np.array_equal(cnn_oracle.labels_from_logits(g["logits"]), g["labels"])
 
 
+def test_cnn_oracle_tiles_and_labels_whole_pictures_like_the_reference_loop():
+    """F-cnn-3: tests/golden/cnn_f3.npz = whole 416x240 and 200x136 pictures through the reference's own frame loop
+    (use_model.py:72-125 exec'd by oracle/gen_fixtures.py gen_cnn_pictures: CTU count and raster order :80-87, quadrant origins :89-90, img.crop past the
+    picture edge :91-92, ToTensor :93-94, four forwards, label files).  The oracle's tiling (rgb_picture_to_ctus: zero fill) + CNN + label rules must give
+    the logits of every (CTU, quadrant) forward and the label file of every CTU.  The 200x136 pictures run whole (ragged right and bottom, 12 CTUs each);
+    of the 416x240 ones the right column and the bottom row (ragged CTUs) plus two inner CTUs, to keep the numpy CNN within seconds."""
+    import cnn_oracle
+    import hevcdl_amd
+    f = np.load(os.path.join(GOLD, "cnn_f3.npz"))
+    w = cnn_oracle.load_weights(hevcdl_amd.WEIGHTS_PATH)
+    assert int(f["n_pictures"]) == 4
+    for n in range(4):
+        rgb = f["rgb%d" % n]
+        ctus = cnn_oracle.rgb_picture_to_ctus(rgb)
+        assert len(ctus) == len(f["labels%d" % n])
+        cx = (rgb.shape[1] + 63) // 64
+        pick = np.arange(len(ctus)) if len(ctus) <= 12 else np.array(sorted(set([0, cx + 1] + list(range(cx - 1, len(ctus), cx)) + list(range(len(ctus) - cx, len(ctus))))))
+        lg = cnn_oracle.ctu_logits(w, ctus[pick])
+        assert np.abs(lg - f["logits%d" % n][pick]).max() < 1e-4
+        # labels: the rules on the REFERENCE's logits must give the reference's files on every CTU; on the oracle's own logits wherever no argmax is within the band
+        assert np.array_equal(cnn_oracle.labels_from_logits(f["logits%d" % n]), f["labels%d" % n])
+        srt = np.sort(f["logits%d" % n][pick].reshape(-1, 4, 4, 4), axis=-1)
+        safe = ((srt[..., -1] - srt[..., -2]) > 1e-3).all(axis=(1, 2))
+        assert safe.sum() >= len(pick) // 2
+        assert np.array_equal(cnn_oracle.labels_from_logits(lg)[safe], f["labels%d" % n][pick][safe])
+
+
 def test_label_postprocessing_matches_reference_lines():
     import cnn_oracle
     f = np.load(os.path.join(GOLD, "cnn_f2.npz"))
@@ -135,6 +162,11 @@ def test_label_postprocessing_matches_reference_lines():
     for k in range(4):
         fake[:, :, 4 * k:4 * k + 4] = np.eye(4, dtype=np.float32)[f["digits"][:, :, k]]
     assert np.array_equal(cnn_oracle.labels_from_logits(fake), f["labels"])
+    g = np.load(os.path.join(GOLD, "cnn_f2b.npz"))          # every quadrant '0000' half of the time: the chain of use_model.py:111-119
+    fake = np.zeros((len(g["digits"]), 4, 16), np.float32)
+    for k in range(4):
+        fake[:, :, 4 * k:4 * k + 4] = np.eye(4, dtype=np.float32)[g["digits"][:, :, k]]
+    assert np.array_equal(cnn_oracle.labels_from_logits(fake), g["labels"])
 
 
 def walk_is_valid(lab, x0, y0, w, h):

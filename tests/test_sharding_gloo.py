@@ -13,10 +13,8 @@ import torch.multiprocessing as tmp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def shard_frames(n_frames, world, rank):
-    """Contiguous frame ranges (better for file reads)."""
-    per = (n_frames + world - 1) // world
-    return range(min(n_frames, rank * per), min(n_frames, (rank + 1) * per))
+sys.path.insert(0, ROOT)
+from hevcdl_amd.sharding import max_shard, shard_frames        # the product's own dealing, not a copy of it  # noqa: E402
 
 
 def _worker(rank, world, port, n_frames, q):
@@ -31,13 +29,14 @@ def _worker(rank, world, port, n_frames, q):
     labels = ref_tools.make_labels(w, h, n_frames, "rand", 78)
     mine = list(shard_frames(n_frames, world, rank))
     recs, recon, stats = ref_tools.run_oracle(yuv[mine], w, h, qp, labels[mine])
-    rec = torch.zeros((len(shard_frames(n_frames, world, 0)), 5), dtype=torch.int64)     # poc, bits, sseY, sseU, sseV
+    rec = torch.full((max_shard(n_frames, world), 5), -1, dtype=torch.int64)     # poc, bits, sseY, sseU, sseV
     for i, f in enumerate(mine):
         rec[i] = torch.tensor([f, int(stats["est_bits"][i])] + [int(v) for v in stats["sse"][i]])
     out = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
     dist.gather(rec, out, dst=0)
     if rank == 0:
-        allrec = torch.cat(out)[:n_frames].numpy()
+        allrec = torch.cat(out)
+        allrec = allrec[allrec[:, 0] >= 0].numpy()              # padding rows of the shorter blocks dropped
         _, _, full = ref_tools.run_oracle(yuv, w, h, qp, labels)
         q.put((allrec.tolist(), [[i, int(full["est_bits"][i])] + [int(v) for v in full["sse"][i]] for i in range(n_frames)]))
     dist.barrier()
@@ -48,7 +47,7 @@ def test_frame_sharding_gather_world2(oracle_built):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = tmp.get_context("spawn")
     q = ctx.Queue()
-    n_frames = 4
+    n_frames = 5                             # uneven: blocks of 2 and 3 frames
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -60,10 +59,13 @@ def test_frame_sharding_gather_world2(oracle_built):
 
 
 def test_shard_ranges_cover_every_frame_once():
-    for n in (1, 7, 75, 600):
+    for n in (1, 5, 7, 9, 75, 600):
         for world in (1, 2, 4, 8):
-            seen = [f for r in range(world) for f in shard_frames(n, world, r)]
-            assert seen == list(range(n))
+            blocks = [shard_frames(n, world, r) for r in range(world)]
+            assert [f for b in blocks for f in b] == list(range(n))
+            assert max(len(b) for b in blocks) == max_shard(n, world)
+            if world <= n:                   # no rank without a frame (5 frames on 4 ranks, 9 on 8: blocks of ceil(n / world) left the last rank empty)
+                assert min(len(b) for b in blocks) >= 1 and max(len(b) for b in blocks) - min(len(b) for b in blocks) <= 1
 
 
 def _tile_worker(rank, world, port, q):
