@@ -424,6 +424,7 @@ def main():
     yuv = synth_frames_torch(torch, dev, W, H, list(mine), seed=1000)
     labels, records, recon, stats = alloc(torch, hevcdl_amd, dev, max(1, Fr), enc.frame_bytes, ctus)
     elapsed, prof = timed_steps(torch, enc, (yuv, labels, records, recon, stats), Fr, a.steps, a.warmup, barrier)
+    rd_launch = enc.last_rd_launch()
     # one frame alone (outside the timed steps): the serial CTU chain of a frame bounds what any sharding of the job can reach
     floor_s = None
     if Fr > 0 and not a.no_latency_floor:
@@ -439,10 +440,14 @@ def main():
     stt = torch.zeros(per_rank, dtype=torch.int64)
     stt[:Fr] = torch.from_numpy(st.copy())
     stt = stt.to(cdev)
+    ranks_seen = 1
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)          # every rank adds one: the collective really spans `world` ranks (the line carries it as rccl_ranks)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
         gathered = [torch.zeros_like(stt) for _ in range(world)] if rank == 0 else None
         dist.gather(stt, gathered, dst=0)
         total_bits = int(sum(int(g.sum().item()) for g in gathered)) if rank == 0 else 0
@@ -465,35 +470,42 @@ def main():
                        "frames": F, "frames_per_gpu": per_rank, "ctus_per_frame": ctus, "parallelism": "frame-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         # (launch_rd's rule: the ten-wave build of the kernel from four frames per workgroup on)
-                         "kernel": "hevcdl_rd_frame_kernel_wide" if Fr >= 4 * min(Fr, torch.cuda.get_device_properties(dev).multi_processor_count) else "hevcdl_rd_frame_kernel", "kernel_ms": 1e3 * rd_avg_s,
+                         "kernel": rd_launch.split(" ")[0], "launch": rd_launch, "kernel_ms": 1e3 * rd_avg_s,      # (what the library's launch_rd chose: hevcdl_last_rd_launch)
                          "cnn_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]), "algorithmic_bytes_per_ctu": ALGO_BYTES_PER_CTU,
                          "units_per_launch": "%d frames x %d CTUs (rank 0)" % (Fr, ctus)},
             "est_bits_per_frame": total_bits / max(1, F),
+            "rccl_ranks": ranks_seen, "collective_backend": backend if world > 1 else "none (one rank)", "frames_gathered": F if world == 1 else int(sum(int((g != 0).sum().item()) for g in gathered)),
         }
         cnn_s = (prof["cnn_conv_ms"] / max(1, prof["cnn_launches"])) / 1e3 if "cnn_conv_ms" in prof else 0.0
         if cnn_s > 0:    # the other stage, the other bound: the convolution kernel against the dense f16 MFMA peak
             ex = 2.0 * CNN_CONV_MACS_EXECUTED * Fr * ctus / cnn_s / 1e12
             us = 2.0 * CNN_CONV_MACS * Fr * ctus / cnn_s / 1e12
             out["roofline_cnn"] = {"bound": "mfma", "kernel": "hevcdl_cnn_ctu_kernel", "operand": "f16 hi/lo split x3, f32 acc", "executed_tflops": ex, "useful_tflops": us,
-                                   "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / MFMA_F16_PEAK_TFLOPS, "kernel_ms": 1e3 * cnn_s,
+                                   "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / MFMA_F16_PEAK_TFLOPS, "useful_frac": us / MFMA_F16_PEAK_TFLOPS, "kernel_ms": 1e3 * cnn_s,
                                    "executed_mflop_per_ctu": 2e-6 * CNN_CONV_MACS_EXECUTED, "useful_mflop_per_ctu": 2e-6 * CNN_CONV_MACS,
                                    "head_kernel_ms": prof["cnn_ms"] / max(1, prof["cnn_launches"]) - 1e3 * cnn_s,
-                                   "note": "executed = the MFMA products issued: three per multiply-accumulate in conv2 / conv3, 320 per output of the 5x5 layers (75 taps as 5 k-steps of 16 raw split words, two MFMAs a step); measured with HIP events on the launch stream over the timed steps"}
+                                   "note": "useful_frac = the graph's own multiply-accumulates (95.2 MFLOP per CTU) against the dense f16 peak: the distance from the roof.  frac prices the MFMA products ISSUED: three per multiply-accumulate in conv2 / conv3 (f16 hi/lo split operands for f32-like accuracy; the f32 MFMA runs at 1/16 of the f16 rate), 320 per output of the 5x5 layers (75 taps as 5 k-steps of 16 raw split words, two MFMAs a step): how busy the matrix pipes are; measured with HIP events on the launch stream over the timed steps"}
         if world == 1 and is_c4 and not a.no_projection:
             # What the frame-sharded job will take on N GPUs, from this GPU alone: a rank's share of the job is a launch of 600 / N frames (frames are independent, the
             # only collective gathers 8 bytes per frame), timed here as one whole step (label CNN + decisions) each.  The driver's SCALE run can be checked against it.
             proj = {1: elapsed / a.steps}
             stream = torch.cuda.current_stream().cuda_stream
+            proj_launch = {1: rd_launch}
             for n_gpu in (2, 4, 8):
                 share = sharding.max_shard(F, n_gpu)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                enc.encode_frames_dev(yuv.data_ptr(), share, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)
-                torch.cuda.synchronize(dev)
-                proj[n_gpu] = time.perf_counter() - t1
+                ts = []
+                for rep in range(4):          # the first launch of a shape is a warm-up (workspace growth, the cooperative form's first use); then the median of three
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    enc.encode_frames_dev(yuv.data_ptr(), share, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)
+                    torch.cuda.synchronize(dev)
+                    if rep:
+                        ts.append(time.perf_counter() - t1)
+                proj[n_gpu] = sorted(ts)[1]
+                proj_launch[n_gpu] = enc.last_rd_launch()
             out["scale_projection"] = {"seconds": {str(k): v for k, v in proj.items()}, "value": {str(k): F * ctus / v for k, v in proj.items()}, "unit": "CTUs/s",
-                                       "note": "seconds of one step over a rank's share of the 600 frames (600 / 300 / 150 / 75 frames), measured as single launches on this GPU; "
+                                       "launch": {str(k): v for k, v in proj_launch.items()},
+                                       "note": "seconds of one step over a rank's share of the 600 frames (600 / 300 / 150 / 75 frames) on this GPU: one warm-up launch per share, then the median of three; "
                                                "N-GPU value = 1 224 000 CTUs / that time"}
             out["share_8gpu_s"] = proj[8]
             # (the shares' records / reconstruction equal what the whole job wrote for those frames: frames are independent, the kernel deterministic -- re-run the job's step so that

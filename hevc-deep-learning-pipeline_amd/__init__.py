@@ -205,6 +205,9 @@ def load_library():
     lib.hevcdl_encode_frames_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.hevcdl_compress_tiles_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, ci, vp]
     lib.hevcdl_encode_pictures.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, vp]
+    lib.hevcdl_reserve_workspace.argtypes = [vp]
+    lib.hevcdl_last_rd_launch.argtypes = [vp]
+    lib.hevcdl_last_rd_launch.restype = ctypes.c_char_p
     lib.hevcdl_profile_enable.argtypes = [vp, ci]
     lib.hevcdl_profile_get.argtypes = [vp, ctypes.POINTER(Profile)]
     lib.hevcdl_ctus_per_frame.argtypes = [ci, ci]
@@ -219,7 +222,7 @@ def load_library():
 
 EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_last_error", "hevcdl_predict_depth",
            "hevcdl_predict_depth_rgb", "hevcdl_labels_from_logits", "hevcdl_compress_frames", "hevcdl_predict_depth_planes", "hevcdl_compress_frames_planes", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
-           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_device_memory", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_encode_pictures_chunked", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
+           "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_device_memory", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_encode_pictures_chunked", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_last_rd_launch", "hevcdl_reserve_workspace", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
            "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5", "hevcdl_write_digest_sei"]
 
@@ -505,6 +508,14 @@ class Encoder:
 
     def profile_enable(self, on=True):
         self._check(self.lib.hevcdl_profile_enable(self._h, int(on)))
+
+    def reserve_workspace(self):
+        """Allocate the decision kernel's largest workspace now (hevcdl_reserve_workspace): raises HevcdlError(OOM) here instead of at the first launch."""
+        self._check(self.lib.hevcdl_reserve_workspace(self._h))
+
+    def last_rd_launch(self):
+        """Build of the decision kernel and launch form of the last decision launch (hevcdl_last_rd_launch)."""
+        return (self.lib.hevcdl_last_rd_launch(self._h) or b"").decode()
 
     def profile_get(self):
         p = Profile()

@@ -71,19 +71,21 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m)
 }
 
 // BN in training mode folded to an affine map (nn.BatchNorm2d defaults: biased variance, eps 1e-5)
-__device__ __forceinline__ void bn_fold(double s, double ss, double n, float gamma, float beta, float &alpha, float &betap)
+// The sums come from accumulators that hold 1 / inv_in times the layer's output (operand scales, hevcdl_dev.h HEVCDL_ACT_SCALE: a power of two, so the sums are
+// unscaled exactly); the map it returns takes such an accumulator to the activation times HEVCDL_ACT_SCALE, the operand scale of the next layer.
+__device__ __forceinline__ void bn_fold(double s, double ss, double n, float gamma, float beta, float inv_in, float &alpha, float &betap)
 {
-  const double rn = 1.0 / n;                       // (n is a power of two at every call: exact)
+  const double rn = (1.0 / n) * (double)inv_in;    // (n is a power of two at every call: exact)
   double mean = s * rn;
-  double var = ss * rn - mean * mean;
+  double var = ss * (rn * (double)inv_in) - mean * mean;
   if (var < 0) var = 0;
   // 1 / sqrt(x): the f32 reciprocal square root (1 ulp) refined by one Newton step in f64 -- 1e-14 relative, against 6e-8 of the float the result is rounded to;
   // the library's f64 sqrt and division are ~70 instructions, this is 8
   const double x = var + 1e-5;
   const double r0 = (double)__builtin_amdgcn_rsqf((float)x);
   const double inv = r0 * (1.5 - (0.5 * x) * (r0 * r0));
-  alpha = (float)(inv * (double)gamma);
-  betap = (float)((double)beta - mean * inv * (double)gamma);
+  alpha = (float)(inv * (double)gamma * ((double)inv_in * (double)HEVCDL_ACT_SCALE));
+  betap = (float)(((double)beta - mean * inv * (double)gamma) * (double)HEVCDL_ACT_SCALE);
 }
 
 // v -> one word: low half f16(v) (rounded toward zero), high half f16(v - low half).
@@ -133,7 +135,7 @@ __device__ __forceinline__ v4f mfma3(const h8 &ah, const h8 &al, const h8 &bh, c
 // phase 0: the whole map in one call (conv1 on a quadrant).  phase 1 / 2: upper / lower half of the CTU for conv64 (tile rows are then
 // relative to the half); the statistics of the halves meet in sm.red and the map is normalised after the second.
 template <int POOL>
-__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float LDS *map, int pb, int tid, int phase)
+__device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, const int LDS *koff, const float GLB *w, float inv_in, float LDS *map, int pb, int tid, int phase)
 {
   constexpr int ROW = (POOL == 4) ? T64_ROW : T32_ROW;
   constexpr int ITERS = (POOL == 4) ? 8 : 4;        // per wave and call: 8 rows of the region, 4 tiles an iteration
@@ -213,7 +215,7 @@ __device__ __noinline__ void conv5_mfma(CnnSmem LDS &sm, const float LDS *tile, 
     constexpr int SIZE = 16 * POOL;
     float al, be;
     if (sm.bn_eval) { al = w[HEVCDL_W_C5 + 16 + tid]; be = w[HEVCDL_W_C5 + 32 + tid]; }      // eval mode: folded on the host (fold_bn_eval)
-    else bn_fold(a, b, (double)(SIZE * SIZE), w[HEVCDL_W_C5 + 16 + tid], w[HEVCDL_W_C5 + 32 + tid], al, be);
+    else bn_fold(a, b, (double)(SIZE * SIZE), w[HEVCDL_W_C5 + 16 + tid], w[HEVCDL_W_C5 + 32 + tid], inv_in, al, be);
     sm.alpha[tid] = al; sm.beta[tid] = be;
   }
   __syncthreads();
@@ -262,7 +264,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
 #endif
 
   // ---- stage 0: CTU input -> LDS (coalesced rows of the planes), LUT, im2col tables, zeroed halo'd maps --------
-  sm.lut[tid] = split_f16((float)tid / 255.0f);
+  sm.lut[tid] = split_f16((float)tid / 255.0f * HEVCDL_ACT_SCALE);       // (a power of two: exact)
   if (tid < 80) {
     const int v = hevcdl_conv5_slot_tap(tid), k = v >= 0 ? v : -v - 1, c = k / 25, r = k - c * 25, ky = r / 5, kx = r - ky * 5;
     sm.koff64[tid] = c * T64_CH + ky * T64_ROW + kx; sm.koff32[tid] = c * T32_CH + ky * T32_ROW + kx;
@@ -347,7 +349,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
       d[T64_CH] = (f2){ v2[0], v2[1] }; d[T64_CH + 1] = (f2){ v2[2], v2[3] };
     }
     __syncthreads();
-    conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, sm.act12, 8, tid, h + 1);
+    conv5_mfma<4>(sm, sm.t64, sm.koff64, W + HEVCDL_W_C64, W[HEVCDL_W_SCALES + 1], sm.act12, 8, tid, h + 1);
   }
 
   CNN_MARK(1);
@@ -373,7 +375,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
     }
     __syncthreads();
     CNN_MARK(2);
-    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, sm.act12, 0, tid, 0);
+    conv5_mfma<2>(sm, sm.q.t32, sm.koff32, W + HEVCDL_W_C1, W[HEVCDL_W_SCALES + 0], sm.act12, 0, tid, 0);
     CNN_MARK(3);
     for (int i = tid; i < 16 * 36; i += 256) {                       // the input tile is dead: zero the 36 border positions of conv2's 10 x 10 output maps, four words each, 16 arrays
       const int c = i / 36, r = i - c * 36;                          // 0..9 top row, 10..19 bottom row, 20..35 the sides of rows 1..8
@@ -449,7 +451,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         double s = 0, ss = 0;
 #pragma unroll
         for (int wv = 0; wv < 4; wv++) { s += sm.red2[0][wv][lane]; ss += sm.red2[1][wv][lane]; }
-        bn_fold(s, ss, 256.0, b2[64 + lane], b2[128 + lane], al_l, be_l);
+        bn_fold(s, ss, 256.0, b2[64 + lane], b2[128 + lane], W[HEVCDL_W_SCALES + 2], al_l, be_l);
       }
       // conv3's operand form: plane m < 32 holds the hi halves of a PAIR of channels, plane 32 + m their lo halves; a lane pairs its N-tiles 0 | 1 (channels i16 | 16 + i16,
       // pair i16) and 2 | 3 (32 + i16 | 48 + i16, pair 16 + i16)
@@ -526,7 +528,7 @@ void hevcdl_cnn_ctu_kernel(hevcdl_cnn_params p)
         s += shfl_xor_d(s, 16); s += shfl_xor_d(s, 32); ss += shfl_xor_d(ss, 16); ss += shfl_xor_d(ss, 32);
         float al, be;
         if (p.bn_eval) { al = b3[128 + ch]; be = b3[256 + ch]; }
-        else bn_fold(s, ss, 64.0, b3[128 + ch], b3[256 + ch], al, be);
+        else bn_fold(s, ss, 64.0, b3[128 + ch], b3[256 + ch], W[HEVCDL_W_SCALES + 3], al, be);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           const v4f a = acc[n][t];

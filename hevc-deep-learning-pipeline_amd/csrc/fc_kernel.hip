@@ -104,6 +104,7 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
       __builtin_amdgcn_sched_barrier(0);
     }
     const float GLB *bias = W + HEVCDL_W_FC1 + 2048 * 256 + wave * 64 + i16;
+    const float inv = W[HEVCDL_W_SCALES + 4];        // 1 / (weight scale * activation scale): a power of two, the product below is exact (hevcdl_dev.h HEVCDL_ACT_SCALE)
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) {
       const float b = bias[nt * 16];
@@ -111,7 +112,7 @@ void hevcdl_fc_kernel(hevcdl_fc_params p)
       for (int mt = 0; mt < 4; mt++) {
         const v4f r = acc[mt][nt];
         float *d = sm.h1 + (mt * 16 + g4 * 4) * H1_ROW + wave * 64 + nt * 16 + i16;
-        d[0] = fmaxf(r.x + b, 0.f); d[H1_ROW] = fmaxf(r.y + b, 0.f); d[2 * H1_ROW] = fmaxf(r.z + b, 0.f); d[3 * H1_ROW] = fmaxf(r.w + b, 0.f);
+        d[0] = fmaxf(r.x * inv + b, 0.f); d[H1_ROW] = fmaxf(r.y * inv + b, 0.f); d[2 * H1_ROW] = fmaxf(r.z * inv + b, 0.f); d[3 * H1_ROW] = fmaxf(r.w * inv + b, 0.f);
       }
     }
   }

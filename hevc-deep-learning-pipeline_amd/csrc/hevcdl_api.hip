@@ -44,6 +44,7 @@ __global__ void hevcdl_clamp_labels_kernel(uint8_t *labels, int n_ctus, int ctus
 }
 
 struct hevcdl_ctx {
+  char last_rd[160] = { 0 };           // which build and launch form the last decision launch took (hevcdl_last_rd_launch)
   hevcdl_config cfg;
   int ctus_x, ctus_y, ctus, n_cus;
   int col_bd[21], row_bd[23];    // tile boundaries in CTUs
@@ -158,18 +159,29 @@ static float f16_to_f32(uint16_t h)
 // then bias, gamma, beta as floats -- the same number of bytes as the f32 packing it replaces.
 // the 5x5 convolutions (3 input channels, 16 output channels = one N-tile): the 75 taps (c * 5 + ky) * 5 + kx in the order of hevcdl_conv5_slot_tap, 5 k-steps of 16.
 // The A operand of a step is four raw split words (hi, lo, hi, lo, ...): B1 carries the weight's hi half against both halves, B2 its lo half against the hi half only.
-static void pack_conv5(const float *w, const float *b, const float *g, const float *be, float *dst)
+// weight scale of a layer (hevcdl_dev.h HEVCDL_ACT_SCALE): the largest power of two that keeps max |w| * scale below 2^15 (f16 holds 65504), at most 2^24
+static float layer_scale(const float *w, size_t n)
+{
+  float m = 0.f;
+  for (size_t i = 0; i < n; i++) { const float a = fabsf(w[i]); if (a > m && a <= 3.0e38f) m = a; }
+  float sc = 1.f;
+  if (m > 0.f) while (sc < 16777216.f && m * sc * 2.f < 32768.f) sc *= 2.f;
+  return sc;
+}
+// sc: the layer's weight scale; the bias enters the accumulator, which holds sc * HEVCDL_ACT_SCALE times the layer's output
+static void pack_conv5(const float *w, const float *b, const float *g, const float *be, float *dst, float sc)
 {
   uint16_t *d16 = (uint16_t *)dst;
   for (int s = 0; s < 5; s++) for (int l = 0; l < 64; l++) for (int e = 0; e < 8; e++) {
     const int k = hevcdl_conv5_slot_tap(16 * s + 4 * (l >> 4) + (e >> 1)), oc = l & 15;
-    const float v = k >= 0 ? w[oc * 75 + k] : 0.f;
+    const float v = (k >= 0 ? w[oc * 75 + k] : 0.f) * sc;
     const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
     d16[(size_t)(s * 2) * 512 + (size_t)l * 8 + e] = hi; d16[(size_t)(s * 2 + 1) * 512 + (size_t)l * 8 + e] = (e & 1) ? (uint16_t)0 : lo;
   }
-  memcpy(dst + HEVCDL_W_C5, b, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 16, g, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 32, be, 16 * sizeof(float));
+  for (int c = 0; c < 16; c++) dst[HEVCDL_W_C5 + c] = b[c] * sc * HEVCDL_ACT_SCALE;
+  memcpy(dst + HEVCDL_W_C5 + 16, g, 16 * sizeof(float)); memcpy(dst + HEVCDL_W_C5 + 32, be, 16 * sizeof(float));
 }
-static void pack_conv3(const float *w, const float *b, const float *g, const float *be, int oc, int ic, float *dst)
+static void pack_conv3(const float *w, const float *b, const float *g, const float *be, int oc, int ic, float *dst, float sc)
 {
   uint16_t *d16 = (uint16_t *)dst;
   const int ks = ic / 32;
@@ -178,33 +190,35 @@ static void pack_conv3(const float *w, const float *b, const float *g, const flo
     // conv2's input (32 channels): pair m = channels 2m | 2m + 1;  conv3's input (64): pairs 0..15 = channels m | m + 16, pairs 16..31 = 16 + m | 32 + m
     const int m = 16 * s + 4 * (j >> 1) + (l >> 4), hf = j & 1;
     const int c = ic == 32 ? 2 * m + hf : (m < 16 ? m + 16 * hf : 16 + m + 16 * hf), o = nt * 16 + (l & 15);
-    const float v = w[((size_t)o * ic + c) * 9 + tap];
+    const float v = w[((size_t)o * ic + c) * 9 + tap] * sc;
     const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
     const size_t base = ((((size_t)nt * 9 + tap) * ks + s) * 2) * 512;        // halves: 64 lanes x 8 per operand
     d16[base + (size_t)l * 8 + j] = hi; d16[base + 512 + (size_t)l * 8 + j] = lo;
   }
   float *t = dst + (size_t)9 * ic * oc;
-  memcpy(t, b, oc * sizeof(float)); memcpy(t + oc, g, oc * sizeof(float)); memcpy(t + 2 * oc, be, oc * sizeof(float));
+  for (int c = 0; c < oc; c++) t[c] = b[c] * sc * HEVCDL_ACT_SCALE;
+  memcpy(t + oc, g, oc * sizeof(float)); memcpy(t + 2 * oc, be, oc * sizeof(float));
 }
 // HEVCDL_BN_EVAL: BatchNorm with the checkpoint's running statistics (model.eval()) is the fixed affine map y = x * alpha + beta' with
 // alpha = gamma / sqrt(running_var + eps), beta' = beta - running_mean * alpha; the kernels find the pair in the gamma / beta slots of the
 // packed layer (state_dict order: weight, bias, running_mean, running_var follow each other, `oc` floats each).
-static void fold_bn_eval(const float *g, const float *be, int oc, float *dst_g, float *dst_be)
+// The map is applied to the accumulator (in_sc = weight scale * HEVCDL_ACT_SCALE times the layer's output) and writes activations scaled by HEVCDL_ACT_SCALE.
+static void fold_bn_eval(const float *g, const float *be, int oc, float *dst_g, float *dst_be, float in_sc)
 {
   const float *rm = be + oc, *rv = be + 2 * oc;
   for (int c = 0; c < oc; c++) {
     const double a = (double)g[c] / sqrt((double)rv[c] + 1e-5);
-    dst_g[c] = (float)a; dst_be[c] = (float)((double)be[c] - (double)rm[c] * a);
+    dst_g[c] = (float)(a / (double)in_sc * (double)HEVCDL_ACT_SCALE); dst_be[c] = (float)(((double)be[c] - (double)rm[c] * a) * (double)HEVCDL_ACT_SCALE);
   }
 }
 // fc1 (2048 -> 256) for the split-f16 MFMA of fc_kernel.hip: [k-step of 32][N-tile of 16][hi | lo][64 lanes][8 halves], lane l element j <-> k = 32 * step + 8 * (l >> 4) + j,
 // n = 16 * tile + (l & 15); the pairs take exactly the bytes of the f32 matrix, the bias follows as before
-static void pack_fc1(const float *w, const float *b, float *dst)
+static void pack_fc1(const float *w, const float *b, float *dst, float sc)
 {
   uint16_t *d16 = (uint16_t *)dst;
   for (int ks = 0; ks < 64; ks++) for (int nt = 0; nt < 16; nt++) for (int l = 0; l < 64; l++) for (int j = 0; j < 8; j++) {
     const int k = 32 * ks + 8 * (l >> 4) + j, n = nt * 16 + (l & 15);
-    const float v = w[(size_t)n * 2048 + k];
+    const float v = w[(size_t)n * 2048 + k] * sc;
     const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
     const size_t base = (((size_t)ks * 16 + nt) * 2) * 512;
     d16[base + (size_t)l * 8 + j] = hi; d16[base + 512 + (size_t)l * 8 + j] = lo;
@@ -250,17 +264,21 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   CK(hipSetDevice(cfg->device));
   { hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, cfg->device)); ctx->n_cus = prop.multiProcessorCount; }
   std::vector<float> pk(HEVCDL_W_TOTAL);
-  pack_conv5(weights + B_C1W, weights + B_C1B, weights + B_C1G, weights + B_C1BE, pk.data() + HEVCDL_W_C1);
-  pack_conv5(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, pk.data() + HEVCDL_W_C64);
-  pack_conv3(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 32, pk.data() + HEVCDL_W_C2);
-  pack_conv3(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 64, pk.data() + HEVCDL_W_C3);
+  // operand scales (hevcdl_dev.h HEVCDL_ACT_SCALE): weights of a layer by a power of two, activations by HEVCDL_ACT_SCALE; the kernels find 1 / (their product) behind the weights
+  const float sc1 = layer_scale(weights + B_C1W, 1200), sc64 = layer_scale(weights + B_C64W, 1200), sc2 = layer_scale(weights + B_C2W, 9 * 32 * 64),
+              sc3 = layer_scale(weights + B_C3W, 9 * 64 * 128), scf = layer_scale(weights + B_F1W, 2048 * 256);
+  { const float scs[5] = { sc1, sc64, sc2, sc3, scf }; for (int i = 0; i < 8; i++) pk[HEVCDL_W_SCALES + i] = i < 5 ? 1.0f / (scs[i] * HEVCDL_ACT_SCALE) : 0.f; }
+  pack_conv5(weights + B_C1W, weights + B_C1B, weights + B_C1G, weights + B_C1BE, pk.data() + HEVCDL_W_C1, sc1);
+  pack_conv5(weights + B_C64W, weights + B_C64B, weights + B_C64G, weights + B_C64BE, pk.data() + HEVCDL_W_C64, sc64);
+  pack_conv3(weights + B_C2W, weights + B_C2B, weights + B_C2G, weights + B_C2BE, 64, 32, pk.data() + HEVCDL_W_C2, sc2);
+  pack_conv3(weights + B_C3W, weights + B_C3B, weights + B_C3G, weights + B_C3BE, 128, 64, pk.data() + HEVCDL_W_C3, sc3);
   if (cfg->bn_mode == HEVCDL_BN_EVAL) {
-    fold_bn_eval(weights + B_C1G, weights + B_C1BE, 16, pk.data() + HEVCDL_W_C1 + HEVCDL_W_C5 + 16, pk.data() + HEVCDL_W_C1 + HEVCDL_W_C5 + 32);
-    fold_bn_eval(weights + B_C64G, weights + B_C64BE, 16, pk.data() + HEVCDL_W_C64 + HEVCDL_W_C5 + 16, pk.data() + HEVCDL_W_C64 + HEVCDL_W_C5 + 32);
-    fold_bn_eval(weights + B_C2G, weights + B_C2BE, 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 128);
-    fold_bn_eval(weights + B_C3G, weights + B_C3BE, 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 256);
+    fold_bn_eval(weights + B_C1G, weights + B_C1BE, 16, pk.data() + HEVCDL_W_C1 + HEVCDL_W_C5 + 16, pk.data() + HEVCDL_W_C1 + HEVCDL_W_C5 + 32, sc1 * HEVCDL_ACT_SCALE);
+    fold_bn_eval(weights + B_C64G, weights + B_C64BE, 16, pk.data() + HEVCDL_W_C64 + HEVCDL_W_C5 + 16, pk.data() + HEVCDL_W_C64 + HEVCDL_W_C5 + 32, sc64 * HEVCDL_ACT_SCALE);
+    fold_bn_eval(weights + B_C2G, weights + B_C2BE, 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 64, pk.data() + HEVCDL_W_C2 + 9 * 32 * 64 + 128, sc2 * HEVCDL_ACT_SCALE);
+    fold_bn_eval(weights + B_C3G, weights + B_C3BE, 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 128, pk.data() + HEVCDL_W_C3 + 9 * 64 * 128 + 256, sc3 * HEVCDL_ACT_SCALE);
   }
-  pack_fc1(weights + B_F1W, weights + B_F1B, pk.data() + HEVCDL_W_FC1);
+  pack_fc1(weights + B_F1W, weights + B_F1B, pk.data() + HEVCDL_W_FC1, scf);
   pack_fc(weights + B_F2W, weights + B_F2B, 64, 256, pk.data() + HEVCDL_W_FC2);
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_flag, sizeof(int)));
@@ -456,7 +474,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   bool wide = false;
   if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW))
     wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 4 * groups);
-  if (wide) p.remote = 0;
+  if (wide) p.remote = 0;      // (the automatic choice never pairs the ten-wave build with the hand-over of units -- four units or more per workgroup against at most three --; forced by exec_flags the pair runs: tests/test_rd_gpu.py::test_units_handed_over_between_workgroups_give_the_same_result)
   const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
   const int threads = 64 * waves;
   const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (const void *)hevcdl_rd_frame_kernel) : (const void *)hevcdl_rd_frame_kernel_bd10;
@@ -483,6 +501,9 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   }
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
+  snprintf(ctx->last_rd, sizeof ctx->last_rd, "%s form=%s workgroups=%d waves=%d units=%d", ctx->cfg.bit_depth != 8 ? "hevcdl_rd_frame_kernel_bd10" : (wide ? "hevcdl_rd_frame_kernel_wide" : "hevcdl_rd_frame_kernel"),
+           p.migrate ? "unit-handover" : (p.remote == 1 ? "few-units(passes)" : (p.remote == 2 ? "few-units(passes+chroma)" : (p.remote == 3 ? "few-units(passes while takers idle)" : "independent"))),
+           p.remote ? ctx->remote_groups : groups, waves, n_units);
 #if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)
   {
     std::vector<unsigned int> hb(8004); hipDeviceSynchronize(); hipMemcpy(hb.data(), d_dbg, 8004 * 4, hipMemcpyDeviceToHost);
@@ -644,6 +665,31 @@ extern "C" hevcdl_status hevcdl_predict_depth_rgb(hevcdl_ctx *ctx, const uint8_t
   }
   hipFree(d_in); hipFree(d_lab); hipFree(d_lg);
   return st;
+}
+
+extern "C" const char *hevcdl_last_rd_launch(const hevcdl_ctx *ctx) { return ctx ? ctx->last_rd : ""; }
+
+// The decision kernel's workspace (1.6 MB per wave of a launch) is allocated by the first launch that needs it and grown when a later one needs more: a context that
+// only ever codes a frame in the independent form holds megabytes, a launch on every CU 3.4 GB (4.3 GB for the ten-wave build).  A caller that wants to learn
+// about a lack of device memory BEFORE its first pictures are in flight reserves the largest workspace any launch of this context can ask for -- launches of 1 ..
+// max_frames frames: every CU's workgroup (the few-units form runs on all of them), ten waves where the ten-wave build can be chosen -- and gets HEVCDL_ERR_OOM here.
+extern "C" hevcdl_status hevcdl_reserve_workspace(hevcdl_ctx *ctx)
+{
+  if (!ctx) return HEVCDL_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(ctx->cfg.device));
+  const long long max_units = (long long)ctx->cfg.max_frames * ctx->cfg.tile_columns * ctx->cfg.tile_rows;
+  const int groups = std::max(ctx->rd_groups, ctx->remote_groups);
+  int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : hevcdl_rd_waves_per_group();
+  if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW) && ((ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || max_units >= 4LL * ctx->rd_groups))
+    waves = std::max(waves, hevcdl_rd_waves_per_group_wide());
+  const size_t need = ctx->scratch_per_wave * (size_t)groups * (size_t)waves;
+  if (need <= ctx->scratch_bytes) return HEVCDL_OK;
+  HIPCHK(hipDeviceSynchronize());
+  if (ctx->d_scratch) { hipFree(ctx->d_scratch); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
+  const hipError_t e = hipMalloc(&ctx->d_scratch, need);
+  if (e != hipSuccess) { (void)hipGetLastError(); ctx->d_scratch = nullptr; return fail(ctx, HEVCDL_ERR_OOM, "decision-kernel workspace (1.6 MB per wave of the largest launch)", e); }
+  ctx->scratch_bytes = need;
+  return HEVCDL_OK;
 }
 
 extern "C" hevcdl_status hevcdl_labels_from_logits(hevcdl_ctx *ctx, const float *logits, int n_ctus, int clamp, uint8_t *labels)

@@ -142,6 +142,7 @@ struct RcclApi {
   int (*AllGather)(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream) = nullptr;
   int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int *) = nullptr; int (*CommCount)(void *comm, int *count) = nullptr;
   int (*hipSetDevice)(int) = nullptr; int (*hipMalloc)(void **, size_t) = nullptr; int (*hipFree)(void *) = nullptr;
   int (*hipMemcpy)(void *, const void *, size_t, int) = nullptr; int (*hipDeviceSynchronize)() = nullptr;
   bool load(std::string &err)
@@ -152,6 +153,7 @@ struct RcclApi {
 #define SYM(lib, field, name) do { *(void **)&field = dlsym(lib, name); if (!field) { err = std::string("missing symbol ") + name; return false; } } while (0)
     SYM(h_rccl, CommInitAll, "ncclCommInitAll"); SYM(h_rccl, CommDestroy, "ncclCommDestroy"); SYM(h_rccl, AllGather, "ncclAllGather");
     SYM(h_rccl, GroupStart, "ncclGroupStart"); SYM(h_rccl, GroupEnd, "ncclGroupEnd"); SYM(h_rccl, GetErrorString, "ncclGetErrorString");
+    SYM(h_rccl, GetVersion, "ncclGetVersion"); SYM(h_rccl, CommCount, "ncclCommCount");
     SYM(h_hip, hipSetDevice, "hipSetDevice"); SYM(h_hip, hipMalloc, "hipMalloc"); SYM(h_hip, hipFree, "hipFree"); SYM(h_hip, hipMemcpy, "hipMemcpy");
     SYM(h_hip, hipDeviceSynchronize, "hipDeviceSynchronize");
 #undef SYM
@@ -160,8 +162,9 @@ struct RcclApi {
 };
 
 // rows_of(i): the rows (row_words 64-bit words each) of block i, coded on device dev_of(i).  -> table: every rank's contribution, padded with rows whose first word is ~0
+// info: what ran, for the log -- the library's version, the size the communicator reports (ncclCommCount), the devices
 bool gather_rows_rccl(size_t n_blocks, const std::function<int(size_t)> &dev_of, const std::function<const std::vector<unsigned long long> &(size_t)> &rows_of, int row_words,
-                      std::vector<unsigned long long> &table, std::string &err)
+                      std::vector<unsigned long long> &table, std::string &err, std::string *info = nullptr)
 {
   RcclApi api;
   if (!api.load(err)) return false;
@@ -190,6 +193,13 @@ bool gather_rows_rccl(size_t n_blocks, const std::function<int(size_t)> &dev_of,
   table.resize(words * (size_t)R);
   api.hipSetDevice(ranks[0]);
   if ((e = api.hipMemcpy(table.data(), d_recv[0], words * 8 * (size_t)R, 2 /* hipMemcpyDeviceToHost */))) return fail("hipMemcpy", e, false);
+  if (info) {
+    int ver = 0, cnt = 0; api.GetVersion(&ver); api.CommCount(comms[0], &cnt);
+    char b[256]; int o = snprintf(b, sizeof b, "ncclAllGather over %d rank%s (ncclCommCount %d, RCCL/NCCL version code %d, one rank per physical device:", R, R == 1 ? "" : "s", cnt, ver);
+    for (int r = 0; r < R && o < (int)sizeof b - 8; r++) o += snprintf(b + o, sizeof b - o, " %d", ranks[r]);
+    snprintf(b + o, sizeof b - o, "), %zu words each", words);
+    *info = b;
+  }
   cleanup();
   return true;
 }
@@ -290,7 +300,10 @@ int main(int argc, char **argv)
   long dev_cap = 2048;
   { size_t free_b = 0, total_b = 0;       // the smallest free memory over the devices named: every shard's batch is sized from it
     for (size_t i = 0; i < devices.size(); i++) { size_t f = 0, t = 0; if (hevcdl_device_memory(devices[i], &f, &t) == HEVCDL_OK && f > 0 && (free_b == 0 || f < free_b)) { free_b = f; total_b = t; } }
-    if (free_b > 0) dev_cap = std::max<long>(1, (long)((double)free_b * 0.8 / (shared_device ? (double)devices.size() : 1.0)) / per_picture_dev); }
+    const size_t workspace = (size_t)4400 << 20;        // the decision kernel's workspace: up to 1.6 MB x 10 waves x 256 workgroups per context (hevcdl_reserve_workspace)
+    if (free_b > 0) { double mine = (double)free_b * 0.8 / (shared_device ? (double)devices.size() : 1.0);       // (contexts that share a device share its memory)
+      if (mine > 2.0 * (double)workspace) mine -= (double)workspace;
+      dev_cap = std::max<long>(1, (long)mine / per_picture_dev); } }
   const long auto_batch = std::max<long>(1, std::min<long>(std::min<long>(2048 / (tile_cols * tile_rows), dev_cap), (24L << 30) / (long)frame_bytes));
   const long even_batch = (per_shard + ((per_shard + auto_batch - 1) / auto_batch) - 1) / ((per_shard + auto_batch - 1) / auto_batch);
   int batch = (int)std::min<long>(per_shard, std::max<long>(1, opt.geti("BatchFrames", even_batch)));
@@ -332,6 +345,8 @@ int main(int argc, char **argv)
     for (;;) {
       cfg.max_frames = batch; cfg.device = shards[i].dev;
       st = hevcdl_create(&cfg, weights.data(), weights.size(), &shards[i].ctx);
+      // the decision kernel's workspace (up to 4.3 GB) is otherwise allocated by the first launch: reserved here, a lack of memory is met by the retry below
+      if (st == HEVCDL_OK && (st = hevcdl_reserve_workspace(shards[i].ctx)) != HEVCDL_OK) { hevcdl_destroy(shards[i].ctx); shards[i].ctx = nullptr; }
       if (st != HEVCDL_ERR_OOM || batch == 1) break;
       batch = (batch + 1) / 2;
       fprintf(stderr, "device %d: not enough memory for the batch, retrying with %d pictures per call\n", shards[i].dev, batch);
@@ -512,10 +527,11 @@ int main(int argc, char **argv)
     // PHYSICAL device (ncclCommInitAll, a single process), every rank contributes the rows of its blocks padded to the largest contribution, one ncclAllGather; rank 0's
     // copy is the table the log and the summary are written from.
     std::vector<unsigned long long> table;
-    std::string err;
-    if (!gather_rows_rccl(shards.size(), [&](size_t i) { return shards[i].dev; }, [&](size_t i) -> const std::vector<unsigned long long> & { return shards[i].rows; }, ROW, table, err)) {
+    std::string err, info;
+    if (!gather_rows_rccl(shards.size(), [&](size_t i) { return shards[i].dev; }, [&](size_t i) -> const std::vector<unsigned long long> & { return shards[i].rows; }, ROW, table, err, &info)) {
       fprintf(stderr, "Error: gathering the per-picture rows with RCCL failed: %s\n", err.c_str()); rc = 3;
     } else {
+      fprintf(stderr, "Picture rows gathered: %s\n", info.c_str());
       std::vector<const unsigned long long *> rows;
       for (size_t o = 0; o + ROW <= table.size(); o += ROW) if (table[o] != ~0ull) rows.push_back(&table[o]);
       std::sort(rows.begin(), rows.end(), [](const unsigned long long *a, const unsigned long long *b) { return a[0] < b[0]; });

@@ -18,7 +18,14 @@
 #define HEVCDL_W_FC1  97952        // 2048*256 + 256
 #define HEVCDL_W_FC2  622496       // 256*64 + 64
 #define HEVCDL_W_FC3  638944       // 64*16 + 16
-#define HEVCDL_W_TOTAL 639984
+#define HEVCDL_W_SCALES 639984      // 8 floats: 1 / (weight scale * HEVCDL_ACT_SCALE) of conv1, conv64, conv2, conv3, fc1 (the scales below), 3 unused
+#define HEVCDL_W_TOTAL 639992
+// Split-f16 operands (cnn_kernel.hip split_f16) carry 22 significant bits only while the lo half is a NORMAL f16, i.e. for |v| >= 2^-3; below that the pair's error
+// is an absolute 2^-25.  Most weights (1e-3 .. 1e-1) and the darker input samples (u8 / 255) lie below 2^-3, so every operand is scaled by an exact power of two
+// before it is split: the weights of a layer by 2^k, k the largest exponent that keeps max |w| 2^k below 2^15 (hevcdl_api.hip layer_scale), activations -- the
+// input LUT, the maps the BatchNorm epilogues write, conv3's output -- by HEVCDL_ACT_SCALE.  An accumulator then holds (weight scale * HEVCDL_ACT_SCALE) times the
+// layer's output; the factor is exact and leaves through the folded BatchNorm map (statistics and alpha unscaled in f64, cnn_kernel.hip bn_fold) or fc1's epilogue.
+#define HEVCDL_ACT_SCALE 16.0f
 
 // K order of the 5x5 convolutions (cnn_kernel.hip conv5_mfma, hevcdl_api.hip pack_conv5): 5 k-steps of 16 taps; slot = 16 s + 4 g + j is word j of lane group g in
 // k-step s.  Two rules shape it.  (1) One half of a ds_read_b32 serves lane groups 2h and 2h + 1: their words must lie 16 banks apart in the input tile (the 16

@@ -338,7 +338,7 @@ struct Tables {                        // read-only after kernel start, one copy
 };
 struct __attribute__((aligned(16))) WgShared {
   Region reg[NW][NREG];               // see NREG
-  int masters_active, quit, remote, pad_;       // waves that currently walk a unit; quit: a workgroup without units has seen the last unit finish; remote: hevcdl_rd_params.remote
+  int masters_active, quit, remote, bell;       // waves that currently walk a unit; quit: a workgroup without units has seen the last unit finish; remote: hevcdl_rd_params.remote; bell: counts the times tasks were put up in any region of the workgroup (ring_bell)
   GLB unsigned char *sched; unsigned long long pad2_;
   Tables tab;
 };
@@ -382,6 +382,24 @@ DEVN int lds_add(LDS int *p, int v)
   if (lane_id() == 0) r = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return uni(r);
 }
+// -DHEVCDL_BELL (round 5, measured and NOT kept): a doorbell.  A wave without work walks the NREG * NW tickets again and again (40 dependent LDS round trips a
+// scan, ~4 k cycles, then s_sleep 32).  With the bell it sleeps on ONE word that region_open / region_publish count up, and walks the tickets when it has moved.
+// On 256-frame launches (one master, seven helpers per workgroup) that takes 7 % off the kernel's vector + scalar instructions (3.00 -> 2.79 M per CTU,
+// profiles/r05b_bell_counters.txt) -- and costs time: one frame 2.82 -> 2.85 s, 600 frames 6.25 -> 6.31 s, 2048 frames 15.68 -> 15.75 s (two runs each, one
+// box): the poll every 512 cycles and the call behind every ticket take more issue slots from the busy waves than the scans did, and a helper that finds its task
+// 2 k cycles sooner shortens nothing (the tasks are 100 k cycles long).  s_wakeup behind the bell ends the other waves' s_sleep at once (tools/wakeup_probe.hip:
+// a wave in s_sleep 32 notices a flag after 370 instead of 1 280 cycles) -- with it the kernel died with GPU memory faults in every launch of the independent
+// form (three builds with it against three without), so it is not even an option.
+#ifdef HEVCDL_BELL
+constexpr int HELPER_BELL = 1;
+DEVN void ring_bell() { if (lane_id() == 0) __hip_atomic_fetch_add(&wg_shared().bell, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#else
+constexpr int HELPER_BELL = 0;
+DEV void ring_bell() { }
+#endif
+#ifndef HEVCDL_IDLE_SLEEP
+#define HEVCDL_IDLE_SLEEP 8          // x 64 cycles between two looks at the bell
+#endif
 // hand-over points between waves of the workgroup (same CU: LDS and the vector L1 are shared, workgroup scope is enough)
 DEV void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 DEV void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -876,21 +894,32 @@ DEV int sig_ctx_inc(const CParam &cp, const ScanFn &scan, int pat, int scan_pos)
   }
   return cp.first_sig_ctx + offset;
 }
-DEV int sig_ctx_inc_xy(const CParam &cp, int pat, int px, int py)
-{ // sig_ctx_inc from the block coordinates of the position
-  if (px + py == 0) return 0;
-  int offset;
-  if (cp.log2 == 2) offset = tb().t_ctx_map4[4 * py + px];
-  else {
-    int cnt; const int xs = px & 3, ys = py & 3;
+// the count of TComTrQuant.cpp:2740-2760 by significance pattern and position inside the group, two bits per (ys, xs): one 32-bit constant per pattern
+constexpr unsigned sig_cnt_table(int pat)
+{
+  unsigned t = 0;
+  for (int ys = 0; ys < 4; ys++) for (int xs = 0; xs < 4; xs++) {
+    int cnt = 2;
     if (pat == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
     else if (pat == 1) cnt = (ys >= 2) ? 0 : ((ys >= 1) ? 1 : 2);
     else if (pat == 2) cnt = (xs >= 2) ? 0 : ((xs >= 1) ? 1 : 2);
     else cnt = 2;
-    const int not_first = ((px >> 2) + (py >> 2)) > 0;
-    offset = (not_first ? (cp.ch ? 0 : 3) : 0) + cnt;
+    t |= (unsigned)cnt << (2 * (ys * 4 + xs));
   }
-  return cp.first_sig_ctx + offset;
+  return t;
+}
+DEV int sig_ctx_inc_xy(const CParam &cp, int pat, int px, int py)
+{ // sig_ctx_inc from the block coordinates of the position; per-lane pattern and position: selects, no branches (the branches were EXEC-masked regions, ~35 instructions)
+  int offset;
+  if (cp.log2 == 2) offset = tb().t_ctx_map4[4 * py + px];       // (wave-uniform)
+  else {
+    constexpr unsigned T0 = sig_cnt_table(0), T1 = sig_cnt_table(1), T2 = sig_cnt_table(2), T3 = sig_cnt_table(3);
+    const unsigned tbl = pat == 0 ? T0 : (pat == 1 ? T1 : (pat == 2 ? T2 : T3));
+    const int cnt = (int)((tbl >> (2 * (((py & 3) << 2) | (px & 3)))) & 3u);
+    const int not_first = ((px | py) >> 2) != 0;
+    offset = ((not_first && !cp.ch) ? 3 : 0) + cnt;
+  }
+  return (px | py) == 0 ? 0 : cp.first_sig_ctx + offset;
 }
 DEV ScanFn scan_of(const LSmem &s, int type, int log2n)
 {
@@ -994,10 +1023,11 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   // the rate of every group's significance flag as it entered the cost (read again by the last-position search) is one of four values -- flag 0 / 1 under context 0 / 1 --
   // or nothing: three masks over the groups (bit = index in scan order) instead of an array of costs
   unsigned long long cgs_set = 0, cgs_ctx = 0, cgs_one = 0;
-  auto level_double = [&](int blk) -> int32_t {
-    const long long tmpl = (long long)abs(src[blk]) * qcoef, lim = 0x7fffffffll - (1ll << (qbits - 1));
-    return (int32_t)(tmpl < lim ? tmpl : lim);
-  };
+  // lLevelDouble = min(|coefficient| * quantiser scale, MAX_INT - (1 << (qbits - 1))) (TComTrQuant.cpp:2180-2183): the product of a 16-bit coefficient (<= 32768) and a
+  // scale <= 26214 is below 2^30, the limit at least 2^31 - 1 - 2^26 (qbits <= 27 at every bit depth, QP and TU size of this path): the minimum never binds and
+  // everything fits 32 bits -- one v_mul_u32_u24 instead of a 64-bit multiply, compare and select per use
+  static_assert(14 + (51 + QP_BD_OFFSET) / 6 + (15 - BD - 2) <= 27, "qbits");
+  auto level_double = [&](int blk) -> int32_t { return (int32_t)__umul24((unsigned)abs((int)src[blk]), (unsigned)qcoef); };
   auto cost0_of = [&](int blk) -> double { const double d = (double)level_double(blk); return d * d * err_scale; };
 #if defined(HEVCDL_MICRO_T)
   unsigned long long mt_[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1014,7 +1044,7 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
     if (sp < ncoef) {
       const int blk = scan[sp];
       const int32_t ld = level_double(blk);
-      uint32_t m = (uint32_t)(((long long)ld + (1ll << (qbits - 1))) >> qbits);
+      uint32_t m = ((uint32_t)ld + (1u << (qbits - 1))) >> qbits;          // (< 2^30 + 2^26: no carry out of 32 bits)
       if (m > 32767u) m = 32767u;
       dst[blk] = (int16_t)m; ma = (int)m;
     }
@@ -1496,21 +1526,39 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
   const int scan_last = wave_max_i(my_last);
   if (scan_last < 0) return;                                    // never called for an empty TU (cbf checked by the caller)
   wsync();
-  int cx0 = c->ctx[lane], cx1 = c->ctx[64 + lane], cx2 = c->ctx[128 + (lane & 31)];
+  // The coefficient contexts of one channel type fit TWO registers whose member is known where a bin is coded (no choice of register at run time):
+  //   A = contexts [BA, BA + 64), BA = 19 (luma) / 21 (chroma): significant-group flags (19..20 / 21..22), significance (23..49 / 51..66), last x (67..81 / 82..84: a chroma TU is at most 16 wide)
+  //   B = contexts [97, 160): last y (97..111 / 112..115), greater-1 (127..142 / 143..150), greater-2 (151..154 / 155..156), transform skip (157 / 158)
+  constexpr int BB = 97;
+  const int BA = ch ? 21 : 19;
+  static_assert(CTX_SIG_CG == 19 && CTX_LAST_X + 15 == 82 && CTX_LAST_Y == 97 && NUM_CTX <= BB + 64 && CTX_LAST_X + 15 + 2 < 21 + 64 && CTX_LAST_X + 14 < 19 + 64, "context windows of code_coeff_wave");
+  int cxa = c->ctx[BA + lane], cxb = c->ctx[BB + (lane < 63 ? lane : 62)];
   const int eb0 = tb().t_ebits[lane], eb1 = tb().t_ebits[64 + lane];
   const int nx = (int)((unsigned)tb().t_next[0][lane] | ((unsigned)tb().t_next[0][64 + lane] << 8) | ((unsigned)tb().t_next[1][lane] << 16) | ((unsigned)tb().t_next[1][64 + lane] << 24));
   unsigned long long frac;
   { const unsigned long long f = c->frac; frac = ((unsigned long long)(unsigned)uni((int)(f >> 32)) << 32) | (unsigned)uni((int)f); }
-  auto bin = [&](int ctx, int b) { // TEncBinCABACCounter::encodeBin TEncBinCoderCABACCounter.cpp:90-105
-    int st;
-    if (ctx < 64) st = __builtin_amdgcn_readlane(cx0, ctx); else if (ctx < 128) st = __builtin_amdgcn_readlane(cx1, ctx - 64); else st = __builtin_amdgcn_readlane(cx2, ctx - 128);
-    const int x = st ^ b;
-    frac += (unsigned)(x < 64 ? __builtin_amdgcn_readlane(eb0, x) : __builtin_amdgcn_readlane(eb1, x - 64));
-    const int nxt = (__builtin_amdgcn_readlane(nx, st & 63) >> (((st >> 6) << 3) + (((st & 1) == b) ? 16 : 0))) & 0xff;
-    if (ctx < 64) cx0 = (lane == ctx) ? nxt : cx0; else if (ctx < 128) cx1 = (lane == ctx - 64) ? nxt : cx1; else cx2 = (lane == ctx - 128) ? nxt : cx2;
+  auto step = [&](int &cx, int l, int b) { // TEncBinCABACCounter::encodeBin TEncBinCoderCABACCounter.cpp:90-105 on the context in lane l of cx; b = 0 / 1, wave-uniform
+    // integer arithmetic only, no conditions: the compiler then keeps the whole bin on the scalar unit (a comparison in here came out as a lane mask, a v_cndmask to
+    // turn it back into a number and two branches: ~35 instructions and six branches a bin before, ~20 and none now)
+    const int st = __builtin_amdgcn_readlane(cx, l);
+    const int x = st ^ b, xl = x & 63;
+    const int e0 = __builtin_amdgcn_readlane(eb0, xl), e1 = __builtin_amdgcn_readlane(eb1, xl);
+    frac += (unsigned)(e0 + ((x >> 6) & 1) * (e1 - e0));
+    const int w = __builtin_amdgcn_readlane(nx, st & 63);
+    const int nxt = (w >> (((st >> 6) << 3) + (((x & 1) ^ 1) << 4))) & 0xff;        // bytes: [0] / [1] LPS transition of states 0..63 / 64..127, [2] / [3] the MPS one (taken when bin == MPS = st & 1)
+    // (this clang has no writelane builtin.  Both scalar operands are results of scalar instructions here -- the lane-select hazard of v_writelane is about SGPRs written
+    //  by VALU instructions --; the s_nop covers it all the same: inline assembly is outside the compiler's hazard pass)
+    // (one SGPR per VALU instruction on gfx9: the lane select goes through M0 -- which nothing else in this file uses (checked in the assembly); it is named as
+    //  clobbered all the same, and the compiler's warning that it treats M0 as reserved is silenced for this statement)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(cx) : "s"(nxt), "s"(l) : "m0");
+#pragma clang diagnostic pop
   };
+  auto bin_a = [&](int ctx, int b) { step(cxa, ctx - BA, b); };
+  auto bin_b = [&](int ctx, int b) { step(cxb, ctx - BB, b); };
   auto ep = [&](int cnt) { frac += 32768ull * (unsigned long long)cnt; };
-  if (n == 4) bin(CTX_TSKIP + ch, tskip_flag);                  // codeTransformSkipFlags :997-1032
+  if (n == 4) bin_b(CTX_TSKIP + ch, tskip_flag);                // codeTransformSkipFlags :997-1032
   { // codeLastSignificantXY TEncSbac.cpp:1051-1113
     const int pos_last = uni(scan[scan_last]);
     int py = pos_last >> log2n, px = pos_last - (py << log2n);
@@ -1518,10 +1566,10 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
     const int gx = uni(tb().t_group_idx[px]), gy = uni(tb().t_group_idx[py]), gmax = uni(tb().t_group_idx[n - 1]); int off, shift, kk;
     last_ctx_params(ch, n, off, shift);
     const int bx = CTX_LAST_X + (ch ? 15 : 0) + off, by = CTX_LAST_Y + (ch ? 15 : 0) + off;
-    for (kk = 0; kk < gx; kk++) bin(bx + (kk >> shift), 1);
-    if (gx < gmax) bin(bx + (kk >> shift), 0);
-    for (kk = 0; kk < gy; kk++) bin(by + (kk >> shift), 1);
-    if (gy < gmax) bin(by + (kk >> shift), 0);
+    for (kk = 0; kk < gx; kk++) bin_a(bx + (kk >> shift), 1);
+    if (gx < gmax) bin_a(bx + (kk >> shift), 0);
+    for (kk = 0; kk < gy; kk++) bin_b(by + (kk >> shift), 1);
+    if (gy < gmax) bin_b(by + (kk >> shift), 0);
     if (gx > 3) ep((gx - 2) >> 1);
     if (gy > 3) ep((gy - 2) >> 1);
   }
@@ -1533,7 +1581,7 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
     const int cgblk = uni(scan_cg[subset]), gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
     int cg_sig;
     if (subset == last_set || subset == 0) { wsync(); if (lane == 0) cgf[cgblk] = 1; wsync(); cg_sig = 1; }
-    else { cg_sig = uni(cgf[cgblk]) != 0; bin(cg_off + uni(sig_cg_ctx(cgf, gx, gy, cp.wg)), cg_sig); }
+    else { cg_sig = uni((int)cgf[cgblk]) & 1; bin_a(cg_off + uni(sig_cg_ctx(cgf, gx, gy, cp.wg)), cg_sig); }
     if (!cg_sig) continue;
     // lane-parallel: the 16 positions of the group
     const int j = lane & 15, sp_j = sub_pos + j, blk_j = scan[sp_j];
@@ -1545,7 +1593,7 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
     if (subset == last_set) { num_nz = 1; jstart = (scan_last & 15) - 1; }
     for (int jj = jstart; jj >= 0; jj--) {
       const int sig = (sigmask >> jj) & 1;
-      if (jj > 0 || subset == 0 || num_nz) bin(__builtin_amdgcn_readlane(sigctx_j, jj), sig);
+      if (jj > 0 || subset == 0 || num_nz) bin_a(__builtin_amdgcn_readlane(sigctx_j, jj), sig);
       num_nz += sig;
     }
     if (num_nz > 0) {
@@ -1556,12 +1604,12 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
       int escape = 0, abs_c2 = -1; unsigned m = sigmask;
       for (int i = 0; i < 8 && m; i++) { // greater-1 flags of the first 8 levels, highest scan position first
         const int p = 31 - __clz((int)m); m &= ~(1u << p);
-        const int av = __builtin_amdgcn_readlane(abs_j, p), sym = av > 1;
-        bin(CTX_ONE + 4 * cset + c1, sym);
+        const int av = __builtin_amdgcn_readlane(abs_j, p), sym = min(av - 1, 1);      // av > 1 as a number (av >= 1 here): s_min, not a comparison (see step)
+        bin_b(CTX_ONE + 4 * cset + c1, sym);
         if (sym) { c1 = 0; if (abs_c2 < 0) abs_c2 = av; else escape = 1; }
         else if (c1 < 3 && c1 > 0) c1++;
       }
-      if (c1 == 0 && abs_c2 >= 0) { const int sym = abs_c2 > 2; bin(CTX_ABS + cset, sym); if (sym) escape = 1; }
+      if (c1 == 0 && abs_c2 >= 0) { const int sym = min(abs_c2 - 2, 1) /* abs_c2 > 2; abs_c2 >= 2 here */; bin_b(CTX_ABS + cset, sym); if (sym) escape = 1; }
       escape = escape || (num_nz > 8);
       ep(sign_hidden ? num_nz - 1 : num_nz);
       if (escape) {
@@ -1586,7 +1634,7 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
     }
   }
   wsync();
-  c->ctx[lane] = (uint8_t)cx0; c->ctx[64 + lane] = (uint8_t)cx1; if (lane < 32) c->ctx[128 + lane] = (uint8_t)cx2;
+  c->ctx[BA + lane] = (uint8_t)cxa; if (lane < 63) c->ctx[BB + lane] = (uint8_t)cxb;       // (the windows overlap nowhere: BA + 63 <= 84 < BB)
   if (lane == 0) c->frac = frac;
   wsync();
 }
@@ -1821,7 +1869,12 @@ DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 // TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved, 3 predict and write the
 // reconstruction to the layer only: a first-pass candidate of a PU coded as one TU -- nothing reads its picture samples)
 // ---------------------------------------------------------------------------------------------------
-DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
+#ifdef HEVCDL_INLINE_TU
+DEV
+#else
+DEVN
+#endif
+uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
 {
   CHECK_EXEC(1);
   PROF_T0();
@@ -1842,6 +1895,8 @@ DEVN uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mod
   } else { wsync(); if (lane_id() < 16) s.pred[lane_id()] = s.ts_pred[comp][lane_id()]; }
   wsync();
   PROF_MARK(24);
+  // (asking for the original samples ahead of the prediction -- four registers a lane for TUs up to 16x16, used in the residual and again in the distortion loop --
+  //  measured WORSE: 600 frames 6.06 -> 6.12 s; the registers cost more than the round trip)
   GLB const pel_t *org = k.org[comp] + (size_t)y * ps + x;
   for (int i = lane_id(); i < n * n; i += 64) s.resi[(i >> log2n) * RS(n) + (i & (n - 1))] = (int16_t)((int)org[(size_t)(i >> log2n) * ps + (i & (n - 1))] - (int)s.pred[i]);
   if (!comp) set_parts(k, s.a[A_TRIDX], zabs, tu.nparts, tu.trd);
@@ -1945,7 +2000,7 @@ DEV void chroma_mode_list(int luma_mode, uint32_t (&mode_list)[5])
 DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_);
 DEVN void region_run(KR k, LRegion &r);
 DEV void region_close(LRegion &r) { }
-DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); }         // one more task (parameters written before)
+DEV void region_publish(LRegion &r) { wg_release(); lds_add(&r.ticket, 1 << 16); ring_bell(); }         // one more task (parameters written before)
 DEVN int remote_poll(LRegion &r);
 DEVN int remote_room(int need = 1);
 DEVN void chroma_post(KR k, const Cu cu_, const Tu tu_, int m0, int m1, int m2, int m3, int m4, int prepare_only);
@@ -2741,6 +2796,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
         wsync();
         wg_release();
         if (lane_id() == 0) __hip_atomic_store(&r.ticket, (nfull << 16) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nfull > c) ring_bell();
         region_run(k, r);
         // the bit counts of the candidates coded ahead, from the fractional bits the CU really starts with
         const unsigned long long f0t = s.curr[cu.depth].frac & 32767ull, f0s = (unsigned long long)s.ahead_f0;
@@ -2964,6 +3020,7 @@ DEVN void region_open(LRegion &r, int kind_, int n_, const Cu cu_, const Tu tu_)
   wsync();
   wg_release();                                              // the master's arrays, snapshots and picture writes before the ticket
   if (lane_id() == 0) __hip_atomic_store(&r.ticket, n << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (n > 0) ring_bell();
 }
 
 // a helper takes over the master's view of the CTU: kernel context + attribute arrays (the coder snapshot a task starts from is
@@ -4176,7 +4233,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
     init_tables(sh.tab);
     if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m;
-                     sh.quit = 0; sh.remote = p.remote; sh.sched = (GLB unsigned char *)p.sched; }
+                     sh.quit = 0; sh.bell = 0; sh.remote = p.remote; sh.sched = (GLB unsigned char *)p.sched; }
   }
 #ifdef HEVCDL_KERNEL_PROF
   s.my_prof = (blockIdx.x == 0 && p.dbgbuf) ? (GLB unsigned long long *)(p.dbgbuf + 2) : nullptr; if (lane == 0) s.prof_task = 0;
@@ -4185,6 +4242,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   __syncthreads();
   if (p.remote && (int)blockIdx.x >= n_units) { // a workgroup without units: wave 0 takes second passes other workgroups post, the other waves serve its regions
     if (wave == 0 && lane == 0) __hip_atomic_fetch_add(rq_idle((GLB unsigned char *)p.sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int seen = -1;
     for (;;) {
       if (wave == 0) {
         if (glb_load(sched_finished(p)) >= n_units) { wsync(); if (lane == 0) __hip_atomic_store(&sh.quit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
@@ -4193,17 +4251,26 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
         if (!remote_serve((GLB unsigned char *)p.sched)) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
       } else {
         if (lds_load(&sh.quit)) break;
-        if (!helper_step()) __builtin_amdgcn_s_sleep(32);
+        const int b = lds_load(&sh.bell);                       // (see ring_bell: the tickets are walked only when tasks were put up since the last walk that found none)
+        if (HELPER_BELL && b == seen) { __builtin_amdgcn_s_sleep(HEVCDL_IDLE_SLEEP); continue; }
+        if (!helper_step()) { seen = b; __builtin_amdgcn_s_sleep(HELPER_BELL ? HEVCDL_IDLE_SLEEP : 32); }
       }
     }
     return;
   }
   // a wave walks a unit (master) or serves the workgroup's regions (helper); with p.migrate units arrive and leave through the mailboxes
   int unit = first < n_units ? first : -1, i_resume = -1;
+  int seen = -1, since_check = 0;          // seen: the doorbell's count when this wave last walked the tickets and found no task (ring_bell)
   for (;;) {
     if (unit >= 0) {
       PROF_T0();
+#ifdef HEVCDL_MASTER_PRIO
+      __builtin_amdgcn_s_setprio(HEVCDL_MASTER_PRIO);          // experiment: the wave that walks a unit wins the issue arbitration of its SIMD against the wave it shares it with
+#endif
       const int moved = process_unit(p, unit, i_resume);
+#ifdef HEVCDL_MASTER_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       PROF_ADD(0, 31);
       int next = -1;
       if (!moved) {
@@ -4215,17 +4282,25 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       if (unit < 0) { wg_release(); lds_add(&sh.masters_active, -1); }
       continue;
     }
-    if (p.migrate) {
-      if (glb_load(sched_finished(p)) >= n_units) break;
-      GLB Mbox *mb = sched_mbox(p, (int)blockIdx.x);
-      if (glb_load(&mb->state) == 1 && glb_cas(&mb->state, 1, 3)) { // a unit handed over by the previous workgroup of the ring
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        unit = uni(mb->unit); i_resume = uni(mb->next_i);
-        lds_add(&sh.masters_active, 1);
-        continue;
+    if (p.migrate) { // (two round trips to HBM: behind every task, and every fourth look of a wave that has none)
+      if (!HELPER_BELL || since_check <= 0) {
+        since_check = 4;
+        if (glb_load(sched_finished(p)) >= n_units) break;
+        GLB Mbox *mb = sched_mbox(p, (int)blockIdx.x);
+        if (glb_load(&mb->state) == 1 && glb_cas(&mb->state, 1, 3)) { // a unit handed over by the previous workgroup of the ring
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          unit = uni(mb->unit); i_resume = uni(mb->next_i);
+          lds_add(&sh.masters_active, 1);
+          continue;
+        }
       }
+      since_check--;
     } else if (lds_load(&sh.masters_active) <= 0) break;
-    { PROF_T0(); if (!helper_step()) { __builtin_amdgcn_s_sleep(32); PROF_ADD(0, 23); } }
+    { PROF_T0();
+      const int b = lds_load(&sh.bell);
+      if (HELPER_BELL && b == seen) { __builtin_amdgcn_s_sleep(HEVCDL_IDLE_SLEEP); PROF_ADD(0, 23); }
+      else if (helper_step()) since_check = 0;
+      else { seen = b; __builtin_amdgcn_s_sleep(HELPER_BELL ? HEVCDL_IDLE_SLEEP : 32); PROF_ADD(0, 23); } }
   }
 #ifdef HEVCDL_KERNEL_PROF
   // in-kernel timers of workgroup 0, summed over its waves (masters and helpers): the host decodes the accumulators (tools/phase_profile.py)

@@ -298,6 +298,15 @@ hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n
                                        void *d_records, void *d_recon, void *d_stats, void *stream);
 
 /* kernel timing with HIP events recorded on the launch stream */
+/* Which build of the decision kernel and which launch form the context's last decision launch took, as text:
+ * "hevcdl_rd_frame_kernel[_wide|_bd10] form=independent|unit-handover|few-units(...) workgroups=N waves=N units=N" ("" before the first launch).  The selection
+ * rule lives in one place (launch_rd); bench.py reports this instead of restating the rule. */
+const char   *hevcdl_last_rd_launch(const hevcdl_ctx *ctx);
+/* The decision kernel's workspace is allocated by the first launch that needs it (megabytes for a frame in the independent form, 3.4 - 4.3 GB for a launch on every
+ * CU) and a launch that cannot get it returns HEVCDL_ERR_OOM; the first launch of a larger shape also synchronises the device while the workspace grows.  This call
+ * allocates the largest workspace any launch of the context (1 .. max_frames frames) can ask for, so that a lack of memory shows up here -- the CLI calls it right
+ * behind hevcdl_create and retries with a smaller batch -- and no later launch allocates or synchronises. */
+hevcdl_status hevcdl_reserve_workspace(hevcdl_ctx *ctx);
 hevcdl_status hevcdl_profile_enable(hevcdl_ctx *ctx, int enable);
 hevcdl_status hevcdl_profile_get(hevcdl_ctx *ctx, hevcdl_profile *out);   /* synchronises, returns and resets */
 

@@ -149,6 +149,8 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
     for tag, extra in (("one", []), ("two", ["--Devices=0,0"]), ("three", ["--Devices", "0,0,0", "--BatchFrames=1"]), ("four", ["--Devices", "0,0,0,0"]), ("seven", ["--Devices", "0,0,0,0,0,0,0"])):
         r = run(app, base + ["-b", tag + ".bin", "-o", tag + ".yuv", "--RecordFile=" + tag + ".rec"] + extra, tmp_path)
         assert r.returncode == 0, r.stdout + r.stderr
+        if extra:      # the rows of the log came through librccl: the collective ran, over one rank per PHYSICAL device (here one), and the communicator says so itself
+            assert "Picture rows gathered: ncclAllGather over 1 rank (ncclCommCount 1," in r.stderr and "one rank per physical device: 0)" in r.stderr, r.stderr
         log = [l.rsplit(" [ET", 1)[0] + l[l.index("[MD5:"):] for l in r.stdout.splitlines() if l.startswith("POC")]
         summary = r.stdout[r.stdout.index("SUMMARY"):]
         outs.append(((tmp_path / (tag + ".bin")).read_bytes(), (tmp_path / (tag + ".yuv")).read_bytes(), (tmp_path / (tag + ".rec")).read_bytes(), log, summary, r.stdout))

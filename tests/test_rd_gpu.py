@@ -44,6 +44,23 @@ def test_golden_records_bit_exact(path):
             assert np.array_equal(y, f["rec_y"][fr, a]) and np.array_equal(u, f["rec_cb"][fr, a]) and np.array_equal(v, f["rec_cr"][fr, a]), (fr, a)
 
 
+def test_workspace_reserved_up_front_changes_nothing_and_names_the_launch():
+    """hevcdl_reserve_workspace (the CLI calls it right behind hevcdl_create so that a lack of device memory shows up before pictures are in flight): the largest workspace
+    of the context is allocated at once; the launches behind it give the fixture's records, and hevcdl_last_rd_launch names the build and the form the library chose."""
+    import hevcdl_amd
+    f = np.load(os.path.join(GOLD, "rd_c192_q32_r2.npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=2)
+    assert enc.last_rd_launch() == ""
+    enc.reserve_workspace()
+    enc.reserve_workspace()                                # (a second call finds it there)
+    recs, recon, stats = enc.compress_frames(f["yuv"], f["labels"])
+    info = enc.last_rd_launch()
+    enc.close()
+    assert_records_equal(recs, f["records"], "reserved workspace")
+    assert info.startswith("hevcdl_rd_frame_kernel form=") and "units=2" in info and "waves=8" in info, info
+
+
 @pytest.mark.parametrize("flags", [2, 4], ids=["ten-wave-build", "eight-wave-build"])
 @pytest.mark.parametrize("path", [p for p in sorted(glob.glob(os.path.join(GOLD, "rd_*.npz"))) if not os.path.basename(p).startswith("rd_x") and "_b10" not in os.path.basename(p)], ids=lambda p: os.path.basename(p)[3:-4])
 def test_golden_records_bit_exact_on_either_build_of_the_kernel(path, flags):
@@ -208,6 +225,9 @@ def test_bench_two_ranks_on_one_gpu_give_the_single_rank_line(tmp_path):
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "strong"
     assert two["config"]["frames"] == one["config"]["frames"] == 6 and two["config"]["frames_per_gpu"] == 3
     assert two["est_bits_per_frame"] == one["est_bits_per_frame"] and one["est_bits_per_frame"] > 0
+    # the collective spans both ranks (every rank adds one in an all-reduce: the driver's SCALE record can be checked by this key) and every frame's record arrived
+    assert two["rccl_ranks"] == 2 and one["rccl_ranks"] == 1 and two["frames_gathered"] == 6 and two["collective_backend"] == "gloo"
+    assert one["roofline"]["launch"].startswith(one["roofline"]["kernel"] + " form=") and "units=6" in one["roofline"]["launch"] and "units=3" in two["roofline"]["launch"]
     for line in (one, two):
         assert line["value"] > 0 and line["latency_floor_s"] > 0 and line["strong_scaling_ceiling"]["value"] > 0 and "roofline" in line
 
@@ -317,10 +337,12 @@ def test_few_units_form_equals_the_independent_form(nf, tiles):
             assert np.array_equal(out[0][2][k], o[2][k]), k
 
 
-def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built):
+@pytest.mark.parametrize("flags", [0, 2], ids=["library-chosen-build", "ten-wave-build-forced"])
+def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built, flags):
     """600 frames on 256 workgroups do not divide evenly: the surplus frames travel round the ring of workgroups (a frame is handed over at a CTU
     boundary: position + coder state).  The launch that migrates must give, frame by frame, what launches without migration give (<= one frame
-    per workgroup), and a sample of frames must equal the oracle."""
+    per workgroup), and a sample of frames must equal the oracle.  exec_flags 2 (HEVCDL_EXEC_RD_WIDE): the same with the ten-wave build of the kernel, a pair the
+    library's own choice never makes (ten waves from four units per workgroup on, hand-over up to three) but the public flag allows."""
     import hevcdl_amd
     import ref_tools
     w, h, qp, nf = 512, 256, 33, 600                       # 32 CTUs per frame: two hand-over points per frame
@@ -328,8 +350,11 @@ def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built)
     rng = np.random.default_rng(3)
     yuv = np.stack([np.clip(base[i % 8].astype(np.int16) + rng.integers(-2, 3, base.shape[1]) * (1 + i % 3), 0, 255).astype(np.uint8) for i in range(nf)])
     labels = ref_tools.make_labels(w, h, nf, "rand", 5)
-    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=nf)
+    cfg.exec_flags = flags
+    enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
     recs, recon, stats = enc.compress_frames(yuv, labels)               # 600 units on min(600, CUs) workgroups: migrates
+    assert "form=unit-handover" in enc.last_rd_launch() and ("_wide " in enc.last_rd_launch()) == (flags == 2), enc.last_rd_launch()
     parts = [enc.compress_frames(yuv[a:a + 200], labels[a:a + 200]) for a in range(0, nf, 200)]      # 200 units: one per workgroup
     enc.close()
     recs2 = np.concatenate([p[0] for p in parts]); recon2 = np.concatenate([p[1] for p in parts]); stats2 = np.concatenate([p[2] for p in parts])
