@@ -791,7 +791,10 @@ template <int N, bool DST> DEV void fwd_transform_n(KR k)
 template <int N, bool DST> DEV void inv_transform_n(KR k)
 { // s->tc (dequantised, raster) -> s->resi (stride RS); xITrMxN TComTrQuant.cpp:927-987
   LSmem &s = lds();
-  LDS int16_t *tmp_ = s.lvl + 16;
+  // the intermediate of a transform up to 16 x 16 (544 bytes) lies in RDOQ's addend area, dead outside rdoq_wave: the TU's LEVELS in s.lvl then survive the inverse
+  // transform, and the bit count that follows every coding (luma_tu_bits) reads them there instead of fetching them back from the layer buffer in HBM
+  static_assert(16 * 17 * 2 <= sizeof(s.chainb), "inverse-transform intermediate");
+  LDS int16_t *tmp_ = N <= 16 ? (LDS int16_t *)&s.chainb[0][0] : s.lvl + 16;
   if (lane_id() < N) {
     int c[N], x[N];
 #pragma unroll
@@ -1509,23 +1512,31 @@ DEV void dequant(KR k, int c_, int n_)
 // v_readlane / v_cndmask and scalar operations instead of five dependent LDS round trips.  Everything a bin
 // needs from the coefficients (significance, context increments, magnitudes of a coefficient group) is computed
 // lane-parallel first; control flow is wave-uniform.
-DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_)
+// pre_: bins coded in front of the coefficients, on contexts below 19 (the CU / TU header flags of a bit count: part size, prev_intra_luma_pred, transform subdivision, cbf)
+// -- up to four, packed six bits each from bit 0: context (5 bits) | value << 5, 63 = none; bits 24..27: bypass bins behind them; bit 28: the bit count starts here
+// (the integer bits are dropped first: reset_bits); bit 29: the TU has coefficients (s.lvl) to count behind the flags.  PRE_COEF | PRE_NONE = coefficients only.
+// The fractional bits the coefficient bins add go to s.cfrac_last when `luma_cfrac` is set.  Returns the coder's integer bits.
+constexpr int PRE_NONE = 0xffffff, PRE_EP_SHIFT = 24, PRE_RESET = 1 << 28, PRE_COEF = 1 << 29;
+DEVN uint32_t code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_ = PRE_COEF | PRE_NONE, int luma_cfrac_ = 0)
 {
-  const int comp = uni(comp_), n = uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_);
+  const int comp = uni(comp_), n = uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_), pre = uni(pre_), luma_cfrac = uni(luma_cfrac_);
   LSmem &s = lds();
   const int lane = lane_id(), ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
   const int log2n = cp.log2, ncoef = n * n;
   LDS const int16_t *coef = s.lvl; const ScanFn scan = scan_of(s, cp.scan_type, log2n); LDS const uint8_t *scan_cg = scan_cg_of(s, cp.scan_type, log2n);
   LDS uint8_t *cgf = s.cgf;
-  cgf[lane] = 0;
-  wsync();
-  // last significant scan position and the significant-CG flags (TEncSbac.cpp:1170-1200)
-  int my_last = -1;
-  for (int sp = lane; sp < ncoef; sp += 64) if (coef[scan[sp]] != 0) { my_last = sp; cgf[scan_cg[sp >> 4]] = 1; }
-  const int scan_last = wave_max_i(my_last);
-  if (scan_last < 0) return;                                    // never called for an empty TU (cbf checked by the caller)
-  wsync();
+  int scan_last = -1;
+  if (pre & PRE_COEF) {
+    cgf[lane] = 0;
+    wsync();
+    // last significant scan position and the significant-CG flags (TEncSbac.cpp:1170-1200)
+    int my_last = -1;
+    for (int sp = lane; sp < ncoef; sp += 64) if (coef[scan[sp]] != 0) { my_last = sp; cgf[scan_cg[sp >> 4]] = 1; }
+    scan_last = wave_max_i(my_last);
+    if (scan_last < 0 && (pre & PRE_NONE) == PRE_NONE && !(pre & PRE_RESET)) return uni((int)get_bits(c));      // never called for an empty TU (cbf checked by the caller)
+    wsync();
+  }
   // The coefficient contexts of one channel type fit TWO registers whose member is known where a bin is coded (no choice of register at run time):
   //   A = contexts [BA, BA + 64), BA = 19 (luma) / 21 (chroma): significant-group flags (19..20 / 21..22), significance (23..49 / 51..66), last x (67..81 / 82..84: a chroma TU is at most 16 wide)
   //   B = contexts [97, 160): last y (97..111 / 112..115), greater-1 (127..142 / 143..150), greater-2 (151..154 / 155..156), transform skip (157 / 158)
@@ -1533,10 +1544,12 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
   const int BA = ch ? 21 : 19;
   static_assert(CTX_SIG_CG == 19 && CTX_LAST_X + 15 == 82 && CTX_LAST_Y == 97 && NUM_CTX <= BB + 64 && CTX_LAST_X + 15 + 2 < 21 + 64 && CTX_LAST_X + 14 < 19 + 64, "context windows of code_coeff_wave");
   int cxa = c->ctx[BA + lane], cxb = c->ctx[BB + (lane < 63 ? lane : 62)];
+  int cxh = c->ctx[lane < 19 ? lane : 18];                      // H = contexts [0, 19): the header flags (its own register: the windows do not overlap)
   const int eb0 = tb().t_ebits[lane], eb1 = tb().t_ebits[64 + lane];
   const int nx = (int)((unsigned)tb().t_next[0][lane] | ((unsigned)tb().t_next[0][64 + lane] << 8) | ((unsigned)tb().t_next[1][lane] << 16) | ((unsigned)tb().t_next[1][64 + lane] << 24));
   unsigned long long frac;
   { const unsigned long long f = c->frac; frac = ((unsigned long long)(unsigned)uni((int)(f >> 32)) << 32) | (unsigned)uni((int)f); }
+  if (pre & PRE_RESET) frac &= 32767ull;
   auto step = [&](int &cx, int l, int b) { // TEncBinCABACCounter::encodeBin TEncBinCoderCABACCounter.cpp:90-105 on the context in lane l of cx; b = 0 / 1, wave-uniform
     // integer arithmetic only, no conditions: the compiler then keeps the whole bin on the scalar unit (a comparison in here came out as a lane mask, a v_cndmask to
     // turn it back into a number and two branches: ~35 instructions and six branches a bin before, ~20 and none now)
@@ -1558,6 +1571,11 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
   auto bin_a = [&](int ctx, int b) { step(cxa, ctx - BA, b); };
   auto bin_b = [&](int ctx, int b) { step(cxb, ctx - BB, b); };
   auto ep = [&](int cnt) { frac += 32768ull * (unsigned long long)cnt; };
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const int e = (pre >> (6 * q)) & 63; if (e != 63) step(cxh, e & 31, e >> 5); }
+  ep((pre >> PRE_EP_SHIFT) & 15);
+  const unsigned long long frac_hdr = frac;
+  if (scan_last >= 0) {
   if (n == 4) bin_b(CTX_TSKIP + ch, tskip_flag);                // codeTransformSkipFlags :997-1032
   { // codeLastSignificantXY TEncSbac.cpp:1051-1113
     const int pos_last = uni(scan[scan_last]);
@@ -1633,10 +1651,13 @@ DEVN void code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int
       }
     }
   }
+  }
   wsync();
-  c->ctx[BA + lane] = (uint8_t)cxa; if (lane < 63) c->ctx[BB + lane] = (uint8_t)cxb;       // (the windows overlap nowhere: BA + 63 <= 84 < BB)
-  if (lane == 0) c->frac = frac;
+  c->ctx[BA + lane] = (uint8_t)cxa; if (lane < 63) c->ctx[BB + lane] = (uint8_t)cxb;       // (the windows overlap nowhere: 18 < BA, BA + 63 <= 84 < BB)
+  if (lane < 19) c->ctx[lane] = (uint8_t)cxh;
+  if (lane == 0) { c->frac = frac; if (luma_cfrac) s.cfrac_last = frac - frac_hdr; }
   wsync();
+  return (uint32_t)(frac >> 15);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1773,6 +1794,45 @@ DEV void enc_intra_header(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma,
     else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel % q) == 0) code_luma_dirs(k, c, cu, tu.zrel / q, 1); }
   }
   if (chroma && tu.zrel == 0) code_chroma_dir(k, c, cu);
+}
+// xGetIntraBitsQT (TEncSearch.cpp:1093-1117), luma only, of a TU that has just been coded as ONE transform block (tr_idx == tu.trd over its partitions: the unsplit
+// alternative of recur_luma, a first-pass candidate, a child of the chain in spec_children) -- what intra_bits_qt<LOG2>(k, cu, tu, 1, 0) counts there, as one pass of the
+// register-resident coder: the header flags (xEncIntraHeader :1018-1087, xEncSubdivCbfQT :907-972) are bins in front of the coefficients (code_coeff_wave) instead of
+// three dependent LDS round trips each on lane 0, and the levels are read where code_tu_block left them (lvl_in_lds: TUs up to 16x16, see inv_transform_n) instead of
+// coming back from the layer buffer.  Same bins, same contexts, same order per context; leaves `go` and s.cfrac_last as intra_bits_qt does.
+DEVN uint32_t luma_tu_bits(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_)
+{
+  CHECK_EXEC(11);
+  PROF_T0();
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int lvl_in_lds = uni(lvl_in_lds_);
+  LSmem &s = lds();
+  const int z = cu.zbase + tu.zrel, n = 1 << tu.log2;
+  int pre = PRE_NONE, nb = 0, nep = 0;
+  auto add = [&](int ctx, int v) { pre = (pre & ~(63 << (6 * nb))) | ((ctx | (v << 5)) << (6 * nb)); nb++; };
+  wsync();
+  if (tu.zrel == 0 && cu.depth == 3) add(CTX_PART_SIZE, cu.part == SIZE_2Nx2N ? 1 : 0);
+  int pu = -1;
+  if (cu.part == SIZE_2Nx2N) { if (tu.zrel == 0) pu = 0; }
+  else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel % q) == 0) pu = tu.zrel / q; }
+  if (pu >= 0) { // code_luma_dirs for this one PU (codeIntraDirLumaAng TEncSbac.cpp:643-696)
+    const int pu_size = (cu.part == SIZE_NxN) ? (1 << (cu.log2 - 1)) : (1 << cu.log2);
+    const int px = cu.x + (pu & 1) * pu_size, py = cu.y + (pu >> 1) * pu_size;
+    const int dir = uni(s.a[A_LDIR][cu.zbase + pu * (cu.nparts >> 2) * (cu.part == SIZE_NxN)]);
+    int preds[3]; get_mpm(k, px, py, preds, nullptr);
+    int idx = -1;
+    for (int i = 0; i < 3; i++) if (dir == uni(preds[i])) idx = i;
+    add(CTX_INTRA_PRED, idx != -1 ? 1 : 0);
+    nep = idx != -1 ? (idx ? 2 : 1) : 5;
+  }
+  if (!(cu.part == SIZE_NxN && tu.trd == 0) && tu.log2 <= 5 && tu.log2 != 2 && tu.log2 != min_tu_log2(cu)) add(CTX_SUBDIV + 5 - tu.log2, 0);
+  const int cbf = (uni(s.a[A_CBF][z]) >> tu.trd) & 1;
+  add(CTX_QT_CBF + (tu.trd == 0 ? 1 : 0), cbf);
+  const int mode = uni(s.a[A_LDIR][z]), tskip = uni(s.a[A_TSKIP][z]);
+  if (cbf && !lvl_in_lds) load_tu_coef(k, 0, 0, tu.log2, z, n);
+  const uint32_t bits = code_coeff_wave(k, &s.go, 0, n, mode, tskip, pre | (nep << PRE_EP_SHIFT) | PRE_RESET | (cbf ? PRE_COEF : 0), 1);
+  wsync();
+  PROF_ADD_T(k, 10, 49);
+  return bits;
 }
 template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_, int luma_, int chroma_)
 {
@@ -2069,7 +2129,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
         if (m == 1 && cbf == 0) cost = MAX_DOUBLE;
         else {
           if (m == 0) store_ts_result(k, cu, tu, 0);           // before the bit count reuses s->lvl
-          const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0); cost = calc_rd_cost(k, bits, d);
+          const uint32_t bits = luma_tu_bits(k, cu, tu, LOG2 <= 4); cost = calc_rd_cost(k, bits, d);
         }
         if (ub(cost < single_cost)) {
           single_cost = cost; single_dist = d; single_cbf = cbf; best_ts = m; single_cfrac = uni64(s.cfrac_last);
@@ -2088,7 +2148,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, 0); wsync();
       single_dist = code_tu_block(k, cu, tu, 0, (check_first == 2 && !check_split) ? 3 : 0);
       if (check_split) single_cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
-      const uint32_t bits = intra_bits_qt<LOG2>(k, cu, tu, 1, 0);
+      const uint32_t bits = luma_tu_bits(k, cu, tu, LOG2 <= 4);
       single_cost = calc_rd_cost(k, bits, single_dist);
       single_cfrac = uni64(s.cfrac_last);
     }
@@ -2230,7 +2290,7 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       set_parts(k, s.a[A_TSKIP + 0], cu.zbase + ch.zrel, ch.nparts, 0); wsync();
       const uint32_t d = code_tu_block(k, cu, ch, 0, 0);
       const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
-      const uint32_t bits = intra_bits_qt<LOG2 - 1>(k, cu, ch, 1, 0);
+      const uint32_t bits = luma_tu_bits(k, cu, ch, LOG2 - 1 <= 4);
       const double cost = calc_rd_cost(k, bits, d);
       if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; r.cfrac[4 + c] = s.cfrac_last; }
       wsync();
@@ -3161,12 +3221,7 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
     if (one_tu) { // the single-TU branch of recur_luma (first pass: no split to check, no transform-skip trial above 4x4) without its call frame
       set_parts(k, s.a[A_TSKIP + 0], zp, tu.nparts, 0); wsync();
       dc.dist = code_tu_block(k, cu, tu, 0, 3);
-      uint32_t bits;
-      switch (tu.log2) {
-        case 5: bits = intra_bits_qt<5>(k, cu, tu, 1, 0); break;
-        case 4: bits = intra_bits_qt<4>(k, cu, tu, 1, 0); break;
-        default: bits = intra_bits_qt<3>(k, cu, tu, 1, 0); break;
-      }
+      const uint32_t bits = luma_tu_bits(k, cu, tu, tu.log2 <= 4);
       dc.cost = calc_rd_cost(k, bits, dc.dist); dc.cfrac = uni64(s.cfrac_last);
     } else dc = recur_luma_any(k, cu, tu, 1);
     PROF_MARK(51);
