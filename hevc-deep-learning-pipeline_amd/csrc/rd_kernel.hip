@@ -544,11 +544,17 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   LDS int16_t *line_out = ref_line(c);
   const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n / u;
   const int x4 = x >> sh, y4 = y >> sh, total = 4 * nu + 1;
-  // availability of the <= 65 units: lanes 0..63 + unit 64 (only for a 64x64 luma block) on lane 0's second pass
+  // availability of the <= 65 units: lanes 0..63 + unit 64 (only for a 64x64 luma block) on lane 0's second pass.  unit_avail's rule, with the picture / tile
+  // limits read ONCE into scalar registers and the tests combined without branches: as a chain of early returns on fields of the LDS-resident context it came out
+  // as six dependent LDS round trips with a wait and a branch each, three times over (the left column, the corner and the top row took their own copies in turn)
+  const int kW = uni(k.W), kH = uni(k.H), ktx0 = uni(k.tx0), kty0 = uni(k.ty0), ktx1 = uni(k.tx1), kty1 = uni(k.ty1), kcx = uni(k.ctus_x);
+  const int lim_x1 = kW < ktx1 ? kW : ktx1, lim_y1 = kH < kty1 ? kH : kty1;          // (x4 * 4 < W and < tx1, y4 likewise; tx0 / ty0 >= 0)
+  const int ca = (y4 >> 4) * kcx + (x4 >> 4), cz = tb().r2z[((y4 & 15) << 4) | (x4 & 15)];
   auto unit_flag = [&](int kk) -> int {
-    if (kk < 2 * nu) return unit_avail(k, x4 - 1, y4 + (2 * nu - 1 - kk), x4, y4);
-    if (kk == 2 * nu) return unit_avail(k, x4 - 1, y4 - 1, x4, y4);
-    return unit_avail(k, x4 + (kk - 2 * nu - 1), y4 - 1, x4, y4);
+    const int ux = kk < 2 * nu ? x4 - 1 : (kk == 2 * nu ? x4 - 1 : x4 + (kk - 2 * nu - 1)), uy = kk < 2 * nu ? y4 + (2 * nu - 1 - kk) : y4 - 1;
+    const int inside = (int)(ux * 4 >= ktx0) & (int)(uy * 4 >= kty0) & (int)(ux * 4 < lim_x1) & (int)(uy * 4 < lim_y1);      // inside the picture and the tile (another tile is never available)
+    const int a = (uy >> 4) * kcx + (ux >> 4), z = tb().r2z[((uy & 15) << 4) | (ux & 15)];       // (the index stays inside the table for any coordinates)
+    return inside & (a != ca ? (int)(a < ca) : (int)(z < cz));                                    // an earlier CTU of the tile, or earlier z-order in this one (TComDataCU.cpp:985-1200)
   };
   const int f0 = (lane_id() < total) ? unit_flag(lane_id()) : 0;
   const unsigned long long m0 = __ballot(f0);
