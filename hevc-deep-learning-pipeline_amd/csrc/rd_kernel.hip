@@ -155,7 +155,8 @@ __constant__ int8_t c_dct_mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80
 struct __attribute__((aligned(8))) Cabac { uint8_t ctx[160]; unsigned long long frac; };   // 168 bytes
 typedef LDS Cabac LCabac;
 struct Rd { double cost; uint32_t bits, dist; };
-struct DistCost { uint32_t dist; double cost; unsigned long long cfrac; };   // cfrac: fractional bits (<< 15) of the TU tree's coefficient bins
+struct DistCost { uint32_t dist; double cost; unsigned long long cfrac; };
+struct TuRes { uint32_t dist, bits; };      // code_tu_block: distortion, and the TU's bit count where it was asked for   // cfrac: fractional bits (<< 15) of the TU tree's coefficient bins
 struct Cu { int x, y, log2, depth, zbase, nparts, part; };
 struct Tu { int x, y, log2, trd, zrel, nparts; };
 DEV int uni(int v);
@@ -286,8 +287,20 @@ DEV void wsync()
 #define PROF_ACC_(id, d) do { GLB unsigned long long *pp_ = lds().my_prof; if (pp_) __hip_atomic_fetch_add(pp_ + (id), ((unsigned long long)(d) & 0xffffffffffull) + (1ull << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #define PROF_MARK(id) do { if (lane_id() == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); PROF_ACC_(id, n_ - prof_m_); prof_m_ = n_; } else prof_m_ = 0; } while (0)
 #define PROF_ADD(k, id) do { if (lane_id() == 0) { PROF_ACC_(id, __builtin_readcyclecounter() - prof_t0_); } } while (0)
+#if defined(HEVCDL_PROF_GLUE)
+// -DHEVCDL_KERNEL_PROF -DHEVCDL_PROF_N=64 -DHEVCDL_PROF_GLUE (tools/phase_profile.py --glue): the RDOQ phase accumulators stay silent and take instead
+//   19 / 20 / 21 / 22  the time inside code_tu_block + the bit counts by the kind of task that called them (first-pass candidate / chroma mode / split of a child / second pass's own chain)
+//   34 split_bits   35 recur_luma: the unsplit TU put back   4 spec_children: own state saved / restored   5 run_task: before the search   8 run_task: behind it   18 recur_chroma
+#define PROF_ADD_T(k, id, tid) do { if (lane_id() == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - prof_t0_; PROF_ACC_(id, d_); const int pk_ = lds().prof_task; if (pk_) { PROF_ACC_(tid, d_); PROF_ACC_(18 + pk_, d_); } } } while (0)
+#define PROF_TASK(v) do { if (lane_id() == 0) lds().prof_task = (v); } while (0)
+#define PROF_GLUE_T0() const unsigned long long glue_t0_ = __builtin_readcyclecounter()
+#define PROF_GLUE(id) do { if (lane_id() == 0) { PROF_ACC_(id, __builtin_readcyclecounter() - glue_t0_); } } while (0)
+#else
 #define PROF_ADD_T(k, id, tid) do { if (lane_id() == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - prof_t0_; PROF_ACC_(id, d_); if (lds().prof_task) { PROF_ACC_(tid, d_); } } } while (0)
 #define PROF_TASK(v) do { if (lane_id() == 0) lds().prof_task = (v); } while (0)
+#define PROF_GLUE(id) do { } while (0)
+#define PROF_GLUE_T0() do { } while (0)
+#endif
 #else
 #define PROF_T0() do { } while (0)
 #define PROF_MARK0() do { } while (0)
@@ -295,6 +308,8 @@ DEV void wsync()
 #define PROF_ADD(k, id) do { } while (0)
 #define PROF_ADD_T(k, id, tid) do { } while (0)
 #define PROF_TASK(v) do { } while (0)
+#define PROF_GLUE(id) do { } while (0)
+#define PROF_GLUE_T0() do { } while (0)
 #endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // -DHEVCDL_TIMELINE (build with -DHEVCDL_KERNEL_DEBUG for the buffer): workgroup 0 logs (clock, wave, event, argument) while it codes CTUs [HEVCDL_TL_CTU0, +4) -- tools/timeline.py
@@ -1806,7 +1821,7 @@ DEV void enc_intra_header(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma,
 // register-resident coder: the header flags (xEncIntraHeader :1018-1087, xEncSubdivCbfQT :907-972) are bins in front of the coefficients (code_coeff_wave) instead of
 // three dependent LDS round trips each on lane 0, and the levels are read where code_tu_block left them (lvl_in_lds: TUs up to 16x16, see inv_transform_n) instead of
 // coming back from the layer buffer.  Same bins, same contexts, same order per context; leaves `go` and s.cfrac_last as intra_bits_qt does.
-DEVN uint32_t luma_tu_bits(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_)
+DEV uint32_t luma_tu_bits_body(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_)
 {
   CHECK_EXEC(11);
   PROF_T0();
@@ -1840,6 +1855,7 @@ DEVN uint32_t luma_tu_bits(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_)
   PROF_ADD_T(k, 10, 49);
   return bits;
 }
+DEVN uint32_t luma_tu_bits(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_) { return luma_tu_bits_body(k, cu_, tu_, lvl_in_lds_); }     // (the call form: the transform-skip trial of a 4x4 TU; everywhere else the count rides inside code_tu_block)
 template <int LOG2> DEVN uint32_t intra_bits_qt(KR k, const Cu cu_, const Tu tu_, int luma_, int chroma_)
 {
   CHECK_EXEC(11);
@@ -1876,6 +1892,7 @@ DEV unsigned long long uni64(unsigned long long v) { return ((unsigned long long
 template <int LOG2> DEVN uint32_t split_bits(KR k, const Cu cu_, const Tu tu_, LCabac *root, unsigned long long cfrac)
 {
   PROF_T0();
+  PROF_GLUE_T0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
   LCabac *c = &s.go;
@@ -1888,7 +1905,11 @@ template <int LOG2> DEVN uint32_t split_bits(KR k, const Cu cu_, const Tu tu_, L
   for (int i = CTX_SIG_CG + lane_id(); i < NUM_CTX; i += 64) c->ctx[i] = s.tbest.ctx[i];
   if (lane_id() == 0) c->frac += cfrac;
   wsync();
+#if defined(HEVCDL_PROF_GLUE) && defined(HEVCDL_KERNEL_PROF)
+  PROF_GLUE(34);
+#else
   PROF_ADD_T(k, 10, 49);
+#endif
   return uni((int)get_bits(c));
 }
 template <int LOG2> DEV void enc_transform(KR k, LCabac *c, const Cu &cu, const Tu &tu)
@@ -1940,12 +1961,13 @@ DEV
 #else
 DEVN
 #endif
-uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_)
-{
+TuRes code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, int count_ = 0)
+{ // count_ (luma, the TU coded as one transform block): the bit count that follows every such coding (luma_tu_bits) is made before the function returns -- one
+  // call frame (37 scalar registers saved and restored, two scratch round trips) per TU coding instead of two
   CHECK_EXEC(1);
   PROF_T0();
   PROF_MARK0();
-  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_);
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_), count = uni(count_);
   LSmem &s = lds();
   const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
   const int zrel = comp ? tu_czrel(tu) : tu.zrel, zabs = cu.zbase + zrel;
@@ -2034,7 +2056,9 @@ uint32_t code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_
   PROF_MARK(29);
   PROF_ADD_T(k, 9, 48);
   PROF_ADD(k, 56 + log2n - 2);
-  return d;
+  TuRes res = { d, 0 };
+  if (count) res.bits = luma_tu_bits_body(k, cu, tu, log2n <= 4);
+  return res;
 }
 
 DEV void store_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
@@ -2130,7 +2154,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       for (int m = 0; m < 2; m++) {
         uint32_t d = 0; double cost;
         set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, m); wsync();
-        d = code_tu_block(k, cu, tu, 0, m == 0 ? 1 : 2);
+        d = code_tu_block(k, cu, tu, 0, m == 0 ? 1 : 2).dist;
         const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
         if (m == 1 && cbf == 0) cost = MAX_DOUBLE;
         else {
@@ -2152,9 +2176,10 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
     } else {
       if (check_split) cabac_copy(k, &s.root[full_depth], &s.go);
       set_parts(k, s.a[A_TSKIP + 0], zabs, tu.nparts, 0); wsync();
-      single_dist = code_tu_block(k, cu, tu, 0, (check_first == 2 && !check_split) ? 3 : 0);
+      const TuRes tr = code_tu_block(k, cu, tu, 0, (check_first == 2 && !check_split) ? 3 : 0, 1);
+      single_dist = tr.dist;
       if (check_split) single_cbf = (uint32_t)(uni(s.a[A_CBF][zabs]) >> tu.trd) & 1;
-      const uint32_t bits = luma_tu_bits(k, cu, tu, LOG2 <= 4);
+      const uint32_t bits = tr.bits;
       single_cost = calc_rd_cost(k, bits, single_dist);
       single_cfrac = uni64(s.cfrac_last);
     }
@@ -2199,6 +2224,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       split_cost = calc_rd_cost(k, bits, split_dist);
       if (ub(split_cost < single_cost)) { const DistCost r = { split_dist, split_cost, split_cfrac }; return r; }
       }
+      PROF_GLUE_T0();
       if (memo) { // the saved best candidate of the first pass IS the unsplit coding (sv_* / best_rec, est_intra_luma)
         wsync();
         for (int i = lane_id(); i < tu.nparts; i += 64) { s.a[A_TRIDX][zabs + i] = cold_sv(0)[i]; s.a[A_CBF][zabs + i] = cold_sv(1)[i]; s.a[A_TSKIP][zabs + i] = cold_sv(2)[i]; }
@@ -2214,6 +2240,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
       wsync();
       for (int i = lane_id(); i < n * n; i += 64) rp[(size_t)(i >> LOG2) * rps + (i & (n - 1))] = rq[(i >> LOG2) * 64 + (i & (n - 1))];
       wsync();
+      PROF_GLUE(35);
     }
   }
   const DistCost r = { single_dist, single_cost, single_cfrac };
@@ -2294,9 +2321,10 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
       region_publish(r);
       // the unsplit alternative (the single-TU branch of recur_luma)
       set_parts(k, s.a[A_TSKIP + 0], cu.zbase + ch.zrel, ch.nparts, 0); wsync();
-      const uint32_t d = code_tu_block(k, cu, ch, 0, 0);
+      const TuRes tr = code_tu_block(k, cu, ch, 0, 0, 1);
+      const uint32_t d = tr.dist;
       const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF][cu.zbase + ch.zrel]) >> ch.trd) & 1;
-      const uint32_t bits = luma_tu_bits(k, cu, ch, LOG2 - 1 <= 4);
+      const uint32_t bits = tr.bits;
       const double cost = calc_rd_cost(k, bits, d);
       if (lane_id() == 0) { r.cost[4 + c] = cost; r.dist[4 + c] = d; r.modes[4 + c] = (int)cbf; r.cfrac[4 + c] = s.cfrac_last; }
       wsync();
@@ -2351,10 +2379,10 @@ template <int LOG2> DEVN DistCbf spec_children(KR k, const Cu cu_, const Tu tu_)
         }
         mine++;
         wsync();
-        for (int i = lane_id(); i < SAVE_WORDS; i += 64) s.my_save[i] = ((LDS const unsigned long long *)&s)[i];
+        { PROF_GLUE_T0(); for (int i = lane_id(); i < SAVE_WORDS; i += 64) s.my_save[i] = ((LDS const unsigned long long *)&s)[i]; wsync(); PROF_GLUE(4); }
         run_task<true>(r, idx);
         wsync();
-        for (int i = lane_id(); i < SAVE_WORDS; i += 64) ((LDS unsigned long long *)&s)[i] = s.my_save[i];
+        { PROF_GLUE_T0(); for (int i = lane_id(); i < SAVE_WORDS; i += 64) ((LDS unsigned long long *)&s)[i] = s.my_save[i]; wsync(); PROF_GLUE(4); }
         wsync();
         if (lane_id() < 3) s.ref_key[lane_id()] = -1;
         if (lane_id() == 0) s.fline_key = -1;
@@ -2758,7 +2786,7 @@ DEVN void ahead_open(KR k, const Cu cu_, int nx_, int ny_, int nl_, int xaddr_ =
   if (lane_id() < n) r.modes[lane_id()] = (int)s.rd_list[lane_id()];
   if (lane_id() == 0) { s.ahead_open = 1; s.ahead_key = (nl << 24) | (ny << 12) | nx; s.ahead_n = n; s.ahead_claimed = 0; s.ahead_f0 = (unsigned)f0; r.pad_ = 0x7fffffff; }
   region_open(r, T_LUMA_AHEAD, n, ncu, ptu);
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER) && !defined(HEVCDL_PROF_GLUE)   // look-ahead statistics on the (then silent) RDOQ accumulators
   if (lane_id() == 0) PROF_ACC_(4, (unsigned long long)n << 10);
 #endif
 }
@@ -2845,7 +2873,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           }
           ok = __ballot(diff) == 0ull;
         }
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER) && !defined(HEVCDL_PROF_GLUE)   // look-ahead statistics on the (then silent) RDOQ accumulators
         if (lane_id() == 0) { if (ok) PROF_ACC_(5, (unsigned long long)c << 10); else PROF_ACC_(8, (unsigned long long)((npu == 1 && uni(s.ahead_key) == rkey ? 0 : 1) + (c > 0 ? 0 : 2) + (n_s == (nfull < 5 ? nfull : 5) ? 0 : 4)) << 10); }
 #endif
         if (ok) use_ahead = true; else ahead_drain();
@@ -3031,7 +3059,7 @@ template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
         cur_id++;
         const int one = (total == 1), last = (cur_id == total);
         const int m012 = one ? 0 : (ts == 0 ? 1 : 2);
-        const uint32_t d = code_tu_block(k, cu, tu, comp, m012);
+        const uint32_t d = code_tu_block(k, cu, tu, comp, m012).dist;
         const uint32_t cbf = (uint32_t)(uni(s.a[A_CBF + comp][zc]) >> tu.trd) & 1;
         if (!one && !last) store_ts_result(k, cu, tu, comp);   // before the bit count reuses s->lvl
         if (ts == 1 && cbf == 0) cost_tmp = MAX_DOUBLE;
@@ -3157,8 +3185,13 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
     TL(40 + T_RMD, idx);
     return;
   }
+#ifdef HEVCDL_PROF_GLUE
+  PROF_TASK(kind == T_LUMA_P1 || kind == T_LUMA_AHEAD ? 1 : (kind == T_CHROMA ? 2 : (kind == T_LUMA_SPLIT ? 3 : 4)));
+#else
   PROF_TASK(kind != T_LUMA_P2);
+#endif
   PROF_MARK0();
+  PROF_GLUE_T0();
   const int pset = kind == T_LUMA_P2 ? uni(r.modes[1]) : uni(kk.pset);    // slot set of the second pass: given with its ticket; a split task finds it in the chain owner's context
   const int slot = kind == T_LUMA_SPLIT ? SLOT_SPLIT + SLOT_PSET * pset + mode : (kind == T_CHROMA ? SLOT_CHROMA + (csplit ? idx >> 1 : idx) : (kind == T_LUMA_P2 ? SLOT_P2 + SLOT_PSET * pset : idx));   // T_LUMA_SPLIT: child `mode` of r.tu
   const Tu ttu = kind == T_LUMA_SPLIT ? tu_child(tu, mode) : tu;
@@ -3175,6 +3208,7 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
   LCabac *start = &ow.curr[cu.depth];
   GLB uint8_t *at = slot_attr(kk.slots, slot);
   uint32_t dist; double cost;
+  PROF_GLUE(5);
   if (!LEAF && kind == T_LUMA_P2) { // second RD pass of the PU (TEncSearch.cpp:2445-2512) with the first pass's result as the unsplit alternative
     const int zp = cu.zbase + tu.zrel;
     const double memo_cost = r.cost[4]; const uint32_t memo_dist = (uint32_t)uni((int)r.dist[4]);
@@ -3226,8 +3260,9 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
     DistCost dc;
     if (one_tu) { // the single-TU branch of recur_luma (first pass: no split to check, no transform-skip trial above 4x4) without its call frame
       set_parts(k, s.a[A_TSKIP + 0], zp, tu.nparts, 0); wsync();
-      dc.dist = code_tu_block(k, cu, tu, 0, 3);
-      const uint32_t bits = luma_tu_bits(k, cu, tu, tu.log2 <= 4);
+      const TuRes tr = code_tu_block(k, cu, tu, 0, 3, 1);
+      dc.dist = tr.dist;
+      const uint32_t bits = tr.bits;
       dc.cost = calc_rd_cost(k, bits, dc.dist); dc.cfrac = uni64(s.cfrac_last);
     } else dc = recur_luma_any(k, cu, tu, 1);
     PROF_MARK(51);
@@ -3251,7 +3286,7 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
       const int m = idx >> 1, comp = 1 + (idx & 1), other = 3 - comp;
       GLB uint32_t *half = (GLB uint32_t *)(slot_state(kk.slots, slot, 1) + 32);        // behind the coder state: the two components' distortions
       set_parts(k, s.a[A_TSKIP + comp], cu.zbase, cu.nparts, 0); wsync();
-      const uint32_t d = code_tu_block(k, cu, tu, comp, 0);
+      const uint32_t d = code_tu_block(k, cu, tu, comp, 0).dist;
       wsync();
       for (int i = lane_id(); i < cu.nparts; i += 64) { at[(comp - 1) * 256 + i] = s.a[A_CBF + comp][cu.zbase + i]; at[(comp + 1) * 256 + i] = 0; }
       GLB int *pair = (GLB int *)uni64((unsigned long long)s.rp_pair);          // != 0: the other component runs in another workgroup, on another XCD (remote_serve)
@@ -3413,7 +3448,7 @@ DEVN uint32_t est_intra_chroma(KR k, const Cu cu_)
         if (next_leaf(k, cu, nx, ny, nl) && nl >= 4 && nl <= 5) {
           rmd_prefetch(k, nx, ny, nl, sliced);
           TL(7, 0);
-#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER)   // look-ahead statistics on the (then silent) RDOQ accumulators
+#if defined(HEVCDL_KERNEL_PROF) && HEVCDL_PROF_N == 64 && !defined(HEVCDL_PROF_MASTER) && !defined(HEVCDL_PROF_GLUE)   // look-ahead statistics on the (then silent) RDOQ accumulators
           if (lane_id() == 0) PROF_ACC_(18, (unsigned long long)((uni(s.lw_valid) ? 0 : 1) + (uni(s.a[A_TRIDX][cu.zbase]) == 0 ? 0 : 2) + (uni(s.ahead_open) ? 4 : 0) + (spare_waves() ? 0 : 8)) << 10);
 #endif
           if (AHEAD && uni(s.lw_valid) && cu.part == SIZE_2Nx2N && uni(s.a[A_TRIDX][cu.zbase]) == 0 && !uni(s.ahead_open) && spare_waves()

@@ -1,5 +1,9 @@
 import sys, os, subprocess
 names=["build_refs","filter_refs","rmd_satd","predict_block","rdoq:cg-prologue","rdoq:cg-walk","rdoq","dequant","rdoq:cg-epilogue","code_tu_block(total)","intra_bits_qt(total)","code_coeff_lane0","cabac_copy","enc_cu_syntax","KERNEL","set_result_cu","est_luma(total)","est_chroma(total)","rdoq:phaseA","rdoq:tail","rdoq:CGloop","rdoq:lastpos","rdoq:sbh","IDLE helper: no task","tu:refs+pred","tu:org+residual","tu:fwd","tu:rdoq(mark)","tu:store+dequant+inv","tu:recon+sse","load_tu_coef","MASTER time (process_unit)","IDLE master: tail of own region","IDLE region_wait (P2 join, carry)","rdoq:serial sums (per group)","rdoq:serial group logic (per group)","luma:pass1 region (wall)","chain owner: wait for its split tasks","restarts (calls) / CUs thrown away (kcycles)","chroma region (wall)","task: first-pass candidate","task: chroma mode","task: split of a child","task: deferred second pass","P2 join: no ticket region free","CTU: compress_cu (master)","CTU: encode_cu_tree","CTU: init + record flush","in tasks: code_tu_block","in tasks: intra_bits_qt","P1 task: prologue","P1 task: recur_luma","P1 task: epilogue","helper: import_owner","P2 join: end of the CTU (behind the encode)","P2 join: found finished at a CU start","TU 4x4 (total)","TU 8x8 (total)","TU 16x16 (total)","TU 32x32 (total)","rdoq 4x4","rdoq 8x8","rdoq 16x16","rdoq 32x32"]
+if os.environ.get("PROF_GLUE"):      # library built with -DHEVCDL_KERNEL_PROF -DHEVCDL_PROF_N=64 -DHEVCDL_PROF_GLUE (csrc/rd_kernel.hip): the RDOQ phase accumulators carry these instead
+    for i, n in ((19, "leaf (TU coding + bit count) in first-pass candidates"), (20, "leaf in chroma modes"), (21, "leaf in splits of a child"), (22, "leaf in the second pass's own chain"),
+                 (34, "split_bits"), (35, "recur_luma: unsplit TU put back"), (4, "spec_children: own state saved / restored"), (5, "run_task: before the search"), (8, "(unused)"), (18, "(unused)")):
+        names[i] = n
 code="""
 import sys
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
