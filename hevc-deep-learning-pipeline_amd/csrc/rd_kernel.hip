@@ -263,6 +263,7 @@ struct __attribute__((aligned(16))) RdSmem {
   // RDOQ rate tables of the call (the contexts are frozen while a TU is quantised): significance [context - first][bin], greater-1 [set][c1][bin], greater-2 [set][bin]
   int32_t rq_sig[28][2], rq_g1[4][4][2], rq_g2[4][2];
   int last_bits[2][12];
+  int32_t rq_misc[8];                 // rdoq_wave: rates of the significant-group flag [context][value] and of the cbf flag [value]
 };
 typedef LDS RdSmem LSmem;
 
@@ -1087,11 +1088,35 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   RDOQ_MARK(18);
   RDOQ_STOP(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
-  { // rate tables: one pair of dependent LDS reads here instead of one per batch and use
+  { // rate tables: ONE pair of dependent LDS reads for everything the call prices with the (frozen) contexts -- significance, greater-1 / greater-2, the
+    // significant-group flags and the cbf flag (lanes 48..53: s.rq_misc), and the last-position prefix tables (TEncSbac.cpp:1910-1930; a second role of lanes 0..31) --
+    // instead of a pair here, a pair for the group flags, and two more at the head of the last-position search
     const int set0 = ch ? 4 : 0;
-    if (lane < 28) { const int st = cab->ctx[sig_off + lane]; s.rq_sig[lane][0] = tb().t_ebits[st]; s.rq_sig[lane][1] = tb().t_ebits[st ^ 1]; }
-    else if (lane < 44) { const int e = lane - 28, st = cab->ctx[CTX_ONE + 4 * set0 + e]; s.rq_g1[e >> 2][e & 3][0] = tb().t_ebits[st]; s.rq_g1[e >> 2][e & 3][1] = tb().t_ebits[st ^ 1]; }
-    else if (lane < 48) { const int e = lane - 44, st = cab->ctx[CTX_ABS + set0 + e]; s.rq_g2[e][0] = tb().t_ebits[st]; s.rq_g2[e][1] = tb().t_ebits[st ^ 1]; }
+    int off, shift; last_ctx_params(ch, n, off, shift);
+    const int ng = tb().t_group_idx[n - 1];
+    const int kk = lane & 15, isy = (lane >> 4) & 1;
+    const int lctx = (isy ? CTX_LAST_Y : CTX_LAST_X) + (ch ? 15 : 0) + off + (kk >> shift);
+    const int lst = cab->ctx[lane < 32 ? lctx : CTX_LAST_X];                                       // (lanes 32..63: any valid context, unused)
+    int role_ctx = sig_off + (lane < 28 ? lane : 0);
+    if (lane >= 28 && lane < 44) role_ctx = CTX_ONE + 4 * set0 + (lane - 28);
+    else if (lane >= 44 && lane < 48) role_ctx = CTX_ABS + set0 + (lane - 44);
+    else if (lane >= 48 && lane < 52) role_ctx = cg_off + ((lane - 48) >> 1);
+    else if (lane >= 52) role_ctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
+    const int st = cab->ctx[role_ctx];
+    const int e_0 = tb().t_ebits[st], e_1 = tb().t_ebits[st ^ 1], l_1 = tb().t_ebits[lst ^ 1], l_0 = tb().t_ebits[lst];
+    if (lane < 28) { s.rq_sig[lane][0] = e_0; s.rq_sig[lane][1] = e_1; }
+    else if (lane < 44) { const int e = lane - 28; s.rq_g1[e >> 2][e & 3][0] = e_0; s.rq_g1[e >> 2][e & 3][1] = e_1; }
+    else if (lane < 48) { const int e = lane - 44; s.rq_g2[e][0] = e_0; s.rq_g2[e][1] = e_1; }
+    else if (lane < 54) s.rq_misc[lane - 48] = ((lane - 48) & 1) ? e_1 : e_0;                     // [0..3]: group flag, context 0 / 1 x value 0 / 1; [4] / [5]: cbf 0 / 1  (ctx_bits(c, x, bin) = ebits[state ^ bin])
+    { // last position: entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar; lanes 0..15: X, lanes 16..31: Y
+      const int b1 = (kk < ng) ? l_1 : 0, b0 = (kk < ng) ? l_0 : 0;
+      int inc = b1;
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+      if (lane < 32 && kk <= ng) s.last_bits[isy][kk] = inc - b1 + b0;
+    }
     wsync();
   }
   double block_uncoded = 0;
@@ -1118,8 +1143,9 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   RDOQ_STOP(19);
   const int cg_last = last_pos >> 4, wg = cp.wg, lwg = log2n - 2;
   // rates of the significant-group flag, by context (0 / 1) and value
-  const double cgr00 = lambda * (double)ctx_bits(cab, cg_off, 0), cgr01 = lambda * (double)ctx_bits(cab, cg_off, 1);
-  const double cgr10 = lambda * (double)ctx_bits(cab, cg_off + 1, 0), cgr11 = lambda * (double)ctx_bits(cab, cg_off + 1, 1);
+  const double cgr00 = lambda * (double)s.rq_misc[0], cgr01 = lambda * (double)s.rq_misc[1];
+  const double cgr10 = lambda * (double)s.rq_misc[2], cgr11 = lambda * (double)s.rq_misc[3];
+  const int cbf_bits0 = s.rq_misc[4], cbf_bits1 = s.rq_misc[5];
   unsigned long long cgf_mask = 0;                     // significant-group flags after RDOQ, bit = raster index of the group
   unsigned long long cgf_scan = 0;                     // the same flags, bit = index of the group in scan order (the last-position search walks them)
   auto cgf_at = [&](int gx, int gy) -> int { return (int)((cgf_mask >> (gy * wg + gx)) & 1ull); };
@@ -1335,29 +1361,9 @@ DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, i
   int best_last_p1 = 0;
   {
     double best_cost;
-    {
-      const int cctx = CTX_QT_CBF + (ch ? 5 : 0) + cbf_ctx;
-      best_cost = block_uncoded + lambda * (double)ctx_bits(cab, cctx, 0);
-      base_cost += lambda * (double)ctx_bits(cab, cctx, 1);
-    }
-    LDS int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];
-    { // TEncSbac.cpp:1910-1930 (prefix sums are integers: any evaluation order)
-      int off, shift; last_ctx_params(ch, n, off, shift);
-      const int bx = CTX_LAST_X + (ch ? 15 : 0), by = CTX_LAST_Y + (ch ? 15 : 0);
-      const int ng = tb().t_group_idx[n - 1];
-      { // lanes 0..15: X, lanes 16..31: Y; entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar
-        const int kk = lane & 15, isy = (lane >> 4) & 1;
-        const int cx_ = (isy ? by : bx) + off + (kk >> shift);
-        const int b1 = (kk < ng) ? ctx_bits(cab, cx_, 1) : 0, b0 = (kk < ng) ? ctx_bits(cab, cx_, 0) : 0;
-        int inc = b1;
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
-        if (lane < 32 && kk <= ng) s.last_bits[isy][kk] = inc - b1 + b0;
-      }
-      wsync();
-    }
+    best_cost = block_uncoded + lambda * (double)cbf_bits0;
+    base_cost += lambda * (double)cbf_bits1;
+    LDS int *last_x_bits = s.last_bits[0], *last_y_bits = s.last_bits[1];      // (filled with the rate tables at the top)
     int found_last = 0;
     // the per-position costs of the larger TUs come back from the wave's HBM workspace: those of the NEXT group that keeps its flag are asked for while this one is
     // walked (a round trip of ~1.5 k cycles per group otherwise, a quarter of the routine's time)
