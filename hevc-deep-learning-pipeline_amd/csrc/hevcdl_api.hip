@@ -469,12 +469,12 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // Which build of the 8-bit kernel.  Measured at 2160p on 256 CUs, eight- / ten-wave build (rd_kernel_wide.hip: 168 registers per lane instead of 256, no look-ahead
   // region): 200 frames 3.53 / 4.21 s, 300 frames 4.16 / 4.59 s, 450 frames 5.17 / 5.21 s, 600 frames 6.24 / 6.11 s, 1024 frames 10.33 / 9.50 s, 2048 frames
   // 16.08 / 15.66 s, 2560 frames 21.47 / 18.14 s -- but the ten-wave build moves three times the bytes (600 frames: 5.8 MB per CTU through the L2s against 1.85 MB:
-  // register spills at 168 registers, the CU walk's snapshots in HBM).  It is chosen where it clearly pays: from four units per workgroup on.  Launches in the
+  // register spills at 168 registers, the CU walk's snapshots in HBM).  It is chosen where it clearly pays: from three units per workgroup on (round 5; four before).  Launches in the
   // few-units form keep the eight-wave build.
   bool wide = false;
   if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW))
-    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 4 * groups);
-  if (wide) p.remote = 0;      // (the automatic choice never pairs the ten-wave build with the hand-over of units -- four units or more per workgroup against at most three --; forced by exec_flags the pair runs: tests/test_rd_gpu.py::test_units_handed_over_between_workgroups_give_the_same_result)
+    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 3 * groups);      // round 5, eight- / ten-wave build on 256 CUs: 450 frames 4.80 / 4.87 s, 600 frames 5.76 / 5.70 s, 768 frames 7.00 / 6.87 s, 1024 frames 9.44 / 8.78 s
+  if (wide) p.remote = 0;      // (the ten-wave build together with the hand-over of units: launches of more than three and fewer than four units per workgroup, or exec_flags; tests/test_rd_gpu.py::test_units_handed_over_between_workgroups_give_the_same_result runs the pair)
   const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
   const int threads = 64 * waves;
   const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (const void *)hevcdl_rd_frame_kernel) : (const void *)hevcdl_rd_frame_kernel_bd10;
@@ -680,7 +680,7 @@ extern "C" hevcdl_status hevcdl_reserve_workspace(hevcdl_ctx *ctx)
   const long long max_units = (long long)ctx->cfg.max_frames * ctx->cfg.tile_columns * ctx->cfg.tile_rows;
   const int groups = std::max(ctx->rd_groups, ctx->remote_groups);
   int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : hevcdl_rd_waves_per_group();
-  if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW) && ((ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || max_units >= 4LL * ctx->rd_groups))
+  if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW) && ((ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || max_units >= 3LL * ctx->rd_groups))
     waves = std::max(waves, hevcdl_rd_waves_per_group_wide());
   const size_t need = ctx->scratch_per_wave * (size_t)groups * (size_t)waves;
   if (need <= ctx->scratch_bytes) return HEVCDL_OK;

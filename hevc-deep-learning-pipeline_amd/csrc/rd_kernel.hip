@@ -538,16 +538,6 @@ DEV int part_attr(KR k, int field, int x4, int y4)
 // ---------------------------------------------------------------------------------------------------
 // reference samples (TComPattern.cpp:119-543)
 // ---------------------------------------------------------------------------------------------------
-DEV int unit_avail(KR k, int x4, int y4, int cur_x4, int cur_y4)
-{ // inside the picture and already coded: earlier CTU, or earlier z-order in this CTU (TComDataCU.cpp:985-1200)
-  if (x4 < 0 || y4 < 0 || x4 * 4 >= k.W || y4 * 4 >= k.H) return 0;
-  if (x4 * 4 < k.tx0 || y4 * 4 < k.ty0 || x4 * 4 >= k.tx1 || y4 * 4 >= k.ty1) return 0;   // another tile is never available (bEnforceTileRestriction)
-  // (the CTU of the block the line is gathered for, not k.addr: the look-ahead gathers for the first CU of the NEXT CTU while this one is finished -- process_unit)
-  const int a = (y4 >> 4) * k.ctus_x + (x4 >> 4), ca = (cur_y4 >> 4) * k.ctus_x + (cur_x4 >> 4);
-  if (a != ca) return a < ca;                           // CTUs of one tile are coded in raster order
-  return tb().r2z[((y4 & 15) << 4) | (x4 & 15)] < tb().r2z[((cur_y4 & 15) << 4) | (cur_x4 & 15)];
-}
-
 DEV LDS int16_t *ref_line(int c) { return c ? lds().cline[c - 1] : lds().line; }
 DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
 {
@@ -570,7 +560,9 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
     const int ux = kk < 2 * nu ? x4 - 1 : (kk == 2 * nu ? x4 - 1 : x4 + (kk - 2 * nu - 1)), uy = kk < 2 * nu ? y4 + (2 * nu - 1 - kk) : y4 - 1;
     const int inside = (int)(ux * 4 >= ktx0) & (int)(uy * 4 >= kty0) & (int)(ux * 4 < lim_x1) & (int)(uy * 4 < lim_y1);      // inside the picture and the tile (another tile is never available)
     const int a = (uy >> 4) * kcx + (ux >> 4), z = tb().r2z[((uy & 15) << 4) | (ux & 15)];       // (the index stays inside the table for any coordinates)
-    return inside & (a != ca ? (int)(a < ca) : (int)(z < cz));                                    // an earlier CTU of the tile, or earlier z-order in this one (TComDataCU.cpp:985-1200)
+    // an earlier CTU of the tile (CTUs of one tile are coded in raster order), or earlier z-order in this one (TComDataCU.cpp:985-1200).  "This one" is the CTU of the
+    // block the line is gathered for, not k.addr: the look-ahead gathers for the first CU of the NEXT CTU while this one is finished (process_unit)
+    return inside & (a != ca ? (int)(a < ca) : (int)(z < cz));
   };
   const int f0 = (lane_id() < total) ? unit_flag(lane_id()) : 0;
   const unsigned long long m0 = __ballot(f0);

@@ -342,7 +342,7 @@ def test_units_handed_over_between_workgroups_give_the_same_result(oracle_built,
     """600 frames on 256 workgroups do not divide evenly: the surplus frames travel round the ring of workgroups (a frame is handed over at a CTU
     boundary: position + coder state).  The launch that migrates must give, frame by frame, what launches without migration give (<= one frame
     per workgroup), and a sample of frames must equal the oracle.  exec_flags 2 (HEVCDL_EXEC_RD_WIDE): the same with the ten-wave build of the kernel, a pair the
-    library's own choice never makes (ten waves from four units per workgroup on, hand-over up to three) but the public flag allows."""
+    library's own choice makes only between three and four units per workgroup (ten waves from three units per workgroup on, hand-over below four) -- 769 frames and more on 256 CUs."""
     import hevcdl_amd
     import ref_tools
     w, h, qp, nf = 512, 256, 33, 600                       # 32 CTUs per frame: two hand-over points per frame
