@@ -1011,9 +1011,15 @@ constexpr int mt_slot(int id) { return id == 18 ? 0 : id == 19 ? 1 : id == 4 ? 2
 //     the number of decisions that differ from the guess (typically 2 passes for the whole batch instead of one serial visit per level).
 //   * The ordered sums and the group-level tests (zero-out of a group, TComTrQuant.cpp:2385-2440) then run group by group in scan order,
 //     addends transposed through LDS once per batch.
-DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
+// NFIX != 0: the TU size as a compile-time constant (the 4x4 / 8x8 copies: group counts, loop bounds and the masks over the groups fold).  HEVCDL_RDOQ_FIX: the
+// largest size that gets a copy of its own.  Measured (round 5): per call 4x4 8 175 -> 6 795 cycles, 8x8 20 035 -> 17 970; whole kernel, none / 4 / 8 / 16:
+// one frame 2.62 / 2.60 / 2.59 / 2.59 s, 600 frames 5.77 / 5.72 / 5.70 / 5.71 s, 2048 frames 14.55 / 14.67 / 14.56 / 14.64 s (every copy is 26 KB more code)
+#ifndef HEVCDL_RDOQ_FIX
+#define HEVCDL_RDOQ_FIX 8
+#endif
+template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, int n_, int dir_mode_, int cbf_ctx_)
 {
-  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
+  const int c = uni(c_), n = NFIX ? NFIX : uni(n_), dir_mode = uni(dir_mode_), cbf_ctx = uni(cbf_ctx_);
   LSmem &s = lds();
   const int lane = lane_id();
   const int ch = c ? 1 : 0, log2n = ilog2(n);
@@ -1536,9 +1542,9 @@ DEV void dequant(KR k, int c_, int n_)
 // (the integer bits are dropped first: reset_bits); bit 29: the TU has coefficients (s.lvl) to count behind the flags.  PRE_COEF | PRE_NONE = coefficients only.
 // The fractional bits the coefficient bins add go to s.cfrac_last when `luma_cfrac` is set.  Returns the coder's integer bits.
 constexpr int PRE_NONE = 0xffffff, PRE_EP_SHIFT = 24, PRE_RESET = 1 << 28, PRE_COEF = 1 << 29;
-DEVN uint32_t code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_ = PRE_COEF | PRE_NONE, int luma_cfrac_ = 0)
-{
-  const int comp = uni(comp_), n = uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_), pre = uni(pre_), luma_cfrac = uni(luma_cfrac_);
+template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_, int luma_cfrac_)
+{ // NFIX != 0: the TU size as a compile-time constant (as for rdoq_wave)
+  const int comp = uni(comp_), n = NFIX ? NFIX : uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_), pre = uni(pre_), luma_cfrac = uni(luma_cfrac_);
   LSmem &s = lds();
   const int lane = lane_id(), ch = comp ? 1 : 0;
   CParam cp; get_cparam(cp, comp, n, dir_mode);
@@ -1677,6 +1683,20 @@ DEVN uint32_t code_coeff_wave(KR k, LCabac *c, int comp_, int n_, int dir_mode_,
   if (lane == 0) { c->frac = frac; if (luma_cfrac) s.cfrac_last = frac - frac_hdr; }
   wsync();
   return (uint32_t)(frac >> 15);
+}
+#ifndef HEVCDL_BITS_FIX
+#define HEVCDL_BITS_FIX 8
+#endif
+DEV uint32_t code_coeff_wave(KR k, LCabac *c, int comp, int n_, int dir_mode, int tskip_flag, int pre = PRE_COEF | PRE_NONE, int luma_cfrac = 0)
+{
+  const int n = uni(n_);
+#if HEVCDL_BITS_FIX >= 4
+  if (n == 4) return code_coeff_wave_n<4>(k, c, comp, n, dir_mode, tskip_flag, pre, luma_cfrac);
+#endif
+#if HEVCDL_BITS_FIX >= 8
+  if (n == 8) return code_coeff_wave_n<8>(k, c, comp, n, dir_mode, tskip_flag, pre, luma_cfrac);
+#endif
+  return code_coeff_wave_n<0>(k, c, comp, n, dir_mode, tskip_flag, pre, luma_cfrac);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1954,12 +1974,9 @@ DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 // TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved, 3 predict and write the
 // reconstruction to the layer only: a first-pass candidate of a PU coded as one TU -- nothing reads its picture samples)
 // ---------------------------------------------------------------------------------------------------
-#ifdef HEVCDL_INLINE_TU
-DEV
-#else
-DEVN
-#endif
-TuRes code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, int count_ = 0)
+// NFIX != 0: the block size as a compile-time constant (4x4 and 8x8 have copies of their own: one round per loop over the samples, strides and shifts as constants,
+// their own copy of rdoq_wave); code_tu_block picks the copy.
+template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, int count_)
 { // count_ (luma, the TU coded as one transform block): the bit count that follows every such coding (luma_tu_bits) is made before the function returns -- one
   // call frame (37 scalar registers saved and restored, two scratch round trips) per TU coding instead of two
   CHECK_EXEC(1);
@@ -1967,7 +1984,7 @@ TuRes code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, i
   PROF_MARK0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_), count = uni(count_);
   LSmem &s = lds();
-  const int n = comp ? tu_csize(tu) : (1 << tu.log2), log2n = ilog2(n);
+  const int n = NFIX ? NFIX : (comp ? tu_csize(tu) : (1 << tu.log2)), log2n = NFIX == 4 ? 2 : (NFIX == 8 ? 3 : ilog2(n));
   const int zrel = comp ? tu_czrel(tu) : tu.zrel, zabs = cu.zbase + zrel;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y;
   const int cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
@@ -2003,7 +2020,9 @@ TuRes code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, i
 #ifdef HEVCDL_STAGE_TRACE
   if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + n * n + i] = (unsigned)(int)s.tc[i];
 #endif
-  { PROF_T0(); const uint32_t as_ = rdoq_wave(k, &s.go, comp, n, mode, cbf_ctx); if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
+  { PROF_T0();
+    const uint32_t as_ = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);
+    if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
   wsync();
   PROF_MARK(27);
   const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
@@ -2057,6 +2076,20 @@ TuRes code_tu_block(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, i
   TuRes res = { d, 0 };
   if (count) res.bits = luma_tu_bits_body(k, cu, tu, log2n <= 4);
   return res;
+}
+#ifndef HEVCDL_TU_FIX
+#define HEVCDL_TU_FIX 8          // 0: one copy of code_tu_block for every size; 4 / 8: 4x4 (and 8x8) blocks get their own
+#endif
+DEV TuRes code_tu_block(KR k, const Cu &cu, const Tu &tu, int comp, int mode012, int count = 0)
+{
+  const int n = uni(comp) ? tu_csize(utu(tu)) : (1 << uni(tu.log2));
+#if HEVCDL_TU_FIX >= 4
+  if (n == 4) return code_tu_block_n<4>(k, cu, tu, comp, mode012, count);
+#endif
+#if HEVCDL_TU_FIX >= 8
+  if (n == 8) return code_tu_block_n<8>(k, cu, tu, comp, mode012, count);
+#endif
+  return code_tu_block_n<0>(k, cu, tu, comp, mode012, count);
 }
 
 DEV void store_ts_result(KR k, const Cu &cu, const Tu &tu, int comp)
@@ -4458,7 +4491,11 @@ void hevcdl_micro_kernel(hevcdl_rd_params p, const int16_t *resi_, int n_blocks,
     unsigned long long t0 = __builtin_readcyclecounter();
     fwd_transform(k, n, !comp && n == 4);
     if (what != 2) t0 = __builtin_readcyclecounter();
+#if HEVCDL_RDOQ_FIX
+    const uint32_t as = n == 4 ? rdoq_wave<4>(k, &s.go, comp, n, mode, 1) : (n == 8 && HEVCDL_RDOQ_FIX >= 8 ? rdoq_wave<HEVCDL_RDOQ_FIX >= 8 ? 8 : 0>(k, &s.go, comp, n, mode, 1) : rdoq_wave<0>(k, &s.go, comp, n, mode, 1));
+#else
     const uint32_t as = rdoq_wave(k, &s.go, comp, n, mode, 1);
+#endif
     wsync();
     unsigned long long t1 = __builtin_readcyclecounter();
     if (what != 0) {
