@@ -1685,7 +1685,7 @@ template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, 
   return (uint32_t)(frac >> 15);
 }
 #ifndef HEVCDL_BITS_FIX
-#define HEVCDL_BITS_FIX 8
+#define HEVCDL_BITS_FIX 16        // per call (tools/micro_rd.py), one copy / own copies: 4x4 4 082 -> 3 495 cycles, 8x8 7 335 -> 6 749
 #endif
 DEV uint32_t code_coeff_wave(KR k, LCabac *c, int comp, int n_, int dir_mode, int tskip_flag, int pre = PRE_COEF | PRE_NONE, int luma_cfrac = 0)
 {
@@ -1695,6 +1695,9 @@ DEV uint32_t code_coeff_wave(KR k, LCabac *c, int comp, int n_, int dir_mode, in
 #endif
 #if HEVCDL_BITS_FIX >= 8
   if (n == 8) return code_coeff_wave_n<8>(k, c, comp, n, dir_mode, tskip_flag, pre, luma_cfrac);
+#endif
+#if HEVCDL_BITS_FIX >= 16
+  if (n == 16) return code_coeff_wave_n<16>(k, c, comp, n, dir_mode, tskip_flag, pre, luma_cfrac);
 #endif
   return code_coeff_wave_n<0>(k, c, comp, n, dir_mode, tskip_flag, pre, luma_cfrac);
 }
@@ -1974,7 +1977,7 @@ DEVN void enc_cu_syntax(KR k, LCabac *c, const Cu cu_)
 // TU coding: xIntraCodingTUBlock TEncSearch.cpp:1129-1424 (mode012: 0 predict, 1 predict+save, 2 reuse saved, 3 predict and write the
 // reconstruction to the layer only: a first-pass candidate of a PU coded as one TU -- nothing reads its picture samples)
 // ---------------------------------------------------------------------------------------------------
-// NFIX != 0: the block size as a compile-time constant (4x4 and 8x8 have copies of their own: one round per loop over the samples, strides and shifts as constants,
+// NFIX != 0: the block size as a compile-time constant (4x4, 8x8 and 16x16 have copies of their own: one round per loop over the samples, strides and shifts as constants,
 // their own copy of rdoq_wave); code_tu_block picks the copy.
 template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_, int comp_, int mode012_, int count_)
 { // count_ (luma, the TU coded as one transform block): the bit count that follows every such coding (luma_tu_bits) is made before the function returns -- one
@@ -1984,7 +1987,7 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
   PROF_MARK0();
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_); const int comp = uni(comp_), mode012 = uni(mode012_), count = uni(count_);
   LSmem &s = lds();
-  const int n = NFIX ? NFIX : (comp ? tu_csize(tu) : (1 << tu.log2)), log2n = NFIX == 4 ? 2 : (NFIX == 8 ? 3 : ilog2(n));
+  const int n = NFIX ? NFIX : (comp ? tu_csize(tu) : (1 << tu.log2)), log2n = NFIX == 4 ? 2 : (NFIX == 8 ? 3 : (NFIX == 16 ? 4 : ilog2(n)));
   const int zrel = comp ? tu_czrel(tu) : tu.zrel, zabs = cu.zbase + zrel;
   const int x = comp ? tu.x >> 1 : tu.x, y = comp ? tu.y >> 1 : tu.y;
   const int cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
@@ -2078,7 +2081,8 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
   return res;
 }
 #ifndef HEVCDL_TU_FIX
-#define HEVCDL_TU_FIX 8          // 0: one copy of code_tu_block for every size; 4 / 8: 4x4 (and 8x8) blocks get their own
+#define HEVCDL_TU_FIX 16         // 0: one copy of code_tu_block for every size; 4 / 8 / 16: blocks up to that size get their own.  Measured (round 5), 0 / 4 / 8 / 16:
+                                 // one frame 2.62 / 2.60 / 2.55 / 2.54 s, 600 frames 5.755 / 5.74 / 5.65 / 5.61 s, 2048 frames 14.64 / 14.48 / 14.43 / 14.47 s
 #endif
 DEV TuRes code_tu_block(KR k, const Cu &cu, const Tu &tu, int comp, int mode012, int count = 0)
 {
@@ -2088,6 +2092,9 @@ DEV TuRes code_tu_block(KR k, const Cu &cu, const Tu &tu, int comp, int mode012,
 #endif
 #if HEVCDL_TU_FIX >= 8
   if (n == 8) return code_tu_block_n<8>(k, cu, tu, comp, mode012, count);
+#endif
+#if HEVCDL_TU_FIX >= 16
+  if (n == 16) return code_tu_block_n<16>(k, cu, tu, comp, mode012, count);
 #endif
   return code_tu_block_n<0>(k, cu, tu, comp, mode012, count);
 }
