@@ -548,7 +548,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   wsync();
   if (lane_id() == 0) { lds().ref_key[c] = key; if (!c) lds().fline_key = -1; }
   LDS int16_t *line_out = ref_line(c);
-  const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n / u;
+  const int u = c ? 2 : 4, sh = c ? 1 : 2, nu = n >> sh;          // (every divisor below is a power of two: shifts, not the ~30-instruction division by a run-time value)
   const int x4 = x >> sh, y4 = y >> sh, total = 4 * nu + 1;
   // availability of the <= 65 units: lanes 0..63 + unit 64 (only for a 64x64 luma block) on lane 0's second pass.  unit_avail's rule, with the picture / tile
   // limits read ONCE into scalar registers and the tests combined without branches: as a chain of early returns on fields of the LDS-resident context it came out
@@ -604,7 +604,7 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
     const int i = lane_id() + 64 * it;
     have[it] = false; val[it] = 1 << (BD - 1);
     if (i <= 4 * n) {
-      const int kk = i < 2 * n ? i / u : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / u);
+      const int kk = i < 2 * n ? i >> sh : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> sh));
       const int fl = kk < 64 ? (int)((m0 >> kk) & 1) : f64;
       int si = i;
       if (!fl) {
@@ -701,7 +701,7 @@ DEV int dc_value(KR k, LDS const int16_t *line, int n)
   int s = 0;
   for (int i = lane_id(); i < n; i += 64) s += line[n2 + 1 + i] + line[n2 - 1 - i];
   s = wave_sum_i(s);
-  return (s + n) / (n + n);
+  return (s + n) >> (ilog2(n) + 1);                           // / (2 n)
 }
 
 // prediction of an n x n TU (n <= 32) into s->pred (stride n)
@@ -1621,7 +1621,7 @@ template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, 
   int c1 = 1;
   for (int subset = last_set; subset >= 0; subset--) {
     const int sub_pos = subset << 4;
-    const int cgblk = uni(scan_cg[subset]), gy = cgblk / cp.wg, gx = cgblk - gy * cp.wg;
+    const int cgblk = uni(scan_cg[subset]), gy = cgblk >> (log2n - 2), gx = cgblk - (gy << (log2n - 2));
     int cg_sig;
     if (subset == last_set || subset == 0) { wsync(); if (lane == 0) cgf[cgblk] = 1; wsync(); cg_sig = 1; }
     else { cg_sig = uni((int)cgf[cgblk]) & 1; bin_a(cg_off + uni(sig_cg_ctx(cgf, gx, gy, cp.wg)), cg_sig); }
@@ -1833,7 +1833,7 @@ DEV void enc_intra_header(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma,
   if (luma) {
     if (tu.zrel == 0 && cu.depth == 3 && lane_id() == 0) enc_bin(c, CTX_PART_SIZE, cu.part == SIZE_2Nx2N);
     if (cu.part == SIZE_2Nx2N) { if (tu.zrel == 0) code_luma_dirs(k, c, cu, 0, 1); }
-    else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel % q) == 0) code_luma_dirs(k, c, cu, tu.zrel / q, 1); }
+    else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel & (q - 1)) == 0) code_luma_dirs(k, c, cu, tu.zrel >> (2 * (cu.log2 - 2) - 2), 1); }
   }
   if (chroma && tu.zrel == 0) code_chroma_dir(k, c, cu);
 }
@@ -1855,7 +1855,7 @@ DEV uint32_t luma_tu_bits_body(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_
   if (tu.zrel == 0 && cu.depth == 3) add(CTX_PART_SIZE, cu.part == SIZE_2Nx2N ? 1 : 0);
   int pu = -1;
   if (cu.part == SIZE_2Nx2N) { if (tu.zrel == 0) pu = 0; }
-  else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel % q) == 0) pu = tu.zrel / q; }
+  else { const int q = cu.nparts >> 2; if (tu.trd > 0 && (tu.zrel & (q - 1)) == 0) pu = tu.zrel >> (2 * (cu.log2 - 2) - 2); }
   if (pu >= 0) { // code_luma_dirs for this one PU (codeIntraDirLumaAng TEncSbac.cpp:643-696)
     const int pu_size = (cu.part == SIZE_NxN) ? (1 << (cu.log2 - 1)) : (1 << cu.log2);
     const int px = cu.x + (pu & 1) * pu_size, py = cu.y + (pu >> 1) * pu_size;
@@ -2579,12 +2579,12 @@ DEVN void rmd_rounds(KR k, LDS unsigned int *satd_dst, int x_, int y_, int pn_, 
 {
   const int x = uni(x_), y = uni(y_), pn = uni(pn_), dcv = uni(dcv_), r0 = uni(r0_), r1 = uni(r1_);
   LSmem &s = lds();
-  const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, nbx = pn / b, nblk = nbx * nbx, ntask = 35 * nblk;
+  const int log2n = ilog2(pn), b = pn >= 8 ? 8 : 4, lb = pn >= 8 ? 3 : 2, lnbx = log2n - lb, nbx = 1 << lnbx, nblk = nbx * nbx, ntask = 35 * nblk;
 #pragma unroll 1
   for (int t0 = r0 * 64; t0 < r1 * 64 && t0 < ntask; t0 += 64) {
     const int t = t0 + lane_id();
     if (t < ntask) {
-      const int mode = t / nblk, blk = t - mode * nblk, bx = (blk % nbx) * b, by = (blk / nbx) * b;
+      const int mode = t >> (2 * lnbx), blk = t & (nblk - 1), bx = (blk & (nbx - 1)) << lb, by = (blk >> lnbx) << lb;
       const unsigned sum = (b == 8) ? rmd_block<8>(k, s, mode, pn, log2n, x, y, bx, by, dcv) : rmd_block<4>(k, s, mode, pn, log2n, x, y, bx, by, dcv);
       __hip_atomic_fetch_add(&satd_dst[mode], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -2597,7 +2597,7 @@ DEVN void rmd_satd(KR k, const Cu cu_, const Tu ptu_)
   const Cu cu = ucu(cu_); const Tu ptu = utu(ptu_);
   const int x = ptu.x, y = ptu.y, pn = 1 << ptu.log2;
   LSmem &s = lds();
-  const int b = pn >= 8 ? 8 : 4, nbx = pn / b, ntask = 35 * nbx * nbx, nrounds = (ntask + 63) >> 6;
+  const int b = pn >= 8 ? 8 : 4, nbx = pn >> (pn >= 8 ? 3 : 2), ntask = 35 * nbx * nbx, nrounds = (ntask + 63) >> 6;
   if (lane_id() < 36) s.satd[lane_id()] = 0;
   const int dcv = dc_value(k, s.line, pn);
   wsync();

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do for L in libhevcdl_hip ab_tu16 ab_tu16b8; do
-  echo $L; HEVCDL_LIB=$GRAFT_REPO_ROOT/hevc-deep-learning-pipeline_amd/lib/$L.so python tools/time_rd.py 1 600 2048 2>&1 | grep frames
-done; done
+for i in 1 2; do python tools/time_rd.py 1 600 2048 2>&1 | grep frames; python tools/time_rd.py 10 --size=1920x1080 2>&1 | grep frames; done
+(time python -m pytest tests/test_rd_gpu.py -m gpu -x -q) > gpurun_out/j14_pytest.txt 2>&1
+grep -E "passed|failed" gpurun_out/j14_pytest.txt
