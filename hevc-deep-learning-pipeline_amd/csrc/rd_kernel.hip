@@ -1540,7 +1540,7 @@ DEV void dequant(KR k, int c_, int n_)
 // pre_: bins coded in front of the coefficients, on contexts below 19 (the CU / TU header flags of a bit count: part size, prev_intra_luma_pred, transform subdivision, cbf)
 // -- up to four, packed six bits each from bit 0: context (5 bits) | value << 5, 63 = none; bits 24..27: bypass bins behind them; bit 28: the bit count starts here
 // (the integer bits are dropped first: reset_bits); bit 29: the TU has coefficients (s.lvl) to count behind the flags.  PRE_COEF | PRE_NONE = coefficients only.
-// The fractional bits the coefficient bins add go to s.cfrac_last when `luma_cfrac` is set.  Returns the coder's integer bits.
+// The fractional bits the coefficient bins add go to s.cfrac_last (luma_cfrac 1), to s.cfrac_last_c (2) or are added to it (3).  Returns the coder's integer bits.
 constexpr int PRE_NONE = 0xffffff, PRE_EP_SHIFT = 24, PRE_RESET = 1 << 28, PRE_COEF = 1 << 29;
 template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_, int luma_cfrac_)
 { // NFIX != 0: the TU size as a compile-time constant (as for rdoq_wave)
@@ -1680,7 +1680,7 @@ template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, 
   wsync();
   c->ctx[BA + lane] = (uint8_t)cxa; if (lane < 63) c->ctx[BB + lane] = (uint8_t)cxb;       // (the windows overlap nowhere: 18 < BA, BA + 63 <= 84 < BB)
   if (lane < 19) c->ctx[lane] = (uint8_t)cxh;
-  if (lane == 0) { c->frac = frac; if (luma_cfrac) s.cfrac_last = frac - frac_hdr; }
+  if (lane == 0) { c->frac = frac; if (luma_cfrac == 1) s.cfrac_last = frac - frac_hdr; else if (luma_cfrac == 2) s.cfrac_last_c = frac - frac_hdr; else if (luma_cfrac == 3) s.cfrac_last_c += frac - frac_hdr; }
   wsync();
   return (uint32_t)(frac >> 15);
 }
@@ -1872,6 +1872,28 @@ DEV uint32_t luma_tu_bits_body(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_
   const int mode = uni(s.a[A_LDIR][z]), tskip = uni(s.a[A_TSKIP][z]);
   if (cbf && !lvl_in_lds) load_tu_coef(k, 0, 0, tu.log2, z, n);
   const uint32_t bits = code_coeff_wave(k, &s.go, 0, n, mode, tskip, pre | (nep << PRE_EP_SHIFT) | PRE_RESET | (cbf ? PRE_COEF : 0), 1);
+  wsync();
+  PROF_ADD_T(k, 10, 49);
+  return bits;
+}
+// xGetIntraBitsQT, chroma only, of a CU that is ONE transform unit (2Nx2N, tr_idx 0, up to 32x32: one block per component) -- what intra_bits_qt<LOG2>(k, cu, root, 0, 1)
+// counts there: intra_chroma_pred_mode, cbf_cb, cbf_cr as bins in front of the first component that has coefficients, then Cb's and Cr's coefficients, on the
+// register-resident coder (the flags were three dependent LDS round trips each on lane 0).  Leaves `go` and s.cfrac_last_c as intra_bits_qt does.
+DEVN uint32_t chroma_cu_bits_1tu(KR k, const Cu cu_, const Tu tu_)
+{
+  CHECK_EXEC(11);
+  PROF_T0();
+  const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
+  LSmem &s = lds();
+  const int z = cu.zbase, n = tu_csize(tu);
+  wsync();
+  const int cdir = uni(s.a[A_CDIR][z]), dm = cdir == DM_CHROMA ? 1 : 0, mode = dm ? uni(s.a[A_LDIR][z]) : cdir;
+  const int cbf1 = uni(s.a[A_CBF + 1][z]) & 1, cbf2 = uni(s.a[A_CBF + 2][z]) & 1;
+  const int hdr = ((CTX_CHROMA_PRED | ((1 - dm) << 5)) | ((CTX_QT_CBF + 5) | (cbf1 << 5)) << 6 | ((CTX_QT_CBF + 5) | (cbf2 << 5)) << 12 | 63 << 18) | ((dm ? 0 : 2) << PRE_EP_SHIFT) | PRE_RESET;
+  uint32_t bits;
+  if (cbf1) { load_tu_coef(k, 0, 1, tu.log2, z, n); bits = code_coeff_wave(k, &s.go, 1, n, mode, uni(s.a[A_TSKIP + 1][z]), hdr | PRE_COEF, 2); }
+  if (cbf2) { load_tu_coef(k, 0, 2, tu.log2, z, n); bits = code_coeff_wave(k, &s.go, 2, n, mode, uni(s.a[A_TSKIP + 2][z]), cbf1 ? (PRE_NONE | PRE_COEF) : (hdr | PRE_COEF), cbf1 ? 3 : 2); }
+  if (!cbf1 && !cbf2) bits = code_coeff_wave(k, &s.go, 1, n, mode, 0, hdr, 2);
   wsync();
   PROF_ADD_T(k, 10, 49);
   return bits;
@@ -3350,17 +3372,27 @@ template <bool LEAF> DEV void run_task_body(LRegion &r, int idx_)
       }
     }
     uint32_t bits = 0;
+    const bool one_tu = cu.part == SIZE_2Nx2N && cu.log2 <= 5 && uni(s.a[A_TRIDX][cu.zbase]) == 0;      // the CU is one transform unit: the short count (chroma_cu_bits_1tu)
     if (csplit) {
       if (counted) {
         cabac_copy(k, &s.go, start);
-        switch (cu.log2) { case 5: bits = intra_bits_qt<5>(k, cu, tu, 0, 1); break; default: bits = intra_bits_qt<4>(k, cu, tu, 0, 1); break; }
+        bits = chroma_cu_bits_1tu(k, cu, tu);            // (components run apart only for a CU of one TU)
       }
-    } else
-    switch (cu.log2) {
-      case 6: dist = recur_chroma<6>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<6>(k, cu, tu, 0, 1); break;
-      case 5: dist = recur_chroma<5>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<5>(k, cu, tu, 0, 1); break;
-      case 4: dist = recur_chroma<4>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<4>(k, cu, tu, 0, 1); break;
-      default: dist = recur_chroma<3>(k, cu, tu); cabac_copy(k, &s.go, start); bits = intra_bits_qt<3>(k, cu, tu, 0, 1); break;
+    } else {
+      switch (cu.log2) {
+        case 6: dist = recur_chroma<6>(k, cu, tu); break;
+        case 5: dist = recur_chroma<5>(k, cu, tu); break;
+        case 4: dist = recur_chroma<4>(k, cu, tu); break;
+        default: dist = recur_chroma<3>(k, cu, tu); break;
+      }
+      cabac_copy(k, &s.go, start);
+      if (one_tu) bits = chroma_cu_bits_1tu(k, cu, tu);
+      else switch (cu.log2) {
+        case 6: bits = intra_bits_qt<6>(k, cu, tu, 0, 1); break;
+        case 5: bits = intra_bits_qt<5>(k, cu, tu, 0, 1); break;
+        case 4: bits = intra_bits_qt<4>(k, cu, tu, 0, 1); break;
+        default: bits = intra_bits_qt<3>(k, cu, tu, 0, 1); break;
+      }
     }
     if (csplit) {
       if (counted) { // the mode's answer, where est_intra_chroma looks for it: cost / fractional bits by mode, distortion behind the fractional bits
