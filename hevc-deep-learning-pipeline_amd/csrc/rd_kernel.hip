@@ -263,7 +263,6 @@ struct __attribute__((aligned(16))) RdSmem {
   // RDOQ rate tables of the call (the contexts are frozen while a TU is quantised): significance [context - first][bin], greater-1 [set][c1][bin], greater-2 [set][bin]
   int32_t rq_sig[28][2], rq_g1[4][4][2], rq_g2[4][2];
   int last_bits[2][12];
-  int32_t rq_misc[8];                 // rdoq_wave: rates of the significant-group flag [context][value] and of the cbf flag [value]
 };
 typedef LDS RdSmem LSmem;
 
@@ -1083,11 +1082,13 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   }
   wsync();
   if (last_pos < 0) return 0;
+  __builtin_assume(last_pos < ncoef);                       // (with NFIX == 4: one group -- the batch logic, the group test and the walk over the groups fold)
   RDOQ_MARK(18);
   RDOQ_STOP(18);
   const int sig_off = CTX_SIG + (ch ? 28 : 0), cg_off = CTX_SIG_CG + (ch ? 2 : 0);
+  int cg_b00, cg_b01, cg_b10, cg_b11, cbf_bits0, cbf_bits1;  // rates of the significant-group flag [context][value] and of the cbf flag [value]
   { // rate tables: ONE pair of dependent LDS reads for everything the call prices with the (frozen) contexts -- significance, greater-1 / greater-2, the
-    // significant-group flags and the cbf flag (lanes 48..53: s.rq_misc), and the last-position prefix tables (TEncSbac.cpp:1910-1930; a second role of lanes 0..31) --
+    // significant-group flags and the cbf flag (lanes 48..53), and the last-position prefix tables (TEncSbac.cpp:1910-1930; a second role of lanes 0..31) --
     // instead of a pair here, a pair for the group flags, and two more at the head of the last-position search
     const int set0 = ch ? 4 : 0;
     int off, shift; last_ctx_params(ch, n, off, shift);
@@ -1105,7 +1106,9 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
     if (lane < 28) { s.rq_sig[lane][0] = e_0; s.rq_sig[lane][1] = e_1; }
     else if (lane < 44) { const int e = lane - 28; s.rq_g1[e >> 2][e & 3][0] = e_0; s.rq_g1[e >> 2][e & 3][1] = e_1; }
     else if (lane < 48) { const int e = lane - 44; s.rq_g2[e][0] = e_0; s.rq_g2[e][1] = e_1; }
-    else if (lane < 54) s.rq_misc[lane - 48] = ((lane - 48) & 1) ? e_1 : e_0;                     // [0..3]: group flag, context 0 / 1 x value 0 / 1; [4] / [5]: cbf 0 / 1  (ctx_bits(c, x, bin) = ebits[state ^ bin])
+    // lanes 48 / 50: the group flag under context 0 / 1, lane 52: the cbf flag (ctx_bits(c, x, bin) = ebits[state ^ bin]): wave-uniform, read across the lanes (no LDS round trip)
+    cg_b00 = __builtin_amdgcn_readlane(e_0, 48); cg_b01 = __builtin_amdgcn_readlane(e_1, 48); cg_b10 = __builtin_amdgcn_readlane(e_0, 50); cg_b11 = __builtin_amdgcn_readlane(e_1, 50);
+    cbf_bits0 = __builtin_amdgcn_readlane(e_0, 52); cbf_bits1 = __builtin_amdgcn_readlane(e_1, 52);
     { // last position: entry kk = bits of kk ones (+ the terminating zero for kk < ng): prefix sum on the DPP crossbar; lanes 0..15: X, lanes 16..31: Y
       const int b1 = (kk < ng) ? l_1 : 0, b0 = (kk < ng) ? l_0 : 0;
       int inc = b1;
@@ -1123,7 +1126,12 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   for (int top = ncoef - 1; top > last_pos; top -= 64) {
     const int sp = top - lane;
     const double c0 = (sp > last_pos) ? cost0_of(scan[sp]) : 0.0;
-    if (!__ballot(c0 != 0.0)) continue;
+    const unsigned long long nzc = __ballot(c0 != 0.0);
+    if (!nzc) continue;
+    if (__popcll(nzc) <= 8) { // a handful: read across the lanes in the same order (lane 0 = the highest position), no transposition through LDS
+      for (unsigned long long m = nzc; m; m &= m - 1ull) block_uncoded += rl_d(c0, __ffsll((long long)m) - 1);
+      continue;
+    }
     wsync();
     s.zb[0][lane] = c0;
     wsync();
@@ -1141,9 +1149,8 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   RDOQ_STOP(19);
   const int cg_last = last_pos >> 4, wg = cp.wg, lwg = log2n - 2;
   // rates of the significant-group flag, by context (0 / 1) and value
-  const double cgr00 = lambda * (double)s.rq_misc[0], cgr01 = lambda * (double)s.rq_misc[1];
-  const double cgr10 = lambda * (double)s.rq_misc[2], cgr11 = lambda * (double)s.rq_misc[3];
-  const int cbf_bits0 = s.rq_misc[4], cbf_bits1 = s.rq_misc[5];
+  const double cgr00 = lambda * (double)cg_b00, cgr01 = lambda * (double)cg_b01;
+  const double cgr10 = lambda * (double)cg_b10, cgr11 = lambda * (double)cg_b11;
   unsigned long long cgf_mask = 0;                     // significant-group flags after RDOQ, bit = raster index of the group
   unsigned long long cgf_scan = 0;                     // the same flags, bit = index of the group in scan order (the last-position search walks them)
   auto cgf_at = [&](int gx, int gy) -> int { return (int)((cgf_mask >> (gy * wg + gx)) & 1ull); };
@@ -1395,11 +1402,17 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
       const int start_pin = (cgp == cg_last) ? (last_pos & 15) : 15;
       const bool in_j = j <= start_pin;
       const double a1_j = in_j ? (lv_j ? -cc_j : -cs_j) : 0.0, a2_j = (in_j && lv_j) ? c0_j : 0.0;
-      wsync();
-      if (lane < 16) { s.zb[0][j] = a1_j; s.zb[1][j] = a2_j; }
-      wsync();
+      const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
+      const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
       double mine = base_cost, acc = base_cost;
-      {
+      // the chain matters from the first position of the group that is in the walk (start_pin: the ones above add +0.0) down to the position the walk ends at (a level
+      // above 1: nothing below it is priced, and the sum behind the group is not used): when that is a short stretch its addends are read across the lanes
+      if (start_pin - stop_pin < 6) {
+        for (int pin = start_pin; pin >= stop_pin; pin--) { mine = (j == pin) ? acc : mine; acc = (acc + rl_d(a1_j, pin)) + rl_d(a2_j, pin); }
+      } else {
+        wsync();
+        if (lane < 16) { s.zb[0][j] = a1_j; s.zb[1][j] = a2_j; }
+        wsync();
         double v1[16], v2[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) { v1[t] = s.zb[0][15 - t]; v2[t] = s.zb[1][15 - t]; }
@@ -1407,8 +1420,6 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
         for (int t = 0; t < 16; t++) { mine = (j == 15 - t) ? acc : mine; acc = (acc + v1[t]) + v2[t]; }
       }
       const double total_j = (mine + cl_j) - cs_j;
-      const unsigned gt1 = (unsigned)(__ballot(lane < 16 && in_j && lv_j > 1) & 0xffffull);
-      const int stop_pin = gt1 ? 31 - __clz((int)gt1) : 0;
       unsigned cand = (unsigned)(__ballot(lane < 16 && in_j && lv_j != 0 && j >= stop_pin) & 0xffffull);
       while (cand) {
         const int pin = 31 - __clz((int)cand);
@@ -2045,12 +2056,12 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
 #ifdef HEVCDL_STAGE_TRACE
   if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + n * n + i] = (unsigned)(int)s.tc[i];
 #endif
+  uint32_t abs_sum;                                             // (wave-uniform as rdoq_wave returns it)
   { PROF_T0();
-    const uint32_t as_ = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);
-    if (lane_id() == 0) s.bc_u32[0] = as_; PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
+    abs_sum = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);
+    PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
   wsync();
   PROF_MARK(27);
-  const uint32_t abs_sum = (uint32_t)uni((int)s.bc_u32[0]);
 #ifdef HEVCDL_STAGE_TRACE
   if (tr) for (int i = lane_id(); i < n * n; i += 64) tr[6 + 2 * n * n + i] = abs_sum > 0 ? (unsigned)(int)s.lvl[i] : 0u;      // levels behind the quantiser (:1525-1528)
   GLB unsigned *ti = abs_sum > 0 ? stage_alloc(k, 6 + 3 * n * n) : nullptr;                                                    // invTransformNxN (:1603-1662)
