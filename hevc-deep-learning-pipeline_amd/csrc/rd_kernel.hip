@@ -1553,8 +1553,8 @@ DEV void dequant(KR k, int c_, int n_)
 // (the integer bits are dropped first: reset_bits); bit 29: the TU has coefficients (s.lvl) to count behind the flags.  PRE_COEF | PRE_NONE = coefficients only.
 // The fractional bits the coefficient bins add go to s.cfrac_last (luma_cfrac 1), to s.cfrac_last_c (2) or are added to it (3).  Returns the coder's integer bits.
 constexpr int PRE_NONE = 0xffffff, PRE_EP_SHIFT = 24, PRE_RESET = 1 << 28, PRE_COEF = 1 << 29;
-template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_, int luma_cfrac_)
-{ // NFIX != 0: the TU size as a compile-time constant (as for rdoq_wave)
+template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_, int luma_cfrac_)
+{ // NFIX != 0: the TU size as a compile-time constant (as for rdoq_wave).  _i: the body, inlined where it is called (code_tu_block's own count); _n: the call form
   const int comp = uni(comp_), n = NFIX ? NFIX : uni(n_), dir_mode = uni(dir_mode_), tskip_flag = uni(tskip_flag_), pre = uni(pre_), luma_cfrac = uni(luma_cfrac_);
   LSmem &s = lds();
   const int lane = lane_id(), ch = comp ? 1 : 0;
@@ -1695,6 +1695,8 @@ template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, 
   wsync();
   return (uint32_t)(frac >> 15);
 }
+template <int NFIX> DEVN uint32_t code_coeff_wave_n(KR k, LCabac *c, int comp_, int n_, int dir_mode_, int tskip_flag_, int pre_, int luma_cfrac_)
+{ return code_coeff_wave_i<NFIX>(k, c, comp_, n_, dir_mode_, tskip_flag_, pre_, luma_cfrac_); }
 #ifndef HEVCDL_BITS_FIX
 #define HEVCDL_BITS_FIX 16        // per call (tools/micro_rd.py), one copy / own copies: 4x4 4 082 -> 3 495 cycles, 8x8 7 335 -> 6 749
 #endif
@@ -1853,7 +1855,10 @@ DEV void enc_intra_header(KR k, LCabac *c, const Cu &cu, const Tu &tu, int luma,
 // register-resident coder: the header flags (xEncIntraHeader :1018-1087, xEncSubdivCbfQT :907-972) are bins in front of the coefficients (code_coeff_wave) instead of
 // three dependent LDS round trips each on lane 0, and the levels are read where code_tu_block left them (lvl_in_lds: TUs up to 16x16, see inv_transform_n) instead of
 // coming back from the layer buffer.  Same bins, same contexts, same order per context; leaves `go` and s.cfrac_last as intra_bits_qt does.
-DEV uint32_t luma_tu_bits_body(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_)
+#ifndef HEVCDL_BITS_INLINE
+#define HEVCDL_BITS_INLINE 1     // the count behind a TU coding runs the bit counter inside code_tu_block's frame (the copies with the block size as a constant): no call frame
+#endif                           // (37 scalar registers saved and restored through scratch) and no s_waitcnt vmcnt(0) at a function entry right behind the coding's stores
+template <int NFIX = 0> DEV uint32_t luma_tu_bits_body(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_)
 {
   CHECK_EXEC(11);
   PROF_T0();
@@ -1882,7 +1887,10 @@ DEV uint32_t luma_tu_bits_body(KR k, const Cu cu_, const Tu tu_, int lvl_in_lds_
   add(CTX_QT_CBF + (tu.trd == 0 ? 1 : 0), cbf);
   const int mode = uni(s.a[A_LDIR][z]), tskip = uni(s.a[A_TSKIP][z]);
   if (cbf && !lvl_in_lds) load_tu_coef(k, 0, 0, tu.log2, z, n);
-  const uint32_t bits = code_coeff_wave(k, &s.go, 0, n, mode, tskip, pre | (nep << PRE_EP_SHIFT) | PRE_RESET | (cbf ? PRE_COEF : 0), 1);
+  const int pre_all = pre | (nep << PRE_EP_SHIFT) | PRE_RESET | (cbf ? PRE_COEF : 0);
+  uint32_t bits;
+  if constexpr (NFIX != 0 && HEVCDL_BITS_INLINE && NFIX <= HEVCDL_BITS_FIX) bits = code_coeff_wave_i<NFIX>(k, &s.go, 0, NFIX, mode, tskip, pre_all, 1);
+  else bits = code_coeff_wave(k, &s.go, 0, n, mode, tskip, pre_all, 1);
   wsync();
   PROF_ADD_T(k, 10, 49);
   return bits;
@@ -2110,7 +2118,7 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
   PROF_ADD_T(k, 9, 48);
   PROF_ADD(k, 56 + log2n - 2);
   TuRes res = { d, 0 };
-  if (count) res.bits = luma_tu_bits_body(k, cu, tu, log2n <= 4);
+  if (count) res.bits = luma_tu_bits_body<NFIX>(k, cu, tu, log2n <= 4);
   return res;
 }
 #ifndef HEVCDL_TU_FIX

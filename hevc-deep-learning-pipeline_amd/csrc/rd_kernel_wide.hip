@@ -9,6 +9,8 @@
 // 6.24 -> 6.11 s, 1024 frames 10.33 -> 9.50 s, 2560 frames 21.47 -> 18.14 s; 300 frames 4.16 -> 4.59 s) and it moves three times the bytes through the L2s (spills,
 // snapshots in HBM): launch_rd (hevcdl_api.hip) picks it from four units per workgroup on.
 #define HEVCDL_NW 10
+#undef HEVCDL_NPEND
+#define HEVCDL_NPEND 2           // (an experiment with more pending passes in the eight-wave build leaves this one alone: its LDS is full)
 #define HEVCDL_AHEAD 0
 #define HEVCDL_RD_WIDE 1
 #undef HEVCDL_KERNEL_PROF       // the in-kernel timers belong to the 8-wave build (no LDS to spare here)

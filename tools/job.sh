@@ -1,9 +1,11 @@
 #!/bin/bash
-# one GPU session: parity of the decision kernel, micro-benchmark of the leaves (new / base), A/B times
-tag=$1
+# one GPU session: parity of the decision kernel + A/B times: tools/job.sh <tag> <lib> <lib> ...
+tag=$1; shift
 python -m pytest tests/test_rd_gpu.py -x -q > gpurun_out/${tag}_pytest.txt 2>&1; tail -3 gpurun_out/${tag}_pytest.txt
-python tools/micro_rd.py --lib hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_micro.so --reps 100 > gpurun_out/${tag}_micro_new.txt 2>&1
-python tools/micro_rd.py --lib hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_micro_base.so --reps 100 > gpurun_out/${tag}_micro_base.txt 2>&1
-grep rdoq gpurun_out/${tag}_micro_base.txt; grep rdoq gpurun_out/${tag}_micro_new.txt
 rm -f gpurun_out/${tag}_time_*.txt
-bash tools/ab.sh $tag ab_base.so libhevcdl_hip.so
+for rep in 1 2; do
+for l in "$@"; do
+  HEVCDL_LIB=hevc-deep-learning-pipeline_amd/lib/$l python tools/time_rd.py 1 600 2048 >> gpurun_out/${tag}_time_${l%.so}.txt 2>&1
+done
+done
+for l in "$@"; do echo "== $l"; grep -a 'flags\|rror' gpurun_out/${tag}_time_${l%.so}.txt; done
