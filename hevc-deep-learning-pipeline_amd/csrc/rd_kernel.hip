@@ -538,8 +538,8 @@ DEV int part_attr(KR k, int field, int x4, int y4)
 // reference samples (TComPattern.cpp:119-543)
 // ---------------------------------------------------------------------------------------------------
 DEV LDS int16_t *ref_line(int c) { return c ? lds().cline[c - 1] : lds().line; }
-DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
-{
+DEV void build_refs_i(KR k, int c_, int x_, int y_, int n_, int force_)
+{ // _i: the body, inlined into code_tu_block (HEVCDL_REFS_INLINE); build_refs: the call form
   PROF_T0();
   const int c = uni(c_), x = uni(x_), y = uni(y_), n = uni(n_);
   const int key = (ilog2(n) << 24) | (y << 12) | x;
@@ -622,6 +622,11 @@ DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_)
   wsync();
   PROF_ADD(k, 0);
 }
+
+DEVN void build_refs(KR k, int c_, int x_, int y_, int n_, int force_) { build_refs_i(k, c_, x_, y_, n_, force_); }
+#ifndef HEVCDL_REFS_INLINE
+#define HEVCDL_REFS_INLINE 1
+#endif
 
 DEV void filter_refs(KR k, int n_)
 {
@@ -2035,7 +2040,7 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
   const int mode = uni(mode_of(k, cu, comp, zrel));
   const int tskip = uni(s.a[A_TSKIP + comp][zabs]);
   if (mode012 != 2) {
-    build_refs(k, comp, x, y, n, 0);
+    if (HEVCDL_REFS_INLINE && NFIX) build_refs_i(k, comp, x, y, n, 0); else build_refs(k, comp, x, y, n, 0);
     if (ub(use_filtered_refs(comp, mode, n))) filter_refs(k, n);
     predict_block(k, comp, mode, n);
     if (mode012 == 1 && lane_id() < 16) s.ts_pred[comp][lane_id()] = s.pred[lane_id()];
