@@ -2998,6 +2998,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
       // the serial loop keeps a candidate when its cost is strictly smaller: the winner is the smallest cost, first in list order
       int win = -1;
       for (int m = 0; m < nfull; m++) { const double c = r.cost[m]; if (ub(c < best_cost)) { best_cost = c; win = m; } }
+      TL(30, win);
       if (win >= 0) { // xSetIntraResultLumaQT + the saved arrays, from the winner's result slot
         best_mode = (uint32_t)uni(r.modes[win]); best_dist = (uint32_t)uni((int)r.dist[win]);
         // Launches of few units: the chain that bounds a frame is luma only -- this CU's winner -> rough modes of the next PU -> its candidates.  The winner's samples
@@ -3019,6 +3020,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
             rmd_prefetch(k, nx, ny, nl, 2);
             if (lane_id() == 0) s.pre_open = (nl << 24) | (ny << 12) | nx;
             wsync();
+            TL(31, 0);
           }
         }
         GLB const uint8_t *at = slot_attr(k.slots, win);
@@ -3029,7 +3031,9 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
           s.a[A_TRIDX][zp + i] = t0; s.a[A_CBF][zp + i] = t1; s.a[A_TSKIP][zp + i] = t2;
         }
         wsync();
+        TL(32, 0);
         set_result_cu(k, cu, ptu, 0, slot_coef(k.slots, win), slot_rec(k.slots, win), zp * 16, ptu.x, ptu.y);        // a first-pass slot's origin is the PU
+        TL(33, 0);
         if (npu == 1 && pu_log2 <= 5) { // the winner's coefficient bits and coder state, kept for the CU's syntax count (its slot may serve a chroma mode next)
           GLB const unsigned long long *src = slot_state(k.slots, win, 1); GLB unsigned long long *dst = s.my_log + 65 * (LEAF_LOG / 8);
           if (lane_id() < 21) dst[lane_id()] = src[lane_id()];
@@ -3074,12 +3078,14 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
             wsync();
           }
         }
+        TL(34, 0);
         state_to_global(slot_state(k.slots, SLOT_P2 + SLOT_PSET * (reg - 1), 0), &s.curr[cu.depth]);
         const int rm = lds_load(&wg_shared().remote);
         // (very few units: the CU's five chroma modes are posted in the same breath -- everything a chroma mode reads is settled once the luma winner is imported, and
         //  posting here instead of in est_intra_chroma brings their answers, which the walk waits for, ~15 k cycles forward and saves a release of its own)
         if (rm && (rm != 3 || remote_room())) remote_post(k, cu, ptu, reg, (int)best_mode, best_cost, best_dist, cu.part == SIZE_2Nx2N && (rm == 2 || (rm == 1 && HEVCDL_CHROMA_ROOM > 0 && remote_room(HEVCDL_CHROMA_ROOM))));    // a workgroup without a unit runs it (few units in the launch)
         else region_open(r2, T_LUMA_P2, 1, cu, ptu);
+        TL(35, 0);
         break;
       }
       PROF_MARK0();

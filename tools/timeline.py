@@ -22,7 +22,8 @@ ev.sort(key=lambda e: e[0])
 t0 = ev[0][0]
 for t, w in ev:
     wave, e, arg = w >> 24, (w >> 16) & 255, w & 0xffff
-    if e >= 40: nm = 'task end   %s' % kinds.get(e - 40, e - 40)
+    if 30 <= e < 40: nm = {30: 'luma: winner known', 31: 'luma: next SATD slices open', 32: 'luma: arrays in', 33: 'luma: winner copied', 34: 'luma: before P2 post', 35: 'luma: P2 (+chroma) posted'}.get(e, str(e))
+    elif e >= 40: nm = 'task end   %s' % kinds.get(e - 40, e - 40)
     elif e >= 20: nm = 'task start %s' % kinds.get(e - 20, e - 20)
     else: nm = names.get(e, str(e))
     print("%9.1f  w%d  %s%s  %d" % (((t - t0) & 0xffffffff) / 1000.0, wave, '    ' * (1 if wave else 0), nm, arg))
