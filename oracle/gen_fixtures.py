@@ -119,6 +119,42 @@ def gen_rd(tiled=False, ten_bit=False, extreme=False):
     return cases
 
 
+def gen_rd_tools():
+    """Tool switches of the cfg other than the reference's values (TAppEncCfg.cpp:900-901,917-918,950,978,1007): the reference encoder run with the switch on its command
+    line; the fixture carries the tool mask (HEVCDL_TOOL_* of include/hevcdl.h)."""
+    T = rt
+    #        name             W    H   frames qp labels seed  tools cleared
+    spec = [("k128_q22_sbh0", 128, 128, 1, 22, "rand", 15, T.TOOL_SIGN_HIDE),                 # the noisy picture of c128_q22_r: escapes, many levels a group
+            ("k128_q27_ts0", 128, 128, 1, 27, "rand", 16, T.TOOL_TSKIP),
+            ("k192_q32_sis0", 192, 128, 1, 32, 1, 51, T.TOOL_STRONG_INTRA),                    # 32x32 CUs on smooth content: the strong filter would apply
+            ("k200_q32_mpm0", 200, 136, 1, 32, "rand", 52, T.TOOL_FAST_UDI_MPM),
+            ("k200_q27_all0", 200, 136, 2, 27, "rand", 53, T.TOOL_SIGN_HIDE | T.TOOL_TSKIP | T.TOOL_STRONG_INTRA | T.TOOL_FAST_UDI_MPM)]
+    cases = []
+    for name, w, h, nf, qp, kind, seed, off in spec:
+        tools = T.TOOLS_REFERENCE & ~off
+        yuv = rt.synth_yuv(w, h, nf, seed)
+        if name.startswith("k128_q22") or name.startswith("k128_q27"):
+            rng = np.random.default_rng(seed)
+            yuv = rng.integers(0, 256, yuv.shape).astype(np.uint8) if name.startswith("k128_q22") else np.clip(yuv.astype(np.int32) + rng.integers(-24, 25, yuv.shape), 0, 255).astype(np.uint8)
+        lab = rt.make_labels(w, h, nf, kind, seed + 100)
+        targs = rt.tool_args(tools)
+        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs)
+        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"])
+        assert dump2.tobytes() == dump.tobytes()
+        dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+        nctu = lab.shape[1]
+        assert len(dump) == nf * nctu
+        summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=8, lf_across_tiles=1, tiles=np.array((1, 1)), tools=tools,
+                            records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
+                            rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
+                            bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),
+                            summary=np.array(summary))
+        cases.append(name)
+        print("rd tools fixture", name, "tools 0x%02x" % tools, "ctus", nf * nctu, summary[0][:60] if summary else "")
+    return cases
+
+
 def load_ref_model():
     import torch
     import torch.nn as nn
@@ -412,7 +448,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "rdtools", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
     if "stage" in what:
         gen_stage_traces()
     if "rd" in what:
@@ -423,6 +459,8 @@ if __name__ == "__main__":
         gen_rd(ten_bit=True)
     if "rdx" in what:
         gen_rd(extreme=True)
+    if "rdtools" in what:
+        gen_rd_tools()
     if "cnn" in what or "weights" in what:
         model, sd, src = load_ref_model()
         if "weights" in what:

@@ -153,6 +153,10 @@ typedef struct { int x, y, log2, depth, zbase, nparts, part; } cu_t;
 /* sample bit depth of the run (8, or 10: InternalBitDepth 10 with RExt__HIGH_BIT_DEPTH_SUPPORT 0, i.e. FULL_NBIT 0, TypeDef.h:162-172).
  * Not thread-safe, like the trace hook: one encode at a time per process. */
 static int g_bd = 8;
+/* tool switches of the cfg (TAppEncCfg.cpp:900-901,917-918,950,978,1007), bits as HEVCDL_TOOL_* of include/hevcdl.h: 0x04 TransformSkip, 0x10 SignHideFlag, 0x20 StrongIntraSmoothing,
+ * 0x40 FastUDIUseMPMEnabled can be cleared; RDOQ, RDOQTS, TransformSkipFast stay on (the reference cfg's values) */
+static unsigned g_tools = 0x7fu;
+void hm_oracle_set_tools(unsigned tools) { g_tools = tools; }
 #define DIST_ADJ(x) (x)          /* DISTORTION_PRECISION_ADJUSTMENT, TypeDef.h:170 */
 
 typedef struct { int x, y, log2, trd, zrel, nparts; } tu_t;   /* luma geometry; zrel relative to the CU */
@@ -268,7 +272,7 @@ static void filter_refs(const pel *src, pel *dst, int n)
 { /* TComPattern.cpp:203-293, luma only; strong smoothing for n >= 32 (SPS flag on) */
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
-  if (n >= 32) {
+  if (n >= 32 && (g_tools & 0x20u)) {          /* sps_strong_intra_smoothing_enable_flag, TComPattern.cpp:226 */
     const int thr = 1 << (g_bd - 5);
     int bl = src[0], tl = src[n2], tr = src[last];
     strong = abs(bl + tl - 2 * src[n]) < thr && abs(tl + tr - 2 * src[n2 + n]) < thr;
@@ -732,7 +736,7 @@ static uint32_t rdoq(const enc_t *e, const cabac_t *cab, int c, int n, int dir_m
   }
   for (int sp = best_last_p1; sp <= last_pos; sp++) dst[cp.scan[sp]] = 0;
   /* sign data hiding, TComTrQuant.cpp:2530-2660 */
-  if (abs_sum >= 2) {
+  if (abs_sum >= 2 && (g_tools & 0x10u)) {     /* getSignDataHidingEnabledFlag, TComTrQuant.cpp:2530 */
     const double inv = (double)g_inv_quant_scales[rem];
     int64_t rd_factor = (int64_t)(inv * inv * (1 << (2 * per)) / lambda / 16 / (1 << DIST_ADJ(2 * (g_bd - 8))) + 0.5);
     int last_cg = -1;
@@ -822,7 +826,7 @@ static void code_coeff_nxn(cabac_t *c, const int32_t *coef, int comp, int n, int
   int num_sig = 0;
   for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
   if (num_sig == 0) { fprintf(stderr, "oracle: code_coeff_nxn on empty TU\n"); abort(); }
-  if (n == 4) enc_bin(c, CTX_TSKIP + ch, tskip_flag);          /* codeTransformSkipFlags :997-1032 */
+  if (n == 4 && (g_tools & 0x04u)) enc_bin(c, CTX_TSKIP + ch, tskip_flag);          /* codeTransformSkipFlags :997-1032 (only with transform_skip_enabled_flag) */
   uint8_t cgf[64]; memset(cgf, 0, sizeof cgf);
   int scan_last = -1, pos_last;
   do {
@@ -854,7 +858,7 @@ static void code_coeff_nxn(cabac_t *c, const int32_t *coef, int comp, int n, int
       }
     } else sp = sub_pos - 1;
     if (num_nz > 0) {
-      int sign_hidden = (last_nz - first_nz >= 4);
+      int sign_hidden = (g_tools & 0x10u) && (last_nz - first_nz >= 4);
       int cset = ctx_set_index(ch, subset, c1 == 0);
       c1 = 1;
       int n_c1 = num_nz < 8 ? num_nz : 8, first_c2 = -1;
@@ -870,7 +874,7 @@ static void code_coeff_nxn(cabac_t *c, const int32_t *coef, int comp, int n, int
         if (sym) escape = 1;
       }
       escape = escape || (num_nz > 8);
-      enc_ep(c, sign_hidden ? num_nz - 1 : num_nz);     /* SBH always valid here */
+      enc_ep(c, sign_hidden ? num_nz - 1 : num_nz);
       int first_coeff2 = 1;
       if (escape) for (int i = 0; i < num_nz; i++) {
         int base = (i < 8) ? (2 + first_coeff2) : 1;
@@ -1155,7 +1159,7 @@ static void recur_luma(enc_t *e, const cu_t *cu, const tu_t *tu, int check_first
   int check_split = tu->log2 > min_tu_log2(cu);
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
-  const int check_ts = (tu->log2 == 2) && (cu->part == SIZE_NxN);
+  const int check_ts = (g_tools & 0x04u) && (tu->log2 == 2) && (cu->part == SIZE_NxN);
   if (check_full) {
     if (check_ts) {
       e->root[full_depth] = e->go;
@@ -1257,7 +1261,8 @@ static void est_intra_luma(enc_t *e, const cu_t *cu, uint32_t *cu_dist)
     pel line[4 * 64 + 1], fline[4 * 64 + 1];
     build_refs(e, 0, ptu.x, ptu.y, pn, line);
     if (pn >= 8 && pn <= 32) filter_refs(line, fline, pn);
-    int nfull = g_num_rd_cand[pu_log2 - 2];
+    static const uint8_t num_rd_cand_no_mpm[5] = { 9, 9, 4, 4, 5 };          /* g_aucIntraModeNumFast_NotUseMPM, TComRom.cpp:554-562 (TEncSearch.cpp:2269) */
+    int nfull = (g_tools & 0x40u) ? g_num_rd_cand[pu_log2 - 2] : num_rd_cand_no_mpm[pu_log2 - 2];
     uint32_t rd_list[16]; double cost_list[16];
     for (int i = 0; i < nfull; i++) cost_list[i] = MAX_DOUBLE;
     const pel *org = org_at(e, 0, ptu.x, ptu.y);
@@ -1276,7 +1281,7 @@ static void est_intra_luma(enc_t *e, const cu_t *cu, uint32_t *cu_dist)
         rd_list[nfull - shift] = (uint32_t)mode; cost_list[nfull - shift] = cost;
       }
     }
-    {
+    if (g_tools & 0x40u) {                       /* FastUDIUseMPMEnabled, TEncSearch.cpp:2324-2346 */
       int preds[3], nm; get_mpm(e, ptu.x, ptu.y, preds, &nm);
       const int nbase = nfull;
       for (int j = 0; j < nm; j++) {
@@ -1329,7 +1334,7 @@ static void recur_chroma(enc_t *e, const cu_t *cu, const tu_t *tu, uint32_t *dis
   if (e->r->a[A_TRIDX][z] == tu->trd) {
     if (!tu_has_chroma_first(tu)) return;
     const int full_depth = cu->depth + tu->trd;
-    int check_ts = (tu->log2 == 2);
+    int check_ts = (g_tools & 0x04u) && (tu->log2 == 2);
     if (check_ts) { int nb = 0; for (int k = 0; k < 4; k++) nb += e->r->a[A_TSKIP + 0][z + k]; check_ts = nb > 0; }
     const int zc = cu->zbase + tu_czrel(tu), np = tu_cnparts(tu);
     for (int comp = 1; comp < 3; comp++) {

@@ -205,7 +205,21 @@ def tile_bounds(tiles, width, height):
     return c, r, np.array(cb, np.int32), np.array(rb, np.int32)
 
 
-def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bit_depth=8):
+TOOLS_REFERENCE = 0x7f
+TOOL_TSKIP, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x04, 0x10, 0x20, 0x40     # HEVCDL_TOOL_* of include/hevcdl.h
+
+
+def tool_args(tools):
+    """The reference's command-line switches for a tool mask (TAppEncCfg.cpp:900-901,917-918,950,978,1007)."""
+    a = []
+    if not tools & TOOL_TSKIP: a.append("--TransformSkip=0")
+    if not tools & TOOL_SIGN_HIDE: a.append("--SignHideFlag=0")
+    if not tools & TOOL_STRONG_INTRA: a.append("--StrongIntraSmoothing=0")
+    if not tools & TOOL_FAST_UDI_MPM: a.append("--FastUDIUseMPMEnabled=0")
+    return a
+
+
+def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bit_depth=8, tools=TOOLS_REFERENCE):
     """Returns (records [frames][ctus] REC_DTYPE, recon [frames][w*h*3/2] (uint8, or uint16 for bit_depth 10), stats [frames])."""
     lib = oracle_lib()
     yuv = np.ascontiguousarray(yuv, np.uint8 if bit_depth == 8 else np.uint16)
@@ -215,6 +229,7 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     recon = np.zeros_like(yuv)
     stats = np.zeros(n_frames, STATS_DTYPE)
     lib.hm_oracle_set_trace(trace_path.encode() if trace_path else None)
+    lib.hm_oracle_set_tools(ctypes.c_uint(tools))
     lib.hm_oracle_encode_frames_tb.restype = ctypes.c_int
     lib.hm_oracle_encode_frames_tb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -222,6 +237,7 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     rc = lib.hm_oracle_encode_frames_tb(yuv.ctypes.data, width, height, n_frames, qp, labels.ctypes.data,
                                         recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tc, tr, cb.ctypes.data, rb.ctypes.data, bit_depth)
     lib.hm_oracle_set_trace(None)
+    lib.hm_oracle_set_tools(ctypes.c_uint(TOOLS_REFERENCE))
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
     return recs, recon, stats

@@ -18,7 +18,8 @@ def test_rd_oracle_matches_reference_records(oracle_built, path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     tiles = fixture_tiles(f)                                                        # rd_t* / rd_n*: reference runs with tiles enabled
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
-    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles, bit_depth=bd)
+    tools = int(f["tools"]) if "tools" in f.files else ref_tools.TOOLS_REFERENCE    # rd_k*: reference runs with a tool switch of the cfg turned off
+    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles, bit_depth=bd, tools=tools)
     for k in FIELDS:
         assert np.array_equal(recs[k], f["records"][k]), k
     for fr in range(f["yuv"].shape[0]):
