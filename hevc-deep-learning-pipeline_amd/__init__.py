@@ -89,7 +89,7 @@ class StreamConfig(ctypes.Structure):
                 ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("lf_across_tiles", ctypes.c_int32)]
+                ("lf_across_tiles", ctypes.c_int32), ("tools", ctypes.c_uint32)]
 
 
 class Profile(ctypes.Structure):
@@ -253,7 +253,11 @@ def load_weights(path=WEIGHTS_PATH):
     return w
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0):
+TOOLS_REFERENCE = 0x7f
+TOOL_TSKIP, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x04, 0x10, 0x20, 0x40      # HEVCDL_TOOL_* (include/hevcdl.h): the switches that may be turned off
+
+
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE):
     lib = load_library()
     cfg = Config()
     st = lib.hevcdl_config_default_bd(ctypes.byref(cfg), width, height, qp, bit_depth)
@@ -263,10 +267,11 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
     cfg.bn_mode = bn_mode                      # 0: training-mode BatchNorm as the reference runs it; 1 (HEVCDL_BN_EVAL): the checkpoint's running statistics
     _set_tiles(cfg, tiles, width, height)        # (columns, rows) uniformly spaced, or explicit sizes: see tile_layout
     cfg.lf_across_tiles = 1 if lf_across_tiles else 0                   # LFCrossTileBoundaryFlag
+    cfg.tools = tools                          # cfg keys TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, tools=TOOLS_REFERENCE):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -277,6 +282,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
     _set_tiles(cfg, tiles, width, height)
     cfg.lf_across_tiles = 1 if lf_across_tiles else 0
     cfg.bit_depth = bit_depth
+    cfg.tools = tools
     sao_ptr = None
     if sao is not None:
         sao = np.ascontiguousarray(sao, SAO_DTYPE)

@@ -298,6 +298,8 @@ int sig_ctx_inc(const CParam &cp, int pat, int scan_pos)
   return cp.first_sig_ctx + offset;
 }
 
+// the tool switches of the access unit being written (hevcdl_stream_config.tools): transform_skip_enabled_flag and sign_data_hiding_enabled_flag change residual_coding()
+thread_local uint32_t t_tools = HEVCDL_TOOLS_REFERENCE;
 // residual_coding(): TEncSbac::codeCoeffNxN TEncSbac.cpp:1115-1541
 void code_coeff(Cabac &c, const int16_t *coef, int comp, int n, int dir_mode, int tskip_flag)
 {
@@ -307,7 +309,7 @@ void code_coeff(Cabac &c, const int16_t *coef, int comp, int n, int dir_mode, in
   int num_sig = 0;
   for (int i = 0; i < n * n; i++) num_sig += coef[i] != 0;
   if (num_sig == 0) return;
-  if (n == 4) c.bin(CTX_TSKIP + ch, tskip_flag);
+  if (n == 4 && (t_tools & HEVCDL_TOOL_TSKIP)) c.bin(CTX_TSKIP + ch, tskip_flag);      // transform_skip_flag only with transform_skip_enabled_flag (TEncSbac.cpp:1007)
   uint8_t cgf[64]; memset(cgf, 0, sizeof cgf);
   int scan_last = -1, pos_last;
   do {
@@ -348,7 +350,7 @@ void code_coeff(Cabac &c, const int16_t *coef, int comp, int n, int dir_mode, in
       }
     } else sp = sub_pos - 1;
     if (num_nz > 0) {
-      const int sign_hidden = (last_nz - first_nz >= 4);
+      const int sign_hidden = (t_tools & HEVCDL_TOOL_SIGN_HIDE) && (last_nz - first_nz >= 4);
       const int cset = (ch ? 4 : 0) + ((!ch && subset > 0) ? 2 : 0) + (c1 == 0 ? 1 : 0);      // TComChromaFormat.h:243-251
       c1 = 1;
       const int n_c1 = num_nz < 8 ? num_nz : 8; int first_c2 = -1, escape = 0;
@@ -525,6 +527,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
   cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1; cfg->lf_across_tiles = 1;
+  cfg->tools = HEVCDL_TOOLS_REFERENCE;
   return HEVCDL_OK;
 }
 
@@ -578,6 +581,8 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   if ((cfg->sao_enabled != 0) != (sao != nullptr)) return HEVCDL_ERR_INVALID_ARG;         // SAO parameters go with sample_adaptive_offset_enabled_flag
   const int bd = cfg->bit_depth;
   if (bd != 8 && bd != 10) return HEVCDL_ERR_UNSUPPORTED;
+  if (!hevcdl_tools_supported(cfg->tools)) return HEVCDL_ERR_UNSUPPORTED;
+  t_tools = cfg->tools;
   const int tcols = cfg->tile_columns, trows = cfg->tile_rows, tiled = tcols * trows > 1;
   if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22) return HEVCDL_ERR_INVALID_ARG;
   int col_bd[21], row_bd[23];
@@ -607,14 +612,14 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     w.ue(2);                                         // two (empty) short-term RPS of the all-intra GOP table
     w.ue(0); w.ue(0);
     w.flag(0); w.ue(0); w.ue(0);                     // RPS 1: inter_ref_pic_set_prediction_flag 0, no pictures
-    w.flag(0); w.flag(1); w.flag(1); w.flag(0); w.flag(0);     // long-term, temporal MVP, strong intra smoothing, VUI, extension
+    w.flag(0); w.flag(1); w.flag((cfg->tools & HEVCDL_TOOL_STRONG_INTRA) != 0); w.flag(0); w.flag(0);     // long-term, temporal MVP, strong intra smoothing, VUI, extension
     w.trailing();
     put_nal(au, 33, w.b, true);
   }
   { // PPS  TEncCavlc.cpp:189-341
     BitOut w;
-    w.ue(0); w.ue(0); w.flag(0); w.flag(0); w.write(0, 3); w.flag(1); w.flag(1); w.ue(3); w.ue(3);
-    w.se(0); w.flag(0); w.flag(1); w.flag(0);        // init_qp_minus26 0, constrained intra, transform skip, cu_qp_delta
+    w.ue(0); w.ue(0); w.flag(0); w.flag(0); w.write(0, 3); w.flag((cfg->tools & HEVCDL_TOOL_SIGN_HIDE) != 0); w.flag(1); w.ue(3); w.ue(3);   // ... sign_data_hiding_enabled_flag, cabac_init_present_flag, ...
+    w.se(0); w.flag(0); w.flag((cfg->tools & HEVCDL_TOOL_TSKIP) != 0); w.flag(0);        // init_qp_minus26 0, constrained intra, transform skip, cu_qp_delta
     w.se(0); w.se(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0);      // chroma qp offsets, slice chroma offsets present, weighted (bi)pred, transquant bypass
     w.flag(tiled); w.flag(0);                        // tiles_enabled_flag, entropy_coding_sync_enabled_flag
     if (tiled) { // :228-246

@@ -40,6 +40,11 @@ typedef enum {
 #define HEVCDL_TOOL_STRONG_INTRA    (1u << 5)
 #define HEVCDL_TOOL_FAST_UDI_MPM    (1u << 6)
 #define HEVCDL_TOOLS_REFERENCE      0x7fu
+/* What may be turned off (cfg keys TransformSkip, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled; each pinned by a run of the reference encoder with the switch on
+ * its command line: tests/golden/rd_k*.npz).  RDOQ, RDOQTS and TransformSkipFast keep the reference cfg's value 1: without RDOQ the quantiser is another routine
+ * (the plain quantiser of TComTrQuant::xQuant), without TransformSkipFast every 4x4 TU is tried both ways (TEncSearch.cpp:1502-1505) -- rejected, not ignored. */
+#define HEVCDL_TOOLS_SWITCHABLE     (HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_SIGN_HIDE | HEVCDL_TOOL_STRONG_INTRA | HEVCDL_TOOL_FAST_UDI_MPM)
+#define hevcdl_tools_supported(t)   ((((t) | HEVCDL_TOOLS_SWITCHABLE) == HEVCDL_TOOLS_REFERENCE) && ((t) & ~HEVCDL_TOOLS_REFERENCE) == 0)
 
 #define HEVCDL_CNN_INPUT_RGB601 0   /* BT.601 limited-range YUV -> RGB, nearest chroma (defined by this project) */
 #define HEVCDL_CNN_INPUT_LUMA   1   /* R = G = B = Y */
@@ -64,7 +69,7 @@ typedef struct hevcdl_config {
   int32_t  ctu_size;             /* 64   (MaxCUWidth/Height)          */
   int32_t  max_partition_depth;  /* 4    (MaxPartitionDepth)          */
   int32_t  tu_log2_min, tu_log2_max, tu_max_depth_intra;   /* 2, 5, 3 */
-  uint32_t tools;                /* HEVCDL_TOOL_* ; must equal HEVCDL_TOOLS_REFERENCE for now */
+  uint32_t tools;                /* HEVCDL_TOOL_* ; HEVCDL_TOOLS_REFERENCE less any of HEVCDL_TOOLS_SWITCHABLE */
   int32_t  bn_mode, boundary_policy, cnn_input;
   int32_t  device;               /* HIP device ordinal */
   int32_t  max_frames;           /* frames per call the workspace is sized for */
@@ -228,6 +233,8 @@ typedef struct hevcdl_stream_config {
   int32_t  tile_uniform_spacing; /* as in the hevcdl_config field, default 1; 0: column_width_minus1 / row_height_minus1 are written */
   int32_t  tile_column_width[19], tile_row_height[21];
   int32_t  lf_across_tiles;      /* loop_filter_across_tiles_enabled_flag of the PPS (default 1) */
+  uint32_t tools;                /* as in hevcdl_config: transform_skip_enabled_flag / sign_data_hiding_enabled_flag of the PPS, strong_intra_smoothing_enabled_flag of the SPS,
+                                    and the residual syntax that goes with the first two */
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
 size_t        hevcdl_access_unit_bound(int width, int height);
