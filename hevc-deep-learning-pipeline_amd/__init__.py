@@ -301,10 +301,10 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE):
         """bit_depth 10: every yuv / recon array of the decision path holds uint16 samples (frame_bytes counts bytes)."""
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode, tools)
         self.bit_depth = self.cfg.bit_depth
         self.sample_dtype = np.uint8 if self.bit_depth == 8 else np.dtype("<u2")
         self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)

@@ -235,7 +235,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51 || cfg->max_frames < 1) return HEVCDL_ERR_INVALID_ARG;
   // keys that would change the path are rejected, not ignored
   if ((cfg->bit_depth != 8 && cfg->bit_depth != 10) || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
-      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || cfg->tools != HEVCDL_TOOLS_REFERENCE || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
+      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || !HEVCDL_TOOLS_SUPPORTED(cfg->tools) || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
       cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA) ||
       (cfg->exec_flags & ~(HEVCDL_EXEC_NO_UNIT_HANDOVER | HEVCDL_EXEC_RD_WIDE | HEVCDL_EXEC_RD_NARROW)) ||
       ((cfg->exec_flags & HEVCDL_EXEC_RD_WIDE) && (cfg->exec_flags & HEVCDL_EXEC_RD_NARROW)))
@@ -428,7 +428,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
   p.k.sbh_rd_factor[0] = ctx->cfg.sbh_rd_factor[0]; p.k.sbh_rd_factor[1] = ctx->cfg.sbh_rd_factor[1];
-  p.k.qp = ctx->cfg.qp; p.k.qp_chroma = ctx->cfg.qp_chroma;
+  p.k.qp = ctx->cfg.qp; p.k.qp_chroma = ctx->cfg.qp_chroma; p.k.tools = (int)ctx->cfg.tools;
 #ifdef HEVCDL_STAGE_TRACE
   // stage-trace build (tests/test_rd_gpu.py, lib/libhevcdl_hip_trace.so): the kernel logs its search events here; hevcdl_stage_trace_fetch reads them
   if (!g_stage_log) HIPCHK(hipMalloc(&g_stage_log, STAGE_LOG_WORDS * 4));

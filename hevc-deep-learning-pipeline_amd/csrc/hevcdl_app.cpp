@@ -48,8 +48,9 @@ const Key KEYS[] = {
   { "MaxCUWidth", 0, PATH, "64" }, { "MaxCUHeight", 0, PATH, "64" }, { "MaxPartitionDepth", 0, PATH, "4" },
   { "QuadtreeTULog2MaxSize", 0, PATH, "5" }, { "QuadtreeTULog2MinSize", 0, PATH, "2" }, { "QuadtreeTUMaxDepthIntra", 0, PATH, "3" },
   { "IntraPeriod", 0, PATH, "1" }, { "GOPSize", 0, PATH, "1" }, { "MaxDeltaQP", 0, PATH, "0" }, { "DeltaQpRD", 0, PATH, "0" },
-  { "RDOQ", 0, PATH, "1" }, { "RDOQTS", 0, PATH, "1" }, { "TransformSkip", 0, PATH, "1" }, { "TransformSkipFast", 0, PATH, "1" },
-  { "SignHideFlag", "SBH", PATH, "1" }, { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, USED, 0 },
+  { "RDOQ", 0, PATH, "1" }, { "RDOQTS", 0, PATH, "1" }, { "TransformSkip", 0, USED, 0 }, { "TransformSkipFast", 0, PATH, "1" },
+  { "SignHideFlag", "SBH", USED, 0 }, { "StrongIntraSmoothing", 0, USED, 0 }, { "FastUDIUseMPMEnabled", 0, USED, 0 },      // tool switches (hevcdl_config.tools): 0 or 1
+  { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, USED, 0 },
   { "NumTileRowsMinus1", 0, USED, 0 }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stream / in-loop filter keys
@@ -316,6 +317,13 @@ int main(int argc, char **argv)
     cfg.tile_uniform_spacing = tile_uniform; cfg.lf_across_tiles = opt.geti("LFCrossTileBoundaryFlag", 1) != 0;
     if (!tile_uniform) { for (int i = 0; i < tile_cols - 1; i++) cfg.tile_column_width[i] = tile_cw[i]; for (int i = 0; i < tile_rows - 1; i++) cfg.tile_row_height[i] = tile_rh[i]; }
   }
+  // tool switches of the cfg (TAppEncCfg.cpp:900-901,917-918,950,978,1007; encoder_intra_main.cfg:37-38,53-54): defaults as the reference's
+  uint32_t tools = HEVCDL_TOOLS_REFERENCE;
+  if (opt.geti("TransformSkip", 1) == 0) tools &= ~HEVCDL_TOOL_TSKIP;
+  if (opt.geti("SignHideFlag", 1) == 0) tools &= ~HEVCDL_TOOL_SIGN_HIDE;
+  if (opt.geti("StrongIntraSmoothing", 1) == 0) tools &= ~HEVCDL_TOOL_STRONG_INTRA;
+  if (opt.geti("FastUDIUseMPMEnabled", 1) == 0) tools &= ~HEVCDL_TOOL_FAST_UDI_MPM;
+  cfg.tools = tools;
   cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
   cfg.bn_mode = bn_mode == "eval" ? HEVCDL_BN_EVAL : HEVCDL_BN_REFERENCE;
   if (shared_device) cfg.exec_flags |= HEVCDL_EXEC_NO_UNIT_HANDOVER;
@@ -380,6 +388,7 @@ int main(int argc, char **argv)
   if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
+  scfg.tools = cfg.tools;
   scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;

@@ -581,7 +581,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   if ((cfg->sao_enabled != 0) != (sao != nullptr)) return HEVCDL_ERR_INVALID_ARG;         // SAO parameters go with sample_adaptive_offset_enabled_flag
   const int bd = cfg->bit_depth;
   if (bd != 8 && bd != 10) return HEVCDL_ERR_UNSUPPORTED;
-  if (!hevcdl_tools_supported(cfg->tools)) return HEVCDL_ERR_UNSUPPORTED;
+  if (!HEVCDL_TOOLS_SUPPORTED(cfg->tools)) return HEVCDL_ERR_UNSUPPORTED;
   t_tools = cfg->tools;
   const int tcols = cfg->tile_columns, trows = cfg->tile_rows, tiled = tcols * trows > 1;
   if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22) return HEVCDL_ERR_INVALID_ARG;

@@ -81,6 +81,7 @@ struct hevcdl_rd_consts {
   double err_scale[2][4];
   long long sbh_rd_factor[2];
   int qp, qp_chroma;
+  int tools, pad_tools;            // hevcdl_config.tools (HEVCDL_TOOL_*): what the cfg's switches leave on
 };
 
 struct hevcdl_rd_params {

@@ -141,6 +141,7 @@ __constant__ int c_inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };            
 __constant__ uint8_t c_group_idx[32] = { 0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9 };   // TComRom.cpp:598
 __constant__ uint8_t c_ctx_ind_map_4x4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };   // TComRom.cpp:589-595
 __constant__ uint8_t c_num_rd_cand[5] = { 8, 8, 3, 3, 3 };                                  // TComRom.cpp:545-553
+__constant__ uint8_t c_num_rd_cand_no_mpm[5] = { 9, 9, 4, 4, 5 };                           // TComRom.cpp:554-562 (FastUDIUseMPMEnabled 0)
 __constant__ uint8_t c_intra_filter_thr[5] = { 10, 7, 1, 0, 10 };                           // TComPrediction.cpp:50-58
 __constant__ int c_ang_table[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };                      // TComPrediction.cpp:265
 __constant__ int c_inv_ang_table[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };     // TComPrediction.cpp:266
@@ -194,6 +195,7 @@ struct K {                             // wave-uniform kernel context (lives in 
   long long sbh[2];
   int qp, qp_c;
   int dbg;
+  int tools;                           // HEVCDL_TOOL_* bits the cfg leaves on (TransformSkip, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled can be off)
   GLB unsigned int *dbgbuf;
 };
 typedef const LDS K &KR;
@@ -639,7 +641,7 @@ DEV void filter_refs(KR k, int n_)
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
   const int bl = src[0], tl = src[n2], tr = src[last];
-  if (n >= 32) strong = (abs(bl + tl - 2 * src[n]) < (1 << (BD - 5))) && (abs(tl + tr - 2 * src[n2 + n]) < (1 << (BD - 5)));
+  if (n >= 32 && (uni(k.tools) & (int)HEVCDL_TOOL_STRONG_INTRA)) strong = (abs(bl + tl - 2 * src[n]) < (1 << (BD - 5))) && (abs(tl + tr - 2 * src[n2 + n]) < (1 << (BD - 5)));     // sps_strong_intra_smoothing_enable_flag
   for (int i = lane_id(); i <= last; i += 64) {
     int v;
     if (i == 0 || i == last) v = src[i];
@@ -1468,7 +1470,7 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   }
   abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
   wsync();
-  if (abs_sum >= 2) { // lanes 0..15 own the positions of the group being visited
+  if (abs_sum >= 2 && (uni(k.tools) & (int)HEVCDL_TOOL_SIGN_HIDE)) { // (with sign_data_hiding_enabled_flag) lanes 0..15 own the positions of the group being visited
     const long long rd_factor = k.sbh[ch];
     const long long I64MAX = 0x7fffffffffffffffll;
     while (sbh_need) {
@@ -1617,7 +1619,8 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
   ep((pre >> PRE_EP_SHIFT) & 15);
   const unsigned long long frac_hdr = frac;
   if (scan_last >= 0) {
-  if (n == 4) bin_b(CTX_TSKIP + ch, tskip_flag);                // codeTransformSkipFlags :997-1032
+  const int tools = uni(k.tools);
+  if (n == 4 && (tools & (int)HEVCDL_TOOL_TSKIP)) bin_b(CTX_TSKIP + ch, tskip_flag);                // codeTransformSkipFlags :997-1032 (with transform_skip_enabled_flag)
   { // codeLastSignificantXY TEncSbac.cpp:1051-1113
     const int pos_last = uni(scan[scan_last]);
     int py = pos_last >> log2n, px = pos_last - (py << log2n);
@@ -1657,7 +1660,7 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
     }
     if (num_nz > 0) {
       const int last_nz = 31 - __clz((int)sigmask), first_nz = __ffs((int)sigmask) - 1;
-      const int sign_hidden = (last_nz - first_nz >= 4);
+      const int sign_hidden = (last_nz - first_nz >= 4) && (tools & (int)HEVCDL_TOOL_SIGN_HIDE);
       const int cset = ctx_set_index(ch, subset, c1 == 0);
       c1 = 1;
       int escape = 0, abs_c2 = -1; unsigned m = sigmask;
@@ -2230,7 +2233,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
   unsigned long long single_cfrac = 0;
-  const int check_ts = (LOG2 == 2) && (cu.part == SIZE_NxN);
+  const int check_ts = (LOG2 == 2) && (cu.part == SIZE_NxN) && (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP);
   if (memo) { single_cost = memo_cost; single_dist = memo_dist; cabac_copy(k, &s.root[full_depth], &s.go); }
   else if (check_full) {
     if (check_ts) {
@@ -2784,7 +2787,9 @@ template <bool TRACE> DEV int rmd_candidates(KR k, int x, int y, int pu_log2, un
 {
   LSmem &s = lds();
   int preds[3], nm; get_mpm(k, x, y, preds, &nm);
-  int nfull = c_num_rd_cand[pu_log2 - 2];
+  const int use_mpm = uni(k.tools) & (int)HEVCDL_TOOL_FAST_UDI_MPM;       // FastUDIUseMPMEnabled: the list is the c_num_rd_cand best + the most probable modes; without it one more and no additions (TEncSearch.cpp:2269, 2322)
+  int nfull = use_mpm ? c_num_rd_cand[pu_log2 - 2] : c_num_rd_cand_no_mpm[pu_log2 - 2];
+  if (!use_mpm) nm = 0;
   if (lane_id() < 35) {
     const int mode = lane_id();
     int idx = -1; for (int i = 0; i < 3; i++) if (mode == preds[i]) idx = i;
@@ -3137,7 +3142,7 @@ template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
   if (uni(s.a[A_TRIDX][z]) == tu.trd) {
     if (!tu_has_chroma_first(tu)) return 0;
     const int full_depth = cu.depth + tu.trd;
-    int check_ts = (LOG2 == 2);
+    int check_ts = (LOG2 == 2) && (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP);
     if (check_ts) { int nb = 0; for (int i = 0; i < 4; i++) nb += s.a[A_TSKIP + 0][z + i]; check_ts = uni(nb) > 0; }
     const int zc = cu.zbase + tu_czrel(tu), np = tu_cnparts(tu);
     for (int comp = 1; comp < 3; comp++) {
@@ -4217,7 +4222,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   k.in_task = 0; k.trx0 = k.try0 = k.trx1 = k.try1 = 0; k.lz = k.lx = k.ly = 0; k.srect[0] = k.srect[1] = k.srect[2] = 0; k.ssrc[0] = k.ssrc[1] = k.ssrc[2] = k.best_rec; k.sorg[0] = k.sorg[1] = k.sorg[2] = k.sorg[3] = 0; k.pset = 0; k.pad_pset = 0;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
-  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf;
+  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = p.debug; k.dbgbuf = (GLB unsigned int *)p.dbgbuf; k.tools = p.k.tools;
   if (lane == 0) { s.est_bits = 0; s.sse_acc[0] = s.sse_acc[1] = s.sse_acc[2] = 0; s.carry_ok = 0; s.restart = 0; s.pend_n = 0; s.p2_pending = 0; s.left_pending = 0; }
   wsync();
   // slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720); the true coder of TEncSlice.cpp:719.
@@ -4535,7 +4540,7 @@ void hevcdl_micro_kernel(hevcdl_rd_params p, const int16_t *resi_, int n_blocks,
   k.q_cost = s.my_qcost; k.q_rate = s.my_qrate;
   k.lambda = p.k.lambda; k.sqrt_lambda = p.k.sqrt_lambda; k.cweight = p.k.chroma_weight; k.lambda_c = p.k.lambda_chroma;
   for (int a = 0; a < 2; a++) { for (int b = 0; b < 4; b++) k.err_scale[a][b] = p.k.err_scale[a][b]; k.sbh[a] = p.k.sbh_rd_factor[a]; }
-  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = 0; k.dbgbuf = nullptr;
+  k.qp = p.k.qp; k.qp_c = p.k.qp_chroma; k.dbg = 0; k.dbgbuf = nullptr; k.tools = p.k.tools;
   LCabac *c0 = &s.truec;
   for (int i = lane; i < NUM_CTX; i += 64) {
     const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
@@ -4590,7 +4595,7 @@ extern "C" int hevcdl_micro_run(const double *consts, const long long *sbh, int 
   hevcdl_rd_params p = {};
   p.k.lambda = consts[0]; p.k.sqrt_lambda = consts[1]; p.k.chroma_weight = consts[2]; p.k.lambda_chroma = consts[3];
   for (int a = 0; a < 2; a++) for (int b = 0; b < 4; b++) p.k.err_scale[a][b] = consts[4 + 4 * a + b];
-  p.k.sbh_rd_factor[0] = sbh[0]; p.k.sbh_rd_factor[1] = sbh[1]; p.k.qp = qp; p.k.qp_chroma = qp_c;
+  p.k.sbh_rd_factor[0] = sbh[0]; p.k.sbh_rd_factor[1] = sbh[1]; p.k.qp = qp; p.k.qp_chroma = qp_c; p.k.tools = (int)HEVCDL_TOOLS_REFERENCE;
   p.scratch_per_wave = SCR_WAVE;
   int16_t *d_resi = nullptr; unsigned long long *d_out = nullptr; unsigned char *d_scr = nullptr;
   const size_t smem = (size_t)NW * sizeof(RdSmem) + sizeof(WgShared);

@@ -44,7 +44,7 @@ typedef enum {
  * its command line: tests/golden/rd_k*.npz).  RDOQ, RDOQTS and TransformSkipFast keep the reference cfg's value 1: without RDOQ the quantiser is another routine
  * (the plain quantiser of TComTrQuant::xQuant), without TransformSkipFast every 4x4 TU is tried both ways (TEncSearch.cpp:1502-1505) -- rejected, not ignored. */
 #define HEVCDL_TOOLS_SWITCHABLE     (HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_SIGN_HIDE | HEVCDL_TOOL_STRONG_INTRA | HEVCDL_TOOL_FAST_UDI_MPM)
-#define hevcdl_tools_supported(t)   ((((t) | HEVCDL_TOOLS_SWITCHABLE) == HEVCDL_TOOLS_REFERENCE) && ((t) & ~HEVCDL_TOOLS_REFERENCE) == 0)
+#define HEVCDL_TOOLS_SUPPORTED(t)   ((((t) | HEVCDL_TOOLS_SWITCHABLE) == HEVCDL_TOOLS_REFERENCE) && ((t) & ~HEVCDL_TOOLS_REFERENCE) == 0)
 
 #define HEVCDL_CNN_INPUT_RGB601 0   /* BT.601 limited-range YUV -> RGB, nearest chroma (defined by this project) */
 #define HEVCDL_CNN_INPUT_LUMA   1   /* R = G = B = Y */

@@ -33,7 +33,8 @@ def test_golden_records_bit_exact(path):
     yuv, labels, ref = f["yuv"], f["labels"], f["records"]
     tiles = fixture_tiles(f)                                                        # rd_t* / rd_n*: reference runs with tiles enabled
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
-    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd)
+    tools = int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE   # rd_k*: reference runs with TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled off
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd, tools=tools)
     recs, recon, stats = enc.compress_frames(yuv, labels)
     enc.close()
     assert recon.dtype == (np.uint8 if bd == 8 else np.uint16)
@@ -71,7 +72,7 @@ def test_golden_records_bit_exact_on_either_build_of_the_kernel(path, flags):
     f = np.load(path)
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     yuv, labels, ref = f["yuv"], f["labels"], f["records"]
-    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=yuv.shape[0], tiles=fixture_tiles(f))
+    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=yuv.shape[0], tiles=fixture_tiles(f), tools=int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE)
     cfg.exec_flags = flags
     enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
     recs, recon, stats = enc.compress_frames(yuv, labels)

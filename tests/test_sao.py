@@ -36,6 +36,10 @@ def tiles_of(f):
     return fixture_tiles(f)
 
 
+def tools_of(f):
+    return int(f["tools"]) if "tools" in f.files else 0x7f          # rd_k*: reference runs with a tool switch of the cfg turned off
+
+
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
 def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     """Final reconstruction == the reference's output picture, and the decided parameters, written by the product's
@@ -48,7 +52,7 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
     aus = [hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f),
-                                        lf_across_tiles=fixture_lf(f)) for poc in range(nf)]
+                                        lf_across_tiles=fixture_lf(f), tools=tools_of(f)) for poc in range(nf)]
     assert b"".join(aus) == strip_sei(f["bitstream"].tobytes())
     # with the decoded-picture-hash SEI (MD5 of the final picture) behind every access unit: the reference's stream, every byte
     assert b"".join(au + hevcdl_amd.picture_hash_sei(w, h, out[poc], bit_depth_of(f)) for poc, au in enumerate(aus)) == f["bitstream"].tobytes()
@@ -64,7 +68,7 @@ def test_gpu_sao_matches_reference(path):
     e.close()
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f)) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f), tools=tools_of(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 
