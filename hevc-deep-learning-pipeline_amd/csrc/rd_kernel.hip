@@ -1530,6 +1530,67 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   return (uint32_t)uni((int)abs_sum);
 }
 
+// The quantiser without RDOQ (cfg RDOQ 0, or RDOQTS 0 for a transform-skipped block): TComTrQuant::xQuant TComTrQuant.cpp:1169-1249 -- dead-zone rounding with the intra offset
+// 171 / 512 -- and, with sign data hiding on, signBitHidingHDQ (:991-1113).  Whole wave, s->tc -> s->lvl, returns uiAbsSum (of the levels before the hiding pass, as the reference).
+// Not the configuration the bench runs: kept out of line and simple.
+DEVN uint32_t plain_quant_wave(KR k, int c_, int n_, int dir_mode_)
+{
+  const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_);
+  LSmem &s = lds();
+  const int lane = lane_id(), log2n = ilog2(n), ncoef = n * n;
+  const int qp = uni(c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;
+  const int qbits = 14 + per + (15 - BD - log2n), qbits8 = qbits - 8;
+  const uint32_t qcoef = (uint32_t)uni(c_quant_scales[rem]), add = 171u << (qbits - 9);       // (|coefficient| * scale < 2^30, qbits <= 27: 32 bits hold every value, see rdoq_wave)
+  LDS const int16_t *src = s.tc; LDS int16_t *dst = s.lvl;
+  uint32_t abs_sum = 0;
+  for (int i = lane; i < ncoef; i += 64) {
+    const int v = src[i];
+    const uint32_t mag = (__umul24((unsigned)abs(v), qcoef) + add) >> qbits;
+    abs_sum += mag;
+    dst[i] = (int16_t)clip16(v < 0 ? -(int)mag : (int)mag);
+  }
+  abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
+  wsync();
+  if ((uni(k.tools) & (int)HEVCDL_TOOL_SIGN_HIDE) && abs_sum >= 2) {
+    CParam cp; get_cparam(cp, c, n, dir_mode);
+    const ScanFn scan = scan_of(s, cp.scan_type, log2n);
+    bool seen = false;                                     // a group with a level has been met (the reference's lastCG: 1 for the first such group from the top)
+    for (int subset = (ncoef - 1) >> 4; subset >= 0; subset--) {
+      const int j = lane & 15, blk_j = scan[(subset << 4) + j];
+      const int lv_j = lane < 16 ? (int)dst[blk_j] : 0, cf_j = src[blk_j];
+      const unsigned nzmask = (unsigned)(__ballot(lv_j != 0) & 0xffffull);
+      if (!nzmask) continue;
+      const int last_cg = seen ? 0 : 1; seen = true;
+      const int last_nz = 31 - __clz((int)nzmask), first_nz = __ffs((int)nzmask) - 1;
+      if (last_nz - first_nz < 4) continue;
+      const int sum = wave_sum_i(lv_j);
+      const unsigned signbit = __builtin_amdgcn_readlane(lv_j, first_nz) > 0 ? 0u : 1u;
+      if (signbit == ((unsigned)sum & 1u)) continue;
+      const int nmax = last_cg ? last_nz : 15;
+      // deltaU of the position, from its coefficient and the level it was given (nothing has changed it yet: a visit only touches its own group, once)
+      const int du_j = (int)(__umul24((unsigned)abs(cf_j), qcoef) - ((unsigned)abs(lv_j) << qbits)) >> qbits8;
+      int cost = 0x7ffffff, change = 1;                    // (0x7ffffff: "not a candidate"; the real costs are a few hundred at most)
+      if (lane < 16 && j <= nmax) {
+        if (lv_j != 0) {
+          if (du_j > 0) cost = -du_j;
+          else if (!(j == first_nz && abs(lv_j) == 1)) { cost = du_j; change = -1; }
+        } else if (!(j < first_nz && (cf_j >= 0 ? 0u : 1u) != signbit)) cost = -du_j;
+      }
+      // the reference walks n = nmax .. 0 and keeps the first strict minimum: smallest cost, ties -> largest n
+      const int key = cost < 0x7ffffff ? cost * 16 + (15 - j) : 0x7fffffff;
+      const int best = -wave_max_i(-key);
+      const int min_n = 15 - (best & 15);
+      int final_change = __builtin_amdgcn_readlane(change, min_n);
+      const int lv_min = __builtin_amdgcn_readlane(lv_j, min_n);
+      if (lv_min == 32767 || lv_min == -32768) final_change = -1;
+      if (lane == min_n) dst[blk_j] = (int16_t)(cf_j >= 0 ? lv_j + final_change : lv_j - final_change);
+      wsync();
+    }
+  }
+  wsync();
+  return (uint32_t)uni((int)abs_sum);
+}
+
 DEV void dequant(KR k, int c_, int n_)
 {
   PROF_T0();
@@ -2074,7 +2135,8 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
 #endif
   uint32_t abs_sum;                                             // (wave-uniform as rdoq_wave returns it)
   { PROF_T0();
-    abs_sum = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);
+    if (uni(k.tools) & (int)(tskip ? HEVCDL_TOOL_RDOQTS : HEVCDL_TOOL_RDOQ)) abs_sum = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);      // useRDOQ = transform skip ? RDOQTS : RDOQ (TComTrQuant.cpp:1152)
+    else abs_sum = plain_quant_wave(k, comp, n, mode);
     PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
   wsync();
   PROF_MARK(27);

@@ -40,10 +40,11 @@ typedef enum {
 #define HEVCDL_TOOL_STRONG_INTRA    (1u << 5)
 #define HEVCDL_TOOL_FAST_UDI_MPM    (1u << 6)
 #define HEVCDL_TOOLS_REFERENCE      0x7fu
-/* What may be turned off (cfg keys TransformSkip, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled; each pinned by a run of the reference encoder with the switch on
- * its command line: tests/golden/rd_k*.npz).  RDOQ, RDOQTS and TransformSkipFast keep the reference cfg's value 1: without RDOQ the quantiser is another routine
- * (the plain quantiser of TComTrQuant::xQuant), without TransformSkipFast every 4x4 TU is tried both ways (TEncSearch.cpp:1502-1505) -- rejected, not ignored. */
-#define HEVCDL_TOOLS_SWITCHABLE     (HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_SIGN_HIDE | HEVCDL_TOOL_STRONG_INTRA | HEVCDL_TOOL_FAST_UDI_MPM)
+/* What may be turned off (cfg keys RDOQ, RDOQTS, TransformSkip, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled; each pinned by a run of the reference encoder with the
+ * switch on its command line: tests/golden/rd_k*.npz).  Without RDOQ the quantiser is the dead-zone rounding of TComTrQuant::xQuant with signBitHidingHDQ behind it
+ * (RDOQTS: the same choice for transform-skipped blocks).  TransformSkipFast keeps the reference cfg's value 1: without it every 4x4 TU is tried both ways
+ * (TEncSearch.cpp:1502-1505) -- rejected, not ignored. */
+#define HEVCDL_TOOLS_SWITCHABLE     (HEVCDL_TOOL_RDOQ | HEVCDL_TOOL_RDOQTS | HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_SIGN_HIDE | HEVCDL_TOOL_STRONG_INTRA | HEVCDL_TOOL_FAST_UDI_MPM)
 #define HEVCDL_TOOLS_SUPPORTED(t)   ((((t) | HEVCDL_TOOLS_SWITCHABLE) == HEVCDL_TOOLS_REFERENCE) && ((t) & ~HEVCDL_TOOLS_REFERENCE) == 0)
 
 #define HEVCDL_CNN_INPUT_RGB601 0   /* BT.601 limited-range YUV -> RGB, nearest chroma (defined by this project) */

@@ -153,8 +153,8 @@ typedef struct { int x, y, log2, depth, zbase, nparts, part; } cu_t;
 /* sample bit depth of the run (8, or 10: InternalBitDepth 10 with RExt__HIGH_BIT_DEPTH_SUPPORT 0, i.e. FULL_NBIT 0, TypeDef.h:162-172).
  * Not thread-safe, like the trace hook: one encode at a time per process. */
 static int g_bd = 8;
-/* tool switches of the cfg (TAppEncCfg.cpp:900-901,917-918,950,978,1007), bits as HEVCDL_TOOL_* of include/hevcdl.h: 0x04 TransformSkip, 0x10 SignHideFlag, 0x20 StrongIntraSmoothing,
- * 0x40 FastUDIUseMPMEnabled can be cleared; RDOQ, RDOQTS, TransformSkipFast stay on (the reference cfg's values) */
+/* tool switches of the cfg (TAppEncCfg.cpp:900-901,917-918,950,978,1007), bits as HEVCDL_TOOL_* of include/hevcdl.h: 0x01 RDOQ, 0x02 RDOQTS, 0x04 TransformSkip, 0x10 SignHideFlag,
+ * 0x20 StrongIntraSmoothing, 0x40 FastUDIUseMPMEnabled can be cleared; TransformSkipFast (0x08) stays on (the reference cfg's value) */
 static unsigned g_tools = 0x7fu;
 void hm_oracle_set_tools(unsigned tools) { g_tools = tools; }
 #define DIST_ADJ(x) (x)          /* DISTORTION_PRECISION_ADJUSTMENT, TypeDef.h:170 */
@@ -559,9 +559,65 @@ static int ic_rate(const cabac_t *cab, uint32_t abs_level, int ctx_one, int ctx_
   return rate;
 }
 
+/* The quantiser without RDOQ (cfg RDOQ 0; RDOQTS 0 for transform-skipped blocks): TComTrQuant::xQuant, TComTrQuant.cpp:1169-1249 -- dead-zone rounding with the intra
+ * offset 171 / 512 -- and, with sign data hiding on, signBitHidingHDQ (:991-1113): per coefficient group whose first and last level are four positions or more apart and
+ * whose parity disagrees with the first level's sign, the level whose change costs least by deltaU alone goes up or down by one. */
+static uint32_t plain_quant(const enc_t *e, int c, int n, int dir_mode, const int32_t *src, int32_t *dst)
+{
+  const int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
+  const int qp = (c ? e->qp_c : e->qp) + 6 * (g_bd - 8), per = qp / 6, rem = qp % 6;
+  const int qbits = 14 + per + (15 - g_bd - log2n), qbits8 = qbits - 8, ncoef = n * n;
+  const int64_t add = (int64_t)171 << (qbits - 9);             /* I slice */
+  const int qcoef = g_quant_scales[rem];
+  static int32_t delta_u[1024];
+  uint32_t abs_sum = 0;
+  for (int i = 0; i < ncoef; i++) {
+    const int64_t tmp = (int64_t)abs(src[i]) * qcoef;
+    const int32_t mag = (int32_t)((tmp + add) >> qbits);
+    delta_u[i] = (int32_t)((tmp - ((int64_t)mag << qbits)) >> qbits8);
+    abs_sum += (uint32_t)mag;
+    int32_t q = src[i] < 0 ? -mag : mag;
+    dst[i] = q < -32768 ? -32768 : (q > 32767 ? 32767 : q);
+  }
+  if ((g_tools & 0x10u) && abs_sum >= 2) {
+    cparam_t cp; get_cparam(&cp, c, n, dir_mode);
+    int last_cg = -1;
+    for (int subset = (ncoef - 1) >> 4; subset >= 0; subset--) {
+      int sub_pos = subset << 4, first_nz = 16, last_nz = -1, sum = 0, k;
+      for (k = 15; k >= 0; --k) if (dst[cp.scan[k + sub_pos]]) { last_nz = k; break; }
+      for (k = 0; k < 16; k++) if (dst[cp.scan[k + sub_pos]]) { first_nz = k; break; }
+      for (k = first_nz; k <= last_nz; k++) sum += dst[cp.scan[k + sub_pos]];
+      if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+      if (last_nz - first_nz >= 4) {
+        const uint32_t signbit = dst[cp.scan[sub_pos + first_nz]] > 0 ? 0 : 1;
+        if (signbit != ((uint32_t)sum & 1u)) {
+          int32_t cur_cost = INT32_MAX, min_cost = INT32_MAX; int min_pos = -1, final_change = 0, cur_change = 0;
+          for (k = (last_cg == 1 ? last_nz : 15); k >= 0; --k) {
+            const int blk = cp.scan[k + sub_pos];
+            if (dst[blk] != 0) {
+              if (delta_u[blk] > 0) { cur_cost = -delta_u[blk]; cur_change = 1; }
+              else if (k == first_nz && abs(dst[blk]) == 1) cur_cost = INT32_MAX;        /* (curChange keeps its value, as in the reference) */
+              else { cur_cost = delta_u[blk]; cur_change = -1; }
+            } else if (k < first_nz) {
+              const uint32_t ts = src[blk] >= 0 ? 0 : 1;
+              if (ts != signbit) cur_cost = INT32_MAX; else { cur_cost = -delta_u[blk]; cur_change = 1; }
+            } else { cur_cost = -delta_u[blk]; cur_change = 1; }
+            if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = blk; }
+          }
+          if (dst[min_pos] == 32767 || dst[min_pos] == -32768) final_change = -1;
+          if (src[min_pos] >= 0) dst[min_pos] += final_change; else dst[min_pos] -= final_change;
+        }
+      }
+      if (last_cg == 1) last_cg = 0;
+    }
+  }
+  return abs_sum;
+}
+
 static uint32_t rdoq(const enc_t *e, const cabac_t *cab, int c, int n, int dir_mode, int is_tskip, int cbf_ctx,
                      const int32_t *src, int32_t *dst)
 {
+  if (!(g_tools & (is_tskip ? 0x02u : 0x01u))) return plain_quant(e, c, n, dir_mode, src, dst);     /* useRDOQ = transform skip ? RDOQTS : RDOQ, TComTrQuant.cpp:1152 */
   const int ch = c ? 1 : 0;
   const int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
   const int qp = (c ? e->qp_c : e->qp) + 6 * (g_bd - 8), per = qp / 6, rem = qp % 6;      /* + qpBdOffset, TComTrQuant.cpp:71-100 */
@@ -571,7 +627,6 @@ static uint32_t rdoq(const enc_t *e, const cabac_t *cab, int c, int n, int dir_m
   const double err_scale = e->err_scale[ch][log2n - 2];
   const int qcoef = g_quant_scales[rem];
   const int ncoef = n * n;
-  (void)is_tskip;
   cparam_t cp; get_cparam(&cp, c, n, dir_mode);
   static double cost_coeff[1024], cost_sig[1024], cost_coeff0[1024];
   static int rate_inc_up[1024], rate_inc_down[1024], sig_rate_delta[1024];

@@ -206,12 +206,14 @@ def tile_bounds(tiles, width, height):
 
 
 TOOLS_REFERENCE = 0x7f
-TOOL_TSKIP, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x04, 0x10, 0x20, 0x40     # HEVCDL_TOOL_* of include/hevcdl.h
+TOOL_RDOQ, TOOL_RDOQTS, TOOL_TSKIP, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x01, 0x02, 0x04, 0x10, 0x20, 0x40     # HEVCDL_TOOL_* of include/hevcdl.h
 
 
 def tool_args(tools):
     """The reference's command-line switches for a tool mask (TAppEncCfg.cpp:900-901,917-918,950,978,1007)."""
     a = []
+    if not tools & TOOL_RDOQ: a.append("--RDOQ=0")
+    if not tools & TOOL_RDOQTS: a.append("--RDOQTS=0")
     if not tools & TOOL_TSKIP: a.append("--TransformSkip=0")
     if not tools & TOOL_SIGN_HIDE: a.append("--SignHideFlag=0")
     if not tools & TOOL_STRONG_INTRA: a.append("--StrongIntraSmoothing=0")
