@@ -1533,7 +1533,7 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
 // The quantiser without RDOQ (cfg RDOQ 0, or RDOQTS 0 for a transform-skipped block): TComTrQuant::xQuant TComTrQuant.cpp:1169-1249 -- dead-zone rounding with the intra offset
 // 171 / 512 -- and, with sign data hiding on, signBitHidingHDQ (:991-1113).  Whole wave, s->tc -> s->lvl, returns uiAbsSum (of the levels before the hiding pass, as the reference).
 // Not the configuration the bench runs: kept out of line and simple.
-DEVN uint32_t plain_quant_wave(KR k, int c_, int n_, int dir_mode_)
+DEV uint32_t plain_quant_wave(KR k, int c_, int n_, int dir_mode_)
 {
   const int c = uni(c_), n = uni(n_), dir_mode = uni(dir_mode_);
   LSmem &s = lds();

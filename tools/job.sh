@@ -1,7 +1,7 @@
 #!/bin/bash
-# one GPU session: the GPU suite + A/B times: tools/job.sh <tag> <lib> <lib> ...
+# one GPU session: parity of the decision kernel + A/B times: tools/job.sh <tag> <lib> <lib> ...
 tag=$1; shift
-python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest.txt 2>&1; tail -4 gpurun_out/${tag}_pytest.txt
+python -m pytest tests/test_rd_gpu.py -x -q > gpurun_out/${tag}_pytest.txt 2>&1; tail -3 gpurun_out/${tag}_pytest.txt
 rm -f gpurun_out/${tag}_time_*.txt
 for rep in 1 2; do
 for l in "$@"; do
