@@ -254,7 +254,7 @@ def load_weights(path=WEIGHTS_PATH):
 
 
 TOOLS_REFERENCE = 0x7f
-TOOL_RDOQ, TOOL_RDOQTS, TOOL_TSKIP, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x01, 0x02, 0x04, 0x10, 0x20, 0x40      # HEVCDL_TOOL_* (include/hevcdl.h): the switches that may be turned off
+TOOL_RDOQ, TOOL_RDOQTS, TOOL_TSKIP, TOOL_TSKIP_FAST, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40      # HEVCDL_TOOL_* (include/hevcdl.h): each may be turned off
 
 
 def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE):

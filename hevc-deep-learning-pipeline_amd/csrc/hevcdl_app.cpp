@@ -48,7 +48,7 @@ const Key KEYS[] = {
   { "MaxCUWidth", 0, PATH, "64" }, { "MaxCUHeight", 0, PATH, "64" }, { "MaxPartitionDepth", 0, PATH, "4" },
   { "QuadtreeTULog2MaxSize", 0, PATH, "5" }, { "QuadtreeTULog2MinSize", 0, PATH, "2" }, { "QuadtreeTUMaxDepthIntra", 0, PATH, "3" },
   { "IntraPeriod", 0, PATH, "1" }, { "GOPSize", 0, PATH, "1" }, { "MaxDeltaQP", 0, PATH, "0" }, { "DeltaQpRD", 0, PATH, "0" },
-  { "RDOQ", 0, USED, 0 }, { "RDOQTS", 0, USED, 0 }, { "TransformSkip", 0, USED, 0 }, { "TransformSkipFast", 0, PATH, "1" },
+  { "RDOQ", 0, USED, 0 }, { "RDOQTS", 0, USED, 0 }, { "TransformSkip", 0, USED, 0 }, { "TransformSkipFast", 0, USED, 0 },
   { "SignHideFlag", "SBH", USED, 0 }, { "StrongIntraSmoothing", 0, USED, 0 }, { "FastUDIUseMPMEnabled", 0, USED, 0 },      // tool switches (hevcdl_config.tools): 0 or 1
   { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, USED, 0 },
   { "NumTileRowsMinus1", 0, USED, 0 }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
@@ -322,6 +322,7 @@ int main(int argc, char **argv)
   if (opt.geti("RDOQ", 1) == 0) tools &= ~HEVCDL_TOOL_RDOQ;
   if (opt.geti("RDOQTS", 1) == 0) tools &= ~HEVCDL_TOOL_RDOQTS;
   if (opt.geti("TransformSkip", 1) == 0) tools &= ~HEVCDL_TOOL_TSKIP;
+  if (opt.geti("TransformSkipFast", 1) == 0) tools &= ~HEVCDL_TOOL_TSKIP_FAST;
   if (opt.geti("SignHideFlag", 1) == 0) tools &= ~HEVCDL_TOOL_SIGN_HIDE;
   if (opt.geti("StrongIntraSmoothing", 1) == 0) tools &= ~HEVCDL_TOOL_STRONG_INTRA;
   if (opt.geti("FastUDIUseMPMEnabled", 1) == 0) tools &= ~HEVCDL_TOOL_FAST_UDI_MPM;

@@ -1030,6 +1030,7 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   const int lane = lane_id();
   const int ch = c ? 1 : 0, log2n = ilog2(n);
   const int qp = uni(c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;      // + qpBdOffset (TComTrQuant.cpp:71-100)
+  const int sign_hide = uni(k.tools) & (int)HEVCDL_TOOL_SIGN_HIDE;                       // (read here, with the other words of the context: one wait for all of them)
   const int tshift = 15 - BD - log2n, qbits = 14 + per + tshift;
   const double lambda = c ? k.lambda_c : k.lambda;
   const double err_scale = k.err_scale[ch][log2n - 2];
@@ -1470,7 +1471,7 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   }
   abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
   wsync();
-  if (abs_sum >= 2 && (uni(k.tools) & (int)HEVCDL_TOOL_SIGN_HIDE)) { // (with sign_data_hiding_enabled_flag) lanes 0..15 own the positions of the group being visited
+  if (abs_sum >= 2 && sign_hide) { // (with sign_data_hiding_enabled_flag) lanes 0..15 own the positions of the group being visited
     const long long rd_factor = k.sbh[ch];
     const long long I64MAX = 0x7fffffffffffffffll;
     while (sbh_need) {
@@ -1647,6 +1648,7 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
   constexpr int BB = 97;
   const int BA = ch ? 21 : 19;
   static_assert(CTX_SIG_CG == 19 && CTX_LAST_X + 15 == 82 && CTX_LAST_Y == 97 && NUM_CTX <= BB + 64 && CTX_LAST_X + 15 + 2 < 21 + 64 && CTX_LAST_X + 14 < 19 + 64, "context windows of code_coeff_wave");
+  const int tools = uni(k.tools);
   int cxa = c->ctx[BA + lane], cxb = c->ctx[BB + (lane < 63 ? lane : 62)];
   int cxh = c->ctx[lane < 19 ? lane : 18];                      // H = contexts [0, 19): the header flags (its own register: the windows do not overlap)
   const int eb0 = tb().t_ebits[lane], eb1 = tb().t_ebits[64 + lane];
@@ -1680,7 +1682,6 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
   ep((pre >> PRE_EP_SHIFT) & 15);
   const unsigned long long frac_hdr = frac;
   if (scan_last >= 0) {
-  const int tools = uni(k.tools);
   if (n == 4 && (tools & (int)HEVCDL_TOOL_TSKIP)) bin_b(CTX_TSKIP + ch, tskip_flag);                // codeTransformSkipFlags :997-1032 (with transform_skip_enabled_flag)
   { // codeLastSignificantXY TEncSbac.cpp:1051-1113
     const int pos_last = uni(scan[scan_last]);
@@ -2103,6 +2104,7 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
   const int cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
   const int mode = uni(mode_of(k, cu, comp, zrel));
   const int tskip = uni(s.a[A_TSKIP + comp][zabs]);
+  const int use_rdoq = uni(k.tools) & (int)(tskip ? HEVCDL_TOOL_RDOQTS : HEVCDL_TOOL_RDOQ);        // useRDOQ = transform skip ? RDOQTS : RDOQ (TComTrQuant.cpp:1152)
   if (mode012 != 2) {
     if (HEVCDL_REFS_INLINE && NFIX) build_refs_i(k, comp, x, y, n, 0); else build_refs(k, comp, x, y, n, 0);
     if (ub(use_filtered_refs(comp, mode, n))) filter_refs(k, n);
@@ -2135,7 +2137,7 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
 #endif
   uint32_t abs_sum;                                             // (wave-uniform as rdoq_wave returns it)
   { PROF_T0();
-    if (uni(k.tools) & (int)(tskip ? HEVCDL_TOOL_RDOQTS : HEVCDL_TOOL_RDOQ)) abs_sum = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);      // useRDOQ = transform skip ? RDOQTS : RDOQ (TComTrQuant.cpp:1152)
+    if (use_rdoq) abs_sum = rdoq_wave<NFIX>(k, &s.go, comp, n, mode, cbf_ctx);
     else abs_sum = plain_quant_wave(k, comp, n, mode);
     PROF_ADD(k, 6); PROF_ADD(k, 60 + log2n - 2); }
   wsync();
@@ -2295,7 +2297,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
   unsigned long long single_cfrac = 0;
-  const int check_ts = (LOG2 == 2) && (cu.part == SIZE_NxN) && (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP);
+  const int check_ts = (LOG2 == 2) && (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP) && (cu.part == SIZE_NxN || !(uni(k.tools) & (int)HEVCDL_TOOL_TSKIP_FAST));     // TransformSkipFast: only in NxN CUs (TEncSearch.cpp:1502-1505)
   if (memo) { single_cost = memo_cost; single_dist = memo_dist; cabac_copy(k, &s.root[full_depth], &s.go); }
   else if (check_full) {
     if (check_ts) {
@@ -3194,9 +3196,11 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 }
 
 // xRecurIntraChromaCodingQT TEncSearch.cpp:1941-2145
-template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
+// TS3: the copy for 8x8 luma TUs that tries transform skip on their 4x4 chroma blocks (TransformSkipFast 0 only: the usual copy stays without that code)
+template <int LOG2, bool TS3 = false> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
 {
   CHECK_EXEC(7);
+  if constexpr (LOG2 == 3 && !TS3) { if ((uni(k.tools) & (int)(HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_TSKIP_FAST)) == (int)HEVCDL_TOOL_TSKIP) return recur_chroma<3, true>(k, cu_, tu_); }
   uint32_t dist_sum = 0;
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
@@ -3204,8 +3208,10 @@ template <int LOG2> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
   if (uni(s.a[A_TRIDX][z]) == tu.trd) {
     if (!tu_has_chroma_first(tu)) return 0;
     const int full_depth = cu.depth + tu.trd;
-    int check_ts = (LOG2 == 2) && (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP);
-    if (check_ts) { int nb = 0; for (int i = 0; i < 4; i++) nb += s.a[A_TSKIP + 0][z + i]; check_ts = uni(nb) > 0; }
+    // a 4x4 chroma block (under a luma TU of 8x8, or of four 4x4); TransformSkipFast: only under 4x4 luma TUs of which one was transform-skipped (TEncSearch.cpp:1965-1990)
+    const int ts_fast = uni(k.tools) & (int)HEVCDL_TOOL_TSKIP_FAST;
+    int check_ts = (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP) && (LOG2 == 2 || (LOG2 == 3 && TS3 && !ts_fast));
+    if (check_ts && ts_fast) { int nb = 0; for (int i = 0; i < 4; i++) nb += s.a[A_TSKIP + 0][z + i]; check_ts = uni(nb) > 0; }
     const int zc = cu.zbase + tu_czrel(tu), np = tu_cnparts(tu);
     for (int comp = 1; comp < 3; comp++) {
       cabac_copy(k, &s.root[full_depth], &s.go);

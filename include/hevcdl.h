@@ -40,11 +40,11 @@ typedef enum {
 #define HEVCDL_TOOL_STRONG_INTRA    (1u << 5)
 #define HEVCDL_TOOL_FAST_UDI_MPM    (1u << 6)
 #define HEVCDL_TOOLS_REFERENCE      0x7fu
-/* What may be turned off (cfg keys RDOQ, RDOQTS, TransformSkip, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled; each pinned by a run of the reference encoder with the
- * switch on its command line: tests/golden/rd_k*.npz).  Without RDOQ the quantiser is the dead-zone rounding of TComTrQuant::xQuant with signBitHidingHDQ behind it
- * (RDOQTS: the same choice for transform-skipped blocks).  TransformSkipFast keeps the reference cfg's value 1: without it every 4x4 TU is tried both ways
- * (TEncSearch.cpp:1502-1505) -- rejected, not ignored. */
-#define HEVCDL_TOOLS_SWITCHABLE     (HEVCDL_TOOL_RDOQ | HEVCDL_TOOL_RDOQTS | HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_SIGN_HIDE | HEVCDL_TOOL_STRONG_INTRA | HEVCDL_TOOL_FAST_UDI_MPM)
+/* Every one of them may be turned off (cfg keys RDOQ, RDOQTS, TransformSkip, TransformSkipFast, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled; each pinned by a run of
+ * the reference encoder with the switch on its command line: tests/golden/rd_k*.npz).  Without RDOQ the quantiser is the dead-zone rounding of TComTrQuant::xQuant with
+ * signBitHidingHDQ behind it (RDOQTS: the same choice for transform-skipped blocks); without TransformSkipFast every 4x4 block is tried both ways, not only those of NxN CUs
+ * (TEncSearch.cpp:1502-1505, 1965-1990).  Bits outside HEVCDL_TOOLS_REFERENCE are rejected. */
+#define HEVCDL_TOOLS_SWITCHABLE     HEVCDL_TOOLS_REFERENCE
 #define HEVCDL_TOOLS_SUPPORTED(t)   ((((t) | HEVCDL_TOOLS_SWITCHABLE) == HEVCDL_TOOLS_REFERENCE) && ((t) & ~HEVCDL_TOOLS_REFERENCE) == 0)
 
 #define HEVCDL_CNN_INPUT_RGB601 0   /* BT.601 limited-range YUV -> RGB, nearest chroma (defined by this project) */
@@ -70,7 +70,7 @@ typedef struct hevcdl_config {
   int32_t  ctu_size;             /* 64   (MaxCUWidth/Height)          */
   int32_t  max_partition_depth;  /* 4    (MaxPartitionDepth)          */
   int32_t  tu_log2_min, tu_log2_max, tu_max_depth_intra;   /* 2, 5, 3 */
-  uint32_t tools;                /* HEVCDL_TOOL_* ; HEVCDL_TOOLS_REFERENCE less any of HEVCDL_TOOLS_SWITCHABLE */
+  uint32_t tools;                /* HEVCDL_TOOL_* : any subset of HEVCDL_TOOLS_REFERENCE (the reference cfg's value) */
   int32_t  bn_mode, boundary_policy, cnn_input;
   int32_t  device;               /* HIP device ordinal */
   int32_t  max_frames;           /* frames per call the workspace is sized for */

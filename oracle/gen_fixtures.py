@@ -131,6 +131,7 @@ def gen_rd_tools():
             ("k200_q27_all0", 200, 136, 2, 27, "rand", 53, T.TOOL_SIGN_HIDE | T.TOOL_TSKIP | T.TOOL_STRONG_INTRA | T.TOOL_FAST_UDI_MPM),
             # the quantiser without RDOQ (dead-zone rounding + signBitHidingHDQ): everywhere / in transform-skipped blocks only / without sign hiding as well
             ("k128_q22_rdoq0", 128, 128, 1, 22, "rand", 15, T.TOOL_RDOQ | T.TOOL_RDOQTS), ("k128_q27_rdoqts0", 128, 128, 1, 27, "rand", 16, T.TOOL_RDOQTS),
+            ("k128_q27_tsf0", 128, 128, 1, 27, "rand", 16, T.TOOL_TSKIP_FAST), ("k200_q32_tsf0", 200, 136, 1, 32, "rand", 56, T.TOOL_TSKIP_FAST),
             ("k200_q32_rdoq0", 200, 136, 1, 32, "rand", 54, T.TOOL_RDOQ), ("k200_q27_rdoq0_sbh0", 200, 136, 1, 27, "rand", 55, T.TOOL_RDOQ | T.TOOL_RDOQTS | T.TOOL_SIGN_HIDE)]
     cases = []
     for name, w, h, nf, qp, kind, seed, off in spec:

@@ -1214,7 +1214,7 @@ static void recur_luma(enc_t *e, const cu_t *cu, const tu_t *tu, int check_first
   int check_split = tu->log2 > min_tu_log2(cu);
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
-  const int check_ts = (g_tools & 0x04u) && (tu->log2 == 2) && (cu->part == SIZE_NxN);
+  const int check_ts = (g_tools & 0x04u) && (tu->log2 == 2) && (cu->part == SIZE_NxN || !(g_tools & 0x08u));      /* TransformSkipFast: only in NxN CUs (TEncSearch.cpp:1502-1505) */
   if (check_full) {
     if (check_ts) {
       e->root[full_depth] = e->go;
@@ -1389,8 +1389,9 @@ static void recur_chroma(enc_t *e, const cu_t *cu, const tu_t *tu, uint32_t *dis
   if (e->r->a[A_TRIDX][z] == tu->trd) {
     if (!tu_has_chroma_first(tu)) return;
     const int full_depth = cu->depth + tu->trd;
-    int check_ts = (g_tools & 0x04u) && (tu->log2 == 2);
-    if (check_ts) { int nb = 0; for (int k = 0; k < 4; k++) nb += e->r->a[A_TSKIP + 0][z + k]; check_ts = nb > 0; }
+    /* a 4x4 chroma block (under a luma TU of 8x8, or of four 4x4); TransformSkipFast: only under 4x4 luma TUs of which one was transform-skipped (TEncSearch.cpp:1965-1990) */
+    int check_ts = (g_tools & 0x04u) && ((g_tools & 0x08u) ? tu->log2 == 2 : tu_csize(tu) == 4);
+    if (check_ts && (g_tools & 0x08u)) { int nb = 0; for (int k = 0; k < 4; k++) nb += e->r->a[A_TSKIP + 0][z + k]; check_ts = nb > 0; }
     const int zc = cu->zbase + tu_czrel(tu), np = tu_cnparts(tu);
     for (int comp = 1; comp < 3; comp++) {
       e->root[full_depth] = e->go;

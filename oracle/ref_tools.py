@@ -206,6 +206,7 @@ def tile_bounds(tiles, width, height):
 
 
 TOOLS_REFERENCE = 0x7f
+TOOL_TSKIP_FAST = 0x08
 TOOL_RDOQ, TOOL_RDOQTS, TOOL_TSKIP, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x01, 0x02, 0x04, 0x10, 0x20, 0x40     # HEVCDL_TOOL_* of include/hevcdl.h
 
 
@@ -215,6 +216,7 @@ def tool_args(tools):
     if not tools & TOOL_RDOQ: a.append("--RDOQ=0")
     if not tools & TOOL_RDOQTS: a.append("--RDOQTS=0")
     if not tools & TOOL_TSKIP: a.append("--TransformSkip=0")
+    if not tools & TOOL_TSKIP_FAST: a.append("--TransformSkipFast=0")
     if not tools & TOOL_SIGN_HIDE: a.append("--SignHideFlag=0")
     if not tools & TOOL_STRONG_INTRA: a.append("--StrongIntraSmoothing=0")
     if not tools & TOOL_FAST_UDI_MPM: a.append("--FastUDIUseMPMEnabled=0")

@@ -67,7 +67,7 @@ def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
 
 def test_keys_that_change_the_path_are_rejected(app, tmp_path):
     write_cfgs(tmp_path)
-    for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--TransformSkipFast=0"], "TransformSkipFast"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
+    for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--ScalingList=1"], "ScalingList"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
                           (["--WaveFrontSynchro=1"], "WaveFrontSynchro"), (["--NumTileColumnsMinus1=1", "--TileColumnWidthArray="], "TileColumnWidthArray"),
                           (["--SEIDecodedPictureHash=2"], "SEIDecodedPictureHash")):
         r = run(app, ["-c", "main.cfg", "-c", "seq.cfg"] + extra + ["--PrintConfig"], tmp_path)
@@ -167,11 +167,11 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10",
-                                  "k128_q22_sbh0", "k128_q27_ts0", "k192_q32_sis0", "k200_q32_mpm0", "k200_q27_all0", "k128_q22_rdoq0", "k128_q27_rdoqts0", "k200_q32_rdoq0", "k200_q27_rdoq0_sbh0"])
+                                  "k128_q22_sbh0", "k128_q27_ts0", "k192_q32_sis0", "k200_q32_mpm0", "k200_q27_all0", "k128_q22_rdoq0", "k128_q27_rdoqts0", "k200_q32_rdoq0", "k200_q27_rdoq0_sbh0", "k128_q27_tsf0", "k200_q32_tsf0"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
     """b416_q32_r is C1 of BASELINE.json (416x240, one frame, QP32, untiled 8-bit, the reference's default configuration); c192 / b200 are
     further untiled 8-bit runs (two frames; a picture that is not a multiple of 64).  The rest:
-    k*: the tool switches RDOQ / RDOQTS / TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled = 0 on the command line, as the reference was run.  The rest:
+    k*: the tool switches RDOQ / RDOQTS / TransformSkip / TransformSkipFast / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled = 0 on the command line, as the reference was run.  The rest:
     the reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) and for 10-bit coding
     (InputBitDepth / InternalBitDepth 10, Profile main10; x576 is C5 of the survey in miniature: both) on the fixtures the reference
     encoder produced with the same switches: reconstruction file and bitstream (its picture-hash SEI aside) byte for byte."""

@@ -63,8 +63,8 @@ def test_invalid_and_unsupported_configurations_are_rejected(lib):
     h = ctypes.c_void_p()
     w = hevcdl_amd.load_weights()
     assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size - 1, ctypes.byref(h)) == 1    # wrong blob size
-    for tools in (0x77, 0xff, 0x17f):                                                               # TransformSkipFast off, unknown bits: another path -> rejected, not ignored
-        cfg.tools = tools                                                                           # (RDOQ, RDOQTS, TransformSkip, SignHideFlag, StrongIntraSmoothing, FastUDIUseMPMEnabled may be off: tests/golden/rd_k*)
+    for tools in (0xff, 0x17f, 0x80000000):                                                         # bits that are no tool of the reference's cfg: rejected, not ignored
+        cfg.tools = tools                                                                           # (each of the seven switches may be off: tests/golden/rd_k*)
         assert lib.hevcdl_create(ctypes.byref(cfg), w.ctypes.data, w.size, ctypes.byref(h)) == 2
     cfg = hevcdl_amd.default_config(64, 64, 32)
     cfg.bit_depth = 12                                                                              # 8 and 10 exist
