@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("HEVCDL_LIB") or os.path.join(PKG_DIR, "lib", "libhevc
 TRACE_LIB_PATH = os.path.join(PKG_DIR, "lib", "libhevcdl_hip_trace.so")      # -DHEVCDL_STAGE_TRACE build, loaded by tests/test_rd_gpu.py only
 WEIGHTS_PATH = os.path.join(PKG_DIR, "weights", "hevc_encoder_model.f32")
 WEIGHT_FLOATS = 637712
-SOURCES = ["cnn_kernel.hip", "fc_kernel.hip", "rd_kernel.hip", "rd_kernel_bd10.hip", "rd_kernel_wide.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
+SOURCES = ["cnn_kernel.hip", "fc_kernel.hip", "rd_kernel.hip", "rd_kernel_bd10.hip", "rd_kernel_wide.hip", "rd_kernel_tools.hip", "deblock_kernel.hip", "sao_kernel.hip", "hevcdl_api.hip", "hevcdl_bitstream.cpp"]
 
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "UNSUPPORTED", 3: "NO_DEVICE", 4: "HIP", 5: "OOM"}
 

@@ -20,6 +20,9 @@ extern "C" __global__ void hevcdl_rd_frame_kernel_wide(hevcdl_rd_params p);     
 extern "C" size_t hevcdl_rd_smem_bytes_wide(void);
 extern "C" size_t hevcdl_rd_scratch_bytes_wide(void);
 extern "C" int hevcdl_rd_waves_per_group_wide(void);
+extern "C" __global__ void hevcdl_rd_frame_kernel_tools(hevcdl_rd_params p);      // rd_kernel_tools.hip: the 8-bit kernel with the cfg's tool switches read at run time
+extern "C" size_t hevcdl_rd_smem_bytes_tools(void);
+extern "C" size_t hevcdl_rd_scratch_bytes_tools(void);
 
 // 10-bit samples -> the 8-bit planes the CNN stage reads (the reference's label producer works on 8-bit frames: gen_frames.py)
 __global__ void hevcdl_narrow_samples_kernel(const uint16_t *src, uint8_t *dst, size_t n, int shift)
@@ -286,7 +289,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (cfg->bit_depth > 8) CK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(cfg->width, cfg->height) * (size_t)cfg->max_frames));    // the CNN stage's 8-bit copy
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
-  ctx->scratch_per_wave = cfg->bit_depth == 8 ? std::max(hevcdl_rd_scratch_bytes(), hevcdl_rd_scratch_bytes_wide()) : hevcdl_rd_scratch_bytes_bd10();
+  ctx->scratch_per_wave = cfg->bit_depth == 8 ? std::max(std::max(hevcdl_rd_scratch_bytes(), hevcdl_rd_scratch_bytes_wide()), hevcdl_rd_scratch_bytes_tools()) : hevcdl_rd_scratch_bytes_bd10();
   ctx->rd_groups = (int)std::min<long long>(ctx->n_cus, (long long)cfg->max_frames * cfg->tile_columns * cfg->tile_rows);
   // (launches of few units run on every CU: the workgroups without a unit take second luma passes from the others, launch_rd -- they need a workspace too)
   ctx->remote_groups = (cfg->bit_depth == 8 && !(cfg->exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) && ctx->n_cus >= 8 && ctx->n_cus <= 1024) ? ctx->n_cus : 0;
@@ -301,6 +304,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_bd10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_bd10()));
   CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_wide()));
+  CK(hipFuncSetAttribute((const void *)hevcdl_rd_frame_kernel_tools, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hevcdl_rd_smem_bytes_tools()));
 #undef CK
   *out = ctx;
   return HEVCDL_OK;
@@ -471,14 +475,16 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // 16.08 / 15.66 s, 2560 frames 21.47 / 18.14 s -- but the ten-wave build moves three times the bytes (600 frames: 5.8 MB per CTU through the L2s against 1.85 MB:
   // register spills at 168 registers, the CU walk's snapshots in HBM).  It is chosen where it clearly pays: from three units per workgroup on (round 5; four before).  Launches in the
   // few-units form keep the eight-wave build.
+  // (a context with other tool switches than the reference cfg's runs the build that reads them: rd_kernel_tools.hip, eight waves)
+  const bool rt_tools = ctx->cfg.bit_depth == 8 && ctx->cfg.tools != HEVCDL_TOOLS_REFERENCE;
   bool wide = false;
-  if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW))
+  if (ctx->cfg.bit_depth == 8 && !rt_tools && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW))
     wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 3 * groups);      // round 5, eight- / ten-wave build on 256 CUs: 450 frames 4.80 / 4.87 s, 600 frames 5.76 / 5.70 s, 768 frames 7.00 / 6.87 s, 1024 frames 9.44 / 8.78 s
   if (wide) p.remote = 0;      // (the ten-wave build together with the hand-over of units: launches of more than three and fewer than four units per workgroup, or exec_flags; tests/test_rd_gpu.py::test_units_handed_over_between_workgroups_give_the_same_result runs the pair)
   const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
   const int threads = 64 * waves;
-  const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (const void *)hevcdl_rd_frame_kernel) : (const void *)hevcdl_rd_frame_kernel_bd10;
-  const size_t smem = ctx->cfg.bit_depth == 8 ? (wide ? hevcdl_rd_smem_bytes_wide() : hevcdl_rd_smem_bytes()) : hevcdl_rd_smem_bytes_bd10();
+  const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (rt_tools ? (const void *)hevcdl_rd_frame_kernel_tools : (const void *)hevcdl_rd_frame_kernel)) : (const void *)hevcdl_rd_frame_kernel_bd10;
+  const size_t smem = ctx->cfg.bit_depth == 8 ? (wide ? hevcdl_rd_smem_bytes_wide() : (rt_tools ? hevcdl_rd_smem_bytes_tools() : hevcdl_rd_smem_bytes())) : hevcdl_rd_smem_bytes_bd10();
   { // the workspace: one block per wave of every workgroup of this launch
     const size_t need = ctx->scratch_per_wave * (size_t)(p.remote ? ctx->remote_groups : groups) * (size_t)waves;
     if (need > ctx->scratch_bytes) {
@@ -497,11 +503,12 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (!p.migrate && !p.remote) {
     if (ctx->cfg.bit_depth != 8) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), smem, s, p);
     else if (wide) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_wide, dim3(groups), dim3(threads), smem, s, p);
+    else if (rt_tools) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_tools, dim3(groups), dim3(threads), smem, s, p);
     else hipLaunchKernelGGL(hevcdl_rd_frame_kernel, dim3(groups), dim3(threads), smem, s, p);
   }
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
-  snprintf(ctx->last_rd, sizeof ctx->last_rd, "%s form=%s workgroups=%d waves=%d units=%d", ctx->cfg.bit_depth != 8 ? "hevcdl_rd_frame_kernel_bd10" : (wide ? "hevcdl_rd_frame_kernel_wide" : "hevcdl_rd_frame_kernel"),
+  snprintf(ctx->last_rd, sizeof ctx->last_rd, "%s form=%s workgroups=%d waves=%d units=%d", ctx->cfg.bit_depth != 8 ? "hevcdl_rd_frame_kernel_bd10" : (wide ? "hevcdl_rd_frame_kernel_wide" : (rt_tools ? "hevcdl_rd_frame_kernel_tools" : "hevcdl_rd_frame_kernel")),
            p.migrate ? "unit-handover" : (p.remote == 1 ? "few-units(passes)" : (p.remote == 2 ? "few-units(passes+chroma)" : (p.remote == 3 ? "few-units(passes while takers idle)" : "independent"))),
            p.remote ? ctx->remote_groups : groups, waves, n_units);
 #if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)

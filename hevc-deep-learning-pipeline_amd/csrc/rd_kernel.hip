@@ -41,12 +41,20 @@
 typedef uint8_t pel_t;
 #ifdef HEVCDL_RD_WIDE
 #define RD_SYM(name) name##_wide      // rd_kernel_wide.hip: more wavefronts per workgroup (launches with a unit for most CUs)
+#elif defined(HEVCDL_RD_TOOLS)
+#define RD_SYM(name) name##_tools     // rd_kernel_tools.hip: the tool switches of the cfg read at run time (contexts whose hevcdl_config.tools is not the reference's)
 #else
 #define RD_SYM(name) name
 #endif
 #else
 typedef uint16_t pel_t;
 #define RD_SYM(name) name##_bd10
+#endif
+// The tool switches (hevcdl_config.tools).  The two 8-bit builds that carry the timed configurations are compiled for the reference cfg's tools: every test on a switch
+// folds away (reading them at run time cost 1 % of the 600-frame job: three dependent LDS reads per TU coding, the plain quantiser's code inside every copy of
+// code_tu_block).  rd_kernel_tools.hip (8-bit) and the 10-bit build read them from the context.
+#ifndef HEVCDL_TOOLS_RT
+#define HEVCDL_TOOLS_RT (HEVCDL_BD != 8)
 #endif
 
 namespace {
@@ -314,6 +322,7 @@ DEV void wsync()
 #define PROF_GLUE_T0() do { } while (0)
 #endif
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV int tools_of(KR k) { return HEVCDL_TOOLS_RT ? __builtin_amdgcn_readfirstlane(k.tools) : (int)HEVCDL_TOOLS_REFERENCE; }
 // -DHEVCDL_TIMELINE (build with -DHEVCDL_KERNEL_DEBUG for the buffer): workgroup 0 logs (clock, wave, event, argument) while it codes CTUs [HEVCDL_TL_CTU0, +4) -- tools/timeline.py
 #ifdef HEVCDL_TIMELINE
 #ifndef HEVCDL_TL_CTU0
@@ -641,7 +650,7 @@ DEV void filter_refs(KR k, int n_)
   const int n2 = 2 * n, last = 4 * n;
   int strong = 0;
   const int bl = src[0], tl = src[n2], tr = src[last];
-  if (n >= 32 && (uni(k.tools) & (int)HEVCDL_TOOL_STRONG_INTRA)) strong = (abs(bl + tl - 2 * src[n]) < (1 << (BD - 5))) && (abs(tl + tr - 2 * src[n2 + n]) < (1 << (BD - 5)));     // sps_strong_intra_smoothing_enable_flag
+  if (n >= 32 && (tools_of(k) & (int)HEVCDL_TOOL_STRONG_INTRA)) strong = (abs(bl + tl - 2 * src[n]) < (1 << (BD - 5))) && (abs(tl + tr - 2 * src[n2 + n]) < (1 << (BD - 5)));     // sps_strong_intra_smoothing_enable_flag
   for (int i = lane_id(); i <= last; i += 64) {
     int v;
     if (i == 0 || i == last) v = src[i];
@@ -1030,7 +1039,7 @@ template <int NFIX = 0> DEV uint32_t rdoq_wave(KR k, const LCabac *cab, int c_, 
   const int lane = lane_id();
   const int ch = c ? 1 : 0, log2n = ilog2(n);
   const int qp = uni(c ? k.qp_c : k.qp) + QP_BD_OFFSET, per = qp / 6, rem = qp % 6;      // + qpBdOffset (TComTrQuant.cpp:71-100)
-  const int sign_hide = uni(k.tools) & (int)HEVCDL_TOOL_SIGN_HIDE;                       // (read here, with the other words of the context: one wait for all of them)
+  const int sign_hide = tools_of(k) & (int)HEVCDL_TOOL_SIGN_HIDE;                       // (read here, with the other words of the context: one wait for all of them)
   const int tshift = 15 - BD - log2n, qbits = 14 + per + tshift;
   const double lambda = c ? k.lambda_c : k.lambda;
   const double err_scale = k.err_scale[ch][log2n - 2];
@@ -1552,7 +1561,7 @@ DEV uint32_t plain_quant_wave(KR k, int c_, int n_, int dir_mode_)
   }
   abs_sum = (uint32_t)wave_sum_i((int)abs_sum);
   wsync();
-  if ((uni(k.tools) & (int)HEVCDL_TOOL_SIGN_HIDE) && abs_sum >= 2) {
+  if ((tools_of(k) & (int)HEVCDL_TOOL_SIGN_HIDE) && abs_sum >= 2) {
     CParam cp; get_cparam(cp, c, n, dir_mode);
     const ScanFn scan = scan_of(s, cp.scan_type, log2n);
     bool seen = false;                                     // a group with a level has been met (the reference's lastCG: 1 for the first such group from the top)
@@ -1648,7 +1657,7 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
   constexpr int BB = 97;
   const int BA = ch ? 21 : 19;
   static_assert(CTX_SIG_CG == 19 && CTX_LAST_X + 15 == 82 && CTX_LAST_Y == 97 && NUM_CTX <= BB + 64 && CTX_LAST_X + 15 + 2 < 21 + 64 && CTX_LAST_X + 14 < 19 + 64, "context windows of code_coeff_wave");
-  const int tools = uni(k.tools);
+  const int tools = tools_of(k);
   int cxa = c->ctx[BA + lane], cxb = c->ctx[BB + (lane < 63 ? lane : 62)];
   int cxh = c->ctx[lane < 19 ? lane : 18];                      // H = contexts [0, 19): the header flags (its own register: the windows do not overlap)
   const int eb0 = tb().t_ebits[lane], eb1 = tb().t_ebits[64 + lane];
@@ -2104,7 +2113,7 @@ template <int NFIX> DEVN TuRes code_tu_block_n(KR k, const Cu cu_, const Tu tu_,
   const int cs = cstride(comp), bo = boff(k, comp, x, y), ps = pstride(k, comp);
   const int mode = uni(mode_of(k, cu, comp, zrel));
   const int tskip = uni(s.a[A_TSKIP + comp][zabs]);
-  const int use_rdoq = uni(k.tools) & (int)(tskip ? HEVCDL_TOOL_RDOQTS : HEVCDL_TOOL_RDOQ);        // useRDOQ = transform skip ? RDOQTS : RDOQ (TComTrQuant.cpp:1152)
+  const int use_rdoq = tools_of(k) & (int)(tskip ? HEVCDL_TOOL_RDOQTS : HEVCDL_TOOL_RDOQ);        // useRDOQ = transform skip ? RDOQTS : RDOQ (TComTrQuant.cpp:1152)
   if (mode012 != 2) {
     if (HEVCDL_REFS_INLINE && NFIX) build_refs_i(k, comp, x, y, n, 0); else build_refs(k, comp, x, y, n, 0);
     if (ub(use_filtered_refs(comp, mode, n))) filter_refs(k, n);
@@ -2297,7 +2306,7 @@ template <int LOG2, bool SPEC = false> DEVN DistCost recur_luma(KR k, const Cu c
   if (check_first && check_full) check_split = 0;
   double single_cost = MAX_DOUBLE; uint32_t single_dist = 0, single_cbf = 0; int best_ts = 0;
   unsigned long long single_cfrac = 0;
-  const int check_ts = (LOG2 == 2) && (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP) && (cu.part == SIZE_NxN || !(uni(k.tools) & (int)HEVCDL_TOOL_TSKIP_FAST));     // TransformSkipFast: only in NxN CUs (TEncSearch.cpp:1502-1505)
+  const int check_ts = (LOG2 == 2) && (tools_of(k) & (int)HEVCDL_TOOL_TSKIP) && (cu.part == SIZE_NxN || !(tools_of(k) & (int)HEVCDL_TOOL_TSKIP_FAST));     // TransformSkipFast: only in NxN CUs (TEncSearch.cpp:1502-1505)
   if (memo) { single_cost = memo_cost; single_dist = memo_dist; cabac_copy(k, &s.root[full_depth], &s.go); }
   else if (check_full) {
     if (check_ts) {
@@ -2851,7 +2860,7 @@ template <bool TRACE> DEV int rmd_candidates(KR k, int x, int y, int pu_log2, un
 {
   LSmem &s = lds();
   int preds[3], nm; get_mpm(k, x, y, preds, &nm);
-  const int use_mpm = uni(k.tools) & (int)HEVCDL_TOOL_FAST_UDI_MPM;       // FastUDIUseMPMEnabled: the list is the c_num_rd_cand best + the most probable modes; without it one more and no additions (TEncSearch.cpp:2269, 2322)
+  const int use_mpm = tools_of(k) & (int)HEVCDL_TOOL_FAST_UDI_MPM;       // FastUDIUseMPMEnabled: the list is the c_num_rd_cand best + the most probable modes; without it one more and no additions (TEncSearch.cpp:2269, 2322)
   int nfull = use_mpm ? c_num_rd_cand[pu_log2 - 2] : c_num_rd_cand_no_mpm[pu_log2 - 2];
   if (!use_mpm) nm = 0;
   if (lane_id() < 35) {
@@ -3200,7 +3209,7 @@ DEVN uint32_t est_intra_luma(KR k, const Cu cu_)
 template <int LOG2, bool TS3 = false> DEVN uint32_t recur_chroma(KR k, const Cu cu_, const Tu tu_)
 {
   CHECK_EXEC(7);
-  if constexpr (LOG2 == 3 && !TS3) { if ((uni(k.tools) & (int)(HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_TSKIP_FAST)) == (int)HEVCDL_TOOL_TSKIP) return recur_chroma<3, true>(k, cu_, tu_); }
+  if constexpr (LOG2 == 3 && !TS3) { if ((tools_of(k) & (int)(HEVCDL_TOOL_TSKIP | HEVCDL_TOOL_TSKIP_FAST)) == (int)HEVCDL_TOOL_TSKIP) return recur_chroma<3, true>(k, cu_, tu_); }
   uint32_t dist_sum = 0;
   const Cu cu = ucu(cu_); const Tu tu = utu(tu_);
   LSmem &s = lds();
@@ -3209,8 +3218,8 @@ template <int LOG2, bool TS3 = false> DEVN uint32_t recur_chroma(KR k, const Cu 
     if (!tu_has_chroma_first(tu)) return 0;
     const int full_depth = cu.depth + tu.trd;
     // a 4x4 chroma block (under a luma TU of 8x8, or of four 4x4); TransformSkipFast: only under 4x4 luma TUs of which one was transform-skipped (TEncSearch.cpp:1965-1990)
-    const int ts_fast = uni(k.tools) & (int)HEVCDL_TOOL_TSKIP_FAST;
-    int check_ts = (uni(k.tools) & (int)HEVCDL_TOOL_TSKIP) && (LOG2 == 2 || (LOG2 == 3 && TS3 && !ts_fast));
+    const int ts_fast = tools_of(k) & (int)HEVCDL_TOOL_TSKIP_FAST;
+    int check_ts = (tools_of(k) & (int)HEVCDL_TOOL_TSKIP) && (LOG2 == 2 || (LOG2 == 3 && TS3 && !ts_fast));
     if (check_ts && ts_fast) { int nb = 0; for (int i = 0; i < 4; i++) nb += s.a[A_TSKIP + 0][z + i]; check_ts = uni(nb) > 0; }
     const int zc = cu.zbase + tu_czrel(tu), np = tu_cnparts(tu);
     for (int comp = 1; comp < 3; comp++) {
@@ -4582,7 +4591,7 @@ extern "C" size_t RD_SYM(hevcdl_rd_smem_bytes)(void) { return (size_t)NW * sizeo
 extern "C" size_t RD_SYM(hevcdl_rd_scratch_bytes)(void) { return SCR_WAVE; }        // per wave
 extern "C" int RD_SYM(hevcdl_rd_waves_per_group)(void) { return NW; }
 
-#if defined(HEVCDL_MICRO) && HEVCDL_BD == 8 && !defined(HEVCDL_RD_WIDE)
+#if defined(HEVCDL_MICRO) && HEVCDL_BD == 8 && !defined(HEVCDL_RD_WIDE) && !defined(HEVCDL_RD_TOOLS)
 // -DHEVCDL_MICRO (tools/micro_rd.py; never in the product library): the leaf routines of a TU coding timed on their own, on synthetic residual blocks.
 // Every wave of every workgroup runs `reps` codings (what: 0 RDOQ, 1 the bit counter, 2 forward transform + RDOQ + bit counter + dequant + inverse);
 // out[wave] = { cycles inside the timed routine, checksum }.

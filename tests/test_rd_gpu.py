@@ -36,7 +36,10 @@ def test_golden_records_bit_exact(path):
     tools = int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE   # rd_k*: reference runs with TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled off
     enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd, tools=tools)
     recs, recon, stats = enc.compress_frames(yuv, labels)
+    launch = enc.last_rd_launch()
     enc.close()
+    # the builds that carry the timed configurations are compiled for the reference cfg's tools; other tool masks run the build that reads them (csrc/rd_kernel_tools.hip)
+    assert launch.split(" ")[0] == ("hevcdl_rd_frame_kernel_bd10" if bd != 8 else ("hevcdl_rd_frame_kernel_tools" if tools != hevcdl_amd.TOOLS_REFERENCE else "hevcdl_rd_frame_kernel")), launch
     assert recon.dtype == (np.uint8 if bd == 8 else np.uint16)
     assert_records_equal(recs, ref, os.path.basename(path))
     for fr in range(yuv.shape[0]):
