@@ -40,7 +40,7 @@ def read_frames(path, width, height, first, count, bit_depth=8):
 
 
 def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None, recon_path=None, frame_skip=0, batch=256, tiles=(1, 1),
-                    lf_across_tiles=True, bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, labels_fn=None, device=None, log=print):
+                    lf_across_tiles=True, bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, labels_fn=None, device=None, log=print, tools=0x7f):
     """Encode frames [frame_skip, frame_skip + n_frames) of a planar YUV file.  Works stand-alone and under torch.distributed
     (initialised by the caller): rank r takes a contiguous share of the frames.  Returns, on rank 0, the summary (metrics.Summary)
     and the list of per-picture rows [poc, bits, sseY, sseU, sseV]; other ranks return (None, None).
@@ -58,7 +58,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
     part_rec = (recon_path + ".part%d" % rank) if recon_path else None
     fb, fr = open(part_bits, "wb") if part_bits else None, open(part_rec, "wb") if part_rec else None
     if len(mine):
-        enc = Encoder(width, height, qp, max_frames=min(batch, len(mine)), device=device, tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles)
+        enc = Encoder(width, height, qp, max_frames=min(batch, len(mine)), device=device, tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools)      # tools: HEVCDL_TOOL_* mask (the cfg's tool switches)
         ysz = width * height
         for b0 in range(mine.start, mine.stop, batch):
             nb = min(batch, mine.stop - b0)
@@ -68,7 +68,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
             recs, final, sao, _ = enc.encode_pictures(yuv, labels)          # CNN -> decisions -> deblocking -> SAO, pictures stay in HBM
             et = (time.time() - t0) / nb
             def one_picture(i):          # host work of a picture (arithmetic coder, hash, SSE): independent -> thread pool (ctypes drops the GIL)
-                au = write_access_unit(width, height, qp, b0 + i, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles)
+                au = write_access_unit(width, height, qp, b0 + i, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools)
                 sei = picture_hash_sei(width, height, final[i], bit_depth) if hash_sei else b""
                 d = (yuv[i].astype(np.int64) - final[i].astype(np.int64)) ** 2
                 return au, sei, [int(d[:ysz].sum()), int(d[ysz:ysz + ysz // 4].sum()), int(d[ysz + ysz // 4:].sum())]
@@ -113,7 +113,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
 
 
 def encode_sequence_tile_sharded(input_path, width, height, qp, n_frames, tiles, bitstream_path=None, recon_path=None, frame_skip=0, batch=None, lf_across_tiles=True,
-                                 bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, device=None, log=print):
+                                 bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, device=None, log=print, tools=0x7f):
     """The within-picture partition: every rank decides its share of the TILES of every picture of a batch
     (`hevcdl_compress_tiles_dev`), one all-to-all moves the tile payloads to the picture's owner (`sharding.exchange_tiles_to_owners`:
     picture i of the batch -> rank i mod world), the owner runs the in-loop filters on the assembled picture and writes its access unit.
@@ -133,7 +133,7 @@ def encode_sequence_tile_sharded(input_path, width, height, qp, n_frames, tiles,
     tl = tile_layout(tiles, width, height)                          # (columns, rows) or explicit CTU sizes
     n_tiles = tl[0] * tl[1]
     t_begin, t_count = sharding.shard_tiles(n_tiles, world, rank)
-    enc = Encoder(width, height, qp, max_frames=batch, device=device, tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles)
+    enc = Encoder(width, height, qp, max_frames=batch, device=device, tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools)
     ctus, fsamp, ysz = enc.ctus, width * height * 3 // 2, width * height
     bps = 1 if bit_depth == 8 else 2
     part_bits = (bitstream_path + ".part%d" % rank) if bitstream_path else None
@@ -172,7 +172,7 @@ def encode_sequence_tile_sharded(input_path, width, height, qp, n_frames, tiles,
             poc = b0 + i
             if i >= nb:
                 continue
-            au = write_access_unit(width, height, qp, poc, recs[j], level_idc=level_idc, sao=sao[j], tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles)
+            au = write_access_unit(width, height, qp, poc, recs[j], level_idc=level_idc, sao=sao[j], tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools)
             blob = au + (picture_hash_sei(width, height, final[j], bit_depth) if hash_sei else b"")
             if fb:
                 fb.write(blob)

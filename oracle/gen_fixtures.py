@@ -132,7 +132,9 @@ def gen_rd_tools():
             # the quantiser without RDOQ (dead-zone rounding + signBitHidingHDQ): everywhere / in transform-skipped blocks only / without sign hiding as well
             ("k128_q22_rdoq0", 128, 128, 1, 22, "rand", 15, T.TOOL_RDOQ | T.TOOL_RDOQTS), ("k128_q27_rdoqts0", 128, 128, 1, 27, "rand", 16, T.TOOL_RDOQTS),
             ("k128_q27_tsf0", 128, 128, 1, 27, "rand", 16, T.TOOL_TSKIP_FAST), ("k200_q32_tsf0", 200, 136, 1, 32, "rand", 56, T.TOOL_TSKIP_FAST),
-            ("k200_q32_rdoq0", 200, 136, 1, 32, "rand", 54, T.TOOL_RDOQ), ("k200_q27_rdoq0_sbh0", 200, 136, 1, 27, "rand", 55, T.TOOL_RDOQ | T.TOOL_RDOQTS | T.TOOL_SIGN_HIDE)]
+            ("k200_q32_rdoq0", 200, 136, 1, 32, "rand", 54, T.TOOL_RDOQ),
+            # 10-bit samples (InternalBitDepth 10): the 10-bit build of the kernel reads the switches at run time
+            ("k200_q30_b10_mix0", 200, 136, 1, 30, "rand", 57, T.TOOL_RDOQ | T.TOOL_SIGN_HIDE | T.TOOL_TSKIP_FAST | T.TOOL_FAST_UDI_MPM), ("k200_q27_rdoq0_sbh0", 200, 136, 1, 27, "rand", 55, T.TOOL_RDOQ | T.TOOL_RDOQTS | T.TOOL_SIGN_HIDE)]
     cases = []
     for name, w, h, nf, qp, kind, seed, off in spec:
         tools = T.TOOLS_REFERENCE & ~off
@@ -140,16 +142,20 @@ def gen_rd_tools():
         if name.startswith("k128_q22") or name.startswith("k128_q27"):
             rng = np.random.default_rng(seed)
             yuv = rng.integers(0, 256, yuv.shape).astype(np.uint8) if name.startswith("k128_q22") else np.clip(yuv.astype(np.int32) + rng.integers(-24, 25, yuv.shape), 0, 255).astype(np.uint8)
+        bd = 10 if "_b10" in name else 8
+        if bd == 10:
+            rng = np.random.default_rng(seed)
+            yuv = yuv.astype(np.uint16) * 4 + rng.integers(0, 4, yuv.shape).astype(np.uint16)
         lab = rt.make_labels(w, h, nf, kind, seed + 100)
         targs = rt.tool_args(tools)
-        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs)
-        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"])
+        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs, bit_depth=bd)
+        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)
         assert dump2.tobytes() == dump.tobytes()
         dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
         nctu = lab.shape[1]
         assert len(dump) == nf * nctu
         summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
-        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=8, lf_across_tiles=1, tiles=np.array((1, 1)), tools=tools,
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd, lf_across_tiles=1, tiles=np.array((1, 1)), tools=tools,
                             records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
                             rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
                             bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),
