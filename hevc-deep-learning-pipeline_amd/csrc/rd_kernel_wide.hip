@@ -7,7 +7,7 @@
 // This build drops the look-ahead region (it only serves workgroups with ONE master: launches of few units, which keep the 8-wave kernel) and is held to 168
 // registers by its launch bound.  The whole kernel gains less than its leaves, and only with two or more masters per workgroup (600 frames of 2160p on 256 CUs
 // 6.24 -> 6.11 s, 1024 frames 10.33 -> 9.50 s, 2560 frames 21.47 -> 18.14 s; 300 frames 4.16 -> 4.59 s) and it moves three times the bytes through the L2s (spills,
-// snapshots in HBM): launch_rd (hevcdl_api.hip) picks it from four units per workgroup on.
+// snapshots in HBM): launch_rd (hevcdl_api.hip) picks it from three units per workgroup on (four until round 5).
 #define HEVCDL_NW 10
 #undef HEVCDL_NPEND
 #define HEVCDL_NPEND 2           // (an experiment with more pending passes in the eight-wave build leaves this one alone: its LDS is full)

@@ -94,8 +94,8 @@ typedef struct hevcdl_config {
    * others: cooperative as well, same fall-back, switched off by this bit (the context then also allocates workspace for its own frames only). */
   int32_t  exec_flags;
 #define HEVCDL_EXEC_NO_UNIT_HANDOVER 1
-  /* The 8-bit decision kernel exists in two builds: 8 wavefronts per workgroup with the look-ahead of the few-units form, and 10 (csrc/rd_kernel_wide.hip) for every
-   * launches of four or more units per workgroup; the library picks by the shape of the launch.  HEVCDL_EXEC_RD_WIDE forces the second for every launch of the context (the few-units form is then
+  /* The 8-bit decision kernel exists in two builds: 8 wavefronts per workgroup with the look-ahead of the few-units form, and 10 (csrc/rd_kernel_wide.hip) for
+   * launches of three or more units per workgroup; the library picks by the shape of the launch.  HEVCDL_EXEC_RD_WIDE forces the second for every launch of the context (the few-units form is then
    * never used), HEVCDL_EXEC_RD_NARROW the first.  Results do not depend on the choice. */
 #define HEVCDL_EXEC_RD_WIDE 2
 #define HEVCDL_EXEC_RD_NARROW 4
