@@ -1661,7 +1661,10 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
   int cxa = c->ctx[BA + lane], cxb = c->ctx[BB + (lane < 63 ? lane : 62)];
   int cxh = c->ctx[lane < 19 ? lane : 18];                      // H = contexts [0, 19): the header flags (its own register: the windows do not overlap)
   const int eb0 = tb().t_ebits[lane], eb1 = tb().t_ebits[64 + lane];
-  const int nx = (int)((unsigned)tb().t_next[0][lane] | ((unsigned)tb().t_next[0][64 + lane] << 8) | ((unsigned)tb().t_next[1][lane] << 16) | ((unsigned)tb().t_next[1][64 + lane] << 24));
+  // next states by x = state ^ bin (the index the rate tables are read with) and bin: lane l holds, byte by byte, (bin 0, x = l), (bin 0, x = 64 + l), (bin 1, x = l), (bin 1, x = 64 + l);
+  // the transition is the MPS one when bin == state & 1, i.e. when x is even, and the state is x ^ bin
+  const int mps_t = (lane & 1) ^ 1;
+  const int nx = (int)((unsigned)tb().t_next[mps_t][lane] | ((unsigned)tb().t_next[mps_t][64 + lane] << 8) | ((unsigned)tb().t_next[mps_t][lane ^ 1] << 16) | ((unsigned)tb().t_next[mps_t][(64 + lane) ^ 1] << 24));
   unsigned long long frac;
   { const unsigned long long f = c->frac; frac = ((unsigned long long)(unsigned)uni((int)(f >> 32)) << 32) | (unsigned)uni((int)f); }
   if (pre & PRE_RESET) frac &= 32767ull;
@@ -1672,8 +1675,8 @@ template <int NFIX> DEV uint32_t code_coeff_wave_i(KR k, LCabac *c, int comp_, i
     const int x = st ^ b, xl = x & 63;
     const int e0 = __builtin_amdgcn_readlane(eb0, xl), e1 = __builtin_amdgcn_readlane(eb1, xl);
     frac += (unsigned)(e0 + ((x >> 6) & 1) * (e1 - e0));
-    const int w = __builtin_amdgcn_readlane(nx, st & 63);
-    const int nxt = (w >> (((st >> 6) << 3) + (((x & 1) ^ 1) << 4))) & 0xff;        // bytes: [0] / [1] LPS transition of states 0..63 / 64..127, [2] / [3] the MPS one (taken when bin == MPS = st & 1)
+    const int w = __builtin_amdgcn_readlane(nx, xl);
+    const int nxt = (w >> (((x >> 6) + 2 * b) << 3)) & 0xff;
     // (this clang has no writelane builtin.  Both scalar operands are results of scalar instructions here -- the lane-select hazard of v_writelane is about SGPRs written
     //  by VALU instructions --; the s_nop covers it all the same: inline assembly is outside the compiler's hazard pass)
     // (one SGPR per VALU instruction on gfx9: the lane select goes through M0 -- which nothing else in this file uses (checked in the assembly); it is named as
