@@ -98,7 +98,7 @@ def test_whole_1080p_frame_matches_the_reference_golden():
     yuv = ref_tools.synth_yuv(w, h, 1, int(f["seed"]))
     enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1)
     recs, recon, stats = enc.compress_frames(yuv, f["labels"])
-    gpu_labels = enc.predict_depth(yuv)
+    gpu_labels, gpu_logits = enc.predict_depth(yuv, want_logits=True)
     enc.close()
     assert_records_equal(recs, f["records"], "full_f1080_q32")
     assert np.array_equal(full_frame_crc(recon[0], w, h, recs.shape[1]), f["recon_crc32"])
@@ -106,7 +106,19 @@ def test_whole_1080p_frame_matches_the_reference_golden():
     # matrix cores -- may only differ where two logits of the fp32 graph are closer than its own error (tests/test_cnn_gpu.py bounds that at 1e-3)
     diff_cells = int((gpu_labels != f["labels"]).sum()); diff_ctus = int((gpu_labels != f["labels"]).any(axis=2).sum())
     print("CNN labels, device vs fp32 numpy oracle on full_f1080_q32: %d of %d CTUs differ (%d of %d cells)" % (diff_ctus, gpu_labels.shape[1], diff_cells, gpu_labels.size))
-    assert diff_ctus <= gpu_labels.shape[1] // 200, "%d CTUs carry other labels than the fp32 oracle's" % diff_ctus
+    # no allowance by count: every CTU that carries another label must be a tie of the fp32 graph itself -- the oracle's own logits of that CTU (computed here) agree with the
+    # device's within the tolerance of tests/test_cnn_gpu.py, and two classes of one of its digits lie closer together than twice that
+    import cnn_oracle
+    wts = cnn_oracle.load_weights(hevcdl_amd.WEIGHTS_PATH)
+    ctus_rgb = cnn_oracle.yuv_to_rgb_ctus(yuv[0], w, h)
+    for a in np.flatnonzero((gpu_labels[0] != f["labels"][0]).any(axis=1)):
+        lg = cnn_oracle.ctu_logits(wts, ctus_rgb[a:a + 1])[0]
+        assert np.abs(lg - gpu_logits[0, a]).max() < 1e-3, a
+        top2 = np.sort(lg.reshape(4, 4, 4), axis=-1)
+        assert (top2[..., 3] - top2[..., 2]).min() < 2e-3, "CTU %d carries another label than the fp32 oracle's without a tie in its logits" % a
+    assert diff_ctus <= 2, "%d CTUs are ties of the fp32 graph: the fixture no longer tests what it was made for" % diff_ctus
+    # (round 5: the one CTU that differed until then was no tie -- the fixture's labels predated the oracle's restatement of use_model.py:101-119 for a quadrant that
+    #  answers "0000"; regenerated, the device's labels are the fixture's on all 510 CTUs)
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
