@@ -59,7 +59,7 @@ class Config(ctypes.Structure):
                 ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("exec_flags", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("lf_across_tiles", ctypes.c_int32)]
+                ("lf_across_tiles", ctypes.c_int32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32)]
 
 
 def tile_layout(tiles, width, height):
@@ -89,7 +89,7 @@ class StreamConfig(ctypes.Structure):
                 ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("lf_across_tiles", ctypes.c_int32), ("tools", ctypes.c_uint32)]
+                ("lf_across_tiles", ctypes.c_int32), ("tools", ctypes.c_uint32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -257,7 +257,7 @@ TOOLS_REFERENCE = 0x7f
 TOOL_RDOQ, TOOL_RDOQTS, TOOL_TSKIP, TOOL_TSKIP_FAST, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40      # HEVCDL_TOOL_* (include/hevcdl.h): each may be turned off
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE):
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE, lf_offsets=(0, 0)):
     lib = load_library()
     cfg = Config()
     st = lib.hevcdl_config_default_bd(ctypes.byref(cfg), width, height, qp, bit_depth)
@@ -268,10 +268,11 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
     _set_tiles(cfg, tiles, width, height)        # (columns, rows) uniformly spaced, or explicit sizes: see tile_layout
     cfg.lf_across_tiles = 1 if lf_across_tiles else 0                   # LFCrossTileBoundaryFlag
     cfg.tools = tools                          # cfg keys TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled
+    cfg.lf_beta_offset_div2, cfg.lf_tc_offset_div2 = lf_offsets      # LoopFilterBetaOffset_div2, LoopFilterTcOffset_div2
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, tools=TOOLS_REFERENCE):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, tools=TOOLS_REFERENCE, lf_offsets=(0, 0), lf_disable=False):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -283,6 +284,8 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
     cfg.lf_across_tiles = 1 if lf_across_tiles else 0
     cfg.bit_depth = bit_depth
     cfg.tools = tools
+    cfg.lf_beta_offset_div2, cfg.lf_tc_offset_div2 = lf_offsets
+    cfg.loop_filter_disable = 1 if lf_disable else 0
     sao_ptr = None
     if sao is not None:
         sao = np.ascontiguousarray(sao, SAO_DTYPE)
@@ -301,10 +304,10 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE, lf_offsets=(0, 0)):
         """bit_depth 10: every yuv / recon array of the decision path holds uint16 samples (frame_bytes counts bytes)."""
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode, tools)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode, tools, lf_offsets)
         self.bit_depth = self.cfg.bit_depth
         self.sample_dtype = np.uint8 if self.bit_depth == 8 else np.dtype("<u2")
         self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)

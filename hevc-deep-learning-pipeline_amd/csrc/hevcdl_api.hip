@@ -238,7 +238,7 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51 || cfg->max_frames < 1) return HEVCDL_ERR_INVALID_ARG;
   // keys that would change the path are rejected, not ignored
   if ((cfg->bit_depth != 8 && cfg->bit_depth != 10) || cfg->chroma_format != 420 || cfg->ctu_size != 64 || cfg->max_partition_depth != 4 || cfg->tu_log2_min != 2 ||
-      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || !HEVCDL_TOOLS_SUPPORTED(cfg->tools) || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
+      cfg->tu_log2_max != 5 || cfg->tu_max_depth_intra != 3 || !HEVCDL_TOOLS_SUPPORTED(cfg->tools) || cfg->lf_beta_offset_div2 < -6 || cfg->lf_beta_offset_div2 > 6 || cfg->lf_tc_offset_div2 < -6 || cfg->lf_tc_offset_div2 > 6 || (cfg->bn_mode != HEVCDL_BN_REFERENCE && cfg->bn_mode != HEVCDL_BN_EVAL) ||
       cfg->boundary_policy != HEVCDL_BOUNDARY_CLAMP || (cfg->cnn_input != HEVCDL_CNN_INPUT_RGB601 && cfg->cnn_input != HEVCDL_CNN_INPUT_LUMA) ||
       (cfg->exec_flags & ~(HEVCDL_EXEC_NO_UNIT_HANDOVER | HEVCDL_EXEC_RD_WIDE | HEVCDL_EXEC_RD_NARROW)) ||
       ((cfg->exec_flags & HEVCDL_EXEC_RD_WIDE) && (cfg->exec_flags & HEVCDL_EXEC_RD_NARROW)))
@@ -771,7 +771,9 @@ extern "C" hevcdl_status hevcdl_deblock_frames_dev(hevcdl_ctx *ctx, const void *
   p.width = ctx->cfg.width; p.height = ctx->cfg.height; p.ctus_x = ctx->ctus_x; p.ctus_per_frame = ctx->ctus; p.n_frames = n_frames;
   const int qp = ctx->cfg.qp, qpc = CHROMA_SCALE_420[qp < 0 ? 0 : (qp > 57 ? 57 : qp)];      // TComLoopFilter.cpp:782-797, cQpOffset 0
   const int bd_scale = 1 << (ctx->cfg.bit_depth - 8);                                       // iBitdepthScale, TComLoopFilter.cpp:596, 770
-  p.tc = DBK_TC[qp + 2 > 53 ? 53 : qp + 2] * bd_scale; p.beta = DBK_BETA[qp] * bd_scale; p.tc_c = DBK_TC[qpc + 2 > 53 ? 53 : qpc + 2] * bd_scale;
+  const int tco = 2 * ctx->cfg.lf_tc_offset_div2, bo = 2 * ctx->cfg.lf_beta_offset_div2;   // slice_tc_offset_div2 / slice_beta_offset_div2 << 1 (TComLoopFilter.cpp:623-624, 804), Bs 2
+  auto clipi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+  p.tc = DBK_TC[clipi(qp + 2 + tco, 53)] * bd_scale; p.beta = DBK_BETA[clipi(qp + bo, 51)] * bd_scale; p.tc_c = DBK_TC[clipi(qpc + 2 + tco, 53)] * bd_scale;
   p.pel_max = (1 << ctx->cfg.bit_depth) - 1;
   p.lf_across_tiles = ctx->cfg.lf_across_tiles != 0; p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
   memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);

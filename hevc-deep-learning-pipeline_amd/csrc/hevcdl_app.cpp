@@ -55,7 +55,7 @@ const Key KEYS[] = {
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stream / in-loop filter keys
   { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, PATH, "1" }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
-  { "LoopFilterBetaOffset_div2", 0, PATH, "0" }, { "LoopFilterTcOffset_div2", 0, PATH, "0" },
+  { "LoopFilterBetaOffset_div2", 0, USED, 0 }, { "LoopFilterTcOffset_div2", 0, USED, 0 },
   { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, USED, 0 }, { "SAOLcuBoundary", 0, PATH, "0" }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
   { "LFCrossTileBoundaryFlag", 0, USED, 0 }, { "SEIDecodedPictureHash", 0, USED, 0 },
   // no effect on an all-intra slice with the settings above
@@ -327,6 +327,7 @@ int main(int argc, char **argv)
   if (opt.geti("StrongIntraSmoothing", 1) == 0) tools &= ~HEVCDL_TOOL_STRONG_INTRA;
   if (opt.geti("FastUDIUseMPMEnabled", 1) == 0) tools &= ~HEVCDL_TOOL_FAST_UDI_MPM;
   cfg.tools = tools;
+  cfg.lf_beta_offset_div2 = (int)opt.geti("LoopFilterBetaOffset_div2", 0); cfg.lf_tc_offset_div2 = (int)opt.geti("LoopFilterTcOffset_div2", 0);      // -6 .. 6 (hevcdl_create checks)
   cfg.cnn_input = cnn_input == "luma" ? HEVCDL_CNN_INPUT_LUMA : HEVCDL_CNN_INPUT_RGB601;
   cfg.bn_mode = bn_mode == "eval" ? HEVCDL_BN_EVAL : HEVCDL_BN_REFERENCE;
   if (shared_device) cfg.exec_flags |= HEVCDL_EXEC_NO_UNIT_HANDOVER;
@@ -388,10 +389,9 @@ int main(int argc, char **argv)
   FILE *frecords = record_path.empty() ? nullptr : fopen(record_path.c_str(), "wb");
   FILE *fbits = bitstream_path.empty() ? nullptr : fopen(bitstream_path.c_str(), "wb");
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
-  if (fbits && !deblock) { fprintf(stderr, "Error: the bitstream writer signals deblocking on (LoopFilterDisable 0)\n"); return 2; }
   if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
-  scfg.tools = cfg.tools;
+  scfg.tools = cfg.tools; scfg.lf_beta_offset_div2 = cfg.lf_beta_offset_div2; scfg.lf_tc_offset_div2 = cfg.lf_tc_offset_div2; scfg.loop_filter_disable = deblock ? 0 : 1;
   scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
   const double ny = (double)width * height, nc = ny / 4;
   double sum_bits = 0, sum_psnr[3] = { 0, 0, 0 }, sum_mse[3] = { 0, 0, 0 }; long done = 0;

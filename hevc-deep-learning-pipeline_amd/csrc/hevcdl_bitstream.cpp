@@ -577,7 +577,12 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
 {
   if (!cfg || cfg->struct_size != sizeof *cfg || !records || !out || !out_len || poc < 0) return HEVCDL_ERR_INVALID_ARG;
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->qp < 0 || cfg->qp > 51) return HEVCDL_ERR_INVALID_ARG;
-  if (cfg->loop_filter_disable) return HEVCDL_ERR_UNSUPPORTED;                          // the PPS below signals deblocking on
+  if (cfg->lf_beta_offset_div2 < -6 || cfg->lf_beta_offset_div2 > 6 || cfg->lf_tc_offset_div2 < -6 || cfg->lf_tc_offset_div2 > 6) return HEVCDL_ERR_INVALID_ARG;
+  // deblocking control as TEncTop.cpp:1007-1035 sets it with LoopFilterOffsetInPPS 1 (the cfg's value): no override in the slice header; the PPS carries the disabled flag
+  // and the offsets, and the control fields are present when any of them differs from the inferred values
+  const int dbk_off = cfg->loop_filter_disable != 0;
+  const int dbk_beta = dbk_off ? 0 : cfg->lf_beta_offset_div2, dbk_tc = dbk_off ? 0 : cfg->lf_tc_offset_div2;
+  const int dbk_control = dbk_off || dbk_beta != 0 || dbk_tc != 0;
   if ((cfg->sao_enabled != 0) != (sao != nullptr)) return HEVCDL_ERR_INVALID_ARG;         // SAO parameters go with sample_adaptive_offset_enabled_flag
   const int bd = cfg->bit_depth;
   if (bd != 8 && bd != 10) return HEVCDL_ERR_UNSUPPORTED;
@@ -630,7 +635,8 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
       }
       w.flag(cfg->lf_across_tiles != 0);             // loop_filter_across_tiles_enabled_flag
     }
-    w.flag(1); w.flag(0);                            // loop filter across slices, deblocking_filter_control_present
+    w.flag(1); w.flag(dbk_control);                  // loop filter across slices, deblocking_filter_control_present  (TEncCavlc.cpp:247-259)
+    if (dbk_control) { w.flag(0); w.flag(dbk_off); if (!dbk_off) { w.se(dbk_beta); w.se(dbk_tc); } }      // override_enabled 0, pps_deblocking_filter_disabled_flag, pps_beta / tc_offset_div2
     w.flag(0); w.flag(0); w.ue(0); w.flag(0); w.flag(0);
     w.trailing();
     put_nal(au, 34, w.b, true);
@@ -642,7 +648,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     if (!idr) { w.write((uint32_t)poc & 255u, 8); w.flag(0); w.flag(0); w.ue(0); w.ue(0); w.flag(1); }   // POC lsb, RPS coded in the header (empty), slice_temporal_mvp_enabled
     if (cfg->sao_enabled) { w.flag(1); w.flag(1); }
     w.se(cfg->qp - 26);
-    w.flag(1);                                       // slice_loop_filter_across_slices_enabled_flag
+    if (cfg->sao_enabled || !dbk_off) w.flag(1);     // slice_loop_filter_across_slices_enabled_flag: only when an in-loop filter is on (TEncCavlc.cpp:1097-1104)
     // slice data: one sub-stream per tile, tiles in raster order, CTUs in raster order inside a tile (TEncSlice.cpp:1030-1145).  Every
     // sub-stream starts from the slice-start contexts and ends with a terminating 1 bin (end_of_slice_segment_flag of the last CTU /
     // end_of_subset_one_bit of the others), the coder flush and byte_alignment().

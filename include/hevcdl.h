@@ -104,6 +104,9 @@ typedef struct hevcdl_config {
   int32_t  tile_uniform_spacing;
   int32_t  tile_column_width[19], tile_row_height[21];
   int32_t  lf_across_tiles;      /* LFCrossTileBoundaryFlag (default 1): 0 = deblocking and SAO stop at tile borders */
+  /* LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2 (-6 .. 6, default 0; with LoopFilterOffsetInPPS 1, the cfg's value): added twice to the QP the deblocking filter's
+   * beta / tc tables are read with (TComLoopFilter.cpp:623-624, 804) */
+  int32_t  lf_beta_offset_div2, lf_tc_offset_div2;
 } hevcdl_config;
 
 /* One CTU of decisions: what compressCtu leaves in the picture's CTU record (TEncCu.cpp:1091 copyToPic).
@@ -227,7 +230,7 @@ typedef struct hevcdl_stream_config {
   int32_t  width, height, qp;    /* as in hevcdl_config */
   int32_t  level_idc;            /* general_level_idc = 30 x Level (cfg key Level, TAppEncCfg.cpp:850): 6.2 -> 186, 3.1 -> 93 */
   int32_t  sao_enabled;          /* 1 iff SAO parameters are passed to hevcdl_write_access_unit */
-  int32_t  loop_filter_disable;  /* must be 0 (LoopFilterDisable 0: deblocking on, zero offsets, no PPS control fields) */
+  int32_t  loop_filter_disable;  /* LoopFilterDisable: 1 = pps_deblocking_filter_disabled_flag (the pictures are then NOT to be passed through hevcdl_deblock_frames) */
   int32_t  tile_columns, tile_rows; /* as in hevcdl_config: PPS tile syntax (loop_filter_across_tiles_enabled_flag 1), CTUs in tile scan,
                                        one sub-stream per tile with entry points in the slice header */
   int32_t  bit_depth;            /* 8 (Profile main) or 10 (Profile main10): profile_tier_level, SPS bit depths, SAO offset range */
@@ -236,6 +239,8 @@ typedef struct hevcdl_stream_config {
   int32_t  lf_across_tiles;      /* loop_filter_across_tiles_enabled_flag of the PPS (default 1) */
   uint32_t tools;                /* as in hevcdl_config: transform_skip_enabled_flag / sign_data_hiding_enabled_flag of the PPS, strong_intra_smoothing_enabled_flag of the SPS,
                                     and the residual syntax that goes with the first two */
+  int32_t  lf_beta_offset_div2, lf_tc_offset_div2;   /* as in hevcdl_config: pps_beta_offset_div2 / pps_tc_offset_div2 (deblocking_filter_control_present_flag is set when
+                                    either is non-zero or the filter is disabled: TEncTop.cpp:1007-1035) */
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
 size_t        hevcdl_access_unit_bound(int width, int height);

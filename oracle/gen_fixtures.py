@@ -165,6 +165,35 @@ def gen_rd_tools():
     return cases
 
 
+def gen_rd_lf():
+    """Deblocking control of the cfg other than the reference's values: LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2 (rd_o*: ordinary fixtures that carry
+    lf_offsets) and LoopFilterDisable 1 (lfoff_*: the stream and the unfiltered picture of a run with SAO 0 only -- this project runs SAO on the deblocked picture)."""
+    for name, w, h, nf, qp, seed, off in (("o192_q32_b2_tm1", 192, 128, 1, 32, 61, (2, -1)), ("o200_q27_bm3_t3", 200, 136, 2, 27, 62, (-3, 3)), ("o128_q37_b6_tm6", 128, 128, 1, 37, 63, (6, -6))):
+        yuv = rt.synth_yuv(w, h, nf, seed)
+        lab = rt.make_labels(w, h, nf, "rand", seed + 100)
+        targs = ["--LoopFilterBetaOffset_div2=%d" % off[0], "--LoopFilterTcOffset_div2=%d" % off[1]]
+        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs)
+        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"])
+        assert dump2.tobytes() == dump.tobytes()
+        dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+        nctu = lab.shape[1]
+        summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=8, lf_across_tiles=1, tiles=np.array((1, 1)), lf_offsets=np.array(off),
+                            records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
+                            rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
+                            bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),
+                            summary=np.array(summary))
+        print("rd lf-offset fixture", name, off, summary[0][:60] if summary else "")
+    w, h, nf, qp, seed = 192, 128, 2, 32, 64
+    yuv = rt.synth_yuv(w, h, nf, seed)
+    lab = rt.make_labels(w, h, nf, "rand", seed + 100)
+    dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--LoopFilterDisable=1", "--SAO=0", "--SEIDecodedPictureHash=0"])
+    dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+    np.savez_compressed(os.path.join(GOLD, "lfoff_c192_q32.npz"), width=w, height=h, qp=qp, yuv=yuv, labels=lab, records=dump["rec"].reshape(nf, lab.shape[1]),
+                        bitstream_nosao=np.frombuffer(bitstream, np.uint8), recon=np.frombuffer(recon, np.uint8), summary=np.array([ln for ln in out.splitlines() if ln.startswith("POC")]))
+    print("LoopFilterDisable fixture lfoff_c192_q32")
+
+
 def load_ref_model():
     import torch
     import torch.nn as nn
@@ -458,7 +487,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "rdtools", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "rdtools", "rdlf", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
     if "stage" in what:
         gen_stage_traces()
     if "rd" in what:
@@ -471,6 +500,8 @@ if __name__ == "__main__":
         gen_rd(extreme=True)
     if "rdtools" in what:
         gen_rd_tools()
+    if "rdlf" in what:
+        gen_rd_lf()
     if "cnn" in what or "weights" in what:
         model, sd, src = load_ref_model()
         if "weights" in what:

@@ -106,6 +106,10 @@ static int on_tile_border(int pos, int n_tiles, const int *bd)
   return 0;
 }
 
+/* LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2 of the cfg (slice_beta_offset_div2 / slice_tc_offset_div2, TComLoopFilter.cpp:584-585, 701) */
+static int g_beta_offset_div2 = 0, g_tc_offset_div2 = 0;
+void hm_oracle_set_deblock_offsets(int beta_offset_div2, int tc_offset_div2) { g_beta_offset_div2 = beta_offset_div2; g_tc_offset_div2 = tc_offset_div2; }
+
 int hm_oracle_deblock_frame16_tb(uint16_t *frame, int width, int height, int qp, const hm_ctu_record *recs, int bit_depth,
                                  int tile_cols, int tile_rows, const int *col_bd, const int *row_bd)
 {
@@ -116,10 +120,10 @@ int hm_oracle_deblock_frame16_tb(uint16_t *frame, int width, int height, int qp,
   g_pel_max = (1 << bit_depth) - 1;
   {
     const int bd_scale = 1 << (bit_depth - 8);                                    /* iBitdepthScale :596, 770 */
-    const int tc = tc_table[clip3(0, 53, qp + 2)] * bd_scale, beta = beta_table[qp] * bd_scale;   /* :623-627, Bs 2, offsets 0 */
+    const int tc = tc_table[clip3(0, 53, qp + 2 + 2 * g_tc_offset_div2)] * bd_scale, beta = beta_table[clip3(0, 51, qp + 2 * g_beta_offset_div2)] * bd_scale;   /* :623-627, Bs 2 */
     const int side_thr = (beta + (beta >> 1)) >> 3, thr_cut = tc * 10;
     const int qpc = g_chroma_scale_420[clip3(0, 57, qp)];                         /* :782-797, cQpOffset 0 */
-    const int tc_c = tc_table[clip3(0, 53, qpc + 2)] * bd_scale;
+    const int tc_c = tc_table[clip3(0, 53, qpc + 2 + 2 * g_tc_offset_div2)] * bd_scale;                                   /* :804 */
     for (dir = 0; dir < 2; dir++) {                                               /* 0: vertical edges (filter across x), 1: horizontal */
       /* luma: 4-sample segments of every edge on the 8x8 grid */
       for (y = 0; y < height; y += dir ? 8 : 4)

@@ -247,10 +247,18 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     return recs, recon, stats
 
 
-def run_deblock(recon, width, height, qp, recs, bit_depth=8, tiles=(1, 1), lf_across_tiles=True):
+def run_deblock(recon, width, height, qp, recs, bit_depth=8, tiles=(1, 1), lf_across_tiles=True, lf_offsets=(0, 0)):
     """Oracle deblocking of pre-filter reconstructions [frames][w*h*3/2] given the records [frames][ctus] -> filtered copy.
-    lf_across_tiles False = LFCrossTileBoundaryFlag 0: edges on the borders of `tiles` are left alone."""
+    lf_across_tiles False = LFCrossTileBoundaryFlag 0: edges on the borders of `tiles` are left alone.  lf_offsets: (LoopFilterBetaOffset_div2, LoopFilterTcOffset_div2)."""
     lib = oracle_lib()
+    lib.hm_oracle_set_deblock_offsets(int(lf_offsets[0]), int(lf_offsets[1]))
+    try:
+        return _run_deblock(lib, recon, width, height, qp, recs, bit_depth, tiles, lf_across_tiles)
+    finally:
+        lib.hm_oracle_set_deblock_offsets(0, 0)
+
+
+def _run_deblock(lib, recon, width, height, qp, recs, bit_depth, tiles, lf_across_tiles):
     if not lf_across_tiles:
         lib.hm_oracle_deblock_frame16_tb.restype = ctypes.c_int
         lib.hm_oracle_deblock_frame16_tb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,

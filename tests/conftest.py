@@ -29,6 +29,11 @@ def fixture_tiles(f):
     return tuple(int(v) for v in f["tiles"]) if "tiles" in f.files else (1, 1)
 
 
+def fixture_lf_offsets(f):
+    """(LoopFilterBetaOffset_div2, LoopFilterTcOffset_div2) of a golden fixture (rd_o*: reference runs with the keys on the command line)."""
+    return tuple(int(v) for v in f["lf_offsets"]) if "lf_offsets" in f.files else (0, 0)
+
+
 def fixture_lf(f):
     """LFCrossTileBoundaryFlag of a golden fixture (rd_l*: 0)."""
     return bool(int(f["lf_across_tiles"])) if "lf_across_tiles" in f.files else True

@@ -167,7 +167,7 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10",
-                                  "k128_q22_sbh0", "k128_q27_ts0", "k192_q32_sis0", "k200_q32_mpm0", "k200_q27_all0", "k128_q22_rdoq0", "k128_q27_rdoqts0", "k200_q32_rdoq0", "k200_q27_rdoq0_sbh0", "k128_q27_tsf0", "k200_q32_tsf0", "k200_q30_b10_mix0"])
+                                  "k128_q22_sbh0", "k128_q27_ts0", "k192_q32_sis0", "k200_q32_mpm0", "k200_q27_all0", "k128_q22_rdoq0", "k128_q27_rdoqts0", "k200_q32_rdoq0", "k200_q27_rdoq0_sbh0", "k128_q27_tsf0", "k200_q32_tsf0", "k200_q30_b10_mix0", "o192_q32_b2_tm1", "o200_q27_bm3_t3", "o128_q37_b6_tm6"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
     """b416_q32_r is C1 of BASELINE.json (416x240, one frame, QP32, untiled 8-bit, the reference's default configuration); c192 / b200 are
     further untiled 8-bit runs (two frames; a picture that is not a multiple of 64).  The rest:
@@ -180,7 +180,7 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hevc_parse as hp
     import ref_tools
-    from conftest import fixture_tiles, fixture_lf
+    from conftest import fixture_tiles, fixture_lf, fixture_lf_offsets
     f = np.load(os.path.join(GOLD, "rd_%s.npz" % case))
     w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8
@@ -193,7 +193,8 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
     r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
                   "--SEIDecodedPictureHash=1",
                   ] + ref_tools.tile_args(fixture_tiles(f)) + bd_args + ([] if fixture_lf(f) else ["--LFCrossTileBoundaryFlag=0"])
-                  + (ref_tools.tool_args(int(f["tools"])) if "tools" in f.files else []), tmp_path)
+                  + (ref_tools.tool_args(int(f["tools"])) if "tools" in f.files else [])
+                  + (["--LoopFilterBetaOffset_div2=%d" % fixture_lf_offsets(f)[0], "--LoopFilterTcOffset_div2=%d" % fixture_lf_offsets(f)[1]] if "lf_offsets" in f.files else []), tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_filtered"])
     assert (tmp_path / "str.bin").read_bytes() == f["bitstream"].tobytes()           # the reference's stream, picture-hash SEI included
@@ -205,3 +206,22 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
     if case == "t520_q37_2x2":
         r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "--TileUniformSpacing=1", "--NumTileColumnsMinus1=2"], tmp_path)
         assert r.returncode == 2 and "4 CTUs wide" in r.stderr          # 9 CTU columns cannot hold three tiles of the minimum width
+
+
+@pytest.mark.gpu
+def test_cli_with_the_deblocking_filter_disabled_reproduces_the_reference_run(app, tmp_path):
+    """--LoopFilterDisable=1 --SAO=0: the pictures leave the decision kernel as they are, the PPS says so (pps_deblocking_filter_disabled_flag): reconstruction file and stream
+    of the reference's run with the same keys, byte for byte."""
+    from conftest import GOLD
+    f = np.load(os.path.join(GOLD, "lfoff_c192_q32.npz"))
+    w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
+    f["yuv"].astype(np.uint8).tofile(tmp_path / "in.yuv")
+    for fr in range(nf):
+        os.makedirs(tmp_path / "pred" / str(fr))
+        for a in range(f["labels"].shape[1]):
+            (tmp_path / "pred" / str(fr) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in f["labels"][fr, a]))
+    r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
+                  "--LoopFilterDisable=1", "--SAO=0"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon"])
+    assert (tmp_path / "str.bin").read_bytes() == f["bitstream_nosao"].tobytes()

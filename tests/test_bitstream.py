@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles, fixture_lf
+from conftest import GOLD, fixture_tiles, fixture_lf, fixture_lf_offsets
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -24,7 +24,7 @@ def stream_of(f):
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8        # rd_x*: reference runs at InternalBitDepth 10, Profile main10
     tools = int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE      # rd_k*: reference runs with a tool switch of the cfg turned off
-    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd, lf_across_tiles=fixture_lf(f), tools=tools) for poc in range(recs.shape[0]))
+    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd, lf_across_tiles=fixture_lf(f), tools=tools, lf_offsets=fixture_lf_offsets(f)) for poc in range(recs.shape[0]))
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
@@ -110,9 +110,11 @@ def test_writer_rejects_what_it_does_not_implement():
     rec = np.zeros(1, hevcdl_amd.REC_DTYPE); buf = np.zeros(4096, np.uint8); n = ctypes.c_size_t(0)
     cfg.sao_enabled = 1
     assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 1    # SAO flag without parameters
-    cfg.sao_enabled = 0; cfg.loop_filter_disable = 1
-    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 2    # UNSUPPORTED
-    cfg.loop_filter_disable = 0
+    cfg.sao_enabled = 0; cfg.tools = 0x80
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 2    # UNSUPPORTED: no tool of the reference's cfg
+    cfg.tools = 0x7f; cfg.lf_tc_offset_div2 = 7                                                                                    # -6 .. 6
+    assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 1
+    cfg.lf_tc_offset_div2 = 0
     assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 8, ctypes.byref(n)) == 1 and n.value > 8
     assert lib.hevcdl_write_access_unit(ctypes.byref(cfg), 0, rec.ctypes.data, None, buf.ctypes.data, 4096, ctypes.byref(n)) == 0
     cfg.tile_columns = 2                                  # a 1-CTU picture cannot hold two tile columns (each at least 4 CTUs wide)
@@ -132,3 +134,14 @@ def test_tile_syntax_parses_back():
     assert pps["tiles_enabled"] == 1 and (pps["tile_columns"], pps["tile_rows"], pps["uniform_spacing"], pps["lf_across_tiles"]) == (2, 3, 1, 1)
     hdr, _ = hp.parse_slice_header(nals[3][1], sps, pps)
     assert len(hdr["entry_points"]) == 5 and sum(hdr["entry_points"]) < len(nals[3][1]) - hdr["data_byte_pos"]
+
+
+def test_stream_with_the_deblocking_filter_disabled_is_byte_exact_with_the_reference():
+    """LoopFilterDisable 1 (with SAO 0): pps_deblocking_filter_disabled_flag behind deblocking_filter_control_present_flag, and no
+    slice_loop_filter_across_slices_enabled_flag in the slice header (no in-loop filter is on: TEncCavlc.cpp:1097-1104) -- the reference's stream of such a run, byte for byte."""
+    import hevcdl_amd
+    f = np.load(os.path.join(GOLD, "lfoff_c192_q32.npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], lf_disable=True) for poc in range(recs.shape[0]))
+    assert ours == f["bitstream_nosao"].tobytes()

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles, fixture_lf
+from conftest import GOLD, fixture_tiles, fixture_lf, fixture_lf_offsets
 
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
 
@@ -43,7 +43,7 @@ def test_oracle_deblock_matches_reference(oracle_built, path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     recs = np.frombuffer(f["records"].tobytes(), dtype=ref_tools.REC_DTYPE).reshape(f["records"].shape[0], -1)
     pre = prefilter_frames(f)
-    out = ref_tools.run_deblock(pre, w, h, qp, recs, bit_depth=bit_depth_of(f), tiles=fixture_tiles(f), lf_across_tiles=fixture_lf(f))
+    out = ref_tools.run_deblock(pre, w, h, qp, recs, bit_depth=bit_depth_of(f), tiles=fixture_tiles(f), lf_across_tiles=fixture_lf(f), lf_offsets=fixture_lf_offsets(f))
     ref = deblocked_of(f, out.shape)
     if qp >= 22 and w * h >= 128 * 128:
         assert (pre != ref).sum() > 1000                   # the filter does something on every ordinary fixture (tc = beta = 0 at QP 0)
@@ -70,7 +70,7 @@ def test_gpu_deblock_matches_reference(path):
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     nf = f["records"].shape[0]
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, bit_depth=bit_depth_of(f), tiles=fixture_tiles(f), lf_across_tiles=fixture_lf(f))
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, bit_depth=bit_depth_of(f), tiles=fixture_tiles(f), lf_across_tiles=fixture_lf(f), lf_offsets=fixture_lf_offsets(f))
     out = e.deblock_frames(prefilter_frames(f), recs)
     e.close()
     assert np.array_equal(out, deblocked_of(f, out.shape))
