@@ -863,7 +863,6 @@ extern "C" hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
   if (n_frames == 0) return HEVCDL_OK;
   if (!yuv || !records || !picture_out) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
-  if (sao_opt && !deblock) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "SAO runs on the deblocked picture only");
   uint8_t *d_final = nullptr;
   st = encode_pictures_device(ctx, yuv, n_frames, labels_opt, deblock, sao_opt != nullptr, &d_final); if (st) return st;
   HIPCHK(hipMemcpy(records, ctx->d_records, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames, hipMemcpyDeviceToHost));
@@ -879,7 +878,6 @@ extern "C" hevcdl_status hevcdl_encode_pictures_chunked(hevcdl_ctx *ctx, const v
   hevcdl_status st = check_frames(ctx, n_frames); if (st) return st;
   if (n_frames == 0) return HEVCDL_OK;
   if (!yuv || !fn) return fail(ctx, HEVCDL_ERR_INVALID_ARG, "null pointer");
-  if (want_sao && !deblock) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "SAO runs on the deblocked picture only");
   const int chunk = std::min(n_frames, chunk_frames > 0 ? chunk_frames : 64);
   const size_t rec_b = (size_t)ctx->ctus * sizeof(hevcdl_ctu_record), sao_b = (size_t)ctx->ctus * sizeof(hevcdl_sao_blk), pic_b = ctx->frame_bytes, stat_b = sizeof(hevcdl_frame_stats);
   auto up64 = [](size_t v) { return (v + 63) & ~(size_t)63; };      // every section of a chunk buffer starts on a 64-byte boundary (the callback gets pointers to structs with 64-bit members)

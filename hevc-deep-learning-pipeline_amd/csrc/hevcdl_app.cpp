@@ -389,7 +389,6 @@ int main(int argc, char **argv)
   FILE *frecords = record_path.empty() ? nullptr : fopen(record_path.c_str(), "wb");
   FILE *fbits = bitstream_path.empty() ? nullptr : fopen(bitstream_path.c_str(), "wb");
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
-  if (sao && !deblock) { fprintf(stderr, "Error: SAO is only implemented on top of the deblocked picture (LoopFilterDisable 0)\n"); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
   scfg.tools = cfg.tools; scfg.lf_beta_offset_div2 = cfg.lf_beta_offset_div2; scfg.lf_tc_offset_div2 = cfg.lf_tc_offset_div2; scfg.loop_filter_disable = deblock ? 0 : 1;
   scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);

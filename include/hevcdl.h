@@ -201,7 +201,7 @@ hevcdl_status hevcdl_sao_frames(hevcdl_ctx *ctx, const uint8_t *org, const uint8
 hevcdl_status hevcdl_sao_frames_dev(hevcdl_ctx *ctx, const void *d_org, const void *d_deblocked, int n_frames, void *d_params, void *d_out, void *stream);
 
 /* ---- the whole picture pipeline in one call (host buffers): CNN labels (labels_opt == NULL) -> decisions -> deblocking (deblock != 0) -> SAO
- * (sao_opt != NULL; needs deblock) with the pictures staying in HBM between the stages.  records + picture_out (the output picture: after the
+ * (sao_opt != NULL; with deblock == 0 -- LoopFilterDisable 1 -- it works on the unfiltered reconstruction, as the reference does) with the pictures staying in HBM between the stages.  records + picture_out (the output picture: after the
  * enabled filters; uint16 samples at 10 bits) + sao_opt feed hevcdl_write_access_unit / hevcdl_write_picture_hash_sei.  stats_opt: SSE before
  * the in-loop filters and estimated bits, as hevcdl_compress_frames.  Replaces TEncGOP::compressGOP's per-picture stages (TEncGOP.cpp:1560-1800). */
 hevcdl_status hevcdl_encode_pictures(hevcdl_ctx *ctx, const void *yuv, int n_frames, const uint8_t *labels_opt, int deblock, hevcdl_ctu_record *records,

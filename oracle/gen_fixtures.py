@@ -189,8 +189,11 @@ def gen_rd_lf():
     lab = rt.make_labels(w, h, nf, "rand", seed + 100)
     dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--LoopFilterDisable=1", "--SAO=0", "--SEIDecodedPictureHash=0"])
     dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+    # ... and with SAO on (the reference's default): SAO then works on the unfiltered reconstruction
+    dump_s, out_s, bitstream_s, recon_s = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--LoopFilterDisable=1"])
     np.savez_compressed(os.path.join(GOLD, "lfoff_c192_q32.npz"), width=w, height=h, qp=qp, yuv=yuv, labels=lab, records=dump["rec"].reshape(nf, lab.shape[1]),
-                        bitstream_nosao=np.frombuffer(bitstream, np.uint8), recon=np.frombuffer(recon, np.uint8), summary=np.array([ln for ln in out.splitlines() if ln.startswith("POC")]))
+                        bitstream_nosao=np.frombuffer(bitstream, np.uint8), recon=np.frombuffer(recon, np.uint8), summary=np.array([ln for ln in out.splitlines() if ln.startswith("POC")]),
+                        bitstream_sao=np.frombuffer(bitstream_s, np.uint8), recon_sao=np.frombuffer(recon_s, np.uint8), summary_sao=np.array([ln for ln in out_s.splitlines() if ln.startswith("POC")]))
     print("LoopFilterDisable fixture lfoff_c192_q32")
 
 

@@ -225,3 +225,9 @@ def test_cli_with_the_deblocking_filter_disabled_reproduces_the_reference_run(ap
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon"])
     assert (tmp_path / "str.bin").read_bytes() == f["bitstream_nosao"].tobytes()
+    # SAO on (the reference's default): it then works on the unfiltered reconstruction; the stream carries the picture-hash SEI of the final picture
+    r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str2.bin", "-o", "rec2.yuv", "--LabelDir=pred", "--Level=6.2",
+                  "--LoopFilterDisable=1", "--SEIDecodedPictureHash=1"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "rec2.yuv", np.uint8), f["recon_sao"])
+    assert (tmp_path / "str2.bin").read_bytes() == f["bitstream_sao"].tobytes()

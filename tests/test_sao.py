@@ -88,3 +88,19 @@ def test_gpu_pipeline_matches_oracle_at_full_size(oracle_built, w, h, qp):
     o_params, o_out = ref_tools.run_sao(yuv, dbk, w, h, qp)
     assert params.tobytes() == o_params.tobytes()
     assert np.array_equal(out, o_out) and (w < 1000 or (out != dbk).any())
+
+
+def test_oracle_sao_on_a_picture_that_was_not_deblocked(oracle_built):
+    """LoopFilterDisable 1 with SAO on: the reference runs SAO on the unfiltered reconstruction; the oracle on the same input gives its final picture, and the writer
+    (pps_deblocking_filter_disabled_flag, SAO syntax) its stream -- the picture-hash SEI aside, and with it."""
+    import hevcdl_amd
+    import ref_tools
+    f = np.load(os.path.join(GOLD, "lfoff_c192_q32.npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"]); nf = f["records"].shape[0]; fb = w * h * 3 // 2
+    org, pre, final = f["yuv"].reshape(nf, fb), np.frombuffer(f["recon"].tobytes(), np.uint8).reshape(nf, fb), np.frombuffer(f["recon_sao"].tobytes(), np.uint8).reshape(nf, fb)
+    params, out = ref_tools.run_sao(org, pre, w, h, qp)
+    assert np.array_equal(out, final)
+    recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
+    aus = [hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), lf_disable=True) for poc in range(nf)]
+    assert b"".join(aus) == strip_sei(f["bitstream_sao"].tobytes())
+    assert b"".join(au + hevcdl_amd.picture_hash_sei(w, h, out[poc]) for poc, au in enumerate(aus)) == f["bitstream_sao"].tobytes()
