@@ -89,7 +89,8 @@ class StreamConfig(ctypes.Structure):
                 ("level_idc", ctypes.c_int32), ("sao_enabled", ctypes.c_int32), ("loop_filter_disable", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("lf_across_tiles", ctypes.c_int32), ("tools", ctypes.c_uint32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32)]
+                ("lf_across_tiles", ctypes.c_int32), ("tools", ctypes.c_uint32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32),
+                ("rewrite_param_sets", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -272,7 +273,8 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
     return cfg
 
 
-def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, tools=TOOLS_REFERENCE, lf_offsets=(0, 0), lf_disable=False):
+def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, tools=TOOLS_REFERENCE, lf_offsets=(0, 0), lf_disable=False,
+                      rewrite_param_sets=True):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -286,6 +288,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
     cfg.tools = tools
     cfg.lf_beta_offset_div2, cfg.lf_tc_offset_div2 = lf_offsets
     cfg.loop_filter_disable = 1 if lf_disable else 0
+    cfg.rewrite_param_sets = 1 if rewrite_param_sets else 0
     sao_ptr = None
     if sao is not None:
         sao = np.ascontiguousarray(sao, SAO_DTYPE)

@@ -54,9 +54,9 @@ const Key KEYS[] = {
   { "NumTileRowsMinus1", 0, USED, 0 }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stream / in-loop filter keys
-  { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, PATH, "1" }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
+  { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, USED, 0 }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
   { "LoopFilterBetaOffset_div2", 0, USED, 0 }, { "LoopFilterTcOffset_div2", 0, USED, 0 },
-  { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, USED, 0 }, { "SAOLcuBoundary", 0, PATH, "0" }, { "LFCrossSliceBoundaryFlag", 0, PATH, "1" },
+  { "DeblockingFilterMetric", 0, PATH, "0" }, { "SAO", 0, USED, 0 }, { "SAOLcuBoundary", 0, PATH, "0" }, { "LFCrossSliceBoundaryFlag", 0, NOEFFECT, 0 },      // (without slices the reference sets it to 1 whatever the cfg says: TAppEncTop.cpp:278-281)
   { "LFCrossTileBoundaryFlag", 0, USED, 0 }, { "SEIDecodedPictureHash", 0, USED, 0 },
   // no effect on an all-intra slice with the settings above
   { "QuadtreeTUMaxDepthInter", 0, NOEFFECT, 0 }, { "FastSearch", 0, NOEFFECT, 0 }, { "SearchRange", 0, NOEFFECT, 0 }, { "HadamardME", 0, NOEFFECT, 0 },
@@ -390,6 +390,7 @@ int main(int argc, char **argv)
   FILE *fbits = bitstream_path.empty() ? nullptr : fopen(bitstream_path.c_str(), "wb");
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
   hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
+  scfg.rewrite_param_sets = opt.geti("ReWriteParamSetsFlag", 1) != 0;
   scfg.tools = cfg.tools; scfg.lf_beta_offset_div2 = cfg.lf_beta_offset_div2; scfg.lf_tc_offset_div2 = cfg.lf_tc_offset_div2; scfg.loop_filter_disable = deblock ? 0 : 1;
   scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);
   const double ny = (double)width * height, nc = ny / 4;

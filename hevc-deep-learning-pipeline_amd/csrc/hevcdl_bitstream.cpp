@@ -527,7 +527,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
   cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1; cfg->lf_across_tiles = 1;
-  cfg->tools = HEVCDL_TOOLS_REFERENCE;
+  cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->rewrite_param_sets = 1;
   return HEVCDL_OK;
 }
 
@@ -595,7 +595,8 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   if (hevcdl_tile_bounds((cfg->width + 63) >> 6, tcols, uniform, cfg->tile_column_width, tiled ? 4 : 1, col_bd) ||      // TComPicSym.cpp:380-392
       hevcdl_tile_bounds((cfg->height + 63) >> 6, trows, uniform, cfg->tile_row_height, 1, row_bd)) return HEVCDL_ERR_INVALID_ARG;
   std::vector<uint8_t> au;
-  { // VPS  TEncCavlc.cpp:677-753
+  const bool write_ps = poc == 0 || cfg->rewrite_param_sets != 0;                       // TEncGOP.cpp:1751: the first picture, or every IRAP with ReWriteParamSetsFlag
+  if (write_ps) { // VPS  TEncCavlc.cpp:677-753
     BitOut w;
     w.write(0, 4); w.flag(1); w.flag(1); w.write(0, 6); w.write(0, 3); w.flag(1); w.write(0xffff, 16);
     profile_tier_level(w, cfg->level_idc, bd);
@@ -604,7 +605,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     w.trailing();
     put_nal(au, 32, w.b, true);
   }
-  { // SPS  TEncCavlc.cpp:500-675
+  if (write_ps) { // SPS  TEncCavlc.cpp:500-675
     BitOut w;
     w.write(0, 4); w.write(0, 3); w.flag(1);
     profile_tier_level(w, cfg->level_idc, bd);
@@ -621,7 +622,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     w.trailing();
     put_nal(au, 33, w.b, true);
   }
-  { // PPS  TEncCavlc.cpp:189-341
+  if (write_ps) { // PPS  TEncCavlc.cpp:189-341
     BitOut w;
     w.ue(0); w.ue(0); w.flag(0); w.flag(0); w.write(0, 3); w.flag((cfg->tools & HEVCDL_TOOL_SIGN_HIDE) != 0); w.flag(1); w.ue(3); w.ue(3);   // ... sign_data_hiding_enabled_flag, cabac_init_present_flag, ...
     w.se(0); w.flag(0); w.flag((cfg->tools & HEVCDL_TOOL_TSKIP) != 0); w.flag(0);        // init_qp_minus26 0, constrained intra, transform skip, cu_qp_delta
@@ -680,7 +681,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     }
     w.trailing();                                    // byte_alignment()
     for (const BitOut &sw : sub) w.b.insert(w.b.end(), sw.b.begin(), sw.b.end());
-    put_nal(au, idr ? 19 : 21, w.b, false);          // IDR_W_RADL, then CRA (DecodingRefreshType 1)
+    put_nal(au, idr ? 19 : 21, w.b, !write_ps);      // IDR_W_RADL, then CRA (DecodingRefreshType 1); the first NAL unit of an access unit carries the zero_byte
   }
   *out_len = au.size();
   if (au.size() > capacity) return HEVCDL_ERR_INVALID_ARG;

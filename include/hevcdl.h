@@ -241,6 +241,10 @@ typedef struct hevcdl_stream_config {
                                     and the residual syntax that goes with the first two */
   int32_t  lf_beta_offset_div2, lf_tc_offset_div2;   /* as in hevcdl_config: pps_beta_offset_div2 / pps_tc_offset_div2 (deblocking_filter_control_present_flag is set when
                                     either is non-zero or the filter is disabled: TEncTop.cpp:1007-1035) */
+  int32_t  rewrite_param_sets;   /* ReWriteParamSetsFlag (default 1: VPS / SPS / PPS in front of every picture, all of them IRAPs here); 0: in front of the first picture only
+                                    (TEncGOP.cpp:1751) */
+                                 /* (LFCrossSliceBoundaryFlag has no field: without slices -- SliceMode 0, the only mode of this path -- the reference sets it to 1 whatever the cfg
+                                    says, TAppEncTop.cpp:278-281; tests/golden/stream_c192_q32.npz pins that) */
 } hevcdl_stream_config;
 hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg, int width, int height, int qp);
 size_t        hevcdl_access_unit_bound(int width, int height);

@@ -195,6 +195,17 @@ def gen_rd_lf():
                         bitstream_nosao=np.frombuffer(bitstream, np.uint8), recon=np.frombuffer(recon, np.uint8), summary=np.array([ln for ln in out.splitlines() if ln.startswith("POC")]),
                         bitstream_sao=np.frombuffer(bitstream_s, np.uint8), recon_sao=np.frombuffer(recon_s, np.uint8), summary_sao=np.array([ln for ln in out_s.splitlines() if ln.startswith("POC")]))
     print("LoopFilterDisable fixture lfoff_c192_q32")
+    # stream-only switches: parameter sets in front of the first picture only, pps_loop_filter_across_slices_enabled_flag 0 (one slice per picture: same pictures)
+    w, h, nf, qp, seed = 192, 128, 3, 32, 65
+    yuv = rt.synth_yuv(w, h, nf, seed)
+    lab = rt.make_labels(w, h, nf, "rand", seed + 100)
+    out = {}
+    for key, args in (("ps0", ["--ReWriteParamSetsFlag=0"]), ("ls0", ["--LFCrossSliceBoundaryFlag=0"]), ("both", ["--ReWriteParamSetsFlag=0", "--LFCrossSliceBoundaryFlag=0"])):
+        dump, _, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=args + ["--SAO=0", "--SEIDecodedPictureHash=0"])
+        out["bitstream_" + key] = np.frombuffer(bitstream, np.uint8); out["recon_" + key] = np.frombuffer(recon, np.uint8)
+    dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+    np.savez_compressed(os.path.join(GOLD, "stream_c192_q32.npz"), width=w, height=h, qp=qp, yuv=yuv, labels=lab, records=dump["rec"].reshape(nf, lab.shape[1]), **out)
+    print("stream-switch fixture stream_c192_q32")
 
 
 def load_ref_model():

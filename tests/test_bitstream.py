@@ -145,3 +145,16 @@ def test_stream_with_the_deblocking_filter_disabled_is_byte_exact_with_the_refer
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
     ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], lf_disable=True) for poc in range(recs.shape[0]))
     assert ours == f["bitstream_nosao"].tobytes()
+
+
+def test_stream_switches_of_the_cfg():
+    """ReWriteParamSetsFlag 0: VPS / SPS / PPS in front of the first picture only (the slice NAL unit then opens the access unit: zero_byte).  LFCrossSliceBoundaryFlag 0: no
+    effect -- without slices the reference sets the flag to 1 whatever the cfg says (TAppEncTop.cpp:278-281).  Three reference runs of three frames: byte for byte."""
+    import hevcdl_amd
+    f = np.load(os.path.join(GOLD, "stream_c192_q32.npz"))
+    w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
+    recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
+    stream = lambda **kw: b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], **kw) for poc in range(recs.shape[0]))
+    assert stream(rewrite_param_sets=False) == f["bitstream_ps0"].tobytes() == f["bitstream_both"].tobytes()
+    assert stream() == f["bitstream_ls0"].tobytes()
+    assert len(f["bitstream_ps0"]) < len(f["bitstream_ls0"])
