@@ -231,3 +231,22 @@ def test_cli_with_the_deblocking_filter_disabled_reproduces_the_reference_run(ap
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec2.yuv", np.uint8), f["recon_sao"])
     assert (tmp_path / "str2.bin").read_bytes() == f["bitstream_sao"].tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_stream_switches_reproduce_the_reference_run(app, tmp_path):
+    """--ReWriteParamSetsFlag=0 --LFCrossSliceBoundaryFlag=0 (--SAO=0): parameter sets in front of the first picture only, the second key without effect: the reference's
+    stream and pictures of the run with the same keys."""
+    from conftest import GOLD
+    f = np.load(os.path.join(GOLD, "stream_c192_q32.npz"))
+    w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
+    f["yuv"].astype(np.uint8).tofile(tmp_path / "in.yuv")
+    for fr in range(nf):
+        os.makedirs(tmp_path / "pred" / str(fr))
+        for a in range(f["labels"].shape[1]):
+            (tmp_path / "pred" / str(fr) / ("ctu%d.txt" % a)).write_text(" ".join(str(int(v)) for v in f["labels"][fr, a]))
+    r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
+                  "--ReWriteParamSetsFlag=0", "--LFCrossSliceBoundaryFlag=0", "--SAO=0"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "str.bin").read_bytes() == f["bitstream_both"].tobytes()
+    assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_both"])
