@@ -225,11 +225,27 @@ EXPORTS = ["hevcdl_config_default", "hevcdl_create", "hevcdl_destroy", "hevcdl_l
            "hevcdl_predict_depth_rgb", "hevcdl_labels_from_logits", "hevcdl_compress_frames", "hevcdl_predict_depth_planes", "hevcdl_compress_frames_planes", "hevcdl_predict_depth_dev", "hevcdl_compress_frames_dev",
            "hevcdl_encode_frames_dev", "hevcdl_compress_tiles_dev", "hevcdl_clamp_labels_dev", "hevcdl_device_memory", "hevcdl_host_alloc", "hevcdl_host_free", "hevcdl_encode_pictures", "hevcdl_encode_pictures_chunked", "hevcdl_profile_enable", "hevcdl_profile_get", "hevcdl_last_rd_launch", "hevcdl_reserve_workspace", "hevcdl_ctus_per_frame", "hevcdl_frame_bytes", "hevcdl_frame_bytes_bd", "hevcdl_config_default_bd",
            "hevcdl_begin_frames", "hevcdl_compress_ctu", "hevcdl_get_recon", "hevcdl_deblock_frames", "hevcdl_deblock_frames_dev",
-           "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5", "hevcdl_write_digest_sei"]
+           "hevcdl_sao_frames", "hevcdl_sao_frames_dev", "hevcdl_stream_config_default", "hevcdl_access_unit_bound", "hevcdl_write_access_unit", "hevcdl_write_picture_hash_sei", "hevcdl_picture_md5", "hevcdl_write_digest_sei", "hevcdl_picture_hash", "hevcdl_write_hash_sei"]
 
 
-def picture_hash_sei(width, height, picture, bit_depth=8):
-    """Suffix SEI NAL with the MD5 of the three planes of `picture` (the final reconstruction) -> bytes."""
+def picture_hash_sei(width, height, picture, bit_depth=8, method=1):
+    """Suffix SEI NAL with the hash of the three planes of `picture` (the final reconstruction) -> bytes.  method: SEIDecodedPictureHash 1 MD5, 2 CRC, 3 checksum."""
+    if method != 1:
+        lib = load_library()
+        cfg = StreamConfig()
+        if lib.hevcdl_stream_config_default(ctypes.byref(cfg), width, height, 32) != 0:
+            raise HevcdlError(1, "stream config")
+        cfg.bit_depth = bit_depth
+        pic = np.ascontiguousarray(picture, np.uint8 if bit_depth == 8 else np.dtype("<u2")).reshape(-1)
+        dg = np.zeros(48, np.uint8); pb = ctypes.c_int(0); buf = np.zeros(128, np.uint8); n = ctypes.c_size_t(0)
+        lib.hevcdl_picture_hash.argtypes = [ctypes.POINTER(StreamConfig), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        lib.hevcdl_write_hash_sei.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        st = lib.hevcdl_picture_hash(ctypes.byref(cfg), pic.ctypes.data, method, dg.ctypes.data, ctypes.byref(pb))
+        if st == 0:
+            st = lib.hevcdl_write_hash_sei(method, dg.ctypes.data, buf.ctypes.data, 128, ctypes.byref(n))
+        if st != 0:
+            raise HevcdlError(st, "picture hash SEI")
+        return buf[:n.value].tobytes()
     lib = load_library()
     cfg = StreamConfig()
     if lib.hevcdl_stream_config_default(ctypes.byref(cfg), width, height, 32) != 0:

@@ -237,7 +237,7 @@ int main(int argc, char **argv)
     if (prof != (bit_depth == 8 ? "main" : "main10")) opt.errors.push_back("Profile = " + prof + " is not implemented by this path (main at 8 bits, main10 at 10 bits)"); }
   // decoded picture hash SEI (TAppEncCfg.cpp:1093): 0 none, 1 MD5 of the output picture behind every access unit
   const int hash_sei = (int)opt.geti("SEIDecodedPictureHash", 0);
-  if (hash_sei != 0 && hash_sei != 1) opt.errors.push_back("SEIDecodedPictureHash = " + std::to_string(hash_sei) + " is not implemented by this path (only 0 and 1 = MD5)");
+  if (hash_sei < 0 || hash_sei > 3) opt.errors.push_back("SEIDecodedPictureHash = " + std::to_string(hash_sei) + " is not a hash of the reference (0 none, 1 MD5, 2 CRC, 3 checksum)");
   // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows or explicit sizes; LFCrossTileBoundaryFlag (default 1) lets the in-loop filters cross tile borders
   const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
   const int tile_uniform = (int)opt.geti("TileUniformSpacing", 0) != 0;
@@ -457,13 +457,13 @@ int main(int argc, char **argv)
             if (po.st != HEVCDL_OK) continue;
             po.bytes.assign(buf.begin(), buf.begin() + po.au_len);
             if (hash_sei) { // suffix SEI after the slice; not part of the picture's bit count (as in the reference)
-              uint8_t sei[128], dg[48]; size_t sei_len = 0;
-              po.st = hevcdl_picture_md5(&scfg, recon + frame_bytes * (size_t)i, dg);
-              if (po.st == HEVCDL_OK) po.st = hevcdl_write_digest_sei(dg, sei, sizeof sei, &sei_len);
+              uint8_t sei[128], dg[48]; size_t sei_len = 0; int pb = 16;
+              po.st = hevcdl_picture_hash(&scfg, recon + frame_bytes * (size_t)i, hash_sei, dg, &pb);
+              if (po.st == HEVCDL_OK) po.st = hevcdl_write_hash_sei(hash_sei, dg, sei, sizeof sei, &sei_len);
               if (po.st != HEVCDL_OK) continue;
               po.bytes.insert(po.bytes.end(), sei, sei + sei_len);
-              char *q = po.md5_text + sprintf(po.md5_text, " [MD5:");
-              for (int c = 0; c < 3; c++) { for (int k = 0; k < 16; k++) q += sprintf(q, "%02x", dg[16 * c + k]); *q++ = c < 2 ? ',' : ']'; }
+              char *q = po.md5_text + sprintf(po.md5_text, " [%s:", hash_sei == 1 ? "MD5" : (hash_sei == 2 ? "CRC" : "Checksum"));          // TEncGOP.cpp:1160-1182
+              for (int c = 0; c < 3; c++) { for (int k = 0; k < pb; k++) q += sprintf(q, "%02x", dg[pb * c + k]); *q++ = c < 2 ? ',' : ']'; }
               *q = 0;
             }
           }

@@ -557,6 +557,56 @@ extern "C" hevcdl_status hevcdl_write_digest_sei(const uint8_t digest[48], uint8
   return HEVCDL_OK;
 }
 
+extern "C" hevcdl_status hevcdl_picture_hash(const hevcdl_stream_config *cfg, const void *picture, int method, uint8_t digest[48], int *plane_bytes)
+{ // calcMD5 / calcCRC / calcChecksum TComPicYuvMD5.cpp:88-180: one digest per colour plane
+  if (method == 1) { if (plane_bytes) *plane_bytes = 16; return hevcdl_picture_md5(cfg, picture, digest); }
+  if (!cfg || cfg->struct_size != sizeof *cfg || !picture || !digest) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7)) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return HEVCDL_ERR_UNSUPPORTED;
+  if (method != 2 && method != 3) return HEVCDL_ERR_UNSUPPORTED;
+  const int wide = cfg->bit_depth > 8;
+  const size_t ysz = (size_t)cfg->width * cfg->height;
+  for (int c = 0; c < 3; c++) {
+    const int pw = c ? cfg->width / 2 : cfg->width, ph = c ? cfg->height / 2 : cfg->height;
+    const size_t off = c == 0 ? 0 : (c == 1 ? ysz : ysz + ysz / 4);
+    auto sample = [&](int x, int y) -> unsigned { const size_t i = off + (size_t)y * pw + x; return wide ? ((const uint16_t *)picture)[i] : ((const uint8_t *)picture)[i]; };
+    if (method == 2) { // CRC-16-CCITT over the bytes of the samples, most significant bit first, low byte first (:89-127)
+      unsigned crc = 0xffff;
+      auto feed = [&](unsigned byte) { for (int b = 0; b < 8; b++) { const unsigned msb = (crc >> 15) & 1, bit = (byte >> (7 - b)) & 1; crc = (((crc << 1) + bit) & 0xffff) ^ (msb * 0x1021); } };
+      for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) { const unsigned v = sample(x, y); feed(v & 0xff); if (wide) feed(v >> 8); }
+      for (int b = 0; b < 16; b++) { const unsigned msb = (crc >> 15) & 1; crc = ((crc << 1) & 0xffff) ^ (msb * 0x1021); }
+      digest[2 * c] = (uint8_t)(crc >> 8); digest[2 * c + 1] = (uint8_t)crc;
+    } else {           // checksum: sum of the bytes, each xor-ed with a mask of its position (:141-165)
+      uint32_t sum = 0;
+      for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
+        const unsigned v = sample(x, y), mask = ((unsigned)x & 0xff) ^ ((unsigned)y & 0xff) ^ ((unsigned)x >> 8) ^ ((unsigned)y >> 8);
+        sum += ((v & 0xff) ^ (mask & 0xff));
+        if (wide) sum += ((v >> 8) ^ (mask & 0xff));
+      }
+      for (int k = 0; k < 4; k++) digest[4 * c + k] = (uint8_t)(sum >> (24 - 8 * k));
+    }
+  }
+  if (plane_bytes) *plane_bytes = method == 2 ? 2 : 4;
+  return HEVCDL_OK;
+}
+
+extern "C" hevcdl_status hevcdl_write_hash_sei(int method, const uint8_t *digest, uint8_t *out, size_t capacity, size_t *out_len)
+{ // SEIwrite.cpp xWriteSEIDecodedPictureHash: hash_type u(8) = method - 1, then per plane 16 bytes (MD5) / u(16) (CRC) / u(32) (checksum)
+  if (method == 1) return hevcdl_write_digest_sei(digest, out, capacity, out_len);
+  if (!digest || !out || !out_len || (method != 2 && method != 3)) return HEVCDL_ERR_INVALID_ARG;
+  const int pb = method == 2 ? 2 : 4;
+  BitOut w;
+  w.write(132, 8); w.write(1 + 3 * pb, 8); w.write((uint32_t)(method - 1), 8);
+  for (int i = 0; i < 3 * pb; i++) w.write(digest[i], 8);
+  w.trailing();
+  std::vector<uint8_t> nal;
+  put_nal(nal, 40, w.b, false);
+  *out_len = nal.size();
+  if (nal.size() > capacity) return HEVCDL_ERR_INVALID_ARG;
+  memcpy(out, nal.data(), nal.size());
+  return HEVCDL_OK;
+}
+
 extern "C" hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, const void *picture, uint8_t *out, size_t capacity, size_t *out_len)
 { // the digests of `picture`, then the SEI above
   if (!cfg || cfg->struct_size != sizeof *cfg || !picture || !out || !out_len) return HEVCDL_ERR_INVALID_ARG;

@@ -261,6 +261,10 @@ hevcdl_status hevcdl_write_picture_hash_sei(const hevcdl_stream_config *cfg, con
 hevcdl_status hevcdl_picture_md5(const hevcdl_stream_config *cfg, const void *picture, uint8_t digest[48]);
 /* The same SEI NAL from digests already computed by hevcdl_picture_md5 (an application that also prints them hashes the picture once). */
 hevcdl_status hevcdl_write_digest_sei(const uint8_t digest[48], uint8_t *out, size_t capacity, size_t *out_len);
+/* The other two hashes of the key (SEIDecodedPictureHash 2 = CRC, 3 = checksum; 1 = MD5 as above): hevcdl_picture_hash leaves the plane digests of `method` side by side in
+ * `digest` (16 / 2 / 4 bytes a plane: *plane_bytes; TComPicYuvMD5.cpp:88-180), hevcdl_write_hash_sei writes the SEI (hash_type = method - 1, SEIwrite.cpp). */
+hevcdl_status hevcdl_picture_hash(const hevcdl_stream_config *cfg, const void *picture, int method, uint8_t digest[48], int *plane_bytes);
+hevcdl_status hevcdl_write_hash_sei(int method, const uint8_t *digest, uint8_t *out, size_t capacity, size_t *out_len);
 
 /* ---- per-CTU session: the semantic drop-in for the reference's call pair ------------------------
  *   TEncCu::compressCtu(Int m_iFrame, TComDataCU* pCtu)   TEncCu.h:120, called at TEncSlice.cpp:879

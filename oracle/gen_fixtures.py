@@ -204,6 +204,14 @@ def gen_rd_lf():
         dump, _, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=args + ["--SAO=0", "--SEIDecodedPictureHash=0"])
         out["bitstream_" + key] = np.frombuffer(bitstream, np.uint8); out["recon_" + key] = np.frombuffer(recon, np.uint8)
     dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+    # SEIDecodedPictureHash 2 (CRC) / 3 (checksum), 8- and 10-bit samples
+    for key, args, bd in (("crc", ["--SEIDecodedPictureHash=2"], 8), ("sum", ["--SEIDecodedPictureHash=3"], 8), ("crc10", ["--SEIDecodedPictureHash=2"], 10), ("sum10", ["--SEIDecodedPictureHash=3"], 10)):
+        y = yuv if bd == 8 else yuv.astype(np.uint16) * 4 + 1
+        d2, o2, bitstream, recon = rt.run_reference(y, w, h, qp, lab, extra_args=args + ["--SAO=0"], bit_depth=bd)
+        d2 = d2[np.lexsort((d2["addr"], d2["frame"]))]
+        out["bitstream_" + key] = np.frombuffer(bitstream, np.uint8); out["recon_" + key] = np.frombuffer(recon, np.uint8)
+        out["summary_" + key] = np.array([ln for ln in o2.splitlines() if ln.startswith("POC")])
+        if bd == 10: out["records10"] = d2["rec"].reshape(nf, lab.shape[1]); out["yuv10"] = y
     np.savez_compressed(os.path.join(GOLD, "stream_c192_q32.npz"), width=w, height=h, qp=qp, yuv=yuv, labels=lab, records=dump["rec"].reshape(nf, lab.shape[1]), **out)
     print("stream-switch fixture stream_c192_q32")
 

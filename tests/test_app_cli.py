@@ -69,7 +69,7 @@ def test_keys_that_change_the_path_are_rejected(app, tmp_path):
     write_cfgs(tmp_path)
     for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--ScalingList=1"], "ScalingList"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
                           (["--WaveFrontSynchro=1"], "WaveFrontSynchro"), (["--NumTileColumnsMinus1=1", "--TileColumnWidthArray="], "TileColumnWidthArray"),
-                          (["--SEIDecodedPictureHash=2"], "SEIDecodedPictureHash")):
+                          (["--SEIDecodedPictureHash=4"], "SEIDecodedPictureHash")):
         r = run(app, ["-c", "main.cfg", "-c", "seq.cfg"] + extra + ["--PrintConfig"], tmp_path)
         assert r.returncode == 2 and needle in " ".join(json.loads(r.stdout)["errors"])
     r = run(app, ["-c", "missing.cfg"], tmp_path)
@@ -250,3 +250,11 @@ def test_cli_stream_switches_reproduce_the_reference_run(app, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "str.bin").read_bytes() == f["bitstream_both"].tobytes()
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_both"])
+    # SEIDecodedPictureHash 2 (CRC) / 3 (checksum): the SEI in the stream and the digests behind the picture lines, as the reference prints them
+    import re
+    for key, method in (("crc", 2), ("sum", 3)):
+        r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "s%d.bin" % method, "--LabelDir=pred", "--Level=6.2", "--SAO=0", "--SEIDecodedPictureHash=%d" % method], tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert (tmp_path / ("s%d.bin" % method)).read_bytes() == f["bitstream_" + key].tobytes()
+        tag = lambda text: re.findall(r"\[(?:CRC|Checksum):[0-9a-f,]+\]", text)
+        assert tag(r.stdout) == tag("\n".join(str(l) for l in f["summary_" + key])) and len(tag(r.stdout)) == nf

@@ -158,3 +158,15 @@ def test_stream_switches_of_the_cfg():
     assert stream(rewrite_param_sets=False) == f["bitstream_ps0"].tobytes() == f["bitstream_both"].tobytes()
     assert stream() == f["bitstream_ls0"].tobytes()
     assert len(f["bitstream_ps0"]) < len(f["bitstream_ls0"])
+
+
+@pytest.mark.parametrize("key,method,bd", [("crc", 2, 8), ("sum", 3, 8), ("crc10", 2, 10), ("sum10", 3, 10)])
+def test_crc_and_checksum_picture_hashes_match_the_reference(key, method, bd):
+    """SEIDecodedPictureHash 2 / 3: access units + the hash SEI of the reference's final pictures == the reference's streams (8- and 10-bit samples)."""
+    import hevcdl_amd
+    f = np.load(os.path.join(GOLD, "stream_c192_q32.npz"))
+    w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["records"].shape[0]
+    recs = np.frombuffer((f["records"] if bd == 8 else f["records10"]).tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
+    pics = np.frombuffer(f["recon_" + key].tobytes(), np.uint8 if bd == 8 else "<u2").reshape(nf, w * h * 3 // 2)
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], bit_depth=bd) + hevcdl_amd.picture_hash_sei(w, h, pics[poc], bd, method) for poc in range(nf))
+    assert ours == f["bitstream_" + key].tobytes()
