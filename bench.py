@@ -263,6 +263,25 @@ def measured_traffic(n_ctus):
     return (tj["fetch_bytes_per_ctu"] + tj["write_bytes_per_ctu"]) * n_ctus, tj["source"] + "; " + tj["note"]
 
 
+def measured_issue(frames, ctus_per_s):
+    """The instruction-issue bound of the decision kernel on a launch of `frames` frames (profiles/r*_issue.json, tools/issue_json.py: SQ counter passes of THIS
+    kernel source, keyed by the sha of rd_kernel.hip like `traffic`) with `frac` = the decision kernel's measured CTUs/s of this run against the ceiling; None
+    when no committed pass was taken on this source or on this launch shape."""
+    import glob
+    sha = hashlib.sha256(open(RD_KERNEL_SRC, "rb").read()).hexdigest()[:16]
+    for ipath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue.json")), reverse=True):
+        cand = json.load(open(ipath))
+        sh = cand.get("shapes", {}).get(str(frames))
+        if cand.get("rd_kernel_sha16") == sha and sh:
+            out = {k: sh[k] for k in ("valu_per_ctu", "salu_per_ctu", "lds_per_ctu", "lanes_enabled", "ceiling_ctus_per_s")}
+            out.update({"frames_per_launch": frames, "unit": "CTUs/s", "achieved": ctus_per_s, "frac": ctus_per_s / sh["ceiling_ctus_per_s"], "frac_under_counters": sh.get("frac_under_counters"),
+                        "model": cand["model"], "source": os.path.relpath(ipath, ROOT) + " <- " + cand["source"],
+                        "note": "valu / salu / lds = wave-instructions per CTU (SQ_INSTS_*), lanes_enabled = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64); achieved = the decision "
+                                "kernel alone (HIP events of this run), the ceiling is the VALU issue time of today's instruction count on every SIMD of the chip"})
+            return out
+    return {"frames_per_launch": frames, "frac": None, "note": "no committed counter pass (profiles/r*_issue.json) was taken on this build of rd_kernel.hip (%s) for a %d-frame launch: not reported" % (sha, frames)}
+
+
 def timed_steps(torch, enc, tensors, n_frames, steps, warmup, barrier):
     yuv, labels, records, recon, stats = tensors
     stream = torch.cuda.current_stream()
@@ -378,6 +397,7 @@ def main():
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--frames", type=int, default=600, help="frames of the job (C4: 600), split over the ranks")
     ap.add_argument("--saturated-frames", type=int, default=2560, help="extra single-GPU measurement with this many frames in flight (0: skip); 2560 = one frame per wave of the ten-wave build on 256 CUs")
+    ap.add_argument("--weak-frames", type=int, default=600, help="N > 1: every rank also runs one step over this many frames of its own (weak scaling beside the strong headline); 0: skip")
     ap.add_argument("--no-projection", action="store_true", help="skip the 300 / 150 / 75-frame launches behind scale_projection / share_8gpu_s")
     ap.add_argument("--no-label-check", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
@@ -454,6 +474,25 @@ def main():
     else:
         total_bits = int(stt.sum().item())
 
+    # Weak scaling beside the strong one (N > 1 only; outside the timed steps): the natural shard of this path is by frame, and 600 / N frames per GPU measures one
+    # frame's latency rather than the machine -- so every rank also runs the WHOLE 600-frame shape on frames of its own (1 warm-up + 1 timed step between barriers,
+    # max over ranks): value = N x 600 frames' CTUs / that time.
+    weak = None
+    if world > 1 and a.weak_frames > 0:
+        Fw = a.weak_frames
+        ew = hevcdl_amd.Encoder(W, H, qp, max_frames=Fw, device=local)
+        yw = synth_frames_torch(torch, dev, W, H, [rank * Fw + i for i in range(Fw)], seed=1000)
+        tw = alloc(torch, hevcdl_amd, dev, Fw, ew.frame_bytes, ctus)
+        elw, prw = timed_steps(torch, ew, (yw,) + tw, Fw, 1, 1, barrier)
+        tmax = torch.tensor([elw], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        weak = {"scaling": "weak", "frames_per_gpu": Fw, "n_gpus": world, "seconds": float(tmax.item()), "value": world * Fw * ctus / float(tmax.item()), "unit": "CTUs/s",
+                "kernel_ms_rank0": prw["rd_ms"], "launch": ew.last_rd_launch(),
+                "note": "every rank runs a full %d-frame step on frames of its own (1 warm-up, 1 timed step between barriers, max over ranks); no data-path collective" % Fw}
+        del yw, tw
+        ew.close()
+        torch.cuda.empty_cache()
+
     if rank == 0:
         total_ctus = F * ctus * a.steps
         value = total_ctus / elapsed
@@ -476,6 +515,8 @@ def main():
             "est_bits_per_frame": total_bits / max(1, F),
             "rccl_ranks": ranks_seen, "collective_backend": backend if world > 1 else "none (one rank)", "frames_gathered": F if world == 1 else int(sum(int((g != 0).sum().item()) for g in gathered)),
         }
+        if rd_avg_s > 0:      # the bound that can steer this kernel: vector-ALU issue (the HBM fraction is ~1e-3 by construction)
+            out["roofline"]["issue"] = measured_issue(Fr, Fr * ctus / rd_avg_s)
         cnn_s = (prof["cnn_conv_ms"] / max(1, prof["cnn_launches"])) / 1e3 if "cnn_conv_ms" in prof else 0.0
         if cnn_s > 0:    # the other stage, the other bound: the convolution kernel against the dense f16 MFMA peak
             ex = 2.0 * CNN_CONV_MACS_EXECUTED * Fr * ctus / cnn_s / 1e12
@@ -508,10 +549,16 @@ def main():
                                        "note": "seconds of one step over a rank's share of the 600 frames (600 / 300 / 150 / 75 frames) on this GPU: one warm-up launch per share, then the median of three; "
                                                "N-GPU value = 1 224 000 CTUs / that time"}
             out["share_8gpu_s"] = proj[8]
+            # the weak-scaling counterpart: %d frames PER GPU is this run's own step on every GPU at once (frames are independent, nothing is exchanged but 8 bytes
+            # per frame at the end), so N GPUs process N x the job in the same time -- a projection by construction; `bench.py --gpus N` measures it (key "weak")
+            out["scale_projection_weak"] = {"frames_per_gpu": F, "seconds": elapsed / a.steps, "value": {str(n): n * F * ctus / (elapsed / a.steps) for n in (1, 2, 4, 8)}, "unit": "CTUs/s",
+                                            "note": "weak scaling: every GPU runs this run's own %d-frame step on frames of its own; measured by `bench.py --gpus N` as key \"weak\"" % F}
             # (the shares' records / reconstruction equal what the whole job wrote for those frames: frames are independent, the kernel deterministic -- re-run the job's step so that
             #  the legs below see the state of the timed job)
             enc.encode_frames_dev(yuv.data_ptr(), Fr, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)
             torch.cuda.synchronize(dev)
+        if weak is not None:
+            out["weak"] = weak
         if floor_s:
             out["latency_floor_s"] = floor_s
             out["strong_scaling_ceiling"] = {"value": F * ctus / floor_s, "unit": "CTUs/s",
@@ -558,6 +605,7 @@ def main():
                 el2, pr2 = timed_steps(torch, e2, (y2,) + t2, S, 1, 0, barrier)
                 out["saturated"] = {"frames_per_gpu": S, "value": S * ctus / el2, "unit": "CTUs/s", "ms_per_step": 1e3 * el2, "kernel_ms": pr2["rd_ms"], "cnn_kernel_ms": pr2["cnn_ms"],
                                     "per_cu": S * ctus / el2 / torch.cuda.get_device_properties(dev).multi_processor_count,
+                                    "issue": measured_issue(S, S * ctus / (pr2["rd_ms"] / 1e3)) if pr2["rd_ms"] > 0 else None,
                                     "note": "one step, %d distinct frames repeated; a frame per wave of the ten-wave build of the decision kernel (csrc/rd_kernel_wide.hip); not the "
                                             "headline: the job of BASELINE.json has 600 frames" % min(S, 64)}
                 del y2, t2

@@ -127,6 +127,15 @@ def build_ext(force=False, verbose=False, defines=(), out=None, extra_flags=(), 
     variant = os.path.splitext(os.path.basename(out))[0] + "-" + hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
     odir = os.path.join(PKG_DIR, "build", variant)
     os.makedirs(odir, exist_ok=True)
+    # a library newer than every source and every header a source includes is current, whether or not its objects are here (build/ does not travel to the
+    # GPU box, the built lib/*.so does: without this a fresh box would recompile every translation unit, or fail where hipcc is absent)
+    deps = set()
+    for src in srcs:
+        _includes(src, deps)
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        tag = out + ".flags"
+        if not os.path.exists(tag) or open(tag).read() == variant:
+            return out
     objs, stale = [], []
     for src in srcs:
         obj = os.path.join(odir, os.path.splitext(os.path.basename(src))[0] + ".o")
@@ -145,6 +154,8 @@ def build_ext(force=False, verbose=False, defines=(), out=None, extra_flags=(), 
     with ThreadPoolExecutor(max_workers=jobs or min(len(stale), os.cpu_count() or 1) or 1) as pool:
         list(pool.map(compile_one, stale))
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out], check=True)
+    with open(out + ".flags", "w") as f:       # which flag set built `out` (the fast path above must not take a library of other -D's for this one)
+        f.write(variant)
     return out
 
 

@@ -687,7 +687,8 @@ extern "C" hevcdl_status hevcdl_reserve_workspace(hevcdl_ctx *ctx)
   const long long max_units = (long long)ctx->cfg.max_frames * ctx->cfg.tile_columns * ctx->cfg.tile_rows;
   const int groups = std::max(ctx->rd_groups, ctx->remote_groups);
   int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : hevcdl_rd_waves_per_group();
-  if (ctx->cfg.bit_depth == 8 && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW) && ((ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || max_units >= 3LL * ctx->rd_groups))
+  const bool rt_tools = ctx->cfg.bit_depth == 8 && ctx->cfg.tools != HEVCDL_TOOLS_REFERENCE;      // launch_rd's rule: such a context never runs the ten-wave build
+  if (ctx->cfg.bit_depth == 8 && !rt_tools && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW) && ((ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || max_units >= 3LL * ctx->rd_groups))
     waves = std::max(waves, hevcdl_rd_waves_per_group_wide());
   const size_t need = ctx->scratch_per_wave * (size_t)groups * (size_t)waves;
   if (need <= ctx->scratch_bytes) return HEVCDL_OK;

@@ -237,6 +237,10 @@ int main(int argc, char **argv)
     if (prof != (bit_depth == 8 ? "main" : "main10")) opt.errors.push_back("Profile = " + prof + " is not implemented by this path (main at 8 bits, main10 at 10 bits)"); }
   // decoded picture hash SEI (TAppEncCfg.cpp:1093): 0 none, 1 MD5 of the output picture behind every access unit
   const int hash_sei = (int)opt.geti("SEIDecodedPictureHash", 0);
+  for (const char *key : { "LoopFilterBetaOffset_div2", "LoopFilterTcOffset_div2" }) {      // the reference's own range check (TAppEncCfg.cpp xConfirmPara: -6 .. 6)
+    const long v = opt.geti(key, 0);
+    if (v < -6 || v > 6) opt.errors.push_back(std::string(key) + " = " + std::to_string(v) + " is out of range (-6 .. 6)");
+  }
   if (hash_sei < 0 || hash_sei > 3) opt.errors.push_back("SEIDecodedPictureHash = " + std::to_string(hash_sei) + " is not a hash of the reference (0 none, 1 MD5, 2 CRC, 3 checksum)");
   // tiles (TAppEncCfg.cpp:1024-1028): uniformly spaced columns x rows or explicit sizes; LFCrossTileBoundaryFlag (default 1) lets the in-loop filters cross tile borders
   const int tile_cols = (int)opt.geti("NumTileColumnsMinus1", 0) + 1, tile_rows = (int)opt.geti("NumTileRowsMinus1", 0) + 1;
@@ -358,7 +362,18 @@ int main(int argc, char **argv)
       cfg.max_frames = batch; cfg.device = shards[i].dev;
       st = hevcdl_create(&cfg, weights.data(), weights.size(), &shards[i].ctx);
       // the decision kernel's workspace (up to 4.3 GB) is otherwise allocated by the first launch: reserved here, a lack of memory is met by the retry below
-      if (st == HEVCDL_OK && (st = hevcdl_reserve_workspace(shards[i].ctx)) != HEVCDL_OK) { hevcdl_destroy(shards[i].ctx); shards[i].ctx = nullptr; }
+      bool ws_oom = false;
+      if (st == HEVCDL_OK && (st = hevcdl_reserve_workspace(shards[i].ctx)) != HEVCDL_OK) { ws_oom = st == HEVCDL_ERR_OOM; hevcdl_destroy(shards[i].ctx); shards[i].ctx = nullptr; }
+      if (st == HEVCDL_ERR_OOM && ws_oom) {
+        // the workspace is sized by the device's CUs, not by the batch: a smaller batch does not shrink it.  What does: the independent launch form (a block per wave of
+        // the context's own frames instead of every CU's workgroup), then the eight-wave build
+        if (!(cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER)) cfg.exec_flags |= HEVCDL_EXEC_NO_UNIT_HANDOVER;
+        else if (!(cfg.exec_flags & HEVCDL_EXEC_RD_NARROW)) cfg.exec_flags = (cfg.exec_flags & ~HEVCDL_EXEC_RD_WIDE) | HEVCDL_EXEC_RD_NARROW;
+        else { fprintf(stderr, "Error: device %d has no memory for the decision kernel's workspace (1.6 MB per wave of a launch) even in the independent launch form\n", shards[i].dev); return 3; }
+        fprintf(stderr, "device %d: not enough memory for the decision kernel's workspace, retrying with exec_flags %d\n", shards[i].dev, (int)cfg.exec_flags);
+        for (int j = 0; j < i; j++) { hevcdl_destroy(shards[j].ctx); shards[j].ctx = nullptr; }
+        i = -1; break;
+      }
       if (st != HEVCDL_ERR_OOM || batch == 1) break;
       batch = (batch + 1) / 2;
       fprintf(stderr, "device %d: not enough memory for the batch, retrying with %d pictures per call\n", shards[i].dev, batch);
@@ -366,7 +381,7 @@ int main(int argc, char **argv)
       i = -1; break;
     }
     if (i < 0) continue;
-    if (st == HEVCDL_ERR_INVALID_ARG) { fprintf(stderr, "Error: invalid configuration (tiles must be at least 4 CTUs wide and 1 CTU high)\n"); return 2; }
+    if (st == HEVCDL_ERR_INVALID_ARG) { fprintf(stderr, "Error: hevcdl_create rejected the configuration as invalid (e.g. tiles narrower than 4 CTUs or lower than 1 CTU, TComPicSym.cpp:380-392)\n"); return 2; }
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: hevcdl_create failed on device %d with status %d (no GPU / unsupported configuration); there is no CPU path\n", shards[i].dev, (int)st); return 3; }
   }
   const int chunk = (int)std::max<long>(1, std::min<long>(batch, opt.geti("ChunkFrames", 48)));

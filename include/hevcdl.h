@@ -96,7 +96,8 @@ typedef struct hevcdl_config {
 #define HEVCDL_EXEC_NO_UNIT_HANDOVER 1
   /* The 8-bit decision kernel exists in two builds: 8 wavefronts per workgroup with the look-ahead of the few-units form, and 10 (csrc/rd_kernel_wide.hip) for
    * launches of three or more units per workgroup; the library picks by the shape of the launch.  HEVCDL_EXEC_RD_WIDE forces the second for every launch of the context (the few-units form is then
-   * never used), HEVCDL_EXEC_RD_NARROW the first.  Results do not depend on the choice. */
+   * never used), HEVCDL_EXEC_RD_NARROW the first.  Results do not depend on the choice.  Contexts whose `tools` are not the reference cfg's and 10-bit contexts have
+   * one build each (eight waves): both bits are without effect there. */
 #define HEVCDL_EXEC_RD_WIDE 2
 #define HEVCDL_EXEC_RD_NARROW 4
   /* TileUniformSpacing 0: explicit sizes in CTUs of every tile column / row but the last (TileColumnWidthArray, TileRowHeightArray,
@@ -318,9 +319,8 @@ hevcdl_status hevcdl_compress_tiles_dev(hevcdl_ctx *ctx, const void *d_yuv, int 
 hevcdl_status hevcdl_encode_frames_dev(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, void *d_labels,
                                        void *d_records, void *d_recon, void *d_stats, void *stream);
 
-/* kernel timing with HIP events recorded on the launch stream */
 /* Which build of the decision kernel and which launch form the context's last decision launch took, as text:
- * "hevcdl_rd_frame_kernel[_wide|_bd10] form=independent|unit-handover|few-units(...) workgroups=N waves=N units=N" ("" before the first launch).  The selection
+ * "hevcdl_rd_frame_kernel[_wide|_tools|_bd10] form=independent|unit-handover|few-units(...) workgroups=N waves=N units=N" ("" before the first launch).  The selection
  * rule lives in one place (launch_rd); bench.py reports this instead of restating the rule. */
 const char   *hevcdl_last_rd_launch(const hevcdl_ctx *ctx);
 /* The decision kernel's workspace is allocated by the first launch that needs it (megabytes for a frame in the independent form, 3.4 - 4.3 GB for a launch on every
@@ -328,6 +328,7 @@ const char   *hevcdl_last_rd_launch(const hevcdl_ctx *ctx);
  * allocates the largest workspace any launch of the context (1 .. max_frames frames) can ask for, so that a lack of memory shows up here -- the CLI calls it right
  * behind hevcdl_create and retries with a smaller batch -- and no later launch allocates or synchronises. */
 hevcdl_status hevcdl_reserve_workspace(hevcdl_ctx *ctx);
+/* kernel timing with HIP events recorded on the launch stream */
 hevcdl_status hevcdl_profile_enable(hevcdl_ctx *ctx, int enable);
 hevcdl_status hevcdl_profile_get(hevcdl_ctx *ctx, hevcdl_profile *out);   /* synchronises, returns and resets */
 

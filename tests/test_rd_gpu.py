@@ -66,7 +66,7 @@ def test_workspace_reserved_up_front_changes_nothing_and_names_the_launch():
 
 
 @pytest.mark.parametrize("flags", [2, 4], ids=["ten-wave-build", "eight-wave-build"])
-@pytest.mark.parametrize("path", [p for p in sorted(glob.glob(os.path.join(GOLD, "rd_*.npz"))) if not os.path.basename(p).startswith("rd_x") and "_b10" not in os.path.basename(p)], ids=lambda p: os.path.basename(p)[3:-4])
+@pytest.mark.parametrize("path", [p for p in sorted(glob.glob(os.path.join(GOLD, "rd_*.npz"))) if not os.path.basename(p).startswith(("rd_x", "rd_k")) and "_b10" not in os.path.basename(p)], ids=lambda p: os.path.basename(p)[3:-4])
 def test_golden_records_bit_exact_on_either_build_of_the_kernel(path, flags):
     """The 8-bit decision kernel exists in two builds (8 wavefronts per workgroup with the look-ahead of the few-units form; 10 without it, csrc/rd_kernel_wide.hip) and the
     library picks by the shape of the launch -- small fixtures would only ever meet one of them.  exec_flags HEVCDL_EXEC_RD_WIDE (2) / HEVCDL_EXEC_RD_NARROW (4) force a build:
@@ -229,7 +229,7 @@ def test_bench_two_ranks_on_one_gpu_give_the_single_rank_line(tmp_path):
     import subprocess
     import sys
     root = os.path.join(os.path.dirname(GOLD), "..")
-    common = ["--steps", "1", "--warmup", "0", "--width", "256", "--height", "192", "--frames", "6", "--no-cpu-baseline", "--no-c2", "--no-e2e", "--saturated-frames", "0"]
+    common = ["--steps", "1", "--warmup", "0", "--width", "256", "--height", "192", "--frames", "6", "--no-cpu-baseline", "--no-c2", "--no-e2e", "--saturated-frames", "0", "--weak-frames", "4"]
     env = dict(os.environ, HEVCDL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r1.returncode == 0, r1.stdout[-1500:] + r1.stderr[-1500:]
@@ -244,6 +244,9 @@ def test_bench_two_ranks_on_one_gpu_give_the_single_rank_line(tmp_path):
     # the collective spans both ranks (every rank adds one in an all-reduce: the driver's SCALE record can be checked by this key) and every frame's record arrived
     assert two["rccl_ranks"] == 2 and one["rccl_ranks"] == 1 and two["frames_gathered"] == 6 and two["collective_backend"] == "gloo"
     assert one["roofline"]["launch"].startswith(one["roofline"]["kernel"] + " form=") and "units=6" in one["roofline"]["launch"] and "units=3" in two["roofline"]["launch"]
+    # weak scaling beside the strong headline: every rank ran a 4-frame step of its own (N > 1 only)
+    assert "weak" not in one and two["weak"]["n_gpus"] == 2 and two["weak"]["frames_per_gpu"] == 4 and two["weak"]["value"] > 0 and "units=4" in two["weak"]["launch"]
+    assert "issue" in one["roofline"]                            # the instruction-issue bound (None unless a counter pass of this kernel source and launch shape is committed)
     for line in (one, two):
         assert line["value"] > 0 and line["latency_floor_s"] > 0 and line["strong_scaling_ceiling"]["value"] > 0 and "roofline" in line
 

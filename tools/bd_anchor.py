@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--procs", type=int, default=0)
     ap.add_argument("--no-device", action="store_true", help="CPU curves only (labels: numpy CNN oracle)")
     ap.add_argument("--seed", type=int, default=3000)
+    ap.add_argument("--reuse", default="", help="a previous result file of the same --frames / --size / --seed: its anchor and label_path curves (runs of the reference encoder on the host: they do not "
+                                               "depend on this project's kernels) are taken over, only the device path is run again and compared with them")
     a = ap.parse_args()
     w, h = [int(v) for v in a.size.split("x")]
     nf = a.frames
@@ -88,6 +90,14 @@ def main():
         labels_by_qp = {}
     res = {"width": w, "height": h, "frames": nf, "qps": list(QPS), "content": "synthetic (bench.synth_frames_torch / ref_tools.synth_yuv, seed %d)" % a.seed,
            "cpu_procs": procs, "curves": {"anchor": [], "label_path": [], "device": []}}
+    import hashlib
+    res["rd_kernel_sha16"] = hashlib.sha256(open(os.path.join(ROOT, "hevc-deep-learning-pipeline_amd", "csrc", "rd_kernel.hip"), "rb").read()).hexdigest()[:16]
+    reuse = None
+    if a.reuse:
+        reuse = json.load(open(a.reuse))
+        if (reuse["width"], reuse["height"], reuse["frames"], reuse["content"]) != (w, h, nf, res["content"]):
+            raise SystemExit("--reuse: %s was made with another size / frame count / seed" % a.reuse)
+        res["cpu_curves_from"] = "%s (reference-encoder runs of kernel sha %s's session)" % (os.path.basename(a.reuse), reuse.get("rd_kernel_sha16", "?"))
     base = tempfile.mkdtemp(prefix="hevcdl_bd_")
     try:
         for qp in QPS:
@@ -111,6 +121,12 @@ def main():
                 labels_by_qp[qp] = labels
             labels = labels_by_qp[qp]
             for name, binary in (("label_path", REF), ("anchor", ANCHOR)):
+                if reuse is not None:
+                    c = next(c for c in reuse["curves"][name] if c["qp"] == qp)
+                    if name == "label_path" and not a.no_device and reuse.get("depth_hist", {}).get(str(qp)) not in (None, res["curves"]["device"][-1]["depth_hist"]):
+                        raise SystemExit("--reuse: the labels of QP %d differ from those the reused label-path runs were made with" % qp)
+                    res["curves"][name].append(c)
+                    continue
                 t0 = time.time()
                 with ThreadPoolExecutor(max_workers=procs) as pool:
                     runs = list(pool.map(lambda i: run_encoder(binary, yuv[i], labels[i], w, h, qp, base, "%s%d_%d" % (name, qp, i)), range(nf)))
@@ -129,6 +145,8 @@ def main():
         an = res["curves"]["anchor"]
         return {"bd_rate_percent": metrics.bd_rate([p["kbps"] for p in an], [p["psnr_y"] for p in an], [p["kbps"] for p in test], [p["psnr_y"] for p in test]),
                 "bd_psnr_db": metrics.bd_psnr([p["kbps"] for p in an], [p["psnr_y"] for p in an], [p["kbps"] for p in test], [p["psnr_y"] for p in test])}
+    if not a.no_device:
+        res["depth_hist"] = {str(c["qp"]): c["depth_hist"] for c in res["curves"]["device"]}
     res["label_path_vs_anchor"] = bd(res["curves"]["label_path"])
     if not a.no_device:
         res["device_vs_anchor"] = bd(res["curves"]["device"])
