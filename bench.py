@@ -120,7 +120,7 @@ def _band(fr, width, full_h, height):
     return np.concatenate([fr[:width * height], fr[ysz:ysz + (width // 2) * (height // 2)], fr[ysz + csz:ysz + csz + (width // 2) * (height // 2)]])
 
 
-def run_reference_pictures(pictures, labels, width, height, qp, procs, dump=False, workers=None):
+def run_reference_pictures(pictures, labels, width, height, qp, procs, dump=False, workers=None, wavefront=0):
     """P reference-encoder processes (oracle/_ref/TAppEncoder_ref; configuration = the reference's cfg as switches, oracle/ref_args.py), one
     picture each, started together; -> (wall seconds, per-process seconds, list of dump arrays or None)."""
     import shutil
@@ -132,7 +132,7 @@ def run_reference_pictures(pictures, labels, width, height, qp, procs, dump=Fals
     dumps = None
     try:
         dirs = [_prepare_ref_run((i, pictures[i], width, height, qp, labels[i:i + 1], base)) for i in range(procs)]
-        cmd = [REF_ENC, "-i", "in.yuv", "-b", "rec/str.bin", "-o", "rec/rec.yuv"] + ref_args.reference_args(width, height, 1, qp)
+        cmd = [REF_ENC, "-i", "in.yuv", "-b", "rec/str.bin", "-o", "rec/rec.yuv"] + ref_args.reference_args(width, height, 1, qp, wavefront=wavefront)
         t = time.time()
         with ThreadPoolExecutor(max_workers=workers or procs) as pool:
             per = list(pool.map(_run_ref, [(d, cmd, dump) for d in dirs]))

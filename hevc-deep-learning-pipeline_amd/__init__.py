@@ -59,7 +59,7 @@ class Config(ctypes.Structure):
                 ("sbh_rd_factor", ctypes.c_int64 * 2), ("qp_chroma", ctypes.c_int32),
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("exec_flags", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
-                ("lf_across_tiles", ctypes.c_int32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32)]
+                ("lf_across_tiles", ctypes.c_int32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32), ("wavefront", ctypes.c_int32)]
 
 
 def tile_layout(tiles, width, height):
@@ -90,7 +90,7 @@ class StreamConfig(ctypes.Structure):
                 ("tile_columns", ctypes.c_int32), ("tile_rows", ctypes.c_int32), ("bit_depth", ctypes.c_int32),
                 ("tile_uniform_spacing", ctypes.c_int32), ("tile_column_width", ctypes.c_int32 * 19), ("tile_row_height", ctypes.c_int32 * 21),
                 ("lf_across_tiles", ctypes.c_int32), ("tools", ctypes.c_uint32), ("lf_beta_offset_div2", ctypes.c_int32), ("lf_tc_offset_div2", ctypes.c_int32),
-                ("rewrite_param_sets", ctypes.c_int32)]
+                ("rewrite_param_sets", ctypes.c_int32), ("wavefront", ctypes.c_int32)]
 
 
 class Profile(ctypes.Structure):
@@ -281,11 +281,12 @@ def load_weights(path=WEIGHTS_PATH):
     return w
 
 
+EXEC_NO_UNIT_HANDOVER, EXEC_RD_WIDE, EXEC_RD_NARROW = 1, 2, 4      # HEVCDL_EXEC_* (hevcdl_config.exec_flags)
 TOOLS_REFERENCE = 0x7f
 TOOL_RDOQ, TOOL_RDOQTS, TOOL_TSKIP, TOOL_TSKIP_FAST, TOOL_SIGN_HIDE, TOOL_STRONG_INTRA, TOOL_FAST_UDI_MPM = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40      # HEVCDL_TOOL_* (include/hevcdl.h): each may be turned off
 
 
-def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE, lf_offsets=(0, 0)):
+def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE, lf_offsets=(0, 0), wavefront=False):
     lib = load_library()
     cfg = Config()
     st = lib.hevcdl_config_default_bd(ctypes.byref(cfg), width, height, qp, bit_depth)
@@ -297,11 +298,12 @@ def default_config(width, height, qp, max_frames=1, device=0, cnn_input=0, tiles
     cfg.lf_across_tiles = 1 if lf_across_tiles else 0                   # LFCrossTileBoundaryFlag
     cfg.tools = tools                          # cfg keys TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled
     cfg.lf_beta_offset_div2, cfg.lf_tc_offset_div2 = lf_offsets      # LoopFilterBetaOffset_div2, LoopFilterTcOffset_div2
+    cfg.wavefront = 1 if wavefront else 0      # WaveFrontSynchro: CTU rows start from the contexts behind the second CTU of the row above (and run as units of their own)
     return cfg
 
 
 def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, tools=TOOLS_REFERENCE, lf_offsets=(0, 0), lf_disable=False,
-                      rewrite_param_sets=True):
+                      rewrite_param_sets=True, wavefront=False):
     """Host-side bitstream writer (no GPU): VPS+SPS+PPS+slice NAL of one picture from its CTU records -> bytes."""
     lib = load_library()
     cfg = StreamConfig()
@@ -316,6 +318,7 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
     cfg.lf_beta_offset_div2, cfg.lf_tc_offset_div2 = lf_offsets
     cfg.loop_filter_disable = 1 if lf_disable else 0
     cfg.rewrite_param_sets = 1 if rewrite_param_sets else 0
+    cfg.wavefront = 1 if wavefront else 0      # a sub-stream per CTU row, entry points in the slice header
     sao_ptr = None
     if sao is not None:
         sao = np.ascontiguousarray(sao, SAO_DTYPE)
@@ -334,10 +337,10 @@ def write_access_unit(width, height, qp, poc, records, level_idc=186, sao=None, 
 class Encoder:
     """One context per device.  Frames are planar 8-bit 4:2:0, numpy [n_frames, w*h*3/2] uint8."""
 
-    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE, lf_offsets=(0, 0)):
+    def __init__(self, width, height, qp, max_frames=1, device=0, cnn_input=0, weights=None, cfg=None, tiles=(1, 1), bit_depth=8, lf_across_tiles=True, bn_mode=0, tools=TOOLS_REFERENCE, lf_offsets=(0, 0), wavefront=False):
         """bit_depth 10: every yuv / recon array of the decision path holds uint16 samples (frame_bytes counts bytes)."""
         self.lib = load_library()
-        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode, tools, lf_offsets)
+        self.cfg = cfg or default_config(width, height, qp, max_frames, device, cnn_input, tiles, bit_depth, lf_across_tiles, bn_mode, tools, lf_offsets, wavefront)
         self.bit_depth = self.cfg.bit_depth
         self.sample_dtype = np.uint8 if self.bit_depth == 8 else np.dtype("<u2")
         self.tiles = (self.cfg.tile_columns, self.cfg.tile_rows)

@@ -68,6 +68,7 @@ struct hevcdl_ctx {
   unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params, *d_sao_cand;
   unsigned char *d_wide;                 // 16-bit staging of hevcdl_*_planes with sample_bytes 2 on an 8-bit context   // SAO workspace
   int *d_flag;                   // device-side error flag of the label check
+  unsigned char *d_wpp;          // WaveFrontSynchro: [max_frames][ctus_y] 256 bytes (the contexts behind a row's second CTU, the row's finished-CTU count: rd_kernel.hip)
   unsigned char *d_sched;        // decision kernel: hand-over of units between workgroups (finished counter, per-workgroup unit counts, mailboxes)
   bool profile;
   std::vector<hipEvent_t> ev_cnn, ev_rd, ev_conv;       // start/stop pairs (ev_conv: the convolution kernel alone, one pair per chunk of CTUs)
@@ -251,6 +252,8 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
     if (hevcdl_tile_bounds(cx, cfg->tile_columns, cfg->tile_uniform_spacing, cfg->tile_column_width, tiled ? 4 : 1, cb) ||
         hevcdl_tile_bounds(cy, cfg->tile_rows, cfg->tile_uniform_spacing, cfg->tile_row_height, 1, rb)) return HEVCDL_ERR_INVALID_ARG;
   }
+  if (cfg->wavefront != 0 && cfg->wavefront != 1) return HEVCDL_ERR_INVALID_ARG;
+  if (cfg->wavefront && cfg->tile_columns * cfg->tile_rows > 1) return HEVCDL_ERR_UNSUPPORTED;      // as the reference (TAppEncCfg.cpp xCheckParameter: only the high-throughput profile has both)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return HEVCDL_ERR_NO_DEVICE;
   hevcdl_ctx *ctx = new (std::nothrow) hevcdl_ctx();
@@ -286,11 +289,13 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   pack_fc(weights + B_F3W, weights + B_F3B, 16, 64, pk.data() + HEVCDL_W_FC3);
   CK(hipMalloc(&ctx->d_flag, sizeof(int)));
   CK(hipMalloc(&ctx->d_sched, 8192 + 1024 * 192));
+  ctx->d_wpp = nullptr;
+  if (cfg->wavefront) CK(hipMalloc(&ctx->d_wpp, (size_t)256 * ctx->ctus_y * cfg->max_frames));
   if (cfg->bit_depth > 8) CK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(cfg->width, cfg->height) * (size_t)cfg->max_frames));    // the CNN stage's 8-bit copy
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
   ctx->scratch_per_wave = cfg->bit_depth == 8 ? std::max(std::max(hevcdl_rd_scratch_bytes(), hevcdl_rd_scratch_bytes_wide()), hevcdl_rd_scratch_bytes_tools()) : hevcdl_rd_scratch_bytes_bd10();
-  ctx->rd_groups = (int)std::min<long long>(ctx->n_cus, (long long)cfg->max_frames * cfg->tile_columns * cfg->tile_rows);
+  ctx->rd_groups = (int)std::min<long long>(ctx->n_cus, (long long)cfg->max_frames * (cfg->wavefront ? ctx->ctus_y : cfg->tile_columns * cfg->tile_rows));
   // (launches of few units run on every CU: the workgroups without a unit take second luma passes from the others, launch_rd -- they need a workspace too)
   ctx->remote_groups = (cfg->bit_depth == 8 && !(cfg->exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) && ctx->n_cus >= 8 && ctx->n_cus <= 1024) ? ctx->n_cus : 0;
   // (the workspace itself -- 1.6 MB per wave -- is sized by the launches: a context that only ever codes a frame or two in the independent form holds a few MB, not the
@@ -321,7 +326,7 @@ extern "C" void hevcdl_destroy(hevcdl_ctx *ctx)
   for (int i = 0; i < 2; i++) { if (ctx->h_chunk[i]) hipHostFree(ctx->h_chunk[i]); if (ctx->copy_ev[i]) hipEventDestroy(ctx->copy_ev[i]); }
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   hipFree(ctx->d_weights); hipFree(ctx->d_scratch); hipFree(ctx->d_yuv); hipFree(ctx->d_labels); hipFree(ctx->d_recon);
-  hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_sao_cand); hipFree(ctx->d_wide); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
+  hipFree(ctx->d_wpp); hipFree(ctx->d_records); hipFree(ctx->d_stats); hipFree(ctx->d_logits); hipFree(ctx->d_yuv8); hipFree(ctx->d_a3); hipFree(ctx->d_picture); hipFree(ctx->d_rgb); hipFree(ctx->d_cabac); hipFree(ctx->d_sao_stats); hipFree(ctx->d_sao_recon); hipFree(ctx->d_sao_params); hipFree(ctx->d_sao_cand); hipFree(ctx->d_wide); hipFree(ctx->d_flag); hipFree(ctx->d_sched);
   delete ctx;
 }
 
@@ -428,6 +433,14 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   p.tile_cols = ctx->cfg.tile_columns; p.tile_rows = ctx->cfg.tile_rows;
   memcpy(p.col_bd, ctx->col_bd, sizeof p.col_bd); memcpy(p.row_bd, ctx->row_bd, sizeof p.row_bd);
   p.tile_begin = tile_begin; p.tile_count = tile_count < 0 ? p.tile_cols * p.tile_rows : tile_count;
+  // WaveFrontSynchro: a unit is one CTU row of a frame (rows of a frame run two CTUs apart on different waves, which wait for each other: a cooperative launch), or -- where
+  // the grid cannot be co-resident, or the caller shares the device (HEVCDL_EXEC_NO_UNIT_HANDOVER) -- a whole frame whose rows one wave walks in order
+  const bool whole_launch = !d_cabac_in && !d_cabac_out && ctu_begin == 0 && p.ctu_end == ctx->ctus && tile_begin == 0 && tile_count < 0;
+  if (ctx->cfg.wavefront) {
+    if (!whole_launch) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "WaveFrontSynchro: only whole-frame launches (no per-CTU session, no tile range)");
+    p.wpp = (ctx->cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) ? 2 : 1; p.wpp_state = ctx->d_wpp; p.tile_count = p.wpp == 1 ? ctx->ctus_y : 1;
+    HIPCHK(hipMemsetAsync(ctx->d_wpp, 0, (size_t)256 * ctx->ctus_y * n_frames, s));
+  }
   if (d_stats) HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(hevcdl_frame_stats) * (size_t)n_frames, s));     // the tile waves of a frame add into its entry
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
   memcpy(p.k.err_scale, ctx->cfg.err_scale, sizeof p.k.err_scale);
@@ -449,7 +462,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // and every frame -- is crowded for the same share of the time (rd_kernel.hip, process_unit).  Only for whole-unit launches of a few units
   // per workgroup.
   p.sched = ctx->d_sched;
-  p.migrate = (n_units > groups && n_units % groups != 0 && n_units / groups <= 3 && groups <= 1024 && groups >= 8 && !d_cabac_in && !d_cabac_out &&
+  p.migrate = (!p.wpp && n_units > groups && n_units % groups != 0 && n_units / groups <= 3 && groups <= 1024 && groups >= 8 && !d_cabac_in && !d_cabac_out &&
                ctu_begin == 0 && p.ctu_end == ctx->ctus && !(ctx->cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER)) ? 1 : 0;
   if (p.migrate) {
     std::vector<int> init(16 + groups, 0);
@@ -496,11 +509,17 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
     p.scratch = ctx->d_scratch;
   }
   prof_begin(ctx, ctx->ev_rd, s);
-  if (p.migrate || p.remote) { // workgroups that wait for each other: a cooperative launch, which the runtime only accepts when the whole grid can be resident at once
+  bool launched = false;
+  if (p.migrate || p.remote || p.wpp == 1) { // workgroups that wait for each other: a cooperative launch, which the runtime only accepts when the whole grid can be resident at once
     void *args[] = { &p };
-    if (hipLaunchCooperativeKernel(kern, dim3(p.remote ? ctx->remote_groups : groups), dim3(threads), args, smem, s) != hipSuccess) { (void)hipGetLastError(); p.migrate = 0; p.remote = 0; }
+    if (hipLaunchCooperativeKernel(kern, dim3(p.remote ? ctx->remote_groups : groups), dim3(threads), args, smem, s) == hipSuccess) launched = true;
+    else {
+      (void)hipGetLastError(); p.migrate = 0; p.remote = 0;
+      if (p.wpp == 1) { prof_end(ctx, ctx->ev_rd, s); ctx->cfg.exec_flags |= HEVCDL_EXEC_NO_UNIT_HANDOVER;      // rows on waves of their own need co-residency: this context walks a frame's rows on one wave from now on
+                        return launch_rd(ctx, d_yuv, n_frames, d_labels, d_records, d_recon, d_stats, s, ctu_begin, ctu_end, d_cabac_in, d_cabac_out, tile_begin, tile_count); }
+    }
   }
-  if (!p.migrate && !p.remote) {
+  if (!launched) {
     if (ctx->cfg.bit_depth != 8) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_bd10, dim3(groups), dim3(threads), smem, s, p);
     else if (wide) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_wide, dim3(groups), dim3(threads), smem, s, p);
     else if (rt_tools) hipLaunchKernelGGL(hevcdl_rd_frame_kernel_tools, dim3(groups), dim3(threads), smem, s, p);
@@ -509,7 +528,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   prof_end(ctx, ctx->ev_rd, s);
   HIPCHK(hipGetLastError());
   snprintf(ctx->last_rd, sizeof ctx->last_rd, "%s form=%s workgroups=%d waves=%d units=%d", ctx->cfg.bit_depth != 8 ? "hevcdl_rd_frame_kernel_bd10" : (wide ? "hevcdl_rd_frame_kernel_wide" : (rt_tools ? "hevcdl_rd_frame_kernel_tools" : "hevcdl_rd_frame_kernel")),
-           p.migrate ? "unit-handover" : (p.remote == 1 ? "few-units(passes)" : (p.remote == 2 ? "few-units(passes+chroma)" : (p.remote == 3 ? "few-units(passes while takers idle)" : "independent"))),
+           p.wpp == 1 ? (p.remote ? "wavefront-rows+few-units" : "wavefront-rows") : p.wpp == 2 ? "wavefront(one wave per frame)" : p.migrate ? "unit-handover" : (p.remote == 1 ? "few-units(passes)" : (p.remote == 2 ? "few-units(passes+chroma)" : (p.remote == 3 ? "few-units(passes while takers idle)" : "independent"))),
            p.remote ? ctx->remote_groups : groups, waves, n_units);
 #if defined(HEVCDL_KERNEL_PROF) || defined(HEVCDL_KERNEL_DEBUG)
   {
@@ -684,7 +703,7 @@ extern "C" hevcdl_status hevcdl_reserve_workspace(hevcdl_ctx *ctx)
 {
   if (!ctx) return HEVCDL_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(ctx->cfg.device));
-  const long long max_units = (long long)ctx->cfg.max_frames * ctx->cfg.tile_columns * ctx->cfg.tile_rows;
+  const long long max_units = (long long)ctx->cfg.max_frames * (ctx->cfg.wavefront ? ctx->ctus_y : ctx->cfg.tile_columns * ctx->cfg.tile_rows);
   const int groups = std::max(ctx->rd_groups, ctx->remote_groups);
   int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : hevcdl_rd_waves_per_group();
   const bool rt_tools = ctx->cfg.bit_depth == 8 && ctx->cfg.tools != HEVCDL_TOOLS_REFERENCE;      // launch_rd's rule: such a context never runs the ten-wave build

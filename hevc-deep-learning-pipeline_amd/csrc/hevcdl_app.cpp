@@ -51,7 +51,7 @@ const Key KEYS[] = {
   { "RDOQ", 0, USED, 0 }, { "RDOQTS", 0, USED, 0 }, { "TransformSkip", 0, USED, 0 }, { "TransformSkipFast", 0, USED, 0 },
   { "SignHideFlag", "SBH", USED, 0 }, { "StrongIntraSmoothing", 0, USED, 0 }, { "FastUDIUseMPMEnabled", 0, USED, 0 },      // tool switches (hevcdl_config.tools): 0 or 1
   { "SliceMode", 0, PATH, "0" }, { "PCMEnabledFlag", 0, PATH, "0" }, { "NumTileColumnsMinus1", 0, USED, 0 },
-  { "NumTileRowsMinus1", 0, USED, 0 }, { "WaveFrontSynchro", 0, PATH, "0" }, { "ScalingList", 0, PATH, "0" },
+  { "NumTileRowsMinus1", 0, USED, 0 }, { "WaveFrontSynchro", 0, USED, 0 }, { "ScalingList", 0, PATH, "0" },
   { "TransquantBypassEnable", 0, PATH, "0" }, { "CUTransquantBypassFlagForce", 0, PATH, "0" },
   // stream / in-loop filter keys
   { "Level", 0, USED, 0 }, { "DecodingRefreshType", 0, PATH, "1" }, { "ReWriteParamSetsFlag", 0, USED, 0 }, { "LoopFilterOffsetInPPS", 0, PATH, "1" },
@@ -247,6 +247,11 @@ int main(int argc, char **argv)
   const int tile_uniform = (int)opt.geti("TileUniformSpacing", 0) != 0;
   std::vector<int> tile_cw, tile_rh;               // TileColumnWidthArray / TileRowHeightArray: sizes in CTUs of all but the last column / row
   auto parse_ints = [](const std::string &text, std::vector<int> &out) { std::string t = text; for (char &ch : t) if (ch == ',') ch = ' '; std::istringstream is(t); int v; while (is >> v) out.push_back(v); };
+  // WaveFrontSynchro (TAppEncCfg.cpp:975): 1 = entropy_coding_sync_enabled_flag; CTU rows start from the contexts behind the second CTU of the row above and are walked by
+  // waves of their own on the device.  The reference refuses the key together with tiles outside the high-throughput profile (TAppEncCfg.cpp xCheckParameter); so does this path.
+  const long wavefront = opt.geti("WaveFrontSynchro", 0);
+  if (wavefront != 0 && wavefront != 1) opt.errors.push_back("WaveFrontSynchro = " + std::to_string(wavefront) + " is not a value of the key (0 or 1)");
+  if (wavefront && tile_cols * tile_rows > 1) opt.errors.push_back("Tiles and entropy-coding-sync (Wavefronts) can not be applied together (as the reference, outside its high-throughput profile)");
   if (tile_cols * tile_rows > 1) {
     if (!tile_uniform) {
       parse_ints(opt.get("TileColumnWidthArray"), tile_cw); parse_ints(opt.get("TileRowHeightArray"), tile_rh);
@@ -309,14 +314,14 @@ int main(int argc, char **argv)
     if (free_b > 0) { double mine = (double)free_b * 0.8 / (shared_device ? (double)devices.size() : 1.0);       // (contexts that share a device share its memory)
       if (mine > 2.0 * (double)workspace) mine -= (double)workspace;
       dev_cap = std::max<long>(1, (long)mine / per_picture_dev); } }
-  const long auto_batch = std::max<long>(1, std::min<long>(std::min<long>(2048 / (tile_cols * tile_rows), dev_cap), (24L << 30) / (long)frame_bytes));
+  const long auto_batch = std::max<long>(1, std::min<long>(std::min<long>(wavefront ? std::max<long>(1, 4096 / ((height + 63) / 64)) : 2048 / (tile_cols * tile_rows), dev_cap), (24L << 30) / (long)frame_bytes));
   const long even_batch = (per_shard + ((per_shard + auto_batch - 1) / auto_batch) - 1) / ((per_shard + auto_batch - 1) / auto_batch);
   int batch = (int)std::min<long>(per_shard, std::max<long>(1, opt.geti("BatchFrames", even_batch)));
 
   hevcdl_config cfg;
   hevcdl_status st = hevcdl_config_default_bd(&cfg, width, height, qp, bit_depth);
   if (st != HEVCDL_OK) { fprintf(stderr, "Error: unsupported picture size / QP (status %d)\n", (int)st); return 2; }
-  cfg.tile_columns = tile_cols; cfg.tile_rows = tile_rows;
+  cfg.tile_columns = tile_cols; cfg.tile_rows = tile_rows; cfg.wavefront = (int)wavefront;
   if (tile_cols * tile_rows > 1) {
     cfg.tile_uniform_spacing = tile_uniform; cfg.lf_across_tiles = opt.geti("LFCrossTileBoundaryFlag", 1) != 0;
     if (!tile_uniform) { for (int i = 0; i < tile_cols - 1; i++) cfg.tile_column_width[i] = tile_cw[i]; for (int i = 0; i < tile_rows - 1; i++) cfg.tile_row_height[i] = tile_rh[i]; }
@@ -404,7 +409,7 @@ int main(int argc, char **argv)
   FILE *frecords = record_path.empty() ? nullptr : fopen(record_path.c_str(), "wb");
   FILE *fbits = bitstream_path.empty() ? nullptr : fopen(bitstream_path.c_str(), "wb");
   if (!bitstream_path.empty() && !fbits) { fprintf(stderr, "Error: cannot open bitstream file '%s'\n", bitstream_path.c_str()); return 2; }
-  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth;
+  hevcdl_stream_config scfg; hevcdl_stream_config_default(&scfg, width, height, qp); scfg.level_idc = level_idc; scfg.sao_enabled = sao; scfg.tile_columns = tile_cols; scfg.tile_rows = tile_rows; scfg.bit_depth = bit_depth; scfg.wavefront = (int)wavefront;
   scfg.rewrite_param_sets = opt.geti("ReWriteParamSetsFlag", 1) != 0;
   scfg.tools = cfg.tools; scfg.lf_beta_offset_div2 = cfg.lf_beta_offset_div2; scfg.lf_tc_offset_div2 = cfg.lf_tc_offset_div2; scfg.loop_filter_disable = deblock ? 0 : 1;
   scfg.lf_across_tiles = cfg.lf_across_tiles; scfg.tile_uniform_spacing = cfg.tile_uniform_spacing; memcpy(scfg.tile_column_width, cfg.tile_column_width, sizeof scfg.tile_column_width); memcpy(scfg.tile_row_height, cfg.tile_row_height, sizeof scfg.tile_row_height);

@@ -526,7 +526,7 @@ extern "C" hevcdl_status hevcdl_stream_config_default(hevcdl_stream_config *cfg,
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = sizeof *cfg; cfg->width = width; cfg->height = height; cfg->qp = qp;
   cfg->level_idc = 186;                    // Level 6.2 (general_level_idc = 30 * level)
-  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1; cfg->lf_across_tiles = 1;
+  cfg->tile_columns = 1; cfg->tile_rows = 1; cfg->bit_depth = 8; cfg->tile_uniform_spacing = 1; cfg->lf_across_tiles = 1; cfg->wavefront = 0;
   cfg->tools = HEVCDL_TOOLS_REFERENCE; cfg->rewrite_param_sets = 1;
   return HEVCDL_OK;
 }
@@ -640,6 +640,8 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
   t_tools = cfg->tools;
   const int tcols = cfg->tile_columns, trows = cfg->tile_rows, tiled = tcols * trows > 1;
   if (tcols < 1 || trows < 1 || tcols > 20 || trows > 22) return HEVCDL_ERR_INVALID_ARG;
+  const int wpp = cfg->wavefront != 0;
+  if (wpp && tiled) return HEVCDL_ERR_UNSUPPORTED;       // the reference refuses the pair outside the high-throughput profile (TAppEncCfg.cpp xCheckParameter)
   int col_bd[21], row_bd[23];
   const int uniform = cfg->tile_uniform_spacing != 0;
   if (hevcdl_tile_bounds((cfg->width + 63) >> 6, tcols, uniform, cfg->tile_column_width, tiled ? 4 : 1, col_bd) ||      // TComPicSym.cpp:380-392
@@ -677,7 +679,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     w.ue(0); w.ue(0); w.flag(0); w.flag(0); w.write(0, 3); w.flag((cfg->tools & HEVCDL_TOOL_SIGN_HIDE) != 0); w.flag(1); w.ue(3); w.ue(3);   // ... sign_data_hiding_enabled_flag, cabac_init_present_flag, ...
     w.se(0); w.flag(0); w.flag((cfg->tools & HEVCDL_TOOL_TSKIP) != 0); w.flag(0);        // init_qp_minus26 0, constrained intra, transform skip, cu_qp_delta
     w.se(0); w.se(0); w.flag(0); w.flag(0); w.flag(0); w.flag(0);      // chroma qp offsets, slice chroma offsets present, weighted (bi)pred, transquant bypass
-    w.flag(tiled); w.flag(0);                        // tiles_enabled_flag, entropy_coding_sync_enabled_flag
+    w.flag(tiled); w.flag(wpp);                      // tiles_enabled_flag, entropy_coding_sync_enabled_flag (TEncCavlc.cpp:226-227)
     if (tiled) { // :228-246
       w.ue((uint32_t)tcols - 1); w.ue((uint32_t)trows - 1); w.flag(uniform);
       if (!uniform) {
@@ -705,8 +707,28 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
     // end_of_subset_one_bit of the others), the coder flush and byte_alignment().
     Pic pic(records, cfg->width, cfg->height);
     const int ctus_y = (cfg->height + 63) >> 6, ctus = pic.ctus_x * ctus_y;
-    std::vector<BitOut> sub((size_t)tcols * trows);
-    for (int tr = 0; tr < trows; tr++) for (int tc = 0; tc < tcols; tc++) {
+    std::vector<BitOut> sub(wpp ? (size_t)ctus_y : (size_t)tcols * trows);
+    if (wpp) { // WaveFrontSynchro: one sub-stream per CTU row (TEncSlice.cpp:1047-1145).  A row starts from the slice-start contexts, or from those behind the SECOND CTU of
+      // the row above when the picture is at least two CTUs wide (the CTU above and to the right exists), and ends like a tile: terminating 1 bin, flush, byte_alignment()
+      uint8_t sync[NUM_CTX];
+      pic.tx0 = 0; pic.ty0 = 0;
+      for (int cy = 0; cy < ctus_y; cy++) {
+        BitOut &sw = sub[(size_t)cy];
+        Cabac c(sw, cfg->qp);
+        if (cy > 0 && pic.ctus_x > 1) memcpy(c.ctx, sync, sizeof sync);
+        for (int cx = 0; cx < pic.ctus_x; cx++) {
+          const int a = cy * pic.ctus_x + cx;
+          if (sao) code_sao_blk(c, sao[a], cx > 0, cy > 0, (1 << ((bd < 10 ? bd : 10) - 5)) - 1);
+          code_cu_tree(c, pic, cx * 64, cy * 64, 0);
+          if (a != ctus - 1) c.terminate(0);
+          if (cx == 1) memcpy(sync, c.ctx, sizeof sync);       // :1127-1130
+        }
+        c.terminate(1);
+        c.finish();
+        sw.trailing();
+      }
+    }
+    else for (int tr = 0; tr < trows; tr++) for (int tc = 0; tc < tcols; tc++) {
       const int cx0 = col_bd[tc], cx1 = col_bd[tc + 1], cy0 = row_bd[tr], cy1 = row_bd[tr + 1];
       BitOut &sw = sub[(size_t)tr * tcols + tc];
       Cabac c(sw, cfg->qp);
@@ -721,7 +743,7 @@ extern "C" hevcdl_status hevcdl_write_access_unit(const hevcdl_stream_config *cf
       c.finish();
       sw.trailing();
     }
-    if (tiled) { // entry points: TEncCavlc::codeTilesWPPEntryPoint :1207-1240; a size counts the emulation prevention bytes of its sub-stream
+    if (tiled || wpp) { // entry points: TEncCavlc::codeTilesWPPEntryPoint :1207-1240; a size counts the emulation prevention bytes of its sub-stream
       std::vector<uint32_t> size(sub.size() - 1);
       uint32_t max_size = 0;
       for (size_t i = 0; i + 1 < sub.size(); i++) { size[i] = (uint32_t)sub[i].b.size() + count_emulations(sub[i].b); if (size[i] > max_size) max_size = size[i]; }

@@ -102,7 +102,12 @@ struct hevcdl_rd_params {
   int width, height, ctus_x, ctus_y, n_frames, debug;
   int tile_cols, tile_rows;        // tiles (1 x 1: none); one wave per (frame, tile)
   int col_bd[21], row_bd[23];      // tile boundaries in CTUs (hevcdl_tile_bounds)
-  int tile_begin, tile_count;      // tiles of every frame this launch covers (raster order of tiles)
+  int tile_begin, tile_count;      // tiles of every frame this launch covers (raster order of tiles); with wpp: the units of a frame (ctus_y rows, or 1)
+  // WaveFrontSynchro (hevcdl_config.wavefront): 1 = a unit is one CTU ROW of a frame (tile_count = ctus_y), rows of a frame run two CTUs apart on different waves; 2 = a unit is a
+  // whole frame whose rows start from the synchronised contexts (one wave walks them in order: the form that needs no co-residency).  wpp_state: [frame][row] 256 bytes --
+  // the contexts behind the row's second CTU (TEncSlice.cpp:925-928) at 0, the number of finished CTUs of the row at 192 (zeroed by the host before the launch)
+  int wpp;
+  unsigned char *wpp_state;
   hevcdl_rd_consts k;
 };
 

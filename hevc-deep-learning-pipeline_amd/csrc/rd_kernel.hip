@@ -4280,11 +4280,28 @@ DEVN int remote_serve(GLB unsigned char *sched_)
   return 1;
 }
 
+// slice start: context init from QP (ContextModel.cpp:56-66, TEncSlice.cpp:719-720), fraction 0 (TEncBinCoderCABAC.cpp:69-79)
+DEV void slice_start_contexts(LCabac *c, int qp)
+{
+  const int lane = lane_id();
+  for (int i = lane; i < NUM_CTX; i += 64) {
+    const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
+    int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+    const int mps = st >= 64;
+    c->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
+  }
+  if (lane == 0) { c->ctx[159] = 0; c->frac = 0; }
+}
+
 // -> 0: the unit is finished, 1: handed over to the next workgroup.  i_resume >= 0: continue a unit taken from this workgroup's mailbox.
 DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
 {
   LSmem &s = lds();
-  const int ntiles = p.tile_cols * p.tile_rows, frame = unit / p.tile_count, tile = p.tile_begin + (unit - frame * p.tile_count);
+  const int wpp = p.wpp;                // WaveFrontSynchro: 1 = this unit is one CTU row of its frame, 2 = a whole frame with synchronised rows (hevcdl_dev.h)
+  const int ntiles = p.tile_cols * p.tile_rows, frame = unit / p.tile_count, tile = wpp ? 0 : p.tile_begin + (unit - frame * p.tile_count);
+  const int wrows = wpp ? p.ctus_y / p.tile_count : 0, wrow0 = wpp ? (unit - frame * p.tile_count) * wrows : 0;      // the unit's CTU rows [wrow0, wrow0 + wrows)
+  GLB unsigned char *wstate = wpp ? (GLB unsigned char *)p.wpp_state + (size_t)frame * p.ctus_y * 256 : nullptr;
+  int wpp_seen = 0;                     // CTUs of the row above known to be finished (and made visible by an acquire)
   LDS K &k = s.k;                       // every lane stores the same values
   const int lane = lane_id();
   k.W = p.width; k.H = p.height; k.cw = p.width >> 1; k.ctus_x = p.ctus_x; k.nctu = p.ctus_x * p.ctus_y;
@@ -4317,15 +4334,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   } else if (p.cabac_in) {
     GLB const unsigned long long *src = (GLB const unsigned long long *)p.cabac_in + (size_t)frame * 21;
     if (lane < 21) ((LDS unsigned long long *)truec)[lane] = src[lane];
-  } else {
-    for (int i = lane; i < NUM_CTX; i += 64) {
-      const int v = c_ctx_init[i], slope = (v >> 4) * 5 - 45, offset = ((v & 15) << 3) - 16;
-      int st = ((slope * p.k.qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
-      const int mps = st >= 64;
-      truec->ctx[i] = (uint8_t)(((mps ? st - 64 : 63 - st) << 1) + mps);
-    }
-    if (lane == 0) { truec->ctx[159] = 0; truec->frac = 0; }
-  }
+  } else slice_start_contexts(truec, p.k.qp);
   wsync();
 
   // tile rectangle from the host's boundary tables (TComPicSym.cpp xInitTiles); CTUs of the tile in raster order.  Without tiles the
@@ -4334,7 +4343,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   const int cx0 = p.col_bd[tcx], cx1 = p.col_bd[tcx + 1], cy0 = p.row_bd[tcy], cy1 = p.row_bd[tcy + 1];
   const int tw = cx1 - cx0;
   k.tx0 = cx0 * 64; k.ty0 = cy0 * 64; k.tx1 = cx1 * 64; k.ty1 = cy1 * 64;
-  const int i_begin = i_resume >= 0 ? i_resume : (ntiles == 1 ? p.ctu_begin : 0), i_end = ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0);
+  const int i_begin = wpp ? wrow0 * tw : (i_resume >= 0 ? i_resume : (ntiles == 1 ? p.ctu_begin : 0)), i_end = wpp ? (wrow0 + wrows) * tw : (ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0));
   for (int i = i_begin; i < i_end; i++) {
     if (p.migrate && i > i_begin && ((i - i_begin) & (HEVCDL_HOP - 1)) == 0) { // every HEVCDL_HOP CTUs: does the next workgroup of the ring walk fewer units than this one?
       const int g = (int)blockIdx.x, ng = (g + 1) % (int)gridDim.x;
@@ -4353,6 +4362,26 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
     }
     const int cx = cx0 + i % tw, cy = cy0 + i / tw, a = cy * p.ctus_x + cx;
     wsync();
+    if (wpp && cy > 0) { // WaveFrontSynchro (TEncSlice.cpp:783-830): this CTU reads the row above up to the CTU above and to the right, a row starts from the contexts behind that CTU
+      if (cx == 0) wpp_seen = 0;
+      const int need = cx + 2 < tw ? cx + 2 : tw;
+      if (wpp == 1 && wpp_seen < need) { // the row above is walked by another wave, most likely on another XCD: its finished-CTU count (agent scope), then an acquire
+        GLB int *prog = (GLB int *)(wstate + (size_t)(cy - 1) * 256 + 192);
+        PROF_T0();
+        // (a look every ~7 us: a CTU takes a wave milliseconds, and thousands of waiting waves must not crowd the fabric with their polls)
+        while ((wpp_seen = glb_load(prog)) < need) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        PROF_ADD(k, 23);
+      }
+      if (cx == 0) { // resetEntropy, then the contexts -- not the fraction -- behind the second CTU of the row above if the picture has one (:808-823)
+        slice_start_contexts(truec, p.k.qp);
+        wsync();
+        if (tw >= 2) { GLB const unsigned int *src = (GLB const unsigned int *)(wstate + (size_t)(cy - 1) * 256); if (lane < 40) ((LDS unsigned int *)truec->ctx)[lane] = src[lane]; }
+        wsync();
+        if (lane == 0) truec->ctx[159] = 0;
+        wsync();
+      }
+    }
     PROF_MARK0();
     k.addr = a; k.cx = cx; k.cy = cy;
     if (lane < 16) s.lab16[lane] = k.labels[a * 16 + lane];
@@ -4382,7 +4411,9 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       // Second passes are still out and this wave is about to wait for them, its workgroup's other waves idle: the look-ahead for the FIRST CU of the next CTU -- its
       // rough-mode sums, then its first-pass candidates.  Nothing of this CTU is touched (the candidates get a context of their own naming the next CTU, ahead_open);
       // what they assume is checked when the CU is reached (est_intra_luma), and a restart of this CTU drops them like any other look-ahead.
+      // (WaveFrontSynchro: the next CTU's first CU reads the row above one CTU further to the right -- only when that is known to be finished already, never into a row start)
       if (AHEAD && HEVCDL_PREFETCH && NPEND >= 2 && !p.migrate && !uni(s.restart) && uni(s.pend_n) && i + 1 < i_end && uni(s.lw_valid) && !uni(s.ahead_open) && !uni(s.pre_open) &&
+          (!wpp || (cx + 1 < tw && (cy == 0 || wpp == 2 || wpp_seen >= (cx + 3 < tw ? cx + 3 : tw)))) &&
           lds_load(&wg_shared().masters_active) <= HEVCDL_AHEAD_MAX && spare_waves()) {
         const int ni = i + 1, ncx = cx0 + ni % tw, ncy = cy0 + ni / tw, na = ncy * p.ctus_x + ncx;
         int nx = 0, ny = 0, nl = 0;
@@ -4433,6 +4464,15 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       *(GLB double *)(rec + REC_COST) = best.cost;
     }
     wsync();
+    if (wpp) { // the contexts behind the row's second CTU for the row below (TEncSlice.cpp:925-928), then the row's progress: record, samples and contexts before the count
+      if (cx == 1 && lane < 40) ((GLB unsigned int *)(wstate + (size_t)cy * 256))[lane] = ((LDS const unsigned int *)truec->ctx)[lane];
+      if (wpp == 1) {
+        wsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store((GLB int *)(wstate + (size_t)cy * 256 + 192), cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      wsync();
+    }
     PROF_MARK(47);
   }
   if (p.cabac_out) {
@@ -4443,8 +4483,9 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   if (p.stats) { // per-frame summary: SSE per plane (lane-parallel) + estimated bits; every tile adds its rectangle (the host zeroed the entry)
     GLB hevcdl_frame_stats *st = (GLB hevcdl_frame_stats *)p.stats + frame;
     for (int c = 0; c < 3; c++) {
-      const int sh = c ? 1 : 0, ps = p.width >> sh, rx0 = k.tx0 >> sh, ry0 = k.ty0 >> sh;
-      const int rw = ((k.tx1 < p.width ? k.tx1 : p.width) >> sh) - rx0, rh = ((k.ty1 < p.height ? k.ty1 : p.height) >> sh) - ry0;
+      const int uy0 = wpp ? wrow0 * 64 : k.ty0, uy1 = wpp ? (wrow0 + wrows) * 64 : k.ty1;        // the unit's sample rows: its tile, or its CTU rows
+      const int sh = c ? 1 : 0, ps = p.width >> sh, rx0 = k.tx0 >> sh, ry0 = uy0 >> sh;
+      const int rw = ((k.tx1 < p.width ? k.tx1 : p.width) >> sh) - rx0, rh = ((uy1 < p.height ? uy1 : p.height) >> sh) - ry0;
       unsigned long long acc = 0;
       GLB const pel_t *po = org0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz)); GLB const pel_t *pr = rec0 + (c == 0 ? 0 : (c == 1 ? ysz : ysz + csz));
       for (int yy = 0; yy < rh; yy++) {
@@ -4454,7 +4495,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       for (int m = 32; m >= 1; m >>= 1) { unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32); lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m); acc += ((unsigned long long)hi << 32) | lo; }
       if (lane == 0) __hip_atomic_fetch_add(&st->sse[c], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) { __hip_atomic_fetch_add(&st->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tile == p.tile_begin) { st->ctus = (uint32_t)nctu; st->pad = 0; } }
+    if (lane == 0) { __hip_atomic_fetch_add(&st->est_bits, (unsigned long long)s.est_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (wpp ? wrow0 == 0 : tile == p.tile_begin) { st->ctus = (uint32_t)nctu; st->pad = 0; } }
   }
   return 0;
 }

@@ -40,7 +40,7 @@ def read_frames(path, width, height, first, count, bit_depth=8):
 
 
 def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None, recon_path=None, frame_skip=0, batch=256, tiles=(1, 1),
-                    lf_across_tiles=True, bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, labels_fn=None, device=None, log=print, tools=0x7f):
+                    lf_across_tiles=True, bit_depth=8, level_idc=186, frame_rate=30.0, hash_sei=False, labels_fn=None, device=None, log=print, tools=0x7f, wavefront=False):
     """Encode frames [frame_skip, frame_skip + n_frames) of a planar YUV file.  Works stand-alone and under torch.distributed
     (initialised by the caller): rank r takes a contiguous share of the frames.  Returns, on rank 0, the summary (metrics.Summary)
     and the list of per-picture rows [poc, bits, sseY, sseU, sseV]; other ranks return (None, None).
@@ -58,7 +58,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
     part_rec = (recon_path + ".part%d" % rank) if recon_path else None
     fb, fr = open(part_bits, "wb") if part_bits else None, open(part_rec, "wb") if part_rec else None
     if len(mine):
-        enc = Encoder(width, height, qp, max_frames=min(batch, len(mine)), device=device, tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools)      # tools: HEVCDL_TOOL_* mask (the cfg's tool switches)
+        enc = Encoder(width, height, qp, max_frames=min(batch, len(mine)), device=device, tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools, wavefront=wavefront)      # tools: HEVCDL_TOOL_*; wavefront: WaveFrontSynchro mask (the cfg's tool switches)
         ysz = width * height
         for b0 in range(mine.start, mine.stop, batch):
             nb = min(batch, mine.stop - b0)
@@ -68,7 +68,7 @@ def encode_sequence(input_path, width, height, qp, n_frames, bitstream_path=None
             recs, final, sao, _ = enc.encode_pictures(yuv, labels)          # CNN -> decisions -> deblocking -> SAO, pictures stay in HBM
             et = (time.time() - t0) / nb
             def one_picture(i):          # host work of a picture (arithmetic coder, hash, SSE): independent -> thread pool (ctypes drops the GIL)
-                au = write_access_unit(width, height, qp, b0 + i, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools)
+                au = write_access_unit(width, height, qp, b0 + i, recs[i], level_idc=level_idc, sao=sao[i], tiles=tiles, bit_depth=bit_depth, lf_across_tiles=lf_across_tiles, tools=tools, wavefront=wavefront)
                 sei = picture_hash_sei(width, height, final[i], bit_depth) if hash_sei else b""
                 d = (yuv[i].astype(np.int64) - final[i].astype(np.int64)) ** 2
                 return au, sei, [int(d[:ysz].sum()), int(d[ysz:ysz + ysz // 4].sum()), int(d[ysz + ysz // 4:].sum())]

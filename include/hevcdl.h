@@ -108,6 +108,12 @@ typedef struct hevcdl_config {
   /* LoopFilterBetaOffset_div2 / LoopFilterTcOffset_div2 (-6 .. 6, default 0; with LoopFilterOffsetInPPS 1, the cfg's value): added twice to the QP the deblocking filter's
    * beta / tc tables are read with (TComLoopFilter.cpp:623-624, 804) */
   int32_t  lf_beta_offset_div2, lf_tc_offset_div2;
+  /* WaveFrontSynchro (cfg key of that name, TAppEncCfg.cpp:975; default 0).  1: entropy_coding_sync_enabled_flag -- the coder is re-initialised at the first CTU of every
+   * CTU row and takes over the contexts behind the second CTU of the row above (TEncSlice.cpp:783-830, 925-928).  The decisions then differ from the default cfg's (every
+   * RD cost is priced with other context states), exactly as the reference's do with the key set; the CTU chain of a frame (2040 steps at 2160p) becomes ctus_y chains two
+   * CTUs apart (126 steps), which the decision kernel walks on different waves.  Not together with tiles (the reference refuses the pair in the main profiles); the per-CTU
+   * session (hevcdl_compress_ctu) and tile-range launches are refused on such a context. */
+  int32_t  wavefront;
 } hevcdl_config;
 
 /* One CTU of decisions: what compressCtu leaves in the picture's CTU record (TEncCu.cpp:1091 copyToPic).
@@ -244,6 +250,9 @@ typedef struct hevcdl_stream_config {
                                     either is non-zero or the filter is disabled: TEncTop.cpp:1007-1035) */
   int32_t  rewrite_param_sets;   /* ReWriteParamSetsFlag (default 1: VPS / SPS / PPS in front of every picture, all of them IRAPs here); 0: in front of the first picture only
                                     (TEncGOP.cpp:1751) */
+  int32_t  wavefront;            /* WaveFrontSynchro (default 0): 1 = entropy_coding_sync_enabled_flag, one sub-stream per CTU row with entry points in the slice header, every row
+                                    starting from the contexts behind the second CTU of the row above (TEncSlice.cpp:1047-1145); the records must come from a context with
+                                    hevcdl_config.wavefront 1.  Not together with tiles (the reference refuses the pair in the main profiles) */
                                  /* (LFCrossSliceBoundaryFlag has no field: without slices -- SliceMode 0, the only mode of this path -- the reference sets it to 1 whatever the cfg
                                     says, TAppEncTop.cpp:278-281; tests/golden/stream_c192_q32.npz pins that) */
 } hevcdl_stream_config;

@@ -216,6 +216,43 @@ def gen_rd_lf():
     print("stream-switch fixture stream_c192_q32")
 
 
+def gen_rd_wpp():
+    """WaveFrontSynchro 1 (entropy_coding_sync_enabled_flag, TAppEncCfg.cpp:975): the reference encoder run with the key on its command line -- CTU rows start from the contexts
+    behind the second CTU of the row above (TEncSlice.cpp:783-830, 925-928), a sub-stream per row.  The fixtures carry wavefront = 1; everything else as the ordinary ones."""
+    #        name             W    H   frames qp labels seed bits
+    spec = [("w256_q32_r", 256, 192, 1, 32, "rand", 81, 8),           # 4 x 3 CTUs
+            ("w200_q27_r2", 200, 136, 2, 27, "rand", 82, 8),          # ragged right / bottom edge, two pictures
+            ("w64_q32_r", 64, 192, 1, 32, "rand", 83, 8),             # one CTU wide: no CTU above and to the right, every row starts from the slice-start contexts
+            ("w128_q22_r", 128, 256, 1, 22, "rand", 84, 8),           # two CTUs wide: the sync state is the state behind the LAST CTU of the row above; noise (escapes, sign hiding)
+            ("w416_q32_r", 416, 240, 1, 32, "rand", 85, 8),           # C1's picture size
+            ("w384_q37_d1", 384, 256, 1, 37, 1, 86, 8),               # 32x32 CUs
+            ("w200_q30_b10", 200, 200, 1, 30, "rand", 87, 10)]        # 10-bit samples
+    for name, w, h, nf, qp, kind, seed, bd in spec:
+        yuv = rt.synth_yuv(w, h, nf, seed)
+        if name.startswith("w128_q22"):
+            yuv = np.random.default_rng(seed).integers(0, 256, yuv.shape).astype(np.uint8)
+        if bd == 10:
+            yuv = yuv.astype(np.uint16) * 4 + np.random.default_rng(seed).integers(0, 4, yuv.shape).astype(np.uint16)
+        lab = rt.make_labels(w, h, nf, kind, seed + 100)
+        targs = ["--WaveFrontSynchro=1"]
+        dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs, bit_depth=bd)
+        dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)
+        assert dump2.tobytes() == dump.tobytes()
+        dump0, _, _, _ = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)      # the same picture without the key: other decisions (the fixture is not vacuous)
+        dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
+        dump0 = dump0[np.lexsort((dump0["addr"], dump0["frame"]))]
+        nctu = lab.shape[1]
+        assert len(dump) == nf * nctu
+        differs = int(sum(not np.array_equal(a, b) for a, b in zip(dump["rec"], dump0["rec"])))
+        summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd, lf_across_tiles=1, tiles=np.array((1, 1)), wavefront=1,
+                            records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
+                            rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
+                            bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),
+                            summary=np.array(summary), ctus_differing_from_the_default_cfg=differs)
+        print("rd wavefront fixture", name, "ctus", nf * nctu, "records that differ from the run without the key:", differs, summary[0][:60] if summary else "")
+
+
 def load_ref_model():
     import torch
     import torch.nn as nn
@@ -509,7 +546,7 @@ def gen_bd():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "rdtools", "rdlf", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
+    what = sys.argv[1:] or ["rd", "rdtiles", "rd10", "rdx", "rdtools", "rdlf", "rdwpp", "cnn", "weights", "bd", "full", "bdanchor", "stage", "cnneval", "cnnpic", "cnnchain"]
     if "stage" in what:
         gen_stage_traces()
     if "rd" in what:
@@ -524,6 +561,8 @@ if __name__ == "__main__":
         gen_rd_tools()
     if "rdlf" in what:
         gen_rd_lf()
+    if "rdwpp" in what:
+        gen_rd_wpp()
     if "cnn" in what or "weights" in what:
         model, sd, src = load_ref_model()
         if "weights" in what:

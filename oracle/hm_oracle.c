@@ -6,7 +6,7 @@
  * (paths relative to /root/reference/HM_dl/source/Lib).  Build: gcc -O2 -ffp-contract=off.
  * Fixed configuration = /root/reference/encoder_intra_main.cfg (CTU 64, 4 depths, TU 4..32,
  * intra TU depth 3, RDOQ, RDOQTS, TransformSkip + Fast, SignHide, StrongIntraSmoothing,
- * FastUDIUseMPM, 8- or 10-bit 4:2:0, one slice, optionally uniformly spaced tiles, no WPP).
+ * FastUDIUseMPM, 8- or 10-bit 4:2:0, one slice, optionally tiles, optionally wavefront rows (WaveFrontSynchro)).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -157,6 +157,10 @@ static int g_bd = 8;
  * 0x20 StrongIntraSmoothing, 0x40 FastUDIUseMPMEnabled can be cleared; TransformSkipFast (0x08) stays on (the reference cfg's value) */
 static unsigned g_tools = 0x7fu;
 void hm_oracle_set_tools(unsigned tools) { g_tools = tools; }
+/* WaveFrontSynchro 1 (entropy_coding_sync_enabled_flag, TAppEncCfg.cpp:975): the coder is re-initialised at the first CTU of every CTU row of a tile and takes over
+   the contexts behind the SECOND CTU of the row above when that CTU exists in the tile (TEncSlice.cpp:783-830, 925-928) */
+static int g_wpp = 0;
+void hm_oracle_set_wpp(int on) { g_wpp = on != 0; }
 #define DIST_ADJ(x) (x)          /* DISTORTION_PRECISION_ADJUSTMENT, TypeDef.h:170 */
 
 typedef struct { int x, y, log2, trd, zrel, nparts; } tu_t;   /* luma geometry; zrel relative to the CU */
@@ -1696,9 +1700,15 @@ int hm_oracle_encode_frames_tb(const void *yuv_, int width, int height, int n_fr
       const int cx0 = col_bd[tc], cx1 = col_bd[tc + 1], cy0 = row_bd[tr], cy1 = row_bd[tr + 1];
       e->tx0 = cx0 * 64; e->ty0 = cy0 * 64; e->tx1 = cx1 * 64; e->ty1 = cy1 * 64;
       cabac_t truec; cabac_init(&truec, qp);
+      cabac_t sync; cabac_init(&sync, qp);           /* m_entropyCodingSyncContextState */
       for (int cy = cy0; cy < cy1; cy++) for (int cx = cx0; cx < cx1; cx++) {
         e->addr = cy * e->ctus_x + cx; e->cx = cx; e->cy = cy;
+        if (g_wpp && cx == cx0 && cy > cy0) {        /* TEncSlice.cpp:808-823: resetEntropy (contexts from the QP, fraction 0), then the contexts -- not the fraction -- of the sync state */
+          cabac_init(&truec, qp);
+          if (cx + 1 < cx1) memcpy(truec.ctx, sync.ctx, sizeof truec.ctx);     /* the CTU above and to the right lies in this tile (and slice) */
+        }
         compress_ctu(e, &truec, e->addr == nctu - 1);
+        if (g_wpp && cx == cx0 + 1) memcpy(sync.ctx, truec.ctx, sizeof sync.ctx);      /* :925-928 */
       }
     }
     for (int a = 0; a < nctu; a++) {

@@ -7,7 +7,7 @@ baseline).  tests/test_ref_args.py proves, in the container that has the referen
 reference's own cfg file produce the same decisions, reconstruction and bitstream."""
 
 
-def reference_args(width, height, n_frames, qp, bit_depth=8, level="6.2", frame_rate=30):
+def reference_args(width, height, n_frames, qp, bit_depth=8, level="6.2", frame_rate=30, wavefront=0):
     a = {
         "Profile": "main" if bit_depth == 8 else "main10", "MaxCUWidth": 64, "MaxCUHeight": 64, "MaxPartitionDepth": 4,
         "QuadtreeTULog2MaxSize": 5, "QuadtreeTULog2MinSize": 2, "QuadtreeTUMaxDepthInter": 3, "QuadtreeTUMaxDepthIntra": 3,
@@ -16,7 +16,7 @@ def reference_args(width, height, n_frames, qp, bit_depth=8, level="6.2", frame_
         "QP": qp, "MaxDeltaQP": 0, "MaxCuDQPDepth": 0, "DeltaQpRD": 0, "RDOQ": 1, "RDOQTS": 1,
         "LoopFilterOffsetInPPS": 1, "LoopFilterDisable": 0, "LoopFilterBetaOffset_div2": 0, "LoopFilterTcOffset_div2": 0, "DeblockingFilterMetric": 0,
         "InputBitDepth": bit_depth, "InternalBitDepth": bit_depth, "SAO": 1, "AMP": 1, "TransformSkip": 1, "TransformSkipFast": 1, "SAOLcuBoundary": 0,
-        "SliceMode": 0, "LFCrossSliceBoundaryFlag": 1, "PCMEnabledFlag": 0, "LFCrossTileBoundaryFlag": 1, "WaveFrontSynchro": 0,
+        "SliceMode": 0, "LFCrossSliceBoundaryFlag": 1, "PCMEnabledFlag": 0, "LFCrossTileBoundaryFlag": 1, "WaveFrontSynchro": int(wavefront),
         "ScalingList": 0, "TransquantBypassEnable": 0, "CUTransquantBypassFlagForce": 0,
         "InputChromaFormat": 420, "FrameRate": frame_rate, "FrameSkip": 0, "SourceWidth": width, "SourceHeight": height,
         "FramesToBeEncoded": n_frames, "Level": level,

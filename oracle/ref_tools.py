@@ -223,7 +223,7 @@ def tool_args(tools):
     return a
 
 
-def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bit_depth=8, tools=TOOLS_REFERENCE):
+def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bit_depth=8, tools=TOOLS_REFERENCE, wpp=False):
     """Returns (records [frames][ctus] REC_DTYPE, recon [frames][w*h*3/2] (uint8, or uint16 for bit_depth 10), stats [frames])."""
     lib = oracle_lib()
     yuv = np.ascontiguousarray(yuv, np.uint8 if bit_depth == 8 else np.uint16)
@@ -234,6 +234,7 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
     stats = np.zeros(n_frames, STATS_DTYPE)
     lib.hm_oracle_set_trace(trace_path.encode() if trace_path else None)
     lib.hm_oracle_set_tools(ctypes.c_uint(tools))
+    lib.hm_oracle_set_wpp(1 if wpp else 0)              # WaveFrontSynchro 1: a sub-stream per CTU row, contexts synchronised with the row above
     lib.hm_oracle_encode_frames_tb.restype = ctypes.c_int
     lib.hm_oracle_encode_frames_tb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -242,6 +243,7 @@ def run_oracle(yuv, width, height, qp, labels, trace_path=None, tiles=(1, 1), bi
                                         recs.ctypes.data, recon.ctypes.data, stats.ctypes.data, tc, tr, cb.ctypes.data, rb.ctypes.data, bit_depth)
     lib.hm_oracle_set_trace(None)
     lib.hm_oracle_set_tools(ctypes.c_uint(TOOLS_REFERENCE))
+    lib.hm_oracle_set_wpp(0)
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
     return recs, recon, stats

@@ -34,6 +34,11 @@ def fixture_lf_offsets(f):
     return tuple(int(v) for v in f["lf_offsets"]) if "lf_offsets" in f.files else (0, 0)
 
 
+def fixture_wavefront(f):
+    """WaveFrontSynchro of a golden fixture (rd_w*: reference runs with --WaveFrontSynchro=1)."""
+    return bool(int(f["wavefront"])) if "wavefront" in f.files else False
+
+
 def fixture_lf(f):
     """LFCrossTileBoundaryFlag of a golden fixture (rd_l*: 0)."""
     return bool(int(f["lf_across_tiles"])) if "lf_across_tiles" in f.files else True

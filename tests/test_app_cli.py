@@ -68,7 +68,8 @@ def test_reference_style_cfg_and_cli_overrides(app, tmp_path):
 def test_keys_that_change_the_path_are_rejected(app, tmp_path):
     write_cfgs(tmp_path)
     for extra, needle in ((["--IntraPeriod=8"], "IntraPeriod"), (["--ScalingList=1"], "ScalingList"), (["--InternalBitDepth=10"], "InternalBitDepth"), (["--NoSuchKey=1"], "unknown option"),
-                          (["--WaveFrontSynchro=1"], "WaveFrontSynchro"), (["--NumTileColumnsMinus1=1", "--TileColumnWidthArray="], "TileColumnWidthArray"),
+                          (["--WaveFrontSynchro=2"], "WaveFrontSynchro"), (["--WaveFrontSynchro=1", "--NumTileColumnsMinus1=1", "--TileUniformSpacing=1"], "Wavefronts"),      # (the key itself is implemented since round 6; with tiles it is refused, as by the reference)
+                          (["--NumTileColumnsMinus1=1", "--TileColumnWidthArray="], "TileColumnWidthArray"),
                           (["--SEIDecodedPictureHash=4"], "SEIDecodedPictureHash")):
         r = run(app, ["-c", "main.cfg", "-c", "seq.cfg"] + extra + ["--PrintConfig"], tmp_path)
         assert r.returncode == 2 and needle in " ".join(json.loads(r.stdout)["errors"])
@@ -166,11 +167,12 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10",
+@pytest.mark.parametrize("case", ["w416_q32_r", "w200_q27_r2", "w128_q22_r", "w200_q30_b10", "b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10",
                                   "k128_q22_sbh0", "k128_q27_ts0", "k192_q32_sis0", "k200_q32_mpm0", "k200_q27_all0", "k128_q22_rdoq0", "k128_q27_rdoqts0", "k200_q32_rdoq0", "k200_q27_rdoq0_sbh0", "k128_q27_tsf0", "k200_q32_tsf0", "k200_q30_b10_mix0", "o192_q32_b2_tm1", "o200_q27_bm3_t3", "o128_q37_b6_tm6"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
     """b416_q32_r is C1 of BASELINE.json (416x240, one frame, QP32, untiled 8-bit, the reference's default configuration); c192 / b200 are
     further untiled 8-bit runs (two frames; a picture that is not a multiple of 64).  The rest:
+    w*: --WaveFrontSynchro=1 on the command line, as the reference was run (a sub-stream per CTU row, rows synchronised with the row above).
     k*: the tool switches RDOQ / RDOQTS / TransformSkip / TransformSkipFast / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled = 0 on the command line, as the reference was run.  The rest:
     the reference's own cfg surface for tiles (TileUniformSpacing / NumTileColumnsMinus1 / NumTileRowsMinus1) and for 10-bit coding
     (InputBitDepth / InternalBitDepth 10, Profile main10; x576 is C5 of the survey in miniature: both) on the fixtures the reference
@@ -180,7 +182,7 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import hevc_parse as hp
     import ref_tools
-    from conftest import fixture_tiles, fixture_lf, fixture_lf_offsets
+    from conftest import fixture_tiles, fixture_lf, fixture_lf_offsets, fixture_wavefront
     f = np.load(os.path.join(GOLD, "rd_%s.npz" % case))
     w, h, qp, nf = int(f["width"]), int(f["height"]), int(f["qp"]), f["yuv"].shape[0]
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8
@@ -193,7 +195,7 @@ def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path,
     r = run(app, ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", str(qp), "-b", "str.bin", "-o", "rec.yuv", "--LabelDir=pred", "--Level=6.2",
                   "--SEIDecodedPictureHash=1",
                   ] + ref_tools.tile_args(fixture_tiles(f)) + bd_args + ([] if fixture_lf(f) else ["--LFCrossTileBoundaryFlag=0"])
-                  + (ref_tools.tool_args(int(f["tools"])) if "tools" in f.files else [])
+                  + (ref_tools.tool_args(int(f["tools"])) if "tools" in f.files else []) + (["--WaveFrontSynchro=1"] if fixture_wavefront(f) else [])
                   + (["--LoopFilterBetaOffset_div2=%d" % fixture_lf_offsets(f)[0], "--LoopFilterTcOffset_div2=%d" % fixture_lf_offsets(f)[1]] if "lf_offsets" in f.files else []), tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "rec.yuv", np.uint8), f["recon_filtered"])

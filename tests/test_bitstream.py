@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles, fixture_lf, fixture_lf_offsets
+from conftest import GOLD, fixture_tiles, fixture_lf, fixture_lf_offsets, fixture_wavefront
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -24,7 +24,7 @@ def stream_of(f):
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(f["records"].shape[0], -1)
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8        # rd_x*: reference runs at InternalBitDepth 10, Profile main10
     tools = int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE      # rd_k*: reference runs with a tool switch of the cfg turned off
-    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd, lf_across_tiles=fixture_lf(f), tools=tools, lf_offsets=fixture_lf_offsets(f)) for poc in range(recs.shape[0]))
+    return b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], tiles=tiles_of(f), bit_depth=bd, lf_across_tiles=fixture_lf(f), tools=tools, lf_offsets=fixture_lf_offsets(f), wavefront=fixture_wavefront(f)) for poc in range(recs.shape[0]))
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[3:-4])
@@ -36,7 +36,7 @@ def test_stream_is_byte_exact_with_the_reference(path):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_DEC), reason="reference decoder build (oracle/_ref) only exists in the survey container")
-@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r", "t520_q37_2x2", "t576_q27_2x3", "x200_q27_r", "x576_q30_2x3", "k128_q22_sbh0", "k128_q27_ts0", "k200_q27_all0"))],
+@pytest.mark.parametrize("path", [p for p in CASES if any(k in p for k in ("w416_q32_r", "w64_q32_r", "w128_q22_r", "w200_q30_b10", "c128_q22_r", "c192_q32_r2", "b200_q27_r2", "b416_q32_r", "t520_q37_2x2", "t576_q27_2x3", "x200_q27_r", "x576_q30_2x3", "k128_q22_sbh0", "k128_q27_ts0", "k200_q27_all0"))],
                          ids=lambda p: os.path.basename(p)[3:-4])
 def test_reference_decoder_reconstructs_the_deblocked_picture(path, tmp_path):
     f = np.load(path)

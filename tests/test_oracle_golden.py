@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles
+from conftest import GOLD, fixture_tiles, fixture_wavefront
 
 FIELDS = ["depth", "part_size", "luma_dir", "chroma_dir", "tr_idx", "cbf", "tskip", "bits", "dist", "cost", "coeff_y", "coeff_cb", "coeff_cr"]
 
@@ -19,7 +19,7 @@ def test_rd_oracle_matches_reference_records(oracle_built, path):
     tiles = fixture_tiles(f)                                                        # rd_t* / rd_n*: reference runs with tiles enabled
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
     tools = int(f["tools"]) if "tools" in f.files else ref_tools.TOOLS_REFERENCE    # rd_k*: reference runs with a tool switch of the cfg turned off
-    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles, bit_depth=bd, tools=tools)
+    recs, recon, stats = ref_tools.run_oracle(f["yuv"], w, h, qp, f["labels"], tiles=tiles, bit_depth=bd, tools=tools, wpp=fixture_wavefront(f))      # rd_w*: reference runs with WaveFrontSynchro 1
     for k in FIELDS:
         assert np.array_equal(recs[k], f["records"][k]), k
     for fr in range(f["yuv"].shape[0]):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles
+from conftest import GOLD, fixture_tiles, fixture_wavefront
 
 pytestmark = pytest.mark.gpu
 FIELDS = ["depth", "part_size", "luma_dir", "chroma_dir", "tr_idx", "cbf", "tskip", "bits", "dist", "cost", "coeff_y", "coeff_cb", "coeff_cr"]
@@ -34,7 +34,7 @@ def test_golden_records_bit_exact(path):
     tiles = fixture_tiles(f)                                                        # rd_t* / rd_n*: reference runs with tiles enabled
     bd = int(f["bit_depth"]) if "bit_depth" in f.files else 8                       # rd_x*: InternalBitDepth 10 (uint16 samples)
     tools = int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE   # rd_k*: reference runs with TransformSkip / SignHideFlag / StrongIntraSmoothing / FastUDIUseMPMEnabled off
-    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd, tools=tools)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=yuv.shape[0], tiles=tiles, bit_depth=bd, tools=tools, wavefront=fixture_wavefront(f))      # rd_w*: reference runs with WaveFrontSynchro 1
     recs, recon, stats = enc.compress_frames(yuv, labels)
     launch = enc.last_rd_launch()
     enc.close()
@@ -75,7 +75,7 @@ def test_golden_records_bit_exact_on_either_build_of_the_kernel(path, flags):
     f = np.load(path)
     w, h, qp = int(f["width"]), int(f["height"]), int(f["qp"])
     yuv, labels, ref = f["yuv"], f["labels"], f["records"]
-    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=yuv.shape[0], tiles=fixture_tiles(f), tools=int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE)
+    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=yuv.shape[0], tiles=fixture_tiles(f), tools=int(f["tools"]) if "tools" in f.files else hevcdl_amd.TOOLS_REFERENCE, wavefront=fixture_wavefront(f))
     cfg.exec_flags = flags
     enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
     recs, recon, stats = enc.compress_frames(yuv, labels)
@@ -192,6 +192,86 @@ def test_c4_regime_launch_matches_live_reference_runs():
     enc.close()
     assert_records_equal(recs, recs2, "C4-regime launch vs independent form")
     assert np.array_equal(recon, recon2) and np.array_equal(stats["est_bits"], stats2["est_bits"])
+
+
+def test_wavefront_rows_on_waves_of_their_own_and_on_one_wave_give_the_oracle(oracle_built):
+    """WaveFrontSynchro 1 (hevcdl_config.wavefront): a CTU row is a unit of the decision kernel -- the rows of a frame run two CTUs apart on different waves, most of them
+    on different workgroups, and wait for each other through finished-CTU counts in HBM; HEVCDL_EXEC_NO_UNIT_HANDOVER selects the form that needs no co-residency (one wave
+    walks a frame's rows in order).  Both forms, frames of 13 x 7 CTUs (more rows than a workgroup has waves, a ragged last row and column), against the oracle with the key
+    set: records, reconstruction, estimated bits; and the two differ from the run without the key (the test is not vacuous)."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf = 808, 424, 32, 3
+    yuv = ref_tools.synth_yuv(w, h, nf, 909)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    labels = enc.predict_depth(yuv)
+    plain, _, _ = enc.compress_frames(yuv, labels)
+    enc.close()
+    o_recs, o_recon, o_stats = ref_tools.run_oracle(yuv, w, h, qp, labels, wpp=True)
+    for flags, form in ((0, "form=wavefront-rows"), (hevcdl_amd.EXEC_NO_UNIT_HANDOVER, "form=wavefront(one wave per frame)"), (hevcdl_amd.EXEC_RD_WIDE, "form=wavefront-rows"), (hevcdl_amd.EXEC_RD_NARROW, "form=wavefront-rows")):
+        cfg = hevcdl_amd.default_config(w, h, qp, max_frames=nf, wavefront=True)
+        cfg.exec_flags = flags
+        enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
+        recs, recon, stats = enc.compress_frames(yuv, labels)
+        launch = enc.last_rd_launch()
+        enc.close()
+        assert form in launch and ("units=%d" % (nf * 7 if "rows" in form else nf)) in launch, launch
+        assert_records_equal(recs, o_recs, "wavefront, exec_flags %d" % flags)
+        assert np.array_equal(recon, o_recon) and np.array_equal(stats["est_bits"], o_stats["est_bits"]) and np.array_equal(stats["sse"], o_stats["sse"]), flags
+    assert any(not np.array_equal(plain[k], o_recs[k]) for k in ref_tools.FIELDS)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("size", [(1920, 1080, 27, 3), (3840, 2160, 32, 2)], ids=["1080p", "2160p"])
+def test_wavefront_whole_frames_match_a_live_reference_run(size):
+    """WaveFrontSynchro 1 at the sizes of C2 / C4: whole frames (17 / 34 CTU rows a frame, each a unit of the launch, the few-units form on top at these counts) against the
+    reference encoder run now on this machine with --WaveFrontSynchro=1 and the device CNN's labels -- every field of every CTU record and the reconstruction."""
+    import sys
+    import hevcdl_amd
+    import ref_tools
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), ".."))
+    import bench
+    w, h, qp, nf = size
+    yuv = ref_tools.synth_yuv(w, h, nf, 1300 + qp)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, wavefront=True)
+    labels = enc.predict_depth(yuv)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    launch = enc.last_rd_launch()
+    enc.close()
+    assert "form=wavefront-rows" in launch and "units=%d" % (nf * ((h + 63) // 64)) in launch, launch
+    wall, per, dumps = bench.run_reference_pictures(list(yuv), labels, w, h, qp, nf, dump=True, wavefront=1)
+    res = bench.parity_against_dumps(dumps, recs, list(recon), w, h)
+    assert res["ctus"] == nf * recs.shape[1] and res["mismatches"] == 0, res
+
+
+def test_wavefront_many_units_launch_equals_the_one_wave_form():
+    """The regime of a 600-frame wavefront job in miniature: more row units than the launch has wave slots (400 frames of 832x448 = 2800 rows on 256 workgroups of ten waves),
+    so units queue behind each other on a slot while the rows they depend on are still walked elsewhere -- against the form in which one wave walks a frame's rows in order
+    (byte for byte), which the test above pins to the oracle.  Then two frames on the same context: few units, the idle workgroups take the second passes the rows post."""
+    import hevcdl_amd
+    import ref_tools
+    w, h, qp, nf = 832, 448, 32, 400
+    base = ref_tools.synth_yuv(w, h, 6, 4343)
+    rng = np.random.default_rng(23)
+    yuv = np.stack([np.clip(base[i % 6].astype(np.int16) + rng.integers(-2, 3, base.shape[1]) * (i // 6 % 3), 0, 255).astype(np.uint8) for i in range(nf)])
+    cfg = hevcdl_amd.default_config(w, h, qp, max_frames=nf, wavefront=True)
+    cfg.exec_flags = hevcdl_amd.EXEC_NO_UNIT_HANDOVER
+    enc = hevcdl_amd.Encoder(w, h, qp, cfg=cfg)
+    labels = enc.predict_depth(yuv)
+    ref_recs, ref_recon, ref_stats = enc.compress_frames(yuv, labels)
+    enc.close()
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, wavefront=True)
+    recs, recon, stats = enc.compress_frames(yuv, labels)
+    launch = enc.last_rd_launch()
+    # a launch of fewer frames on the same context: few units, the idle workgroups take posted second passes
+    recs8, recon8, stats8 = enc.compress_frames(yuv[:2], labels[:2])
+    launch8 = enc.last_rd_launch()
+    enc.close()
+    assert "form=wavefront-rows" in launch and "units=2800" in launch and "form=wavefront-rows+few-units" in launch8 and "units=14" in launch8, (launch, launch8)
+    assert_records_equal(recs, ref_recs, "wavefront rows vs one wave per frame")
+    assert np.array_equal(recon, ref_recon) and np.array_equal(stats["est_bits"], ref_stats["est_bits"])
+    assert_records_equal(recs8, ref_recs[:2], "wavefront rows, few units")
+    assert np.array_equal(recon8, ref_recon[:2])
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLD, fixture_tiles, fixture_lf, fixture_lf_offsets
+from conftest import GOLD, fixture_tiles, fixture_lf, fixture_lf_offsets, fixture_wavefront
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(GOLD, "rd_*.npz")))
@@ -52,7 +52,7 @@ def test_oracle_sao_matches_reference_picture_and_stream(oracle_built, path):
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
     aus = [hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc].view(hevcdl_amd.SAO_DTYPE), tiles=tiles_of(f), bit_depth=bit_depth_of(f),
-                                        lf_across_tiles=fixture_lf(f), tools=tools_of(f), lf_offsets=fixture_lf_offsets(f)) for poc in range(nf)]
+                                        lf_across_tiles=fixture_lf(f), tools=tools_of(f), lf_offsets=fixture_lf_offsets(f), wavefront=fixture_wavefront(f)) for poc in range(nf)]
     assert b"".join(aus) == strip_sei(f["bitstream"].tobytes())
     # with the decoded-picture-hash SEI (MD5 of the final picture) behind every access unit: the reference's stream, every byte
     assert b"".join(au + hevcdl_amd.picture_hash_sei(w, h, out[poc], bit_depth_of(f)) for poc, au in enumerate(aus)) == f["bitstream"].tobytes()
@@ -68,7 +68,7 @@ def test_gpu_sao_matches_reference(path):
     e.close()
     assert np.array_equal(out, final)
     recs = np.frombuffer(f["records"].tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nf, -1)
-    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f), tools=tools_of(f), lf_offsets=fixture_lf_offsets(f)) for poc in range(nf))
+    ours = b"".join(hevcdl_amd.write_access_unit(w, h, qp, poc, recs[poc], sao=params[poc], tiles=tiles_of(f), bit_depth=bit_depth_of(f), lf_across_tiles=fixture_lf(f), tools=tools_of(f), lf_offsets=fixture_lf_offsets(f), wavefront=fixture_wavefront(f)) for poc in range(nf))
     assert ours == strip_sei(f["bitstream"].tobytes())
 
 

@@ -1,4 +1,4 @@
-"""Decision-kernel timing at 2160p (or WxH): tools/time_rd.py frames [frames ...] [--size WxH]; labels from the on-device CNN."""
+"""Decision-kernel timing at 2160p (or WxH): tools/time_rd.py frames [frames ...] [--size WxH] [--flags=N] [--wavefront]; labels from the on-device CNN."""
 import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
 import numpy as np, torch
@@ -12,10 +12,11 @@ flags = 0
 for a in sys.argv[1:]:
     if a.startswith('--flags='):
         flags = int(a[8:])          # hevcdl_config.exec_flags: 1 independent form only, 2 / 4 the ten- / eight-wave build of the kernel
+wavefront = '--wavefront' in sys.argv[1:]      # WaveFrontSynchro 1: CTU rows as units of the launch
 counts = [int(a) for a in args] or [1, 75, 600]
 nmax = max(counts)
 base = ref_tools.synth_yuv(W, H, 4, seed=4000)
-cfg = hevcdl_amd.default_config(W, H, 32, max_frames=nmax)
+cfg = hevcdl_amd.default_config(W, H, 32, max_frames=nmax, wavefront=wavefront)
 cfg.exec_flags = flags
 enc = hevcdl_amd.Encoder(W, H, 32, cfg=cfg)
 fb = hevcdl_amd.frame_bytes(W, H) if hasattr(hevcdl_amd, 'frame_bytes') else W * H * 3 // 2
@@ -37,5 +38,5 @@ for n in counts:
     enc.compress_frames_dev(yuv.data_ptr(), n, labels.data_ptr(), recs.data_ptr(), recon.data_ptr(), stats.data_ptr())
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print("flags %d  frames %5d  rd %.3f s  %.1f CTU/s" % (flags, n, dt, n * ctus / dt), flush=True)
+    print("flags %d  frames %5d  rd %.3f s  %.1f CTU/s  %s" % (flags, n, dt, n * ctus / dt, enc.last_rd_launch()), flush=True)
 enc.close()
