@@ -382,6 +382,57 @@ def e2e_leg(torch, hevcdl_amd, dev, enc, tensors, n_frames, width, height, qp, c
             "frames": n_frames, "stream_bytes": int(total_bytes), "stages": E2E_STAGES}
 
 
+def wavefront_leg(torch, hevcdl_amd, dev, local, tensors, n_frames, width, height, qp, ctus, barrier, check):
+    """EXTRA keys, not the headline: the same frames with WaveFrontSynchro 1 (cfg key of the reference, TAppEncCfg.cpp:975).  The key changes the stream (a sub-stream per CTU
+    row, rows start from the contexts behind the second CTU of the row above) and with it the decisions -- parity is against the reference run WITH the key -- and it is the
+    one key of the kept cfg surface that breaks a frame's serial chain of CTUs: rows run two CTUs apart (34 + 2 x 33 CTU steps at 2160p instead of 2040), each row a unit of
+    the launch.  Reported: the 600-frame step, a GPU's share of the 8-GPU job (75 frames), one frame alone, C2; the records of the timed step overwrite the job's (this leg
+    runs last)."""
+    yuv, labels, records, recon, stats = tensors
+    enc = hevcdl_amd.Encoder(width, height, qp, max_frames=max(1, n_frames), device=local, wavefront=True)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"cfg": "WaveFrontSynchro 1 (all other keys as the headline)", "unit": "CTUs/s"}
+
+    def timed(n, reps):
+        ts = []
+        for rep in range(reps + 1):                # the first launch of a shape is a warm-up
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            enc.encode_frames_dev(yuv.data_ptr(), n, labels.data_ptr(), records.data_ptr(), recon.data_ptr(), stats.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            if rep:
+                ts.append(time.perf_counter() - t1)
+        return sorted(ts)[len(ts) // 2], enc.last_rd_launch()
+    for key, n, reps in (("latency_floor_s", 1, 3), ("share_8gpu_s", min(n_frames, 75), 3), ("share_4gpu_s", min(n_frames, 150), 2), ("share_2gpu_s", min(n_frames, 300), 2), ("job_s", n_frames, 2)):
+        t, launch = timed(n, reps)
+        out[key] = t
+        out[key.replace("_s", "_launch")] = launch
+    out["value"] = n_frames * ctus / out["job_s"]
+    out["scale_projection"] = {"seconds": {"1": out["job_s"], "2": out["share_2gpu_s"], "4": out["share_4gpu_s"], "8": out["share_8gpu_s"]},
+                               "value": {k: n_frames * ctus / v for k, v in (("1", out["job_s"]), ("2", out["share_2gpu_s"]), ("4", out["share_4gpu_s"]), ("8", out["share_8gpu_s"]))},
+                               "note": "as the headline's scale_projection: a rank's share of the %d frames on this GPU (label CNN + decisions), median of the repeats" % n_frames}
+    if check:     # parity with the key set: whole frames of the timed step against the reference encoder run with --WaveFrontSynchro=1
+        nw = min(n_frames, 4)
+        rec_w = np.frombuffer(records[:nw].contiguous().cpu().numpy().tobytes(), dtype=hevcdl_amd.REC_DTYPE).reshape(nw, ctus)
+        t1 = time.time()
+        _, _, dumps = run_reference_pictures(list(yuv[:nw].cpu().numpy()), labels[:nw].cpu().numpy(), width, height, qp, nw, dump=True, wavefront=1)
+        par = parity_against_dumps(dumps, rec_w, list(recon[:nw].cpu().numpy()), width, height)
+        par["sample"] = "%d WHOLE %dx%d frames of the 600-frame wavefront step against the reference run with --WaveFrontSynchro=1, %.1f s" % (nw, width, height, time.time() - t1)
+        out["parity_check"] = par
+    enc.close()
+    # C2 with the key: 10 frames of 1080p
+    w2, h2, n2 = 1920, 1080, 10
+    e3 = hevcdl_amd.Encoder(w2, h2, qp, max_frames=n2, device=local, wavefront=True)
+    y3 = synth_frames_torch(torch, dev, w2, h2, list(range(n2)), seed=2000)
+    t3 = alloc(torch, hevcdl_amd, dev, n2, e3.frame_bytes, e3.ctus)
+    el3, pr3 = timed_steps(torch, e3, (y3,) + t3, n2, 3, 1, barrier)
+    out["c2"] = {"workload": "1920x1080 8-bit 4:2:0 all-intra QP%d, 10 frames (C2 of BASELINE.json) with WaveFrontSynchro 1" % qp, "value": 3 * n2 * e3.ctus / el3, "unit": "CTUs/s",
+                 "ms_per_step": 1e3 * el3 / 3, "kernel_ms": pr3["rd_ms"] / 3, "launch": e3.last_rd_launch()}
+    e3.close()
+    del y3, t3
+    return out
+
+
 def alloc(torch, hevcdl_amd, dev, n, frame_bytes, ctus):
     return (torch.zeros((n, ctus, 16), dtype=torch.uint8, device=dev), torch.zeros((n, ctus, hevcdl_amd.REC_DTYPE.itemsize), dtype=torch.uint8, device=dev),
             torch.zeros((n, frame_bytes), dtype=torch.uint8, device=dev), torch.zeros((n, hevcdl_amd.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev))
@@ -404,6 +455,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-latency-floor", action="store_true")
+    ap.add_argument("--no-wavefront", action="store_true", help="skip the extra measurements with WaveFrontSynchro 1 (key \"wavefront\"; the headline is the default cfg)")
     ap.add_argument("--cpu-procs", type=int, default=0)
     ap.add_argument("--cpu-baseline", default="reference", choices=["reference", "port"], help="reference: oracle/_ref/TAppEncoder_ref when present; port: the plain-C oracle")
     a = ap.parse_args()
@@ -593,6 +645,9 @@ def main():
                 if "cpu_baseline" in out and out["cpu_baseline"].get("kind") == "reference":
                     out["e2e"]["over_cpu_baseline"] = out["e2e"]["value"] / out["cpu_baseline"]["value"]
                     out["e2e"]["stages_cpu"] = REF_STAGES
+            if not a.no_wavefront and is_c4:
+                out["wavefront"] = wavefront_leg(torch, hevcdl_amd, dev, local, (yuv, labels, records, recon, stats), Fr, W, H, qp, ctus, barrier,
+                                                 check=(not a.no_cpu_baseline and os.path.exists(REF_ENC) and a.cpu_baseline != "port"))
             del yuv, labels, records, recon, stats
             enc.close()
             torch.cuda.empty_cache()
@@ -625,6 +680,8 @@ def main():
                                            "stages_cpu": REF_STAGES, "stages_gpu": GPU_STAGES}
                     c2["gpu_over_cpu"] = c2["value"] / c2["cpu_reference"]["value"]
                 out["c2"] = c2
+                if "wavefront" in out and "cpu_reference" in c2:      # (the reference's own time does not depend on the key: one process per frame either way)
+                    out["wavefront"]["c2"]["gpu_over_cpu_reference_default_cfg"] = out["wavefront"]["c2"]["value"] / c2["cpu_reference"]["value"]
                 e3.close()
         print(json.dumps(out), flush=True)
     if world > 1 or rank != 0:

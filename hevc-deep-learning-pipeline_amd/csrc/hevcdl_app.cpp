@@ -386,7 +386,7 @@ int main(int argc, char **argv)
       i = -1; break;
     }
     if (i < 0) continue;
-    if (st == HEVCDL_ERR_INVALID_ARG) { fprintf(stderr, "Error: hevcdl_create rejected the configuration as invalid (e.g. tiles narrower than 4 CTUs or lower than 1 CTU, TComPicSym.cpp:380-392)\n"); return 2; }
+    if (st == HEVCDL_ERR_INVALID_ARG) { fprintf(stderr, "Error: hevcdl_create rejected the configuration as invalid (e.g. tiles, which must be at least 4 CTUs wide and 1 CTU high: TComPicSym.cpp:380-392)\n"); return 2; }
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: hevcdl_create failed on device %d with status %d (no GPU / unsupported configuration); there is no CPU path\n", shards[i].dev, (int)st); return 3; }
   }
   const int chunk = (int)std::max<long>(1, std::min<long>(batch, opt.geti("ChunkFrames", 48)));
