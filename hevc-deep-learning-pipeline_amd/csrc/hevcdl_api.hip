@@ -68,6 +68,7 @@ struct hevcdl_ctx {
   unsigned char *d_sao_stats, *d_sao_recon, *d_sao_params, *d_sao_cand;
   unsigned char *d_wide;                 // 16-bit staging of hevcdl_*_planes with sample_bytes 2 on an 8-bit context   // SAO workspace
   int *d_flag;                   // device-side error flag of the label check
+  int wpp_ring; size_t wpp_state_bytes;
   unsigned char *d_wpp;          // WaveFrontSynchro: [max_frames][ctus_y] 256 bytes (the contexts behind a row's second CTU, the row's finished-CTU count: rd_kernel.hip)
   unsigned char *d_sched;        // decision kernel: hand-over of units between workgroups (finished counter, per-workgroup unit counts, mailboxes)
   bool profile;
@@ -290,7 +291,11 @@ extern "C" hevcdl_status hevcdl_create(const hevcdl_config *cfg, const float *we
   CK(hipMalloc(&ctx->d_flag, sizeof(int)));
   CK(hipMalloc(&ctx->d_sched, 8192 + 1024 * 192));
   ctx->d_wpp = nullptr;
-  if (cfg->wavefront) CK(hipMalloc(&ctx->d_wpp, (size_t)256 * ctx->ctus_y * cfg->max_frames));
+  if (cfg->wavefront) { // per (frame, row) 256 bytes, then the queue of claimable rows: 1024 bytes of counters + a ring of one int per frame (rounded up to a power of two)
+    ctx->wpp_ring = 64; while (ctx->wpp_ring < cfg->max_frames) ctx->wpp_ring <<= 1;
+    ctx->wpp_state_bytes = (size_t)256 * ctx->ctus_y * cfg->max_frames;
+    CK(hipMalloc(&ctx->d_wpp, ctx->wpp_state_bytes + 1024 + (size_t)4 * ctx->wpp_ring));
+  }
   if (cfg->bit_depth > 8) CK(hipMalloc(&ctx->d_yuv8, hevcdl_frame_bytes(cfg->width, cfg->height) * (size_t)cfg->max_frames));    // the CNN stage's 8-bit copy
   CK(hipMalloc(&ctx->d_weights, sizeof(float) * HEVCDL_W_TOTAL));
   CK(hipMemcpy(ctx->d_weights, pk.data(), sizeof(float) * HEVCDL_W_TOTAL, hipMemcpyHostToDevice));
@@ -439,7 +444,9 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (ctx->cfg.wavefront) {
     if (!whole_launch) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "WaveFrontSynchro: only whole-frame launches (no per-CTU session, no tile range)");
     p.wpp = (ctx->cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) ? 2 : 1; p.wpp_state = ctx->d_wpp; p.tile_count = p.wpp == 1 ? ctx->ctus_y : 1;
+    p.wpp_queue = ctx->d_wpp + ctx->wpp_state_bytes; p.wpp_ring = ctx->wpp_ring;
     HIPCHK(hipMemsetAsync(ctx->d_wpp, 0, (size_t)256 * ctx->ctus_y * n_frames, s));
+    HIPCHK(hipMemsetAsync(p.wpp_queue, 0, 1024 + (size_t)4 * ctx->wpp_ring, s));
   }
   if (d_stats) HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(hevcdl_frame_stats) * (size_t)n_frames, s));     // the tile waves of a frame add into its entry
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
@@ -457,7 +464,12 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
 #endif
   // One workgroup (hevcdl_rd_waves_per_group() wavefronts, the whole LDS) per CU; the units (frame x tile) are dealt round-robin to the
   // workgroups, a wave per unit; waves left without a unit help the others (rd_kernel.hip).
-  const int n_units = n_frames * p.tile_count, groups = std::min(n_units, ctx->rd_groups);
+  const int n_units = n_frames * p.tile_count;
+  // WaveFrontSynchro, rows on waves of their own: rows are claimed as they become startable, so what sizes the launch is not the number of rows but how many of them can be
+  // under way at once -- a row starts two CTUs behind the row above, i.e. at most (ctus_x + 1) / 2 rows of a frame (+ 1: one being claimed) -- `walkers`
+  const long long walkers = p.wpp == 1 ? (long long)n_frames * std::min(ctx->ctus_y, (ctx->ctus_x + 1) / 2 + 1) : (long long)n_units;
+  const int groups = (int)std::min<long long>(walkers, ctx->rd_groups);
+  p.master_groups = (int)std::min<long long>(walkers, 1 << 30);
   // Uneven dealing (e.g. 600 frames on 256 workgroups): the surplus units travel round the ring of workgroups so that every workgroup --
   // and every frame -- is crowded for the same share of the time (rd_kernel.hip, process_unit).  Only for whole-unit launches of a few units
   // per workgroup.
@@ -473,15 +485,15 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   }
   // Few units (one frame, ten, a GPU's share of a sharded job): a frame is bound by the work of its CU's eight waves while most CUs have nothing to do -> the
   // kernel runs on ALL CUs and the workgroups without a unit take the second luma passes the others post (rd_kernel.hip, remote_post / remote_serve)
-  p.remote = (!p.migrate && ctx->remote_groups && 3 * n_units <= 2 * ctx->remote_groups && !d_cabac_in && !d_cabac_out && ctu_begin == 0 && p.ctu_end == ctx->ctus) ? 1 : 0;
+  p.remote = (!p.migrate && p.wpp != 2 && ctx->remote_groups && 3 * walkers <= 2 * ctx->remote_groups && !d_cabac_in && !d_cabac_out && ctu_begin == 0 && p.ctu_end == ctx->ctus) ? 1 : 0;
   // more units than takers (up to two units per taker; measured on 256 CUs: 150 frames 3.89 -> 3.79 s, 200 frames 3.92 -> 4.00 s, hence the limit): a pass is
   // posted only while a taker is free (rd_kernel.hip, remote_room)
-  if (p.remote && 2 * n_units > ctx->remote_groups) p.remote = 3;
+  if (p.remote && 2 * walkers > ctx->remote_groups) p.remote = 3;
   // very few units: enough idle workgroups for the chroma modes of every master as well (eleven jobs per unit in flight).  Measured on 256 CUs, chroma jobs posted /
   // kept in the unit's own workgroup: 1 frame 2.84 / 3.10 s, 10 frames 2.95 / 3.17 s, 16 frames 3.38 / 3.18 s -- hence a twenty-second of the CUs, not a sixteenth
-  if (p.remote && 22 * n_units <= ctx->remote_groups) p.remote = 2;
+  if (p.remote && 22 * walkers <= ctx->remote_groups) p.remote = 2;
   // the ring of posted jobs has 2048 entries (rd_kernel.hip RQ_SIZE): a unit has at most two passes and the ten component jobs of its chroma modes posted
-  if (p.remote && 12 * n_units > 2048) p.remote = 0;
+  if (p.remote && 12 * walkers > 2048) p.remote = 0;
   if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 4096 + 2048 * 8, s));      // finished counter, queue head / tail, the ring (2048 pointers behind byte 4096)
   // Which build of the 8-bit kernel.  Measured at 2160p on 256 CUs, eight- / ten-wave build (rd_kernel_wide.hip: 168 registers per lane instead of 256, no look-ahead
   // region): 200 frames 3.53 / 4.21 s, 300 frames 4.16 / 4.59 s, 450 frames 5.17 / 5.21 s, 600 frames 6.24 / 6.11 s, 1024 frames 10.33 / 9.50 s, 2048 frames
@@ -492,10 +504,11 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   const bool rt_tools = ctx->cfg.bit_depth == 8 && ctx->cfg.tools != HEVCDL_TOOLS_REFERENCE;
   bool wide = false;
   if (ctx->cfg.bit_depth == 8 && !rt_tools && !(ctx->cfg.exec_flags & HEVCDL_EXEC_RD_NARROW))
-    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && n_units >= 3 * groups);      // round 5, eight- / ten-wave build on 256 CUs: 450 frames 4.80 / 4.87 s, 600 frames 5.76 / 5.70 s, 768 frames 7.00 / 6.87 s, 1024 frames 9.44 / 8.78 s
+    wide = (ctx->cfg.exec_flags & HEVCDL_EXEC_RD_WIDE) || (!p.remote && walkers >= 3LL * groups);      // round 5, eight- / ten-wave build on 256 CUs: 450 frames 4.80 / 4.87 s, 600 frames 5.76 / 5.70 s, 768 frames 7.00 / 6.87 s, 1024 frames 9.44 / 8.78 s
   if (wide) p.remote = 0;      // (the ten-wave build together with the hand-over of units: launches of more than three and fewer than four units per workgroup, or exec_flags; tests/test_rd_gpu.py::test_units_handed_over_between_workgroups_give_the_same_result runs the pair)
   const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
   const int threads = 64 * waves;
+  if (p.wpp == 1) p.wpp_masters = p.remote ? 1 : (int)std::min<long long>(waves, (walkers + groups - 1) / groups);       // waves of a workgroup that claim rows (the rest help them)
   const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (rt_tools ? (const void *)hevcdl_rd_frame_kernel_tools : (const void *)hevcdl_rd_frame_kernel)) : (const void *)hevcdl_rd_frame_kernel_bd10;
   const size_t smem = ctx->cfg.bit_depth == 8 ? (wide ? hevcdl_rd_smem_bytes_wide() : (rt_tools ? hevcdl_rd_smem_bytes_tools() : hevcdl_rd_smem_bytes())) : hevcdl_rd_smem_bytes_bd10();
   { // the workspace: one block per wave of every workgroup of this launch

@@ -108,6 +108,13 @@ struct hevcdl_rd_params {
   // the contexts behind the row's second CTU (TEncSlice.cpp:925-928) at 0, the number of finished CTUs of the row at 192 (zeroed by the host before the launch)
   int wpp;
   unsigned char *wpp_state;
+  // wpp == 1: rows are CLAIMED, not dealt -- a row becomes claimable when the row above has finished the CTU above and to the right of its first one (a ring of ready rows in
+  // HBM), a wave without a unit takes a ready row or else the first row of a frame nobody has started; no wave ever holds a slot for a row that cannot start.
+  // wpp_masters: waves of a workgroup that claim (the rest help); wpp_queue: ints -- [0] next frame, [32] ring head, [64] ring tail, [96] rows claimed, ring of wpp_ring
+  // entries (a power of two >= n_frames: a frame has at most one ready row at a time) from [256]; zeroed by the host
+  int wpp_masters, wpp_ring;
+  unsigned char *wpp_queue;
+  int master_groups;               // workgroups that walk units: in the few-units form the workgroups from this index on take the jobs the others post (without wpp: the number of units)
   hevcdl_rd_consts k;
 };
 

@@ -4293,6 +4293,28 @@ DEV void slice_start_contexts(LCabac *c, int qp)
   if (lane == 0) { c->ctx[159] = 0; c->frac = 0; }
 }
 
+// WaveFrontSynchro, rows claimed (hevcdl_dev.h wpp_masters): -> a unit (frame * ctus_y + row) this wave now owns, -1: nothing can start right now, -2: every row has an owner.
+// Ready rows first (their frame is under way), then the first row of a frame nobody has started.
+DEVN int wpp_claim(const hevcdl_rd_params &p, int n_units)
+{
+  int r = -1;
+  if (lane_id() == 0) {
+    GLB int *q = (GLB int *)p.wpp_queue;
+    int h = __hip_atomic_load(q + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int v = __hip_atomic_load(q + 256 + (h & (p.wpp_ring - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v && __hip_atomic_compare_exchange_strong(q + 32, &h, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      __hip_atomic_store(q + 256 + (h & (p.wpp_ring - 1)), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (head == h when v was read non-zero: the entry of this lap)
+      r = v - 1;
+    } else if (__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_frames) {
+      const int f = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (f < p.n_frames) r = f * p.ctus_y;
+    }
+    if (r >= 0) __hip_atomic_fetch_add(q + 96, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (__hip_atomic_load(q + 96, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_units) r = -2;
+  }
+  return uni(r);
+}
+
 // -> 0: the unit is finished, 1: handed over to the next workgroup.  i_resume >= 0: continue a unit taken from this workgroup's mailbox.
 DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
 {
@@ -4469,7 +4491,14 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
       if (wpp == 1) {
         wsync();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_store((GLB int *)(wstate + (size_t)cy * 256 + 192), cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store((GLB int *)(wstate + (size_t)cy * 256 + 192), cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p.wpp_masters && cx + 1 == (tw >= 2 ? 2 : 1) && cy + 1 < p.ctus_y) { // the row below can start now: into the ring of ready rows (the count above is already out)
+            GLB int *q = (GLB int *)p.wpp_queue;
+            const int t = __hip_atomic_fetch_add(q + 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 256 + (t & (p.wpp_ring - 1)), frame * p.ctus_y + cy + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // unit + 1: zero marks an empty entry
+          }
+        }
       }
       wsync();
     }
@@ -4543,7 +4572,8 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   }
   // units are dealt round-robin: unit u belongs to workgroup u mod G, wave (u div G) mod NW
   const int n_units = p.n_frames * p.tile_count, G = (int)gridDim.x;
-  int first = (int)blockIdx.x + G * wave;
+  const int dyn = p.wpp == 1 && p.wpp_masters > 0;          // WaveFrontSynchro: rows are claimed as they become startable (wpp_claim), not dealt
+  int first = dyn ? n_units : (int)blockIdx.x + G * wave;
   if (p.migrate) { // the surplus units (beyond `base` per workgroup) start evenly spaced round the ring, not bunched in the first workgroups
     const int base = n_units / G, extra = n_units - base * G, g = (int)blockIdx.x;
     if (wave == base) { const int e = (g * extra + G - 1) / G; first = (e < extra && (e * G) / extra == g) ? base * G + e : n_units; }
@@ -4554,7 +4584,9 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   if (lane == 0) { s.bound_reg = 0; s.bound_child = -1; s.rp_pair = nullptr; s.chroma_jobs = 5; }
   if (wave == 0) { // the workgroup's shared part: read-only tables (z-scan map, CABAC tables, scans), master count
     init_tables(sh.tab);
-    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x)); sh.masters_active = m;
+    if (lane == 0) { int m = 0; for (int w = 0; w < NW; w++) m += ((int)blockIdx.x + G * w) < n_units; if (p.migrate) m = glb_load_lane0(sched_count(p, (int)blockIdx.x));
+                     if (dyn) m = (int)blockIdx.x < p.master_groups ? (p.wpp_masters < NW ? p.wpp_masters : NW) : 0;
+                     sh.masters_active = m;
                      sh.quit = 0; sh.bell = 0; sh.remote = p.remote; sh.sched = (GLB unsigned char *)p.sched; }
   }
 #ifdef HEVCDL_KERNEL_PROF
@@ -4562,7 +4594,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   const unsigned long long prof_start_ = __builtin_readcyclecounter();
 #endif
   __syncthreads();
-  if (p.remote && (int)blockIdx.x >= n_units) { // a workgroup without units: wave 0 takes second passes other workgroups post, the other waves serve its regions
+  if (p.remote && (int)blockIdx.x >= p.master_groups) { // a workgroup without units: wave 0 takes second passes other workgroups post, the other waves serve its regions
     if (wave == 0 && lane == 0) __hip_atomic_fetch_add(rq_idle((GLB unsigned char *)p.sched), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int seen = -1;
     for (;;) {
@@ -4583,7 +4615,13 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
   // a wave walks a unit (master) or serves the workgroup's regions (helper); with p.migrate units arrive and leave through the mailboxes
   int unit = first < n_units ? first : -1, i_resume = -1;
   int seen = -1, since_check = 0;          // seen: the doorbell's count when this wave last walked the tickets and found no task (ring_bell)
+  bool can_claim = dyn && (int)blockIdx.x < p.master_groups && wave < p.wpp_masters;
   for (;;) {
+    if (can_claim && unit < 0) {
+      const int c = wpp_claim(p, n_units);
+      if (c >= 0) { unit = c; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+      else if (c == -2) { can_claim = false; wg_release(); lds_add(&sh.masters_active, -1); }
+    }
     if (unit >= 0) {
       PROF_T0();
 #ifdef HEVCDL_MASTER_PRIO
@@ -4595,6 +4633,7 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
 #endif
       PROF_ADD(0, 31);
       int next = -1;
+      if (dyn) { if (p.remote) glb_add(sched_finished(p), 1); unit = -1; i_resume = -1; continue; }      // (the wave stays a claimer: masters_active counts it until every row has an owner)
       if (!moved) {
         if (p.migrate) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); glb_add(sched_count(p, (int)blockIdx.x), -1); glb_add(sched_finished(p), 1); }
         else if (p.remote) glb_add(sched_finished(p), 1);               // (every pass this unit posted has been joined)
@@ -4618,6 +4657,11 @@ void RD_SYM(hevcdl_rd_frame_kernel)(hevcdl_rd_params p)
       }
       since_check--;
     } else if (lds_load(&sh.masters_active) <= 0) break;
+    if (can_claim) { // nothing can start right now: serve the workgroup's regions if there are tasks, look again in a few microseconds (the ring's words are shared by every idle wave of the chip)
+      PROF_T0();
+      if (!helper_step()) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); PROF_ADD(0, 23); }
+      continue;
+    }
     { PROF_T0();
       const int b = lds_load(&sh.bell);
       if (HELPER_BELL && b == seen) { __builtin_amdgcn_s_sleep(HEVCDL_IDLE_SLEEP); PROF_ADD(0, 23); }
