@@ -494,6 +494,7 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (p.remote && 22 * walkers <= ctx->remote_groups) p.remote = 2;
   // the ring of posted jobs has 2048 entries (rd_kernel.hip RQ_SIZE): a unit has at most two passes and the ten component jobs of its chroma modes posted
   if (p.remote && 12 * walkers > 2048) p.remote = 0;
+  if (p.remote && p.wpp == 1) { const char *e = getenv("HEVCDL_WPP_REMOTE"); if (e && atoi(e) >= 1 && atoi(e) <= 3) p.remote = atoi(e); }      // (measurement knob)
   if (p.remote) HIPCHK(hipMemsetAsync(ctx->d_sched, 0, 4096 + 2048 * 8, s));      // finished counter, queue head / tail, the ring (2048 pointers behind byte 4096)
   // Which build of the 8-bit kernel.  Measured at 2160p on 256 CUs, eight- / ten-wave build (rd_kernel_wide.hip: 168 registers per lane instead of 256, no look-ahead
   // region): 200 frames 3.53 / 4.21 s, 300 frames 4.16 / 4.59 s, 450 frames 5.17 / 5.21 s, 600 frames 6.24 / 6.11 s, 1024 frames 10.33 / 9.50 s, 2048 frames
@@ -508,7 +509,14 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   if (wide) p.remote = 0;      // (the ten-wave build together with the hand-over of units: launches of more than three and fewer than four units per workgroup, or exec_flags; tests/test_rd_gpu.py::test_units_handed_over_between_workgroups_give_the_same_result runs the pair)
   const int waves = ctx->cfg.bit_depth != 8 ? hevcdl_rd_waves_per_group() : (wide ? hevcdl_rd_waves_per_group_wide() : hevcdl_rd_waves_per_group());
   const int threads = 64 * waves;
-  if (p.wpp == 1) p.wpp_masters = p.remote ? 1 : (int)std::min<long long>(waves, (walkers + groups - 1) / groups);       // waves of a workgroup that claim rows (the rest help them)
+  // Waves of a workgroup that claim rows (the rest help them).  A frame's rows form a chain of ctus_x + 2 (ctus_y - 1) CTU steps; a step takes a claimer ~1.5 ms with seven
+  // helpers and ~8 ms without any (t(m) ~ 0.75 + 0.75 m ms at m claimers per workgroup, measured on 600-frame launches: profiles/r06d_wavefront_masters.txt), while the
+  // chip's rate grows with m (216 k CTU/s at 2 ... 313 k at 10).  A launch is bound by that chain until the work per claimer exceeds it: m = 0.7 x (CTUs of the launch) /
+  // (workgroups x chain), at least 1, at most every wave.  Measured at 2160p, 75 frames: m = 3 0.79 s, m = 10 0.98 s; 150 frames: flat from 6 up (1.32 - 1.34 s); 600 frames:
+  // m = 10 3.91 s, m = 6 4.54 s, m = 3 5.06 s.
+  if (p.wpp == 1) { const long long chain = ctx->ctus_x + 2LL * (ctx->ctus_y - 1);
+                    p.wpp_masters = p.remote ? 1 : (int)std::max<long long>(1, std::min<long long>(waves, (7LL * n_frames * ctx->ctus) / (10LL * groups * chain))); }
+  if (p.wpp == 1 && !p.remote) { const char *e = getenv("HEVCDL_WPP_MASTERS"); if (e && atoi(e) > 0) p.wpp_masters = std::min(waves, atoi(e)); }      // (measurement knob: tools/time_rd.py sweeps)
   const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (rt_tools ? (const void *)hevcdl_rd_frame_kernel_tools : (const void *)hevcdl_rd_frame_kernel)) : (const void *)hevcdl_rd_frame_kernel_bd10;
   const size_t smem = ctx->cfg.bit_depth == 8 ? (wide ? hevcdl_rd_smem_bytes_wide() : (rt_tools ? hevcdl_rd_smem_bytes_tools() : hevcdl_rd_smem_bytes())) : hevcdl_rd_smem_bytes_bd10();
   { // the workspace: one block per wave of every workgroup of this launch
