@@ -12,7 +12,8 @@ W,H=%s,%s
 yuv=ref_tools.synth_yuv(W,H,1,seed=1)
 F=int(sys.argv[3]) if len(sys.argv)>3 else 1
 yuv=np.concatenate([ref_tools.synth_yuv(W,H,min(F,4),seed=1)]*((F+3)//4))[:F]
-enc=hevcdl_amd.Encoder(W,H,32,max_frames=F); lab=enc.predict_depth(yuv); enc.compress_frames(yuv,lab); enc.close()
+import os
+enc=hevcdl_amd.Encoder(W,H,32,max_frames=F,wavefront=bool(os.environ.get('PROF_WAVEFRONT'))); lab=enc.predict_depth(yuv); enc.compress_frames(yuv,lab); enc.close()
 """%(sys.argv[1],sys.argv[2])
 code=code.replace("sys.argv[3]", repr(sys.argv[3]) if len(sys.argv)>3 else "'1'").replace("len(sys.argv)>3","True")
 out=subprocess.run([sys.executable,'-c',code],env=dict(os.environ,HEVCDL_LIB=os.environ.get('PROF_LIB','/root/repo/hevc-deep-learning-pipeline_amd/lib/libhevcdl_hip_prof.so')),capture_output=True,text=True)

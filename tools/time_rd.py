@@ -13,10 +13,14 @@ for a in sys.argv[1:]:
     if a.startswith('--flags='):
         flags = int(a[8:])          # hevcdl_config.exec_flags: 1 independent form only, 2 / 4 the ten- / eight-wave build of the kernel
 wavefront = '--wavefront' in sys.argv[1:]      # WaveFrontSynchro 1: CTU rows as units of the launch
+tools = 0x7f
+for a in sys.argv[1:]:
+    if a.startswith('--tools='):
+        tools = int(a[8:], 0)        # hevcdl_config.tools: a mask other than 0x7f runs the build of the kernel that reads the switches at run time (csrc/rd_kernel_tools.hip)
 counts = [int(a) for a in args] or [1, 75, 600]
 nmax = max(counts)
 base = ref_tools.synth_yuv(W, H, 4, seed=4000)
-cfg = hevcdl_amd.default_config(W, H, 32, max_frames=nmax, wavefront=wavefront)
+cfg = hevcdl_amd.default_config(W, H, 32, max_frames=nmax, wavefront=wavefront, tools=tools)
 cfg.exec_flags = flags
 enc = hevcdl_amd.Encoder(W, H, 32, cfg=cfg)
 fb = hevcdl_amd.frame_bytes(W, H) if hasattr(hevcdl_amd, 'frame_bytes') else W * H * 3 // 2
