@@ -544,6 +544,17 @@ def main():
         del yw, tw
         ew.close()
         torch.cuda.empty_cache()
+    # ... and the job itself once more with WaveFrontSynchro 1 (extra key, not the headline: DESIGN.md section 5e): the rank's share of the job's frames, rows as units
+    wave_n = None
+    if world > 1 and not a.no_wavefront:
+        ewf = hevcdl_amd.Encoder(W, H, qp, max_frames=max(1, per_rank), device=local, wavefront=True)
+        elf, prf = timed_steps(torch, ewf, (yuv, labels, records, recon, stats), Fr, 1, 1, barrier)
+        tmax = torch.tensor([elf], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wave_n = {"cfg": "WaveFrontSynchro 1 (all other keys as the headline)", "scaling": "strong", "n_gpus": world, "frames": F, "seconds": float(tmax.item()), "value": F * ctus / float(tmax.item()),
+                  "unit": "CTUs/s", "kernel_ms_rank0": prf["rd_ms"], "launch": ewf.last_rd_launch(), "note": "1 warm-up + 1 timed step between barriers, max over ranks"}
+        ewf.close()
+        torch.cuda.empty_cache()
 
     if rank == 0:
         total_ctus = F * ctus * a.steps
@@ -611,6 +622,8 @@ def main():
             torch.cuda.synchronize(dev)
         if weak is not None:
             out["weak"] = weak
+        if wave_n is not None:
+            out["wavefront"] = wave_n
         if floor_s:
             out["latency_floor_s"] = floor_s
             out["strong_scaling_ceiling"] = {"value": F * ctus / floor_s, "unit": "CTUs/s",

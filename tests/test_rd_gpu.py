@@ -326,6 +326,8 @@ def test_bench_two_ranks_on_one_gpu_give_the_single_rank_line(tmp_path):
     assert one["roofline"]["launch"].startswith(one["roofline"]["kernel"] + " form=") and "units=6" in one["roofline"]["launch"] and "units=3" in two["roofline"]["launch"]
     # weak scaling beside the strong headline: every rank ran a 4-frame step of its own (N > 1 only)
     assert "weak" not in one and two["weak"]["n_gpus"] == 2 and two["weak"]["frames_per_gpu"] == 4 and two["weak"]["value"] > 0 and "units=4" in two["weak"]["launch"]
+    # ... and the job once more with WaveFrontSynchro 1 (extra key): the ranks' shares with CTU rows as units
+    assert two["wavefront"]["n_gpus"] == 2 and two["wavefront"]["value"] > 0 and "form=wavefront-rows" in two["wavefront"]["launch"] and "units=9" in two["wavefront"]["launch"]
     assert "issue" in one["roofline"]                            # the instruction-issue bound (None unless a counter pass of this kernel source and launch shape is committed)
     for line in (one, two):
         assert line["value"] > 0 and line["latency_floor_s"] > 0 and line["strong_scaling_ceiling"]["value"] > 0 and "roofline" in line
