@@ -307,7 +307,7 @@ E2E_STAGES = ("on-device label CNN + CTU decisions + deblocking + SAO, frames re
               "chunk is copied; streams and pictures stay in memory (no file I/O, no process start-up)")
 
 
-def e2e_leg(torch, hevcdl_amd, dev, enc, tensors, n_frames, width, height, qp, chunk=60):
+def e2e_leg(torch, hevcdl_amd, dev, enc, tensors, n_frames, width, height, qp, chunk=60, wavefront=False):
     """The job once more through the WHOLE picture pipeline -- the stages the CPU baseline's number contains (TEncGOP.cpp:1742-1935: decisions, in-loop filters,
     entropy coding), the label CNN on top: one like-for-like throughput.  The device side is one batch (a smaller batch is no faster: a frame is a serial
     chain); the host codes chunk k on its threads while chunk k + 1 is copied."""
@@ -326,6 +326,7 @@ def e2e_leg(torch, hevcdl_amd, dev, enc, tensors, n_frames, width, height, qp, c
     if lib.hevcdl_stream_config_default(ctypes.byref(cfg), width, height, qp) != 0:
         raise RuntimeError("stream config")
     cfg.sao_enabled = 1
+    cfg.wavefront = 1 if wavefront else 0          # (records of a context with WaveFrontSynchro 1: a sub-stream per CTU row)
     cap = lib.hevcdl_access_unit_bound(width, height)
     outs = [np.empty(cap, np.uint8) for _ in range(threads)]
     free = list(range(threads))
@@ -419,6 +420,7 @@ def wavefront_leg(torch, hevcdl_amd, dev, local, tensors, n_frames, width, heigh
         par = parity_against_dumps(dumps, rec_w, list(recon[:nw].cpu().numpy()), width, height)
         par["sample"] = "%d WHOLE %dx%d frames of the 600-frame wavefront step against the reference run with --WaveFrontSynchro=1, %.1f s" % (nw, width, height, time.time() - t1)
         out["parity_check"] = par
+    out["e2e"] = e2e_leg(torch, hevcdl_amd, dev, enc, tensors, n_frames, width, height, qp, wavefront=True)      # the whole picture pipeline with the key, as the headline's e2e
     enc.close()
     # C2 with the key: 10 frames of 1080p
     w2, h2, n2 = 1920, 1080, 10
