@@ -314,7 +314,7 @@ int main(int argc, char **argv)
     if (free_b > 0) { double mine = (double)free_b * 0.8 / (shared_device ? (double)devices.size() : 1.0);       // (contexts that share a device share its memory)
       if (mine > 2.0 * (double)workspace) mine -= (double)workspace;
       dev_cap = std::max<long>(1, (long)mine / per_picture_dev); } }
-  const long auto_batch = std::max<long>(1, std::min<long>(std::min<long>(wavefront ? std::max<long>(1, 4096 / ((height + 63) / 64)) : 2048 / (tile_cols * tile_rows), dev_cap), (24L << 30) / (long)frame_bytes));
+  const long auto_batch = std::max<long>(1, std::min<long>(std::min<long>(2048 / (tile_cols * tile_rows), dev_cap), (24L << 30) / (long)frame_bytes));
   const long even_batch = (per_shard + ((per_shard + auto_batch - 1) / auto_batch) - 1) / ((per_shard + auto_batch - 1) / auto_batch);
   int batch = (int)std::min<long>(per_shard, std::max<long>(1, opt.geti("BatchFrames", even_batch)));
 

@@ -14,3 +14,4 @@ bash tools/r05_pmc.sh kernel 256 > gpurun_out/${TAG}_pmc256.log 2>&1; cp gpurun_
 bash tools/r05_pmc.sh kernel 2560 > gpurun_out/${TAG}_pmc2560.log 2>&1; cp gpurun_out/prof/r05pmc_k2560.txt gpurun_out/${TAG}_pmc_k2560.txt
 timeout 300 python tools/time_rd.py 1 75 600 --tools=0x6b > gpurun_out/${TAG}_time_tools_build.txt 2>&1; timeout 300 python tools/time_rd.py 1 75 600 >> gpurun_out/${TAG}_time_tools_build.txt 2>&1
 grep hevcdl_rd gpurun_out/${TAG}_pmc_k600.txt | cut -c1-200
+du -sh gpurun_out

@@ -28,3 +28,4 @@ else
   python tools/rocpd_summary.py $dirs > gpurun_out/prof/r05pmc_k$FR.txt 2>&1
   grep "hevcdl_rd" gpurun_out/prof/r05pmc_k$FR.txt | cut -c1-200
 fi
+rm -rf $dirs          # (the rocpd databases: summarised above; gpurun_out/ only travels back up to 64 MiB)
