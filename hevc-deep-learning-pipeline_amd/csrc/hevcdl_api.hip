@@ -516,8 +516,6 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // m = 10 3.91 s, m = 6 4.54 s, m = 3 5.06 s.
   if (p.wpp == 1) { const long long chain = ctx->ctus_x + 2LL * (ctx->ctus_y - 1);
                     p.wpp_masters = p.remote ? 1 : (int)std::max<long long>(1, std::min<long long>(waves, (7LL * n_frames * ctx->ctus) / (10LL * groups * chain))); }
-  p.wpp_lag = 2;
-  if (p.wpp == 1) { const char *e = getenv("HEVCDL_WPP_LAG"); if (e && atoi(e) >= 2) p.wpp_lag = atoi(e); }      // (measurement knob)
   if (p.wpp == 1 && !p.remote) { const char *e = getenv("HEVCDL_WPP_MASTERS"); if (e && atoi(e) > 0) p.wpp_masters = std::min(waves, atoi(e)); }      // (measurement knob: tools/time_rd.py sweeps)
   const void *kern = ctx->cfg.bit_depth == 8 ? (wide ? (const void *)hevcdl_rd_frame_kernel_wide : (rt_tools ? (const void *)hevcdl_rd_frame_kernel_tools : (const void *)hevcdl_rd_frame_kernel)) : (const void *)hevcdl_rd_frame_kernel_bd10;
   const size_t smem = ctx->cfg.bit_depth == 8 ? (wide ? hevcdl_rd_smem_bytes_wide() : (rt_tools ? hevcdl_rd_smem_bytes_tools() : hevcdl_rd_smem_bytes())) : hevcdl_rd_smem_bytes_bd10();

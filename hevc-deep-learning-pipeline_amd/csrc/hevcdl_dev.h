@@ -113,7 +113,6 @@ struct hevcdl_rd_params {
   // wpp_masters: waves of a workgroup that claim (the rest help); wpp_queue: ints -- [0] next frame, [32] ring head, [64] ring tail, [96] rows claimed, ring of wpp_ring
   // entries (a power of two >= n_frames: a frame has at most one ready row at a time) from [256]; zeroed by the host
   int wpp_masters, wpp_ring;
-  int wpp_lag;                     // a row becomes claimable when the row above has finished this many CTUs (>= 2: what its first CTU needs; more: slack against the row above stalling it later)
   unsigned char *wpp_queue;
   int master_groups;               // workgroups that walk units: in the few-units form the workgroups from this index on take the jobs the others post (without wpp: the number of units)
   hevcdl_rd_consts k;

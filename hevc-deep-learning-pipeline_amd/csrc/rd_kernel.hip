@@ -4493,7 +4493,7 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) {
           __hip_atomic_store((GLB int *)(wstate + (size_t)cy * 256 + 192), cx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (p.wpp_masters && cx + 1 == (p.wpp_lag < tw ? p.wpp_lag : tw) && cy + 1 < p.ctus_y) { // the row below can start now: into the ring of ready rows (the count above is already out)
+          if (p.wpp_masters && cx + 1 == (tw >= 2 ? 2 : 1) && cy + 1 < p.ctus_y) { // the row below can start now: into the ring of ready rows (the count above is already out)
             GLB int *q = (GLB int *)p.wpp_queue;
             const int t = __hip_atomic_fetch_add(q + 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(q + 256 + (t & (p.wpp_ring - 1)), frame * p.ctus_y + cy + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // unit + 1: zero marks an empty entry
