@@ -226,26 +226,30 @@ def gen_rd_wpp():
             ("w128_q22_r", 128, 256, 1, 22, "rand", 84, 8),           # two CTUs wide: the sync state is the state behind the LAST CTU of the row above; noise (escapes, sign hiding)
             ("w416_q32_r", 416, 240, 1, 32, "rand", 85, 8),           # C1's picture size
             ("w384_q37_d1", 384, 256, 1, 37, 1, 86, 8),               # 32x32 CUs
-            ("w200_q30_b10", 200, 200, 1, 30, "rand", 87, 10)]        # 10-bit samples
+            ("w200_q30_b10", 200, 200, 1, 30, "rand", 87, 10),        # 10-bit samples
+            ("w192_q27_k", 192, 192, 1, 27, "rand", 88, 8)]           # with tool switches off as well (sign hiding, transform skip): the build of the kernel that reads them at run time
     for name, w, h, nf, qp, kind, seed, bd in spec:
+        tools = rt.TOOLS_REFERENCE & ~(rt.TOOL_SIGN_HIDE | rt.TOOL_TSKIP) if name.endswith("_k") else rt.TOOLS_REFERENCE
         yuv = rt.synth_yuv(w, h, nf, seed)
         if name.startswith("w128_q22"):
             yuv = np.random.default_rng(seed).integers(0, 256, yuv.shape).astype(np.uint8)
         if bd == 10:
             yuv = yuv.astype(np.uint16) * 4 + np.random.default_rng(seed).integers(0, 4, yuv.shape).astype(np.uint16)
         lab = rt.make_labels(w, h, nf, kind, seed + 100)
-        targs = ["--WaveFrontSynchro=1"]
+        targs = ["--WaveFrontSynchro=1"] + (rt.tool_args(tools) if tools != rt.TOOLS_REFERENCE else [])
+        if name.endswith("_k"):
+            yuv = np.clip(yuv.astype(np.int32) + np.random.default_rng(seed).integers(-24, 25, yuv.shape), 0, 255).astype(np.uint8)
         dump, out, bitstream, recon = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs, bit_depth=bd)
         dump2, _, bitstream_nosao, recon_dbk = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs + ["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)
         assert dump2.tobytes() == dump.tobytes()
-        dump0, _, _, _ = rt.run_reference(yuv, w, h, qp, lab, extra_args=["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)      # the same picture without the key: other decisions (the fixture is not vacuous)
+        dump0, _, _, _ = rt.run_reference(yuv, w, h, qp, lab, extra_args=targs[1:] + ["--SAO=0", "--SEIDecodedPictureHash=0"], bit_depth=bd)      # the same picture without the key: other decisions (the fixture is not vacuous)
         dump = dump[np.lexsort((dump["addr"], dump["frame"]))]
         dump0 = dump0[np.lexsort((dump0["addr"], dump0["frame"]))]
         nctu = lab.shape[1]
         assert len(dump) == nf * nctu
         differs = int(sum(not np.array_equal(a, b) for a, b in zip(dump["rec"], dump0["rec"])))
         summary = [ln for ln in out.splitlines() if ln.startswith("POC")]
-        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd, lf_across_tiles=1, tiles=np.array((1, 1)), wavefront=1,
+        np.savez_compressed(os.path.join(GOLD, "rd_%s.npz" % name), width=w, height=h, qp=qp, yuv=yuv, labels=lab, bit_depth=bd, lf_across_tiles=1, tiles=np.array((1, 1)), wavefront=1, **({"tools": tools} if tools != rt.TOOLS_REFERENCE else {}),
                             records=dump["rec"].reshape(nf, nctu), rec_y=dump["rec_y"].reshape(nf, nctu, 4096),
                             rec_cb=dump["rec_cb"].reshape(nf, nctu, 1024), rec_cr=dump["rec_cr"].reshape(nf, nctu, 1024),
                             bitstream=np.frombuffer(bitstream, np.uint8), recon_filtered=np.frombuffer(recon, np.uint8), recon_deblocked=np.frombuffer(recon_dbk, np.uint8), bitstream_nosao=np.frombuffer(bitstream_nosao, np.uint8),

@@ -167,7 +167,7 @@ def test_cli_on_several_devices_writes_the_single_device_stream_and_log(app, tmp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["w416_q32_r", "w200_q27_r2", "w128_q22_r", "w200_q30_b10", "b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10",
+@pytest.mark.parametrize("case", ["w416_q32_r", "w200_q27_r2", "w128_q22_r", "w200_q30_b10", "w192_q27_k", "b416_q32_r", "c192_q32_r2", "b200_q27_r2", "t520_q37_2x2", "x576_q30_2x3", "x192_q37_r2", "n832_q32_544x12", "n712_q27_b10", "l576_q32_lf0", "l520_q27_lf0_b10",
                                   "k128_q22_sbh0", "k128_q27_ts0", "k192_q32_sis0", "k200_q32_mpm0", "k200_q27_all0", "k128_q22_rdoq0", "k128_q27_rdoqts0", "k200_q32_rdoq0", "k200_q27_rdoq0_sbh0", "k128_q27_tsf0", "k200_q32_tsf0", "k200_q30_b10_mix0", "o192_q32_b2_tm1", "o200_q27_bm3_t3", "o128_q37_b6_tm6"])
 def test_cli_with_tiles_and_ten_bits_reproduces_the_reference_run(app, tmp_path, case):
     """b416_q32_r is C1 of BASELINE.json (416x240, one frame, QP32, untiled 8-bit, the reference's default configuration); c192 / b200 are

@@ -13,16 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_DEC = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder_ref")
 
 
-@pytest.mark.parametrize("w,h,nf,tiles,bd", [(192, 128, 5, "1x1", 8), (512, 128, 3, "2x2", 10)])
+@pytest.mark.parametrize("w,h,nf,tiles,bd", [(192, 128, 5, "1x1", 8), (512, 128, 3, "2x2", 10), (256, 192, 4, "wavefront", 8)])
 def test_sharded_encode_equals_single_process_and_cli(tmp_path, w, h, nf, tiles, bd):
     import hevcdl_amd
     import ref_tools
+    wavefront = tiles == "wavefront"          # WaveFrontSynchro 1 instead of tiles: a sub-stream per CTU row
+    tiles = "1x1" if wavefront else tiles
     yuv = ref_tools.synth_yuv(w, h, nf, seed=123)
     if bd == 10:
         yuv = yuv.astype(np.uint16) * 4 + np.random.default_rng(3).integers(0, 4, yuv.shape).astype(np.uint16)
     yuv.astype(np.uint8 if bd == 8 else "<u2").tofile(tmp_path / "in.yuv")
     script = os.path.join(ROOT, "tools", "encode_sharded.py")
-    common = ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", "30", "-f", str(nf), "--batch", "2", "--tiles", tiles, "--bit-depth", str(bd), "--hash"]
+    common = ["-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", "30", "-f", str(nf), "--batch", "2", "--tiles", tiles, "--bit-depth", str(bd), "--hash"] + (["--wavefront"] if wavefront else [])
     r1 = subprocess.run([sys.executable, script] + common + ["-b", "one.bin", "-o", "one.yuv"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -39,6 +41,8 @@ def test_sharded_encode_equals_single_process_and_cli(tmp_path, w, h, nf, tiles,
     extra = ["--TileUniformSpacing=1", "--NumTileColumnsMinus1=%d" % (tc - 1), "--NumTileRowsMinus1=%d" % (tr - 1), "--SEIDecodedPictureHash=1", "--Level=6.2"]
     if bd == 10:
         extra += ["--InputBitDepth=10", "--InternalBitDepth=10", "--Profile=main10"]
+    if wavefront:
+        extra += ["--WaveFrontSynchro=1"]
     r3 = subprocess.run([app, "-i", "in.yuv", "-wdt", str(w), "-hgt", str(h), "-q", "30", "-f", str(nf), "-b", "cli.bin", "-o", "cli.yuv"] + extra, cwd=tmp_path,
                         capture_output=True, text=True, timeout=600)
     assert r3.returncode == 0, r3.stdout[-2000:] + r3.stderr[-2000:]

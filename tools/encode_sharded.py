@@ -17,6 +17,7 @@ def main():
     ap.add_argument("-b", default=None); ap.add_argument("-o", default=None); ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--tiles", default="1x1"); ap.add_argument("--bit-depth", type=int, default=8); ap.add_argument("--level", type=float, default=6.2)
     ap.add_argument("--hash", action="store_true", help="SEIDecodedPictureHash 1 (MD5)")
+    ap.add_argument("--wavefront", action="store_true", help="WaveFrontSynchro 1 (frame shards only): a sub-stream per CTU row, rows as units of the decision kernel")
     ap.add_argument("--shard", default="frames", choices=["frames", "tiles"], help="frames: rank r codes a frame range; tiles: rank r decides its tiles of every picture")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the summary gather (gloo when ranks share a GPU)")
     a = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
                                               bit_depth=a.bit_depth, level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=say)
     else:
         pipeline.encode_sequence(a.i, a.wdt, a.hgt, a.q, a.f, a.b, a.o, frame_skip=a.fs, batch=a.batch, tiles=tiles, bit_depth=a.bit_depth,
-                                 level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=say)
+                                 level_idc=int(a.level * 30 + 0.5), hash_sei=a.hash, log=say, wavefront=a.wavefront)
     if world > 1:
         dist.destroy_process_group()
 
