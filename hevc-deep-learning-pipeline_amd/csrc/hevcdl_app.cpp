@@ -209,6 +209,7 @@ bool gather_rows_rccl(size_t n_blocks, const std::function<int(size_t)> &dev_of,
 
 int main(int argc, char **argv)
 {
+  const std::chrono::steady_clock::time_point t_main0 = std::chrono::steady_clock::now();
   Options opt;
   opt.parse_argv(argc, argv);
   // keys that define the path must carry the implemented value
@@ -389,6 +390,7 @@ int main(int argc, char **argv)
     if (st == HEVCDL_ERR_INVALID_ARG) { fprintf(stderr, "Error: hevcdl_create rejected the configuration as invalid (e.g. tiles, which must be at least 4 CTUs wide and 1 CTU high: TComPicSym.cpp:380-392)\n"); return 2; }
     if (st != HEVCDL_OK) { fprintf(stderr, "Error: hevcdl_create failed on device %d with status %d (no GPU / unsupported configuration); there is no CPU path\n", shards[i].dev, (int)st); return 3; }
   }
+  const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main0).count();      // options, weights, contexts, the decision kernel's workspace
   const int chunk = (int)std::max<long>(1, std::min<long>(batch, opt.geti("ChunkFrames", 48)));
 
   printf("HEVC-DL MI355X path: %dx%d  QP %d  frames %ld (skip %ld)  batch %d  labels: %s\n", width, height, qp, n_frames, frame_skip, batch,
@@ -580,8 +582,8 @@ int main(int argc, char **argv)
   }
   { double t_read = 0, t_dev = 0, t_host = 0, t_write = 0;
     for (const Shard &S : shards) { t_read = std::max(t_read, S.t_read); t_dev = std::max(t_dev, S.t_dev); t_host = std::max(t_host, S.t_host); t_write = std::max(t_write, S.t_write); }
-    fprintf(stderr, "stage seconds%s: read %.2f  device (upload + CNN + decisions + filters; its chunk copies run behind the host work) %.2f  host (entropy coding, hashes, %d threads) %.2f  write %.2f\n",
-            multi ? " (slowest device)" : "", t_read, t_dev, max_threads, t_host, t_write); }
+    fprintf(stderr, "stage seconds%s: set-up (contexts, workspace) %.2f  read %.2f  device (upload + CNN + decisions + filters; its chunk copies run behind the host work) %.2f  host (entropy coding, hashes, %d threads) %.2f  write %.2f  whole run %.2f\n",
+            multi ? " (slowest device)" : "", t_setup, t_read, t_dev, max_threads, t_host, t_write, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main0).count()); }
   if (rc == 0 && done > 0) { // TEncAnalyze::printOut, 4:2:0 layout
     const double mse_yuv = (4 * sum_mse[0] + sum_mse[1] + sum_mse[2]) / done / 6.0;
     printf("\n\nSUMMARY --------------------------------------------------------\n");
