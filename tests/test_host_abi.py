@@ -136,3 +136,29 @@ def test_k_slot_map_of_the_5x5_layers_covers_every_tap_once_without_bank_conflic
         for slot in range(80):
             if not (slot >> 2) & 1:
                 assert (off(tap[slot + 4]) - off(tap[slot])) % 32 == 16, (slot, tap[slot], tap[slot + 4])
+
+
+def test_issue_bound_file_is_keyed_to_the_shipped_kernel_and_adds_up():
+    """bench.py reports `roofline.issue` (the instruction-issue bound of the decision kernel) and `roofline.traffic` from profiles/r*_issue.json / r*_traffic.json while their
+    hash equals that of the shipped csrc/rd_kernel.hip: the newest committed files must carry that hash (a kernel edit without a new counter pass makes the line say "not
+    reported"), and the ceiling must follow from the counters the way tools/issue_json.py states (256 CUs x 4 SIMDs x 2.4 GHz / (VALU wave-instructions per CTU x 4 cycles))."""
+    import glob
+    import hashlib
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    sha = hashlib.sha256(open(bench.RD_KERNEL_SRC, "rb").read()).hexdigest()[:16]
+    issue = json.load(open(sorted(glob.glob(os.path.join(root, "profiles", "r*_issue.json")))[-1]))
+    traffic = json.load(open(sorted(glob.glob(os.path.join(root, "profiles", "r*_traffic.json")))[-1]))
+    assert issue["rd_kernel_sha16"] == sha and traffic["rd_kernel_sha16"] == sha
+    for frames in ("600", "2560"):
+        sh = issue["shapes"][frames]
+        assert abs(sh["ceiling_ctus_per_s"] - 256 * 4 * 2.4e9 / (sh["valu_per_ctu"] * 4)) < 1.0
+        assert 0.2 < sh["frac_under_counters"] < 1.0 and 16 < sh["lanes_enabled"] <= 64
+    got = bench.measured_issue(600, 234000.0)
+    assert got["frac"] is not None and abs(got["frac"] - 234000.0 / issue["shapes"]["600"]["ceiling_ctus_per_s"]) < 1e-9 and got["valu_per_ctu"] > 5e5
+    assert bench.measured_issue(123, 1.0)["frac"] is None                   # no counter pass on that launch shape: said so, not guessed
+    t, src = bench.measured_traffic(1224000)
+    assert t is not None and t > 27408 * 1224000
