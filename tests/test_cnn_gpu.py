@@ -1,5 +1,6 @@
 """GPU parity of the on-device CNN (through the C ABI) against the reference-generated fixtures and the numpy oracle."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -161,3 +162,38 @@ def test_label_stage_on_the_device_gives_the_reference_lines_on_30000_tuples(enc
     ties[2][:, [3, 0]] = 1.0
     ties[3][:, 2:4] = 2.0
     assert np.array_equal(enc.labels_from_logits(ties), cnn_oracle.labels_from_logits(ties))
+
+
+def test_sidecar_writes_the_label_files_of_the_reference_loop(tmp_path):
+    """The file-level drop-in for use_model.py (hevcdl_amd.sidecar): the whole pictures of tests/golden/cnn_f3.npz -- which the reference's own loop (use_model.py:72-125) turned
+    into label files -- are put where the reference expects its frames (rec/frames/<n>.jpg; stored losslessly, PIL reads by content, so the decoder hands over exactly the
+    fixture's RGB) and go through the sidecar: same directory layout, same file text (16 digits, a blank behind each), the reference's labels outside the logits' tie band."""
+    import io
+    from PIL import Image
+    import hevcdl_amd.sidecar as sidecar
+    f = np.load(os.path.join(GOLD, "cnn_f3.npz"))
+    n_pic = int(f["n_pictures"])
+    frames = tmp_path / "rec" / "frames"
+    os.makedirs(frames)
+    for n in range(n_pic):
+        buf = io.BytesIO(); Image.fromarray(f["rgb%d" % n]).save(buf, format="PNG")
+        (frames / ("%d.jpg" % (n + 1))).write_bytes(buf.getvalue())
+    (tmp_path / "bitstream.cfg").write_text("InputFile : in.yuv\nFramesToBeEncoded            : %d\n" % (n_pic - 1))
+    assert sidecar.frames_to_be_encoded(str(tmp_path / "bitstream.cfg")) == n_pic - 1
+    done = sidecar.label_frames(str(frames), str(tmp_path / "pred"), n_frames=n_pic - 1, log=lambda *a: None)
+    assert done == n_pic - 1 and sorted(os.listdir(tmp_path / "pred")) == [str(i) for i in range(n_pic - 1)]          # FramesToBeEncoded stops the loop (use_model.py:74-75)
+    for n in range(n_pic - 1):
+        ref_lab, ref_lg = f["labels%d" % n], f["logits%d" % n]
+        files = sorted(os.listdir(tmp_path / "pred" / str(n)), key=lambda s: int(s[3:-4]))
+        assert files == ["ctu%d.txt" % i for i in range(len(ref_lab))]
+        got = []
+        for name in files:
+            text = (tmp_path / "pred" / str(n) / name).read_text()
+            assert re.fullmatch(r"(\d ){16}", text), text
+            got.append([int(v) for v in text.split()])
+        got = np.array(got, np.uint8)
+        srt = np.sort(ref_lg.reshape(-1, 4, 4, 4), axis=-1)
+        safe = ((srt[..., -1] - srt[..., -2]) > 1e-2).all(axis=(1, 2))
+        assert safe.sum() >= len(ref_lab) // 2 and np.array_equal(got[safe], ref_lab[safe])
+    with pytest.raises(FileExistsError):                # labels of an old run are never mixed in (os.mkdir in the reference)
+        sidecar.label_frames(str(frames), str(tmp_path / "pred"), n_frames=1, log=lambda *a: None)

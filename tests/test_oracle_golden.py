@@ -227,3 +227,22 @@ def test_rd_oracle_rejects_bad_arguments(oracle_built):
     lib = ref_tools.oracle_lib()
     assert lib.hm_oracle_encode_frames(None, 100, 64, 1, 32, None, None, None, None) != 0     # width not a multiple of 8
     assert lib.hm_oracle_encode_frames(None, 64, 64, 1, 99, None, None, None, None) != 0      # QP out of range
+
+
+def test_sidecar_tiling_and_label_files(tmp_path):
+    """Host side of the file-level drop-in for use_model.py (hevcdl_amd.sidecar; the CNN itself needs the GPU: tests/test_cnn_gpu.py): its CTU tiling equals the oracle's
+    restatement of use_model.py:80-95 (pinned by cnn_f3.npz) on ragged pictures, and a label file reads back as the 16 digits it was given, in the reference's text form."""
+    import cnn_oracle
+    import hevcdl_amd.sidecar as sidecar
+    rng = np.random.default_rng(5)
+    for h, w in ((240, 416), (136, 200), (64, 64), (72, 130)):
+        rgb = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        assert np.array_equal(sidecar.rgb_picture_to_ctus(rgb), cnn_oracle.rgb_picture_to_ctus(rgb))
+    f = np.load(os.path.join(GOLD, "cnn_f3.npz"))
+    assert np.array_equal(sidecar.rgb_picture_to_ctus(f["rgb0"]), cnn_oracle.rgb_picture_to_ctus(f["rgb0"]))
+    labels = rng.integers(0, 4, (5, 16)).astype(np.uint8)
+    sidecar.write_label_files(str(tmp_path), 3, labels)
+    for i in range(5):
+        text = (tmp_path / "3" / ("ctu%d.txt" % i)).read_text()
+        assert text == "".join("%d " % v for v in labels[i]) and [int(v) for v in text.split()] == labels[i].tolist()
+    assert not (tmp_path / "3" / "ctu.txt").exists()
