@@ -661,8 +661,11 @@ def main():
                     out["e2e"]["over_cpu_baseline"] = out["e2e"]["value"] / out["cpu_baseline"]["value"]
                     out["e2e"]["stages_cpu"] = REF_STAGES
             if not a.no_wavefront and is_c4:
-                out["wavefront"] = wavefront_leg(torch, hevcdl_amd, dev, local, (yuv, labels, records, recon, stats), Fr, W, H, qp, ctus, barrier,
-                                                 check=(not a.no_cpu_baseline and os.path.exists(REF_ENC) and a.cpu_baseline != "port"))
+                try:      # (extra keys: whatever happens in this leg, the headline line is printed)
+                    out["wavefront"] = wavefront_leg(torch, hevcdl_amd, dev, local, (yuv, labels, records, recon, stats), Fr, W, H, qp, ctus, barrier,
+                                                     check=(not a.no_cpu_baseline and os.path.exists(REF_ENC) and a.cpu_baseline != "port"))
+                except Exception as exc:
+                    out["wavefront"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             del yuv, labels, records, recon, stats
             enc.close()
             torch.cuda.empty_cache()
@@ -695,7 +698,7 @@ def main():
                                            "stages_cpu": REF_STAGES, "stages_gpu": GPU_STAGES}
                     c2["gpu_over_cpu"] = c2["value"] / c2["cpu_reference"]["value"]
                 out["c2"] = c2
-                if "wavefront" in out and "cpu_reference" in c2:      # (the reference's own time does not depend on the key: one process per frame either way)
+                if "c2" in out.get("wavefront", {}) and "cpu_reference" in c2:      # (the reference's own time does not depend on the key: one process per frame either way)
                     out["wavefront"]["c2"]["gpu_over_cpu_reference_default_cfg"] = out["wavefront"]["c2"]["value"] / c2["cpu_reference"]["value"]
                 e3.close()
         print(json.dumps(out), flush=True)
