@@ -219,6 +219,15 @@ def test_wavefront_rows_on_waves_of_their_own_and_on_one_wave_give_the_oracle(or
         assert_records_equal(recs, o_recs, "wavefront, exec_flags %d" % flags)
         assert np.array_equal(recon, o_recon) and np.array_equal(stats["est_bits"], o_stats["est_bits"]) and np.array_equal(stats["sse"], o_stats["sse"]), flags
     assert any(not np.array_equal(plain[k], o_recs[k]) for k in ref_tools.FIELDS)
+    # what such a context refuses (rows of a frame are decided concurrently): the per-CTU session, and the key together with tiles (as the reference)
+    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1, wavefront=True)
+    enc.begin_frames(yuv[:1], labels[:1])
+    with pytest.raises(hevcdl_amd.HevcdlError) as err:
+        enc.compress_ctu(0, 0)
+    assert err.value.status == 2                                         # HEVCDL_ERR_UNSUPPORTED
+    enc.close()
+    with pytest.raises(hevcdl_amd.HevcdlError):
+        hevcdl_amd.Encoder(832, 448, qp, max_frames=1, wavefront=True, tiles=(2, 1))
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "TAppEncoder_ref")), reason="reference build (oracle/_ref) not present")
