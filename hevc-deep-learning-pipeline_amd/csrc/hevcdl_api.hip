@@ -427,7 +427,7 @@ extern "C" size_t hevcdl_stage_trace_fetch(unsigned int *dst, size_t cap_words)
 
 static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames, const void *d_labels, void *d_records, void *d_recon, void *d_stats, hipStream_t s,
                                int ctu_begin = 0, int ctu_end = -1, const void *d_cabac_in = nullptr, void *d_cabac_out = nullptr,
-                               int tile_begin = 0, int tile_count = -1)
+                               int tile_begin = 0, int tile_count = -1, int session_frame = -1)
 {
   hevcdl_rd_params p;
   memset(&p, 0, sizeof p);
@@ -442,11 +442,17 @@ static hevcdl_status launch_rd(hevcdl_ctx *ctx, const void *d_yuv, int n_frames,
   // the grid cannot be co-resident, or the caller shares the device (HEVCDL_EXEC_NO_UNIT_HANDOVER) -- a whole frame whose rows one wave walks in order
   const bool whole_launch = !d_cabac_in && !d_cabac_out && ctu_begin == 0 && p.ctu_end == ctx->ctus && tile_begin == 0 && tile_count < 0;
   if (ctx->cfg.wavefront) {
-    if (!whole_launch) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "WaveFrontSynchro: only whole-frame launches (no per-CTU session, no tile range)");
-    p.wpp = (ctx->cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) ? 2 : 1; p.wpp_state = ctx->d_wpp; p.tile_count = p.wpp == 1 ? ctx->ctus_y : 1;
-    p.wpp_queue = ctx->d_wpp + ctx->wpp_state_bytes; p.wpp_ring = ctx->wpp_ring;
-    HIPCHK(hipMemsetAsync(ctx->d_wpp, 0, (size_t)256 * ctx->ctus_y * n_frames, s));
-    HIPCHK(hipMemsetAsync(p.wpp_queue, 0, 1024 + (size_t)4 * ctx->wpp_ring, s));
+    if (session_frame >= 0 && n_frames == 1 && tile_begin == 0 && tile_count < 0) {
+      // the per-CTU session (hevcdl_compress_ctu): one CTU a launch in the one-wave form; the contexts behind the second CTU of every row stay in the session frame's part of
+      // d_wpp from call to call (hevcdl_begin_frames cleared it), so a row's first CTU finds what the row above left -- whatever state the caller hands in for that CTU
+      p.wpp = 2; p.tile_count = 1; p.wpp_state = ctx->d_wpp + (size_t)256 * ctx->ctus_y * session_frame; p.wpp_queue = ctx->d_wpp + ctx->wpp_state_bytes; p.wpp_ring = ctx->wpp_ring;
+    } else {
+      if (!whole_launch) return fail(ctx, HEVCDL_ERR_UNSUPPORTED, "WaveFrontSynchro: whole-frame launches or the per-CTU session (no tile range, no CTU range of several frames)");
+      p.wpp = (ctx->cfg.exec_flags & HEVCDL_EXEC_NO_UNIT_HANDOVER) ? 2 : 1; p.wpp_state = ctx->d_wpp; p.tile_count = p.wpp == 1 ? ctx->ctus_y : 1;
+      p.wpp_queue = ctx->d_wpp + ctx->wpp_state_bytes; p.wpp_ring = ctx->wpp_ring;
+      HIPCHK(hipMemsetAsync(ctx->d_wpp, 0, (size_t)256 * ctx->ctus_y * n_frames, s));
+      HIPCHK(hipMemsetAsync(p.wpp_queue, 0, 1024 + (size_t)4 * ctx->wpp_ring, s));
+    }
   }
   if (d_stats) HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(hevcdl_frame_stats) * (size_t)n_frames, s));     // the tile waves of a frame add into its entry
   p.k.lambda = ctx->cfg.lambda; p.k.sqrt_lambda = ctx->cfg.sqrt_lambda; p.k.chroma_weight = ctx->cfg.chroma_weight; p.k.lambda_chroma = ctx->cfg.lambda_chroma;
@@ -970,6 +976,7 @@ extern "C" hevcdl_status hevcdl_begin_frames(hevcdl_ctx *ctx, const uint8_t *yuv
   else { st = hevcdl_predict_depth_dev(ctx, ctx->d_yuv, n_frames, ctx->d_labels, nullptr, nullptr); if (st) return st; }
   HIPCHK(hipMemset(ctx->d_recon, 0, ctx->frame_bytes * n_frames));
   HIPCHK(hipMemset(ctx->d_records, 0, (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * n_frames));
+  if (ctx->d_wpp) HIPCHK(hipMemset(ctx->d_wpp, 0, (size_t)256 * ctx->ctus_y * n_frames));      // WaveFrontSynchro: the rows' synchronisation contexts of this session
   HIPCHK(hipDeviceSynchronize());
   if (labels_out_opt) HIPCHK(hipMemcpy(labels_out_opt, ctx->d_labels, (size_t)ctx->ctus * 16 * n_frames, hipMemcpyDeviceToHost));
   ctx->next_ctu.assign(n_frames, 0); ctx->session_frames = n_frames;
@@ -992,7 +999,7 @@ extern "C" hevcdl_status hevcdl_compress_ctu(hevcdl_ctx *ctx, int frame, int ctu
   const void *cab_in = (state_in_opt || ctu_addr > 0) ? cab : nullptr;      // NULL: slice-start contexts from the QP
   hevcdl_status st = launch_rd(ctx, ctx->d_yuv + ctx->frame_bytes * frame, 1, ctx->d_labels + (size_t)ctx->ctus * 16 * frame,
                                ctx->d_records + (size_t)ctx->ctus * sizeof(hevcdl_ctu_record) * frame, ctx->d_recon + ctx->frame_bytes * frame, nullptr, nullptr,
-                               ctu_addr, ctu_addr + 1, cab_in, cab);
+                               ctu_addr, ctu_addr + 1, cab_in, cab, 0, -1, frame);
   if (st) return st;
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return fail(ctx, HEVCDL_ERR_HIP, "rd kernel", e);

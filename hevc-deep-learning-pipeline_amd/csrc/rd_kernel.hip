@@ -4365,7 +4365,9 @@ DEV int process_unit(const hevcdl_rd_params &p, int unit, int i_resume)
   const int cx0 = p.col_bd[tcx], cx1 = p.col_bd[tcx + 1], cy0 = p.row_bd[tcy], cy1 = p.row_bd[tcy + 1];
   const int tw = cx1 - cx0;
   k.tx0 = cx0 * 64; k.ty0 = cy0 * 64; k.tx1 = cx1 * 64; k.ty1 = cy1 * 64;
-  const int i_begin = wpp ? wrow0 * tw : (i_resume >= 0 ? i_resume : (ntiles == 1 ? p.ctu_begin : 0)), i_end = wpp ? (wrow0 + wrows) * tw : (ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0));
+  // (a wavefront unit's rows, cut to the caller's CTU range: the per-CTU session walks one CTU a launch in the one-wave form)
+  const int i_begin = wpp ? (wrow0 * tw > p.ctu_begin ? wrow0 * tw : p.ctu_begin) : (i_resume >= 0 ? i_resume : (ntiles == 1 ? p.ctu_begin : 0));
+  const int i_end = wpp ? ((wrow0 + wrows) * tw < p.ctu_end ? (wrow0 + wrows) * tw : p.ctu_end) : (ntiles == 1 ? p.ctu_end : tw * (cy1 - cy0));
   for (int i = i_begin; i < i_end; i++) {
     if (p.migrate && i > i_begin && ((i - i_begin) & (HEVCDL_HOP - 1)) == 0) { // every HEVCDL_HOP CTUs: does the next workgroup of the ring walk fewer units than this one?
       const int g = (int)blockIdx.x, ng = (g + 1) % (int)gridDim.x;

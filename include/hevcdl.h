@@ -111,8 +111,9 @@ typedef struct hevcdl_config {
   /* WaveFrontSynchro (cfg key of that name, TAppEncCfg.cpp:975; default 0).  1: entropy_coding_sync_enabled_flag -- the coder is re-initialised at the first CTU of every
    * CTU row and takes over the contexts behind the second CTU of the row above (TEncSlice.cpp:783-830, 925-928).  The decisions then differ from the default cfg's (every
    * RD cost is priced with other context states), exactly as the reference's do with the key set; the CTU chain of a frame (2040 steps at 2160p) becomes ctus_y chains two
-   * CTUs apart (126 steps), which the decision kernel walks on different waves.  Not together with tiles (the reference refuses the pair in the main profiles); the per-CTU
-   * session (hevcdl_compress_ctu) and tile-range launches are refused on such a context. */
+   * CTUs apart (126 steps), which the decision kernel walks on different waves.  Not together with tiles (the reference refuses the pair in the main profiles).  The per-CTU
+   * session (hevcdl_compress_ctu) works on such a context too: the contexts behind the second CTU of every row are kept per session frame, a row's first CTU starts from them
+   * whatever state the caller hands in (that IS the reference's behaviour: resetEntropy + loadContexts in front of compressCtu, TEncSlice.cpp:808-823). */
   int32_t  wavefront;
 } hevcdl_config;
 

@@ -219,13 +219,7 @@ def test_wavefront_rows_on_waves_of_their_own_and_on_one_wave_give_the_oracle(or
         assert_records_equal(recs, o_recs, "wavefront, exec_flags %d" % flags)
         assert np.array_equal(recon, o_recon) and np.array_equal(stats["est_bits"], o_stats["est_bits"]) and np.array_equal(stats["sse"], o_stats["sse"]), flags
     assert any(not np.array_equal(plain[k], o_recs[k]) for k in ref_tools.FIELDS)
-    # what such a context refuses (rows of a frame are decided concurrently): the per-CTU session, and the key together with tiles (as the reference)
-    enc = hevcdl_amd.Encoder(w, h, qp, max_frames=1, wavefront=True)
-    enc.begin_frames(yuv[:1], labels[:1])
-    with pytest.raises(hevcdl_amd.HevcdlError) as err:
-        enc.compress_ctu(0, 0)
-    assert err.value.status == 2                                         # HEVCDL_ERR_UNSUPPORTED
-    enc.close()
+    # what the library refuses: the key together with tiles (as the reference)
     with pytest.raises(hevcdl_amd.HevcdlError):
         hevcdl_amd.Encoder(832, 448, qp, max_frames=1, wavefront=True, tiles=(2, 1))
 
@@ -732,15 +726,18 @@ def test_matches_oracle_on_hard_content(oracle_built, kind, qp, seed):
     assert np.array_equal(stats["est_bits"], o_stats["est_bits"])
 
 
-def test_per_ctu_session_equals_batch_and_rejects_disorder():
+@pytest.mark.parametrize("wavefront", [False, True], ids=["default-cfg", "wavefront"])
+def test_per_ctu_session_equals_batch_and_rejects_disorder(wavefront):
     """hevcdl_compress_ctu (compressCtu + encodeCtu of one CTU) called in coding order reproduces the batched path
-    bit for bit; the coder state it returns can be fed back; out-of-order submission is an error, not a hang."""
+    bit for bit; the coder state it returns can be fed back; out-of-order submission is an error, not a hang.
+    With WaveFrontSynchro 1 as well (3 x 3 CTUs there): a row's first CTU starts from the contexts the session kept behind the second CTU of the row above, whatever
+    state the caller hands in, and the batched launch it is compared with walks the rows on waves of their own."""
     import hevcdl_amd
     import ref_tools
-    w, h, qp, nf = 192, 128, 32, 2
+    w, h, qp, nf = (192, 192, 32, 2) if wavefront else (192, 128, 32, 2)
     yuv = ref_tools.synth_yuv(w, h, nf, seed=21)
     labels = ref_tools.make_labels(w, h, nf, "rand", 22)
-    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf)
+    e = hevcdl_amd.Encoder(w, h, qp, max_frames=nf, wavefront=wavefront)
     recs, recon, stats = e.compress_frames(yuv, labels)
     used = e.begin_frames(yuv, labels)
     assert np.array_equal(used.reshape(labels.shape), labels)
