@@ -1,8 +1,8 @@
 #!/bin/bash
 # End-of-round measurement in one GPU session: the GPU test suite, the round profile (bench line, kernel trace, HBM counter passes), the in-kernel phase profiles
-# and the SQ counter passes of the decision kernel (timed 600-frame launch, 256-frame launch, the saturated 2560-frame launch).  usage (through gpurun): bash tools/final_round.sh r06f
+# and the SQ counter passes of the decision kernel (timed 600-frame launch, 256-frame launch, the saturated 2560-frame launch).  usage (through gpurun): bash tools/final_round.sh r06q
 # afterwards, here: cp the summaries into profiles/, python tools/traffic_json.py <tag>; python tools/issue_json.py <tag> 600 256 2560
-TAG=${1:-r06f}
+TAG=${1:-r06q}
 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.txt 2>&1; tail -3 gpurun_out/${TAG}_pytest_gpu.txt
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1; tail -12 gpurun_out/${TAG}_profile.log
 python tools/phase_profile.py 3840 2160 600 > gpurun_out/${TAG}_phase_f600.txt 2>&1
